@@ -1,0 +1,650 @@
+/*
+ * neddf_oracle.c -- CPU restatement of the reference renderer's hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the *checker* for the HIP path: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * The product (neddf_amd/) never links, imports or falls back to it.
+ *
+ * Parity is PINNED: every function below is checked in tests/test_oracle.py
+ * against golden vectors produced by importing the reference PyTorch code
+ * (tests/golden/gen_goldens.py, run where /root/reference exists).
+ *
+ * Each function cites the reference file:line it restates (paths relative to
+ * the reference checkout).  Arithmetic is fp32 with the same operation order as
+ * the eager torch ops; torch-CPU cumsum/cumprod accumulate in double and round
+ * every output element (SURVEY.md App.A N2), F.normalize(p=1) sums
+ * sequentially in fp32 (N3).  Build with -ffp-contract=off (see Makefile); the
+ * only fused multiply-adds are the explicit fmaf() of the dense layers.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_MAX_LAYERS 16
+#define ORC_MAX_IN 1024
+
+enum { ORC_RELU = 0, ORC_LEAKY = 1, ORC_TANHEXP = 2 };
+
+/* ------------------------------------------------------------------------ */
+/* Camera.create_rays camera.py:155-171, get_center_of_pixels :173-187,
+ * PinholeCalib.unproject_local pinhole_calib.py:51-74.
+ * uv given as float (the reference converts with .to(float32)). */
+void orc_create_rays(const float *uv, int B, const float *R, const float *T,
+                     const float *calib, float *ray_dir, float *ray_orig)
+{
+    const float fx = calib[0], fy = calib[1], cx = calib[2], cy = calib[3];
+    const float ifx = 1.0f / fx, ify = 1.0f / fy;
+    for (int b = 0; b < B; ++b) {
+        float u = 0.5f + 1.0f * uv[2 * b + 0];
+        float v = 0.5f + 1.0f * uv[2 * b + 1];
+        float x = ifx * (u - cx);
+        float y = ify * (v - cy);
+        float z = 1.0f;
+        /* rdf2rub = diag(1,-1,-1) */
+        float px = x, py = -y, pz = -z;
+        float nrm = sqrtf(px * px + py * py + pz * pz);
+        if (nrm < 1e-12f) nrm = 1e-12f;            /* F.normalize eps */
+        px /= nrm; py /= nrm; pz /= nrm;
+        for (int i = 0; i < 3; ++i) {
+            ray_dir[3 * b + i] = R[3 * i + 0] * px + R[3 * i + 1] * py + R[3 * i + 2] * pz;
+            ray_orig[3 * b + i] = T[i];
+        }
+    }
+}
+
+/* torch.linspace (CPU, float): symmetric evaluation around the midpoint. */
+static float orc_linspace(float start, float end, int steps, int i)
+{
+    if (steps == 1) return start;
+    float step = (end - start) / (float)(steps - 1);
+    int half = steps / 2;
+    if (i < half) return start + step * (float)i;
+    return end - step * (float)(steps - i - 1);
+}
+
+/* Stratified coarse distances, nerf_render.py:131-140. */
+void orc_sample_coarse(const float *U, int B, int S1, float dist_near, float dist_far, float *dists)
+{
+    const float step = (float)(((double)dist_far - (double)dist_near) / (double)(S1 - 1));
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < S1; ++j)
+            dists[b * S1 + j] = orc_linspace(dist_near, dist_far, S1, j) + U[b * S1 + j] * step;
+}
+
+/* Ray.get_sampling_points ray.py:88-126. */
+void orc_sampling_points(const float *ray_dir, const float *ray_orig, const float *dists, int B, int S,
+                         float *pos, float *dir, float *var)
+{
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < S; ++j)
+            for (int i = 0; i < 3; ++i) {
+                size_t o = ((size_t)b * S + j) * 3 + i;
+                pos[o] = ray_orig[3 * b + i] + ray_dir[3 * b + i] * dists[b * S + j];
+                dir[o] = ray_dir[3 * b + i];
+                var[o] = 0.0f;
+            }
+}
+
+/* Ray.get_sampling_cones ray.py:128-194 (mip-NeRF conical frustum moments). */
+void orc_sampling_cones(const float *ray_dir, const float *ray_orig, const float *dists, int B, int S,
+                        double ray_radius, float *pos, float *dir, float *var)
+{
+    const float r2 = (float)(ray_radius * ray_radius);
+    const float c13 = (float)(1.0 / 3), c415 = (float)(4.0 / 15), c14 = 0.25f, c512 = (float)(5.0 / 12);
+    for (int b = 0; b < B; ++b) {
+        const float *d = dists + (size_t)b * S;
+        for (int j = 0; j < S; ++j) {
+            float dn = d[j];
+            float df = (j + 1 < S) ? d[j + 1] : (2 * d[S - 1] - d[S - 2]);
+            float mu = 0.5f * (dn + df);
+            float sg = 0.5f * (df - dn);
+            float mu2 = mu * mu, s2 = sg * sg, s4 = s2 * s2;
+            float minv = 1.0f / (3 * mu2 + s2 + 1e-7f);
+            float t_mu = mu + (2 * mu * s2) * minv;
+            float t_var = c13 * s2 - c415 * s4 * (12 * mu2 - s2) * (minv * minv);
+            float r_var = r2 * (c14 * mu2 + c512 * s2 - c415 * s4 * minv);
+            for (int i = 0; i < 3; ++i) {
+                size_t o = ((size_t)b * S + j) * 3 + i;
+                float dd = ray_dir[3 * b + i];
+                float dsq = dd * dd;
+                var[o] = t_var * dsq + r_var * (1.0f - dsq);
+                pos[o] = ray_orig[3 * b + i] + dd * t_mu;
+                dir[o] = dd;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* BaseNeuralRender.integrate_volume_render base_neural_render.py:117-172.
+ * weight [B,S-1]; colors [B,S,3].  Returns 1 if any weight is NaN (the
+ * reference asserts, :155). */
+int orc_integrate(const float *dists, const float *dens, const float *col, int B, int S, float max_dist,
+                  float *weight, float *depth, float *color, float *trans)
+{
+    int nan = 0;
+    for (int b = 0; b < B; ++b) {
+        const float *d = dists + (size_t)b * S, *r = dens + (size_t)b * S, *c = col + (size_t)b * S * 3;
+        double T = 1.0;                      /* cumprod accumulates in double (N2) */
+        float tprev = 1.0f, sd = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < S - 1; ++j) {
+            float delta = d[j + 1] - d[j];
+            float o = 1.0f - expf(-r[j] * delta);
+            float w = o * tprev;
+            if (w != w) nan = 1;
+            weight[(size_t)b * (S - 1) + j] = w;
+            sd += w * d[j];
+            s0 += w * c[3 * j + 0];
+            s1 += w * c[3 * j + 1];
+            s2 += w * c[3 * j + 2];
+            T *= (double)(1.0f - o + 1e-7f);
+            tprev = (float)T;
+        }
+        depth[b] = sd + tprev * max_dist;
+        color[3 * b + 0] = s0; color[3 * b + 1] = s1; color[3 * b + 2] = s2;
+        trans[b] = tprev;
+    }
+    return nan;
+}
+
+/* penalty line integral nerf_render.py:153-159 */
+void orc_integrate_penalty(const float *dists, const float *pen, int B, int S, float *out)
+{
+    for (int b = 0; b < B; ++b) {
+        float s = 0.f;
+        for (int j = 0; j < S - 1; ++j)
+            s += (dists[(size_t)b * S + j + 1] - dists[(size_t)b * S + j]) * pen[(size_t)b * S + j];
+        out[b] = s;
+    }
+}
+
+static int orc_cmp_float(const void *a, const void *b)
+{
+    float x = *(const float *)a, y = *(const float *)b;
+    if (x != x) return (y != y) ? 0 : 1;     /* NaN sorts last like torch.sort */
+    if (y != y) return -1;
+    return (x > y) - (x < y);
+}
+
+/* BaseNeuralRender.sample_pdf base_neural_render.py:27-115.
+ * dists [B,n], weights [B,n-1] (MUTATED in place like the reference, :52-55),
+ * U [B,nf].  out [B, nf+n] if cat_coarse else [B,nf]; ids_out (optional) [B,nf]
+ * are the searchsorted indices.  Returns 1 when the NaN fallback (:105-114)
+ * replaced the whole batch. */
+int orc_sample_pdf(const float *dists, float *weights, const float *U, int B, int n, int nf, int cat_coarse,
+                   float *out, int64_t *ids_out)
+{
+    const int nw = n - 1;
+    const int no = cat_coarse ? nf + n : nf;
+    float *w = (float *)malloc(sizeof(float) * nw);
+    float *cdf = (float *)malloc(sizeof(float) * n);
+    int any_nan = 0;
+    /* the reference sanitises only if any element is NaN/negative, which is
+     * equivalent to sanitising unconditionally */
+    for (size_t i = 0; i < (size_t)B * nw; ++i) {
+        if (weights[i] < 0.0f) weights[i] *= 0.0f;
+        if (weights[i] != weights[i]) weights[i] = 0.0f;
+    }
+    for (int b = 0; b < B; ++b) {
+        const float *d = dists + (size_t)b * n;
+        for (int j = 0; j < nw; ++j) w[j] = weights[(size_t)b * nw + j] + 1e-2f;
+        if (!cat_coarse && nw >= 3) {       /* :61-68 neighbour-max smoothing */
+            float *t = (float *)malloc(sizeof(float) * nw);
+            memcpy(t, w, sizeof(float) * nw);
+            for (int j = 1; j < nw - 1; ++j) {
+                float w1 = t[j + 1] > t[j] ? t[j + 1] : t[j];
+                float w2 = t[j - 1] > t[j] ? t[j - 1] : t[j];
+                w[j] = 0.5f * (w1 + w2);
+            }
+            free(t);
+        }
+        float l1 = 0.f;                      /* sequential fp32 sum (N3) */
+        for (int j = 0; j < nw; ++j) l1 += fabsf(w[j]);
+        if (l1 < 1e-12f) l1 = 1e-12f;
+        double acc = 0.0;                    /* cumsum in double, rounded per element (N2) */
+        cdf[0] = 0.0f;
+        for (int j = 0; j < nw; ++j) {
+            acc += (double)(w[j] / l1);
+            cdf[j + 1] = (float)acc;
+        }
+        float *o = out + (size_t)b * no;
+        for (int s = 0; s < nf; ++s) {
+            float u = U[(size_t)b * nf + s];
+            int id = 0;                      /* searchsorted(right=True): #cdf <= u */
+            while (id < n && !(cdf[id] > u)) ++id;
+            int below = id - 1 > 0 ? id - 1 : 0;
+            int above = id < n - 1 ? id : n - 1;
+            if (ids_out) ids_out[(size_t)b * nf + s] = id;
+            float denom = cdf[above] - cdf[below];
+            if (denom < 1e-5f) denom = 1.0f;
+            float t = (u - cdf[below]) / denom;
+            o[s] = d[below] + t * (d[above] - d[below]);
+        }
+        if (cat_coarse) memcpy(o + nf, d, sizeof(float) * n);
+        qsort(o, no, sizeof(float), orc_cmp_float);
+        for (int s = 0; s < no; ++s) if (o[s] != o[s]) any_nan = 1;
+    }
+    if (any_nan) {
+        for (int b = 0; b < B; ++b)
+            for (int s = 0; s < no; ++s)
+                out[(size_t)b * no + s] = orc_linspace(dists[0], dists[n - 1], no, s);
+    }
+    free(w); free(cdf);
+    return any_nan;
+}
+
+/* ------------------------------------------------------------------------ */
+/* activations */
+static inline float orc_act(int kind, float x)
+{
+    if (kind == ORC_RELU) return x > 0.f ? x : 0.f;              /* F.relu */
+    if (kind == ORC_LEAKY) return x > 0.f ? x : 0.01f * x;        /* F.leaky_relu */
+    /* tanhExp nn_module/tanh_exp.py:15-33 */
+    if (x > 20.0f) return x;
+    return x * tanhf(expf(x));
+}
+
+/* (value, derivative) activations with_grad/{relu,leaky_relu,tanh_exp}.py */
+static inline void orc_act_grad(int kind, float x, float *y, float *dy)
+{
+    if (kind == ORC_RELU) {               /* relu.py:36-38: mask = x >= 0 */
+        float m = (x >= 0.f) ? 1.f : 0.f;
+        *y = x * m; *dy = m;
+    } else if (kind == ORC_LEAKY) {       /* leaky_relu.py:36-39 */
+        float s = (x < 0.f) ? 0.01f : 1.f;
+        *y = x * s; *dy = s;
+    } else {                              /* tanh_exp.py:38-46 */
+        if (x > 20.0f) { *y = x; *dy = 1.0f; return; }
+        float ex = expf(x), tx = tanhf(ex);
+        *y = x * tx;
+        *dy = tx - x * ex * (tx * tx - 1.0f);
+    }
+}
+
+/* standalone op entry points for the unit goldens (ops.npz) */
+void orc_activation_grad(int kind, const float *x, const float *J, int N, int C, float *y, float *G)
+{
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < C; ++c) {
+            float yy, dy;
+            orc_act_grad(kind, x[n * C + c], &yy, &dy);
+            y[n * C + c] = yy;
+            for (int i = 0; i < 3; ++i) G[(n * 3 + i) * C + c] = dy * J[(n * 3 + i) * C + c];
+        }
+}
+
+/* SoftplusGradFunction softplus.py:38-49 */
+static inline void orc_softplus_grad(float x, float *y, float *dy)
+{
+    if (x > 20.0f) { *y = x; *dy = 1.0f; return; }
+    *y = logf(1.0f + expf(x));
+    *dy = 1.0f / (1.0f + expf(-x));
+}
+/* SigmoidGradFunction sigmoid.py:38-43 (s = 1) */
+static inline void orc_sigmoid_grad(float x, float *y, float *dy)
+{
+    float t = (1.0f + tanhf(1.0f * x * 0.5f)) * 0.5f;
+    *y = t; *dy = 1.0f * t * (1 - t);
+}
+void orc_softplus_grad_op(const float *x, const float *J, int N, int C, float *y, float *G)
+{
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < C; ++c) {
+            float yy, dy;
+            orc_softplus_grad(x[n * C + c], &yy, &dy);
+            y[n * C + c] = yy;
+            for (int i = 0; i < 3; ++i) G[(n * 3 + i) * C + c] = dy * J[(n * 3 + i) * C + c];
+        }
+}
+void orc_sigmoid_grad_op(const float *x, const float *J, int N, float *y, float *G)
+{
+    for (int n = 0; n < N; ++n) {
+        float yy, dy;
+        orc_sigmoid_grad(x[n], &yy, &dy);
+        y[n] = yy;
+        for (int i = 0; i < 3; ++i) G[n * 3 + i] = dy * J[n * 3 + i];
+    }
+}
+
+/* LinearGradFunction.forward linear.py:40-46: y = xW + b, G = JW.
+ * W [Cin,Cout] row-major. */
+void orc_linear_grad(const float *x, const float *J, const float *W, const float *b, int N, int Cin, int Cout,
+                     float *y, float *G)
+{
+    for (int n = 0; n < N; ++n)
+        for (int r = 0; r < 4; ++r) {
+            const float *in = r == 0 ? x + (size_t)n * Cin : J + ((size_t)n * 3 + r - 1) * Cin;
+            float *o = r == 0 ? y + (size_t)n * Cout : G + ((size_t)n * 3 + r - 1) * Cout;
+            for (int j = 0; j < Cout; ++j) o[j] = 0.f;
+            for (int k = 0; k < Cin; ++k)
+                for (int j = 0; j < Cout; ++j) o[j] = fmaf(in[k], W[(size_t)k * Cout + j], o[j]);
+            if (r == 0 && b) for (int j = 0; j < Cout; ++j) o[j] += b[j];
+        }
+}
+
+/* Sampling.get_pe_weights sampling.py:55-71: w[e*3+d] = exp(-0.5 * 4^e * var_d) */
+void orc_pe_weights(const float *var, int N, int E, float *w)
+{
+    for (int n = 0; n < N; ++n)
+        for (int e = 0; e < E; ++e) {
+            float f = ldexpf(1.0f, e);
+            for (int d = 0; d < 3; ++d) w[(size_t)n * 3 * E + e * 3 + d] = expf(-0.5f * (f * f) * var[n * 3 + d]);
+        }
+}
+
+/* PositionalEncodingGradLayer.forward with_grad/positional_encoding.py:55-87
+ * with a general input Jacobian J [N,3,3]; scale [N,3E] or NULL (ones).
+ * y [N,6E], G [N,3,6E]; channel c = e*3+d (sin half), 3E + e*3+d (cos half). */
+void orc_pe_grad(const float *x, const float *J, const float *scale, int N, int E, float *y, float *G)
+{
+    const int C = 3 * E;
+    for (int n = 0; n < N; ++n)
+        for (int e = 0; e < E; ++e)
+            for (int d = 0; d < 3; ++d) {
+                int c = e * 3 + d;
+                float f = ldexpf(1.0f, e);
+                float p = f * x[n * 3 + d];
+                float s = scale ? scale[(size_t)n * C + c] : 1.0f;
+                float sn = sinf(p), cs = cosf(p);
+                y[(size_t)n * 2 * C + c] = s * sn;
+                y[(size_t)n * 2 * C + C + c] = s * cs;
+                for (int i = 0; i < 3; ++i) {
+                    /* pG[n,i,e*3+d] = J[n,i,d]  (:70-74) */
+                    float sG = f * s * J[(n * 3 + i) * 3 + d];
+                    G[((size_t)n * 3 + i) * 2 * C + c] = sG * cs;
+                    G[((size_t)n * 3 + i) * 2 * C + C + c] = -sG * sn;
+                }
+            }
+}
+
+/* PositionalEncoding.forward nn_module/positional_encoding.py:51-65 */
+void orc_pe(const float *x, const float *scale, int N, int E, float *y)
+{
+    const int C = 3 * E;
+    for (int n = 0; n < N; ++n)
+        for (int e = 0; e < E; ++e)
+            for (int d = 0; d < 3; ++d) {
+                int c = e * 3 + d;
+                float p = ldexpf(1.0f, e) * x[n * 3 + d];
+                float s = scale ? scale[(size_t)n * C + c] : 1.0f;
+                y[(size_t)n * 2 * C + c] = s * sinf(p);
+                y[(size_t)n * 2 * C + C + c] = s * cosf(p);
+            }
+}
+
+/* ------------------------------------------------------------------------ */
+/* dense layer on a block of rows: out[r][j] = sum_k in[r][k] W[k][j] (+ b[j]) */
+static void orc_dense(const float *in, int ldin, int rows, const float *W, const float *b, int Cin, int Cout,
+                      float *out, int ldout, int bias_every /* bias on rows r % bias_every == 0; 0 = none */)
+{
+    for (int r = 0; r < rows; ++r) {
+        float *o = out + (size_t)r * ldout;
+        for (int j = 0; j < Cout; ++j) o[j] = 0.f;
+    }
+    for (int k = 0; k < Cin; ++k) {
+        const float *wr = W + (size_t)k * Cout;
+        for (int r = 0; r < rows; ++r) {
+            float a = in[(size_t)r * ldin + k];
+            float *o = out + (size_t)r * ldout;
+            for (int j = 0; j < Cout; ++j) o[j] = fmaf(a, wr[j], o[j]);
+        }
+    }
+    if (b && bias_every)
+        for (int r = 0; r < rows; r += bias_every) {
+            float *o = out + (size_t)r * ldout;
+            for (int j = 0; j < Cout; ++j) o[j] += b[j];
+        }
+}
+
+typedef struct {
+    int embed_pos_rank, embed_dir_rank;
+    int n_ddf;              /* trunk layers of the distance net = ddf_layer_count - 1 */
+    int ddf_width;
+    int n_col;              /* hidden layers of the colour net = col_layer_count - 1 */
+    int col_width;
+    int n_skips;
+    int skips[8];
+    int activation, density_activation;
+    float d_near, aux_grad_scale, distance_range_max;
+    /* penalty weights in dict insertion order of neddf.py:260-291:
+     * constraints_aux_grad, constraints_dDdt, range_distance, range_aux_grad,
+     * range_color, constraints_color; missing keys are left unweighted (:296-299) */
+    float penalty_weight[6];
+    int penalty_has[6];
+    const float *lowpass;   /* [embed_pos_rank] get_lowpass_scale(lowpass_alpha) */
+    const float *ddf_w[ORC_MAX_LAYERS], *ddf_b[ORC_MAX_LAYERS];
+    const float *col_w[ORC_MAX_LAYERS], *col_b[ORC_MAX_LAYERS];
+    const float *ddf_out_w, *ddf_out_b, *aux_out_w, *aux_out_b, *col_out_w, *col_out_b;
+} orc_neddf_t;
+
+static int orc_in_skips(const int *skips, int n, int id)
+{
+    for (int i = 0; i < n; ++i) if (skips[i] == id) return 1;
+    return 0;
+}
+
+/* NeDDF.forward neddf.py:162-309 for N points (pos/dir/var [N,3]).
+ * Outputs (any may be NULL): distance, density, color[N,3], fields_penalty, aux_grad;
+ * extra (optional, for stage tests): features [N,W]. */
+void orc_neddf_forward(const orc_neddf_t *net, const float *pos, const float *dir, const float *var, int N,
+                       float *distance, float *density, float *color, float *penalty, float *aux_grad_out)
+{
+    const int E = net->embed_pos_rank, Ed = net->embed_dir_rank;
+    const int Cpe = 6 * E, Cdir = 6 * Ed, W = net->ddf_width, Wc = net->col_width;
+    const int in_col = Cpe + Cdir + 3 + W;
+#pragma omp parallel
+    {
+        const int LD = ORC_MAX_IN;
+        float *bufA = (float *)malloc(sizeof(float) * 4 * LD);
+        float *bufB = (float *)malloc(sizeof(float) * 4 * LD);
+        float *pe_s = (float *)malloc(sizeof(float) * 4 * Cpe);   /* embed_pos_scaled value + J rows */
+        float *pe_u = (float *)malloc(sizeof(float) * 4 * Cpe);   /* embed_pos (unscaled by grad scale) */
+        float *pe_d = (float *)malloc(sizeof(float) * Cdir);
+#pragma omp for schedule(static)
+        for (int n = 0; n < N; ++n) {
+            const float *x = pos + 3 * n;
+            /* :193-209 positional encodings; J_in = I3 (:186-191) */
+            memset(pe_s, 0, sizeof(float) * 4 * Cpe);
+            memset(pe_u, 0, sizeof(float) * 4 * Cpe);
+            for (int e = 0; e < E; ++e) {
+                float f = ldexpf(1.0f, e);
+                float gs = 1.0f / (0.5f * f);                /* get_grad_scale with_grad/positional_encoding.py:130-135 */
+                float lp = net->lowpass[e];
+                for (int d = 0; d < 3; ++d) {
+                    int c = e * 3 + d;
+                    float w = expf(-0.5f * (f * f) * var[3 * n + d]);  /* sampling.py:71 */
+                    float p = f * x[d];
+                    float sn = sinf(p), cs = cosf(p);
+                    float s1 = gs * lp * w;
+                    float s2 = lp * w;
+                    pe_s[c] = s1 * sn;           pe_s[3 * E + c] = s1 * cs;
+                    pe_u[c] = s2 * sn;           pe_u[3 * E + c] = s2 * cs;
+                    float g1 = f * s1 * 1.0f, g2 = f * s2 * 1.0f;
+                    pe_s[(1 + d) * Cpe + c] = g1 * cs;  pe_s[(1 + d) * Cpe + 3 * E + c] = -g1 * sn;
+                    pe_u[(1 + d) * Cpe + c] = g2 * cs;  pe_u[(1 + d) * Cpe + 3 * E + c] = -g2 * sn;
+                }
+            }
+            for (int e = 0; e < Ed; ++e)
+                for (int d = 0; d < 3; ++d) {    /* :210, PositionalEncoding */
+                    float p = ldexpf(1.0f, e) * dir[3 * n + d];
+                    pe_d[e * 3 + d] = sinf(p);
+                    pe_d[3 * Ed + e * 3 + d] = cosf(p);
+                }
+            /* :212-219 distance trunk with (value, Jacobian) rows */
+            float *h = bufA, *o = bufB;
+            int cin = Cpe;
+            for (int r = 0; r < 4; ++r) memcpy(h + r * LD, pe_s + r * Cpe, sizeof(float) * Cpe);
+            for (int l = 0; l < net->n_ddf; ++l) {
+                int off = orc_in_skips(net->skips, net->n_skips, l) ? Cpe : 0;   /* room for the concat */
+                orc_dense(h, LD, 4, net->ddf_w[l], net->ddf_b[l], cin, W, o + off, LD, 4);
+                for (int j = 0; j < W; ++j) {
+                    float y, dy;
+                    orc_act_grad(net->activation, o[off + j], &y, &dy);
+                    o[off + j] = y;
+                    for (int r = 1; r < 4; ++r) o[r * LD + off + j] = dy * o[r * LD + off + j];
+                }
+                cin = W;
+                if (off) {      /* :217-219 cat([embed_pos_scaled, h]) -- embedding first */
+                    for (int r = 0; r < 4; ++r) memcpy(o + r * LD, pe_s + r * Cpe, sizeof(float) * Cpe);
+                    cin = W + Cpe;
+                }
+                float *t = h; h = o; o = t;
+            }
+            /* heads :220-241 */
+            float head[4 * 2];
+            orc_dense(h, LD, 4, net->ddf_out_w, net->ddf_out_b, cin, 1, head, 1, 4);
+            float aux4[4];
+            orc_dense(h, LD, 4, net->aux_out_w, net->aux_out_b, cin, 1, aux4, 1, 4);
+            float sp, dsp;
+            orc_softplus_grad(head[0], &sp, &dsp);
+            float D = sp + net->d_near;
+            float dg[3] = { dsp * head[1], dsp * head[2], dsp * head[3] };
+            float sg, dsg;
+            orc_sigmoid_grad(aux4[0], &sg, &dsg);
+            float aux = net->aux_grad_scale * sg;
+            float aux_gg[3] = { net->aux_grad_scale * (dsg * aux4[1]), net->aux_grad_scale * (dsg * aux4[2]),
+                                net->aux_grad_scale * (dsg * aux4[3]) };
+            float dgn = sqrtf(dg[0] * dg[0] + dg[1] * dg[1] + dg[2] * dg[2]);
+            float dDdt = sqrtf(dg[0] * dg[0] + dg[1] * dg[1] + dg[2] * dg[2] + aux * aux);
+            float Dinv = 1.0f / D;
+            float rho = orc_act(net->density_activation, Dinv * (1 - dDdt));
+            float ninv = 1.0f / (dgn + 1e-7f);
+            float nd[3] = { ninv * dg[0], ninv * dg[1], ninv * dg[2] };
+            /* colour trunk :243-257; Jacobian of dir/normal columns is zero */
+            float *c_in = o;
+            for (int r = 0; r < 4; ++r) {
+                float *row = c_in + r * LD;
+                memcpy(row, pe_u + r * Cpe, sizeof(float) * Cpe);
+                for (int j = 0; j < Cdir + 3; ++j) row[Cpe + j] = 0.f;
+                memcpy(row + Cpe + Cdir + 3, h + r * LD + (cin - W), sizeof(float) * W);
+            }
+            memcpy(c_in + Cpe, pe_d, sizeof(float) * Cdir);
+            for (int i = 0; i < 3; ++i) c_in[Cpe + Cdir + i] = nd[i];
+            float *ci = c_in, *co = h;
+            int ccin = in_col;
+            for (int l = 0; l < net->n_col; ++l) {
+                orc_dense(ci, LD, 4, net->col_w[l], net->col_b[l], ccin, Wc, co, LD, 4);
+                for (int j = 0; j < Wc; ++j) {
+                    float y, dy;
+                    orc_act_grad(net->activation, co[j], &y, &dy);
+                    co[j] = y;
+                    for (int r = 1; r < 4; ++r) co[r * LD + j] = dy * co[r * LD + j];
+                }
+                ccin = Wc;
+                float *t = ci; ci = co; co = t;
+            }
+            float col4[4 * 3];
+            orc_dense(ci, LD, 4, net->col_out_w, net->col_out_b, ccin, 3, col4, 3, 4);
+            /* penalties :260-300 */
+            float pen[6];
+            float d2 = aux_gg[0] * nd[0] + aux_gg[1] * nd[1] + aux_gg[2] * nd[2];
+            float rest = 3 * aux * Dinv;
+            float scale = aux * dgn * D;
+            pen[0] = scale * ((d2 - rest) * (d2 - rest));
+            float t1 = -1.0f + dDdt; t1 = t1 > 0 ? t1 : 0;
+            pen[1] = t1 * t1;
+            float a1 = -4.6f - head[0]; a1 = a1 > 0 ? a1 : 0;
+            float a2 = -net->distance_range_max + head[0]; a2 = a2 > 0 ? a2 : 0;
+            pen[2] = (a1 + a2) * (a1 + a2);
+            float b1 = -4.6f - aux4[0]; b1 = b1 > 0 ? b1 : 0;
+            float b2 = -4.6f + aux4[0]; b2 = b2 > 0 ? b2 : 0;
+            pen[3] = (b1 + b2) * (b1 + b2);
+            pen[4] = 0.f;
+            for (int k = 0; k < 3; ++k) {
+                float c1 = -0.0f - col4[k]; c1 = c1 > 0 ? c1 : 0;
+                float c2 = -1.0f + col4[k]; c2 = c2 > 0 ? c2 : 0;
+                pen[4] += (c1 + c2) * (c1 + c2);
+            }
+            pen[5] = 0.f;
+            for (int k = 0; k < 3; ++k) {
+                float s = col4[3 + k] * dg[0] + col4[6 + k] * dg[1] + col4[9 + k] * dg[2];
+                pen[5] += s * s;
+            }
+            float ptot = 0.f;
+            for (int k = 0; k < 6; ++k) ptot += net->penalty_has[k] ? pen[k] * net->penalty_weight[k] : pen[k];
+            if (distance) distance[n] = D;
+            if (density) density[n] = rho;
+            if (color) { color[3 * n] = col4[0]; color[3 * n + 1] = col4[1]; color[3 * n + 2] = col4[2]; }
+            if (penalty) penalty[n] = ptot;
+            if (aux_grad_out) aux_grad_out[n] = aux;
+        }
+        free(bufA); free(bufB); free(pe_s); free(pe_u); free(pe_d);
+    }
+}
+
+typedef struct {
+    int embed_pos_rank, embed_dir_rank;
+    int n_layers;           /* layer_count */
+    int width;
+    int n_skips;
+    int skips[8];
+    int activation, density_activation;
+    const float *lowpass;   /* [embed_pos_rank] */
+    /* nn.Linear layout [out,in] (nerf.py:88-103) */
+    const float *w[ORC_MAX_LAYERS], *b[ORC_MAX_LAYERS];
+    const float *dens_w, *dens_b, *col0_w, *col0_b, *col1_w, *col1_b;
+} orc_nerf_t;
+
+static void orc_linear_t(const float *in, const float *Wt, const float *b, int Cin, int Cout, float *out)
+{
+    for (int j = 0; j < Cout; ++j) {
+        const float *wr = Wt + (size_t)j * Cin;
+        float acc = 0.f;
+        for (int k = 0; k < Cin; ++k) acc = fmaf(in[k], wr[k], acc);
+        out[j] = acc + b[j];
+    }
+}
+
+/* NeRF.forward nerf.py:107-165 */
+void orc_nerf_forward(const orc_nerf_t *net, const float *pos, const float *dir, const float *var, int N,
+                      float *density, float *color)
+{
+    const int E = net->embed_pos_rank, Ed = net->embed_dir_rank, Cpe = 6 * E, Cdir = 6 * Ed, W = net->width;
+#pragma omp parallel
+    {
+        float *pe = (float *)malloc(sizeof(float) * Cpe);
+        float *h = (float *)malloc(sizeof(float) * ORC_MAX_IN);
+        float *o = (float *)malloc(sizeof(float) * ORC_MAX_IN);
+#pragma omp for schedule(static)
+        for (int n = 0; n < N; ++n) {
+            for (int e = 0; e < E; ++e) {
+                float f = ldexpf(1.0f, e);
+                for (int d = 0; d < 3; ++d) {
+                    float w = expf(-0.5f * (f * f) * var[3 * n + d]);
+                    float s = net->lowpass[e] * w;
+                    float p = f * pos[3 * n + d];
+                    pe[e * 3 + d] = s * sinf(p);
+                    pe[3 * E + e * 3 + d] = s * cosf(p);
+                }
+            }
+            memcpy(h, pe, sizeof(float) * Cpe);
+            int cin = Cpe;
+            for (int l = 0; l < net->n_layers; ++l) {
+                orc_linear_t(h, net->w[l], net->b[l], cin, W, o);
+                for (int j = 0; j < W; ++j) o[j] = orc_act(net->activation, o[j]);
+                cin = W;
+                if (orc_in_skips(net->skips, net->n_skips, l)) {   /* :154-155 cat([hx, embed_pos]) */
+                    memcpy(o + W, pe, sizeof(float) * Cpe);
+                    cin = W + Cpe;
+                }
+                float *t = h; h = o; o = t;
+            }
+            float dens;
+            orc_linear_t(h, net->dens_w, net->dens_b, cin, 1, &dens);
+            density[n] = orc_act(net->density_activation, dens);
+            for (int e = 0; e < Ed; ++e)
+                for (int d = 0; d < 3; ++d) {
+                    float p = ldexpf(1.0f, e) * dir[3 * n + d];
+                    h[cin + e * 3 + d] = sinf(p);
+                    h[cin + 3 * Ed + e * 3 + d] = cosf(p);
+                }
+            orc_linear_t(h, net->col0_w, net->col0_b, cin + Cdir, W / 2, o);
+            for (int j = 0; j < W / 2; ++j) o[j] = o[j] > 0.f ? o[j] : 0.f;   /* nn.ReLU */
+            orc_linear_t(o, net->col1_w, net->col1_b, W / 2, 3, color + 3 * n);
+        }
+        free(pe); free(h); free(o);
+    }
+}
+
+int orc_struct_sizes(int which) { return which == 0 ? (int)sizeof(orc_neddf_t) : (int)sizeof(orc_nerf_t); }

@@ -1,0 +1,378 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  Runs ONLY in the build container, where the
+reference checkout exists at /root/reference; nothing of the reference travels.
+
+It imports the reference PyTorch renderer (with three stub modules for the
+absent cv2 / hydra / omegaconf packages), drives its
+public functions on seeded inputs and stores inputs + expected outputs as
+.npz fixtures next to this file.  The fixtures are data only.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_goldens.py
+"""
+import importlib
+import json
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+
+import synth  # noqa: E402
+
+
+# --------------------------------------------------------------------------
+# stub modules (only what neddf.render imports at module scope)
+def _install_stubs():
+    cv2 = types.ModuleType("cv2")
+    cv2.COLORMAP_JET = 2
+    cv2.IMREAD_UNCHANGED = -1
+    cv2.applyColorMap = lambda img, cm: img
+    cv2.imread = cv2.imwrite = lambda *a, **k: None
+    sys.modules["cv2"] = cv2
+    oc = types.ModuleType("omegaconf")
+
+    class DictConfig(dict):
+        pass
+
+    oc.DictConfig = DictConfig
+    sys.modules["omegaconf"] = oc
+    hydra = types.ModuleType("hydra")
+    utils = types.ModuleType("hydra.utils")
+
+    def instantiate(cfg, **kw):
+        cfg = dict(cfg)
+        cfg.update(kw)
+        target = cfg.pop("_target_")
+        cfg.pop("_recursive_", None)
+        mod, cls = target.rsplit(".", 1)
+        return getattr(importlib.import_module(mod), cls)(**cfg)
+
+    utils.instantiate = instantiate
+    hydra.utils = utils
+    sys.modules["hydra"] = hydra
+    sys.modules["hydra.utils"] = utils
+
+
+_install_stubs()
+from neddf.camera import Camera, PinholeCalib  # noqa: E402
+from neddf.network import NeDDF, NeRF  # noqa: E402
+from neddf.nn_module import PositionalEncoding  # noqa: E402
+from neddf.nn_module.with_grad import (  # noqa: E402
+    LeakyReLUGradFunction, LinearGradFunction, PositionalEncodingGradLayer,
+    ReLUGradFunction, SigmoidGradFunction, SoftplusGradFunction, TanhExpGradFunction)
+from neddf.ray import Ray, Sampling  # noqa: E402
+from neddf.render import NeRFRender  # noqa: E402
+from scipy.spatial.transform import Rotation  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez(path, **arrs)
+    print("wrote %s (%.1f KB)" % (name, os.path.getsize(path) / 1024))
+
+
+def to_torch_sd(sd):
+    return {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+def make_camera(width, height, frame, angle_x):
+    """Mirrors the pose/intrinsics maths of nerf_synthetic_dataset.py:49-62."""
+    focal = 0.5 * width / math.tan(0.5 * angle_x)
+    m = np.array(frame["transform_matrix"], dtype=np.float64)
+    rotvec = Rotation.from_matrix(m[:3, :3]).as_rotvec()
+    t = m[:3, 3]
+    calib = np.array([focal, focal, width / 2.0, height / 2.0])
+    cam = Camera(PinholeCalib(calib), np.r_[rotvec, t].astype(np.float32))
+    return cam, calib.astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+def gen_bunny():
+    cfg = yaml.safe_load(open(os.path.join(REF, "pretrained/bunny_smoke/.hydra/config.yaml")))
+    rcfg = dict(cfg["render"])
+    rcfg.pop("_target_")
+    render = NeRFRender(network_config=cfg["network"], **rcfg)
+    sd = torch.load(os.path.join(REF, "pretrained/bunny_smoke/models/model_02000.pth"),
+                    map_location="cpu")
+    print(render.load_state_dict(sd))
+    render.set_iter(-1)
+    render.network_fine.eval()
+    net_sd = {k: npy(v) for k, v in render.network_fine.state_dict().items()}
+    save("bunny_weights.npz", **net_sd)
+
+    tf = json.load(open(os.path.join(REF, "data/bunny_smoke/transforms_test.json")))
+    W = H = 400
+    cam, calib = make_camera(W, H, tf["frames"][0], tf["camera_angle_x"])
+    cam.update_transform()
+    rng = np.random.default_rng(2024)
+    uv_c = rng.integers(120, 280, (48, 2))
+    uv_a = rng.integers(0, 400, (16, 2))
+    uv = torch.from_numpy(np.concatenate([uv_c, uv_a]).astype(np.int64))
+    B = uv.shape[0]
+    Sc, Sf = render.sample_coarse, render.sample_fine
+
+    # --- end-to-end render_rays with captured uniforms (SURVEY App.B step 4)
+    torch.manual_seed(0)
+    state = torch.get_rng_state()
+    u_coarse = torch.rand(B, Sc + 1)
+    u_fine = torch.rand(B, Sf + 1)
+    torch.set_rng_state(state)
+    out = render.render_rays(uv, cam)
+
+    # --- stage by stage on the same inputs (all public functions)
+    rays = cam.create_rays(uv)
+    dists_c = (torch.linspace(render.dist_near, render.dist_far, Sc + 1).reshape(1, -1).expand(B, -1)
+               + u_coarse * ((render.dist_far - render.dist_near) / Sc))
+    radius = 1.0 / 1111 / math.sqrt(12)
+    samp_c = rays.get_sampling_cones(dists_c, radius)
+    val_c = render.network_coarse(samp_c)
+    int_c = render.integrate_volume_render(dists_c, val_c["density"], val_c["color"])
+    w_c_raw = npy(int_c["weight"])
+    torch.set_rng_state(state)
+    _ = torch.rand(B, Sc + 1)
+    dists_f = render.sample_pdf(dists_c, int_c["weight"], Sf + 1)  # mutates weight in place
+    samp_f = rays.get_sampling_cones(dists_f, radius)
+    val_f = render.network_fine(samp_f)
+    int_f = render.integrate_volume_render(dists_f, val_f["density"], val_f["color"])
+    for k in ("color", "depth", "transmittance", "weight"):
+        assert torch.equal(int_f[k], out[k]), k
+    pen_c = torch.sum((dists_c[:, 1:] - dists_c[:, :-1]) * val_c["fields_penalty"][:, :-1], dim=1)
+    pen_f = torch.sum((dists_f[:, 1:] - dists_f[:, :-1]) * val_f["fields_penalty"][:, :-1], dim=1)
+    assert torch.equal(pen_f, out["fields_penalty"])
+    # point sampling of the same coarse distances (ray.py:88)
+    samp_p = rays.get_sampling_points(dists_c)
+    arrs = dict(
+        uv=npy(uv), R=npy(cam.R), T=npy(cam.T), calib=calib,
+        dist_near=np.float32(render.dist_near), dist_far=np.float32(render.dist_far),
+        max_dist=np.float32(render.max_dist), ray_radius=np.float64(radius),
+        sample_coarse=np.int32(Sc), sample_fine=np.int32(Sf),
+        ray_dir=npy(rays.ray_dir), ray_orig=npy(rays.ray_orig),
+        u_coarse=npy(u_coarse), u_fine=npy(u_fine),
+        dists_coarse=npy(dists_c), dists_fine=npy(dists_f),
+        c_pos=npy(samp_c.sample_pos), c_dir=npy(samp_c.sample_dir), c_var=npy(samp_c.diag_variance),
+        p_pos=npy(samp_p.sample_pos), p_var=npy(samp_p.diag_variance),
+        f_pos=npy(samp_f.sample_pos), f_dir=npy(samp_f.sample_dir), f_var=npy(samp_f.diag_variance),
+        weight_coarse_raw=w_c_raw, weight_coarse=npy(int_c["weight"]),
+        pen_coarse=npy(pen_c), pen_fine=npy(pen_f),
+        num_threads=np.int32(torch.get_num_threads()),
+    )
+    for k, v in val_c.items():
+        arrs["c_" + k] = npy(v)
+    for k, v in val_f.items():
+        arrs["f_" + k] = npy(v)
+    for k in ("color", "depth", "transmittance"):
+        arrs["ic_" + k] = npy(int_c[k])
+    for k, v in out.items():
+        arrs["out_" + k] = npy(v)
+    save("bunny_stages.npz", **arrs)
+
+    # --- render_image on a tiny frame: pins uv order, chunking and RNG draw order
+    w, h, chunk = 12, 10, 50
+    cam2, calib2 = make_camera(w, h, tf["frames"][7], tf["camera_angle_x"])
+    cam2.update_transform()
+    torch.manual_seed(0)
+    img = render.render_image(w, h, cam2, ["color", "depth", "transmittance"], 1, chunk)
+    torch.manual_seed(0)
+    img2 = render.render_image(2 * w, 2 * h, cam2, ["color", "depth"], 2, 64)
+    save("bunny_image_small.npz", R=npy(cam2.R), T=npy(cam2.T), calib=calib2,
+         width=np.int32(w), height=np.int32(h), chunk=np.int32(chunk), seed=np.int32(0),
+         color=npy(img["color"]), depth=npy(img["depth"]), transmittance=npy(img["transmittance"]),
+         ds_color=npy(img2["color"]), ds_depth=npy(img2["depth"]), ds_chunk=np.int32(64))
+    return render
+
+
+# --------------------------------------------------------------------------
+def gen_ops():
+    """Unit goldens for the (value, Jacobian) ops on the inputs the reference's
+    own tests use (tests/nn_module/with_grad/*.py: torch.manual_seed(1))."""
+    a = {}
+    torch.manual_seed(1)
+    x = torch.rand(10, 15) * 8 - 4          # wider than the test's [0,1) to hit both signs
+    J = torch.rand(10, 3, 15) * 2 - 1
+    x[0, 0] = 25.0                          # threshold branch (x > 20)
+    x[0, 1] = -30.0
+    a["act_x"], a["act_J"] = npy(x), npy(J)
+    for name, fn in (("leaky", LeakyReLUGradFunction), ("relu", ReLUGradFunction),
+                     ("softplus", SoftplusGradFunction), ("tanhexp", TanhExpGradFunction)):
+        y, G = fn.apply(x.clone(), J.clone())
+        a[name + "_y"], a[name + "_G"] = npy(y), npy(G)
+    xs, Js = x[:, :1].clone(), J[:, :, :1].clone()
+    y, G = SigmoidGradFunction.apply(xs, Js)
+    a["sigmoid_y"], a["sigmoid_G"] = npy(y), npy(G)
+    # linear (test_linear.py inputs)
+    torch.manual_seed(1)
+    x = torch.rand(10, 3)
+    J = torch.eye(3).unsqueeze(0).expand(10, 3, 3).contiguous()
+    w = torch.rand(3, 128)
+    b = torch.rand(128)
+    y, G = LinearGradFunction.apply(x, J, w, b)
+    a.update(lin_x=npy(x), lin_J=npy(J), lin_w=npy(w), lin_b=npy(b), lin_y=npy(y), lin_G=npy(G))
+    # PE with grad (test_positional_encoding.py inputs) and a scaled rank-10 case
+    torch.manual_seed(1)
+    x = torch.rand(10, 3)
+    J = torch.rand(10, 3, 3)
+    y, G = PositionalEncodingGradLayer(4)(x, J)
+    a.update(pe4_x=npy(x), pe4_J=npy(J), pe4_y=npy(y), pe4_G=npy(G))
+    layer = PositionalEncodingGradLayer(10)
+    x = torch.rand(12, 3) * 4 - 2
+    var = torch.rand(12, 1, 3) * 1e-3
+    smp = Sampling(x.reshape(12, 1, 3), x.reshape(12, 1, 3), var)
+    wts = smp.get_pe_weights(layer.freq)
+    eye = torch.eye(3).unsqueeze(0).expand(12, 3, 3)
+    y, G = layer(x, eye, layer.get_grad_scale() * wts)
+    a.update(pe10_x=npy(x), pe10_var=npy(var.reshape(12, 3)), pe10_w=npy(wts), pe10_y=npy(y), pe10_G=npy(G),
+             pe10_gradscale=npy(layer.get_grad_scale()))
+    for alpha in (3.25, 9.5, 10.0):
+        a["lowpass_%g" % alpha] = npy(layer.get_lowpass_scale(alpha))
+    a["pedir_y"] = npy(PositionalEncoding(4)(x))
+    save("ops.npz", **a)
+
+
+# --------------------------------------------------------------------------
+def gen_fields():
+    """Field goldens on synthetic seeded weights (tests/golden/synth.py)."""
+    pos, d, var = synth.random_sampling(6, 40, seed=5, cone=True)
+    smp = Sampling(torch.from_numpy(pos), torch.from_numpy(d), torch.from_numpy(var))
+    cases = {
+        # reference test fixture config (tests/conftest.py:77-99)
+        "neddf_relu": dict(embed_pos_rank=6, embed_dir_rank=4, ddf_layer_count=8, ddf_layer_width=256,
+                           col_layer_count=8, col_layer_width=256, d_near=0.01, activation_type="ReLU",
+                           density_activation_type="ReLU", skips=[4], lowpass_alpha_offset=10,
+                           penalty_weight={"constraints_aux_grad": 0.05, "constraints_dDdt": 0.05,
+                                           "constraints_color": 0.0, "range_distance": 1.0,
+                                           "range_aux_grad": 1.0}),
+        # shipped architecture (config/network/neddf.yaml) on synthetic weights
+        "neddf_tanhexp": dict(embed_pos_rank=10, embed_dir_rank=4, ddf_layer_count=8, ddf_layer_width=256,
+                              col_layer_count=4, col_layer_width=256, d_near=0.001, activation_type="tanhExp",
+                              density_activation_type="ReLU", skips=[4], lowpass_alpha_offset=10,
+                              penalty_weight={"constraints_aux_grad": 0.05, "constraints_dDdt": 1.0,
+                                              "constraints_color": 0.0001, "range_distance": 1.0,
+                                              "range_aux_grad": 1.0, "range_color": 0.1}),
+        "neddf_leaky": dict(embed_pos_rank=8, embed_dir_rank=3, ddf_layer_count=6, ddf_layer_width=256,
+                            col_layer_count=3, col_layer_width=256, d_near=0.01, activation_type="LeakyReLU",
+                            density_activation_type="tanhExp", skips=[2], lowpass_alpha_offset=3),
+    }
+    for name, kw in cases.items():
+        net = NeDDF(**kw)
+        sd = synth.neddf_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["ddf_layer_count"],
+                               kw["ddf_layer_width"], kw["col_layer_count"], kw["col_layer_width"],
+                               tuple(kw["skips"]), seed=7)
+        print(name, net.load_state_dict(to_torch_sd(sd)))
+        arrs = dict(pos=pos, dir=d, var=var, config=np.array(json.dumps(kw)))
+        for it in (-1, 2500):   # eval, and a warm-up iteration (lowpass + aux_grad_scale live)
+            net.set_iter(it)
+            out = net(smp)
+            tag = "eval" if it == -1 else "it%d" % it
+            for k, v in out.items():
+                arrs["%s_%s" % (tag, k)] = npy(v)
+        save(name + ".npz", **arrs)
+
+    kw = dict(embed_pos_rank=10, embed_dir_rank=4, layer_count=8, layer_width=256, activation_type="ReLU",
+              density_activation_type="ReLU", skips=[4], lowpass_alpha_offset=10)
+    for name, kw2 in (("nerf_relu", kw),
+                      ("nerf_tanhexp", dict(kw, activation_type="tanhExp", density_activation_type="LeakyReLU",
+                                            embed_pos_rank=6, layer_count=6, skips=[2],
+                                            lowpass_alpha_offset=2))):
+        net = NeRF(**kw2)
+        sd = synth.nerf_state(kw2["embed_pos_rank"], kw2["embed_dir_rank"], kw2["layer_count"],
+                              kw2["layer_width"], tuple(kw2["skips"]), seed=11)
+        print(name, net.load_state_dict(to_torch_sd(sd)))
+        arrs = dict(pos=pos, dir=d, var=var, config=np.array(json.dumps(kw2)))
+        for it in (-1, 2500):
+            net.set_iter(it)
+            out = net(smp)
+            tag = "eval" if it == -1 else "it%d" % it
+            for k, v in out.items():
+                arrs["%s_%s" % (tag, k)] = npy(v)
+        save(name + ".npz", **arrs)
+
+    # NeRFRender with a NeRF network pair, point sampling, 2 separate nets (config/render/nerf_render.yaml)
+    ncfg = dict(kw, _target_="neddf.network.NeRF")
+    render = NeRFRender(network_config=ncfg, sample_coarse=32, sample_fine=48, dist_near=2.0, dist_far=6.0,
+                        max_dist=6.0, use_coarse_network=True, sampling_type="point")
+    render.network_coarse.load_state_dict(to_torch_sd(synth.nerf_state(seed=21)))
+    render.network_fine.load_state_dict(to_torch_sd(synth.nerf_state(seed=22)))
+    render.set_iter(-1)
+    calib = np.array([100.0, 100.0, 320.0, 240.0])
+    cam = Camera(PinholeCalib(calib), np.array([0.02, 0.04, 0.06, 0.1, 0.2, 0.3], dtype=np.float32))
+    us = torch.linspace(0, 480, 32)
+    vs = torch.linspace(0, 640, 32)
+    uvf = torch.stack([us, vs], 1)            # float uv as in tests/render/test_nerf_render.py:51-53
+    torch.manual_seed(3)
+    state = torch.get_rng_state()
+    u_c = torch.rand(32, 33)
+    u_f = torch.rand(32, 49)
+    torch.set_rng_state(state)
+    out = render.render_rays(uvf, cam)
+    arrs = dict(uv=npy(uvf), R=npy(cam.R), T=npy(cam.T), calib=calib.astype(np.float32),
+                u_coarse=npy(u_c), u_fine=npy(u_f))
+    for k, v in out.items():
+        arrs["out_" + k] = npy(v)
+    save("nerf_render_rays.npz", **arrs)
+
+
+# --------------------------------------------------------------------------
+def gen_render_edges(render):
+    """integrate_volume_render / sample_pdf on edge-case inputs."""
+    a = {}
+    rng = np.random.default_rng(99)
+    B, S = 9, 33
+    dists = np.sort(rng.uniform(2, 6, (B, S)).astype(np.float32), axis=1)
+    dens = rng.uniform(-5, 30, (B, S)).astype(np.float32)
+    dens[0] = 0.0
+    dens[1] = 1e4                       # saturating opacity
+    dens[2] = -3.0                      # negative density -> T > 1
+    dists[3, 10:14] = dists[3, 10]      # repeated distances (zero deltas)
+    col = rng.uniform(-0.5, 1.2, (B, S, 3)).astype(np.float32)
+    r = render.integrate_volume_render(torch.from_numpy(dists), torch.from_numpy(dens), torch.from_numpy(col))
+    a.update(iv_dists=dists, iv_dens=dens, iv_col=col, iv_weight=npy(r["weight"]), iv_depth=npy(r["depth"]),
+             iv_color=npy(r["color"]), iv_trans=npy(r["transmittance"]), iv_max_dist=np.float32(render.max_dist))
+    # test_nerf_render.py:17-30 inputs (constant density/colour)
+    d2 = torch.linspace(0.0, 2.0, 64).unsqueeze(0).expand(32, 64).contiguous()
+    r = render.integrate_volume_render(d2, torch.ones(32, 64), torch.ones(32, 64, 3))
+    a.update(ivc_depth=npy(r["depth"]), ivc_color=npy(r["color"]), ivc_trans=npy(r["transmittance"]),
+             ivc_weight=npy(r["weight"]))
+
+    B, Sc, Sf = 8, 16, 21
+    dists = np.sort(rng.uniform(2, 6, (B, Sc + 1)).astype(np.float32), axis=1)
+    w = rng.uniform(0, 1, (B, Sc)).astype(np.float32) ** 3
+    w[0] = 0.0                                  # flat pdf
+    w[1, :] = 0.0
+    w[1, 5] = 1.0                               # single spike
+    w[2, ::2] = -0.3                            # negative weights -> sanitised
+    w[3, 4] = np.nan                            # NaN weight -> sanitised
+    w[4] = 1e-9
+    for cat in (True, False):
+        torch.manual_seed(5)
+        state = torch.get_rng_state()
+        u = torch.rand(B, Sf)
+        torch.set_rng_state(state)
+        wt = torch.from_numpy(w.copy())
+        out = render.sample_pdf(torch.from_numpy(dists), wt, Sf, cat_coarse=cat)
+        tag = "cat" if cat else "nocat"
+        a.update({"sp_%s_out" % tag: npy(out), "sp_%s_wafter" % tag: npy(wt)})
+        a["sp_u"] = npy(u)
+    a.update(sp_dists=dists, sp_w=w)
+    save("render_edges.npz", **a)
+
+
+if __name__ == "__main__":
+    r = gen_bunny()
+    gen_ops()
+    gen_fields()
+    gen_render_edges(r)

@@ -1,0 +1,181 @@
+"""Pins the CPU oracle (oracle/) against golden vectors generated from the
+reference PyTorch renderer (tests/golden/gen_goldens.py).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+from conftest import BUNNY_CFG, assert_close, golden
+
+import synth
+from oracle import oracle as orc
+
+
+def test_raygen(bunny_stages):
+    g = bunny_stages
+    d, o = orc.create_rays(g["uv"], g["R"], g["T"], g["calib"])
+    assert_close(d, g["ray_dir"], 1e-6, 1e-7, "ray_dir")
+    assert np.array_equal(o, g["ray_orig"])
+
+
+def test_sample_coarse_bitexact(bunny_stages):
+    g = bunny_stages
+    dc = orc.sample_coarse(g["u_coarse"], float(g["dist_near"]), float(g["dist_far"]))
+    assert np.array_equal(dc, g["dists_coarse"])
+
+
+def test_sampling(bunny_stages):
+    g = bunny_stages
+    pos, d, var = orc.sampling(g["ray_dir"], g["ray_orig"], g["dists_coarse"], float(g["ray_radius"]))
+    assert_close(pos, g["c_pos"], 1e-6, 1e-7, "cone pos")
+    assert np.array_equal(d, g["c_dir"])
+    assert_close(var, g["c_var"], 2e-5, 1e-12, "cone var")
+    pos, d, var = orc.sampling(g["ray_dir"], g["ray_orig"], g["dists_fine"], float(g["ray_radius"]))
+    assert_close(pos, g["f_pos"], 1e-6, 1e-7, "cone pos fine")
+    assert_close(var, g["f_var"], 1e-4, 1e-12, "cone var fine")
+    pos, d, var = orc.sampling(g["ray_dir"], g["ray_orig"], g["dists_coarse"], None)
+    assert_close(pos, g["p_pos"], 1e-6, 1e-7, "point pos")
+    assert np.array_equal(var, g["p_var"])
+
+
+def test_ops():
+    g = golden("ops.npz")
+    for kind, key in (("LeakyReLU", "leaky"), ("ReLU", "relu"), ("tanhExp", "tanhexp"), ("softplus", "softplus")):
+        y, G = orc.activation_grad(kind, g["act_x"], g["act_J"])
+        assert_close(y, g[key + "_y"], 2e-6, 1e-7, key + " y")
+        assert_close(G, g[key + "_G"], 2e-6, 1e-7, key + " G")
+    y, G = orc.activation_grad("sigmoid", g["act_x"][:, :1], g["act_J"][:, :, :1])
+    assert_close(y, g["sigmoid_y"], 2e-6, 1e-7, "sigmoid y")
+    assert_close(G, g["sigmoid_G"], 2e-6, 1e-7, "sigmoid G")
+    y, G = orc.linear_grad(g["lin_x"], g["lin_J"], g["lin_w"], g["lin_b"])
+    assert_close(y, g["lin_y"], 1e-6, 1e-7, "linear y")
+    assert_close(G, g["lin_G"], 1e-6, 1e-7, "linear G")
+    y, G = orc.pe_grad(g["pe4_x"], g["pe4_J"], None, 4)
+    assert_close(y, g["pe4_y"], 1e-6, 2e-7, "pe4 y")
+    assert_close(G, g["pe4_G"], 1e-6, 1e-6, "pe4 G")
+    w = orc.pe_weights(g["pe10_var"], 10)
+    assert_close(w, g["pe10_w"], 1e-6, 1e-30, "pe weights")
+    eye = np.broadcast_to(np.eye(3, dtype=np.float32), (12, 3, 3))
+    y, G = orc.pe_grad(g["pe10_x"], eye, g["pe10_gradscale"] * g["pe10_w"], 10)
+    assert_close(y, g["pe10_y"], 1e-6, 3e-7, "pe10 y")
+    assert_close(G, g["pe10_G"], 1e-6, 3e-7, "pe10 G")
+    assert_close(orc.pe(g["pe10_x"], None, 4), g["pedir_y"], 1e-6, 2e-7, "pe dir")
+    for alpha in (3.25, 9.5, 10.0):
+        lp = np.repeat(orc.lowpass_scale(alpha, 10), 3)[None]
+        assert np.array_equal(lp, g["lowpass_%g" % alpha])
+
+
+def test_integrate(bunny_stages):
+    g = bunny_stages
+    r = orc.integrate(g["dists_coarse"], g["c_density"], g["c_color"], float(g["max_dist"]))
+    assert not r["nan"]
+    assert_close(r["weight"], g["weight_coarse_raw"], 1e-5, 1e-7, "weight")
+    assert_close(r["color"], g["ic_color"], 1e-5, 1e-6, "color")
+    assert_close(r["depth"], g["ic_depth"], 1e-5, 1e-6, "depth")
+    assert_close(r["transmittance"], g["ic_transmittance"], 1e-5, 1e-7, "trans")
+    assert_close(orc.integrate_penalty(g["dists_coarse"], g["c_fields_penalty"]), g["pen_coarse"], 1e-5, 1e-7)
+    e = golden("render_edges.npz")
+    r = orc.integrate(e["iv_dists"], e["iv_dens"], e["iv_col"], float(e["iv_max_dist"]))
+    assert_close(r["weight"], e["iv_weight"], 2e-5, 1e-7, "edge weight")
+    assert_close(r["color"], e["iv_color"], 2e-5, 1e-6, "edge color")
+    assert_close(r["depth"], e["iv_depth"], 2e-5, 1e-6, "edge depth")
+    assert_close(r["transmittance"], e["iv_trans"], 2e-5, 1e-12, "edge trans")
+    d2 = np.broadcast_to(np.linspace(0.0, 2.0, 64, dtype=np.float32), (32, 64))
+    r = orc.integrate(d2, np.ones((32, 64), np.float32), np.ones((32, 64, 3), np.float32), float(e["iv_max_dist"]))
+    assert_close(r["color"], e["ivc_color"], 1e-6, 1e-7)
+    assert_close(r["depth"], e["ivc_depth"], 1e-6, 1e-7)
+
+
+def test_sample_pdf_bitexact(bunny_stages):
+    """Same weights/dists/uniforms => bit-identical samples (SURVEY App.A N4)."""
+    g = bunny_stages
+    w = g["weight_coarse_raw"].copy()
+    out, ids, fb = orc.sample_pdf(g["dists_coarse"], w, g["u_fine"], True)
+    assert not fb
+    assert np.array_equal(out, g["dists_fine"])
+    assert np.array_equal(w, g["weight_coarse"])          # in-place sanitisation
+    assert ids.min() >= 1 and ids.max() <= 64
+    e = golden("render_edges.npz")
+    for cat, tag in ((True, "cat"), (False, "nocat")):
+        w = e["sp_w"].copy()
+        out, _, fb = orc.sample_pdf(e["sp_dists"], w, e["sp_u"], cat)
+        assert np.array_equal(out, e["sp_%s_out" % tag]), tag
+        assert np.array_equal(w, e["sp_%s_wafter" % tag], equal_nan=True)
+
+
+def test_sample_pdf_nan_fallback():
+    d = np.sort(np.random.default_rng(0).uniform(2, 6, (3, 9)).astype(np.float32), axis=1)
+    d[1, 3] = np.nan
+    w = np.ones((3, 8), np.float32)
+    u = np.random.default_rng(1).uniform(0, 1, (3, 5)).astype(np.float32)
+    out, _, fb = orc.sample_pdf(d, w, u, True)
+    assert fb and np.isfinite(out).all()
+    assert np.allclose(out[2], np.linspace(d[0, 0], d[0, -1], 14), rtol=1e-6)
+
+
+def test_neddf_bunny_field(bunny_weights, bunny_stages):
+    g = bunny_stages
+    net = orc.NeDDFOracle(bunny_weights, **BUNNY_CFG)
+    for tag in ("c", "f"):
+        o = net.forward(g[tag + "_pos"], g[tag + "_dir"], g[tag + "_var"])
+        assert_close(o["distance"], g[tag + "_distance"], 1e-4, 1e-6, tag + " distance")
+        assert_close(o["aux_grad"], g[tag + "_aux_grad"], 1e-4, 1e-6, tag + " aux")
+        assert_close(o["color"], g[tag + "_color"], 1e-4, 2e-5, tag + " color")
+        # density = (1 - |grad|)/D amplifies fp32 noise (SURVEY App.A N7): abs 5e-5 on range ~40
+        assert_close(o["density"], g[tag + "_density"], 1e-4, 3e-4, tag + " density")
+        assert_close(o["fields_penalty"], g[tag + "_fields_penalty"], 2e-3, 1e-5, tag + " penalty")
+
+
+@pytest.mark.parametrize("name", ["neddf_relu", "neddf_tanhexp", "neddf_leaky"])
+def test_neddf_synth(name):
+    g = golden(name + ".npz")
+    kw = json.loads(str(g["config"]))
+    sd = synth.neddf_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["ddf_layer_count"], kw["ddf_layer_width"],
+                           kw["col_layer_count"], kw["col_layer_width"], tuple(kw["skips"]), seed=7)
+    net = orc.NeDDFOracle(sd, **kw)
+    for it, tag in ((-1, "eval"), (2500, "it2500")):
+        net.set_iter(it)
+        o = net.forward(g["pos"], g["dir"], g["var"])
+        for k in ("distance", "aux_grad", "color", "density", "fields_penalty"):
+            assert_close(o[k], g["%s_%s" % (tag, k)], 2e-4, 2e-5, "%s %s %s" % (name, tag, k))
+
+
+@pytest.mark.parametrize("name", ["nerf_relu", "nerf_tanhexp"])
+def test_nerf_synth(name):
+    g = golden(name + ".npz")
+    kw = json.loads(str(g["config"]))
+    sd = synth.nerf_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["layer_count"], kw["layer_width"],
+                          tuple(kw["skips"]), seed=11)
+    net = orc.NeRFOracle(sd, **kw)
+    for it, tag in ((-1, "eval"), (2500, "it2500")):
+        net.set_iter(it)
+        o = net.forward(g["pos"], g["dir"], g["var"])
+        for k in ("density", "color"):
+            assert_close(o[k], g["%s_%s" % (tag, k)], 1e-4, 1e-5, "%s %s %s" % (name, tag, k))
+
+
+def test_render_rays_end_to_end(bunny_weights, bunny_stages):
+    g = bunny_stages
+    net = orc.NeDDFOracle(bunny_weights, **BUNNY_CFG)
+    out = orc.render_rays(net, net, g["uv"], g["R"], g["T"], g["calib"], g["u_coarse"], g["u_fine"],
+                          float(g["dist_near"]), float(g["dist_far"]), float(g["max_dist"]), "cone")
+    assert_close(out["color"], g["out_color"], 1e-4, 1e-5, "color")
+    assert_close(out["depth"], g["out_depth"], 1e-4, 1e-5, "depth")
+    assert_close(out["transmittance"], g["out_transmittance"], 1e-4, 1e-5, "transmittance")
+    assert_close(out["color_coarse"], g["out_color_coarse"], 1e-4, 1e-5, "color_coarse")
+    assert_close(out["depth_coarse"], g["out_depth_coarse"], 1e-4, 1e-5, "depth_coarse")
+    # end-to-end sample positions: identical up to knot flips ("bit-exact indices")
+    flips = np.mean(out["dists_fine"] != g["dists_fine"])
+    assert flips < 0.5
+    assert_close(out["dists_fine"], g["dists_fine"], 1e-4, 1e-4, "dists_fine")
+
+
+def test_nerf_render_rays():
+    g = golden("nerf_render_rays.npz")
+    kw = dict(embed_pos_rank=10, embed_dir_rank=4, layer_count=8, layer_width=256, activation_type="ReLU",
+              density_activation_type="ReLU", skips=[4], lowpass_alpha_offset=10)
+    nc = orc.NeRFOracle(synth.nerf_state(seed=21), **kw)
+    nf = orc.NeRFOracle(synth.nerf_state(seed=22), **kw)
+    out = orc.render_rays(nc, nf, g["uv"], g["R"], g["T"], g["calib"], g["u_coarse"], g["u_fine"], 2.0, 6.0, 6.0,
+                          "point")
+    for k in ("color", "depth", "transmittance", "color_coarse", "depth_coarse", "transmittance_coarse"):
+        assert_close(out[k], g["out_" + k], 1e-4, 1e-5, k)
