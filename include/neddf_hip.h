@@ -1,0 +1,183 @@
+/*
+ * neddf_hip.h -- C ABI of libneddf_hip.so, the MI355X (gfx950) volumetric
+ * renderer behind the reference project's Python plugin surface.
+ *
+ * The reference (ueda0319/neddf) has no FFI: its "plugin API" is the set of
+ * Python classes Hydra instantiates.  This header is
+ * the boundary those classes' replacements (package neddf_amd, aliased as
+ * neddf) call through ctypes.  Each entry point names the reference function
+ * it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - extern "C", POD only, no torch types.  Every `d_` pointer is a DEVICE
+ *     pointer owned by the caller (a torch allocation); `h_` pointers are HOST.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *     stage calls are asynchronous on that stream; the caller synchronises.
+ *   - Return 0 on success, a negative NEDDF_E* code otherwise; never throws.
+ *     neddf_last_error(ctx) returns a static/ctx-owned message.
+ *   - One ctx per device; a ctx is not thread-safe, distinct ctxs are
+ *     independent.  The ctx owns packed weights and scratch workspaces.
+ */
+#ifndef NEDDF_HIP_H
+#define NEDDF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEDDF_ABI_VERSION 1
+
+enum { NEDDF_OK = 0, NEDDF_EINVAL = -1, NEDDF_EHIP = -2, NEDDF_EUNSUPPORTED = -3, NEDDF_ENOFIELD = -4 };
+enum { NEDDF_FIELD_NEDDF = 0, NEDDF_FIELD_NERF = 1 };
+enum { NEDDF_ACT_RELU = 0, NEDDF_ACT_LEAKY = 1, NEDDF_ACT_TANHEXP = 2 };
+enum { NEDDF_SLOT_COARSE = 0, NEDDF_SLOT_FINE = 1, NEDDF_NUM_SLOTS = 4 };
+/* uv element types accepted by neddf_raygen (the reference takes int64 in
+ * render_image, int16 in training, float in its tests) */
+enum { NEDDF_UV_F32 = 0, NEDDF_UV_I64 = 1, NEDDF_UV_I32 = 2, NEDDF_UV_I16 = 3 };
+/* field output selection */
+enum { NEDDF_OUT_MINIMAL = 0,   /* density + color (+distance, aux_grad): what compositing consumes */
+       NEDDF_OUT_FULL = 1 };    /* + fields_penalty: Jacobian through the colour trunk (neddf.py:243-300) */
+
+typedef struct neddf_ctx neddf_ctx;
+
+/* Architecture of one field network.  Mirrors the constructor keywords of
+ * NeDDF (neddf/network/neddf.py:52-66) and NeRF (neddf/network/nerf.py:34-44). */
+typedef struct {
+    int kind;                 /* NEDDF_FIELD_* */
+    int embed_pos_rank;       /* <= 10 */
+    int embed_dir_rank;       /* <= 4  */
+    int layer_count;          /* NeDDF: ddf_layer_count, NeRF: layer_count */
+    int layer_width;          /* must be 256 */
+    int col_layer_count;      /* NeDDF only */
+    int col_layer_width;      /* NeDDF only, must be 256 */
+    int n_skips;
+    int skips[8];
+    int activation;           /* NEDDF_ACT_* */
+    int density_activation;   /* NEDDF_ACT_* */
+    float d_near;             /* NeDDF only */
+    /* NeDDF penalty weights in the dict order of neddf.py:260-291:
+     * constraints_aux_grad, constraints_dDdt, range_distance, range_aux_grad,
+     * range_color, constraints_color; has[i]==0 leaves the term unweighted. */
+    float penalty_weight[6];
+    int penalty_has[6];
+} neddf_field_desc;
+
+/* Pinhole camera: Camera.R / Camera.T (camera.py:117-118) and
+ * PinholeCalib [fx, fy, cx, cy] (pinhole_calib.py:8). */
+typedef struct {
+    float R[9];
+    float T[3];
+    float calib[4];
+} neddf_camera;
+
+/* NeRFRender constructor values (neddf/render/nerf_render.py:40-81). */
+typedef struct {
+    int sample_coarse;
+    int sample_fine;
+    float dist_near, dist_far, max_dist;
+    int cone_sampling;        /* sampling_type == "cone" */
+    double ray_radius;        /* 1/1111/sqrt(12), nerf_render.py:144-145 */
+} neddf_render_params;
+
+int neddf_abi_version(void);
+int neddf_create(int device, neddf_ctx **out);
+void neddf_destroy(neddf_ctx *ctx);
+const char *neddf_last_error(neddf_ctx *ctx);
+/* number of compute units of the ctx's device (for roofline reporting) */
+int neddf_device_cus(neddf_ctx *ctx);
+
+/* Replaces nn.Module.load_state_dict for one network (base_trainer.py:121).
+ * h_weights / h_biases: HOST fp32 arrays in state-dict order
+ *   NeDDF: layers_ddf.0..n, layers_col.0..m, layer_ddf_out, layer_aux_out, layer_col_out
+ *          (LinearGradLayer weights are [in,out], linear.py:113)
+ *   NeRF : layers.0..n, outL_density, outL_color.0, outL_color.2
+ *          (nn.Linear weights are [out,in], nerf.py:88-103)
+ * The library packs them into MFMA fragment order and uploads; the caller keeps
+ * ownership of the sources. */
+int neddf_set_field(neddf_ctx *ctx, int slot, const neddf_field_desc *desc,
+                    const float *const *h_weights, const float *const *h_biases, int n_tensors);
+/* Replaces NeDDF.set_iter / NeRF.set_iter (neddf.py:311-326, nerf.py:167-178):
+ * h_lowpass[embed_pos_rank] = get_lowpass_scale(lowpass_alpha) per frequency. */
+int neddf_set_iter(neddf_ctx *ctx, int slot, float aux_grad_scale, float distance_range_max,
+                   const float *h_lowpass);
+
+/* Camera.create_rays (camera.py:155-171) + get_center_of_pixels (:173-187) +
+ * PinholeCalib.unproject_local (pinhole_calib.py:51-74). */
+int neddf_raygen(neddf_ctx *ctx, const void *d_uv, int uv_type, int64_t n_rays, const neddf_camera *h_cam,
+                 float *d_ray_dir, float *d_ray_orig, void *stream);
+/* Stratified coarse distances (nerf_render.py:131-140): dists[b,j] =
+ * linspace(near,far,S1)[j] + U[b,j]*(far-near)/(S1-1). */
+int neddf_sample_coarse(neddf_ctx *ctx, const float *d_U, int64_t n_rays, int S1, float dist_near,
+                        float dist_far, float *d_dists, void *stream);
+/* Ray.get_sampling_cones (ray.py:128-194) when ray_radius >= 0, else
+ * Ray.get_sampling_points (ray.py:88-126).  Outputs [n_rays,S,3] each. */
+int neddf_sampling(neddf_ctx *ctx, const float *d_ray_dir, const float *d_ray_orig, const float *d_dists,
+                   int64_t n_rays, int S, double ray_radius, float *d_pos, float *d_dir, float *d_var,
+                   void *stream);
+/* NeDDF.forward (neddf.py:162-309) / NeRF.forward (nerf.py:107-165) on N
+ * sample points (pos/dir/var [N,3]).  Any output pointer may be NULL.
+ * NeRF fields produce density and color only. */
+int neddf_field_forward(neddf_ctx *ctx, int slot, const float *d_pos, const float *d_dir, const float *d_var,
+                        int64_t n_points, int out_mode, float *d_distance, float *d_density, float *d_color,
+                        float *d_fields_penalty, float *d_aux_grad, void *stream);
+/* BaseNeuralRender.integrate_volume_render (base_neural_render.py:117-172).
+ * d_weight [n_rays,S-1] may be NULL.  *d_nan_flag (int, may be NULL) is set to 1
+ * if any weight is NaN (the reference asserts, :155). */
+int neddf_composite(neddf_ctx *ctx, const float *d_dists, const float *d_density, const float *d_color,
+                    int64_t n_rays, int S, float max_dist, float *d_weight, float *d_depth, float *d_out_color,
+                    float *d_transmittance, int *d_nan_flag, void *stream);
+/* penalty line integral (nerf_render.py:153-159): out[b] = sum_j (t[j+1]-t[j]) * pen[b,j] */
+int neddf_integrate_penalty(neddf_ctx *ctx, const float *d_dists, const float *d_penalty, int64_t n_rays, int S,
+                            float *d_out, void *stream);
+/* BaseNeuralRender.sample_pdf (base_neural_render.py:27-115) with explicit
+ * uniforms d_U [n_rays,n_fine].  d_dists [n_rays,n], d_weights [n_rays,n-1] is
+ * sanitised IN PLACE like the reference (:52-55).  d_out [n_rays, n_fine+n]
+ * (cat_coarse) or [n_rays,n_fine]; d_ids (int64, may be NULL) receives the
+ * searchsorted indices.  The batch-wide NaN fallback (:105-114) is applied on
+ * device. */
+int neddf_importance_resample(neddf_ctx *ctx, const float *d_dists, float *d_weights, const float *d_U,
+                              int64_t n_rays, int n, int n_fine, int cat_coarse, float *d_out, int64_t *d_ids,
+                              void *stream);
+
+/* Outputs of the fused renderer; every pointer may be NULL. Shapes per ray. */
+typedef struct {
+    float *color;            /* [3] */
+    float *depth;            /* [1] */
+    float *transmittance;    /* [1] */
+    float *weight;           /* [S_fine-1]   (S_fine = sample_fine+1+sample_coarse+1) */
+    float *fields_penalty;   /* [1]  (forces NEDDF_OUT_FULL on NeDDF fields) */
+    float *color_coarse, *depth_coarse, *transmittance_coarse;
+    float *weight_coarse;    /* [sample_coarse] (sanitised, as the reference returns it) */
+    float *fields_penalty_coarse;
+    float *dists_coarse;     /* [sample_coarse+1] */
+    float *dists_fine;       /* [S_fine] */
+    int *nan_flag;           /* single int: NaN weight seen (reference asserts) */
+} neddf_render_outputs;
+
+/* NeRFRender.render_rays (nerf_render.py:109-188): raygen -> stratified ->
+ * sampling -> field(coarse) -> composite -> sample_pdf -> sampling ->
+ * field(fine) -> composite, all on `stream`, no host round trip.
+ * d_U_coarse [n_rays, sample_coarse+1], d_U_fine [n_rays, sample_fine+1]: the
+ * uniforms the reference draws with torch.rand (nerf_render.py:137,
+ * base_neural_render.py:75). */
+int neddf_render_rays(neddf_ctx *ctx, const void *d_uv, int uv_type, int64_t n_rays, const neddf_camera *h_cam,
+                      const neddf_render_params *params, const float *d_U_coarse, const float *d_U_fine,
+                      const neddf_render_outputs *out, void *stream);
+/* Single-pass variant (BASELINE.json configs[1]: "128 samples/ray"): raygen ->
+ * stratified S1 samples -> sampling -> field(slot) -> composite. */
+int neddf_render_rays_single(neddf_ctx *ctx, int slot, const void *d_uv, int uv_type, int64_t n_rays,
+                             const neddf_camera *h_cam, const neddf_render_params *params, int S1,
+                             const float *d_U, const neddf_render_outputs *out, void *stream);
+
+/* Timing of the dominant kernels of the LAST render/field call on this ctx,
+ * measured with hipEvents on the call's stream (forces a stream sync).
+ * ms[0] distance-trunk kernel, ms[1] colour-trunk kernel, ms[2] everything else. */
+int neddf_set_timing(neddf_ctx *ctx, int enable);
+int neddf_get_timings(neddf_ctx *ctx, float *ms, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEDDF_HIP_H */

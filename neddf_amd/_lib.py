@@ -1,0 +1,268 @@
+"""ctypes binding of libneddf_hip.so (include/neddf_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing, or a tensor is
+not on a HIP device, the product path raises.  (The CPU oracle under oracle/ is
+test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libneddf_hip.so")
+ABI_VERSION = 1
+
+FIELD_NEDDF, FIELD_NERF = 0, 1
+ACT = {"ReLU": 0, "LeakyReLU": 1, "tanhExp": 2}
+SLOT_COARSE, SLOT_FINE, SLOT_GENERIC = 0, 1, 2
+OUT_MINIMAL, OUT_FULL = 0, 1
+UV_TYPES = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.int16: 3}
+PENALTY_KEYS = ("constraints_aux_grad", "constraints_dDdt", "range_distance", "range_aux_grad",
+                "range_color", "constraints_color")     # dict order of neddf.py:260-291
+
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+
+class NeddfError(RuntimeError):
+    pass
+
+
+class FieldDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("embed_pos_rank", C.c_int), ("embed_dir_rank", C.c_int),
+                ("layer_count", C.c_int), ("layer_width", C.c_int), ("col_layer_count", C.c_int),
+                ("col_layer_width", C.c_int), ("n_skips", C.c_int), ("skips", C.c_int * 8),
+                ("activation", C.c_int), ("density_activation", C.c_int), ("d_near", C.c_float),
+                ("penalty_weight", C.c_float * 6), ("penalty_has", C.c_int * 6)]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [("R", C.c_float * 9), ("T", C.c_float * 3), ("calib", C.c_float * 4)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("sample_coarse", C.c_int), ("sample_fine", C.c_int), ("dist_near", C.c_float),
+                ("dist_far", C.c_float), ("max_dist", C.c_float), ("cone_sampling", C.c_int),
+                ("ray_radius", C.c_double)]
+
+
+class RenderOutputs(C.Structure):
+    _fields_ = [(k, _vp) for k in ("color", "depth", "transmittance", "weight", "fields_penalty", "color_coarse",
+                                   "depth_coarse", "transmittance_coarse", "weight_coarse", "fields_penalty_coarse",
+                                   "dists_coarse", "dists_fine", "nan_flag")]
+
+
+# every symbol include/neddf_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("neddf_abi_version", C.c_int, []),
+    ("neddf_create", C.c_int, [C.c_int, C.POINTER(_vp)]),
+    ("neddf_destroy", None, [_vp]),
+    ("neddf_last_error", C.c_char_p, [_vp]),
+    ("neddf_device_cus", C.c_int, [_vp]),
+    ("neddf_set_field", C.c_int, [_vp, C.c_int, C.POINTER(FieldDesc), C.POINTER(_fp), C.POINTER(_fp), C.c_int]),
+    ("neddf_set_iter", C.c_int, [_vp, C.c_int, C.c_float, C.c_float, _fp]),
+    ("neddf_raygen", C.c_int, [_vp, _vp, C.c_int, _i64, C.POINTER(CameraDesc), _vp, _vp, _vp]),
+    ("neddf_sample_coarse", C.c_int, [_vp, _vp, _i64, C.c_int, C.c_float, C.c_float, _vp, _vp]),
+    ("neddf_sampling", C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_double, _vp, _vp, _vp, _vp]),
+    ("neddf_field_forward", C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("neddf_composite", C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("neddf_integrate_penalty", C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp, _vp]),
+    ("neddf_importance_resample", C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    ("neddf_render_rays", C.c_int, [_vp, _vp, C.c_int, _i64, C.POINTER(CameraDesc), C.POINTER(RenderParams), _vp, _vp,
+                                    C.POINTER(RenderOutputs), _vp]),
+    ("neddf_render_rays_single", C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, C.POINTER(CameraDesc),
+                                           C.POINTER(RenderParams), C.c_int, _vp, C.POINTER(RenderOutputs), _vp]),
+    ("neddf_set_timing", C.c_int, [_vp, C.c_int]),
+    ("neddf_get_timings", C.c_int, [_vp, _fp, C.c_int]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libneddf_hip.so; raises NeddfError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NeddfError("libneddf_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "or `make -C neddf_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.neddf_abi_version() != ABI_VERSION:
+            raise NeddfError("libneddf_hip.so ABI %d != binding %d" % (lib.neddf_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def require_device(t, what):
+    if not t.is_cuda:
+        raise NeddfError("%s must live on a HIP device (got %s); the MI355X path has no CPU fallback" % (what, t.device))
+
+
+def f32c(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.to(torch.float32).contiguous()
+
+
+class Context:
+    """One neddf_ctx per device, shared by every module on that device."""
+    _instances = {}
+
+    @classmethod
+    def get(cls, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise NeddfError("neddf_amd runs on HIP devices only (got %s)" % device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if idx not in cls._instances:
+            cls._instances[idx] = cls(idx)
+        return cls._instances[idx]
+
+    def __init__(self, index):
+        self.lib = load()
+        self.index = index
+        self.device = torch.device("cuda", index)
+        h = _vp()
+        rc = self.lib.neddf_create(index, C.byref(h))
+        if rc != 0:
+            raise NeddfError("neddf_create(%d) failed: %s" % (index, self.lib.neddf_last_error(None).decode()))
+        self.h = h
+        self.slot_owner = {}        # slot -> signature of the field currently loaded
+
+    def check(self, rc):
+        if rc != 0:
+            raise NeddfError("libneddf_hip: %s (code %d)" % (self.lib.neddf_last_error(self.h).decode(), rc))
+
+    @property
+    def cus(self):
+        return self.lib.neddf_device_cus(self.h)
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ fields
+    def set_field(self, slot, desc, weights, biases, signature):
+        """weights/biases: lists of CPU float32 contiguous tensors in state-dict order."""
+        n = len(weights)
+        wa = (_fp * n)(*[C.cast(w.data_ptr(), _fp) for w in weights])
+        ba = (_fp * n)(*[C.cast(b.data_ptr(), _fp) for b in biases])
+        self.check(self.lib.neddf_set_field(self.h, slot, C.byref(desc), wa, ba, n))
+        self.slot_owner[slot] = signature
+
+    def set_iter(self, slot, aux_grad_scale, distance_range_max, lowpass):
+        arr = (C.c_float * len(lowpass))(*[float(x) for x in lowpass])
+        self.check(self.lib.neddf_set_iter(self.h, slot, aux_grad_scale, distance_range_max, arr))
+
+    # ------------------------------------------------------------------ stages
+    def raygen(self, uv, cam):
+        require_device(uv, "uv")
+        if uv.dtype not in UV_TYPES:
+            uv = uv.to(torch.float32)
+        uv = uv.contiguous()
+        n = uv.shape[0]
+        rd = torch.empty(n, 3, device=uv.device, dtype=torch.float32)
+        ro = torch.empty_like(rd)
+        self.check(self.lib.neddf_raygen(self.h, _ptr(uv), UV_TYPES[uv.dtype], n, C.byref(cam), _ptr(rd), _ptr(ro),
+                                         self.stream()))
+        return rd, ro
+
+    def sample_coarse(self, U, near, far):
+        require_device(U, "U")
+        U = f32c(U)
+        out = torch.empty_like(U)
+        self.check(self.lib.neddf_sample_coarse(self.h, _ptr(U), U.shape[0], U.shape[1], near, far, _ptr(out), self.stream()))
+        return out
+
+    def sampling(self, ray_dir, ray_orig, dists, ray_radius):
+        require_device(dists, "dists")
+        ray_dir, ray_orig, dists = f32c(ray_dir), f32c(ray_orig), f32c(dists)
+        B, S = dists.shape
+        pos = torch.empty(B, S, 3, device=dists.device, dtype=torch.float32)
+        d = torch.empty_like(pos)
+        var = torch.empty_like(pos)
+        self.check(self.lib.neddf_sampling(self.h, _ptr(ray_dir), _ptr(ray_orig), _ptr(dists), B, S,
+                                           -1.0 if ray_radius is None else float(ray_radius), _ptr(pos), _ptr(d), _ptr(var),
+                                           self.stream()))
+        return pos, d, var
+
+    def field_forward(self, slot, pos, dir, var, out_mode, want):
+        """want: iterable of output names; returns dict of flat tensors."""
+        require_device(pos, "sample_pos")
+        pos, dir, var = f32c(pos), f32c(dir), f32c(var)
+        N = pos.numel() // 3
+        dev = pos.device
+        o = {k: (torch.empty(N * (3 if k == "color" else 1), device=dev, dtype=torch.float32) if k in want else None)
+             for k in ("distance", "density", "color", "fields_penalty", "aux_grad")}
+        self.check(self.lib.neddf_field_forward(self.h, slot, _ptr(pos), _ptr(dir), _ptr(var), N, out_mode,
+                                                _ptr(o["distance"]), _ptr(o["density"]), _ptr(o["color"]),
+                                                _ptr(o["fields_penalty"]), _ptr(o["aux_grad"]), self.stream()))
+        return {k: v for k, v in o.items() if v is not None}
+
+    def composite(self, dists, dens, col, max_dist):
+        require_device(dists, "dists")
+        dists, dens, col = f32c(dists), f32c(dens), f32c(col)
+        B, S = dists.shape
+        dev = dists.device
+        w = torch.empty(B, S - 1, device=dev, dtype=torch.float32)
+        depth = torch.empty(B, device=dev, dtype=torch.float32)
+        color = torch.empty(B, 3, device=dev, dtype=torch.float32)
+        trans = torch.empty(B, device=dev, dtype=torch.float32)
+        flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.check(self.lib.neddf_composite(self.h, _ptr(dists), _ptr(dens), _ptr(col), B, S, max_dist, _ptr(w), _ptr(depth),
+                                            _ptr(color), _ptr(trans), _ptr(flag), self.stream()))
+        return dict(weight=w, depth=depth, color=color, transmittance=trans), flag
+
+    def integrate_penalty(self, dists, pen):
+        dists, pen = f32c(dists), f32c(pen)
+        out = torch.empty(dists.shape[0], device=dists.device, dtype=torch.float32)
+        self.check(self.lib.neddf_integrate_penalty(self.h, _ptr(dists), _ptr(pen), dists.shape[0], dists.shape[1], _ptr(out),
+                                                    self.stream()))
+        return out
+
+    def importance_resample(self, dists, weights, U, cat_coarse=True, want_ids=False):
+        """weights (float32, contiguous, on device) is sanitised in place."""
+        require_device(dists, "dists")
+        dists, U = f32c(dists), f32c(U)
+        assert weights.dtype == torch.float32 and weights.is_contiguous()
+        B, n = dists.shape
+        nf = U.shape[1]
+        out = torch.empty(B, nf + n if cat_coarse else nf, device=dists.device, dtype=torch.float32)
+        ids = torch.empty(B, nf, device=dists.device, dtype=torch.int64) if want_ids else None
+        self.check(self.lib.neddf_importance_resample(self.h, _ptr(dists), _ptr(weights), _ptr(U), B, n, nf, int(cat_coarse),
+                                                      _ptr(out), _ptr(ids), self.stream()))
+        return (out, ids) if want_ids else out
+
+    def render_rays(self, uv, cam, params, U_coarse, U_fine, outputs, single_slot=None):
+        """outputs: dict name -> preallocated device tensor (subset of RenderOutputs fields)."""
+        require_device(uv, "uv")
+        if uv.dtype not in UV_TYPES:
+            uv = uv.to(torch.float32)
+        uv = uv.contiguous()
+        ro = RenderOutputs()
+        for k, t in outputs.items():
+            setattr(ro, k, t.data_ptr())
+        if single_slot is None:
+            self.check(self.lib.neddf_render_rays(self.h, _ptr(uv), UV_TYPES[uv.dtype], uv.shape[0], C.byref(cam),
+                                                  C.byref(params), _ptr(U_coarse), _ptr(U_fine), C.byref(ro), self.stream()))
+        else:
+            self.check(self.lib.neddf_render_rays_single(self.h, single_slot, _ptr(uv), UV_TYPES[uv.dtype], uv.shape[0],
+                                                         C.byref(cam), C.byref(params), U_coarse.shape[1], _ptr(U_coarse),
+                                                         C.byref(ro), self.stream()))
+
+    def set_timing(self, on):
+        self.check(self.lib.neddf_set_timing(self.h, int(on)))
+
+    def get_timings(self):
+        """{'ddf_ms','col_ms','nerf_ms','ddf_launches','col_launches','nerf_launches'} since the last call."""
+        arr = (C.c_float * 6)()
+        self.check(self.lib.neddf_get_timings(self.h, arr, 6))
+        return dict(ddf_ms=arr[0], col_ms=arr[1], nerf_ms=arr[2], ddf_launches=int(arr[3]), col_launches=int(arr[4]),
+                    nerf_launches=int(arr[5]))

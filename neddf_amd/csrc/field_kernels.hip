@@ -1,0 +1,621 @@
+// field_kernels.hip -- the coordinate-MLP hot path (99.8 % of render time in the
+// reference) as hand-written gfx950 kernels.
+//
+// Tile engine.  A workgroup of 4 waves (one per SIMD) owns a tile of MT*32
+// activation ROWS that stay in LDS for the whole network; every dense layer is
+//     acc[rows, 256] (+)= act[rows, K] x W[K, 256]
+// on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak = the number the roofline
+// is priced against).  Wave w owns output columns [64w, 64w+64) for all rows:
+//   * A operand  = activations, ds_read_b128 from LDS (row stride 260 floats ->
+//     conflict-free for the 32x32x2 A fragment: lane = row, 4 consecutive k);
+//   * B operand  = weights, read ONCE per workgroup straight from global/L2
+//     into registers, pre-packed on the host in fragment order so that each
+//     lane issues one global_load_dwordx4 per four MFMA k-steps (1 KiB/wave,
+//     fully coalesced); no LDS staging, no inter-wave traffic for weights;
+//   * the k order inside a super-step of 8 is permuted (lane-half h reads
+//     k = 8S+4h..8S+4h+3) -- legal because A and B use the same permutation.
+// For the NeDDF distance trunk the 4 rows of a sample point (value, d/dx,
+// d/dy, d/dz -- the forward-mode Jacobian the density is defined from) are
+// 4 CONSECUTIVE rows, so in the 32x32 accumulator layout
+//     row = 8*(reg>>2) + 4*(lane>>5) + (reg&3),  col = lane&31
+// one lane holds all four rows of a point for one feature in acc[4g..4g+3]:
+// the activation + JVP epilogue (y = a(x), G = a'(x)*J) is register-local, one
+// transcendental evaluation per four accumulators.
+// Skip-connection inputs (positional encoding concatenated in front of the
+// hidden state) never exist as a concatenated tensor: their partial product is
+// computed at tile start, while the encoding sits in LDS, and parked in a
+// per-workgroup global scratch in accumulator layout ("stash").
+#include "kernels.h"
+
+namespace neddf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int MT_DDF = 4;   // 128 rows = 32 points x (value + 3 Jacobian rows)
+constexpr int MT_COL = 4;   // 128 rows = 128 points (value only) or 32 points (full mode)
+
+// ----------------------------------------------------------------------------
+// activations (with_grad/{relu,leaky_relu,tanh_exp}.py forward halves)
+template <int KIND>
+__device__ __forceinline__ void act_grad(float x, float &y, float &dy)
+{
+    if (KIND == 0) {            // relu.py:36-38, mask = x >= 0
+        float m = (x >= 0.f) ? 1.f : 0.f;
+        y = x * m; dy = m;
+    } else if (KIND == 1) {     // leaky_relu.py:36-39
+        float s = (x < 0.f) ? 0.01f : 1.f;
+        y = x * s; dy = s;
+    } else {                    // tanh_exp.py:38-46
+        float ex = expf(x);
+        float tx = tanhf(ex);
+        float yy = x * tx;
+        float dd = tx - x * ex * (tx * tx - 1.0f);
+        bool big = x > 20.0f;
+        y = big ? x : yy;
+        dy = big ? 1.0f : dd;
+    }
+}
+
+template <int KIND>
+__device__ __forceinline__ float act_val(float x)
+{
+    if (KIND == 0) return x > 0.f ? x : 0.f;            // F.relu
+    if (KIND == 1) return x > 0.f ? x : 0.01f * x;       // F.leaky_relu
+    float t = x * tanhf(expf(x));                        // nn_module/tanh_exp.py:28-31
+    return x > 20.0f ? x : t;
+}
+
+__device__ __forceinline__ float act_val_rt(int kind, float x)
+{
+    if (kind == 0) return act_val<0>(x);
+    if (kind == 1) return act_val<1>(x);
+    return act_val<2>(x);
+}
+
+// ----------------------------------------------------------------------------
+// dense: acc[mt][t] += act[rows, k0 .. k0+8*ksteps) x Wpacked
+template <int MT, int NT>
+__device__ __forceinline__ void dense_load(f32x4v (&a)[MT], f32x4v (&b)[NT], const float *act_lane, const f32x4v *wl, int ksteps, int S)
+{
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[t] = wl[((size_t)t * ksteps + S) * 64];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4v *)(act_lane + mt * 32 * kActLd + 8 * S);
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void dense_mfma(f32x16 (&acc)[MT][NT], const f32x4v (&a)[MT], const f32x4v (&b)[NT])
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][r], b[t][r], acc[mt][t], 0, 0, 0);
+}
+
+// Software pipeline, ping-pong operand registers: the operands of super-step
+// S+1 are requested (global -> VGPR for B, LDS -> VGPR for A) before the 32
+// MFMAs (2048 cycles) of super-step S issue.
+template <int MT, int NT>
+__device__ __forceinline__ void dense(f32x16 (&acc)[MT][NT], const float *act_lane, const f32x4v *wl, int ksteps)
+{
+    f32x4v a0[MT], b0[NT], a1[MT], b1[NT];
+    dense_load<MT, NT>(a0, b0, act_lane, wl, ksteps, 0);
+    for (int S = 0; S < ksteps; S += 2) {
+        const bool more = S + 1 < ksteps;
+        dense_load<MT, NT>(a1, b1, act_lane, wl, ksteps, more ? S + 1 : S);
+        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
+        dense_mfma<MT, NT>(acc, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            dense_load<MT, NT>(a0, b0, act_lane, wl, ksteps, S + 2 < ksteps ? S + 2 : S);
+            __builtin_amdgcn_sched_barrier(0);
+            dense_mfma<MT, NT>(acc, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int MT, int NT, bool ROWS4>
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[MT][NT], const float *bias, int wave, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float bv = bias ? bias[(wave * NT + t) * 32 + (lane & 31)] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mt][t][q] = (ROWS4 && (q & 3)) ? 0.f : bv;   // bias only on value rows (linear.py:43-45)
+    }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void stash_store(const f32x16 (&acc)[MT][NT], float *slot, int wave, int lane)
+{
+    f32x4v *dst = (f32x4v *)slot + (size_t)wave * (MT * NT * 4) * 64 + lane;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4v v = { acc[mt][t][4 * g], acc[mt][t][4 * g + 1], acc[mt][t][4 * g + 2], acc[mt][t][4 * g + 3] };
+                dst[((mt * NT + t) * 4 + g) * 64] = v;
+            }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void stash_add(f32x16 (&acc)[MT][NT], const float *slot, int wave, int lane)
+{
+    const f32x4v *src = (const f32x4v *)slot + (size_t)wave * (MT * NT * 4) * 64 + lane;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4v v = src[((mt * NT + t) * 4 + g) * 64];
+                acc[mt][t][4 * g] += v[0]; acc[mt][t][4 * g + 1] += v[1];
+                acc[mt][t][4 * g + 2] += v[2]; acc[mt][t][4 * g + 3] += v[3];
+            }
+}
+
+// activation epilogue: registers -> LDS activations (columns [0, NT*128))
+template <int MT, int NT, bool ROWS4, int KIND>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[MT][NT], float *act, int wave, int lane)
+{
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float *o = act + (mt * 32 + 4 * h) * kActLd + (wave * NT + t) * 32 + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (ROWS4) {
+                    float y, dy;
+                    act_grad<KIND>(acc[mt][t][4 * g], y, dy);
+                    o[(8 * g + 0) * kActLd] = y;
+                    o[(8 * g + 1) * kActLd] = dy * acc[mt][t][4 * g + 1];
+                    o[(8 * g + 2) * kActLd] = dy * acc[mt][t][4 * g + 2];
+                    o[(8 * g + 3) * kActLd] = dy * acc[mt][t][4 * g + 3];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[(8 * g + r) * kActLd] = act_val<KIND>(acc[mt][t][4 * g + r]);
+                }
+            }
+        }
+}
+
+template <int MT, int NT, bool ROWS4>
+__device__ __forceinline__ void epilogue_rt(const f32x16 (&acc)[MT][NT], float *act, int kind, int wave, int lane)
+{
+    if (kind == 0) epilogue<MT, NT, ROWS4, 0>(acc, act, wave, lane);
+    else if (kind == 1) epilogue<MT, NT, ROWS4, 1>(acc, act, wave, lane);
+    else epilogue<MT, NT, ROWS4, 2>(acc, act, wave, lane);
+}
+
+// ----------------------------------------------------------------------------
+// input encodings
+__device__ __forceinline__ void zero_cols(float *act, int rows, int ncols, int tid)
+{
+    for (int i = tid; i < rows * ncols; i += kThreads) {
+        int r = i / ncols, c = i - r * ncols;
+        act[r * kActLd + c] = 0.f;
+    }
+}
+
+// Integrated positional encoding of the sample position into act columns
+// [col0, col0+2*KH) as [sin half | cos half] (sampling.py:55-71 weights,
+// with_grad/positional_encoding.py:55-87 values + Jacobian for J_in = I3).
+// Region must be pre-zeroed.  GRADSCALE selects embed_pos_scaled (neddf.py:200-204).
+template <bool ROWS4, bool GRADSCALE>
+__device__ __forceinline__ void encode_pos(float *act, int col0, const EncodeDesc &enc, const float *lp, const float *pos,
+                                           const float *var, int64_t p0, int64_t N, int P, int tid)
+{
+    const int K3 = 3 * enc.E, KH = enc.KH;
+    for (int item = tid; item < P * K3; item += kThreads) {
+        int p = item / K3, q = item - p * K3;
+        int e = q / 3, d = q - 3 * e;
+        int64_t gp = p0 + p < N ? p0 + p : N - 1;
+        float f = (float)(1 << e);
+        float x = pos[gp * 3 + d], v = var[gp * 3 + d];
+        float w = expf(-0.5f * (f * f) * v);
+        float s = GRADSCALE ? ((1.0f / (0.5f * f)) * lp[e]) * w : lp[e] * w;
+        float sn, cs;
+        sincosf(f * x, &sn, &cs);
+        if (ROWS4) {
+            float *r0 = act + (4 * p) * kActLd + col0 + q;
+            r0[0] = s * sn;
+            r0[KH] = s * cs;
+            float g = f * s;
+            r0[(1 + d) * kActLd] = g * cs;
+            r0[(1 + d) * kActLd + KH] = -g * sn;
+        } else {
+            float *r0 = act + p * kActLd + col0 + q;
+            r0[0] = s * sn;
+            r0[KH] = s * cs;
+        }
+    }
+}
+
+// PositionalEncoding of the view direction (positional_encoding.py:51-65), value rows only.
+template <bool ROWS4>
+__device__ __forceinline__ void encode_dir(float *act, int col0, const EncodeDesc &enc, const float *dir, int64_t p0,
+                                           int64_t N, int P, int tid)
+{
+    const int K3 = 3 * enc.Ed, KD = enc.KD;
+    for (int item = tid; item < P * K3; item += kThreads) {
+        int p = item / K3, q = item - p * K3;
+        int e = q / 3, d = q - 3 * e;
+        int64_t gp = p0 + p < N ? p0 + p : N - 1;
+        float sn, cs;
+        sincosf((float)(1 << e) * dir[gp * 3 + d], &sn, &cs);
+        float *r0 = act + (ROWS4 ? 4 * p : p) * kActLd + col0 + q;
+        r0[0] = sn;
+        r0[KD] = cs;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// NeDDF distance trunk
+__global__ __launch_bounds__(kThreads, 1) void ddf_trunk_kernel(const DdfArgs a)
+{
+    constexpr int MT = MT_DDF, NT = 2, ROWS = MT * 32, P = MT * 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *act = smem;
+    float *hd = smem + ROWS * kActLd;       // [2][ROWS] head dot products
+    float *lp = hd + 2 * ROWS;              // [16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *act_lane = act + (lane & 31) * kActLd + 4 * (lane >> 5);
+    float *scratch = a.scratch + (size_t)blockIdx.x * kStashFloatsPerWg * kMaxStash;
+    if (tid == 0) {
+#pragma unroll
+        for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
+    }
+    const int kin = 2 * a.enc.KH;
+    const int64_t ntiles = (a.n_points + P - 1) / P;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t p0 = tile * P;
+        zero_cols(act, ROWS, kin, tid);
+        __syncthreads();
+        encode_pos<true, true>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
+        __syncthreads();
+
+        f32x16 acc[MT][NT];
+        for (int s = 0; s < a.n_stash; ++s) {       // early partials of skip layers (neddf.py:217-219)
+            acc_init<MT, NT, true>(acc, nullptr, wave, lane);
+            const f32x4v *wl = (const f32x4v *)a.stash[s].wp + (size_t)wave * NT * a.stash[s].ksteps * 64 + lane;
+            dense<MT, NT>(acc, act_lane + a.stash[s].col0, wl, a.stash[s].ksteps);
+            stash_store<MT, NT>(acc, scratch + (size_t)s * kStashFloatsPerWg, wave, lane);
+        }
+        for (int l = 0; l < a.n_layers; ++l) {      // neddf.py:214-216
+            const LayerW &L = a.layer[l];
+            acc_init<MT, NT, true>(acc, L.bias, wave, lane);
+            if (L.stash >= 0) stash_add<MT, NT>(acc, scratch + (size_t)L.stash * kStashFloatsPerWg, wave, lane);
+            const f32x4v *wl = (const f32x4v *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane;
+            dense<MT, NT>(acc, act_lane, wl, L.ksteps);
+            __syncthreads();                        // every wave finished reading the previous activations
+            epilogue_rt<MT, NT, true>(acc, act, a.activation, wave, lane);
+            __syncthreads();
+        }
+        // heads (neddf.py:220-230): ddf_out on all four rows, aux_out likewise (rows 1..3 feed aux_gg)
+        for (int idx = tid; idx < 2 * ROWS; idx += kThreads) {
+            int head = idx / ROWS, row = idx - head * ROWS;
+            const f32x4v *w = (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out);
+            const f32x4v *ar = (const f32x4v *)(act + row * kActLd);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < kWidth / 4; ++k) {
+                f32x4v x = ar[k], ww = w[k];
+                s0 = fmaf(x[0], ww[0], s0); s1 = fmaf(x[1], ww[1], s1);
+                s2 = fmaf(x[2], ww[2], s2); s3 = fmaf(x[3], ww[3], s3);
+            }
+            hd[idx] = (s0 + s1) + (s2 + s3);
+        }
+        __syncthreads();
+        if (tid < P && p0 + tid < a.n_points) {
+            const int64_t gp = p0 + tid;
+            float z = hd[4 * tid] + a.b_ddf_out;
+            float az = hd[ROWS + 4 * tid] + a.b_aux_out;
+            // SoftplusGradFunction softplus.py:38-49 (log(1.0 + exp(x)), threshold 20)
+            bool big = z > 20.0f;
+            float sp = big ? z : logf(1.0f + expf(z));
+            float dsp = big ? 1.0f : 1.0f / (1.0f + expf(-z));
+            float D = sp + a.d_near;
+            float dg0 = dsp * hd[4 * tid + 1], dg1 = dsp * hd[4 * tid + 2], dg2 = dsp * hd[4 * tid + 3];
+            // SigmoidGradFunction sigmoid.py:38-43
+            float t = (1.0f + tanhf(1.0f * az * 0.5f)) * 0.5f;
+            float dsg = 1.0f * t * (1 - t);
+            float aux = a.aux_grad_scale * t;
+            float q2 = dg0 * dg0 + dg1 * dg1 + dg2 * dg2;
+            float dgn = sqrtf(q2);
+            float dDdt = sqrtf(q2 + aux * aux);              // neddf.py:234-238
+            float Dinv = 1.0f / D;
+            float rho = act_val_rt(a.density_activation, Dinv * (1 - dDdt));   // :239-240
+            float ninv = 1.0f / (dgn + 1e-7f);               // :241
+            float *pa = a.ptaux + gp * kPtAux;
+            f32x4v v0 = { D, rho, aux, ninv * dg0 };
+            f32x4v v1 = { ninv * dg1, ninv * dg2, z, az };
+            f32x4v v2 = { dg0, dg1, dg2, a.aux_grad_scale * (dsg * hd[ROWS + 4 * tid + 1]) };
+            f32x4v v3 = { a.aux_grad_scale * (dsg * hd[ROWS + 4 * tid + 2]),
+                          a.aux_grad_scale * (dsg * hd[ROWS + 4 * tid + 3]), dgn, dDdt };
+            ((f32x4v *)pa)[0] = v0; ((f32x4v *)pa)[1] = v1; ((f32x4v *)pa)[2] = v2; ((f32x4v *)pa)[3] = v3;
+            if (a.distance) a.distance[gp] = D;
+            if (a.density) a.density[gp] = rho;
+            if (a.aux_grad) a.aux_grad[gp] = aux;
+        }
+        // hand the trunk features to the colour kernel (value row, or all four rows in full mode)
+        {
+            const int fr = a.feat_rows;
+            for (int idx = tid; idx < P * fr * 64; idx += kThreads) {
+                int r = idx >> 6, c4 = idx & 63;
+                int p = r / fr, rr = r - p * fr;
+                if (p0 + p < a.n_points) {
+                    f32x4v v = *(const f32x4v *)(act + (4 * p + rr) * kActLd + 4 * c4);
+                    *(f32x4v *)(a.features + ((size_t)(p0 + p) * fr + rr) * kWidth + 4 * c4) = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------
+// NeDDF colour trunk.  ROWS4 = false: eval-minimal, one row per point (the
+// colour Jacobian is dead code in eval); ROWS4 = true:
+// full mode with Jacobian rows + field penalties (neddf.py:244-300).
+template <bool ROWS4>
+__global__ __launch_bounds__(kThreads, 1) void col_trunk_kernel(const ColArgs a)
+{
+    constexpr int MT = MT_COL, NT = 2, ROWS = MT * 32, P = ROWS4 ? MT * 8 : ROWS, RPP = ROWS4 ? 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *act = smem;
+    float *hd = smem + ROWS * kActLd;       // [2][ROWS][3] partial colour dots
+    float *lp = hd + 2 * ROWS * 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *act_lane = act + (lane & 31) * kActLd + 4 * (lane >> 5);
+    if (tid == 0) {
+#pragma unroll
+        for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
+    }
+    const int ka = 8 * a.ksteps_a;
+    const int c_dir = 2 * a.enc.KH, c_n = c_dir + 2 * a.enc.KD;
+    const int64_t ntiles = (a.n_points + P - 1) / P;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t p0 = tile * P;
+        // layer 0, small-input segment: [embed_pos | embed_dir | norm_dir] (neddf.py:243)
+        zero_cols(act, ROWS, ka, tid);
+        __syncthreads();
+        encode_pos<ROWS4, false>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
+        encode_dir<ROWS4>(act, c_dir, a.enc, a.dir, p0, a.n_points, P, tid);
+        for (int i = tid; i < P * 3; i += kThreads) {
+            int p = i / 3, d = i - 3 * p;
+            int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
+            act[(RPP * p) * kActLd + c_n + d] = a.ptaux[gp * kPtAux + PA_N0 + d];
+        }
+        __syncthreads();
+        f32x16 acc[MT][NT];
+        acc_init<MT, NT, ROWS4>(acc, a.layer[0].bias, wave, lane);
+        dense<MT, NT>(acc, act_lane, (const f32x4v *)a.wp_a + (size_t)wave * NT * a.ksteps_a * 64 + lane, a.ksteps_a);
+        __syncthreads();
+        // layer 0, feature segment: trunk features from the distance kernel
+        for (int idx = tid; idx < ROWS * 64; idx += kThreads) {
+            int r = idx >> 6, c4 = idx & 63;
+            int64_t grow = p0 * RPP + r;
+            int64_t last = a.n_points * RPP - 1;
+            if (grow > last) grow = last;
+            int64_t src = ROWS4 ? grow : grow * a.feat_rows;      // value row of [n][feat_rows][256]
+            *(f32x4v *)(act + r * kActLd + 4 * c4) = *(const f32x4v *)(a.features + (size_t)src * kWidth + 4 * c4);
+        }
+        __syncthreads();
+        for (int l = 0; l < a.n_layers; ++l) {                     // neddf.py:254-256
+            const LayerW &L = a.layer[l];
+            if (l > 0) acc_init<MT, NT, ROWS4>(acc, L.bias, wave, lane);
+            dense<MT, NT>(acc, act_lane, (const f32x4v *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane, L.ksteps);
+            __syncthreads();
+            epilogue_rt<MT, NT, ROWS4>(acc, act, a.activation, wave, lane);
+            __syncthreads();
+        }
+        // layer_col_out 256 -> 3 (neddf.py:257), no output activation; two k-halves per row
+        for (int idx = tid; idx < 2 * ROWS; idx += kThreads) {
+            int half = idx / ROWS, row = idx - half * ROWS;
+            const f32x4v *ar = (const f32x4v *)(act + row * kActLd + half * 128);
+            const float *w = a.w_out + half * 128 * 3;
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < 32; ++k) {
+                f32x4v x = ar[k];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    c0 = fmaf(x[u], w[(4 * k + u) * 3 + 0], c0);
+                    c1 = fmaf(x[u], w[(4 * k + u) * 3 + 1], c1);
+                    c2 = fmaf(x[u], w[(4 * k + u) * 3 + 2], c2);
+                }
+            }
+            hd[idx * 3 + 0] = c0; hd[idx * 3 + 1] = c1; hd[idx * 3 + 2] = c2;
+        }
+        __syncthreads();
+        if (tid < P && p0 + tid < a.n_points) {
+            const int64_t gp = p0 + tid;
+            float c[RPP][3];
+#pragma unroll
+            for (int r = 0; r < RPP; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    c[r][k] = hd[(RPP * tid + r) * 3 + k] + hd[(ROWS + RPP * tid + r) * 3 + k] + (r == 0 ? a.b_out[k] : 0.f);
+            a.color[gp * 3 + 0] = c[0][0]; a.color[gp * 3 + 1] = c[0][1]; a.color[gp * 3 + 2] = c[0][2];
+            if (ROWS4 && a.penalty) {                          // neddf.py:260-300
+                const float *pa = a.ptaux + gp * kPtAux;
+                float D = pa[PA_D], aux = pa[PA_AUX], dgn = pa[PA_DGN], dDdt = pa[PA_DDDT];
+                float z = pa[PA_DDF_RAW], az = pa[PA_AUX_RAW];
+                float Dinv = 1.0f / D;
+                float pen[6];
+                float d2 = pa[PA_AGG0] * pa[PA_N0] + pa[PA_AGG1] * pa[PA_N1] + pa[PA_AGG2] * pa[PA_N2];
+                float rest = 3 * aux * Dinv;
+                float sc = aux * dgn * D;
+                pen[0] = sc * ((d2 - rest) * (d2 - rest));
+                float t1 = fmaxf(-1.0f + dDdt, 0.f);
+                pen[1] = t1 * t1;
+                float a1 = fmaxf(-4.6f - z, 0.f), a2 = fmaxf(-a.distance_range_max + z, 0.f);
+                pen[2] = (a1 + a2) * (a1 + a2);
+                float b1 = fmaxf(-4.6f - az, 0.f), b2 = fmaxf(-4.6f + az, 0.f);
+                pen[3] = (b1 + b2) * (b1 + b2);
+                pen[4] = 0.f; pen[5] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float c1 = fmaxf(-0.0f - c[0][k], 0.f), c2 = fmaxf(-1.0f + c[0][k], 0.f);
+                    pen[4] += (c1 + c2) * (c1 + c2);
+                    float s = c[RPP > 1 ? 1 : 0][k] * pa[PA_DG0] + c[RPP > 2 ? 2 : 0][k] * pa[PA_DG1] + c[RPP > 3 ? 3 : 0][k] * pa[PA_DG2];
+                    pen[5] += s * s;
+                }
+                float tot = 0.f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) tot += a.penalty_has[k] ? pen[k] * a.penalty_weight[k] : pen[k];
+                a.penalty[gp] = tot;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------
+// plain NeRF field (nerf.py:139-165): value rows only, 128 points per tile
+__global__ __launch_bounds__(kThreads, 1) void nerf_kernel(const NerfArgs a)
+{
+    constexpr int MT = MT_COL, NT = 2, ROWS = MT * 32, P = ROWS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *act = smem;
+    float *hd = smem + ROWS * kActLd;       // [2][ROWS][3]
+    float *lp = hd + 2 * ROWS * 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *act_lane = act + (lane & 31) * kActLd + 4 * (lane >> 5);
+    float *scratch = a.scratch + (size_t)blockIdx.x * kStashFloatsPerWg * kMaxStash;
+    if (tid == 0) {
+#pragma unroll
+        for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
+    }
+    const int c_dir = 2 * a.enc.KH;
+    const int kin = c_dir + ((2 * a.enc.KD + 7) & ~7);
+    const int64_t ntiles = (a.n_points + P - 1) / P;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t p0 = tile * P;
+        zero_cols(act, ROWS, kin, tid);
+        __syncthreads();
+        encode_pos<false, false>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
+        encode_dir<false>(act, c_dir, a.enc, a.dir, p0, a.n_points, P, tid);
+        __syncthreads();
+        f32x16 acc[MT][NT];
+        for (int s = 0; s < a.n_stash; ++s) {
+            const f32x4v *wl = (const f32x4v *)a.stash[s].wp;
+            float *slot = scratch + (size_t)s * kStashFloatsPerWg;
+            if (s == a.col_stash) {         // colour head's view-direction segment: 128 outputs, NT = 1
+                f32x16 acc1[MT][1];
+                acc_init<MT, 1, false>(acc1, nullptr, wave, lane);
+                dense<MT, 1>(acc1, act_lane + a.stash[s].col0, wl + (size_t)wave * a.stash[s].ksteps * 64 + lane, a.stash[s].ksteps);
+                stash_store<MT, 1>(acc1, slot, wave, lane);
+            } else {                        // skip layers: cat([hx, embed_pos]) (nerf.py:154-155)
+                acc_init<MT, NT, false>(acc, nullptr, wave, lane);
+                dense<MT, NT>(acc, act_lane + a.stash[s].col0, wl + (size_t)wave * NT * a.stash[s].ksteps * 64 + lane, a.stash[s].ksteps);
+                stash_store<MT, NT>(acc, slot, wave, lane);
+            }
+        }
+        for (int l = 0; l < a.n_layers; ++l) {
+            const LayerW &L = a.layer[l];
+            acc_init<MT, NT, false>(acc, L.bias, wave, lane);
+            if (L.stash >= 0) stash_add<MT, NT>(acc, scratch + (size_t)L.stash * kStashFloatsPerWg, wave, lane);
+            dense<MT, NT>(acc, act_lane, (const f32x4v *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane, L.ksteps);
+            __syncthreads();
+            epilogue_rt<MT, NT, false>(acc, act, a.activation, wave, lane);
+            __syncthreads();
+        }
+        // density head (nerf.py:156)
+        if (tid < ROWS) {
+            const f32x4v *ar = (const f32x4v *)(act + tid * kActLd);
+            const f32x4v *w = (const f32x4v *)a.w_density;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < kWidth / 4; ++k) {
+                f32x4v x = ar[k], ww = w[k];
+                s0 = fmaf(x[0], ww[0], s0); s1 = fmaf(x[1], ww[1], s1);
+                s2 = fmaf(x[2], ww[2], s2); s3 = fmaf(x[3], ww[3], s3);
+            }
+            if (p0 + tid < a.n_points)
+                a.density[p0 + tid] = act_val_rt(a.density_activation, (s0 + s1) + (s2 + s3) + a.b_density);
+        }
+        // colour head: Linear(256+dir, 128) -> ReLU -> Linear(128, 3) (nerf.py:99-103,158-159)
+        {
+            f32x16 acc1[MT][1];
+            acc_init<MT, 1, false>(acc1, a.col0.bias, wave, lane);
+            stash_add<MT, 1>(acc1, scratch + (size_t)a.col_stash * kStashFloatsPerWg, wave, lane);
+            dense<MT, 1>(acc1, act_lane, (const f32x4v *)a.col0.wp + (size_t)wave * a.col0.ksteps * 64 + lane, a.col0.ksteps);
+            __syncthreads();
+            epilogue<MT, 1, false, 0>(acc1, act, wave, lane);
+            __syncthreads();
+        }
+        for (int idx = tid; idx < 2 * ROWS; idx += kThreads) {
+            int half = idx / ROWS, row = idx - half * ROWS;
+            const f32x4v *ar = (const f32x4v *)(act + row * kActLd + half * 64);
+            float c[3] = { 0.f, 0.f, 0.f };
+#pragma unroll 4
+            for (int k = 0; k < 16; ++k) {
+                f32x4v x = ar[k];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) c[o] = fmaf(x[u], a.w_col1[o * 128 + half * 64 + 4 * k + u], c[o]);
+            }
+            hd[idx * 3 + 0] = c[0]; hd[idx * 3 + 1] = c[1]; hd[idx * 3 + 2] = c[2];
+        }
+        __syncthreads();
+        if (tid < P && p0 + tid < a.n_points)
+            for (int k = 0; k < 3; ++k)
+                a.color[(p0 + tid) * 3 + k] = hd[tid * 3 + k] + hd[(ROWS + tid) * 3 + k] + a.b_col1[k];
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------
+size_t field_lds_bytes(int mt) { return (size_t)(mt * 32 * kActLd + 2 * mt * 32 * 3 + 16) * sizeof(float); }
+int ddf_points_per_tile() { return MT_DDF * 8; }
+int col_points_per_tile(bool rows4) { return rows4 ? MT_COL * 8 : MT_COL * 32; }
+int nerf_points_per_tile() { return MT_COL * 32; }
+
+static void set_lds(const void *fn, size_t bytes)
+{
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
+{
+    size_t lds = field_lds_bytes(MT_DDF);
+    static bool once = (set_lds((const void *)ddf_trunk_kernel, field_lds_bytes(MT_DDF)), true);
+    (void)once;
+    hipLaunchKernelGGL(ddf_trunk_kernel, dim3(grid), dim3(kThreads), lds, s, a);
+}
+
+void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)
+{
+    size_t lds = field_lds_bytes(MT_COL);
+    static bool once = (set_lds((const void *)col_trunk_kernel<false>, field_lds_bytes(MT_COL)),
+                        set_lds((const void *)col_trunk_kernel<true>, field_lds_bytes(MT_COL)), true);
+    (void)once;
+    if (rows4) hipLaunchKernelGGL(col_trunk_kernel<true>, dim3(grid), dim3(kThreads), lds, s, a);
+    else hipLaunchKernelGGL(col_trunk_kernel<false>, dim3(grid), dim3(kThreads), lds, s, a);
+}
+
+void launch_nerf(const NerfArgs &a, int grid, hipStream_t s)
+{
+    size_t lds = field_lds_bytes(MT_COL);
+    static bool once = (set_lds((const void *)nerf_kernel, field_lds_bytes(MT_COL)), true);
+    (void)once;
+    hipLaunchKernelGGL(nerf_kernel, dim3(grid), dim3(kThreads), lds, s, a);
+}
+
+}  // namespace neddf

@@ -1,0 +1,131 @@
+// kernels.h -- argument blocks shared by the HIP kernels and the C-ABI host code.
+// gfx950 only (wave64, f32 MFMA 32x32x2); no portability layer on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace neddf {
+
+constexpr int kWaves = 4;            // waves per workgroup (one per SIMD)
+constexpr int kThreads = 64 * kWaves;
+constexpr int kActLd = 260;          // LDS row stride (floats): 256 + 4 -> conflict-free ds_read_b128 of MFMA A fragments
+constexpr int kWidth = 256;          // hidden width handled by the tile engine
+constexpr int kMaxLayers = 12;
+constexpr int kMaxStash = 2;
+constexpr int kPtAux = 16;           // floats per point handed from the distance kernel to the colour kernel
+// floats of one stash slot of one workgroup: 4 waves x (MT=4 x NT=2 x 4 float4) x 64 lanes x 4
+constexpr size_t kStashFloatsPerWg = (size_t)kWaves * (4 * 2 * 4) * 64 * 4;
+
+// per-point record written by the distance-trunk kernel (float index)
+enum { PA_D = 0, PA_RHO = 1, PA_AUX = 2, PA_N0 = 3, PA_N1 = 4, PA_N2 = 5, PA_DDF_RAW = 6, PA_AUX_RAW = 7,
+       PA_DG0 = 8, PA_DG1 = 9, PA_DG2 = 10, PA_AGG0 = 11, PA_AGG1 = 12, PA_AGG2 = 13, PA_DGN = 14, PA_DDDT = 15 };
+
+// One dense layer in "fragment-major" packing (see pack_layer() in neddf_capi.hip):
+//   wp[(((wave*NT + t)*ksteps + S)*64 + lane)*4 + r] = W[k = 8S + 4*(lane>>5) + r][n = (wave*NT + t)*32 + (lane&31)]
+// so that one global_load_dwordx4 per lane yields the B operands of four
+// v_mfma_f32_32x32x2_f32 k-steps, and a wave's load is 1 KiB contiguous.
+struct LayerW {
+    const float *wp;       // packed weights of the act-segment (K = 8*ksteps)
+    const float *bias;     // [nout]
+    int ksteps;            // super-steps of 8 k's
+    int stash;             // -1, or index of the early partial (input-feature segment of a skip layer) to add
+};
+
+struct StashW {
+    const float *wp;       // packed weights of the input-feature segment
+    int col0;              // first act column of the segment (multiple of 8)
+    int ksteps;
+};
+
+struct EncodeDesc {
+    int E, Ed;             // embed_pos_rank, embed_dir_rank
+    int KH, KD;            // padded half-widths: roundup(3E,4), roundup(3Ed,4)
+    float lowpass[10];     // get_lowpass_scale per frequency
+};
+
+// Distance trunk of NeDDF (neddf.py:193-241): PE -> n_layers x (LinearGrad + activation) with
+// (value, d/dx, d/dy, d/dz) rows -> distance / aux-gradient heads -> density, normal.
+struct DdfArgs {
+    const float *pos, *dir, *var;
+    int64_t n_points;
+    EncodeDesc enc;
+    int n_layers;
+    int activation, density_activation;
+    LayerW layer[kMaxLayers];
+    int n_stash;
+    StashW stash[kMaxStash];
+    const float *w_ddf_out, *w_aux_out;   // [256] each
+    float b_ddf_out, b_aux_out;
+    float d_near, aux_grad_scale;
+    float *scratch;                       // per-workgroup stash area
+    float *features;                      // [n_points][feat_rows][256]
+    int feat_rows;                        // 1 (value row) or 4 (value + Jacobian rows)
+    float *ptaux;                         // [n_points][kPtAux]
+    float *distance, *density, *aux_grad; // optional outputs [n_points]
+};
+
+// Colour trunk of NeDDF (neddf.py:243-300).
+struct ColArgs {
+    const float *pos, *dir, *var;
+    int64_t n_points;
+    EncodeDesc enc;
+    int n_layers;                         // hidden layers (col_layer_count - 1)
+    int activation;
+    int ksteps_a;                         // super-steps of layer 0's small-input segment [pe_pos | pe_dir | normal]
+    const float *wp_a;                    // its packed weights
+    LayerW layer[kMaxLayers];             // layer[0] = feature segment of layer 0
+    const float *w_out;                   // [256][3] row-major (layer_col_out.weight)
+    float b_out[3];
+    const float *features;                // from DdfArgs
+    int feat_rows;
+    const float *ptaux;
+    float *color;                         // [n_points][3]
+    float *penalty;                       // [n_points] (full mode) or NULL
+    float distance_range_max;
+    float penalty_weight[6];
+    int penalty_has[6];
+};
+
+// Plain NeRF field (nerf.py:107-165), value rows only.
+struct NerfArgs {
+    const float *pos, *dir, *var;
+    int64_t n_points;
+    EncodeDesc enc;
+    int n_layers;
+    int activation, density_activation;
+    LayerW layer[kMaxLayers];
+    int n_stash;
+    StashW stash[kMaxStash];              // [0..] skip partials, last = colour-head dir partial
+    int col_stash;                        // stash index of the colour head's dir segment
+    const float *w_density;               // [256]
+    float b_density;
+    LayerW col0;                          // outL_color.0: 256(+dir) -> 128
+    const float *w_col1;                  // [3][128] (nn.Linear layout)
+    float b_col1[3];
+    float *scratch;
+    float *density, *color;
+};
+
+struct CameraArg {
+    float R[9], T[3], calib[4];
+};
+
+size_t field_lds_bytes(int mt);
+void launch_ddf(const DdfArgs &a, int grid, hipStream_t s);
+void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s);
+void launch_nerf(const NerfArgs &a, int grid, hipStream_t s);
+int ddf_points_per_tile();
+int col_points_per_tile(bool rows4);
+int nerf_points_per_tile();
+
+void launch_raygen(const void *uv, int uv_type, int64_t n, const CameraArg &cam, float *dir, float *orig, hipStream_t s);
+void launch_sample_coarse(const float *U, int64_t n, int S1, float near_, float far_, float *dists, hipStream_t s);
+void launch_sampling(const float *rd, const float *ro, const float *dists, int64_t n, int S, double radius,
+                     float *pos, float *dir, float *var, hipStream_t s);
+void launch_composite(const float *dists, const float *dens, const float *col, int64_t n, int S, float max_dist,
+                      float *w, float *depth, float *color, float *trans, int *nan_flag, hipStream_t s);
+void launch_integrate_penalty(const float *dists, const float *pen, int64_t n, int S, float *out, hipStream_t s);
+void launch_resample(const float *dists, float *weights, const float *U, int64_t n_rays, int n, int nf, int cat,
+                     float *out, int64_t *ids, int *flag, hipStream_t s);
+
+}  // namespace neddf

@@ -1,0 +1,660 @@
+// neddf_capi.hip -- C ABI of libneddf_hip.so (include/neddf_hip.h): context,
+// weight packing into MFMA fragment order, workspaces, stage entry points and
+// the fused render_rays orchestration (all launches on the caller's stream, no
+// host round trip inside a call).
+#include "../../include/neddf_hip.h"
+#include "kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+using namespace neddf;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Field {
+    bool valid = false;
+    neddf_field_desc d{};
+    float aux_grad_scale = 1.1f, distance_range_max = 2.0f;
+    float lowpass[10];
+    DevBuf blob;
+    DdfArgs ddf{};
+    ColArgs col{};
+    NerfArgs nerf{};
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int which;
+};
+
+}  // namespace
+
+struct neddf_ctx {
+    int device = 0;
+    int cus = 256;
+    std::string err;
+    Field field[NEDDF_NUM_SLOTS];
+    DevBuf features, ptaux, scratch, arena, flags;
+    bool timing = false;
+    std::vector<EventPair> events;
+    std::vector<EventPair> pool;
+};
+
+static char g_err[256] = "no context";
+
+#define HIPCHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+            return NEDDF_EHIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+static int fail(neddf_ctx *ctx, int code, const std::string &msg)
+{
+    ctx->err = msg;
+    return code;
+}
+
+static int ensure(neddf_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (b.cap >= bytes) return 0;
+    if (b.p) {
+        HIPCHK(hipDeviceSynchronize());      // nothing in flight may still use the old block
+        HIPCHK(hipFree(b.p));
+        b.p = nullptr; b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8;
+    HIPCHK(hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+static inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------
+// weight packing
+struct Src {
+    const float *w;
+    int rows, cols;       // logical [in][out]
+    bool transposed;      // storage is [out][in] (nn.Linear)
+    float at(int k, int n) const { return transposed ? w[(size_t)n * rows + k] : w[(size_t)k * cols + n]; }
+};
+
+// fragment-major packing, see kernels.h LayerW
+static size_t pack_layer(std::vector<float> &blob, const Src &src, const std::vector<int> &kmap, int nout)
+{
+    const int ks = (int)kmap.size() / 8, NT = nout / 128;
+    size_t off = roundup((int)blob.size(), 64);
+    blob.resize(off + (size_t)ks * 8 * nout, 0.f);
+    float *dst = blob.data() + off;
+    for (int w = 0; w < kWaves; ++w)
+        for (int t = 0; t < NT; ++t)
+            for (int S = 0; S < ks; ++S)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int r = 0; r < 4; ++r) {
+                        int n = (w * NT + t) * 32 + (lane & 31);
+                        int k = kmap[8 * S + 4 * (lane >> 5) + r];
+                        dst[((((size_t)(w * NT + t) * ks + S) * 64 + lane) * 4) + r] = k < 0 ? 0.f : src.at(k, n);
+                    }
+    return off;
+}
+
+static size_t put(std::vector<float> &blob, const float *p, size_t n)
+{
+    size_t off = roundup((int)blob.size(), 64);
+    blob.resize(off + n);
+    memcpy(blob.data() + off, p, n * sizeof(float));
+    return off;
+}
+
+// engine columns of the [sin half | cos half] encoding -> reference feature index base+...
+static void enc_map(std::vector<int> &m, int rank, int K, int base)
+{
+    for (int q = 0; q < K; ++q) m.push_back(q < 3 * rank ? base + q : -1);
+    for (int q = 0; q < K; ++q) m.push_back(q < 3 * rank ? base + 3 * rank + q : -1);
+}
+
+static bool in_skips(const neddf_field_desc &d, int id)
+{
+    for (int i = 0; i < d.n_skips; ++i) if (d.skips[i] == id) return true;
+    return false;
+}
+
+static void fill_enc(EncodeDesc &e, const Field &f)
+{
+    e.E = f.d.embed_pos_rank; e.Ed = f.d.embed_dir_rank;
+    e.KH = roundup(3 * e.E, 4); e.KD = roundup(3 * e.Ed, 4);
+    for (int i = 0; i < 10; ++i) e.lowpass[i] = f.lowpass[i];
+}
+
+static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const float *const *B, int n_tensors)
+{
+    const neddf_field_desc &d = f.d;
+    const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n_trunk = d.layer_count - 1, n_col = d.col_layer_count - 1;
+    const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
+    if (n_tensors != n_trunk + n_col + 3) return fail(ctx, NEDDF_EINVAL, "NeDDF: wrong tensor count");
+    if (n_trunk < 1 || n_trunk > kMaxLayers || n_col < 1 || n_col > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeDDF: layer count out of range");
+    for (int i = 0; i < d.n_skips; ++i)
+        if (d.skips[i] < 0 || d.skips[i] >= n_trunk - 1)
+            return fail(ctx, NEDDF_EUNSUPPORTED, "NeDDF: skip index must address a trunk layer followed by another (the reference itself fails otherwise)");
+    std::vector<float> blob;
+    DdfArgs &a = f.ddf;
+    ColArgs &c = f.col;
+    a = DdfArgs{}; c = ColArgs{};
+    std::vector<size_t> o_wp(n_trunk), o_b(n_trunk), o_st;
+    std::vector<int> pe;
+    enc_map(pe, E, KH, 0);
+    a.n_layers = n_trunk; a.n_stash = 0;
+    for (int l = 0; l < n_trunk; ++l) {
+        bool wide = l > 0 && in_skips(d, l - 1);
+        int cin = l == 0 ? Cpe : (wide ? kWidth + Cpe : kWidth);
+        Src src{ W[l], cin, kWidth, false };
+        std::vector<int> km;
+        a.layer[l].stash = -1;
+        if (l == 0) km = pe;
+        else for (int k = 0; k < kWidth; ++k) km.push_back(wide ? Cpe + k : k);
+        o_wp[l] = pack_layer(blob, src, km, kWidth);
+        a.layer[l].ksteps = (int)km.size() / 8;
+        if (wide) {
+            if (a.n_stash >= kMaxStash) return fail(ctx, NEDDF_EUNSUPPORTED, "NeDDF: too many skip connections");
+            o_st.push_back(pack_layer(blob, src, pe, kWidth));
+            a.stash[a.n_stash].col0 = 0;
+            a.stash[a.n_stash].ksteps = (int)pe.size() / 8;
+            a.layer[l].stash = a.n_stash++;
+        }
+        o_b[l] = put(blob, B[l], kWidth);
+    }
+    const int i_ddf = n_trunk + n_col, i_aux = i_ddf + 1, i_cout = i_ddf + 2;
+    size_t o_wddf = put(blob, W[i_ddf], kWidth), o_waux = put(blob, W[i_aux], kWidth);
+    a.b_ddf_out = B[i_ddf][0]; a.b_aux_out = B[i_aux][0];
+    // colour trunk
+    std::vector<int> ka;
+    enc_map(ka, E, KH, 0);
+    enc_map(ka, Ed, KD, Cpe);
+    for (int k = 0; k < 3; ++k) ka.push_back(Cpe + Cdir + k);
+    while (ka.size() % 8) ka.push_back(-1);
+    std::vector<size_t> c_wp(n_col), c_b(n_col);
+    Src s0{ W[n_trunk], Cpe + Cdir + 3 + kWidth, kWidth, false };
+    size_t o_wa = pack_layer(blob, s0, ka, kWidth);
+    c.ksteps_a = (int)ka.size() / 8;
+    c.n_layers = n_col;
+    for (int l = 0; l < n_col; ++l) {
+        std::vector<int> km;
+        for (int k = 0; k < kWidth; ++k) km.push_back(l == 0 ? Cpe + Cdir + 3 + k : k);
+        Src src{ W[n_trunk + l], l == 0 ? Cpe + Cdir + 3 + kWidth : kWidth, kWidth, false };
+        c_wp[l] = pack_layer(blob, src, km, kWidth);
+        c.layer[l].ksteps = 32;
+        c.layer[l].stash = -1;
+        c_b[l] = put(blob, B[n_trunk + l], kWidth);
+    }
+    size_t o_cout = put(blob, W[i_cout], kWidth * 3);
+    for (int k = 0; k < 3; ++k) c.b_out[k] = B[i_cout][k];
+
+    if (int rc = ensure(ctx, f.blob, blob.size() * sizeof(float))) return rc;
+    HIPCHK(hipMemcpy(f.blob.p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    const float *base = (const float *)f.blob.p;
+    for (int l = 0; l < n_trunk; ++l) { a.layer[l].wp = base + o_wp[l]; a.layer[l].bias = base + o_b[l]; }
+    for (int s = 0; s < a.n_stash; ++s) a.stash[s].wp = base + o_st[s];
+    a.w_ddf_out = base + o_wddf; a.w_aux_out = base + o_waux;
+    c.wp_a = base + o_wa;
+    for (int l = 0; l < n_col; ++l) { c.layer[l].wp = base + c_wp[l]; c.layer[l].bias = base + c_b[l]; }
+    c.w_out = base + o_cout;
+    a.activation = c.activation = d.activation;
+    a.density_activation = d.density_activation;
+    a.d_near = d.d_near;
+    for (int k = 0; k < 6; ++k) { c.penalty_weight[k] = d.penalty_weight[k]; c.penalty_has[k] = d.penalty_has[k]; }
+    return 0;
+}
+
+static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const float *const *B, int n_tensors)
+{
+    const neddf_field_desc &d = f.d;
+    const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n = d.layer_count;
+    const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
+    if (n_tensors != n + 3) return fail(ctx, NEDDF_EINVAL, "NeRF: wrong tensor count");
+    if (n < 1 || n > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: layer count out of range");
+    for (int i = 0; i < d.n_skips; ++i)
+        if (d.skips[i] < 0 || d.skips[i] >= n - 1)
+            return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: skip index must address a layer followed by another");
+    std::vector<float> blob;
+    NerfArgs &a = f.nerf;
+    a = NerfArgs{};
+    std::vector<int> pe;
+    enc_map(pe, E, KH, 0);
+    std::vector<size_t> o_wp(n), o_b(n), o_st;
+    a.n_layers = n; a.n_stash = 0;
+    for (int l = 0; l < n; ++l) {
+        bool wide = l > 0 && in_skips(d, l - 1);
+        int cin = l == 0 ? Cpe : (wide ? kWidth + Cpe : kWidth);
+        Src src{ W[l], cin, kWidth, true };
+        std::vector<int> km;
+        a.layer[l].stash = -1;
+        if (l == 0) km = pe;
+        else for (int k = 0; k < kWidth; ++k) km.push_back(k);       // cat([hx, embed_pos]): hidden state first
+        o_wp[l] = pack_layer(blob, src, km, kWidth);
+        a.layer[l].ksteps = (int)km.size() / 8;
+        if (wide) {
+            if (a.n_stash >= kMaxStash - 1) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: too many skip connections");
+            std::vector<int> ps;
+            enc_map(ps, E, KH, kWidth);
+            o_st.push_back(pack_layer(blob, src, ps, kWidth));
+            a.stash[a.n_stash].col0 = 0;
+            a.stash[a.n_stash].ksteps = (int)ps.size() / 8;
+            a.layer[l].stash = a.n_stash++;
+        }
+        o_b[l] = put(blob, B[l], kWidth);
+    }
+    size_t o_wd = put(blob, W[n], kWidth);
+    a.b_density = B[n][0];
+    // colour head: Linear(256 + dir, 128)
+    Src sc{ W[n + 1], kWidth + Cdir, kWidth / 2, true };
+    std::vector<int> km, kd;
+    for (int k = 0; k < kWidth; ++k) km.push_back(k);
+    enc_map(kd, Ed, KD, kWidth);
+    while (kd.size() % 8) kd.push_back(-1);
+    size_t o_c0 = pack_layer(blob, sc, km, kWidth / 2);
+    size_t o_c0s = pack_layer(blob, sc, kd, kWidth / 2);
+    a.col_stash = a.n_stash;
+    a.stash[a.n_stash].col0 = 2 * KH;
+    a.stash[a.n_stash].ksteps = (int)kd.size() / 8;
+    a.n_stash++;
+    size_t o_c0b = put(blob, B[n + 1], kWidth / 2);
+    size_t o_c1 = put(blob, W[n + 2], 3 * (kWidth / 2));
+    for (int k = 0; k < 3; ++k) a.b_col1[k] = B[n + 2][k];
+
+    if (int rc = ensure(ctx, f.blob, blob.size() * sizeof(float))) return rc;
+    HIPCHK(hipMemcpy(f.blob.p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    const float *base = (const float *)f.blob.p;
+    for (int l = 0; l < n; ++l) { a.layer[l].wp = base + o_wp[l]; a.layer[l].bias = base + o_b[l]; }
+    for (int s = 0; s + 1 < a.n_stash; ++s) a.stash[s].wp = base + o_st[s];
+    a.stash[a.col_stash].wp = base + o_c0s;
+    a.w_density = base + o_wd;
+    a.col0.wp = base + o_c0; a.col0.bias = base + o_c0b; a.col0.ksteps = 32; a.col0.stash = a.col_stash;
+    a.w_col1 = base + o_c1;
+    a.activation = d.activation;
+    a.density_activation = d.density_activation;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+static void tick(neddf_ctx *ctx, hipStream_t s, int which, bool begin)
+{
+    if (!ctx->timing) return;
+    if (begin) {
+        EventPair e;
+        if (!ctx->pool.empty()) { e = ctx->pool.back(); ctx->pool.pop_back(); }
+        else { (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); }
+        e.which = which;
+        (void)hipEventRecord(e.a, s);
+        ctx->events.push_back(e);
+    } else {
+        (void)hipEventRecord(ctx->events.back().b, s);
+    }
+}
+
+static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float *dir, const float *var, int64_t N,
+                         int out_mode, float *distance, float *density, float *color, float *penalty, float *aux,
+                         hipStream_t s)
+{
+    if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");
+    if (N <= 0) return 0;
+    Field &f = ctx->field[slot];
+    const int grid_cap = ctx->cus;
+    if (int rc = ensure(ctx, ctx->scratch, (size_t)grid_cap * kMaxStash * kStashFloatsPerWg * sizeof(float))) return rc;
+    if (f.d.kind == NEDDF_FIELD_NERF) {
+        NerfArgs a = f.nerf;
+        fill_enc(a.enc, f);
+        a.pos = pos; a.dir = dir; a.var = var; a.n_points = N;
+        a.scratch = (float *)ctx->scratch.p;
+        DevBuf &tmp = ctx->ptaux;   // NeRF needs no hand-off buffers; reuse ptaux for optional sinks
+        if (!density || !color) {
+            if (int rc = ensure(ctx, tmp, (size_t)N * 4 * sizeof(float))) return rc;
+        }
+        a.density = density ? density : (float *)tmp.p;
+        a.color = color ? color : (float *)tmp.p + N;
+        int64_t tiles = (N + nerf_points_per_tile() - 1) / nerf_points_per_tile();
+        tick(ctx, s, 2, true);
+        launch_nerf(a, (int)(tiles < grid_cap ? tiles : grid_cap), s);
+        tick(ctx, s, 2, false);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    const bool full = (out_mode == NEDDF_OUT_FULL) && penalty;
+    const int fr = full ? 4 : 1;
+    const int64_t chunk_cap = full ? (1 << 19) : (1 << 21);
+    const int64_t chunk = N < chunk_cap ? N : chunk_cap;
+    if (int rc = ensure(ctx, ctx->features, (size_t)chunk * fr * kWidth * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->ptaux, (size_t)chunk * kPtAux * sizeof(float))) return rc;
+    DevBuf &sink = ctx->flags;      // [>= 64 B] flags live in front; colour sink handled below
+    (void)sink;
+    for (int64_t off = 0; off < N; off += chunk) {
+        const int64_t n = (N - off < chunk) ? N - off : chunk;
+        DdfArgs a = f.ddf;
+        fill_enc(a.enc, f);
+        a.pos = pos + off * 3; a.dir = dir + off * 3; a.var = var + off * 3; a.n_points = n;
+        a.aux_grad_scale = f.aux_grad_scale;
+        a.scratch = (float *)ctx->scratch.p;
+        a.features = (float *)ctx->features.p; a.feat_rows = fr;
+        a.ptaux = (float *)ctx->ptaux.p;
+        a.distance = distance ? distance + off : nullptr;
+        a.density = density ? density + off : nullptr;
+        a.aux_grad = aux ? aux + off : nullptr;
+        int64_t tiles = (n + ddf_points_per_tile() - 1) / ddf_points_per_tile();
+        tick(ctx, s, 0, true);
+        launch_ddf(a, (int)(tiles < grid_cap ? tiles : grid_cap), s);
+        tick(ctx, s, 0, false);
+        if (color || full) {
+            ColArgs c = f.col;
+            fill_enc(c.enc, f);
+            c.pos = a.pos; c.dir = a.dir; c.var = a.var; c.n_points = n;
+            c.features = a.features; c.feat_rows = fr; c.ptaux = a.ptaux;
+            c.distance_range_max = f.distance_range_max;
+            c.penalty = full ? penalty + off : nullptr;
+            if (color) c.color = color + off * 3;
+            else {      // penalty requested without colour: park colour in the (already consumed) head of ptaux? no -- own sink
+                if (int rc = ensure(ctx, ctx->arena, (size_t)chunk * 3 * sizeof(float))) return rc;
+                c.color = (float *)ctx->arena.p;
+            }
+            int ppt = col_points_per_tile(full);
+            int64_t ctiles = (n + ppt - 1) / ppt;
+            tick(ctx, s, 1, true);
+            launch_col(c, (int)(ctiles < grid_cap ? ctiles : grid_cap), full, s);
+            tick(ctx, s, 1, false);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int neddf_abi_version(void) { return NEDDF_ABI_VERSION; }
+
+const char *neddf_last_error(neddf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err; }
+
+int neddf_create(int device, neddf_ctx **out)
+{
+    if (!out) return NEDDF_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || device < 0 || device >= count) {
+        snprintf(g_err, sizeof(g_err), "neddf_create: no HIP device %d (%s)", device, hipGetErrorString(e));
+        return NEDDF_EHIP;
+    }
+    neddf_ctx *ctx = new neddf_ctx();
+    ctx->device = device;
+    (void)hipSetDevice(device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cus = prop.multiProcessorCount;
+    if (ctx->cus <= 0) ctx->cus = 256;
+    void *p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "neddf_create: hipMalloc failed");
+        delete ctx;
+        return NEDDF_EHIP;
+    }
+    (void)hipMemset(p, 0, 256);
+    ctx->flags.p = p; ctx->flags.cap = 256;
+    *out = ctx;
+    return 0;
+}
+
+void neddf_destroy(neddf_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto &f : ctx->field) if (f.blob.p) (void)hipFree(f.blob.p);
+    for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags })
+        if (b->p) (void)hipFree(b->p);
+    for (auto &e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &e : ctx->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    delete ctx;
+}
+
+int neddf_device_cus(neddf_ctx *ctx) { return ctx ? ctx->cus : 0; }
+
+int neddf_set_field(neddf_ctx *ctx, int slot, const neddf_field_desc *desc, const float *const *W, const float *const *B, int n)
+{
+    if (!ctx || !desc || !W || !B) return NEDDF_EINVAL;
+    if (slot < 0 || slot >= NEDDF_NUM_SLOTS) return fail(ctx, NEDDF_EINVAL, "bad slot");
+    (void)hipSetDevice(ctx->device);
+    if (desc->embed_pos_rank < 1 || desc->embed_pos_rank > 10 || desc->embed_dir_rank < 1 || desc->embed_dir_rank > 4)
+        return fail(ctx, NEDDF_EUNSUPPORTED, "embed_pos_rank must be in [1,10] and embed_dir_rank in [1,4]");
+    if (desc->layer_width != kWidth || (desc->kind == NEDDF_FIELD_NEDDF && desc->col_layer_width != kWidth))
+        return fail(ctx, NEDDF_EUNSUPPORTED, "the tile engine is built for hidden width 256");
+    if (desc->n_skips < 0 || desc->n_skips > 8) return fail(ctx, NEDDF_EINVAL, "bad n_skips");
+    if (desc->activation < 0 || desc->activation > 2 || desc->density_activation < 0 || desc->density_activation > 2)
+        return fail(ctx, NEDDF_EINVAL, "bad activation id");
+    Field &f = ctx->field[slot];
+    HIPCHK(hipDeviceSynchronize());
+    f.valid = false;
+    f.d = *desc;
+    f.aux_grad_scale = 1.1f; f.distance_range_max = 2.0f;
+    for (int i = 0; i < 10; ++i) f.lowpass[i] = 1.0f;
+    int rc = desc->kind == NEDDF_FIELD_NEDDF ? build_neddf(ctx, f, W, B, n)
+           : desc->kind == NEDDF_FIELD_NERF ? build_nerf(ctx, f, W, B, n)
+           : fail(ctx, NEDDF_EINVAL, "bad field kind");
+    if (rc) return rc;
+    f.valid = true;
+    return 0;
+}
+
+int neddf_set_iter(neddf_ctx *ctx, int slot, float aux_grad_scale, float distance_range_max, const float *h_lowpass)
+{
+    if (!ctx) return NEDDF_EINVAL;
+    if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");
+    Field &f = ctx->field[slot];
+    f.aux_grad_scale = aux_grad_scale;
+    f.distance_range_max = distance_range_max;
+    for (int i = 0; i < f.d.embed_pos_rank; ++i) f.lowpass[i] = h_lowpass ? h_lowpass[i] : 1.0f;
+    return 0;
+}
+
+static CameraArg cam_arg(const neddf_camera *c)
+{
+    CameraArg a;
+    memcpy(a.R, c->R, sizeof(a.R)); memcpy(a.T, c->T, sizeof(a.T)); memcpy(a.calib, c->calib, sizeof(a.calib));
+    return a;
+}
+
+int neddf_raygen(neddf_ctx *ctx, const void *uv, int uv_type, int64_t n, const neddf_camera *cam, float *rd, float *ro, void *stream)
+{
+    if (!ctx || !uv || !cam || !rd || !ro) return NEDDF_EINVAL;
+    if (uv_type < 0 || uv_type > 3) return fail(ctx, NEDDF_EINVAL, "bad uv_type");
+    launch_raygen(uv, uv_type, n, cam_arg(cam), rd, ro, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neddf_sample_coarse(neddf_ctx *ctx, const float *U, int64_t n, int S1, float near_, float far_, float *dists, void *stream)
+{
+    if (!ctx || !U || !dists || S1 < 2) return NEDDF_EINVAL;
+    launch_sample_coarse(U, n, S1, near_, far_, dists, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neddf_sampling(neddf_ctx *ctx, const float *rd, const float *ro, const float *dists, int64_t n, int S, double radius,
+                   float *pos, float *dir, float *var, void *stream)
+{
+    if (!ctx || !rd || !ro || !dists || !pos || !dir || !var) return NEDDF_EINVAL;
+    if (radius >= 0.0 && S < 2) return fail(ctx, NEDDF_EINVAL, "cone sampling needs at least 2 samples");
+    launch_sampling(rd, ro, dists, n, S, radius, pos, dir, var, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neddf_field_forward(neddf_ctx *ctx, int slot, const float *pos, const float *dir, const float *var, int64_t N, int out_mode,
+                        float *distance, float *density, float *color, float *penalty, float *aux, void *stream)
+{
+    if (!ctx || !pos || !dir || !var) return NEDDF_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    return field_forward(ctx, slot, pos, dir, var, N, out_mode, distance, density, color, penalty, aux, (hipStream_t)stream);
+}
+
+int neddf_composite(neddf_ctx *ctx, const float *dists, const float *dens, const float *col, int64_t n, int S, float max_dist,
+                    float *w, float *depth, float *color, float *trans, int *nan_flag, void *stream)
+{
+    if (!ctx || !dists || !dens || !col || !depth || !color || !trans || S < 2) return NEDDF_EINVAL;
+    launch_composite(dists, dens, col, n, S, max_dist, w, depth, color, trans, nan_flag, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neddf_integrate_penalty(neddf_ctx *ctx, const float *dists, const float *pen, int64_t n, int S, float *out, void *stream)
+{
+    if (!ctx || !dists || !pen || !out) return NEDDF_EINVAL;
+    launch_integrate_penalty(dists, pen, n, S, out, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neddf_importance_resample(neddf_ctx *ctx, const float *dists, float *weights, const float *U, int64_t n_rays, int n, int nf,
+                              int cat, float *out, int64_t *ids, void *stream)
+{
+    if (!ctx || !dists || !weights || !U || !out || n < 2 || nf < 1) return NEDDF_EINVAL;
+    if (n + nf > 8192) return fail(ctx, NEDDF_EUNSUPPORTED, "importance_resample: n + n_fine must be <= 8192");
+    launch_resample(dists, weights, U, n_rays, n, nf, cat, out, ids, (int *)ctx->flags.p + 1, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// carve helper for the render arena
+struct Carver {
+    char *p;
+    size_t off = 0;
+    float *take(size_t n_floats)
+    {
+        float *r = (float *)(p + off);
+        off += (n_floats * sizeof(float) + 255) & ~(size_t)255;
+        return r;
+    }
+};
+
+static size_t carve_bytes(size_t n_floats) { return (n_floats * sizeof(float) + 255) & ~(size_t)255; }
+
+static int render_pass(neddf_ctx *ctx, int slot, const float *rd, const float *ro, const float *dists, int64_t B, int S,
+                       const neddf_render_params *rp, float *pos, float *dir, float *var, float *dens, float *col, float *pen,
+                       float *w_out, float *depth, float *color, float *trans, float *pen_out, int *nan_flag, hipStream_t s)
+{
+    launch_sampling(rd, ro, dists, B, S, rp->cone_sampling ? rp->ray_radius : -1.0, pos, dir, var, s);
+    const bool want_pen = pen_out && ctx->field[slot].d.kind == NEDDF_FIELD_NEDDF;
+    int rc = field_forward(ctx, slot, pos, dir, var, B * S, want_pen ? NEDDF_OUT_FULL : NEDDF_OUT_MINIMAL, nullptr, dens, col,
+                           want_pen ? pen : nullptr, nullptr, s);
+    if (rc) return rc;
+    launch_composite(dists, dens, col, B, S, rp->max_dist, w_out, depth, color, trans, nan_flag, s);
+    if (want_pen) launch_integrate_penalty(dists, pen, B, S, pen_out, s);
+    return 0;
+}
+
+int neddf_render_rays(neddf_ctx *ctx, const void *uv, int uv_type, int64_t B, const neddf_camera *cam, const neddf_render_params *rp,
+                      const float *Uc, const float *Uf, const neddf_render_outputs *out, void *stream)
+{
+    if (!ctx || !uv || !cam || !rp || !Uc || !Uf || !out) return NEDDF_EINVAL;
+    if (B <= 0) return 0;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int Sc1 = rp->sample_coarse + 1, Sf1 = rp->sample_fine + 1, S2 = Sc1 + Sf1;
+    if (!ctx->field[NEDDF_SLOT_COARSE].valid || !ctx->field[NEDDF_SLOT_FINE].valid) return fail(ctx, NEDDF_ENOFIELD, "render_rays needs coarse and fine fields");
+    size_t need = 2 * carve_bytes(B * 3) + carve_bytes(B * Sc1) + carve_bytes(B * S2) + 3 * carve_bytes(B * S2 * 3) +
+                  2 * carve_bytes(B * S2) + carve_bytes(B * S2 * 3) + carve_bytes(B * (Sc1 - 1)) + carve_bytes(B * (S2 - 1)) +
+                  6 * carve_bytes(B * 3);
+    // the arena is also used by field_forward as a colour sink only when colour is not requested; never the case here
+    if (int rc = ensure(ctx, ctx->arena, need)) return rc;
+    Carver cv{ (char *)ctx->arena.p };
+    float *rd = cv.take(B * 3), *ro = cv.take(B * 3);
+    float *dc = out->dists_coarse ? out->dists_coarse : cv.take(B * Sc1);
+    float *df = out->dists_fine ? out->dists_fine : cv.take(B * S2);
+    float *pos = cv.take(B * S2 * 3), *dir = cv.take(B * S2 * 3), *var = cv.take(B * S2 * 3);
+    float *dens = cv.take(B * S2), *pen = cv.take(B * S2), *col = cv.take(B * S2 * 3);
+    float *wc = out->weight_coarse ? out->weight_coarse : cv.take(B * (Sc1 - 1));
+    float *depth_c = out->depth_coarse ? out->depth_coarse : cv.take(B);
+    float *color_c = out->color_coarse ? out->color_coarse : cv.take(B * 3);
+    float *trans_c = out->transmittance_coarse ? out->transmittance_coarse : cv.take(B);
+    float *depth = out->depth ? out->depth : cv.take(B);
+    float *color = out->color ? out->color : cv.take(B * 3);
+    float *trans = out->transmittance ? out->transmittance : cv.take(B);
+    int *flags = (int *)ctx->flags.p;
+    int *nan_flag = out->nan_flag ? out->nan_flag : flags;
+
+    launch_raygen(uv, uv_type, B, cam_arg(cam), rd, ro, s);
+    launch_sample_coarse(Uc, B, Sc1, rp->dist_near, rp->dist_far, dc, s);
+    int rc = render_pass(ctx, NEDDF_SLOT_COARSE, rd, ro, dc, B, Sc1, rp, pos, dir, var, dens, col, pen, wc, depth_c, color_c,
+                         trans_c, out->fields_penalty_coarse, nan_flag, s);
+    if (rc) return rc;
+    launch_resample(dc, wc, Uf, B, Sc1, Sf1, 1, df, nullptr, flags + 1, s);
+    rc = render_pass(ctx, NEDDF_SLOT_FINE, rd, ro, df, B, S2, rp, pos, dir, var, dens, col, pen, out->weight, depth, color, trans,
+                     out->fields_penalty, nan_flag, s);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neddf_render_rays_single(neddf_ctx *ctx, int slot, const void *uv, int uv_type, int64_t B, const neddf_camera *cam,
+                             const neddf_render_params *rp, int S1, const float *U, const neddf_render_outputs *out, void *stream)
+{
+    if (!ctx || !uv || !cam || !rp || !U || !out || S1 < 2) return NEDDF_EINVAL;
+    if (B <= 0) return 0;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");
+    size_t need = 2 * carve_bytes(B * 3) + carve_bytes(B * S1) + 3 * carve_bytes(B * S1 * 3) + 2 * carve_bytes(B * S1) +
+                  carve_bytes(B * S1 * 3) + 3 * carve_bytes(B * 3);
+    if (int rc = ensure(ctx, ctx->arena, need)) return rc;
+    Carver cv{ (char *)ctx->arena.p };
+    float *rd = cv.take(B * 3), *ro = cv.take(B * 3);
+    float *dc = out->dists_fine ? out->dists_fine : cv.take(B * S1);
+    float *pos = cv.take(B * S1 * 3), *dir = cv.take(B * S1 * 3), *var = cv.take(B * S1 * 3);
+    float *dens = cv.take(B * S1), *pen = cv.take(B * S1), *col = cv.take(B * S1 * 3);
+    float *depth = out->depth ? out->depth : cv.take(B);
+    float *color = out->color ? out->color : cv.take(B * 3);
+    float *trans = out->transmittance ? out->transmittance : cv.take(B);
+    int *nan_flag = out->nan_flag ? out->nan_flag : (int *)ctx->flags.p;
+    launch_raygen(uv, uv_type, B, cam_arg(cam), rd, ro, s);
+    launch_sample_coarse(U, B, S1, rp->dist_near, rp->dist_far, dc, s);
+    int rc = render_pass(ctx, slot, rd, ro, dc, B, S1, rp, pos, dir, var, dens, col, pen, out->weight, depth, color, trans,
+                         out->fields_penalty, nan_flag, s);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neddf_set_timing(neddf_ctx *ctx, int enable)
+{
+    if (!ctx) return NEDDF_EINVAL;
+    ctx->timing = enable != 0;
+    return 0;
+}
+
+int neddf_get_timings(neddf_ctx *ctx, float *ms, int n)
+{
+    if (!ctx || !ms || n < 6) return NEDDF_EINVAL;
+    for (int i = 0; i < n; ++i) ms[i] = 0.f;
+    for (auto &e : ctx->events) {
+        HIPCHK(hipEventSynchronize(e.b));
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, e.a, e.b));
+        ms[e.which] += t;        // [0] distance trunk, [1] colour trunk, [2] NeRF field
+        ms[3 + e.which] += 1.f;  // launch counts
+        ctx->pool.push_back(e);
+    }
+    ctx->events.clear();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,244 @@
+"""Neural fields -- host-side mirror of neddf/network/{neddf,nerf,base_neuralfield}.py.
+
+The modules own their parameters under the reference's state-dict keys
+(`layers_ddf.N.weight` [in,out], ... / `layers.N.weight` [out,in], ...) so that
+checkpoints written by the reference load unchanged; `forward(sampling)` keeps
+the reference signature and dict keys but the computation is the fused HIP
+field kernels (csrc/field_kernels.hip) reached through the C ABI.
+"""
+import math
+from abc import ABC, abstractmethod
+from typing import Dict, List, Optional
+
+import torch
+from torch import Tensor, nn
+
+from ._lib import ACT, FIELD_NEDDF, FIELD_NERF, OUT_FULL, OUT_MINIMAL, PENALTY_KEYS, SLOT_GENERIC, Context, FieldDesc
+from .ray import Sampling
+
+
+def lowpass_scale(alpha: float, embed_dim: int) -> List[float]:
+    """Per-frequency progressive low-pass (with_grad/positional_encoding.py:137-157)."""
+    s = [1.0] * embed_dim
+    if alpha >= embed_dim:
+        return s
+    k = int(alpha)
+    s[k] = 0.5 * (1 - math.cos(math.pi * (alpha - k))) + 1e-7
+    for j in range(k + 1, embed_dim):
+        s[j] = 1e-7
+    # the reference stores the scale in a float32 tensor
+    return torch.tensor(s, dtype=torch.float32).tolist()
+
+
+class PositionalEncodingInfo(nn.Module):
+    """Carries embed_dim / freq like the reference PE layers (their tensors are
+    plain attributes, not buffers, so they never enter the state dict)."""
+
+    def __init__(self, embed_dim: int) -> None:
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.freq = torch.tensor([(2.0 ** t) for t in range(embed_dim)])
+
+    def get_grad_scale(self, input_dim: int = 3) -> Tensor:
+        return torch.reciprocal(0.5 * self.freq).unsqueeze(1).expand(-1, input_dim).reshape(1, -1)
+
+    def get_lowpass_scale(self, alpha: float = 1.0, input_dim: int = 3) -> Tensor:
+        s = torch.tensor(lowpass_scale(alpha, self.embed_dim), dtype=torch.float32)
+        return s.unsqueeze(1).expand(-1, input_dim).reshape(1, -1)
+
+
+class LinearGradLayer(nn.Module):
+    """Parameter holder with the reference layout weight [in,out], bias [out]
+    (with_grad/linear.py:113-116: xavier-normal weight, zero bias)."""
+
+    def __init__(self, input_ch: int = 128, output_ch: int = 128) -> None:
+        super().__init__()
+        self.input_ch, self.output_ch = input_ch, output_ch
+        self.weight = nn.Parameter(torch.empty(input_ch, output_ch))
+        self.bias = nn.Parameter(torch.zeros(output_ch))
+        nn.init.xavier_normal_(self.weight)
+
+
+class BaseNeuralField(ABC, nn.Module):
+    def __init__(self) -> None:
+        super().__init__()
+        self._slot = SLOT_GENERIC
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    @abstractmethod
+    def set_iter(self, iter: int) -> None:
+        raise NotImplementedError()
+
+    @abstractmethod
+    def _descriptor(self) -> FieldDesc:
+        raise NotImplementedError()
+
+    @abstractmethod
+    def _tensors(self):
+        """(weights, biases) in the order neddf_set_field documents."""
+        raise NotImplementedError()
+
+    @abstractmethod
+    def _iter_state(self):
+        """(aux_grad_scale, distance_range_max, lowpass list)"""
+        raise NotImplementedError()
+
+    def voxelize(self, *a, **k):  # base_neuralfield.py:49-79 (marching-cubes tooling)
+        raise NotImplementedError("voxelize is visualisation tooling outside the accelerated path")
+
+    def upload(self, ctx: Context, slot: int) -> None:
+        """Pack + upload the parameters into `slot` if they changed since the last upload."""
+        ws, bs = self._tensors()
+        sig = (id(self), slot, tuple((t.data_ptr(), t._version) for t in ws + bs))
+        if ctx.slot_owner.get(slot) != sig:
+            hw = [t.detach().to("cpu", torch.float32).contiguous() for t in ws]
+            hb = [t.detach().to("cpu", torch.float32).contiguous() for t in bs]
+            ctx.set_field(slot, self._descriptor(), hw, hb, sig)
+        ags, drm, lp = self._iter_state()
+        ctx.set_iter(slot, ags, drm, lp)
+
+    def _run(self, sampling: Sampling, out_mode: int, want) -> Dict[str, Tensor]:
+        pos = sampling.sample_pos
+        ctx = Context.get(pos.device)
+        self.upload(ctx, self._slot)
+        batch_size, sampling_size = pos.shape[0], pos.shape[1]
+        o = ctx.field_forward(self._slot, pos, sampling.sample_dir, sampling.diag_variance, out_mode, want)
+        return {k: (v.view(batch_size, sampling_size, 3) if k == "color" else v.view(batch_size, sampling_size))
+                for k, v in o.items()}
+
+
+class NeDDF(BaseNeuralField):
+    """Density-distance field (neddf.py:52-160 constructor keywords)."""
+
+    def __init__(self, embed_pos_rank: int = 10, embed_dir_rank: int = 4, ddf_layer_count: int = 8,
+                 ddf_layer_width: int = 256, col_layer_count: int = 8, col_layer_width: int = 256,
+                 activation_type: str = "tanhExp", density_activation_type: str = "ReLU", d_near: float = 0.01,
+                 lowpass_alpha_offset: float = 10.0, skips: Optional[List[int]] = None,
+                 penalty_weight: Optional[Dict[str, float]] = None) -> None:
+        super().__init__()
+        in_ddf = embed_pos_rank * 6
+        in_col = (embed_pos_rank + embed_dir_rank) * 6 + 3 + ddf_layer_width
+        self.skips = [4] if skips is None else list(skips)
+        self.activation_type, self.density_activation_type = activation_type, density_activation_type
+        self.pe_pos = PositionalEncodingInfo(embed_pos_rank)
+        self.pe_dir = PositionalEncodingInfo(embed_dir_rank)
+        ddf = [LinearGradLayer(in_ddf, ddf_layer_width)]
+        for layer_id in range(ddf_layer_count - 2):
+            ddf.append(LinearGradLayer(ddf_layer_width + (in_ddf if layer_id in self.skips else 0), ddf_layer_width))
+        col = [LinearGradLayer(in_col, col_layer_width)]
+        col += [LinearGradLayer(col_layer_width, col_layer_width) for _ in range(col_layer_count - 2)]
+        self.layers_ddf = nn.ModuleList(ddf)
+        self.layers_col = nn.ModuleList(col)
+        self.layer_ddf_out = LinearGradLayer(ddf_layer_width, 1)
+        self.layer_aux_out = LinearGradLayer(ddf_layer_width, 1)
+        self.layer_col_out = LinearGradLayer(ddf_layer_width, 3)     # sic: ddf width (neddf.py:145)
+        self.ddf_layer_count, self.ddf_layer_width = ddf_layer_count, ddf_layer_width
+        self.col_layer_count, self.col_layer_width = col_layer_count, col_layer_width
+        self.d_near = d_near
+        self.aux_grad_scale = 1.1
+        self.distance_range_max = 2.0
+        self.lowpass_alpha_offset = lowpass_alpha_offset
+        self.lowpass_alpha = lowpass_alpha_offset
+        if penalty_weight is None:      # neddf.py:152-159
+            penalty_weight = {"constraints_aux_grad": 0.05, "constraints_dDdt": 0.05, "constraints_color": 0.01,
+                              "range_distance": 1.0, "range_aux_grad": 1.0}
+        self.penalty_weight = dict(penalty_weight)
+        # "full" reproduces every key of the reference dict; "minimal" skips the
+        # colour-trunk Jacobian + penalties that eval rendering never reads
+        self.output_mode = "full"
+
+    def _descriptor(self) -> FieldDesc:
+        d = FieldDesc()
+        d.kind = FIELD_NEDDF
+        d.embed_pos_rank, d.embed_dir_rank = self.pe_pos.embed_dim, self.pe_dir.embed_dim
+        d.layer_count, d.layer_width = self.ddf_layer_count, self.ddf_layer_width
+        d.col_layer_count, d.col_layer_width = self.col_layer_count, self.col_layer_width
+        d.n_skips = len(self.skips)
+        for i, s in enumerate(self.skips[:8]):
+            d.skips[i] = s
+        d.activation, d.density_activation = ACT[self.activation_type], ACT[self.density_activation_type]
+        d.d_near = self.d_near
+        for i, k in enumerate(PENALTY_KEYS):
+            d.penalty_has[i] = int(k in self.penalty_weight)
+            d.penalty_weight[i] = float(self.penalty_weight.get(k, 1.0))
+        return d
+
+    def _tensors(self):
+        mods = list(self.layers_ddf) + list(self.layers_col) + [self.layer_ddf_out, self.layer_aux_out, self.layer_col_out]
+        return [m.weight for m in mods], [m.bias for m in mods]
+
+    def _iter_state(self):
+        return self.aux_grad_scale, self.distance_range_max, lowpass_scale(self.lowpass_alpha, self.pe_pos.embed_dim)
+
+    def forward(self, sampling: Sampling) -> Dict[str, Tensor]:
+        """distance, density, fields_penalty, aux_grad [B,S]; color [B,S,3] (neddf.py:302-308)."""
+        if self.output_mode == "full":
+            return self._run(sampling, OUT_FULL, ("distance", "density", "color", "fields_penalty", "aux_grad"))
+        return self._run(sampling, OUT_MINIMAL, ("distance", "density", "color", "aux_grad"))
+
+    def set_iter(self, iter: int) -> None:
+        """Warm-up schedule (neddf.py:311-326); -1 = evaluation."""
+        if iter == -1:
+            self.aux_grad_scale, self.distance_range_max = 1.1, 2.0
+            self.lowpass_alpha = self.pe_pos.embed_dim
+        else:
+            self.aux_grad_scale = min(1.1, max(0.01, 0.0001 * iter))
+            self.distance_range_max = min(2.0, 2.0 + 0.0001 * iter)
+            self.lowpass_alpha = self.lowpass_alpha_offset + 0.001 * iter
+
+
+class NeRF(BaseNeuralField):
+    """Plain NeRF field (nerf.py:34-105 constructor keywords)."""
+
+    def __init__(self, embed_pos_rank: int = 10, embed_dir_rank: int = 4, layer_count: int = 8, layer_width: int = 256,
+                 activation_type: str = "ReLU", density_activation_type: str = "ReLU", skips: Optional[List[int]] = None,
+                 lowpass_alpha_offset: float = 10.0) -> None:
+        super().__init__()
+        in_pos, in_dir = embed_pos_rank * 6, embed_dir_rank * 6
+        self.skips = [4] if skips is None else list(skips)
+        self.activation_type, self.density_activation_type = activation_type, density_activation_type
+        self.pe_pos = PositionalEncodingInfo(embed_pos_rank)
+        self.pe_dir = PositionalEncodingInfo(embed_dir_rank)
+        layers = [nn.Linear(in_pos, layer_width)]
+        for layer_id in range(layer_count - 1):
+            layers.append(nn.Linear(layer_width + (in_pos if layer_id in self.skips else 0), layer_width))
+        self.layers = nn.ModuleList(layers)
+        self.outL_density = nn.Linear(layer_width, 1)
+        self.outL_color = nn.Sequential(nn.Linear(layer_width + in_dir, layer_width // 2), nn.ReLU(),
+                                        nn.Linear(layer_width // 2, 3))
+        self.layer_count, self.layer_width = layer_count, layer_width
+        self.lowpass_alpha_offset = lowpass_alpha_offset
+        self.lowpass_alpha = lowpass_alpha_offset
+
+    def _descriptor(self) -> FieldDesc:
+        d = FieldDesc()
+        d.kind = FIELD_NERF
+        d.embed_pos_rank, d.embed_dir_rank = self.pe_pos.embed_dim, self.pe_dir.embed_dim
+        d.layer_count, d.layer_width = self.layer_count, self.layer_width
+        d.n_skips = len(self.skips)
+        for i, s in enumerate(self.skips[:8]):
+            d.skips[i] = s
+        d.activation, d.density_activation = ACT[self.activation_type], ACT[self.density_activation_type]
+        return d
+
+    def _tensors(self):
+        mods = list(self.layers) + [self.outL_density, self.outL_color[0], self.outL_color[2]]
+        return [m.weight for m in mods], [m.bias for m in mods]
+
+    def _iter_state(self):
+        return 1.1, 2.0, lowpass_scale(self.lowpass_alpha, self.pe_pos.embed_dim)
+
+    def forward(self, sampling: Sampling) -> Dict[str, Tensor]:
+        """density [B,S], color [B,S,3] (nerf.py:161-164)."""
+        return self._run(sampling, OUT_MINIMAL, ("density", "color"))
+
+    def set_iter(self, iter: int) -> None:
+        self.lowpass_alpha = self.pe_pos.embed_dim if iter == -1 else self.lowpass_alpha_offset + 0.001 * iter
+
+
+# spellings used by BASELINE.json's north_star
+NeDDFField = NeDDF
+NeRFField = NeRF

@@ -1,0 +1,229 @@
+"""Volume renderer -- host-side mirror of neddf/render/{base_neural_render,nerf_render}.py.
+
+Same constructor keywords, methods, dict keys and RNG draw order as the
+reference; the work is the fused HIP pipeline behind neddf_render_rays
+(raygen -> stratified/cone sampling -> field -> wave-scan compositing ->
+inverse-CDF resampling -> field -> compositing) on the current HIP stream.
+"""
+import math
+from typing import Any, Dict, Iterable, List, Optional
+
+import torch
+from torch import Tensor, nn
+
+from ._lib import SLOT_COARSE, SLOT_FINE, Context, NeddfError, RenderParams
+from .camera import Camera
+from .config import instantiate
+from .network import BaseNeuralField, NeDDF
+
+RenderTarget = str          # Literal["color", "depth", "transmittance"]
+SamplingType = str          # Literal["point", "cone"]
+
+
+class BaseNeuralRender(nn.Module):
+    def __init__(self) -> None:
+        super().__init__()
+        self.iteration: int = -1
+
+    def next_iter(self) -> None:
+        self.set_iter(self.iteration + 1)
+
+    def set_iter(self, iter: int) -> None:
+        self.iteration = iter
+
+
+class NeRFRender(BaseNeuralRender):
+    """nerf_render.py:40-81.  Extra (non-reference) attributes:
+
+    rng            "torch_cpu" (default; the reference draws its uniforms with
+                   torch.rand on the CPU generator, nerf_render.py:137 and
+                   base_neural_render.py:75 -- same seed => same samples) or
+                   "device" (draw on the HIP device; faster, not seed-compatible)
+    rays_per_call  rays handed to one neddf_render_rays call by render_image
+    """
+
+    def __init__(self, network_config: Any, sample_coarse: int = 128, sample_fine: int = 128, dist_near: float = 2.0,
+                 dist_far: float = 6.0, max_dist: float = 6.0, use_coarse_network: bool = True,
+                 sampling_type: SamplingType = "point") -> None:
+        super().__init__()
+        self.use_coarse_network = use_coarse_network
+        self.network_fine: BaseNeuralField = instantiate(network_config)
+        self.network_coarse: BaseNeuralField = instantiate(network_config) if use_coarse_network else self.network_fine
+        self.sample_coarse, self.sample_fine = sample_coarse, sample_fine
+        self.dist_near, self.dist_far, self.max_dist = dist_near, dist_far, max_dist
+        self.sampling_type = sampling_type
+        self.rng = "torch_cpu"
+        self.rays_per_call = 1 << 16
+
+    # ------------------------------------------------------------------ helpers
+    def get_network(self) -> BaseNeuralField:
+        return self.network_fine
+
+    def get_parameters_list(self) -> List[Any]:
+        if self.use_coarse_network:
+            return list(self.network_coarse.parameters()) + list(self.network_fine.parameters())
+        return list(self.network_coarse.parameters())
+
+    def set_iter(self, iter: int) -> None:
+        super().set_iter(iter)
+        self.network_coarse.set_iter(iter)
+        self.network_fine.set_iter(iter)
+
+    def _params(self) -> RenderParams:
+        if self.sampling_type not in ("point", "cone"):
+            raise ValueError("sampling_type must be 'point' or 'cone'")
+        p = RenderParams()
+        p.sample_coarse, p.sample_fine = self.sample_coarse, self.sample_fine
+        p.dist_near, p.dist_far, p.max_dist = self.dist_near, self.dist_far, self.max_dist
+        p.cone_sampling = int(self.sampling_type == "cone")
+        p.ray_radius = 1.0 / 1111 / math.sqrt(12)      # nerf_render.py:144-145
+        return p
+
+    def _ctx(self, device) -> Context:
+        ctx = Context.get(device)
+        self.network_coarse.upload(ctx, SLOT_COARSE)
+        self.network_fine.upload(ctx, SLOT_FINE)
+        return ctx
+
+    def _rand(self, rows: int, cols: int, device) -> Tensor:
+        if self.rng == "torch_cpu":
+            return torch.rand(rows, cols).to(device)
+        if self.rng == "device":
+            return torch.rand(rows, cols, device=device)
+        raise ValueError("rng must be 'torch_cpu' or 'device'")
+
+    def _has_penalty(self) -> bool:
+        return isinstance(self.network_fine, NeDDF)
+
+    # --------------------------------------------------------------- stage API
+    def integrate_volume_render(self, dists: Tensor, densities: Tensor, colors: Tensor) -> Dict[str, Tensor]:
+        """base_neural_render.py:117-172: weight [B,S-1], depth [B], color [B,3], transmittance [B]."""
+        ctx = Context.get(dists.device)
+        out, flag = ctx.composite(dists, densities, colors, self.max_dist)
+        assert int(flag.item()) == 0, "NaN weight in integrate_volume_render"      # reference asserts (:155)
+        return out
+
+    def sample_pdf(self, dists: Tensor, weights: Tensor, samples_fine: int, cat_coarse: bool = True) -> Tensor:
+        """base_neural_render.py:27-115.  `weights` is sanitised in place like the reference."""
+        ctx = Context.get(dists.device)
+        U = self._rand(dists.shape[0], samples_fine, dists.device).contiguous()
+        if weights.dtype == torch.float32 and weights.is_contiguous():
+            return ctx.importance_resample(dists, weights, U, cat_coarse)
+        w = weights.to(torch.float32).contiguous()
+        out = ctx.importance_resample(dists, w, U, cat_coarse)
+        weights.copy_(w)
+        return out
+
+    # -------------------------------------------------------------- render_rays
+    def _render(self, ctx: Context, uv: Tensor, camera: Camera, U_c: Tensor, U_f: Tensor, full: bool) -> Dict[str, Tensor]:
+        B = uv.shape[0]
+        dev = uv.device
+        S2 = self.sample_coarse + self.sample_fine + 2
+
+        def buf(*shape):
+            return torch.empty(*shape, device=dev, dtype=torch.float32)
+
+        o = dict(color=buf(B, 3), depth=buf(B), transmittance=buf(B))
+        if full:
+            o.update(weight=buf(B, S2 - 1), color_coarse=buf(B, 3), depth_coarse=buf(B), transmittance_coarse=buf(B),
+                     weight_coarse=buf(B, self.sample_coarse))
+            if self._has_penalty():
+                o.update(fields_penalty=buf(B), fields_penalty_coarse=buf(B))
+        flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        ctx.render_rays(uv, camera.descriptor(), self._params(), U_c, U_f, dict(o, nan_flag=flag))
+        o["_nan"] = flag
+        return o
+
+    def render_rays(self, uv: Tensor, camera: Camera) -> Dict[str, Tensor]:
+        """nerf_render.py:109-188.  Keys: weight, depth, color, transmittance[, fields_penalty] + *_coarse."""
+        uv = uv.to(camera.device)
+        ctx = self._ctx(uv.device)
+        B = uv.shape[0]
+        U_c = self._rand(B, self.sample_coarse + 1, uv.device)       # draw order is part of the contract
+        U_f = self._rand(B, self.sample_fine + 1, uv.device)
+        o = self._render(ctx, uv, camera, U_c, U_f, full=True)
+        assert int(o.pop("_nan").item()) == 0, "NaN weight in integrate_volume_render"
+        order = ["weight", "depth", "color", "transmittance", "fields_penalty", "weight_coarse", "depth_coarse",
+                 "color_coarse", "transmittance_coarse", "fields_penalty_coarse"]
+        return {k: o[k] for k in order if k in o}
+
+    # ------------------------------------------------------------- render_image
+    def render_image(self, width: int, height: int, camera: Camera, target_types: Iterable[RenderTarget],
+                     downsampling: int = 1, chunk: int = 512, pixel_range=None) -> Dict[str, Tensor]:
+        """nerf_render.py:190-249.  Pixels are row-major (idx = v*w + u).  In
+        "torch_cpu" RNG mode the uniforms are drawn chunk by chunk in the
+        reference's order ([B,Sc+1] then [B,Sf+1] per chunk of `chunk` rays), so a
+        given torch seed renders the same samples; rays are then processed in
+        batches of `rays_per_call` regardless of `chunk` (rays are independent).
+        pixel_range=(lo, hi) (not in the reference) renders only that slab of the
+        row-major pixel index and returns flat [hi-lo, C] tensors -- the unit of
+        multi-GPU ray sharding (neddf_amd/parallel.py); the uniforms are still
+        drawn for the whole frame so the image does not depend on the sharding."""
+        target_types = list(target_types)
+        with torch.no_grad():
+            dev = camera.device
+            w, h = width // downsampling, height // downsampling
+            us = torch.arange(w, device=dev).reshape(1, w).expand(h, w).reshape(-1) * downsampling
+            vs = torch.arange(h, device=dev).reshape(h, 1).expand(h, w).reshape(-1) * downsampling
+            uv = torch.stack([us, vs], 1)
+            n = uv.shape[0]
+            self.network_coarse.eval()
+            self.network_fine.eval()
+            ctx = self._ctx(dev)
+            if self.rng == "torch_cpu":
+                uc, uf = [], []
+                for below in range(0, n, chunk):
+                    b = min(n, below + chunk) - below
+                    uc.append(torch.rand(b, self.sample_coarse + 1))
+                    uf.append(torch.rand(b, self.sample_fine + 1))
+                U_c, U_f = torch.cat(uc).to(dev), torch.cat(uf).to(dev)
+            else:
+                U_c = self._rand(n, self.sample_coarse + 1, dev)
+                U_f = self._rand(n, self.sample_fine + 1, dev)
+            parts: Dict[str, List[Tensor]] = {k: [] for k in target_types}
+            flags = []
+            lo, hi = (0, n) if pixel_range is None else pixel_range
+            for below in range(lo, hi, self.rays_per_call):
+                above = min(hi, below + self.rays_per_call)
+                o = self._render(ctx, uv[below:above], camera, U_c[below:above], U_f[below:above], full=False)
+                flags.append(o["_nan"])
+                for k in target_types:
+                    parts[k].append(o[k])
+            assert int(torch.stack(flags).sum().item()) == 0, "NaN weight in integrate_volume_render"
+            if pixel_range is None:
+                images = {k: torch.cat(parts[k], 0).reshape(h, w, -1) for k in target_types}
+            else:
+                images = {k: torch.cat(parts[k], 0).reshape(hi - lo, -1) for k in target_types}
+            self.network_coarse.train(True)
+            self.network_fine.train(True)
+        return images
+
+    def render_image_single_pass(self, width: int, height: int, camera: Camera, samples: int,
+                                 U: Optional[Tensor] = None, pixel_range=None) -> Dict[str, Tensor]:
+        """One stratified pass of `samples` points per ray through network_fine
+        (BASELINE.json configs[1]).  Not a reference method: it is render_rays'
+        coarse half (nerf_render.py:128-152) at image scale.  pixel_range=(lo,hi)
+        restricts to a slab of the row-major pixel index (multi-GPU sharding).
+        Returns flat per-ray tensors color [n,3], depth [n], transmittance [n]."""
+        with torch.no_grad():
+            dev = camera.device
+            lo, hi = (0, width * height) if pixel_range is None else pixel_range
+            idx = torch.arange(lo, hi, device=dev)
+            uv = torch.stack([idx % width, idx // width], 1)
+            n = hi - lo
+            ctx = self._ctx(dev)
+            if U is None:
+                U = self._rand(n, samples, dev)
+            out = dict(color=torch.empty(n, 3, device=dev), depth=torch.empty(n, device=dev),
+                       transmittance=torch.empty(n, device=dev))
+            flag = torch.zeros(1, device=dev, dtype=torch.int32)
+            for below in range(0, n, self.rays_per_call):
+                above = min(n, below + self.rays_per_call)
+                o = {k: v[below:above] for k, v in out.items()}
+                ctx.render_rays(uv[below:above], camera.descriptor(), self._params(), U[below:above], None,
+                                dict(o, nan_flag=flag), single_slot=SLOT_FINE)
+            out["_nan"] = flag
+        return out
+
+    def render_field_slice(self, *a, **k):  # nerf_render.py:263-336 (cv2 colour-map debug view)
+        raise NotImplementedError("render_field_slice is visualisation tooling outside the accelerated path")

@@ -1,0 +1,373 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle
+and the committed golden vectors.  Run on the GPU box with `-m gpu`.
+
+Gates: bit-exact for index/integer work and for the stages that contain only
++,-,*,/,sqrt (raygen, stratified distances, cone moments, sample_pdf given the
+same inputs); `|a-b| <= rtol*|b| + atol` with rtol = 1e-4 (BASELINE.json) for
+everything that goes through the MLP or a transcendental.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+from conftest import BUNNY_CFG, assert_close, golden
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ctx(dev):
+    from neddf_amd import Context
+    return Context.get(dev)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def cam_desc(g):
+    from neddf_amd._lib import CameraDesc
+    d = CameraDesc()
+    d.R[:] = g["R"].reshape(-1).tolist()
+    d.T[:] = g["T"].tolist()
+    d.calib[:] = g["calib"].tolist()
+    return d
+
+
+def make_camera(g, dev):
+    import neddf_amd
+    cam = neddf_amd.Camera(neddf_amd.PinholeCalib(g["calib"].astype(np.float64)), None).to(dev)
+    cam.R, cam.T = T(g["R"], dev), T(g["T"], dev)
+    return cam
+
+
+def bunny_render(dev, bunny_weights, **kw):
+    import neddf_amd
+    cfg = dict(BUNNY_CFG, _target_="neddf.network.NeDDF")
+    args = dict(sample_coarse=64, sample_fine=128, dist_near=2.0, dist_far=6.0, max_dist=6.0,
+                use_coarse_network=False, sampling_type="cone")
+    args.update(kw)
+    r = neddf_amd.NeRFRender(cfg, **args)
+    # checkpoint layout of the reference: both prefixes present (base_trainer.py:121)
+    sd = {}
+    for k, v in bunny_weights.items():
+        sd["network_fine." + k] = torch.from_numpy(v)
+        sd["network_coarse." + k] = torch.from_numpy(v)
+    r.load_state_dict(sd)        # strict: the 52-entry key set of the shipped checkpoint must match exactly
+    r.to(dev)
+    r.set_iter(-1)
+    return r
+
+
+# --------------------------------------------------------------------- stages
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32, torch.int16, torch.float32])
+def test_raygen(ctx, dev, orc, bunny_stages, dtype):
+    g = bunny_stages
+    rd, ro = ctx.raygen(T(g["uv"], dev).to(dtype), cam_desc(g))
+    ord_, oro = orc.create_rays(g["uv"], g["R"], g["T"], g["calib"])
+    assert np.array_equal(N(rd), ord_), "ray_dir not bit-identical to the oracle"
+    assert np.array_equal(N(ro), oro)
+    assert_close(N(rd), g["ray_dir"], 1e-6, 1e-7, "ray_dir vs golden")
+
+
+def test_sample_coarse_bitexact(ctx, dev, bunny_stages):
+    g = bunny_stages
+    d = ctx.sample_coarse(T(g["u_coarse"], dev), 2.0, 6.0)
+    assert np.array_equal(N(d), g["dists_coarse"])
+
+
+def test_sampling_bitexact_vs_oracle(ctx, dev, orc, bunny_stages):
+    g = bunny_stages
+    for dk in ("dists_coarse", "dists_fine"):
+        for radius in (float(g["ray_radius"]), None):
+            pos, d, var = ctx.sampling(T(g["ray_dir"], dev), T(g["ray_orig"], dev), T(g[dk], dev), radius)
+            op, od, ov = orc.sampling(g["ray_dir"], g["ray_orig"], g[dk], radius)
+            assert np.array_equal(N(pos), op) and np.array_equal(N(d), od) and np.array_equal(N(var), ov), (dk, radius)
+    pos, d, var = ctx.sampling(T(g["ray_dir"], dev), T(g["ray_orig"], dev), T(g["dists_fine"], dev), float(g["ray_radius"]))
+    assert_close(N(pos), g["f_pos"], 1e-6, 1e-7, "pos vs golden")
+    assert_close(N(var), g["f_var"], 1e-4, 1e-12, "var vs golden")
+
+
+def test_composite(ctx, dev, orc, bunny_stages):
+    g = bunny_stages
+    for tag, dk in (("c", "dists_coarse"), ("f", "dists_fine")):
+        out, flag = ctx.composite(T(g[dk], dev), T(g[tag + "_density"], dev), T(g[tag + "_color"], dev), 6.0)
+        ref = orc.integrate(g[dk], g[tag + "_density"], g[tag + "_color"], 6.0)
+        assert int(flag.item()) == 0
+        assert_close(N(out["weight"]), ref["weight"], 2e-6, 1e-7, "weight")       # libm exp differs by an ulp (N5)
+        for k in ("color", "depth", "transmittance"):
+            assert_close(N(out[k]), ref[k], 1e-5, 1e-6, k)
+    assert_close(N(out["color"]), g["out_color"], 1e-5, 1e-6, "color vs golden")
+    assert_close(N(out["depth"]), g["out_depth"], 1e-5, 1e-6, "depth vs golden")
+    assert_close(N(out["weight"]), g["out_weight"], 1e-5, 1e-7, "weight vs golden")
+
+
+def test_composite_edges(ctx, dev, orc):
+    e = golden("render_edges.npz")
+    out, flag = ctx.composite(T(e["iv_dists"], dev), T(e["iv_dens"], dev), T(e["iv_col"], dev), float(e["iv_max_dist"]))
+    assert_close(N(out["weight"]), e["iv_weight"], 2e-5, 1e-7, "edge weight")
+    assert_close(N(out["color"]), e["iv_color"], 2e-5, 1e-6, "edge color")
+    assert_close(N(out["depth"]), e["iv_depth"], 2e-5, 1e-6, "edge depth")
+    assert_close(N(out["transmittance"]), e["iv_trans"], 2e-5, 1e-12, "edge trans")
+    # NaN density must raise the flag (the reference asserts, base_neural_render.py:155)
+    dens = e["iv_dens"].copy()
+    dens[4, 7] = np.nan
+    _, flag = ctx.composite(T(e["iv_dists"], dev), T(dens, dev), T(e["iv_col"], dev), 6.0)
+    assert int(flag.item()) == 1
+    # S not a multiple of 64 and > 64: chunk carry
+    rng = np.random.default_rng(3)
+    d = np.sort(rng.uniform(2, 6, (5, 200)).astype(np.float32), axis=1)
+    r = rng.uniform(-1, 20, (5, 200)).astype(np.float32)
+    c = rng.uniform(0, 1, (5, 200, 3)).astype(np.float32)
+    out, _ = ctx.composite(T(d, dev), T(r, dev), T(c, dev), 6.0)
+    ref = orc.integrate(d, r, c, 6.0)
+    for k in ("weight", "color", "depth", "transmittance"):
+        assert_close(N(out[k]), ref[k], 1e-5, 1e-6, k)
+    pen = rng.uniform(0, 1, (5, 200)).astype(np.float32)
+    assert_close(N(ctx.integrate_penalty(T(d, dev), T(pen, dev))), orc.integrate_penalty(d, pen), 1e-5, 1e-7)
+
+
+def test_resample_bitexact(ctx, dev, orc, bunny_stages):
+    """Same weights / dists / uniforms => identical searchsorted indices and samples."""
+    g = bunny_stages
+    w = T(g["weight_coarse_raw"].copy(), dev)
+    out, ids = ctx.importance_resample(T(g["dists_coarse"], dev), w, T(g["u_fine"], dev), True, want_ids=True)
+    wo = g["weight_coarse_raw"].copy()
+    oout, oids, fb = orc.sample_pdf(g["dists_coarse"], wo, g["u_fine"], True)
+    assert np.array_equal(N(ids), oids)
+    assert np.array_equal(N(out), oout)
+    assert np.array_equal(N(out), g["dists_fine"])            # and the reference itself
+    assert np.array_equal(N(w), g["weight_coarse"])           # in-place sanitisation
+
+
+def test_resample_edges(ctx, dev, orc):
+    e = golden("render_edges.npz")
+    for cat, tag in ((True, "cat"), (False, "nocat")):
+        w = T(e["sp_w"].copy(), dev)
+        out = ctx.importance_resample(T(e["sp_dists"], dev), w, T(e["sp_u"], dev), cat)
+        assert np.array_equal(N(out), e["sp_%s_out" % tag]), tag
+        assert np.array_equal(N(w), e["sp_%s_wafter" % tag], equal_nan=True)
+    # batch-wide NaN fallback (base_neural_render.py:105-114)
+    d = np.sort(np.random.default_rng(0).uniform(2, 6, (3, 9)).astype(np.float32), axis=1)
+    d[1, 3] = np.nan
+    w = np.ones((3, 8), np.float32)
+    u = np.random.default_rng(1).uniform(0, 1, (3, 5)).astype(np.float32)
+    out = ctx.importance_resample(T(d, dev), T(w, dev), T(u, dev), True)
+    oo, _, fb = orc.sample_pdf(d, w.copy(), u, True)
+    assert fb and np.array_equal(N(out), oo)
+    # larger, ragged sizes: n=200 coarse knots, 333 fine samples
+    rng = np.random.default_rng(5)
+    d = np.sort(rng.uniform(0, 1, (7, 200)).astype(np.float32), axis=1)
+    w = (rng.uniform(0, 1, (7, 199)) ** 6).astype(np.float32)
+    u = rng.uniform(0, 1, (7, 333)).astype(np.float32)
+    wt = T(w.copy(), dev)
+    out, ids = ctx.importance_resample(T(d, dev), wt, T(u, dev), True, want_ids=True)
+    oo, oi, _ = orc.sample_pdf(d, w.copy(), u, True)
+    assert np.array_equal(N(ids), oi) and np.array_equal(N(out), oo)
+
+
+# --------------------------------------------------------------------- fields
+def neddf_module(kw, sd, dev):
+    import neddf_amd
+    net = neddf_amd.NeDDF(**kw)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return net.to(dev)
+
+
+def smp(g, dev, tag=None):
+    from neddf_amd import Sampling
+    if tag is None:
+        return Sampling(T(g["pos"], dev), T(g["dir"], dev), T(g["var"], dev))
+    return Sampling(T(g[tag + "_pos"], dev), T(g[tag + "_dir"], dev), T(g[tag + "_var"], dev))
+
+
+def test_neddf_bunny_field(dev, orc, bunny_weights, bunny_stages):
+    g = bunny_stages
+    net = neddf_module(BUNNY_CFG, bunny_weights, dev)
+    net.set_iter(-1)
+    onet = orc.NeDDFOracle(bunny_weights, **BUNNY_CFG)
+    for tag in ("c", "f"):
+        o = net(smp(g, dev, tag))
+        assert set(o.keys()) == {"distance", "density", "color", "fields_penalty", "aux_grad"}
+        assert o["color"].shape == g[tag + "_color"].shape and o["density"].shape == g[tag + "_density"].shape
+        ref = onet.forward(g[tag + "_pos"], g[tag + "_dir"], g[tag + "_var"])
+        for src, name in ((ref, "oracle"), ({k: g[tag + "_" + k] for k in ref}, "golden")):
+            assert_close(N(o["distance"]), src["distance"], 1e-4, 1e-6, tag + " distance vs " + name)
+            assert_close(N(o["aux_grad"]), src["aux_grad"], 1e-4, 1e-6, tag + " aux vs " + name)
+            assert_close(N(o["color"]), src["color"], 1e-4, 2e-5, tag + " color vs " + name)
+            # (1 - |grad|)/D amplifies fp32 noise: reference fp32-vs-fp64 differs by 5e-5 abs here
+            assert_close(N(o["density"]), src["density"], 1e-4, 3e-4, tag + " density vs " + name)
+            assert_close(N(o["fields_penalty"]), src["fields_penalty"], 2e-3, 1e-5, tag + " penalty vs " + name)
+    # minimal mode = same values, no penalty key
+    net.output_mode = "minimal"
+    o2 = net(smp(g, dev, "f"))
+    assert "fields_penalty" not in o2
+    for k in ("distance", "density", "aux_grad"):
+        assert torch.equal(o2[k], o[k]), k
+    assert_close(N(o2["color"]), N(o["color"]), 1e-5, 1e-6, "minimal vs full colour")
+
+
+@pytest.mark.parametrize("name", ["neddf_relu", "neddf_tanhexp", "neddf_leaky"])
+def test_neddf_synth(dev, orc, name):
+    g = golden(name + ".npz")
+    kw = json.loads(str(g["config"]))
+    sd = synth.neddf_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["ddf_layer_count"], kw["ddf_layer_width"],
+                           kw["col_layer_count"], kw["col_layer_width"], tuple(kw["skips"]), seed=7)
+    net = neddf_module(kw, sd, dev)
+    onet = orc.NeDDFOracle(sd, **kw)
+    for it, tag in ((-1, "eval"), (2500, "it2500")):
+        net.set_iter(it)
+        onet.set_iter(it)
+        o = net(smp(g, dev))
+        ref = onet.forward(g["pos"], g["dir"], g["var"])
+        for k in ("distance", "aux_grad", "color", "density", "fields_penalty"):
+            assert_close(N(o[k]), g["%s_%s" % (tag, k)], 2e-4, 2e-5, "%s %s %s vs golden" % (name, tag, k))
+            assert_close(N(o[k]), ref[k], 2e-4, 2e-5, "%s %s %s vs oracle" % (name, tag, k))
+
+
+@pytest.mark.parametrize("name", ["nerf_relu", "nerf_tanhexp"])
+def test_nerf_synth(dev, orc, name):
+    import neddf_amd
+    g = golden(name + ".npz")
+    kw = json.loads(str(g["config"]))
+    sd = synth.nerf_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["layer_count"], kw["layer_width"],
+                          tuple(kw["skips"]), seed=11)
+    net = neddf_amd.NeRF(**kw)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.to(dev)
+    for it, tag in ((-1, "eval"), (2500, "it2500")):
+        net.set_iter(it)
+        o = net(smp(g, dev))
+        assert set(o.keys()) == {"density", "color"}
+        for k in ("density", "color"):
+            assert_close(N(o[k]), g["%s_%s" % (tag, k)], 1e-4, 1e-5, "%s %s %s" % (name, tag, k))
+
+
+def test_field_ragged_sizes_and_chunks(dev, bunny_weights):
+    """Tile tails (N not a multiple of 32/128), N = 1, and batch invariance."""
+    net = neddf_module(BUNNY_CFG, bunny_weights, dev)
+    net.set_iter(-1)
+    net.output_mode = "minimal"
+    from neddf_amd import Sampling
+    pos, d, var = synth.random_sampling(1, 1000, seed=9)
+    full = net(Sampling(T(pos, dev), T(d, dev), T(var, dev)))
+    for n in (1, 31, 33, 127, 129, 777):
+        part = net(Sampling(T(pos[:, :n], dev), T(d[:, :n], dev), T(var[:, :n], dev)))
+        for k in ("distance", "density", "color", "aux_grad"):
+            assert torch.equal(part[k], full[k][:, :n]), (k, n)
+
+
+# --------------------------------------------------------------- render_rays
+def test_render_rays_end_to_end(dev, bunny_weights, bunny_stages):
+    """NeRFRender.render_rays on identical weights / rays / uniforms vs the reference's output."""
+    g = bunny_stages
+    r = bunny_render(dev, bunny_weights)
+    cam = make_camera(g, dev)
+    ctx = r._ctx(dev)
+    o = r._render(ctx, T(g["uv"], dev), cam, T(g["u_coarse"], dev), T(g["u_fine"], dev), full=True)
+    assert int(o["_nan"].item()) == 0
+    for k in ("color", "depth", "transmittance", "color_coarse", "depth_coarse", "transmittance_coarse"):
+        assert_close(N(o[k]), g["out_" + k], 1e-4, 1e-5, k)
+    assert_close(N(o["weight_coarse"]), g["out_weight_coarse"], 1e-4, 1e-5, "weight_coarse")
+    assert_close(N(o["fields_penalty"]), g["out_fields_penalty"], 2e-3, 1e-5, "fields_penalty")
+    assert_close(N(o["fields_penalty_coarse"]), g["out_fields_penalty_coarse"], 2e-3, 1e-5, "fields_penalty_coarse")
+    assert o["weight"].shape == g["out_weight"].shape
+    mse = float(np.mean((N(o["color"]) - g["out_color"]) ** 2))
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
+    assert psnr > 80.0, psnr
+
+
+def test_render_rays_api_and_rng_order(dev, bunny_weights, bunny_stages):
+    """Public render_rays draws torch.rand [B,Sc+1] then [B,Sf+1] on the CPU generator like the reference."""
+    g = bunny_stages
+    r = bunny_render(dev, bunny_weights)
+    cam = make_camera(g, dev)
+    torch.manual_seed(0)
+    o = r.render_rays(T(g["uv"], dev), cam)
+    keys = ["weight", "depth", "color", "transmittance", "fields_penalty", "weight_coarse", "depth_coarse",
+            "color_coarse", "transmittance_coarse", "fields_penalty_coarse"]
+    assert list(o.keys()) == keys
+    for k in ("color", "depth", "transmittance"):
+        assert_close(N(o[k]), g["out_" + k], 1e-4, 1e-5, k)
+
+
+def test_render_image_small(dev, bunny_weights):
+    """Pixel order, chunked RNG draw order (incl. the short last chunk) and downsampling (nerf_render.py:190-249)."""
+    g = golden("bunny_image_small.npz")
+    r = bunny_render(dev, bunny_weights)
+    cam = make_camera(g, dev)
+    w, h = int(g["width"]), int(g["height"])
+    torch.manual_seed(int(g["seed"]))
+    img = r.render_image(w, h, cam, ["color", "depth", "transmittance"], 1, int(g["chunk"]))
+    assert img["color"].shape == (h, w, 3) and img["depth"].shape == (h, w, 1)
+    for k in ("color", "depth", "transmittance"):
+        assert_close(N(img[k]), g[k], 1e-4, 1e-5, k)
+    torch.manual_seed(int(g["seed"]))
+    img = r.render_image(2 * w, 2 * h, cam, ["color", "depth"], 2, int(g["ds_chunk"]))
+    assert_close(N(img["color"]), g["ds_color"], 1e-4, 1e-5, "downsampled color")
+    assert_close(N(img["depth"]), g["ds_depth"], 1e-4, 1e-5, "downsampled depth")
+
+
+def test_nerf_render_rays(dev):
+    """Two separate NeRF nets, point sampling, float uv (tests/render/test_nerf_render.py:48-68 shape)."""
+    import neddf_amd
+    g = golden("nerf_render_rays.npz")
+    kw = dict(embed_pos_rank=10, embed_dir_rank=4, layer_count=8, layer_width=256, activation_type="ReLU",
+              density_activation_type="ReLU", skips=[4], lowpass_alpha_offset=10, _target_="neddf.network.NeRF")
+    r = neddf_amd.NeRFRender(kw, sample_coarse=32, sample_fine=48, dist_near=2.0, dist_far=6.0, max_dist=6.0,
+                             use_coarse_network=True, sampling_type="point")
+    r.network_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_state(seed=21).items()})
+    r.network_fine.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_state(seed=22).items()})
+    r.to(dev)
+    r.set_iter(-1)
+    cam = make_camera(g, dev)
+    torch.manual_seed(3)
+    o = r.render_rays(T(g["uv"], dev), cam)
+    assert "fields_penalty" not in o
+    for k in ("color", "depth", "transmittance", "color_coarse", "depth_coarse", "transmittance_coarse"):
+        assert_close(N(o[k]), g["out_" + k], 1e-4, 1e-5, k)
+    assert o["depth"].shape == (32,) and o["color"].shape == (32, 3)
+
+
+# ------------------------------------------------ full-size property checks
+def test_full_size_properties(dev, bunny_weights):
+    """BASELINE configs[1] shape (800x800, 128 samples/ray) on a 32k-ray slab:
+    determinism, slab-invariance (the multi-GPU sharding contract) and physical ranges."""
+    r = bunny_render(dev, bunny_weights)
+    g = golden("bunny_stages.npz")
+    import neddf_amd
+    fx = 0.5 * 800 / np.tan(0.5 * 0.6911112070083618)
+    cam = neddf_amd.Camera(neddf_amd.PinholeCalib(np.array([fx, fx, 400.0, 400.0])), None).to(dev)
+    cam.R, cam.T = T(g["R"], dev), T(g["T"], dev)
+    lo, hi = 300 * 800, 300 * 800 + 32768
+    gen = torch.Generator().manual_seed(11)
+    U = torch.rand(hi - lo, 128, generator=gen).to(dev)
+    a = r.render_image_single_pass(800, 800, cam, 128, U=U, pixel_range=(lo, hi))
+    b = r.render_image_single_pass(800, 800, cam, 128, U=U, pixel_range=(lo, hi))
+    mid = lo + 12345
+    c = r.render_image_single_pass(800, 800, cam, 128, U=U[mid - lo:], pixel_range=(mid, hi))
+    for k in ("color", "depth", "transmittance"):
+        assert torch.equal(a[k], b[k]), "non-deterministic " + k
+        assert torch.equal(a[k][mid - lo:], c[k]), "slab-dependent " + k
+        assert torch.isfinite(a[k]).all()
+    assert int(a["_nan"].item()) == 0
+    assert float(a["depth"].min()) > 1.0 and float(a["depth"].max()) < 7.5
