@@ -113,12 +113,12 @@ def test_composite(ctx, dev, orc, bunny_stages):
         out, flag = ctx.composite(T(g[dk], dev), T(g[tag + "_density"], dev), T(g[tag + "_color"], dev), 6.0)
         ref = orc.integrate(g[dk], g[tag + "_density"], g[tag + "_color"], 6.0)
         assert int(flag.item()) == 0
-        assert_close(N(out["weight"]), ref["weight"], 2e-6, 1e-7, "weight")       # libm exp differs by an ulp (N5)
+        assert_close(N(out["weight"]), ref["weight"], 2e-6, 3e-7, "weight")       # o = 1 - exp(.): one ulp of exp is 1.2e-7 abs (N5)
         for k in ("color", "depth", "transmittance"):
             assert_close(N(out[k]), ref[k], 1e-5, 1e-6, k)
     assert_close(N(out["color"]), g["out_color"], 1e-5, 1e-6, "color vs golden")
     assert_close(N(out["depth"]), g["out_depth"], 1e-5, 1e-6, "depth vs golden")
-    assert_close(N(out["weight"]), g["out_weight"], 1e-5, 1e-7, "weight vs golden")
+    assert_close(N(out["weight"]), g["out_weight"], 1e-5, 3e-7, "weight vs golden")
 
 
 def test_composite_edges(ctx, dev, orc):
