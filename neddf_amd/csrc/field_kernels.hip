@@ -27,16 +27,34 @@
 // per-workgroup global scratch in accumulator layout ("stash").
 #include "kernels.h"
 
+#include <stdlib.h>
+
 namespace neddf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-constexpr int MT_DDF = 4;   // 128 rows = 32 points x (value + 3 Jacobian rows)
-constexpr int MT_COL = 4;   // 128 rows = 128 points (value only) or 32 points (full mode)
+constexpr int MT_COL = 4;   // NeRF kernel: 128 rows = 128 points (value only)
 
 // ----------------------------------------------------------------------------
 // activations (with_grad/{relu,leaky_relu,tanh_exp}.py forward halves)
+// tanh(exp(x)) building blocks on the raw transcendental units: v_exp_f32 is
+// exp2 (<= 1 ulp), v_rcp_f32 <= 1 ulp.  u = e^x >= 0; tanh(u) = 1 - 2/(e^{2u}+1)
+// loses relative accuracy for small u (cancellation), so u < 0.3 uses the odd
+// Taylor polynomial to u^9 (truncation < 6e-8 relative at 0.3).  Measured against
+// fp64 over x in [-30, 20]: |err(y)| <= 1.8e-7, |err(y')| <= 1.2e-6 -- inside the
+// error of evaluating the reference formula itself in fp32 (2.3e-7 / 2.6e-6).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+__device__ __forceinline__ float tanh_nonneg(float u)
+{
+    float e2u = __builtin_amdgcn_exp2f((u + u) * 1.4426950408889634f);
+    float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e2u + 1.0f);
+    float p = u * u;
+    float poly = fmaf(p, fmaf(p, fmaf(p, fmaf(p, 62.0f / 2835.0f, -17.0f / 315.0f), 2.0f / 15.0f), -1.0f / 3.0f), 1.0f) * u;
+    return u < 0.3f ? poly : big;
+}
+
 template <int KIND>
 __device__ __forceinline__ void act_grad(float x, float &y, float &dy)
 {
@@ -47,10 +65,10 @@ __device__ __forceinline__ void act_grad(float x, float &y, float &dy)
         float s = (x < 0.f) ? 0.01f : 1.f;
         y = x * s; dy = s;
     } else {                    // tanh_exp.py:38-46
-        float ex = expf(x);
-        float tx = tanhf(ex);
+        float ex = fast_exp(x);
+        float tx = tanh_nonneg(ex);
         float yy = x * tx;
-        float dd = tx - x * ex * (tx * tx - 1.0f);
+        float dd = fmaf(-(x * ex), fmaf(tx, tx, -1.0f), tx);      // tx - x*ex*(tx^2 - 1)
         bool big = x > 20.0f;
         y = big ? x : yy;
         dy = big ? 1.0f : dd;
@@ -62,7 +80,7 @@ __device__ __forceinline__ float act_val(float x)
 {
     if (KIND == 0) return x > 0.f ? x : 0.f;            // F.relu
     if (KIND == 1) return x > 0.f ? x : 0.01f * x;       // F.leaky_relu
-    float t = x * tanhf(expf(x));                        // nn_module/tanh_exp.py:28-31
+    float t = x * tanh_nonneg(fast_exp(x));              // nn_module/tanh_exp.py:28-31
     return x > 20.0f ? x : t;
 }
 
@@ -262,9 +280,10 @@ __device__ __forceinline__ void encode_dir(float *act, int col0, const EncodeDes
 
 // ----------------------------------------------------------------------------
 // NeDDF distance trunk
-__global__ __launch_bounds__(kThreads, 1) void ddf_trunk_kernel(const DdfArgs a)
+template <int MT, int WPS>
+__global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs a)
 {
-    constexpr int MT = MT_DDF, NT = 2, ROWS = MT * 32, P = MT * 8;
+    constexpr int NT = 2, ROWS = MT * 32, P = MT * 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *act = smem;
     float *hd = smem + ROWS * kActLd;       // [2][ROWS] head dot products
@@ -369,10 +388,10 @@ __global__ __launch_bounds__(kThreads, 1) void ddf_trunk_kernel(const DdfArgs a)
 // NeDDF colour trunk.  ROWS4 = false: eval-minimal, one row per point (the
 // colour Jacobian is dead code in eval); ROWS4 = true:
 // full mode with Jacobian rows + field penalties (neddf.py:244-300).
-template <bool ROWS4>
-__global__ __launch_bounds__(kThreads, 1) void col_trunk_kernel(const ColArgs a)
+template <bool ROWS4, int MT, int WPS>
+__global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs a)
 {
-    constexpr int MT = MT_COL, NT = 2, ROWS = MT * 32, P = ROWS4 ? MT * 8 : ROWS, RPP = ROWS4 ? 4 : 1;
+    constexpr int NT = 2, ROWS = MT * 32, P = ROWS4 ? MT * 8 : ROWS, RPP = ROWS4 ? 4 : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *act = smem;
     float *hd = smem + ROWS * kActLd;       // [2][ROWS][3] partial colour dots
@@ -583,8 +602,21 @@ __global__ __launch_bounds__(kThreads, 1) void nerf_kernel(const NerfArgs a)
 
 // ----------------------------------------------------------------------------
 size_t field_lds_bytes(int mt) { return (size_t)(mt * 32 * kActLd + 2 * mt * 32 * 3 + 16) * sizeof(float); }
-int ddf_points_per_tile() { return MT_DDF * 8; }
-int col_points_per_tile(bool rows4) { return rows4 ? MT_COL * 8 : MT_COL * 32; }
+
+// Tile geometry: MT = 4 -> one workgroup per CU (133 KB LDS, 128-row tiles, each weight fragment feeds 4 M-tiles);
+// MT = 2 -> two workgroups per CU (2 x 67 KB), so one workgroup's VALU epilogue overlaps the other's MFMA stream.
+static int g_mt = 0;
+static int tile_mt()
+{
+    if (!g_mt) {
+        const char *e = getenv("NEDDF_TILE_MT");
+        g_mt = (e && atoi(e) == 4) ? 4 : 2;      // measured on MI355X (C2 workload): MT=2 129 TF vs MT=4 118 TF on the distance trunk
+    }
+    return g_mt;
+}
+int field_wgs_per_cu() { return tile_mt() == 2 ? 2 : 1; }
+int ddf_points_per_tile() { return tile_mt() * 8; }
+int col_points_per_tile(bool rows4) { return rows4 ? tile_mt() * 8 : tile_mt() * 32; }
 int nerf_points_per_tile() { return MT_COL * 32; }
 
 static void set_lds(const void *fn, size_t bytes)
@@ -594,20 +626,27 @@ static void set_lds(const void *fn, size_t bytes)
 
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
 {
-    size_t lds = field_lds_bytes(MT_DDF);
-    static bool once = (set_lds((const void *)ddf_trunk_kernel, field_lds_bytes(MT_DDF)), true);
+    static bool once = (set_lds((const void *)ddf_trunk_kernel<4, 1>, field_lds_bytes(4)),
+                        set_lds((const void *)ddf_trunk_kernel<2, 2>, field_lds_bytes(2)), true);
     (void)once;
-    hipLaunchKernelGGL(ddf_trunk_kernel, dim3(grid), dim3(kThreads), lds, s, a);
+    if (tile_mt() == 2) hipLaunchKernelGGL((ddf_trunk_kernel<2, 2>), dim3(grid), dim3(kThreads), field_lds_bytes(2), s, a);
+    else hipLaunchKernelGGL((ddf_trunk_kernel<4, 1>), dim3(grid), dim3(kThreads), field_lds_bytes(4), s, a);
 }
 
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 {
-    size_t lds = field_lds_bytes(MT_COL);
-    static bool once = (set_lds((const void *)col_trunk_kernel<false>, field_lds_bytes(MT_COL)),
-                        set_lds((const void *)col_trunk_kernel<true>, field_lds_bytes(MT_COL)), true);
+    static bool once = (set_lds((const void *)col_trunk_kernel<false, 4, 1>, field_lds_bytes(4)),
+                        set_lds((const void *)col_trunk_kernel<true, 4, 1>, field_lds_bytes(4)),
+                        set_lds((const void *)col_trunk_kernel<false, 2, 2>, field_lds_bytes(2)),
+                        set_lds((const void *)col_trunk_kernel<true, 2, 2>, field_lds_bytes(2)), true);
     (void)once;
-    if (rows4) hipLaunchKernelGGL(col_trunk_kernel<true>, dim3(grid), dim3(kThreads), lds, s, a);
-    else hipLaunchKernelGGL(col_trunk_kernel<false>, dim3(grid), dim3(kThreads), lds, s, a);
+    if (tile_mt() == 2) {
+        if (rows4) hipLaunchKernelGGL((col_trunk_kernel<true, 2, 2>), dim3(grid), dim3(kThreads), field_lds_bytes(2), s, a);
+        else hipLaunchKernelGGL((col_trunk_kernel<false, 2, 2>), dim3(grid), dim3(kThreads), field_lds_bytes(2), s, a);
+    } else {
+        if (rows4) hipLaunchKernelGGL((col_trunk_kernel<true, 4, 1>), dim3(grid), dim3(kThreads), field_lds_bytes(4), s, a);
+        else hipLaunchKernelGGL((col_trunk_kernel<false, 4, 1>), dim3(grid), dim3(kThreads), field_lds_bytes(4), s, a);
+    }
 }
 
 void launch_nerf(const NerfArgs &a, int grid, hipStream_t s)

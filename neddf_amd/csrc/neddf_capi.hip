@@ -311,7 +311,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");
     if (N <= 0) return 0;
     Field &f = ctx->field[slot];
-    const int grid_cap = ctx->cus;
+    const int grid_cap = ctx->cus * field_wgs_per_cu();
     if (int rc = ensure(ctx, ctx->scratch, (size_t)grid_cap * kMaxStash * kStashFloatsPerWg * sizeof(float))) return rc;
     if (f.d.kind == NEDDF_FIELD_NERF) {
         NerfArgs a = f.nerf;
@@ -326,7 +326,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         a.color = color ? color : (float *)tmp.p + N;
         int64_t tiles = (N + nerf_points_per_tile() - 1) / nerf_points_per_tile();
         tick(ctx, s, 2, true);
-        launch_nerf(a, (int)(tiles < grid_cap ? tiles : grid_cap), s);
+        launch_nerf(a, (int)(tiles < ctx->cus ? tiles : ctx->cus), s);
         tick(ctx, s, 2, false);
         HIPCHK(hipGetLastError());
         return 0;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd database (ROCm 7.2's default --kernel-trace --stats
-output) as CSV: kernel, calls, total_us, avg_us, pct; plus launch geometry and
+output) as CSV: kernel, calls, total_ms, avg_ms, pct (the top_kernels view reports microseconds); plus launch geometry and
 register counts of the first dispatch of each kernel.
 
     python tools/rocpd_summary.py gpurun_out/prof/r1_results.db > profiles/xxx.csv
@@ -17,7 +17,7 @@ def main(path):
                        "from kernels group by name"):
         geo[r[0]] = r[1:]
     w = csv.writer(sys.stdout)
-    w.writerow(["kernel", "calls", "total_us", "avg_us", "pct", "grid_x", "workgroup_x", "lds_bytes", "vgpr", "agpr", "sgpr",
+    w.writerow(["kernel", "calls", "total_ms", "avg_ms", "pct", "grid_x", "workgroup_x", "lds_bytes", "vgpr", "agpr", "sgpr",
                 "scratch"])
     for name, calls, total, avg, pct in c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
         short = name if len(name) < 120 else name[:117] + "..."
