@@ -171,9 +171,11 @@ int neddf_render_rays_single(neddf_ctx *ctx, int slot, const void *d_uv, int uv_
                              const neddf_camera *h_cam, const neddf_render_params *params, int S1,
                              const float *d_U, const neddf_render_outputs *out, void *stream);
 
-/* Timing of the dominant kernels of the LAST render/field call on this ctx,
- * measured with hipEvents on the call's stream (forces a stream sync).
- * ms[0] distance-trunk kernel, ms[1] colour-trunk kernel, ms[2] everything else. */
+/* Kernel timing of the field kernels launched on this ctx since the last
+ * neddf_get_timings call, measured with hipEvents recorded on the launch
+ * stream around each launch (neddf_get_timings synchronises on them).
+ * ms[0..2] = summed duration of the distance-trunk / colour-trunk / NeRF kernel
+ * launches, ms[3..5] = the corresponding launch counts; n must be >= 6. */
 int neddf_set_timing(neddf_ctx *ctx, int enable);
 int neddf_get_timings(neddf_ctx *ctx, float *ms, int n);
 
