@@ -306,16 +306,41 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
         __syncthreads();
 
         f32x16 acc[MT][NT];
-        for (int s = 0; s < a.n_stash; ++s) {       // early partials of skip layers (neddf.py:217-219)
-            acc_init<MT, NT, true>(acc, nullptr, wave, lane);
+        // Early partials of skip layers (neddf.py:217-219).  With one skip connection (every shipped
+        // config) and the 64-row tile the partial stays in registers until its layer; otherwise it is
+        // parked in the per-workgroup global scratch.
+        constexpr bool REG_STASH = (MT == 2);
+        const bool in_regs = REG_STASH && a.n_stash == 1;
+        f32x16 held[REG_STASH ? MT : 1][REG_STASH ? NT : 1];
+        for (int s = 0; s < a.n_stash; ++s) {
             const f32x4v *wl = (const f32x4v *)a.stash[s].wp + (size_t)wave * NT * a.stash[s].ksteps * 64 + lane;
+            if constexpr (REG_STASH) {
+                if (in_regs) {
+                    acc_init<MT, NT, true>(held, nullptr, wave, lane);
+                    dense<MT, NT>(held, act_lane + a.stash[s].col0, wl, a.stash[s].ksteps);
+                    continue;
+                }
+            }
+            acc_init<MT, NT, true>(acc, nullptr, wave, lane);
             dense<MT, NT>(acc, act_lane + a.stash[s].col0, wl, a.stash[s].ksteps);
             stash_store<MT, NT>(acc, scratch + (size_t)s * kStashFloatsPerWg, wave, lane);
         }
         for (int l = 0; l < a.n_layers; ++l) {      // neddf.py:214-216
             const LayerW &L = a.layer[l];
             acc_init<MT, NT, true>(acc, L.bias, wave, lane);
-            if (L.stash >= 0) stash_add<MT, NT>(acc, scratch + (size_t)L.stash * kStashFloatsPerWg, wave, lane);
+            if (L.stash >= 0) {
+                bool done = false;
+                if constexpr (REG_STASH) {
+                    if (in_regs) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[mt][t] += held[mt][t];
+                        done = true;
+                    }
+                }
+                if (!done) stash_add<MT, NT>(acc, scratch + (size_t)L.stash * kStashFloatsPerWg, wave, lane);
+            }
             const f32x4v *wl = (const f32x4v *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane;
             dense<MT, NT>(acc, act_lane, wl, L.ksteps);
             __syncthreads();                        // every wave finished reading the previous activations
