@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+                    help="c2 = BASELINE configs[1] (headline, default); c3 = configs[2], 65 coarse + 129 importance samples")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,9 +130,26 @@ def main():
     U = torch.rand(n_rays, SAMPLES, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
     ctx = render._ctx(dev)
     keys = ("color", "depth", "transmittance")
+    idx = torch.arange(n_rays, device=dev)
+    uv_all = torch.stack([idx % WIDTH, idx // WIDTH], 1)
+    samples_per_ray = SAMPLES if args.workload == "c2" else 65 + 194
+
+    if args.workload == "c3":
+        U_c = torch.rand(n_rays, 65, device=dev)
+        U_f = torch.rand(n_rays, 129, device=dev)
 
     def step():
-        out = render.render_image_single_pass(WIDTH, HEIGHT, cam, SAMPLES, U=U)
+        if args.workload == "c3":
+            parts = {k: [] for k in keys}
+            for lo in range(0, n_rays, render.rays_per_call):
+                hi = min(n_rays, lo + render.rays_per_call)
+                o = render._render(ctx, uv_all[lo:hi], cam, U_c[lo:hi], U_f[lo:hi], full=False)
+                for k in keys:
+                    parts[k].append(o[k])
+            out = {k: torch.cat(v) for k, v in parts.items()}
+            out["_nan"] = o["_nan"]
+        else:
+            out = render.render_image_single_pass(WIDTH, HEIGHT, cam, SAMPLES, U=U)
         if world > 1:       # every rank ends with all N views: [N * n_rays, 5]
             return gather_pixels(pack_pixels(out, keys), n_rays * world)
         return out
@@ -158,11 +177,12 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        pts = n_rays * SAMPLES * args.steps                       # field evaluations on this rank
+        pts = n_rays * samples_per_ray * args.steps               # field evaluations on this rank
         ddf_s = tm["ddf_ms"] / 1e3
         achieved = pts * DDF_FLOP_PER_POINT / ddf_s / 1e12 if ddf_s > 0 else 0.0
         line = {
-            "metric": "rendered rays/sec (800x800, 128 samples/ray)",
+            "metric": "rendered rays/sec (800x800, 128 samples/ray)" if args.workload == "c2" else
+                      "rendered rays/sec (800x800, 65 coarse + 194 fine hierarchical samples/ray)",
             "value": n_rays * world * args.steps / elapsed,
             "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,7 +192,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: 800x800 view, 128 stratified cone samples/ray, NeDDF "
                                    "(8x256 distance trunk with Jacobian rows + 4x256 colour trunk) fp32, 1 view per GPU "
                                    "per step, synthetic poses, shipped bunny_smoke weights",
-                       "rays_per_step_per_gpu": n_rays, "samples_per_ray": SAMPLES, "parallelism": "ray-parallel x%d" % world},
+                       "rays_per_step_per_gpu": n_rays, "samples_per_ray": samples_per_ray, "workload_id": args.workload, "parallelism": "ray-parallel x%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                          "kernel": "neddf::ddf_trunk_kernel", "launches": tm["ddf_launches"],
@@ -181,6 +201,14 @@ def main():
                          "colour_kernel": {"avg_launch_ms": tm["col_ms"] / max(tm["col_launches"], 1),
                                            "achieved": (pts * COL_FLOP_PER_POINT / (tm["col_ms"] / 1e3) / 1e12) if tm["col_ms"] > 0 else 0.0}},
         }
+        try:        # HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            ent = next(v for k, v in pmc.items() if "ddf_trunk_kernel" in k)
+            line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
+            line["roofline"]["traffic_source"] = ent["source"]
+            line["roofline"]["algorithmic_hbm_bytes_per_launch"] = ent["algorithmic_bytes_per_launch"]
+        except Exception:
+            pass
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights, R, T, calib.astype(np.float32))
         nan = int(res["_nan"].item()) if isinstance(res, dict) else 0

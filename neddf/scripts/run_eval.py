@@ -1,0 +1,8 @@
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from neddf_amd.scripts.run_eval import main  # noqa: E402
+
+if __name__ == "__main__":
+    main()

@@ -374,22 +374,43 @@ void orc_pe(const float *x, const float *scale, int N, int E, float *y)
 }
 
 /* ------------------------------------------------------------------------ */
-/* dense layer on a block of rows: out[r][j] = sum_k in[r][k] W[k][j] (+ b[j]) */
+/* dense layer on a block of rows: out[r][j] = sum_k in[r][k] W[k][j] (+ b[j]).
+ * Register-blocked (4 rows x 16 columns per inner kernel) so that it vectorises
+ * to FMA; every output element is still one k-ascending fmaf chain. */
 static void orc_dense(const float *in, int ldin, int rows, const float *W, const float *b, int Cin, int Cout,
                       float *out, int ldout, int bias_every /* bias on rows r % bias_every == 0; 0 = none */)
 {
-    for (int r = 0; r < rows; ++r) {
-        float *o = out + (size_t)r * ldout;
-        for (int j = 0; j < Cout; ++j) o[j] = 0.f;
-    }
-    for (int k = 0; k < Cin; ++k) {
-        const float *wr = W + (size_t)k * Cout;
-        for (int r = 0; r < rows; ++r) {
-            float a = in[(size_t)r * ldin + k];
-            float *o = out + (size_t)r * ldout;
-            for (int j = 0; j < Cout; ++j) o[j] = fmaf(a, wr[j], o[j]);
+    int j0 = 0;
+    for (; j0 + 16 <= Cout; j0 += 16) {
+        for (int r0 = 0; r0 < rows; r0 += 4) {
+            const int nr = rows - r0 < 4 ? rows - r0 : 4;
+            float acc[4][16];
+            for (int r = 0; r < 4; ++r)
+                for (int jj = 0; jj < 16; ++jj) acc[r][jj] = 0.f;
+            const float *i0 = in + (size_t)r0 * ldin;
+            const float *i1 = in + (size_t)(r0 + (nr > 1 ? 1 : 0)) * ldin;
+            const float *i2 = in + (size_t)(r0 + (nr > 2 ? 2 : 0)) * ldin;
+            const float *i3 = in + (size_t)(r0 + (nr > 3 ? 3 : 0)) * ldin;
+            for (int k = 0; k < Cin; ++k) {
+                const float *wr = W + (size_t)k * Cout + j0;
+                const float a0 = i0[k], a1 = i1[k], a2 = i2[k], a3 = i3[k];
+                for (int jj = 0; jj < 16; ++jj) {
+                    acc[0][jj] = fmaf(a0, wr[jj], acc[0][jj]);
+                    acc[1][jj] = fmaf(a1, wr[jj], acc[1][jj]);
+                    acc[2][jj] = fmaf(a2, wr[jj], acc[2][jj]);
+                    acc[3][jj] = fmaf(a3, wr[jj], acc[3][jj]);
+                }
+            }
+            for (int r = 0; r < nr; ++r)
+                for (int jj = 0; jj < 16; ++jj) out[(size_t)(r0 + r) * ldout + j0 + jj] = acc[r][jj];
         }
     }
+    for (; j0 < Cout; ++j0)            /* column tail (heads: 1 or 3 outputs) */
+        for (int r = 0; r < rows; ++r) {
+            float acc = 0.f;
+            for (int k = 0; k < Cin; ++k) acc = fmaf(in[(size_t)r * ldin + k], W[(size_t)k * Cout + j0], acc);
+            out[(size_t)r * ldout + j0] = acc;
+        }
     if (b && bias_every)
         for (int r = 0; r < rows; r += bias_every) {
             float *o = out + (size_t)r * ldout;
@@ -425,151 +446,175 @@ static int orc_in_skips(const int *skips, int n, int id)
 }
 
 /* NeDDF.forward neddf.py:162-309 for N points (pos/dir/var [N,3]).
- * Outputs (any may be NULL): distance, density, color[N,3], fields_penalty, aux_grad;
- * extra (optional, for stage tests): features [N,W]. */
+ * Outputs (any may be NULL): distance, density, color[N,3], fields_penalty, aux_grad.
+ * Points are processed in blocks of ORC_PB so that a weight row streamed from
+ * cache feeds ORC_PB*4 activation rows (the per-row arithmetic and its order
+ * are those of a point-at-a-time evaluation). */
+#define ORC_PB 8
 void orc_neddf_forward(const orc_neddf_t *net, const float *pos, const float *dir, const float *var, int N,
                        float *distance, float *density, float *color, float *penalty, float *aux_grad_out)
 {
     const int E = net->embed_pos_rank, Ed = net->embed_dir_rank;
     const int Cpe = 6 * E, Cdir = 6 * Ed, W = net->ddf_width, Wc = net->col_width;
     const int in_col = Cpe + Cdir + 3 + W;
+    const int nblk = (N + ORC_PB - 1) / ORC_PB;
 #pragma omp parallel
     {
-        const int LD = ORC_MAX_IN;
-        float *bufA = (float *)malloc(sizeof(float) * 4 * LD);
-        float *bufB = (float *)malloc(sizeof(float) * 4 * LD);
-        float *pe_s = (float *)malloc(sizeof(float) * 4 * Cpe);   /* embed_pos_scaled value + J rows */
-        float *pe_u = (float *)malloc(sizeof(float) * 4 * Cpe);   /* embed_pos (unscaled by grad scale) */
-        float *pe_d = (float *)malloc(sizeof(float) * Cdir);
-#pragma omp for schedule(static)
-        for (int n = 0; n < N; ++n) {
-            const float *x = pos + 3 * n;
-            /* :193-209 positional encodings; J_in = I3 (:186-191) */
-            memset(pe_s, 0, sizeof(float) * 4 * Cpe);
-            memset(pe_u, 0, sizeof(float) * 4 * Cpe);
-            for (int e = 0; e < E; ++e) {
-                float f = ldexpf(1.0f, e);
-                float gs = 1.0f / (0.5f * f);                /* get_grad_scale with_grad/positional_encoding.py:130-135 */
-                float lp = net->lowpass[e];
-                for (int d = 0; d < 3; ++d) {
-                    int c = e * 3 + d;
-                    float w = expf(-0.5f * (f * f) * var[3 * n + d]);  /* sampling.py:71 */
-                    float p = f * x[d];
-                    float sn = sinf(p), cs = cosf(p);
-                    float s1 = gs * lp * w;
-                    float s2 = lp * w;
-                    pe_s[c] = s1 * sn;           pe_s[3 * E + c] = s1 * cs;
-                    pe_u[c] = s2 * sn;           pe_u[3 * E + c] = s2 * cs;
-                    float g1 = f * s1 * 1.0f, g2 = f * s2 * 1.0f;
-                    pe_s[(1 + d) * Cpe + c] = g1 * cs;  pe_s[(1 + d) * Cpe + 3 * E + c] = -g1 * sn;
-                    pe_u[(1 + d) * Cpe + c] = g2 * cs;  pe_u[(1 + d) * Cpe + 3 * E + c] = -g2 * sn;
+        const int LD = ORC_MAX_IN, R = 4 * ORC_PB;
+        float *bufA = (float *)malloc(sizeof(float) * R * LD);
+        float *bufB = (float *)malloc(sizeof(float) * R * LD);
+        float *pe_s = (float *)malloc(sizeof(float) * R * Cpe);   /* embed_pos_scaled value + J rows */
+        float *pe_u = (float *)malloc(sizeof(float) * R * Cpe);   /* embed_pos (not scaled by the grad scale) */
+        float *pe_d = (float *)malloc(sizeof(float) * ORC_PB * Cdir);
+        float *head = (float *)malloc(sizeof(float) * R), *aux4 = (float *)malloc(sizeof(float) * R);
+        float *col4 = (float *)malloc(sizeof(float) * R * 3);
+#pragma omp for schedule(dynamic, 4)
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int n0 = blk * ORC_PB;
+            const int np = (N - n0 < ORC_PB) ? N - n0 : ORC_PB;
+            const int rows = 4 * np;
+            memset(pe_s, 0, sizeof(float) * R * Cpe);
+            memset(pe_u, 0, sizeof(float) * R * Cpe);
+            for (int p = 0; p < np; ++p) {
+                const float *x = pos + 3 * (n0 + p);
+                float *ps = pe_s + 4 * p * Cpe, *pu = pe_u + 4 * p * Cpe;
+                /* :193-209 positional encodings; J_in = I3 (:186-191) */
+                for (int e = 0; e < E; ++e) {
+                    float f = ldexpf(1.0f, e);
+                    float gs = 1.0f / (0.5f * f);                /* get_grad_scale with_grad/positional_encoding.py:130-135 */
+                    float lp = net->lowpass[e];
+                    for (int d = 0; d < 3; ++d) {
+                        int c = e * 3 + d;
+                        float w = expf(-0.5f * (f * f) * var[3 * (n0 + p) + d]);  /* sampling.py:71 */
+                        float ph = f * x[d];
+                        float sn = sinf(ph), cs = cosf(ph);
+                        float s1 = gs * lp * w;
+                        float s2 = lp * w;
+                        ps[c] = s1 * sn;           ps[3 * E + c] = s1 * cs;
+                        pu[c] = s2 * sn;           pu[3 * E + c] = s2 * cs;
+                        float g1 = f * s1 * 1.0f, g2 = f * s2 * 1.0f;
+                        ps[(1 + d) * Cpe + c] = g1 * cs;  ps[(1 + d) * Cpe + 3 * E + c] = -g1 * sn;
+                        pu[(1 + d) * Cpe + c] = g2 * cs;  pu[(1 + d) * Cpe + 3 * E + c] = -g2 * sn;
+                    }
                 }
+                for (int e = 0; e < Ed; ++e)
+                    for (int d = 0; d < 3; ++d) {    /* :210, PositionalEncoding */
+                        float ph = ldexpf(1.0f, e) * dir[3 * (n0 + p) + d];
+                        pe_d[p * Cdir + e * 3 + d] = sinf(ph);
+                        pe_d[p * Cdir + 3 * Ed + e * 3 + d] = cosf(ph);
+                    }
             }
-            for (int e = 0; e < Ed; ++e)
-                for (int d = 0; d < 3; ++d) {    /* :210, PositionalEncoding */
-                    float p = ldexpf(1.0f, e) * dir[3 * n + d];
-                    pe_d[e * 3 + d] = sinf(p);
-                    pe_d[3 * Ed + e * 3 + d] = cosf(p);
-                }
             /* :212-219 distance trunk with (value, Jacobian) rows */
             float *h = bufA, *o = bufB;
             int cin = Cpe;
-            for (int r = 0; r < 4; ++r) memcpy(h + r * LD, pe_s + r * Cpe, sizeof(float) * Cpe);
+            for (int r = 0; r < rows; ++r) memcpy(h + r * LD, pe_s + r * Cpe, sizeof(float) * Cpe);
             for (int l = 0; l < net->n_ddf; ++l) {
                 int off = orc_in_skips(net->skips, net->n_skips, l) ? Cpe : 0;   /* room for the concat */
-                orc_dense(h, LD, 4, net->ddf_w[l], net->ddf_b[l], cin, W, o + off, LD, 4);
-                for (int j = 0; j < W; ++j) {
-                    float y, dy;
-                    orc_act_grad(net->activation, o[off + j], &y, &dy);
-                    o[off + j] = y;
-                    for (int r = 1; r < 4; ++r) o[r * LD + off + j] = dy * o[r * LD + off + j];
+                orc_dense(h, LD, rows, net->ddf_w[l], net->ddf_b[l], cin, W, o + off, LD, 4);
+                for (int p = 0; p < np; ++p) {
+                    float *o0 = o + (4 * p) * LD + off;
+                    for (int j = 0; j < W; ++j) {
+                        float y, dy;
+                        orc_act_grad(net->activation, o0[j], &y, &dy);
+                        o0[j] = y;
+                        for (int r = 1; r < 4; ++r) o0[r * LD + j] = dy * o0[r * LD + j];
+                    }
                 }
                 cin = W;
                 if (off) {      /* :217-219 cat([embed_pos_scaled, h]) -- embedding first */
-                    for (int r = 0; r < 4; ++r) memcpy(o + r * LD, pe_s + r * Cpe, sizeof(float) * Cpe);
+                    for (int r = 0; r < rows; ++r) memcpy(o + r * LD, pe_s + r * Cpe, sizeof(float) * Cpe);
                     cin = W + Cpe;
                 }
                 float *t = h; h = o; o = t;
             }
             /* heads :220-241 */
-            float head[4 * 2];
-            orc_dense(h, LD, 4, net->ddf_out_w, net->ddf_out_b, cin, 1, head, 1, 4);
-            float aux4[4];
-            orc_dense(h, LD, 4, net->aux_out_w, net->aux_out_b, cin, 1, aux4, 1, 4);
-            float sp, dsp;
-            orc_softplus_grad(head[0], &sp, &dsp);
-            float D = sp + net->d_near;
-            float dg[3] = { dsp * head[1], dsp * head[2], dsp * head[3] };
-            float sg, dsg;
-            orc_sigmoid_grad(aux4[0], &sg, &dsg);
-            float aux = net->aux_grad_scale * sg;
-            float aux_gg[3] = { net->aux_grad_scale * (dsg * aux4[1]), net->aux_grad_scale * (dsg * aux4[2]),
-                                net->aux_grad_scale * (dsg * aux4[3]) };
-            float dgn = sqrtf(dg[0] * dg[0] + dg[1] * dg[1] + dg[2] * dg[2]);
-            float dDdt = sqrtf(dg[0] * dg[0] + dg[1] * dg[1] + dg[2] * dg[2] + aux * aux);
-            float Dinv = 1.0f / D;
-            float rho = orc_act(net->density_activation, Dinv * (1 - dDdt));
-            float ninv = 1.0f / (dgn + 1e-7f);
-            float nd[3] = { ninv * dg[0], ninv * dg[1], ninv * dg[2] };
-            /* colour trunk :243-257; Jacobian of dir/normal columns is zero */
+            orc_dense(h, LD, rows, net->ddf_out_w, net->ddf_out_b, cin, 1, head, 1, 4);
+            orc_dense(h, LD, rows, net->aux_out_w, net->aux_out_b, cin, 1, aux4, 1, 4);
+            float D_[ORC_PB], rho_[ORC_PB], aux_[ORC_PB], dgn_[ORC_PB], dDdt_[ORC_PB], dg_[ORC_PB][3], agg_[ORC_PB][3], nd_[ORC_PB][3];
             float *c_in = o;
-            for (int r = 0; r < 4; ++r) {
-                float *row = c_in + r * LD;
-                memcpy(row, pe_u + r * Cpe, sizeof(float) * Cpe);
-                for (int j = 0; j < Cdir + 3; ++j) row[Cpe + j] = 0.f;
-                memcpy(row + Cpe + Cdir + 3, h + r * LD + (cin - W), sizeof(float) * W);
+            for (int p = 0; p < np; ++p) {
+                const float *hd = head + 4 * p, *ax = aux4 + 4 * p;
+                float sp, dsp;
+                orc_softplus_grad(hd[0], &sp, &dsp);
+                float D = sp + net->d_near;
+                float dg[3] = { dsp * hd[1], dsp * hd[2], dsp * hd[3] };
+                float sg, dsg;
+                orc_sigmoid_grad(ax[0], &sg, &dsg);
+                float aux = net->aux_grad_scale * sg;
+                for (int i = 0; i < 3; ++i) agg_[p][i] = net->aux_grad_scale * (dsg * ax[1 + i]);
+                float dgn = sqrtf(dg[0] * dg[0] + dg[1] * dg[1] + dg[2] * dg[2]);
+                float dDdt = sqrtf(dg[0] * dg[0] + dg[1] * dg[1] + dg[2] * dg[2] + aux * aux);
+                float Dinv = 1.0f / D;
+                rho_[p] = orc_act(net->density_activation, Dinv * (1 - dDdt));
+                float ninv = 1.0f / (dgn + 1e-7f);
+                for (int i = 0; i < 3; ++i) { nd_[p][i] = ninv * dg[i]; dg_[p][i] = dg[i]; }
+                D_[p] = D; aux_[p] = aux; dgn_[p] = dgn; dDdt_[p] = dDdt;
+                /* colour trunk input :243-253; Jacobian of dir/normal columns is zero */
+                for (int r = 0; r < 4; ++r) {
+                    float *row = c_in + (4 * p + r) * LD;
+                    memcpy(row, pe_u + (4 * p + r) * Cpe, sizeof(float) * Cpe);
+                    for (int j = 0; j < Cdir + 3; ++j) row[Cpe + j] = 0.f;
+                    memcpy(row + Cpe + Cdir + 3, h + (4 * p + r) * LD + (cin - W), sizeof(float) * W);
+                }
+                memcpy(c_in + (4 * p) * LD + Cpe, pe_d + p * Cdir, sizeof(float) * Cdir);
+                for (int i = 0; i < 3; ++i) c_in[(4 * p) * LD + Cpe + Cdir + i] = nd_[p][i];
             }
-            memcpy(c_in + Cpe, pe_d, sizeof(float) * Cdir);
-            for (int i = 0; i < 3; ++i) c_in[Cpe + Cdir + i] = nd[i];
             float *ci = c_in, *co = h;
             int ccin = in_col;
-            for (int l = 0; l < net->n_col; ++l) {
-                orc_dense(ci, LD, 4, net->col_w[l], net->col_b[l], ccin, Wc, co, LD, 4);
-                for (int j = 0; j < Wc; ++j) {
-                    float y, dy;
-                    orc_act_grad(net->activation, co[j], &y, &dy);
-                    co[j] = y;
-                    for (int r = 1; r < 4; ++r) co[r * LD + j] = dy * co[r * LD + j];
+            for (int l = 0; l < net->n_col; ++l) {              /* :254-256 */
+                orc_dense(ci, LD, rows, net->col_w[l], net->col_b[l], ccin, Wc, co, LD, 4);
+                for (int p = 0; p < np; ++p) {
+                    float *o0 = co + (4 * p) * LD;
+                    for (int j = 0; j < Wc; ++j) {
+                        float y, dy;
+                        orc_act_grad(net->activation, o0[j], &y, &dy);
+                        o0[j] = y;
+                        for (int r = 1; r < 4; ++r) o0[r * LD + j] = dy * o0[r * LD + j];
+                    }
                 }
                 ccin = Wc;
                 float *t = ci; ci = co; co = t;
             }
-            float col4[4 * 3];
-            orc_dense(ci, LD, 4, net->col_out_w, net->col_out_b, ccin, 3, col4, 3, 4);
-            /* penalties :260-300 */
-            float pen[6];
-            float d2 = aux_gg[0] * nd[0] + aux_gg[1] * nd[1] + aux_gg[2] * nd[2];
-            float rest = 3 * aux * Dinv;
-            float scale = aux * dgn * D;
-            pen[0] = scale * ((d2 - rest) * (d2 - rest));
-            float t1 = -1.0f + dDdt; t1 = t1 > 0 ? t1 : 0;
-            pen[1] = t1 * t1;
-            float a1 = -4.6f - head[0]; a1 = a1 > 0 ? a1 : 0;
-            float a2 = -net->distance_range_max + head[0]; a2 = a2 > 0 ? a2 : 0;
-            pen[2] = (a1 + a2) * (a1 + a2);
-            float b1 = -4.6f - aux4[0]; b1 = b1 > 0 ? b1 : 0;
-            float b2 = -4.6f + aux4[0]; b2 = b2 > 0 ? b2 : 0;
-            pen[3] = (b1 + b2) * (b1 + b2);
-            pen[4] = 0.f;
-            for (int k = 0; k < 3; ++k) {
-                float c1 = -0.0f - col4[k]; c1 = c1 > 0 ? c1 : 0;
-                float c2 = -1.0f + col4[k]; c2 = c2 > 0 ? c2 : 0;
-                pen[4] += (c1 + c2) * (c1 + c2);
+            orc_dense(ci, LD, rows, net->col_out_w, net->col_out_b, ccin, 3, col4, 3, 4);
+            for (int p = 0; p < np; ++p) {
+                const int n = n0 + p;
+                const float *c4 = col4 + 12 * p, *hd = head + 4 * p, *ax = aux4 + 4 * p;
+                float D = D_[p], aux = aux_[p], Dinv = 1.0f / D;
+                /* penalties :260-300 */
+                float pen[6];
+                float d2 = agg_[p][0] * nd_[p][0] + agg_[p][1] * nd_[p][1] + agg_[p][2] * nd_[p][2];
+                float rest = 3 * aux * Dinv;
+                float scale = aux * dgn_[p] * D;
+                pen[0] = scale * ((d2 - rest) * (d2 - rest));
+                float t1 = -1.0f + dDdt_[p]; t1 = t1 > 0 ? t1 : 0;
+                pen[1] = t1 * t1;
+                float a1 = -4.6f - hd[0]; a1 = a1 > 0 ? a1 : 0;
+                float a2 = -net->distance_range_max + hd[0]; a2 = a2 > 0 ? a2 : 0;
+                pen[2] = (a1 + a2) * (a1 + a2);
+                float b1 = -4.6f - ax[0]; b1 = b1 > 0 ? b1 : 0;
+                float b2 = -4.6f + ax[0]; b2 = b2 > 0 ? b2 : 0;
+                pen[3] = (b1 + b2) * (b1 + b2);
+                pen[4] = 0.f;
+                for (int k = 0; k < 3; ++k) {
+                    float c1 = -0.0f - c4[k]; c1 = c1 > 0 ? c1 : 0;
+                    float c2 = -1.0f + c4[k]; c2 = c2 > 0 ? c2 : 0;
+                    pen[4] += (c1 + c2) * (c1 + c2);
+                }
+                pen[5] = 0.f;
+                for (int k = 0; k < 3; ++k) {
+                    float s = c4[3 + k] * dg_[p][0] + c4[6 + k] * dg_[p][1] + c4[9 + k] * dg_[p][2];
+                    pen[5] += s * s;
+                }
+                float ptot = 0.f;
+                for (int k = 0; k < 6; ++k) ptot += net->penalty_has[k] ? pen[k] * net->penalty_weight[k] : pen[k];
+                if (distance) distance[n] = D;
+                if (density) density[n] = rho_[p];
+                if (color) { color[3 * n] = c4[0]; color[3 * n + 1] = c4[1]; color[3 * n + 2] = c4[2]; }
+                if (penalty) penalty[n] = ptot;
+                if (aux_grad_out) aux_grad_out[n] = aux;
             }
-            pen[5] = 0.f;
-            for (int k = 0; k < 3; ++k) {
-                float s = col4[3 + k] * dg[0] + col4[6 + k] * dg[1] + col4[9 + k] * dg[2];
-                pen[5] += s * s;
-            }
-            float ptot = 0.f;
-            for (int k = 0; k < 6; ++k) ptot += net->penalty_has[k] ? pen[k] * net->penalty_weight[k] : pen[k];
-            if (distance) distance[n] = D;
-            if (density) density[n] = rho;
-            if (color) { color[3 * n] = col4[0]; color[3 * n + 1] = col4[1]; color[3 * n + 2] = col4[2]; }
-            if (penalty) penalty[n] = ptot;
-            if (aux_grad_out) aux_grad_out[n] = aux;
         }
-        free(bufA); free(bufB); free(pe_s); free(pe_u); free(pe_d);
+        free(bufA); free(bufB); free(pe_s); free(pe_u); free(pe_d); free(head); free(aux4); free(col4);
     }
 }
 

@@ -205,3 +205,72 @@ def test_sharded_gather_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def _make_dataset(root, n=2, w=20, h=16, seed=0):
+    import json
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(root, "test"), exist_ok=True)
+    tf = golden("bunny_stages.npz")
+    frames = []
+    for i in range(n):
+        rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        Image.fromarray(rgba, "RGBA").save(os.path.join(root, "test", "r_%d.png" % i))
+        m = np.eye(4)
+        m[:3, :3] = tf["R"] @ Rotation.from_euler("z", 0.3 * i).as_matrix()
+        m[:3, 3] = tf["T"]
+        frames.append({"file_path": "./test/r_%d" % i, "transform_matrix": m.tolist()})
+    json.dump({"camera_angle_x": 0.6911112070083618, "frames": frames}, open(os.path.join(root, "transforms_test.json"), "w"))
+    return frames
+
+
+def test_dataset_reader(tmp_path):
+    """nerf_synthetic_dataset.py:25-84 semantics on a synthetic RGBA dataset (BGR order, premultiplied alpha)."""
+    from PIL import Image
+    from neddf_amd.dataset import NeRFSyntheticDataset, imread_unchanged_bgr, imwrite_bgr
+    root = str(tmp_path / "ds")
+    _make_dataset(root)
+    ds = NeRFSyntheticDataset(root, "test", use_depth=False, use_mask=True)
+    assert len(ds) == 2 and ds.image_width == 20 and ds.image_height == 16
+    rgba = np.asarray(Image.open(os.path.join(root, "test", "r_1.png")))
+    item = ds[1]
+    want = (1.0 / 256) * rgba[:, :, 3:4].astype(np.float32) * rgba[:, :, [2, 1, 0]].astype(np.float32)
+    assert np.array_equal(item["rgb_images"], want) and np.array_equal(item["mask_images"], rgba[:, :, 3])
+    f = 0.5 * 20 / np.tan(0.5 * 0.6911112070083618)
+    assert np.allclose(item["camera_calib_params"], [f, f, 10.0, 8.0])
+    assert item["camera_params"].shape == (6,) and item["camera_params"].dtype == np.float32
+    ds2 = NeRFSyntheticDataset(root, "test", use_mask=False)
+    assert np.array_equal(ds2[0]["rgb_images"], np.asarray(Image.open(os.path.join(root, "test", "r_0.png")))[:, :, [2, 1, 0]].astype(np.float32))
+    assert (ds2[0]["mask_images"] == 255).all()
+    # imwrite/imread round trip keeps the BGR convention
+    p = str(tmp_path / "x.png")
+    img = np.random.default_rng(1).integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    imwrite_bgr(p, img)
+    assert np.array_equal(imread_unchanged_bgr(p), img)
+    assert np.array_equal(np.asarray(Image.open(p)), img[:, :, ::-1])
+
+
+def test_metrics_against_direct_evaluation():
+    from neddf_amd.metrics import peak_signal_noise_ratio, structural_similarity
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (24, 31, 3), dtype=np.uint8)
+    b = np.clip(a.astype(int) + rng.integers(-20, 21, a.shape), 0, 255).astype(np.uint8)
+    mse = np.mean((a.astype(float) - b.astype(float)) ** 2)
+    assert abs(peak_signal_noise_ratio(a, b) - 10 * np.log10(255 ** 2 / mse)) < 1e-9
+    # brute-force SSIM over every fully-inside 7x7 window
+    tot = []
+    for c in range(3):
+        x, y = a[:, :, c].astype(float), b[:, :, c].astype(float)
+        vals = []
+        for i in range(3, 24 - 3):
+            for j in range(3, 31 - 3):
+                wx, wy = x[i - 3:i + 4, j - 3:j + 4].ravel(), y[i - 3:i + 4, j - 3:j + 4].ravel()
+                ux, uy = wx.mean(), wy.mean()
+                vx, vy = wx.var(ddof=1), wy.var(ddof=1)
+                vxy = np.sum((wx - ux) * (wy - uy)) / 48
+                c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+                vals.append((2 * ux * uy + c1) * (2 * vxy + c2) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2)))
+        tot.append(np.mean(vals))
+    assert abs(structural_similarity(a, b, channel_axis=2) - np.mean(tot)) < 1e-9
+    assert structural_similarity(a, a) == 1.0
