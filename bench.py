@@ -70,7 +70,7 @@ def cpu_baseline(weights, R, T, calib, budget_s=15.0):
     from conftest import BUNNY_CFG
     from oracle import oracle as orc
     net = orc.NeDDFOracle(weights, **BUNNY_CFG)
-    threads = os.cpu_count() or 1
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     rng = np.random.default_rng(0)
     n_rays, rate, spent, total = 256, 0.0, 0.0, 0
     while True:

@@ -141,6 +141,28 @@ int neddf_importance_resample(neddf_ctx *ctx, const float *d_dists, float *d_wei
                               int64_t n_rays, int n, int n_fine, int cat_coarse, float *d_out, int64_t *d_ids,
                               void *stream);
 
+/* ---- stand-alone layer ops (neddf/nn_module): unit-level counterparts of what the
+ * fused field kernels do internally; same device code as their epilogues. ---- */
+enum { NEDDF_OP_RELU = 0, NEDDF_OP_LEAKY = 1, NEDDF_OP_TANHEXP = 2, NEDDF_OP_SOFTPLUS = 3, NEDDF_OP_SIGMOID = 4 };
+/* {ReLU,LeakyReLU,TanhExp,Softplus,Sigmoid}GradFunction.forward (with_grad/{relu,leaky_relu,tanh_exp,softplus,sigmoid}.py):
+ * d_x [N,C], d_J [N,3,C] -> d_y [N,C], d_G [N,3,C].  With d_J == NULL: the plain
+ * activation (F.relu / F.leaky_relu / tanhExp, nn_module/tanh_exp.py:15-33). */
+int neddf_op_activation(neddf_ctx *ctx, int op, const float *d_x, const float *d_J, int64_t N, int C, float *d_y,
+                        float *d_G, void *stream);
+/* PositionalEncodingGradLayer.forward (with_grad/positional_encoding.py:34-87) when
+ * d_J != NULL, PositionalEncoding.forward (positional_encoding.py:37-65) otherwise.
+ * d_x [N,3], d_J [N,3,3], d_scale [N,3E] or NULL -> d_y [N,6E], d_G [N,3,6E]. */
+int neddf_op_positional_encoding(neddf_ctx *ctx, const float *d_x, const float *d_J, const float *d_scale, int64_t N,
+                                 int embed_dim, float *d_y, float *d_G, void *stream);
+/* Sampling.get_pe_weights (sampling.py:44-71): d_var [N,3] -> d_w [N,3E] */
+int neddf_op_pe_weights(neddf_ctx *ctx, const float *d_var, int64_t N, int embed_dim, float *d_w, void *stream);
+/* LinearGradFunction.forward (with_grad/linear.py:15-46) on the MFMA tile engine:
+ * y = xW + b, G = JW.  h_W [Cin,Cout] / h_b [Cout] are HOST arrays (packed + uploaded
+ * per call: this op is a test/compat entry point, the renderer keeps weights resident).
+ * Supported: Cin <= 256, Cout in {128, 256}. */
+int neddf_op_linear_grad(neddf_ctx *ctx, const float *d_x, const float *d_J, const float *h_W, const float *h_b,
+                         int64_t N, int Cin, int Cout, float *d_y, float *d_G, void *stream);
+
 /* Outputs of the fused renderer; every pointer may be NULL. Shapes per ray. */
 typedef struct {
     float *color;            /* [3] */

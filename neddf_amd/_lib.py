@@ -74,6 +74,10 @@ SYMBOLS = [
                                     C.POINTER(RenderOutputs), _vp]),
     ("neddf_render_rays_single", C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, C.POINTER(CameraDesc),
                                            C.POINTER(RenderParams), C.c_int, _vp, C.POINTER(RenderOutputs), _vp]),
+    ("neddf_op_activation", C.c_int, [_vp, C.c_int, _vp, _vp, _i64, C.c_int, _vp, _vp, _vp]),
+    ("neddf_op_positional_encoding", C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, _vp, _vp, _vp]),
+    ("neddf_op_pe_weights", C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
+    ("neddf_op_linear_grad", C.c_int, [_vp, _vp, _vp, _fp, _fp, _i64, C.c_int, C.c_int, _vp, _vp, _vp]),
     ("neddf_set_timing", C.c_int, [_vp, C.c_int]),
     ("neddf_get_timings", C.c_int, [_vp, _fp, C.c_int]),
 ]
@@ -256,6 +260,55 @@ class Context:
             self.check(self.lib.neddf_render_rays_single(self.h, single_slot, _ptr(uv), UV_TYPES[uv.dtype], uv.shape[0],
                                                          C.byref(cam), C.byref(params), U_coarse.shape[1], _ptr(U_coarse),
                                                          C.byref(ro), self.stream()))
+
+    # ----------------------------------------------------------- stand-alone ops
+    def op_activation(self, op, x, J=None):
+        require_device(x, "x")
+        x = f32c(x)
+        y = torch.empty_like(x)
+        if J is None:
+            self.check(self.lib.neddf_op_activation(self.h, op, _ptr(x), None, x.shape[0], x.shape[1], _ptr(y), None, self.stream()))
+            return y
+        J = f32c(J)
+        G = torch.empty_like(J)
+        self.check(self.lib.neddf_op_activation(self.h, op, _ptr(x), _ptr(J), x.shape[0], x.shape[1], _ptr(y), _ptr(G), self.stream()))
+        return y, G
+
+    def op_positional_encoding(self, x, J, scale, embed_dim):
+        require_device(x, "x")
+        x = f32c(x)
+        N = x.shape[0]
+        if scale is not None:
+            scale = f32c(scale.to(x.device).expand(N, 3 * embed_dim))
+        y = torch.empty(N, 6 * embed_dim, device=x.device, dtype=torch.float32)
+        G = None
+        if J is not None:
+            J = f32c(J)
+            G = torch.empty(N, 3, 6 * embed_dim, device=x.device, dtype=torch.float32)
+        self.check(self.lib.neddf_op_positional_encoding(self.h, _ptr(x), _ptr(J), _ptr(scale), N, embed_dim, _ptr(y), _ptr(G),
+                                                         self.stream()))
+        return y if J is None else (y, G)
+
+    def op_pe_weights(self, var, embed_dim):
+        require_device(var, "diag_variance")
+        var = f32c(var).reshape(-1, 3)
+        w = torch.empty(var.shape[0], 3 * embed_dim, device=var.device, dtype=torch.float32)
+        self.check(self.lib.neddf_op_pe_weights(self.h, _ptr(var), var.shape[0], embed_dim, _ptr(w), self.stream()))
+        return w
+
+    def op_linear_grad(self, x, J, weight_t, bias):
+        require_device(x, "x")
+        x, J = f32c(x), f32c(J)
+        hw = weight_t.detach().to("cpu", torch.float32).contiguous()
+        hb = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
+        N, cin = x.shape
+        cout = hw.shape[1]
+        y = torch.empty(N, cout, device=x.device, dtype=torch.float32)
+        G = torch.empty(N, 3, cout, device=x.device, dtype=torch.float32)
+        self.check(self.lib.neddf_op_linear_grad(self.h, _ptr(x), _ptr(J), C.cast(hw.data_ptr(), _fp),
+                                                 None if hb is None else C.cast(hb.data_ptr(), _fp), N, cin, cout, _ptr(y), _ptr(G),
+                                                 self.stream()))
+        return y, G
 
     def set_timing(self, on):
         self.check(self.lib.neddf_set_timing(self.h, int(on)))

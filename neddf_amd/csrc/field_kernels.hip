@@ -26,6 +26,7 @@
 // computed at tile start, while the encoding sits in LDS, and parked in a
 // per-workgroup global scratch in accumulator layout ("stash").
 #include "kernels.h"
+#include "device_math.h"
 
 #include <stdlib.h>
 
@@ -38,59 +39,6 @@ constexpr int MT_COL = 4;   // NeRF kernel: 128 rows = 128 points (value only)
 
 // ----------------------------------------------------------------------------
 // activations (with_grad/{relu,leaky_relu,tanh_exp}.py forward halves)
-// tanh(exp(x)) building blocks on the raw transcendental units: v_exp_f32 is
-// exp2 (<= 1 ulp), v_rcp_f32 <= 1 ulp.  u = e^x >= 0; tanh(u) = 1 - 2/(e^{2u}+1)
-// loses relative accuracy for small u (cancellation), so u < 0.3 uses the odd
-// Taylor polynomial to u^9 (truncation < 6e-8 relative at 0.3).  Measured against
-// fp64 over x in [-30, 20]: |err(y)| <= 1.8e-7, |err(y')| <= 1.2e-6 -- inside the
-// error of evaluating the reference formula itself in fp32 (2.3e-7 / 2.6e-6).
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
-
-__device__ __forceinline__ float tanh_nonneg(float u)
-{
-    float e2u = __builtin_amdgcn_exp2f((u + u) * 1.4426950408889634f);
-    float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e2u + 1.0f);
-    float p = u * u;
-    float poly = fmaf(p, fmaf(p, fmaf(p, fmaf(p, 62.0f / 2835.0f, -17.0f / 315.0f), 2.0f / 15.0f), -1.0f / 3.0f), 1.0f) * u;
-    return u < 0.3f ? poly : big;
-}
-
-template <int KIND>
-__device__ __forceinline__ void act_grad(float x, float &y, float &dy)
-{
-    if (KIND == 0) {            // relu.py:36-38, mask = x >= 0
-        float m = (x >= 0.f) ? 1.f : 0.f;
-        y = x * m; dy = m;
-    } else if (KIND == 1) {     // leaky_relu.py:36-39
-        float s = (x < 0.f) ? 0.01f : 1.f;
-        y = x * s; dy = s;
-    } else {                    // tanh_exp.py:38-46
-        float ex = fast_exp(x);
-        float tx = tanh_nonneg(ex);
-        float yy = x * tx;
-        float dd = fmaf(-(x * ex), fmaf(tx, tx, -1.0f), tx);      // tx - x*ex*(tx^2 - 1)
-        bool big = x > 20.0f;
-        y = big ? x : yy;
-        dy = big ? 1.0f : dd;
-    }
-}
-
-template <int KIND>
-__device__ __forceinline__ float act_val(float x)
-{
-    if (KIND == 0) return x > 0.f ? x : 0.f;            // F.relu
-    if (KIND == 1) return x > 0.f ? x : 0.01f * x;       // F.leaky_relu
-    float t = x * tanh_nonneg(fast_exp(x));              // nn_module/tanh_exp.py:28-31
-    return x > 20.0f ? x : t;
-}
-
-__device__ __forceinline__ float act_val_rt(int kind, float x)
-{
-    if (kind == 0) return act_val<0>(x);
-    if (kind == 1) return act_val<1>(x);
-    return act_val<2>(x);
-}
-
 // ----------------------------------------------------------------------------
 // dense: acc[mt][t] += act[rows, k0 .. k0+8*ksteps) x Wpacked
 template <int MT, int NT>
@@ -239,23 +187,18 @@ __device__ __forceinline__ void encode_pos(float *act, int col0, const EncodeDes
         int p = item / K3, q = item - p * K3;
         int e = q / 3, d = q - 3 * e;
         int64_t gp = p0 + p < N ? p0 + p : N - 1;
-        float f = (float)(1 << e);
-        float x = pos[gp * 3 + d], v = var[gp * 3 + d];
-        float w = expf(-0.5f * (f * f) * v);
-        float s = GRADSCALE ? ((1.0f / (0.5f * f)) * lp[e]) * w : lp[e] * w;
-        float sn, cs;
-        sincosf(f * x, &sn, &cs);
+        float vs, vc, js, jc;
+        pe_pair<GRADSCALE>(e, pos[gp * 3 + d], var[gp * 3 + d], lp[e], vs, vc, js, jc);
         if (ROWS4) {
             float *r0 = act + (4 * p) * kActLd + col0 + q;
-            r0[0] = s * sn;
-            r0[KH] = s * cs;
-            float g = f * s;
-            r0[(1 + d) * kActLd] = g * cs;
-            r0[(1 + d) * kActLd + KH] = -g * sn;
+            r0[0] = vs;
+            r0[KH] = vc;
+            r0[(1 + d) * kActLd] = js;
+            r0[(1 + d) * kActLd + KH] = jc;
         } else {
             float *r0 = act + p * kActLd + col0 + q;
-            r0[0] = s * sn;
-            r0[KH] = s * cs;
+            r0[0] = vs;
+            r0[KH] = vc;
         }
     }
 }
@@ -366,15 +309,11 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
             const int64_t gp = p0 + tid;
             float z = hd[4 * tid] + a.b_ddf_out;
             float az = hd[ROWS + 4 * tid] + a.b_aux_out;
-            // SoftplusGradFunction softplus.py:38-49 (log(1.0 + exp(x)), threshold 20)
-            bool big = z > 20.0f;
-            float sp = big ? z : logf(1.0f + expf(z));
-            float dsp = big ? 1.0f : 1.0f / (1.0f + expf(-z));
+            float sp, dsp, t, dsg;
+            softplus_grad(z, sp, dsp);               // softplus.py:38-49
             float D = sp + a.d_near;
             float dg0 = dsp * hd[4 * tid + 1], dg1 = dsp * hd[4 * tid + 2], dg2 = dsp * hd[4 * tid + 3];
-            // SigmoidGradFunction sigmoid.py:38-43
-            float t = (1.0f + tanhf(1.0f * az * 0.5f)) * 0.5f;
-            float dsg = 1.0f * t * (1 - t);
+            sigmoid_grad(az, t, dsg);                // sigmoid.py:38-43
             float aux = a.aux_grad_scale * t;
             float q2 = dg0 * dg0 + dg1 * dg1 + dg2 * dg2;
             float dgn = sqrtf(q2);
@@ -623,6 +562,62 @@ __global__ __launch_bounds__(kThreads, 1) void nerf_kernel(const NerfArgs a)
                 a.color[(p0 + tid) * 3 + k] = hd[tid * 3 + k] + hd[(ROWS + tid) * 3 + k] + a.b_col1[k];
         __syncthreads();
     }
+}
+
+// ----------------------------------------------------------------------------
+// LinearGradFunction.forward (linear.py:40-46) as a stand-alone op on the same tile
+// engine: y = xW + b, G = JW for N points; Cin <= 256 (zero-padded to 8), Cout = 128*NT.
+template <int NT>
+__global__ __launch_bounds__(kThreads, 1) void linear_grad_kernel(const float *x, const float *J, int64_t n_points, int cin,
+                                                                  int ksteps, const float *wp, const float *bias, float *y, float *G)
+{
+    constexpr int MT = 4, ROWS = MT * 32, P = MT * 8, COUT = NT * 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *act = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *act_lane = act + (lane & 31) * kActLd + 4 * (lane >> 5);
+    const int64_t ntiles = (n_points + P - 1) / P;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t p0 = tile * P;
+        zero_cols(act, ROWS, 8 * ksteps, tid);
+        __syncthreads();
+        for (int i = tid; i < ROWS * cin; i += kThreads) {
+            int r = i / cin, c = i - r * cin;
+            int64_t gp = p0 + (r >> 2);
+            if (gp < n_points) act[r * kActLd + c] = (r & 3) == 0 ? x[gp * cin + c] : J[(gp * 3 + (r & 3) - 1) * cin + c];
+        }
+        __syncthreads();
+        f32x16 acc[MT][NT];
+        acc_init<MT, NT, true>(acc, bias, wave, lane);
+        dense<MT, NT>(acc, act_lane, (const f32x4v *)wp + (size_t)wave * NT * ksteps * 64 + lane, ksteps);
+        const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int64_t gp = p0 + mt * 8 + 2 * g + h;
+                    int col = (wave * NT + t) * 32 + j;
+                    if (gp < n_points) {
+                        y[gp * COUT + col] = acc[mt][t][4 * g];
+#pragma unroll
+                        for (int r = 1; r < 4; ++r) G[(gp * 3 + r - 1) * COUT + col] = acc[mt][t][4 * g + r];
+                    }
+                }
+        __syncthreads();
+    }
+}
+
+void launch_linear_grad(const float *x, const float *J, int64_t n, int cin, int cout, int ksteps, const float *wp,
+                        const float *bias, float *y, float *G, int grid, hipStream_t s)
+{
+    size_t lds = field_lds_bytes(4);
+    static bool once = ((void)hipFuncSetAttribute((const void *)linear_grad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)field_lds_bytes(4)),
+                        (void)hipFuncSetAttribute((const void *)linear_grad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)field_lds_bytes(4)), true);
+    (void)once;
+    if (cout == 256) hipLaunchKernelGGL((linear_grad_kernel<2>), dim3(grid), dim3(kThreads), lds, s, x, J, n, cin, ksteps, wp, bias, y, G);
+    else hipLaunchKernelGGL((linear_grad_kernel<1>), dim3(grid), dim3(kThreads), lds, s, x, J, n, cin, ksteps, wp, bias, y, G);
 }
 
 // ----------------------------------------------------------------------------

@@ -634,6 +634,58 @@ int neddf_render_rays_single(neddf_ctx *ctx, int slot, const void *uv, int uv_ty
     return 0;
 }
 
+int neddf_op_activation(neddf_ctx *ctx, int op, const float *x, const float *J, int64_t N, int C, float *y, float *G, void *stream)
+{
+    if (!ctx || !x || !y || op < 0 || op > 4 || (J && !G)) return NEDDF_EINVAL;
+    if (!J && op > 2) return fail(ctx, NEDDF_EINVAL, "softplus/sigmoid exist only as (value, Jacobian) ops in the reference");
+    if (J && op == 4 && C != 1) return fail(ctx, NEDDF_EUNSUPPORTED, "SigmoidGradFunction is defined for one channel (sigmoid.py:42)");
+    launch_op_activation(op, x, J, N, C, y, G, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neddf_op_positional_encoding(neddf_ctx *ctx, const float *x, const float *J, const float *scale, int64_t N, int E, float *y,
+                                 float *G, void *stream)
+{
+    if (!ctx || !x || !y || E < 1 || E > 30 || (J && !G)) return NEDDF_EINVAL;
+    launch_op_pe(x, J, scale, N, E, y, G, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neddf_op_pe_weights(neddf_ctx *ctx, const float *var, int64_t N, int E, float *w, void *stream)
+{
+    if (!ctx || !var || !w || E < 1 || E > 30) return NEDDF_EINVAL;
+    launch_op_pe_weights(var, N, E, w, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neddf_op_linear_grad(neddf_ctx *ctx, const float *x, const float *J, const float *W, const float *b, int64_t N, int Cin,
+                         int Cout, float *y, float *G, void *stream)
+{
+    if (!ctx || !x || !J || !W || !y || !G) return NEDDF_EINVAL;
+    if (Cin < 1 || Cin > 256 || (Cout != 128 && Cout != 256)) return fail(ctx, NEDDF_EUNSUPPORTED, "op_linear_grad: Cin <= 256, Cout in {128, 256}");
+    if (N <= 0) return 0;
+    (void)hipSetDevice(ctx->device);
+    std::vector<float> blob;
+    std::vector<int> km;
+    for (int k = 0; k < roundup(Cin, 8); ++k) km.push_back(k < Cin ? k : -1);
+    Src src{ W, Cin, Cout, false };
+    size_t o_w = pack_layer(blob, src, km, Cout);
+    std::vector<float> zeros(Cout, 0.f);
+    size_t o_b = put(blob, b ? b : zeros.data(), Cout);
+    if (int rc = ensure(ctx, ctx->features, blob.size() * sizeof(float))) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->features.p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));       // blob is a host temporary
+    const float *base = (const float *)ctx->features.p;
+    int64_t tiles = (N + 31) / 32;
+    launch_linear_grad(x, J, N, Cin, Cout, (int)km.size() / 8, base + o_w, base + o_b, y, G, (int)(tiles < ctx->cus ? tiles : ctx->cus),
+                       (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int neddf_set_timing(neddf_ctx *ctx, int enable)
 {
     if (!ctx) return NEDDF_EINVAL;

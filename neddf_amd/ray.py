@@ -26,12 +26,13 @@ class Sampling:
     def get_pe_weights(self, freq: Tensor) -> Tensor:
         """exp(-0.5 f^2 var) per (frequency, axis) -> [N, len(freq)*3] (sampling.py:44-71).
 
-        Kept for API compatibility; the fused field kernels evaluate the same
-        weights on chip and never call this."""
-        with torch.no_grad():
-            var = self.diag_variance.reshape(-1, 1, self.diag_variance.shape[-1])
-            f2 = torch.square(freq.to(var.device)).reshape(1, -1, 1)
-            return torch.exp(-0.5 * f2 * var).reshape(var.shape[0], -1)
+        Stand-alone op for API compatibility; the fused field kernels evaluate
+        the same weights on chip and never call this."""
+        embed_dim = int(freq.shape[0])
+        expect = torch.tensor([2.0 ** t for t in range(embed_dim)])
+        if not torch.equal(freq.detach().cpu().to(torch.float32), expect):
+            raise ValueError("get_pe_weights: the HIP kernels assume the reference's frequencies 2**t")
+        return Context.get(self.device).op_pe_weights(self.diag_variance, embed_dim)
 
 
 class Ray:
