@@ -199,6 +199,7 @@ int neddf_render_rays_single(neddf_ctx *ctx, int slot, const void *d_uv, int uv_
  * ms[0..2] = summed duration of the distance-trunk / colour-trunk / NeRF kernel
  * launches, ms[3..5] = the corresponding launch counts; n must be >= 6. */
 int neddf_set_timing(neddf_ctx *ctx, int enable);
+
 int neddf_get_timings(neddf_ctx *ctx, float *ms, int n);
 
 #ifdef __cplusplus

@@ -65,6 +65,62 @@ __device__ __forceinline__ void dense_mfma(f32x16 (&acc)[MT][NT], const f32x4v (
 // Software pipeline, ping-pong operand registers: the operands of super-step
 // S+1 are requested (global -> VGPR for B, LDS -> VGPR for A) before the 32
 // MFMAs (2048 cycles) of super-step S issue.
+// Operands that do not depend on the previous layer's activations (first weight
+// fragments + bias) are requested BEFORE the activation epilogue / barriers of the
+// previous layer, so their L2 latency is off the critical path.
+template <int NT>
+struct LayerPre {
+    f32x4v b[NT];
+    float bias[NT];
+};
+
+template <int NT>
+__device__ __forceinline__ void layer_prefetch(LayerPre<NT> &p, const float *wp, const float *bias, int ksteps, int wave, int lane)
+{
+    const f32x4v *wl = (const f32x4v *)wp + (size_t)wave * NT * ksteps * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        p.b[t] = wl[(size_t)t * ksteps * 64];
+        p.bias[t] = bias ? bias[(wave * NT + t) * 32 + (lane & 31)] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int MT, int NT, bool ROWS4>
+__device__ __forceinline__ void acc_init_pre(f32x16 (&acc)[MT][NT], const LayerPre<NT> &p)
+{
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mt][t][q] = (ROWS4 && (q & 3)) ? 0.f : p.bias[t];
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void dense_pre(f32x16 (&acc)[MT][NT], const float *act_lane, const f32x4v *wl, int ksteps,
+                                          const LayerPre<NT> &p)
+{
+    f32x4v a0[MT], b0[NT], a1[MT], b1[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b0[t] = p.b[t];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a0[mt] = *(const f32x4v *)(act_lane + mt * 32 * kActLd);
+    for (int S = 0; S < ksteps; S += 2) {
+        const bool more = S + 1 < ksteps;
+        dense_load<MT, NT>(a1, b1, act_lane, wl, ksteps, more ? S + 1 : S);
+        __builtin_amdgcn_sched_barrier(0);
+        dense_mfma<MT, NT>(acc, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            dense_load<MT, NT>(a0, b0, act_lane, wl, ksteps, S + 2 < ksteps ? S + 2 : S);
+            __builtin_amdgcn_sched_barrier(0);
+            dense_mfma<MT, NT>(acc, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void dense(f32x16 (&acc)[MT][NT], const float *act_lane, const f32x4v *wl, int ksteps)
 {
@@ -222,6 +278,25 @@ __device__ __forceinline__ void encode_dir(float *act, int col0, const EncodeDes
 }
 
 // ----------------------------------------------------------------------------
+// Tile scheduling: tiles are pulled from a global queue (one atomicAdd per tile,
+// issued a whole tile ahead of its use) instead of a static stride, so workgroups
+// that progress unevenly (two share a CU) do not unbalance the launch tail.
+// sched_flags (NEDDF_SCHED, debug): bit 1 = dynamic queue (default on); bits 2..5
+// switch off phases of the distance kernel for timing ablations (results invalid).
+// ctl[0] = next tile index, written by thread 0.
+__device__ __forceinline__ int64_t sched_begin(int *sched, int flags, int *ctl, int tid)
+{
+    if (tid == 0) ctl[0] = (flags & 2) ? atomicAdd(&sched[0], 1) : (int)blockIdx.x;
+    __syncthreads();
+    return ctl[0];
+}
+
+__device__ __forceinline__ int sched_next(int *sched, int flags, int64_t tile)
+{
+    return (flags & 2) ? atomicAdd(&sched[0], 1) : (int)(tile + gridDim.x);
+}
+
+// ----------------------------------------------------------------------------
 // NeDDF distance trunk
 template <int MT, int WPS>
 __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs a)
@@ -229,8 +304,8 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
     constexpr int NT = 2, ROWS = MT * 32, P = MT * 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *act = smem;
-    float *hd = smem + ROWS * kActLd;       // [2][ROWS] head dot products
-    float *lp = hd + 2 * ROWS;              // [16]
+    float *hd = smem + ROWS * kActLd;       // [HSPLIT][2][ROWS] head dot products
+    float *lp = hd + 6 * ROWS;              // [16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *act_lane = act + (lane & 31) * kActLd + 4 * (lane >> 5);
     float *scratch = a.scratch + (size_t)blockIdx.x * kStashFloatsPerWg * kMaxStash;
@@ -241,11 +316,17 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
     const int kin = 2 * a.enc.KH;
     const int64_t ntiles = (a.n_points + P - 1) / P;
 
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int *ctl = (int *)(lp + 12);
+    int64_t tile = sched_begin(a.sched, a.sched_flags, ctl, tid);
+    while (tile < ntiles) {
         const int64_t p0 = tile * P;
+        LayerPre<NT> pre;
+        layer_prefetch<NT>(pre, a.layer[0].wp, a.layer[0].bias, a.layer[0].ksteps, wave, lane);
         zero_cols(act, ROWS, kin, tid);
         __syncthreads();
-        encode_pos<true, true>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
+        int next_tile = 0;
+        if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);     // consumed at the end of this tile
+        if (!(a.sched_flags & 32)) encode_pos<true, true>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
         __syncthreads();
 
         f32x16 acc[MT][NT];
@@ -270,7 +351,7 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
         }
         for (int l = 0; l < a.n_layers; ++l) {      // neddf.py:214-216
             const LayerW &L = a.layer[l];
-            acc_init<MT, NT, true>(acc, L.bias, wave, lane);
+            acc_init_pre<MT, NT, true>(acc, pre);
             if (L.stash >= 0) {
                 bool done = false;
                 if constexpr (REG_STASH) {
@@ -285,19 +366,30 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
                 if (!done) stash_add<MT, NT>(acc, scratch + (size_t)L.stash * kStashFloatsPerWg, wave, lane);
             }
             const f32x4v *wl = (const f32x4v *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane;
-            dense<MT, NT>(acc, act_lane, wl, L.ksteps);
+            if (!(a.sched_flags & 8)) dense_pre<MT, NT>(acc, act_lane, wl, L.ksteps, pre);
+            if (l + 1 < a.n_layers)                 // next layer's first fragments fly during the epilogue
+                layer_prefetch<NT>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
             __syncthreads();                        // every wave finished reading the previous activations
-            epilogue_rt<MT, NT, true>(acc, act, a.activation, wave, lane);
+            if (!(a.sched_flags & 4)) epilogue_rt<MT, NT, true>(acc, act, a.activation, wave, lane);
             __syncthreads();
         }
-        // heads (neddf.py:220-230): ddf_out on all four rows, aux_out likewise (rows 1..3 feed aux_gg)
-        for (int idx = tid; idx < 2 * ROWS; idx += kThreads) {
-            int head = idx / ROWS, row = idx - head * ROWS;
-            const f32x4v *w = (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out);
-            const f32x4v *ar = (const f32x4v *)(act + row * kActLd);
+        if (a.sched_flags & 16) {                   // ablation: skip heads / hand-off
+            if (tid == 0) ctl[0] = next_tile;
+            __syncthreads();
+            tile = ctl[0];
+            continue;
+        }
+        // heads (neddf.py:220-230): ddf_out on all four rows, aux_out likewise (rows 1..3 feed aux_gg);
+        // HSPLIT threads share one (row, head) dot product so that all 256 threads work on a 64-row tile
+        constexpr int HSPLIT = (4 * ROWS <= kThreads) ? 2 : 1, KQ = kWidth / 4 / HSPLIT;
+        for (int idx = tid; idx < HSPLIT * 2 * ROWS; idx += kThreads) {
+            int part = idx / (2 * ROWS), pr = idx - part * 2 * ROWS;
+            int head = pr / ROWS, row = pr - head * ROWS;
+            const f32x4v *w = (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out) + part * KQ;
+            const f32x4v *ar = (const f32x4v *)(act + row * kActLd) + part * KQ;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
-            for (int k = 0; k < kWidth / 4; ++k) {
+            for (int k = 0; k < KQ; ++k) {
                 f32x4v x = ar[k], ww = w[k];
                 s0 = fmaf(x[0], ww[0], s0); s1 = fmaf(x[1], ww[1], s1);
                 s2 = fmaf(x[2], ww[2], s2); s3 = fmaf(x[3], ww[3], s3);
@@ -305,6 +397,10 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
             hd[idx] = (s0 + s1) + (s2 + s3);
         }
         __syncthreads();
+        if (HSPLIT == 2) {
+            if (tid < 2 * ROWS) hd[tid] += hd[2 * ROWS + tid];
+            __syncthreads();
+        }
         if (tid < P && p0 + tid < a.n_points) {
             const int64_t gp = p0 + tid;
             float z = hd[4 * tid] + a.b_ddf_out;
@@ -344,7 +440,9 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
                 }
             }
         }
+        if (tid == 0) ctl[0] = next_tile;
         __syncthreads();
+        tile = ctl[0];
     }
 }
 
@@ -370,11 +468,15 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
     const int c_dir = 2 * a.enc.KH, c_n = c_dir + 2 * a.enc.KD;
     const int64_t ntiles = (a.n_points + P - 1) / P;
 
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int *ctl = (int *)(lp + 12);
+    int64_t tile = sched_begin(a.sched, a.sched_flags, ctl, tid);
+    while (tile < ntiles) {
         const int64_t p0 = tile * P;
         // layer 0, small-input segment: [embed_pos | embed_dir | norm_dir] (neddf.py:243)
         zero_cols(act, ROWS, ka, tid);
         __syncthreads();
+        int next_tile = 0;
+        if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
         encode_pos<ROWS4, false>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
         encode_dir<ROWS4>(act, c_dir, a.enc, a.dir, p0, a.n_points, P, tid);
         for (int i = tid; i < P * 3; i += kThreads) {
@@ -384,23 +486,46 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
         }
         __syncthreads();
         f32x16 acc[MT][NT];
-        acc_init<MT, NT, ROWS4>(acc, a.layer[0].bias, wave, lane);
-        dense<MT, NT>(acc, act_lane, (const f32x4v *)a.wp_a + (size_t)wave * NT * a.ksteps_a * 64 + lane, a.ksteps_a);
-        __syncthreads();
-        // layer 0, feature segment: trunk features from the distance kernel
-        for (int idx = tid; idx < ROWS * 64; idx += kThreads) {
+        // layer 0, feature segment: in the eval-minimal 64-row tile the trunk features are requested now
+        // (global -> VGPR) and land in LDS after the small-input dense; the other variants lack the registers
+        constexpr int NF = ROWS * 64 / kThreads;
+        constexpr bool FPRE = (MT == 2) && !ROWS4;
+        f32x4v fpre[FPRE ? NF : 1];
+        auto feature_src = [&](int idx) {
             int r = idx >> 6, c4 = idx & 63;
             int64_t grow = p0 * RPP + r;
             int64_t last = a.n_points * RPP - 1;
             if (grow > last) grow = last;
             int64_t src = ROWS4 ? grow : grow * a.feat_rows;      // value row of [n][feat_rows][256]
-            *(f32x4v *)(act + r * kActLd + 4 * c4) = *(const f32x4v *)(a.features + (size_t)src * kWidth + 4 * c4);
+            return (const f32x4v *)(a.features + (size_t)src * kWidth + 4 * c4);
+        };
+        if constexpr (FPRE) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) fpre[i] = *feature_src(tid + i * kThreads);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc_init<MT, NT, ROWS4>(acc, a.layer[0].bias, wave, lane);
+        dense<MT, NT>(acc, act_lane, (const f32x4v *)a.wp_a + (size_t)wave * NT * a.ksteps_a * 64 + lane, a.ksteps_a);
+        LayerPre<NT> pre;
+        layer_prefetch<NT>(pre, a.layer[0].wp, nullptr, a.layer[0].ksteps, wave, lane);
+        __syncthreads();
+        if constexpr (FPRE) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                int idx = tid + i * kThreads;
+                *(f32x4v *)(act + (idx >> 6) * kActLd + 4 * (idx & 63)) = fpre[i];
+            }
+        } else {
+            for (int idx = tid; idx < ROWS * 64; idx += kThreads)
+                *(f32x4v *)(act + (idx >> 6) * kActLd + 4 * (idx & 63)) = *feature_src(idx);
         }
         __syncthreads();
         for (int l = 0; l < a.n_layers; ++l) {                     // neddf.py:254-256
             const LayerW &L = a.layer[l];
-            if (l > 0) acc_init<MT, NT, ROWS4>(acc, L.bias, wave, lane);
-            dense<MT, NT>(acc, act_lane, (const f32x4v *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane, L.ksteps);
+            if (l > 0) acc_init_pre<MT, NT, ROWS4>(acc, pre);
+            dense_pre<MT, NT>(acc, act_lane, (const f32x4v *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane, L.ksteps, pre);
+            if (l + 1 < a.n_layers)
+                layer_prefetch<NT>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
             __syncthreads();
             epilogue_rt<MT, NT, ROWS4>(acc, act, a.activation, wave, lane);
             __syncthreads();
@@ -463,7 +588,9 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
                 a.penalty[gp] = tot;
             }
         }
+        if (tid == 0) ctl[0] = next_tile;
         __syncthreads();
+        tile = ctl[0];
     }
 }
 

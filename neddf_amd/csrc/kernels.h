@@ -12,6 +12,7 @@ constexpr int kActLd = 260;          // LDS row stride (floats): 256 + 4 -> conf
 constexpr int kWidth = 256;          // hidden width handled by the tile engine
 constexpr int kMaxLayers = 12;
 constexpr int kMaxStash = 2;
+constexpr int kSchedInts = 16;          // tile-queue head (+ padding)
 constexpr int kPtAux = 16;           // floats per point handed from the distance kernel to the colour kernel
 // floats of one stash slot of one workgroup: 4 waves x (MT=4 x NT=2 x 4 float4) x 64 lanes x 4
 constexpr size_t kStashFloatsPerWg = (size_t)kWaves * (4 * 2 * 4) * 64 * 4;
@@ -58,6 +59,8 @@ struct DdfArgs {
     float b_ddf_out, b_aux_out;
     float d_near, aux_grad_scale;
     float *scratch;                       // per-workgroup stash area
+    int *sched;                           // [0] tile queue head (zeroed before each launch)
+    int sched_flags;                      // bit 1: dynamic tile queue; bits 2..5: timing ablations (debug)
     float *features;                      // [n_points][feat_rows][256]
     int feat_rows;                        // 1 (value row) or 4 (value + Jacobian rows)
     float *ptaux;                         // [n_points][kPtAux]
@@ -79,6 +82,8 @@ struct ColArgs {
     const float *features;                // from DdfArgs
     int feat_rows;
     const float *ptaux;
+    int *sched;                           // as DdfArgs::sched
+    int sched_flags;
     float *color;                         // [n_points][3]
     float *penalty;                       // [n_points] (full mode) or NULL
     float distance_range_max;

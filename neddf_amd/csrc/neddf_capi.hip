@@ -7,6 +7,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -44,7 +45,7 @@ struct neddf_ctx {
     int cus = 256;
     std::string err;
     Field field[NEDDF_NUM_SLOTS];
-    DevBuf features, ptaux, scratch, arena, flags;
+    DevBuf features, ptaux, scratch, arena, flags, sched;
     bool timing = false;
     std::vector<EventPair> events;
     std::vector<EventPair> pool;
@@ -79,6 +80,17 @@ static int ensure(neddf_ctx *ctx, DevBuf &b, size_t bytes)
     HIPCHK(hipMalloc(&b.p, want));
     b.cap = want;
     return 0;
+}
+
+// NEDDF_SCHED (debug/ablation): bit 1 dynamic tile queue (default on); bits 2..5 phase ablations of the distance kernel
+static int sched_flags()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("NEDDF_SCHED");
+        v = e ? atoi(e) & 62 : 2;      // bits 2..5: timing ablations of the distance kernel (results invalid)
+    }
+    return v;
 }
 
 static inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
@@ -337,6 +349,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     const int64_t chunk = N < chunk_cap ? N : chunk_cap;
     if (int rc = ensure(ctx, ctx->features, (size_t)chunk * fr * kWidth * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ptaux, (size_t)chunk * kPtAux * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->sched, 2 * kSchedInts * sizeof(int))) return rc;
     DevBuf &sink = ctx->flags;      // [>= 64 B] flags live in front; colour sink handled below
     (void)sink;
     for (int64_t off = 0; off < N; off += chunk) {
@@ -352,6 +365,9 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         a.density = density ? density + off : nullptr;
         a.aux_grad = aux ? aux + off : nullptr;
         int64_t tiles = (n + ddf_points_per_tile() - 1) / ddf_points_per_tile();
+        a.sched = (int *)ctx->sched.p;
+        a.sched_flags = sched_flags();
+        HIPCHK(hipMemsetAsync(a.sched, 0, kSchedInts * sizeof(int), s));
         tick(ctx, s, 0, true);
         launch_ddf(a, (int)(tiles < grid_cap ? tiles : grid_cap), s);
         tick(ctx, s, 0, false);
@@ -369,6 +385,9 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
             }
             int ppt = col_points_per_tile(full);
             int64_t ctiles = (n + ppt - 1) / ppt;
+            c.sched = (int *)ctx->sched.p + kSchedInts;
+            c.sched_flags = sched_flags();
+            HIPCHK(hipMemsetAsync(c.sched, 0, kSchedInts * sizeof(int), s));
             tick(ctx, s, 1, true);
             launch_col(c, (int)(ctiles < grid_cap ? ctiles : grid_cap), full, s);
             tick(ctx, s, 1, false);
@@ -419,7 +438,7 @@ void neddf_destroy(neddf_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto &f : ctx->field) if (f.blob.p) (void)hipFree(f.blob.p);
-    for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags })
+    for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags, &ctx->sched })
         if (b->p) (void)hipFree(b->p);
     for (auto &e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : ctx->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
