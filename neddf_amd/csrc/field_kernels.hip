@@ -369,9 +369,9 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
             if (!(a.sched_flags & 8)) dense_pre<MT, NT>(acc, act_lane, wl, L.ksteps, pre);
             if (l + 1 < a.n_layers)                 // next layer's first fragments fly during the epilogue
                 layer_prefetch<NT>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
-            __syncthreads();                        // every wave finished reading the previous activations
+            if (!(a.sched_flags & 64)) __syncthreads();   // every wave finished reading the previous activations
             if (!(a.sched_flags & 4)) epilogue_rt<MT, NT, true>(acc, act, a.activation, wave, lane);
-            __syncthreads();
+            if (!(a.sched_flags & 64)) __syncthreads();
         }
         if (a.sched_flags & 16) {                   // ablation: skip heads / hand-off
             if (tid == 0) ctl[0] = next_tile;

@@ -88,7 +88,7 @@ static int sched_flags()
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("NEDDF_SCHED");
-        v = e ? atoi(e) & 62 : 2;      // bits 2..5: timing ablations of the distance kernel (results invalid)
+        v = e ? atoi(e) & 126 : 2;      // bits 2..5: timing ablations of the distance kernel (results invalid)
     }
     return v;
 }
