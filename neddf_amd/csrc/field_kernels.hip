@@ -35,7 +35,6 @@ namespace neddf {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-constexpr int MT_COL = 4;   // NeRF kernel: 128 rows = 128 points (value only)
 
 // ----------------------------------------------------------------------------
 // activations (with_grad/{relu,leaky_relu,tanh_exp}.py forward halves)
@@ -596,9 +595,10 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
 
 // ----------------------------------------------------------------------------
 // plain NeRF field (nerf.py:139-165): value rows only, 128 points per tile
-__global__ __launch_bounds__(kThreads, 1) void nerf_kernel(const NerfArgs a)
+template <int MT, int WPS>
+__global__ __launch_bounds__(kThreads, WPS) void nerf_kernel(const NerfArgs a)
 {
-    constexpr int MT = MT_COL, NT = 2, ROWS = MT * 32, P = ROWS;
+    constexpr int NT = 2, ROWS = MT * 32, P = ROWS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *act = smem;
     float *hd = smem + ROWS * kActLd;       // [2][ROWS][3]
@@ -764,7 +764,7 @@ static int tile_mt()
 int field_wgs_per_cu() { return tile_mt() == 2 ? 2 : 1; }
 int ddf_points_per_tile() { return tile_mt() * 8; }
 int col_points_per_tile(bool rows4) { return rows4 ? tile_mt() * 8 : tile_mt() * 32; }
-int nerf_points_per_tile() { return MT_COL * 32; }
+int nerf_points_per_tile() { return tile_mt() * 32; }
 
 static void set_lds(const void *fn, size_t bytes)
 {
@@ -798,10 +798,11 @@ void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 
 void launch_nerf(const NerfArgs &a, int grid, hipStream_t s)
 {
-    size_t lds = field_lds_bytes(MT_COL);
-    static bool once = (set_lds((const void *)nerf_kernel, field_lds_bytes(MT_COL)), true);
+    static bool once = (set_lds((const void *)nerf_kernel<4, 1>, field_lds_bytes(4)),
+                        set_lds((const void *)nerf_kernel<2, 2>, field_lds_bytes(2)), true);
     (void)once;
-    hipLaunchKernelGGL(nerf_kernel, dim3(grid), dim3(kThreads), lds, s, a);
+    if (tile_mt() == 2) hipLaunchKernelGGL((nerf_kernel<2, 2>), dim3(grid), dim3(kThreads), field_lds_bytes(2), s, a);
+    else hipLaunchKernelGGL((nerf_kernel<4, 1>), dim3(grid), dim3(kThreads), field_lds_bytes(4), s, a);
 }
 
 }  // namespace neddf

@@ -338,7 +338,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         a.color = color ? color : (float *)tmp.p + N;
         int64_t tiles = (N + nerf_points_per_tile() - 1) / nerf_points_per_tile();
         tick(ctx, s, 2, true);
-        launch_nerf(a, (int)(tiles < ctx->cus ? tiles : ctx->cus), s);
+        launch_nerf(a, (int)(tiles < grid_cap ? tiles : grid_cap), s);
         tick(ctx, s, 2, false);
         HIPCHK(hipGetLastError());
         return 0;
