@@ -86,8 +86,18 @@ class BaseNeuralField(ABC, nn.Module):
         """(aux_grad_scale, distance_range_max, lowpass list)"""
         raise NotImplementedError()
 
-    def voxelize(self, *a, **k):  # base_neuralfield.py:49-79 (marching-cubes tooling)
-        raise NotImplementedError("voxelize is visualisation tooling outside the accelerated path")
+    def voxelize(self, field_name: str = "density", cube_range: float = 1.1, cube_resolution: int = 64,
+                 chunk: int = 65536):
+        """base_neuralfield.py:49-79: `field_name` on a cube_resolution^3 grid (meshing / visualisation)."""
+        import numpy as np
+        with torch.no_grad():
+            ids = np.linspace(-cube_range, cube_range, cube_resolution)
+            zs, ys, xs = np.meshgrid(ids, ids, ids)
+            dev = self.device
+            pos = torch.from_numpy(np.stack([xs, ys, zs], -1).reshape(1, -1, 3).astype(np.float32)).to(dev)
+            d = torch.tensor([1.0, 0.0, 0.0], device=dev).expand_as(pos).contiguous()
+            val = self.forward(Sampling(pos, d, torch.zeros_like(pos)))     # one call: no need to chunk on 288 GB
+            return val[field_name].reshape(cube_resolution, cube_resolution, cube_resolution).cpu().numpy()
 
     def upload(self, ctx: Context, slot: int) -> None:
         """Pack + upload the parameters into `slot` if they changed since the last upload."""

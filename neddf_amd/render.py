@@ -225,5 +225,39 @@ class NeRFRender(BaseNeuralRender):
             out["_nan"] = flag
         return out
 
-    def render_field_slice(self, *a, **k):  # nerf_render.py:263-336 (cv2 colour-map debug view)
-        raise NotImplementedError("render_field_slice is visualisation tooling outside the accelerated path")
+    def render_field_slice(self, slice_t: float = 0.0, render_size: float = 1.1, render_resolution: int = 128):
+        """nerf_render.py:263-336: z = slice_t plane of the fine network's fields as uint8 images (debug view).
+        Scalar fields are JET colour-mapped (BGR, same control points as cv2.COLORMAP_JET; cv2 itself is not a
+        dependency here), colour is scaled by 256."""
+        import numpy as np
+        from .ray import Sampling
+        with torch.no_grad():
+            device = self.network_fine.device
+            n = render_resolution
+            lin = torch.linspace(-render_size, render_size, n, device=device)
+            xs = lin.reshape(1, n).expand(n, n)
+            ys = -lin.reshape(n, 1).expand(n, n)
+            zs = torch.zeros(n, n, device=device) + slice_t
+            pos = torch.stack([xs, ys, zs], 2).contiguous()
+            d = torch.zeros(n, n, 3, device=device)
+            d[:, :, 2] = 1.0
+            self.network_fine.train(False)
+            values = self.network_fine(Sampling(pos, d, torch.zeros_like(pos)))
+            self.network_fine.train(True)
+            scales = {"distance": 256.0, "density": 12.8, "color": 256.0, "aux_grad": 256.0}
+            fields = {}
+            for key, val in values.items():
+                if key not in scales:
+                    continue
+                f = (scales[key] * val.reshape(n, n, -1)).cpu().numpy().clip(0, 255).astype(np.uint8)
+                fields[key] = jet_bgr(f[:, :, 0]) if f.shape[2] == 1 else f
+            return fields
+
+
+def jet_bgr(gray):
+    """uint8 [h,w] -> uint8 [h,w,3] (B,G,R) with the classic jet ramp (r = 1.5-|4v-3|, g = 1.5-|4v-2|, b = 1.5-|4v-1|)."""
+    import numpy as np
+    v = np.arange(256, dtype=np.float64) / 255.0
+    lut = np.stack([np.clip(1.5 - np.abs(4 * v - 1), 0, 1), np.clip(1.5 - np.abs(4 * v - 2), 0, 1),
+                    np.clip(1.5 - np.abs(4 * v - 3), 0, 1)], 1)
+    return (lut * 255 + 0.5).astype(np.uint8)[gray]

@@ -17,6 +17,7 @@
  * only fused multiply-adds are the explicit fmaf() of the dense layers.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -691,5 +692,8 @@ void orc_nerf_forward(const orc_nerf_t *net, const float *pos, const float *dir,
         free(pe); free(h); free(o);
     }
 }
+
+int orc_num_threads(void) { return omp_get_max_threads(); }
+void orc_set_num_threads(int n) { omp_set_num_threads(n); }
 
 int orc_struct_sizes(int which) { return which == 0 ? (int)sizeof(orc_neddf_t) : (int)sizeof(orc_nerf_t); }

@@ -484,3 +484,23 @@ def test_layer_ops(dev, orc):
     oy, oG = orc.linear_grad(xx, JJ, ww, bb)
     assert_close(N(y), oy, 1e-5, 1e-5, "linear 200->256 y")
     assert_close(N(G), oG, 1e-5, 1e-5, "linear 200->256 G")
+
+
+def test_field_grid_views(dev, bunny_weights):
+    """render_field_slice (nerf_render.py:263-336) and voxelize (base_neuralfield.py:49-79) reuse the field kernels."""
+    from neddf_amd import Sampling
+    r = bunny_render(dev, bunny_weights)
+    f = r.render_field_slice(0.1, 1.1, 48)
+    assert set(f) == {"distance", "density", "color", "aux_grad"}
+    assert f["distance"].shape == (48, 48, 3) and f["color"].shape == (48, 48, 3) and f["density"].dtype == np.uint8
+    lin = torch.linspace(-1.1, 1.1, 48, device=dev)
+    pos = torch.stack([lin.reshape(1, 48).expand(48, 48), -lin.reshape(48, 1).expand(48, 48), torch.full((48, 48), 0.1, device=dev)], 2).contiguous()
+    d = torch.zeros_like(pos); d[:, :, 2] = 1.0
+    v = r.network_fine(Sampling(pos, d, torch.zeros_like(pos)))
+    assert np.array_equal(f["color"], (256.0 * v["color"]).cpu().numpy().clip(0, 255).astype(np.uint8))
+    vox = r.network_fine.voxelize("density", 1.1, 12)
+    assert vox.shape == (12, 12, 12) and np.isfinite(vox).all()
+    ids = np.linspace(-1.1, 1.1, 12).astype(np.float32)
+    p = torch.tensor([[[ids[5], ids[3], ids[7]]]], device=dev)           # meshgrid(ids,ids,ids): [iy, iz, ix] -> (x, y, z)
+    one = r.network_fine(Sampling(p, torch.tensor([[[1.0, 0.0, 0.0]]], device=dev), torch.zeros_like(p)))["density"]
+    assert abs(float(one) - float(vox[3, 7, 5])) <= 1e-4 * abs(float(one)) + 3e-4
