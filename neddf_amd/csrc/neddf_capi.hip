@@ -521,7 +521,9 @@ int neddf_sampling(neddf_ctx *ctx, const float *rd, const float *ro, const float
 int neddf_field_forward(neddf_ctx *ctx, int slot, const float *pos, const float *dir, const float *var, int64_t N, int out_mode,
                         float *distance, float *density, float *color, float *penalty, float *aux, void *stream)
 {
-    if (!ctx || !pos || !dir || !var) return NEDDF_EINVAL;
+    if (!ctx) return NEDDF_EINVAL;
+    if (N <= 0) return 0;
+    if (!pos || !dir || !var) return NEDDF_EINVAL;
     (void)hipSetDevice(ctx->device);
     return field_forward(ctx, slot, pos, dir, var, N, out_mode, distance, density, color, penalty, aux, (hipStream_t)stream);
 }
@@ -584,8 +586,9 @@ static int render_pass(neddf_ctx *ctx, int slot, const float *rd, const float *r
 int neddf_render_rays(neddf_ctx *ctx, const void *uv, int uv_type, int64_t B, const neddf_camera *cam, const neddf_render_params *rp,
                       const float *Uc, const float *Uf, const neddf_render_outputs *out, void *stream)
 {
-    if (!ctx || !uv || !cam || !rp || !Uc || !Uf || !out) return NEDDF_EINVAL;
-    if (B <= 0) return 0;
+    if (!ctx) return NEDDF_EINVAL;
+    if (B <= 0) return 0;           // empty batch: nothing to do (pointers of empty tensors may be NULL)
+    if (!uv || !cam || !rp || !Uc || !Uf || !out) return NEDDF_EINVAL;
     (void)hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     const int Sc1 = rp->sample_coarse + 1, Sf1 = rp->sample_fine + 1, S2 = Sc1 + Sf1;
@@ -627,8 +630,9 @@ int neddf_render_rays(neddf_ctx *ctx, const void *uv, int uv_type, int64_t B, co
 int neddf_render_rays_single(neddf_ctx *ctx, int slot, const void *uv, int uv_type, int64_t B, const neddf_camera *cam,
                              const neddf_render_params *rp, int S1, const float *U, const neddf_render_outputs *out, void *stream)
 {
-    if (!ctx || !uv || !cam || !rp || !U || !out || S1 < 2) return NEDDF_EINVAL;
+    if (!ctx) return NEDDF_EINVAL;
     if (B <= 0) return 0;
+    if (!uv || !cam || !rp || !U || !out || S1 < 2) return NEDDF_EINVAL;
     (void)hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");

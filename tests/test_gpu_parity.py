@@ -504,3 +504,48 @@ def test_field_grid_views(dev, bunny_weights):
     p = torch.tensor([[[ids[5], ids[3], ids[7]]]], device=dev)           # meshgrid(ids,ids,ids): [iy, iz, ix] -> (x, y, z)
     one = r.network_fine(Sampling(p, torch.tensor([[[1.0, 0.0, 0.0]]], device=dev), torch.zeros_like(p)))["density"]
     assert abs(float(one) - float(vox[3, 7, 5])) <= 1e-4 * abs(float(one)) + 3e-4
+
+
+# ---------------------------------------------- public stage methods + variants
+def test_public_stage_methods(dev):
+    """integrate_volume_render on the reference test's inputs (tests/render/test_nerf_render.py:17-46) and sample_pdf's RNG."""
+    import neddf_amd
+    e = golden("render_edges.npz")
+    kw = dict(embed_pos_rank=10, embed_dir_rank=4, layer_count=8, layer_width=256, activation_type="ReLU",
+              skips=[4], lowpass_alpha_offset=10, _target_="neddf.network.NeRF")
+    r = neddf_amd.NeRFRender(network_config=kw).to(dev)
+    d = torch.linspace(0.0, 2.0, 64, device=dev).unsqueeze(0).expand(32, 64).contiguous()
+    out = r.integrate_volume_render(d, torch.ones(32, 64, device=dev), torch.ones(32, 64, 3, device=dev))
+    assert out["depth"].shape == (32,) and out["color"].shape == (32, 3) and out["transmittance"].shape == (32,)
+    assert_close(N(out["color"]), e["ivc_color"], 1e-5, 1e-6, "color")
+    assert_close(N(out["depth"]), e["ivc_depth"], 1e-5, 1e-6, "depth")
+    assert_close(N(out["weight"]), e["ivc_weight"], 1e-5, 3e-7, "weight")
+    with pytest.raises(AssertionError):         # the reference asserts on NaN weights
+        r.integrate_volume_render(d, torch.full((32, 64), float("nan"), device=dev), torch.ones(32, 64, 3, device=dev))
+    # sample_pdf draws torch.rand(batch, samples_fine) on the CPU generator (base_neural_render.py:75)
+    for cat, tag in ((True, "cat"), (False, "nocat")):
+        torch.manual_seed(5)
+        w = T(e["sp_w"].copy(), dev)
+        out = r.sample_pdf(T(e["sp_dists"], dev), w, 21, cat_coarse=cat)
+        assert np.array_equal(N(out), e["sp_%s_out" % tag]) and np.array_equal(N(w), e["sp_%s_wafter" % tag], equal_nan=True)
+    # empty batch is a no-op, not an error
+    cam = neddf_amd.Camera(neddf_amd.PinholeCalib(np.array([100.0, 100.0, 320.0, 240.0])), None).to(dev)
+    cam.update_transform()
+    o = r.render_rays(torch.zeros(0, 2, dtype=torch.int64, device=dev), cam)
+    assert o["color"].shape == (0, 3)
+    # device RNG mode renders finite values of the right shape
+    r.rng = "device"
+    o = r.render_rays(torch.tensor([[300, 200], [320, 240]], device=dev), cam)
+    assert torch.isfinite(o["color"]).all() and o["weight"].shape == (2, 257)
+
+
+def test_128_row_tile_variant_in_subprocess():
+    """NEDDF_TILE_MT=4 (one 128-row workgroup per CU, global-scratch skip partial) must give the same parity."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, NEDDF_TILE_MT="4")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py"), "smoke"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0 and "smoke ok" in p.stdout, p.stdout + p.stderr
