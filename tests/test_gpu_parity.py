@@ -549,3 +549,48 @@ def test_128_row_tile_variant_in_subprocess():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py"), "smoke"], env=env, capture_output=True, text=True,
                        timeout=600)
     assert p.returncode == 0 and "smoke ok" in p.stdout, p.stdout + p.stderr
+
+
+def test_full_frame_invariants(dev, bunny_weights):
+    """One full BASELINE configs[1] frame (640 000 rays x 128 samples) and a 64k-ray hierarchical batch: invariants
+    that hold at any size -- sorted fine distances containing every coarse knot, compositing linear in colour,
+    sum(w) + T_end = 1 (up to the reference's +1e-7 per sample) for non-negative densities."""
+    import neddf_amd
+    r = bunny_render(dev, bunny_weights)
+    g = golden("bunny_stages.npz")
+    ctx = r._ctx(dev)
+    fx = 0.5 * 800 / np.tan(0.5 * 0.6911112070083618)
+    cam = neddf_amd.Camera(neddf_amd.PinholeCalib(np.array([fx, fx, 400.0, 400.0])), None).to(dev)
+    cam.R, cam.T = T(g["R"], dev), T(g["T"], dev)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    U = torch.rand(640000, 128, device=dev, generator=gen)
+    out = r.render_image_single_pass(800, 800, cam, 128, U=U)
+    assert int(out["_nan"].item()) == 0 and torch.isfinite(out["color"]).all() and torch.isfinite(out["depth"]).all()
+    assert out["color"].shape == (640000, 3)
+    # compositing: linearity in colour, weights + transmittance
+    n, S = 200000, 128
+    d = torch.sort(torch.rand(n, S, device=dev, generator=gen) * 4 + 2, dim=1)[0]
+    rho = torch.rand(n, S, device=dev, generator=gen) * 8
+    c1 = torch.rand(n, S, 3, device=dev, generator=gen)
+    c2 = torch.rand(n, S, 3, device=dev, generator=gen)
+    o1, _ = ctx.composite(d, rho, c1, 6.0)
+    o2, _ = ctx.composite(d, rho, c2, 6.0)
+    o12, _ = ctx.composite(d, rho, c1 + 2 * c2, 6.0)
+    assert torch.allclose(o12["color"], o1["color"] + 2 * o2["color"], rtol=1e-5, atol=2e-6)
+    assert torch.equal(o1["weight"], o2["weight"]) and torch.equal(o1["transmittance"], o12["transmittance"])
+    total = o1["weight"].sum(1) + o1["transmittance"]
+    assert float((total - 1).abs().max()) < 5e-5
+    assert float(o1["weight"].min()) >= 0.0
+    # hierarchical pass on 65 536 rays: fine distances sorted, every coarse knot present
+    uv = torch.stack([torch.arange(65536, device=dev) % 800 + 0, torch.arange(65536, device=dev) // 800 + 300], 1)
+    dc = torch.empty(65536, 65, device=dev)
+    df = torch.empty(65536, 194, device=dev)
+    col = torch.empty(65536, 3, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx.render_rays(uv, cam.descriptor(), r._params(), torch.rand(65536, 65, device=dev, generator=gen),
+                    torch.rand(65536, 129, device=dev, generator=gen), dict(color=col, dists_coarse=dc, dists_fine=df, nan_flag=flag))
+    assert int(flag.item()) == 0
+    assert bool((df[:, 1:] >= df[:, :-1]).all())
+    merged = torch.sort(torch.cat([df, dc], 1), dim=1)[0]
+    assert bool((merged[:, 1:] == merged[:, :-1]).sum(1).ge(65).all())          # each coarse knot appears in df
+    assert float(df.min()) >= 2.0 and float(df.max()) <= float(dc.max()) + 1e-6
