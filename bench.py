@@ -119,10 +119,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # NEDDF_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL communicator, pixel all-gather, max-over-ranks) with one rank
+    use_dist = world > 1 or os.environ.get("NEDDF_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     import neddf_amd
@@ -158,12 +162,12 @@ def main():
             out["_nan"] = o["_nan"]
         else:
             out = render.render_image_single_pass(WIDTH, HEIGHT, cam, SAMPLES, U=U)
-        if world > 1:       # every rank ends with all N views: [N * n_rays, 5]
-            return gather_pixels(pack_pixels(out, keys), n_rays * world)
+        if use_dist:        # every rank ends with all N views: [N * n_rays, 5]
+            return gather_pixels(pack_pixels(out, keys), n_rays * world, force_collective=True)
         return out
 
     def sync():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -179,7 +183,7 @@ def main():
     elapsed = time.perf_counter() - t0
     tm = ctx.get_timings()
     ctx.set_timing(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -221,9 +225,14 @@ def main():
             line["cpu_baseline"] = cpu_baseline(weights, R, T, calib.astype(np.float32))
         nan = int(res["_nan"].item()) if isinstance(res, dict) else 0
         assert nan == 0
-        print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the last line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -39,10 +39,11 @@ def unpack_pixels(packed: Tensor, keys: Iterable[str]) -> Dict[str, Tensor]:
     return out
 
 
-def gather_pixels(local: Tensor, n_total: int, group=None) -> Tensor:
-    """All-gather per-rank slabs [n_rank, C] (shard_range order) into [n_total, C] on every rank."""
+def gather_pixels(local: Tensor, n_total: int, group=None, force_collective: bool = False) -> Tensor:
+    """All-gather per-rank slabs [n_rank, C] (shard_range order) into [n_total, C] on every rank.
+    force_collective runs the collective even for a single rank (used to exercise the RCCL path on one GPU)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force_collective:
         return local
     sizes = [shard_range(n_total, r, world) for r in range(world)]
     pad = max(hi - lo for lo, hi in sizes)

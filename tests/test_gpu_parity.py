@@ -594,3 +594,40 @@ def test_full_frame_invariants(dev, bunny_weights):
     merged = torch.sort(torch.cat([df, dc], 1), dim=1)[0]
     assert bool((merged[:, 1:] == merged[:, :-1]).sum(1).ge(65).all())          # each coarse knot appears in df
     assert float(df.min()) >= 2.0 and float(df.max()) <= float(dc.max()) + 1e-6
+
+
+_RCCL_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from neddf_amd.parallel import gather_pixels, pack_pixels, unpack_pixels
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=0, world_size=1, device_id=dev)
+parts = {"color": torch.rand(1000, 3, device=dev), "depth": torch.rand(1000, device=dev), "transmittance": torch.rand(1000, device=dev)}
+keys = ("color", "depth", "transmittance")
+full = gather_pixels(pack_pixels(parts, keys), 1000, force_collective=True)        # all_gather_into_tensor over RCCL
+back = unpack_pixels(full, keys)
+assert torch.equal(back["color"], parts["color"]) and torch.equal(back["depth"][:, 0], parts["depth"])
+t = torch.tensor([1.25], device=dev, dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)                                            # bench.py's max-over-ranks timing
+dist.barrier()
+torch.cuda.synchronize()
+assert float(t.item()) == 1.25
+dist.destroy_process_group()
+print("rccl ok")
+'''
+
+
+def test_rccl_collectives_single_rank(tmp_path):
+    """The collectives bench.py / parallel.py issue at N > 1 (all_gather_into_tensor, all_reduce MAX f64, barrier)
+    on a 1-rank RCCL communicator: API usage and the RCCL runtime itself, as far as one GPU can show."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script), ROOT, str(29600 + os.getpid() % 1000)], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0 and "rccl ok" in p.stdout, p.stdout + p.stderr
