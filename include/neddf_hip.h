@@ -30,7 +30,7 @@ extern "C" {
 #define NEDDF_ABI_VERSION 1
 
 enum { NEDDF_OK = 0, NEDDF_EINVAL = -1, NEDDF_EHIP = -2, NEDDF_EUNSUPPORTED = -3, NEDDF_ENOFIELD = -4 };
-enum { NEDDF_FIELD_NEDDF = 0, NEDDF_FIELD_NERF = 1 };
+enum { NEDDF_FIELD_NEDDF = 0, NEDDF_FIELD_NERF = 1, NEDDF_FIELD_NEUS = 2 };
 enum { NEDDF_ACT_RELU = 0, NEDDF_ACT_LEAKY = 1, NEDDF_ACT_TANHEXP = 2 };
 enum { NEDDF_SLOT_COARSE = 0, NEDDF_SLOT_FINE = 1, NEDDF_NUM_SLOTS = 4 };
 /* uv element types accepted by neddf_raygen (the reference takes int64 in
@@ -94,6 +94,9 @@ int neddf_device_cus(neddf_ctx *ctx);
  *          (LinearGradLayer weights are [in,out], linear.py:113)
  *   NeRF : layers.0..n, outL_density, outL_color.0, outL_color.2
  *          (nn.Linear weights are [out,in], nerf.py:88-103)
+ *   NeuS : layers_sdf.0..n-1, layers_col.0..m (m = col_layer_count; last is 256 -> 3), then `variance`
+ *          as a 1-element weight with a dummy bias (nn.Linear layout, neus.py:80-99); desc.layer_count =
+ *          sdf_layer_count, desc.col_layer_count = col_layer_count, activation ReLU or tanhExp
  * The library packs them into MFMA fragment order and uploads; the caller keeps
  * ownership of the sources. */
 int neddf_set_field(neddf_ctx *ctx, int slot, const neddf_field_desc *desc,
@@ -118,7 +121,7 @@ int neddf_sampling(neddf_ctx *ctx, const float *d_ray_dir, const float *d_ray_or
                    void *stream);
 /* NeDDF.forward (neddf.py:162-309) / NeRF.forward (nerf.py:107-165) on N
  * sample points (pos/dir/var [N,3]).  Any output pointer may be NULL.
- * NeRF fields produce density and color only. */
+ * NeRF fields produce density and color only; NeuS fields (neus.py:101-162) return the sdf in d_distance. */
 int neddf_field_forward(neddf_ctx *ctx, int slot, const float *d_pos, const float *d_dir, const float *d_var,
                         int64_t n_points, int out_mode, float *d_distance, float *d_density, float *d_color,
                         float *d_fields_penalty, float *d_aux_grad, void *stream);

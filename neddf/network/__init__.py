@@ -1,1 +1,1 @@
-from neddf_amd.network import BaseNeuralField, NeDDF, NeDDFField, NeRF, NeRFField  # noqa: F401
+from neddf_amd.network import BaseNeuralField, NeDDF, NeDDFField, NeRF, NeRFField, NeuS  # noqa: F401

@@ -7,7 +7,7 @@ on first use and there is no CPU fallback."""
 from . import camera, config, dataset, metrics, network, nn_module, ray, render, trainer  # noqa: F401
 from ._lib import Context, NeddfError, load  # noqa: F401
 from .camera import Camera, PinholeCalib  # noqa: F401
-from .network import NeDDF, NeDDFField, NeRF, NeRFField  # noqa: F401
+from .network import NeDDF, NeDDFField, NeRF, NeRFField, NeuS  # noqa: F401
 from .ray import Ray, Sampling  # noqa: F401
 from .render import NeRFRender, RenderTarget  # noqa: F401
 

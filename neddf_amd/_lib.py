@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libneddf_hip.so")
 ABI_VERSION = 1
 
-FIELD_NEDDF, FIELD_NERF = 0, 1
+FIELD_NEDDF, FIELD_NERF, FIELD_NEUS = 0, 1, 2
 ACT = {"ReLU": 0, "LeakyReLU": 1, "tanhExp": 2}
 SLOT_COARSE, SLOT_FINE, SLOT_GENERIC = 0, 1, 2
 OUT_MINIMAL, OUT_FULL = 0, 1

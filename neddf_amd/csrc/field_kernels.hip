@@ -235,7 +235,7 @@ __device__ __forceinline__ void zero_cols(float *act, int rows, int ncols, int t
 // Region must be pre-zeroed.  GRADSCALE selects embed_pos_scaled (neddf.py:200-204).
 template <bool ROWS4, bool GRADSCALE>
 __device__ __forceinline__ void encode_pos(float *act, int col0, const EncodeDesc &enc, const float *lp, const float *pos,
-                                           const float *var, int64_t p0, int64_t N, int P, int tid)
+                                           const float *var, int64_t p0, int64_t N, int P, int tid, bool use_var = true)
 {
     const int K3 = 3 * enc.E, KH = enc.KH;
     for (int item = tid; item < P * K3; item += kThreads) {
@@ -243,7 +243,7 @@ __device__ __forceinline__ void encode_pos(float *act, int col0, const EncodeDes
         int e = q / 3, d = q - 3 * e;
         int64_t gp = p0 + p < N ? p0 + p : N - 1;
         float vs, vc, js, jc;
-        pe_pair<GRADSCALE>(e, pos[gp * 3 + d], var[gp * 3 + d], lp[e], vs, vc, js, jc);
+        pe_pair<GRADSCALE>(e, pos[gp * 3 + d], use_var ? var[gp * 3 + d] : 0.0f, lp[e], vs, vc, js, jc);
         if (ROWS4) {
             float *r0 = act + (4 * p) * kActLd + col0 + q;
             r0[0] = vs;
@@ -325,7 +325,10 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
         __syncthreads();
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);     // consumed at the end of this tile
-        if (!(a.sched_flags & 32)) encode_pos<true, true>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
+        if (!(a.sched_flags & 32)) {
+            if (a.neus) encode_pos<true, false>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid, false);   // plain PE (neus.py:118)
+            else encode_pos<true, true>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
+        }
         __syncthreads();
 
         f32x16 acc[MT][NT];
@@ -378,6 +381,21 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
             tile = ctl[0];
             continue;
         }
+        if (a.neus) {       // NeuS: sdf = feature 0 of the last activated layer, normal = its Jacobian rows (neus.py:132-145)
+            if (tid < P && p0 + tid < a.n_points) {
+                const int64_t gp = p0 + tid;
+                float sdf = act[(4 * tid) * kActLd];
+                float ex = expf(-a.neus_v10 * sdf);
+                float den = 1 + ex;
+                float rho = a.neus_v10 * ex * (1.0f / (den * den));          // neus.py:153-156
+                float *pa = a.ptaux + gp * kPtAux;
+                f32x4v v0 = { sdf, rho, 0.f, act[(4 * tid + 1) * kActLd] };
+                f32x4v v1 = { act[(4 * tid + 2) * kActLd], act[(4 * tid + 3) * kActLd], 0.f, 0.f };
+                ((f32x4v *)pa)[0] = v0; ((f32x4v *)pa)[1] = v1;
+                if (a.distance) a.distance[gp] = sdf;
+                if (a.density) a.density[gp] = rho;
+            }
+        } else {
         // heads (neddf.py:220-230): ddf_out on all four rows, aux_out likewise (rows 1..3 feed aux_gg);
         // HSPLIT threads share one (row, head) dot product so that all 256 threads work on a 64-row tile
         constexpr int HSPLIT = (4 * ROWS <= kThreads) ? 2 : 1, KQ = kWidth / 4 / HSPLIT;
@@ -426,6 +444,7 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
             if (a.distance) a.distance[gp] = D;
             if (a.density) a.density[gp] = rho;
             if (a.aux_grad) a.aux_grad[gp] = aux;
+        }
         }
         // hand the trunk features to the colour kernel (value row, or all four rows in full mode)
         {
@@ -476,12 +495,22 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
         __syncthreads();
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
-        encode_pos<ROWS4, false>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
-        encode_dir<ROWS4>(act, c_dir, a.enc, a.dir, p0, a.n_points, P, tid);
-        for (int i = tid; i < P * 3; i += kThreads) {
-            int p = i / 3, d = i - 3 * p;
-            int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
-            act[(RPP * p) * kActLd + c_n + d] = a.ptaux[gp * kPtAux + PA_N0 + d];
+        if (a.mode == 1) {      // NeuS: [pos | gradient | pad | embed_dir] (neus.py:146-149)
+            for (int i = tid; i < P * 3; i += kThreads) {
+                int p = i / 3, d = i - 3 * p;
+                int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
+                act[(RPP * p) * kActLd + d] = a.pos[gp * 3 + d];
+                act[(RPP * p) * kActLd + 3 + d] = a.ptaux[gp * kPtAux + PA_N0 + d];
+            }
+            encode_dir<ROWS4>(act, 8, a.enc, a.dir, p0, a.n_points, P, tid);
+        } else {
+            encode_pos<ROWS4, false>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
+            encode_dir<ROWS4>(act, c_dir, a.enc, a.dir, p0, a.n_points, P, tid);
+            for (int i = tid; i < P * 3; i += kThreads) {
+                int p = i / 3, d = i - 3 * p;
+                int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
+                act[(RPP * p) * kActLd + c_n + d] = a.ptaux[gp * kPtAux + PA_N0 + d];
+            }
         }
         __syncthreads();
         f32x16 acc[MT][NT];
@@ -556,6 +585,9 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     c[r][k] = hd[(RPP * tid + r) * 3 + k] + hd[(ROWS + RPP * tid + r) * 3 + k] + (r == 0 ? a.b_out[k] : 0.f);
+            if (a.final_act >= 0)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) c[0][k] = act_val_rt(a.final_act, c[0][k]);
             a.color[gp * 3 + 0] = c[0][0]; a.color[gp * 3 + 1] = c[0][1]; a.color[gp * 3 + 2] = c[0][2];
             if (ROWS4 && a.penalty) {                          // neddf.py:260-300
                 const float *pa = a.ptaux + gp * kPtAux;

@@ -58,6 +58,8 @@ struct DdfArgs {
     const float *w_ddf_out, *w_aux_out;   // [256] each
     float b_ddf_out, b_aux_out;
     float d_near, aux_grad_scale;
+    int neus;                             // 1: NeuS sdf trunk (neus.py:118-145): plain PE, no heads, sdf = feature 0
+    float neus_v10;                       // variance * 10
     float *scratch;                       // per-workgroup stash area
     int *sched;                           // [0] tile queue head (zeroed before each launch)
     int sched_flags;                      // bit 1: dynamic tile queue; bits 2..5: timing ablations (debug)
@@ -72,8 +74,10 @@ struct ColArgs {
     const float *pos, *dir, *var;
     int64_t n_points;
     EncodeDesc enc;
-    int n_layers;                         // hidden layers (col_layer_count - 1)
+    int n_layers;                         // hidden layers (NeDDF: col_layer_count - 1, NeuS: col_layer_count)
     int activation;
+    int mode;                             // 0 NeDDF inputs [embed_pos | embed_dir | normal], 1 NeuS inputs [pos | gradient | embed_dir]
+    int final_act;                        // activation id applied to the 3 outputs (NeuS, neus.py:150-152) or -1
     int ksteps_a;                         // super-steps of layer 0's small-input segment [pe_pos | pe_dir | normal]
     const float *wp_a;                    // its packed weights
     LayerW layer[kMaxLayers];             // layer[0] = feature segment of layer 0

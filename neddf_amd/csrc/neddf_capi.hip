@@ -226,7 +226,93 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     a.activation = c.activation = d.activation;
     a.density_activation = d.density_activation;
     a.d_near = d.d_near;
+    c.final_act = -1;
     for (int k = 0; k < 6; ++k) { c.penalty_weight[k] = d.penalty_weight[k]; c.penalty_has[k] = d.penalty_has[k]; }
+    return 0;
+}
+
+// NeuS (neddf/network/neus.py): sdf trunk with Jacobian rows on the distance kernel (forward-mode replaces the
+// reference's torch.autograd.grad), colour trunk on the colour kernel.
+static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const float *const *B, int n_tensors)
+{
+    const neddf_field_desc &d = f.d;
+    const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n_sdf = d.layer_count, n_col = d.col_layer_count;
+    const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
+    if (n_tensors != n_sdf + n_col + 2) return fail(ctx, NEDDF_EINVAL, "NeuS: wrong tensor count");
+    if (n_sdf < 1 || n_sdf > kMaxLayers || n_col < 1 || n_col > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: layer count out of range");
+    if (d.activation == NEDDF_ACT_LEAKY) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: activation must be ReLU or tanhExp");
+    for (int i = 0; i < d.n_skips; ++i)
+        if (d.skips[i] < 0 || d.skips[i] >= n_sdf - 1)
+            return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: skip index must address an sdf layer followed by another");
+    std::vector<float> blob;
+    DdfArgs &a = f.ddf;
+    ColArgs &c = f.col;
+    a = DdfArgs{}; c = ColArgs{};
+    std::vector<size_t> o_wp(n_sdf), o_b(n_sdf), o_st;
+    std::vector<int> pe;
+    enc_map(pe, E, KH, 0);
+    a.n_layers = n_sdf; a.n_stash = 0;
+    for (int l = 0; l < n_sdf; ++l) {
+        bool wide = l > 0 && in_skips(d, l - 1);
+        int cin = l == 0 ? Cpe : (wide ? kWidth + Cpe : kWidth);
+        Src src{ W[l], cin, kWidth, true };
+        std::vector<int> km;
+        a.layer[l].stash = -1;
+        if (l == 0) km = pe;
+        else for (int k = 0; k < kWidth; ++k) km.push_back(k);       // cat([hx, embed_pos]): hidden state first
+        o_wp[l] = pack_layer(blob, src, km, kWidth);
+        a.layer[l].ksteps = (int)km.size() / 8;
+        if (wide) {
+            if (a.n_stash >= kMaxStash) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: too many skip connections");
+            std::vector<int> ps;
+            enc_map(ps, E, KH, kWidth);
+            o_st.push_back(pack_layer(blob, src, ps, kWidth));
+            a.stash[a.n_stash].col0 = 0;
+            a.stash[a.n_stash].ksteps = (int)ps.size() / 8;
+            a.layer[l].stash = a.n_stash++;
+        }
+        o_b[l] = put(blob, B[l], kWidth);
+    }
+    // colour trunk: engine columns [pos 3 | gradient 3 | pad 2 | dir sin KD | dir cos KD]
+    std::vector<int> ka;
+    for (int k = 0; k < 3; ++k) ka.push_back(k);
+    for (int k = 0; k < 3; ++k) ka.push_back(3 + Cdir + k);
+    ka.push_back(-1); ka.push_back(-1);
+    enc_map(ka, Ed, KD, 3);
+    while (ka.size() % 8) ka.push_back(-1);
+    const int in_col = 6 + Cdir + kWidth;
+    Src s0{ W[n_sdf], in_col, kWidth, true };
+    size_t o_wa = pack_layer(blob, s0, ka, kWidth);
+    c.ksteps_a = (int)ka.size() / 8;
+    c.n_layers = n_col;
+    std::vector<size_t> c_wp(n_col), c_b(n_col);
+    for (int l = 0; l < n_col; ++l) {
+        std::vector<int> km;
+        for (int k = 0; k < kWidth; ++k) km.push_back(l == 0 ? 6 + Cdir + k : k);
+        Src src{ W[n_sdf + l], l == 0 ? in_col : kWidth, kWidth, true };
+        c_wp[l] = pack_layer(blob, src, km, kWidth);
+        c.layer[l].ksteps = 32;
+        c.layer[l].stash = -1;
+        c_b[l] = put(blob, B[n_sdf + l], kWidth);
+    }
+    std::vector<float> wout(kWidth * 3);                  // [3][256] -> [256][3]
+    for (int k = 0; k < kWidth; ++k)
+        for (int o = 0; o < 3; ++o) wout[k * 3 + o] = W[n_sdf + n_col][(size_t)o * kWidth + k];
+    size_t o_cout = put(blob, wout.data(), wout.size());
+    for (int k = 0; k < 3; ++k) c.b_out[k] = B[n_sdf + n_col][k];
+    if (int rc = ensure(ctx, f.blob, blob.size() * sizeof(float))) return rc;
+    HIPCHK(hipMemcpy(f.blob.p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    const float *base = (const float *)f.blob.p;
+    for (int l = 0; l < n_sdf; ++l) { a.layer[l].wp = base + o_wp[l]; a.layer[l].bias = base + o_b[l]; }
+    for (int s = 0; s < a.n_stash; ++s) a.stash[s].wp = base + o_st[s];
+    c.wp_a = base + o_wa;
+    for (int l = 0; l < n_col; ++l) { c.layer[l].wp = base + c_wp[l]; c.layer[l].bias = base + c_b[l]; }
+    c.w_out = base + o_cout;
+    a.activation = c.activation = d.activation;
+    a.neus = 1;
+    a.neus_v10 = W[n_sdf + n_col + 1][0] * 10.0f;
+    c.mode = 1;
+    c.final_act = d.activation;
     return 0;
 }
 
@@ -343,7 +429,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         HIPCHK(hipGetLastError());
         return 0;
     }
-    const bool full = (out_mode == NEDDF_OUT_FULL) && penalty;
+    const bool full = (out_mode == NEDDF_OUT_FULL) && penalty && f.d.kind == NEDDF_FIELD_NEDDF;
     const int fr = full ? 4 : 1;
     const int64_t chunk_cap = full ? (1 << 19) : (1 << 21);
     const int64_t chunk = N < chunk_cap ? N : chunk_cap;
@@ -454,7 +540,7 @@ int neddf_set_field(neddf_ctx *ctx, int slot, const neddf_field_desc *desc, cons
     (void)hipSetDevice(ctx->device);
     if (desc->embed_pos_rank < 1 || desc->embed_pos_rank > 10 || desc->embed_dir_rank < 1 || desc->embed_dir_rank > 4)
         return fail(ctx, NEDDF_EUNSUPPORTED, "embed_pos_rank must be in [1,10] and embed_dir_rank in [1,4]");
-    if (desc->layer_width != kWidth || (desc->kind == NEDDF_FIELD_NEDDF && desc->col_layer_width != kWidth))
+    if (desc->layer_width != kWidth || (desc->kind != NEDDF_FIELD_NERF && desc->col_layer_width != kWidth))
         return fail(ctx, NEDDF_EUNSUPPORTED, "the tile engine is built for hidden width 256");
     if (desc->n_skips < 0 || desc->n_skips > 8) return fail(ctx, NEDDF_EINVAL, "bad n_skips");
     if (desc->activation < 0 || desc->activation > 2 || desc->density_activation < 0 || desc->density_activation > 2)
@@ -467,6 +553,7 @@ int neddf_set_field(neddf_ctx *ctx, int slot, const neddf_field_desc *desc, cons
     for (int i = 0; i < 10; ++i) f.lowpass[i] = 1.0f;
     int rc = desc->kind == NEDDF_FIELD_NEDDF ? build_neddf(ctx, f, W, B, n)
            : desc->kind == NEDDF_FIELD_NERF ? build_nerf(ctx, f, W, B, n)
+           : desc->kind == NEDDF_FIELD_NEUS ? build_neus(ctx, f, W, B, n)
            : fail(ctx, NEDDF_EINVAL, "bad field kind");
     if (rc) return rc;
     f.valid = true;

@@ -13,7 +13,7 @@ from typing import Dict, List, Optional
 import torch
 from torch import Tensor, nn
 
-from ._lib import ACT, FIELD_NEDDF, FIELD_NERF, OUT_FULL, OUT_MINIMAL, PENALTY_KEYS, SLOT_GENERIC, Context, FieldDesc
+from ._lib import ACT, FIELD_NEDDF, FIELD_NERF, FIELD_NEUS, OUT_FULL, OUT_MINIMAL, PENALTY_KEYS, SLOT_GENERIC, Context, FieldDesc
 from .ray import Sampling
 
 
@@ -247,6 +247,72 @@ class NeRF(BaseNeuralField):
 
     def set_iter(self, iter: int) -> None:
         self.lowpass_alpha = self.pe_pos.embed_dim if iter == -1 else self.lowpass_alpha_offset + 0.001 * iter
+
+
+class NeuS(BaseNeuralField):
+    """NeuS SDF field (neus.py:30-99 constructor keywords).  The reference takes the
+    surface normal with torch.autograd.grad; here it is the forward-mode Jacobian
+    carried through the sdf trunk by the same tile engine as NeDDF's distance trunk."""
+
+    def __init__(self, embed_pos_rank: int = 6, embed_dir_rank: int = 4, sdf_layer_count: int = 8,
+                 sdf_layer_width: int = 256, col_layer_count: int = 8, col_layer_width: int = 256,
+                 activation_type: str = "ReLU", init_variance: float = 0.3, skips: Optional[List[int]] = None) -> None:
+        super().__init__()
+        in_sdf = embed_pos_rank * 6
+        in_col = 6 + embed_dir_rank * 6 + sdf_layer_width
+        self.skips = [4] if skips is None else list(skips)
+        self.activation_type = activation_type
+        self.activation = activation_type
+        self.pe_pos = PositionalEncodingInfo(embed_pos_rank)
+        self.pe_dir = PositionalEncodingInfo(embed_dir_rank)
+        sdf = [nn.Linear(in_sdf, sdf_layer_width)]
+        for layer_id in range(sdf_layer_count - 1):
+            sdf.append(nn.Linear(sdf_layer_width + (in_sdf if layer_id in self.skips else 0), sdf_layer_width))
+        col = [nn.Linear(in_col, col_layer_width)]
+        col += [nn.Linear(col_layer_width, col_layer_width) for _ in range(col_layer_count - 1)]
+        col.append(nn.Linear(col_layer_width, 3))
+        self.layers_sdf = nn.ModuleList(sdf)
+        self.layers_col = nn.ModuleList(col)
+        self.variance = nn.Parameter(torch.tensor(init_variance))
+        self.sdf_layer_count, self.sdf_layer_width = sdf_layer_count, sdf_layer_width
+        self.col_layer_count, self.col_layer_width = col_layer_count, col_layer_width
+
+    def _descriptor(self) -> FieldDesc:
+        d = FieldDesc()
+        d.kind = FIELD_NEUS
+        d.embed_pos_rank, d.embed_dir_rank = self.pe_pos.embed_dim, self.pe_dir.embed_dim
+        d.layer_count, d.layer_width = self.sdf_layer_count, self.sdf_layer_width
+        d.col_layer_count, d.col_layer_width = self.col_layer_count, self.col_layer_width
+        d.n_skips = len(self.skips)
+        for i, s in enumerate(self.skips[:8]):
+            d.skips[i] = s
+        d.activation = d.density_activation = ACT[self.activation_type]
+        return d
+
+    def _tensors(self):
+        mods = list(self.layers_sdf) + list(self.layers_col)
+        dummy = torch.zeros(1)
+        return [m.weight for m in mods] + [self.variance.reshape(1)], [m.bias for m in mods] + [dummy]
+
+    def upload(self, ctx: Context, slot: int) -> None:
+        # `variance.reshape(1)` is a fresh view each call: key the upload on the parameter itself
+        ws, bs = self._tensors()
+        sig = (id(self), slot, tuple((t.data_ptr(), t._version) for t in ws[:-1] + bs[:-1]), self.variance.data_ptr(), self.variance._version)
+        if ctx.slot_owner.get(slot) != sig:
+            hw = [t.detach().to("cpu", torch.float32).contiguous() for t in ws]
+            hb = [t.detach().to("cpu", torch.float32).contiguous() for t in bs]
+            ctx.set_field(slot, self._descriptor(), hw, hb, sig)
+
+    def _iter_state(self):
+        return 1.1, 2.0, [1.0] * self.pe_pos.embed_dim
+
+    def forward(self, sampling: Sampling) -> Dict[str, Tensor]:
+        """sdf, density [B,S]; color [B,S,3] (neus.py:157-161)."""
+        o = self._run(sampling, OUT_MINIMAL, ("distance", "density", "color"))
+        return {"sdf": o["distance"], "density": o["density"], "color": o["color"]}
+
+    def set_iter(self, iter: int) -> None:      # base_neuralfield.py:14-22: no warm-up state
+        pass
 
 
 # spellings used by BASELINE.json's north_star

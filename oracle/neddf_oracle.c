@@ -693,7 +693,110 @@ void orc_nerf_forward(const orc_nerf_t *net, const float *pos, const float *dir,
     }
 }
 
+typedef struct {
+    int embed_pos_rank, embed_dir_rank;
+    int n_sdf;              /* sdf_layer_count */
+    int width;
+    int n_col;              /* col_layer_count hidden layers; layers_col has n_col + 1 entries */
+    int n_skips;
+    int skips[8];
+    int activation;         /* ORC_RELU (nn.ReLU) or ORC_TANHEXP */
+    float variance;
+    /* nn.Linear layout [out,in] (neus.py:80-99) */
+    const float *sdf_w[ORC_MAX_LAYERS], *sdf_b[ORC_MAX_LAYERS];
+    const float *col_w[ORC_MAX_LAYERS], *col_b[ORC_MAX_LAYERS];
+} orc_neus_t;
+
+/* value + derivative of the plain activations NeuS uses (nn.ReLU / tanhExp) */
+static inline void orc_act_plain_grad(int kind, float x, float *y, float *dy)
+{
+    if (kind == ORC_RELU) { *y = x > 0.f ? x : 0.f; *dy = x > 0.f ? 1.f : 0.f; return; }
+    orc_act_grad(ORC_TANHEXP, x, y, dy);
+}
+
+/* NeuS.forward neus.py:101-162.  The reference obtains d sdf / d pos with
+ * torch.autograd.grad (reverse mode); here the same Jacobian is carried forward
+ * through the sdf trunk as three extra rows (exactly what the HIP engine does),
+ * which is the same quantity up to fp32 rounding order. */
+void orc_neus_forward(const orc_neus_t *net, const float *pos, const float *dir, int N, float *sdf_out, float *density,
+                      float *color)
+{
+    const int E = net->embed_pos_rank, Ed = net->embed_dir_rank, Cpe = 6 * E, Cdir = 6 * Ed, W = net->width;
+#pragma omp parallel
+    {
+        const int LD = ORC_MAX_IN;
+        float *pe = (float *)malloc(sizeof(float) * 4 * Cpe);
+        float *h = (float *)malloc(sizeof(float) * 4 * LD), *o = (float *)malloc(sizeof(float) * 4 * LD);
+#pragma omp for schedule(static)
+        for (int n = 0; n < N; ++n) {
+            memset(pe, 0, sizeof(float) * 4 * Cpe);
+            for (int e = 0; e < E; ++e) {
+                float f = ldexpf(1.0f, e);
+                for (int d = 0; d < 3; ++d) {
+                    int c = e * 3 + d;
+                    float p = f * pos[3 * n + d];
+                    float sn = sinf(p), cs = cosf(p);
+                    pe[c] = sn; pe[3 * E + c] = cs;                       /* positional_encoding.py:51-65, scale None */
+                    pe[(1 + d) * Cpe + c] = f * cs; pe[(1 + d) * Cpe + 3 * E + c] = -f * sn;
+                }
+            }
+            for (int r = 0; r < 4; ++r) memcpy(h + r * LD, pe + r * Cpe, sizeof(float) * Cpe);
+            int cin = Cpe;
+            for (int l = 0; l < net->n_sdf; ++l) {                          /* :128-131 */
+                for (int r = 0; r < 4; ++r)
+                    for (int j = 0; j < W; ++j) {
+                        const float *wr = net->sdf_w[l] + (size_t)j * cin;
+                        float acc = 0.f;
+                        for (int k = 0; k < cin; ++k) acc = fmaf(h[r * LD + k], wr[k], acc);
+                        o[r * LD + j] = r == 0 ? acc + net->sdf_b[l][j] : acc;
+                    }
+                for (int j = 0; j < W; ++j) {
+                    float y, dy;
+                    orc_act_plain_grad(net->activation, o[j], &y, &dy);
+                    o[j] = y;
+                    for (int r = 1; r < 4; ++r) o[r * LD + j] *= dy;
+                }
+                cin = W;
+                if (orc_in_skips(net->skips, net->n_skips, l)) {           /* cat([hx, embed_pos]) */
+                    for (int r = 0; r < 4; ++r) memcpy(o + r * LD + W, pe + r * Cpe, sizeof(float) * Cpe);
+                    cin = W + Cpe;
+                }
+                float *t = h; h = o; o = t;
+            }
+            float sdf = h[0];
+            float g[3] = { h[LD], h[2 * LD], h[3 * LD] };
+            /* colour input :146-149: [pos, embed_dir, gradients, sdf_feature] */
+            float *ci = o;
+            for (int d = 0; d < 3; ++d) ci[d] = pos[3 * n + d];
+            for (int e = 0; e < Ed; ++e)
+                for (int d = 0; d < 3; ++d) {
+                    float p = ldexpf(1.0f, e) * dir[3 * n + d];
+                    ci[3 + e * 3 + d] = sinf(p);
+                    ci[3 + 3 * Ed + e * 3 + d] = cosf(p);
+                }
+            for (int d = 0; d < 3; ++d) ci[3 + Cdir + d] = g[d];
+            memcpy(ci + 6 + Cdir, h, sizeof(float) * cin);
+            int ccin = 6 + Cdir + cin;
+            float *co = h;
+            for (int l = 0; l <= net->n_col; ++l) {                         /* :150-152, activation on every layer */
+                int cout = l < net->n_col ? W : 3;
+                orc_linear_t(ci, net->col_w[l], net->col_b[l], ccin, cout, co);
+                for (int j = 0; j < cout; ++j) co[j] = orc_act(net->activation, co[j]);
+                ccin = cout;
+                float *t = ci; ci = co; co = t;
+            }
+            float v10 = net->variance * 10.0f;
+            float ex = expf(-v10 * sdf);
+            float den = 1 + ex;
+            sdf_out[n] = sdf;
+            density[n] = v10 * ex * (1.0f / (den * den));                    /* :153-156 */
+            color[3 * n] = ci[0]; color[3 * n + 1] = ci[1]; color[3 * n + 2] = ci[2];
+        }
+        free(pe); free(h); free(o);
+    }
+}
+
 int orc_num_threads(void) { return omp_get_max_threads(); }
 void orc_set_num_threads(int n) { omp_set_num_threads(n); }
 
-int orc_struct_sizes(int which) { return which == 0 ? (int)sizeof(orc_neddf_t) : (int)sizeof(orc_nerf_t); }
+int orc_struct_sizes(int which) { return which == 0 ? (int)sizeof(orc_neddf_t) : which == 1 ? (int)sizeof(orc_nerf_t) : (int)sizeof(orc_neus_t); }

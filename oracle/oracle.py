@@ -35,6 +35,7 @@ def lib():
         _LIB = C.CDLL(path)
         assert _LIB.orc_struct_sizes(0) == C.sizeof(_NeDDF), "struct layout mismatch"
         assert _LIB.orc_struct_sizes(1) == C.sizeof(_NeRF), "struct layout mismatch"
+        assert _LIB.orc_struct_sizes(2) == C.sizeof(_NeuS), "struct layout mismatch"
     return _LIB
 
 
@@ -55,6 +56,13 @@ class _NeRF(C.Structure):
                 ("density_activation", C.c_int), ("lowpass", _fp), ("w", _fp * MAXL), ("b", _fp * MAXL),
                 ("dens_w", _fp), ("dens_b", _fp), ("col0_w", _fp), ("col0_b", _fp), ("col1_w", _fp),
                 ("col1_b", _fp)]
+
+
+class _NeuS(C.Structure):
+    _fields_ = [("embed_pos_rank", C.c_int), ("embed_dir_rank", C.c_int), ("n_sdf", C.c_int), ("width", C.c_int),
+                ("n_col", C.c_int), ("n_skips", C.c_int), ("skips", C.c_int * 8), ("activation", C.c_int),
+                ("variance", C.c_float), ("sdf_w", _fp * MAXL), ("sdf_b", _fp * MAXL), ("col_w", _fp * MAXL),
+                ("col_b", _fp * MAXL)]
 
 
 def _f32(a):
@@ -286,6 +294,40 @@ class NeRFOracle:
         dens = np.empty(N, np.float32); col = np.empty((N, 3), np.float32)
         lib().orc_nerf_forward(C.byref(self.s), _p(pos), _p(dir), _p(var), N, _p(dens), _p(col))
         return dict(density=dens.reshape(shp), color=col.reshape(shp + (3,)))
+
+
+class NeuSOracle:
+    """Mirrors NeuS(...) ctor keywords (neus.py:30-41) + a numpy state dict."""
+
+    def __init__(self, state, embed_pos_rank=6, embed_dir_rank=4, sdf_layer_count=8, sdf_layer_width=256,
+                 col_layer_count=8, col_layer_width=256, activation_type="ReLU", init_variance=0.3, skips=None):
+        if skips is None:
+            skips = [4]
+        assert sdf_layer_width == col_layer_width
+        self._keep = {k: _f32(v) for k, v in state.items()}
+        s = _NeuS()
+        s.embed_pos_rank, s.embed_dir_rank, s.n_sdf, s.width, s.n_col = embed_pos_rank, embed_dir_rank, sdf_layer_count, sdf_layer_width, col_layer_count
+        s.n_skips = len(skips)
+        for i, k in enumerate(skips):
+            s.skips[i] = k
+        s.activation = ACT[activation_type]
+        s.variance = float(np.asarray(self._keep["variance"]).reshape(-1)[0])
+        for i in range(sdf_layer_count):
+            s.sdf_w[i] = _p(self._keep["layers_sdf.%d.weight" % i]); s.sdf_b[i] = _p(self._keep["layers_sdf.%d.bias" % i])
+        for i in range(col_layer_count + 1):
+            s.col_w[i] = _p(self._keep["layers_col.%d.weight" % i]); s.col_b[i] = _p(self._keep["layers_col.%d.bias" % i])
+        self.s = s
+
+    def set_iter(self, it):
+        pass
+
+    def forward(self, pos, dir, var=None):
+        pos = _f32(pos); dir = _f32(dir)
+        shp = pos.shape[:-1]
+        N = int(np.prod(shp))
+        sdf = np.empty(N, np.float32); dens = np.empty(N, np.float32); col = np.empty((N, 3), np.float32)
+        lib().orc_neus_forward(C.byref(self.s), _p(pos), _p(dir), N, _p(sdf), _p(dens), _p(col))
+        return dict(sdf=sdf.reshape(shp), density=dens.reshape(shp), color=col.reshape(shp + (3,)))
 
 
 def render_rays(field_coarse, field_fine, uv, R, T, calib, u_coarse, u_fine, dist_near, dist_far, max_dist,

@@ -64,7 +64,7 @@ def _install_stubs():
 
 _install_stubs()
 from neddf.camera import Camera, PinholeCalib  # noqa: E402
-from neddf.network import NeDDF, NeRF  # noqa: E402
+from neddf.network import NeDDF, NeRF, NeuS  # noqa: E402
 from neddf.nn_module import PositionalEncoding  # noqa: E402
 from neddf.nn_module.with_grad import (  # noqa: E402
     LeakyReLUGradFunction, LinearGradFunction, PositionalEncodingGradLayer,
@@ -371,8 +371,34 @@ def gen_render_edges(render):
     save("render_edges.npz", **a)
 
 
+def gen_neus():
+    """NeuS field (neus.py:101-162; normals by torch.autograd.grad) on synthetic seeded weights."""
+    pos, d, var = synth.random_sampling(6, 40, seed=5, cone=False)
+    cases = {
+        "neus_relu": dict(embed_pos_rank=6, embed_dir_rank=4, sdf_layer_count=8, sdf_layer_width=256, col_layer_count=8,
+                          col_layer_width=256, init_variance=0.3, activation_type="ReLU", skips=[4]),     # tests/conftest.py:61-74
+        "neus_tanhexp": dict(embed_pos_rank=10, embed_dir_rank=3, sdf_layer_count=6, sdf_layer_width=256, col_layer_count=3,
+                             col_layer_width=256, init_variance=0.7, activation_type="tanhExp", skips=[2]),
+    }
+    for name, kw in cases.items():
+        net = NeuS(**kw)
+        sd = synth.neus_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["sdf_layer_count"], kw["sdf_layer_width"],
+                              kw["col_layer_count"], kw["col_layer_width"], tuple(kw["skips"]), kw["init_variance"], seed=13)
+        print(name, net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}))
+        with torch.enable_grad():
+            out = net(Sampling(torch.from_numpy(pos.copy()), torch.from_numpy(d), torch.from_numpy(var)))
+        arrs = dict(pos=pos, dir=d, var=var, config=np.array(json.dumps(kw)))
+        for k, v in out.items():
+            arrs["eval_" + k] = npy(v)
+        save(name + ".npz", **arrs)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "neus":
+        gen_neus()
+        sys.exit(0)
     r = gen_bunny()
     gen_ops()
     gen_fields()
     gen_render_edges(r)
+    gen_neus()

@@ -93,3 +93,23 @@ def random_sampling(n_rays, n_samples, seed, cone=True):
     else:
         var = np.zeros((n_rays, n_samples, 3), np.float32)
     return pos, d, var
+
+
+def neus_state(embed_pos_rank=6, embed_dir_rank=4, sdf_layer_count=8, sdf_layer_width=256, col_layer_count=8,
+               col_layer_width=256, skips=(4,), init_variance=0.3, seed=13):
+    """State dict (numpy) with the key names/shapes of the reference NeuS
+    (neddf/network/neus.py:80-99): nn.Linear weights [out, in] + scalar `variance`."""
+    rng = np.random.default_rng(seed)
+    in_sdf = embed_pos_rank * 6
+    in_col = 6 + embed_dir_rank * 6 + sdf_layer_width
+    sd = OrderedDict()
+    dims = [(in_sdf, sdf_layer_width)]
+    for layer_id in range(sdf_layer_count - 1):
+        dims.append((sdf_layer_width + (in_sdf if layer_id in skips else 0), sdf_layer_width))
+    for i, (a, b) in enumerate(dims):
+        sd["layers_sdf.%d.weight" % i], sd["layers_sdf.%d.bias" % i] = _layer(rng, a, b, True)
+    dims = [(in_col, col_layer_width)] + [(col_layer_width, col_layer_width)] * (col_layer_count - 1) + [(col_layer_width, 3)]
+    for i, (a, b) in enumerate(dims):
+        sd["layers_col.%d.weight" % i], sd["layers_col.%d.bias" % i] = _layer(rng, a, b, True)
+    sd["variance"] = np.float32(init_variance)
+    return sd

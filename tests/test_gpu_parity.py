@@ -631,3 +631,22 @@ def test_rccl_collectives_single_rank(tmp_path):
     p = subprocess.run([sys.executable, str(script), ROOT, str(29600 + os.getpid() % 1000)], env=env, capture_output=True, text=True,
                        timeout=300)
     assert p.returncode == 0 and "rccl ok" in p.stdout, p.stdout + p.stderr
+
+
+@pytest.mark.parametrize("name", ["neus_relu", "neus_tanhexp"])
+def test_neus_synth(dev, orc, name):
+    """NeuS (neus.py:101-162): forward-mode normals on the tile engine vs the reference's autograd normals."""
+    import neddf_amd
+    g = golden(name + ".npz")
+    kw = json.loads(str(g["config"]))
+    sd = synth.neus_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["sdf_layer_count"], kw["sdf_layer_width"],
+                          kw["col_layer_count"], kw["col_layer_width"], tuple(kw["skips"]), kw["init_variance"], seed=13)
+    net = neddf_amd.NeuS(**kw)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    net.to(dev)
+    o = net(smp(g, dev))
+    assert set(o) == {"sdf", "density", "color"} and o["color"].shape == g["eval_color"].shape
+    ref = orc.NeuSOracle(sd, **kw).forward(g["pos"], g["dir"])
+    for k in ("sdf", "density", "color"):
+        assert_close(N(o[k]), g["eval_" + k], 1e-4, 1e-5, "%s %s vs golden" % (name, k))
+        assert_close(N(o[k]), ref[k], 1e-4, 1e-5, "%s %s vs oracle" % (name, k))

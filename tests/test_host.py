@@ -85,6 +85,9 @@ def test_state_dict_matches_reference_checkpoint(bunny_weights):
     sdn = n.state_dict()
     assert tuple(sdn["layers.5.weight"].shape) == (256, 316) and tuple(sdn["outL_color.0.weight"].shape) == (128, 280)
     assert set(sdn) == set(__import__("synth").nerf_state().keys())
+    s = neddf_amd.NeuS()
+    assert {k: tuple(v.shape) for k, v in s.state_dict().items()} == \
+        {k: tuple(np.asarray(v).shape) for k, v in __import__("synth").neus_state().items()}
 
 
 def test_constructor_signatures_match_reference():

@@ -179,3 +179,16 @@ def test_nerf_render_rays():
                           "point")
     for k in ("color", "depth", "transmittance", "color_coarse", "depth_coarse", "transmittance_coarse"):
         assert_close(out[k], g["out_" + k], 1e-4, 1e-5, k)
+
+
+@pytest.mark.parametrize("name", ["neus_relu", "neus_tanhexp"])
+def test_neus_synth(name):
+    """NeuS (neus.py:101-162): forward-mode normals of the oracle vs the reference's autograd normals."""
+    g = golden(name + ".npz")
+    kw = json.loads(str(g["config"]))
+    sd = synth.neus_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["sdf_layer_count"], kw["sdf_layer_width"],
+                          kw["col_layer_count"], kw["col_layer_width"], tuple(kw["skips"]), kw["init_variance"], seed=13)
+    net = orc.NeuSOracle(sd, **kw)
+    o = net.forward(g["pos"], g["dir"])
+    for k in ("sdf", "density", "color"):
+        assert_close(o[k], g["eval_" + k], 1e-4, 1e-5, "%s %s" % (name, k))
