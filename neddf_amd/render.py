@@ -170,25 +170,38 @@ class NeRFRender(BaseNeuralRender):
             self.network_coarse.eval()
             self.network_fine.eval()
             ctx = self._ctx(dev)
-            if self.rng == "torch_cpu":
-                uc, uf = [], []
-                for below in range(0, n, chunk):
-                    b = min(n, below + chunk) - below
-                    uc.append(torch.rand(b, self.sample_coarse + 1))
-                    uf.append(torch.rand(b, self.sample_fine + 1))
-                U_c, U_f = torch.cat(uc).to(dev), torch.cat(uf).to(dev)
-            else:
-                U_c = self._rand(n, self.sample_coarse + 1, dev)
-                U_f = self._rand(n, self.sample_fine + 1, dev)
             parts: Dict[str, List[Tensor]] = {k: [] for k in target_types}
             flags = []
             lo, hi = (0, n) if pixel_range is None else pixel_range
-            for below in range(lo, hi, self.rays_per_call):
-                above = min(hi, below + self.rays_per_call)
-                o = self._render(ctx, uv[below:above], camera, U_c[below:above], U_f[below:above], full=False)
+
+            def launch(below, above, U_c, U_f):
+                o = self._render(ctx, uv[below:above], camera, U_c, U_f, full=False)
                 flags.append(o["_nan"])
                 for k in target_types:
                     parts[k].append(o[k])
+
+            if self.rng == "torch_cpu":
+                # Draw chunk by chunk in the reference's order, but hand rays_per_call rays at a time to the GPU:
+                # launches are asynchronous, so the host draws the next batch while the device renders this one.
+                uc, uf, start, count = [], [], 0, 0
+                for below in range(0, n, chunk):
+                    b = min(n, below + chunk) - below
+                    c_, f_ = torch.rand(b, self.sample_coarse + 1), torch.rand(b, self.sample_fine + 1)
+                    if below + b <= lo or below >= hi:
+                        start = below + b           # outside the requested slab: the draws only advance the generator
+                        continue
+                    uc.append(c_); uf.append(f_); count += b
+                    if count >= self.rays_per_call or below + b >= min(n, hi):
+                        a0, a1 = max(start, lo), min(start + count, hi)
+                        U_c = torch.cat(uc)[a0 - start:a1 - start].to(dev, non_blocking=True)
+                        U_f = torch.cat(uf)[a0 - start:a1 - start].to(dev, non_blocking=True)
+                        launch(a0, a1, U_c, U_f)
+                        uc, uf, start, count = [], [], start + count, 0
+            else:
+                for below in range(lo, hi, self.rays_per_call):
+                    above = min(hi, below + self.rays_per_call)
+                    launch(below, above, self._rand(above - below, self.sample_coarse + 1, dev),
+                           self._rand(above - below, self.sample_fine + 1, dev))
             assert int(torch.stack(flags).sum().item()) == 0, "NaN weight in integrate_volume_render"
             if pixel_range is None:
                 images = {k: torch.cat(parts[k], 0).reshape(h, w, -1) for k in target_types}

@@ -277,3 +277,46 @@ def test_metrics_against_direct_evaluation():
         tot.append(np.mean(vals))
     assert abs(structural_similarity(a, b, channel_axis=2) - np.mean(tot)) < 1e-9
     assert structural_similarity(a, a) == 1.0
+
+
+def test_render_image_rng_order_and_batching():
+    """render_image (nerf_render.py:190-249) must consume the CPU generator chunk by chunk in the reference's order
+    ([b,Sc+1] then [b,Sf+1] per chunk) whatever rays_per_call / pixel_range are; the device work is stubbed out."""
+    from neddf_amd.render import NeRFRender
+
+    class Stub(NeRFRender):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.sample_coarse, self.sample_fine, self.rng, self.rays_per_call = 4, 6, "torch_cpu", 7
+            self.network_coarse = self.network_fine = torch.nn.Linear(1, 1)
+
+        def _ctx(self, dev):
+            return None
+
+        def _render(self, ctx, uv, camera, U_c, U_f, full):
+            assert uv.shape[0] == U_c.shape[0] == U_f.shape[0]
+            return {"color": torch.cat([U_c[:, :1], U_f[:, :1], uv[:, :1].float()], 1), "_nan": torch.zeros(1, dtype=torch.int32)}
+
+    class Cam:
+        device = torch.device("cpu")
+
+    def reference_draws(n, chunk):
+        uc, uf = [], []
+        for b0 in range(0, n, chunk):
+            b = min(n, b0 + chunk) - b0
+            uc.append(torch.rand(b, 5)); uf.append(torch.rand(b, 7))
+        return torch.cat(uc)[:, 0], torch.cat(uf)[:, 0]
+
+    r = Stub()
+    for rpc in (1, 3, 7, 10, 1000):
+        for chunk in (1, 4, 5, 100):
+            for pr in (None, (0, 3), (5, 17), (19, 20), (0, 20)):
+                r.rays_per_call = rpc
+                torch.manual_seed(1)
+                a, b = reference_draws(20, chunk)
+                torch.manual_seed(1)
+                img = r.render_image(5, 4, Cam(), ["color"], 1, chunk, pixel_range=pr)["color"].reshape(-1, 3)
+                lo, hi = pr if pr else (0, 20)
+                assert torch.equal(img[:, 0], a[lo:hi]) and torch.equal(img[:, 1], b[lo:hi]), (rpc, chunk, pr)
+                assert torch.equal(img[:, 2], (torch.arange(20) % 5).float()[lo:hi])
+    assert r.render_image(5, 4, Cam(), ["color"], 1, 6)["color"].shape == (4, 5, 3)
