@@ -393,7 +393,108 @@ def gen_neus():
         save(name + ".npz", **arrs)
 
 
+def gen_train():
+    """One training step of the reference (nerf_trainer.py:81-140) on 12 bunny_smoke rays: render_rays with autograd
+    through the hand-written backward passes of neddf/nn_module/with_grad, the three losses of config/loss/neddf_loss.yaml,
+    loss.backward().  Stores inputs, losses and the parameter gradients (selected tensors in full, all of them as norms +
+    a fixed random projection)."""
+    from neddf.loss import ColorLoss, FieldsConstraintLoss, MaskBCELoss
+    cfg = yaml.safe_load(open(os.path.join(REF, "pretrained/bunny_smoke/.hydra/config.yaml")))
+    rcfg = dict(cfg["render"]); rcfg.pop("_target_")
+    # density activation ReLU (config/network/neddf.yaml default) instead of the checkpoint's LeakyReLU: with negative
+    # densities the reference's in-place weight sanitisation (base_neural_render.py:52-55) invalidates its own autograd
+    # graph ("modified by an inplace operation"), i.e. the reference cannot take a training step in that regime
+    ncfg = dict(cfg["network"], density_activation_type="ReLU")
+    render = NeRFRender(network_config=ncfg, **rcfg)
+    render.load_state_dict(torch.load(os.path.join(REF, "pretrained/bunny_smoke/models/model_02000.pth"), map_location="cpu"))
+    render.set_iter(1500)           # a warm-up iteration: aux_grad_scale 0.15, low-pass all-pass (alpha 11.5)
+    tf = json.load(open(os.path.join(REF, "data/bunny_smoke/transforms_test.json")))
+    cam, calib = make_camera(400, 400, tf["frames"][3], tf["camera_angle_x"])
+    cam.update_transform()
+    rng = np.random.default_rng(77)
+    uv = torch.from_numpy(rng.integers(140, 260, (12, 2)).astype(np.int16))
+    target = {"color": torch.from_numpy(rng.uniform(0, 1, (12, 3)).astype(np.float32)),
+              "mask": torch.from_numpy((rng.uniform(0, 1, 12) > 0.5).astype(np.float32)),
+              "fields_penalty": torch.zeros(12)}
+    losses = [ColorLoss(weight=1.0, weight_coarse=0.1), MaskBCELoss(weight=0.05, weight_coarse=0.005),
+              FieldsConstraintLoss(weight=0.01, weight_coarse=0.01)]
+    torch.manual_seed(9)
+    state = torch.get_rng_state()
+    u_c, u_f = torch.rand(12, 65), torch.rand(12, 129)
+    torch.set_rng_state(state)
+    with torch.enable_grad():
+        render.zero_grad()
+        out = render.render_rays(uv, cam)
+        ld = {}
+        for f in losses:
+            ld.update(f(out, target))
+        loss = torch.sum(torch.stack(list(ld.values())))
+        loss.backward()
+    arrs = dict(uv=npy(uv), R=npy(cam.R), T=npy(cam.T), calib=calib, u_coarse=npy(u_c), u_fine=npy(u_f),
+                target_color=npy(target["color"]), target_mask=npy(target["mask"]), loss=npy(loss), iteration=np.int32(1500))
+    for k, v in ld.items():
+        arrs["loss_" + k] = npy(v)
+    for k, v in out.items():
+        arrs["out_" + k] = npy(v)
+    proj = np.random.default_rng(123)
+    full = ("layers_ddf.0.weight", "layers_ddf.5.weight", "layers_ddf.6.bias", "layers_col.0.weight", "layers_col.2.weight",
+            "layer_ddf_out.weight", "layer_ddf_out.bias", "layer_aux_out.weight", "layer_aux_out.bias", "layer_col_out.weight",
+            "layer_col_out.bias", "layers_ddf.0.bias", "layers_col.0.bias")
+    names = []
+    for k, p_ in render.network_fine.named_parameters():
+        gnp = npy(p_.grad)
+        names.append(k)
+        arrs["gnorm_" + k] = np.float64(np.linalg.norm(gnp.astype(np.float64)))
+        arrs["gproj_" + k] = np.float64(np.sum(gnp.astype(np.float64) * proj.standard_normal(gnp.shape)))
+        if k in full:
+            arrs["grad_" + k] = gnp
+    arrs["param_names"] = np.array(json.dumps(names))
+
+    # stage: integrate_volume_render backward alone
+    B, S = 7, 40
+    d = torch.sort(torch.from_numpy(rng.uniform(2, 6, (B, S)).astype(np.float32)), dim=1)[0]
+    dens = torch.from_numpy(rng.uniform(-2, 15, (B, S)).astype(np.float32)).requires_grad_(True)
+    col = torch.from_numpy(rng.uniform(-0.2, 1.1, (B, S, 3)).astype(np.float32)).requires_grad_(True)
+    g_col = torch.from_numpy(rng.standard_normal((B, 3)).astype(np.float32))
+    g_dep = torch.from_numpy(rng.standard_normal(B).astype(np.float32))
+    g_tr = torch.from_numpy(rng.standard_normal(B).astype(np.float32))
+    g_w = torch.from_numpy(rng.standard_normal((B, S - 1)).astype(np.float32))
+    with torch.enable_grad():
+        r = render.integrate_volume_render(d, dens, col)
+        obj = (r["color"] * g_col).sum() + (r["depth"] * g_dep).sum() + (r["transmittance"] * g_tr).sum() + (r["weight"] * g_w).sum()
+        obj.backward()
+    arrs.update(cb_dists=npy(d), cb_dens=npy(dens), cb_col=npy(col), cb_g_color=npy(g_col), cb_g_depth=npy(g_dep),
+                cb_g_trans=npy(g_tr), cb_g_weight=npy(g_w), cb_grad_dens=npy(dens.grad), cb_grad_col=npy(col.grad))
+
+    # stage: field backward alone on 40 sample points with random upstream gradients
+    pos, dd, var = synth.random_sampling(2, 20, seed=31, cone=True)
+    smp = Sampling(torch.from_numpy(pos), torch.from_numpy(dd), torch.from_numpy(var))
+    ups = {k: torch.from_numpy(rng.standard_normal((2, 20) + ((3,) if k == "color" else ())).astype(np.float32))
+           for k in ("distance", "density", "color", "fields_penalty", "aux_grad")}
+    with torch.enable_grad():
+        render.zero_grad()
+        o = render.network_fine(smp)
+        obj = sum((o[k] * ups[k]).sum() for k in ups)
+        obj.backward()
+    arrs.update(fb_pos=pos, fb_dir=dd, fb_var=var)
+    for k, v in ups.items():
+        arrs["fb_g_" + k] = npy(v)
+    for k, v in o.items():
+        arrs["fb_out_" + k] = npy(v)
+    proj = np.random.default_rng(456)
+    for k, p_ in render.network_fine.named_parameters():
+        gnp = npy(p_.grad)
+        arrs["fb_gnorm_" + k] = np.float64(np.linalg.norm(gnp.astype(np.float64)))
+        arrs["fb_gproj_" + k] = np.float64(np.sum(gnp.astype(np.float64) * proj.standard_normal(gnp.shape)))
+        if k in full:
+            arrs["fb_grad_" + k] = gnp
+    save("train_step.npz", **arrs)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        gen_train()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "neus":
         gen_neus()
         sys.exit(0)
@@ -402,3 +503,4 @@ if __name__ == "__main__":
     gen_fields()
     gen_render_edges(r)
     gen_neus()
+    gen_train()
