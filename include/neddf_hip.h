@@ -205,6 +205,34 @@ int neddf_set_timing(neddf_ctx *ctx, int enable);
 
 int neddf_get_timings(neddf_ctx *ctx, float *ms, int n);
 
+/* ---- training step -------------------------------------------
+ * The reference trains through torch autograd over its with_grad modules
+ * (the modules under neddf/nn_module/with_grad: each has a hand-written backward for the
+ * (value, Jacobian) pair).  These entry points are that forward + backward for one NeDDF
+ * network on N sample points.  The parameters are DEVICE fp32 arrays in the reference's
+ * state-dict layout and order (see neddf_set_field); gradients are ACCUMULATED into d_gW / d_gB
+ * (same shapes).  The slot supplies the architecture and the set_iter state; the weights it was
+ * loaded with are not used here.  `d_workspace` (neddf_train_workspace_floats floats, caller-owned)
+ * carries the saved activations from the forward call to the matching backward call. */
+int64_t neddf_train_workspace_floats(neddf_ctx *ctx, int slot, int64_t n_points);
+/* NeDDF.forward (neddf.py:162-309) in training mode: all five outputs ([N] each, color [N,3]); any may be NULL. */
+int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *d_W, const float *const *d_B, int n_tensors,
+                              const float *d_pos, const float *d_dir, const float *d_var, int64_t n_points,
+                              float *d_workspace, float *d_distance, float *d_density, float *d_color,
+                              float *d_fields_penalty, float *d_aux_grad, void *stream);
+/* Reverse pass: upstream gradients of the five outputs (any may be NULL = zero) -> parameter gradients. */
+int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *d_W, const float *const *d_B, int n_tensors,
+                               int64_t n_points, const float *d_workspace, const float *d_g_distance,
+                               const float *d_g_density, const float *d_g_color, const float *d_g_fields_penalty,
+                               const float *d_g_aux_grad, float *const *d_gW, float *const *d_gB, void *stream);
+/* Backward of integrate_volume_render (base_neural_render.py:148-171): gradients of weight [n_rays,S-1],
+ * depth [n_rays], color [n_rays,3], transmittance [n_rays] (any may be NULL) -> d_g_density [n_rays,S],
+ * d_g_point_color [n_rays,S,3]. */
+int neddf_composite_backward(neddf_ctx *ctx, const float *d_dists, const float *d_density, const float *d_color,
+                             int64_t n_rays, int S, float max_dist, const float *d_g_weight, const float *d_g_depth,
+                             const float *d_g_color, const float *d_g_transmittance, float *d_g_density,
+                             float *d_g_point_color, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,12 @@ SYMBOLS = [
     ("neddf_op_linear_grad", C.c_int, [_vp, _vp, _vp, _fp, _fp, _i64, C.c_int, C.c_int, _vp, _vp, _vp]),
     ("neddf_set_timing", C.c_int, [_vp, C.c_int]),
     ("neddf_get_timings", C.c_int, [_vp, _fp, C.c_int]),
+    ("neddf_train_workspace_floats", _i64, [_vp, C.c_int, _i64]),
+    ("neddf_train_field_forward", C.c_int, [_vp, C.c_int, C.POINTER(_fp), C.POINTER(_fp), C.c_int, _vp, _vp, _vp, _i64, _vp,
+                                            _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("neddf_train_field_backward", C.c_int, [_vp, C.c_int, C.POINTER(_fp), C.POINTER(_fp), C.c_int, _i64, _vp, _vp, _vp, _vp,
+                                             _vp, _vp, C.POINTER(_fp), C.POINTER(_fp), _vp]),
+    ("neddf_composite_backward", C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 ]
 
 _lib = None
@@ -312,6 +318,57 @@ class Context:
 
     def set_timing(self, on):
         self.check(self.lib.neddf_set_timing(self.h, int(on)))
+
+    # ------------------------------------------------------------------ training step
+    @staticmethod
+    def _dev_ptrs(tensors, what):
+        for t in tensors:
+            require_device(t, what)
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise NeddfError("%s must be contiguous float32 device tensors" % what)
+        return (_fp * len(tensors))(*[C.cast(t.data_ptr(), _fp) for t in tensors])
+
+    def train_field_forward(self, slot, weights, biases, pos, dir, var):
+        """NeDDF.forward keeping the activations: returns (workspace, distance, density, color, penalty, aux_grad)."""
+        require_device(pos, "sample positions")
+        pos, dir, var = f32c(pos).reshape(-1, 3), f32c(dir).reshape(-1, 3), f32c(var).reshape(-1, 3)
+        N = pos.shape[0]
+        n_ws = self.lib.neddf_train_workspace_floats(self.h, slot, N)
+        if n_ws < 0:
+            raise NeddfError("libneddf_hip: %s" % self.lib.neddf_last_error(self.h).decode())
+        dev = pos.device
+        ws = torch.empty(max(int(n_ws), 1), device=dev, dtype=torch.float32)
+        out = [torch.empty(N, device=dev, dtype=torch.float32) for _ in range(2)]
+        color = torch.empty(N, 3, device=dev, dtype=torch.float32)
+        pen = torch.empty(N, device=dev, dtype=torch.float32)
+        aux = torch.empty(N, device=dev, dtype=torch.float32)
+        wa, ba = self._dev_ptrs(weights, "weights"), self._dev_ptrs(biases, "biases")
+        self.check(self.lib.neddf_train_field_forward(self.h, slot, wa, ba, len(weights), _ptr(pos), _ptr(dir), _ptr(var), N,
+                                                      _ptr(ws), _ptr(out[0]), _ptr(out[1]), _ptr(color), _ptr(pen), _ptr(aux),
+                                                      self.stream()))
+        return ws, out[0], out[1], color, pen, aux
+
+    def train_field_backward(self, slot, weights, biases, N, ws, g_distance, g_density, g_color, g_penalty, g_aux):
+        """Returns (grad_weights, grad_biases) in the layout of `weights` / `biases`."""
+        gs = [None if g is None else f32c(g) for g in (g_distance, g_density, g_color, g_penalty, g_aux)]
+        gw = [torch.zeros_like(w) for w in weights]
+        gb = [torch.zeros_like(b) for b in biases]
+        wa, ba = self._dev_ptrs(weights, "weights"), self._dev_ptrs(biases, "biases")
+        gwa, gba = self._dev_ptrs(gw, "weight gradients"), self._dev_ptrs(gb, "bias gradients")
+        self.check(self.lib.neddf_train_field_backward(self.h, slot, wa, ba, len(weights), N, _ptr(ws), _ptr(gs[0]), _ptr(gs[1]),
+                                                       _ptr(gs[2]), _ptr(gs[3]), _ptr(gs[4]), gwa, gba, self.stream()))
+        return gw, gb
+
+    def composite_backward(self, dists, density, color, max_dist, g_weight, g_depth, g_color, g_trans):
+        dists, density, color = f32c(dists), f32c(density), f32c(color)
+        B, S = dists.shape
+        gs = [None if g is None else f32c(g) for g in (g_weight, g_depth, g_color, g_trans)]
+        g_density = torch.empty(B, S, device=dists.device, dtype=torch.float32)
+        g_pc = torch.empty(B, S, 3, device=dists.device, dtype=torch.float32)
+        self.check(self.lib.neddf_composite_backward(self.h, _ptr(dists), _ptr(density), _ptr(color), B, S, float(max_dist),
+                                                     _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(gs[3]), _ptr(g_density),
+                                                     _ptr(g_pc), self.stream()))
+        return g_density, g_pc
 
     def get_timings(self):
         """{'ddf_ms','col_ms','nerf_ms','ddf_launches','col_launches','nerf_launches'} since the last call."""

@@ -1,0 +1,88 @@
+// capi_internal.h -- context layout shared by the C-ABI translation units
+// (neddf_capi.hip: inference path, train_capi.hip: training step).  Not installed.
+#pragma once
+#include "../../include/neddf_hip.h"
+#include "kernels.h"
+
+#include <string>
+#include <vector>
+
+using namespace neddf;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Field {
+    bool valid = false;
+    neddf_field_desc d{};
+    float aux_grad_scale = 1.1f, distance_range_max = 2.0f;
+    float lowpass[10];
+    DevBuf blob;
+    DdfArgs ddf{};
+    ColArgs col{};
+    NerfArgs nerf{};
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int which;
+};
+
+struct neddf_ctx {
+    int device = 0;
+    int cus = 256;
+    std::string err;
+    Field field[NEDDF_NUM_SLOTS];
+    DevBuf features, ptaux, scratch, arena, flags, sched;
+    DevBuf tpack, ttmp;          // training step: packed weights of the layer in flight, gradient ping-pong buffers
+    bool timing = false;
+    std::vector<EventPair> events;
+    std::vector<EventPair> pool;
+};
+
+#define HIPCHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+            return NEDDF_EHIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+static inline int fail(neddf_ctx *ctx, int code, const std::string &msg)
+{
+    ctx->err = msg;
+    return code;
+}
+
+static inline int ensure(neddf_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (b.cap >= bytes) return 0;
+    if (b.p) {
+        HIPCHK(hipDeviceSynchronize());      // nothing in flight may still use the old block
+        HIPCHK(hipFree(b.p));
+        b.p = nullptr; b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8;
+    HIPCHK(hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+
+static inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
+
+static inline bool in_skips(const neddf_field_desc &d, int id)
+{
+    for (int i = 0; i < d.n_skips; ++i) if (d.skips[i] == id) return true;
+    return false;
+}
+
+static inline void fill_enc(EncodeDesc &e, const Field &f)
+{
+    e.E = f.d.embed_pos_rank; e.Ed = f.d.embed_dir_rank;
+    e.KH = roundup(3 * e.E, 4); e.KD = roundup(3 * e.Ed, 4);
+    for (int i = 0; i < 10; ++i) e.lowpass[i] = f.lowpass[i];
+}

@@ -15,72 +15,9 @@
 
 using namespace neddf;
 
-namespace {
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-};
-
-struct Field {
-    bool valid = false;
-    neddf_field_desc d{};
-    float aux_grad_scale = 1.1f, distance_range_max = 2.0f;
-    float lowpass[10];
-    DevBuf blob;
-    DdfArgs ddf{};
-    ColArgs col{};
-    NerfArgs nerf{};
-};
-
-struct EventPair {
-    hipEvent_t a, b;
-    int which;
-};
-
-}  // namespace
-
-struct neddf_ctx {
-    int device = 0;
-    int cus = 256;
-    std::string err;
-    Field field[NEDDF_NUM_SLOTS];
-    DevBuf features, ptaux, scratch, arena, flags, sched;
-    bool timing = false;
-    std::vector<EventPair> events;
-    std::vector<EventPair> pool;
-};
+#include "capi_internal.h"
 
 static char g_err[256] = "no context";
-
-#define HIPCHK(call)                                                                          \
-    do {                                                                                      \
-        hipError_t e_ = (call);                                                               \
-        if (e_ != hipSuccess) {                                                               \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
-            return NEDDF_EHIP;                                                                \
-        }                                                                                     \
-    } while (0)
-
-static int fail(neddf_ctx *ctx, int code, const std::string &msg)
-{
-    ctx->err = msg;
-    return code;
-}
-
-static int ensure(neddf_ctx *ctx, DevBuf &b, size_t bytes)
-{
-    if (b.cap >= bytes) return 0;
-    if (b.p) {
-        HIPCHK(hipDeviceSynchronize());      // nothing in flight may still use the old block
-        HIPCHK(hipFree(b.p));
-        b.p = nullptr; b.cap = 0;
-    }
-    size_t want = bytes + bytes / 8;
-    HIPCHK(hipMalloc(&b.p, want));
-    b.cap = want;
-    return 0;
-}
 
 // NEDDF_SCHED (debug/ablation): bit 1 dynamic tile queue (default on); bits 2..5 phase ablations of the distance kernel
 static int sched_flags()
@@ -93,7 +30,6 @@ static int sched_flags()
     return v;
 }
 
-static inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
 
 // ---------------------------------------------------------------------------
 // weight packing
@@ -138,18 +74,7 @@ static void enc_map(std::vector<int> &m, int rank, int K, int base)
     for (int q = 0; q < K; ++q) m.push_back(q < 3 * rank ? base + 3 * rank + q : -1);
 }
 
-static bool in_skips(const neddf_field_desc &d, int id)
-{
-    for (int i = 0; i < d.n_skips; ++i) if (d.skips[i] == id) return true;
-    return false;
-}
 
-static void fill_enc(EncodeDesc &e, const Field &f)
-{
-    e.E = f.d.embed_pos_rank; e.Ed = f.d.embed_dir_rank;
-    e.KH = roundup(3 * e.E, 4); e.KD = roundup(3 * e.Ed, 4);
-    for (int i = 0; i < 10; ++i) e.lowpass[i] = f.lowpass[i];
-}
 
 static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const float *const *B, int n_tensors)
 {
@@ -524,7 +449,7 @@ void neddf_destroy(neddf_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto &f : ctx->field) if (f.blob.p) (void)hipFree(f.blob.p);
-    for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags, &ctx->sched })
+    for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags, &ctx->sched, &ctx->tpack, &ctx->ttmp })
         if (b->p) (void)hipFree(b->p);
     for (auto &e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : ctx->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

@@ -1,0 +1,235 @@
+// train_capi.hip -- C ABI of the training step (include/neddf_hip.h, "training" section):
+// NeDDF.forward with everything its hand-written backward passes need kept in a caller-owned
+// workspace, the reverse pass producing parameter gradients in the reference's own
+// state-dict layout, and the backward of integrate_volume_render.
+//
+// The parameters stay where the optimiser updates them (torch tensors on the device, reference
+// layout); each call re-packs them into MFMA fragment order on the device (launch_pack), so
+// there is no host copy of the weights on the training path.
+#include "capi_internal.h"
+#include "train_kernels.h"
+
+namespace {
+
+struct Plan {
+    int E, Ed, Cpe, Cdir, Ca, ldxa, n_trunk, n_col, i_ddf, i_aux, i_cout;
+    int64_t N, R;
+    // workspace offsets (floats)
+    size_t o_pes, o_xa, o_pt, o_cr, o_z[kMaxLayers], o_h[kMaxLayers], o_zc[kMaxLayers], o_hc[kMaxLayers], total;
+};
+
+constexpr int kLdPe = 64, kLdDir = 32, kLdNarrow = 4;
+
+int make_plan(neddf_ctx *ctx, int slot, int64_t N, int n_tensors, Plan &p)
+{
+    if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");
+    const Field &f = ctx->field[slot];
+    if (f.d.kind != NEDDF_FIELD_NEDDF) return fail(ctx, NEDDF_EUNSUPPORTED, "the training step is implemented for NeDDF fields");
+    p.E = f.d.embed_pos_rank; p.Ed = f.d.embed_dir_rank;
+    p.Cpe = 6 * p.E; p.Cdir = 6 * p.Ed; p.Ca = p.Cpe + p.Cdir + 3; p.ldxa = roundup(p.Ca, 8);
+    p.n_trunk = f.d.layer_count - 1; p.n_col = f.d.col_layer_count - 1;
+    p.i_ddf = p.n_trunk + p.n_col; p.i_aux = p.i_ddf + 1; p.i_cout = p.i_ddf + 2;
+    if (n_tensors >= 0 && n_tensors != p.n_trunk + p.n_col + 3) return fail(ctx, NEDDF_EINVAL, "NeDDF: wrong tensor count");
+    p.N = N; p.R = 4 * N;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += (n + 63) & ~(size_t)63; return at; };
+    p.o_pes = take((size_t)p.R * kLdPe);
+    p.o_xa = take((size_t)p.R * p.ldxa);
+    p.o_pt = take((size_t)N * kTrainPt);
+    p.o_cr = take((size_t)p.R * kLdNarrow);
+    for (int l = 0; l < p.n_trunk; ++l) { p.o_z[l] = take((size_t)p.R * kWidth); p.o_h[l] = take((size_t)p.R * kWidth); }
+    for (int l = 0; l < p.n_col; ++l) { p.o_zc[l] = take((size_t)p.R * kWidth); p.o_hc[l] = take((size_t)p.R * kWidth); }
+    p.total = o;
+    return 0;
+}
+
+void point_args(TrainPointArgs &a, const Field &f, const Plan &p, float *ws)
+{
+    a = TrainPointArgs{};
+    a.N = p.N;
+    fill_enc(a.enc, f);
+    a.density_activation = f.d.density_activation;
+    a.d_near = f.d.d_near;
+    a.aux_grad_scale = f.aux_grad_scale;
+    a.distance_range_max = f.distance_range_max;
+    for (int k = 0; k < 6; ++k) { a.penalty_weight[k] = f.d.penalty_weight[k]; a.penalty_has[k] = f.d.penalty_has[k]; }
+    a.ldh = kLdNarrow; a.ldpe = kLdPe; a.ldd = kLdDir; a.ldxa = p.ldxa; a.ldc = kLdNarrow;
+    a.XA = ws + p.o_xa; a.PT = ws + p.o_pt; a.CR = ws + p.o_cr;
+}
+
+constexpr size_t kPackFloats = (size_t)kWidth * kWidth;        // one packed 256 x 256 segment
+
+}  // namespace
+
+extern "C" {
+
+int64_t neddf_train_workspace_floats(neddf_ctx *ctx, int slot, int64_t n_points)
+{
+    if (!ctx || n_points < 0) return -1;
+    Plan p;
+    if (make_plan(ctx, slot, n_points, -1, p)) return -1;
+    return (int64_t)p.total;
+}
+
+int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, const float *const *B, int n_tensors,
+                              const float *pos, const float *dir, const float *var, int64_t N, float *ws, float *distance,
+                              float *density, float *color, float *penalty, float *aux_grad, void *stream)
+{
+    if (!ctx) return NEDDF_EINVAL;
+    if (N <= 0) return 0;
+    if (!W || !B || !pos || !dir || !var || !ws) return fail(ctx, NEDDF_EINVAL, "null argument");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    Plan p;
+    if (int rc = make_plan(ctx, slot, N, n_tensors, p)) return rc;
+    const Field &f = ctx->field[slot];
+    const int act = f.d.activation;
+    if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->ttmp, ((size_t)p.R * (kLdPe + kLdNarrow) + (size_t)N * kLdDir) * sizeof(float))) return rc;
+    float *wp = (float *)ctx->tpack.p, *wp2 = wp + kPackFloats;
+    float *PEu = (float *)ctx->ttmp.p, *Ed = PEu + (size_t)p.R * kLdPe, *ZH = Ed + (size_t)N * kLdDir;
+    float *PEs = ws + p.o_pes;
+    TrainPointArgs a;
+    point_args(a, f, p, ws);
+    launch_pe_rows(pos, dir, var, N, a.enc, PEs, PEu, kLdPe, Ed, kLdDir, s);
+    // distance trunk (neddf.py:206-218)
+    for (int l = 0; l < p.n_trunk; ++l) {
+        float *Z = ws + p.o_z[l], *H = ws + p.o_h[l];
+        const bool wide = l > 0 && in_skips(f.d, l - 1);
+        if (l == 0) {
+            launch_pack(W[0], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp, s);
+            launch_rows_gemm(PEs, p.R, kLdPe, p.Cpe, wp, (p.Cpe + 7) / 8, kWidth, kWidth, B[0], 4, Z, kWidth, 0, ctx->cus, s);
+        } else {
+            launch_pack(W[l], kWidth, 1, wide ? p.Cpe : 0, 0, kWidth, kWidth, kWidth, wp, s);
+            launch_rows_gemm(ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, 32, kWidth, kWidth, B[l], 4, Z, kWidth, 0, ctx->cus, s);
+            if (wide) {      // hx = cat([embed_pos_scaled, hx]): the encoding feeds rows 0 .. Cpe-1
+                launch_pack(W[l], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp2, s);
+                launch_rows_gemm(PEs, p.R, kLdPe, p.Cpe, wp2, (p.Cpe + 7) / 8, kWidth, kWidth, nullptr, 4, Z, kWidth, 1, ctx->cus, s);
+            }
+        }
+        launch_act_rows(act, 4, Z, H, N, kWidth, kWidth, s);
+    }
+    const float *Hlast = ws + p.o_h[p.n_trunk - 1];
+    NarrowW heads{};
+    heads.nc = 2; heads.wstride = 1;
+    heads.w[0] = W[p.i_ddf]; heads.w[1] = W[p.i_aux];
+    heads.b[0] = B[p.i_ddf]; heads.b[1] = B[p.i_aux];
+    launch_narrow_forward(Hlast, kWidth, p.R, heads, 4, ZH, kLdNarrow, s);
+    a.ZH = ZH; a.PEu = PEu; a.Ed = Ed;
+    a.distance = distance; a.density = density; a.aux_grad = aux_grad;
+    launch_point_forward(a, s);
+    // colour trunk (neddf.py:243-258)
+    for (int l = 0; l < p.n_col; ++l) {
+        float *Z = ws + p.o_zc[l], *H = ws + p.o_hc[l];
+        const float *Wl = W[p.n_trunk + l], *Bl = B[p.n_trunk + l];
+        if (l == 0) {
+            launch_pack(Wl, kWidth, 1, 0, 0, p.Ca, kWidth, kWidth, wp, s);
+            launch_rows_gemm(ws + p.o_xa, p.R, p.ldxa, p.Ca, wp, (p.Ca + 7) / 8, kWidth, kWidth, Bl, 4, Z, kWidth, 0, ctx->cus, s);
+            launch_pack(Wl, kWidth, 1, p.Ca, 0, kWidth, kWidth, kWidth, wp2, s);
+            launch_rows_gemm(Hlast, p.R, kWidth, kWidth, wp2, 32, kWidth, kWidth, nullptr, 4, Z, kWidth, 1, ctx->cus, s);
+        } else {
+            launch_pack(Wl, kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
+            launch_rows_gemm(ws + p.o_hc[l - 1], p.R, kWidth, kWidth, wp, 32, kWidth, kWidth, Bl, 4, Z, kWidth, 0, ctx->cus, s);
+        }
+        launch_act_rows(act, 4, Z, H, N, kWidth, kWidth, s);
+    }
+    NarrowW cout{};
+    cout.nc = 3; cout.wstride = 3;
+    for (int c = 0; c < 3; ++c) { cout.w[c] = W[p.i_cout] + c; cout.b[c] = B[p.i_cout] + c; }
+    launch_narrow_forward(ws + p.o_hc[p.n_col - 1], kWidth, p.R, cout, 4, ws + p.o_cr, kLdNarrow, s);
+    a.color = color; a.penalty = penalty;
+    launch_penalty_forward(a, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, const float *const *B, int n_tensors, int64_t N,
+                               const float *ws_, const float *g_distance, const float *g_density, const float *g_color,
+                               const float *g_penalty, const float *g_aux_grad, float *const *gW, float *const *gB, void *stream)
+{
+    if (!ctx) return NEDDF_EINVAL;
+    if (N <= 0) return 0;
+    if (!W || !B || !ws_ || !gW || !gB) return fail(ctx, NEDDF_EINVAL, "null argument");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    Plan p;
+    if (int rc = make_plan(ctx, slot, N, n_tensors, p)) return rc;
+    const Field &f = ctx->field[slot];
+    const int act = f.d.activation;
+    float *ws = const_cast<float *>(ws_);
+    if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->ttmp, (size_t)p.R * (2 * kWidth + 2 * kLdNarrow) * sizeof(float))) return rc;
+    float *wp = (float *)ctx->tpack.p;
+    float *dA = (float *)ctx->ttmp.p, *dB = dA + (size_t)p.R * kWidth, *GZH = dB + (size_t)p.R * kWidth, *GCR = GZH + (size_t)p.R * kLdNarrow;
+    const float *PEs = ws + p.o_pes;
+    TrainPointArgs a;
+    point_args(a, f, p, ws);
+    a.g_distance = g_distance; a.g_density = g_density; a.g_color = g_color; a.g_penalty = g_penalty; a.g_aux = g_aux_grad;
+    a.GZH = GZH; a.GCR = GCR;
+    launch_point_backward(a, s);
+    // colour head: LinearGradFunction.backward (linear.py:62-88) on [HC | JC] rows
+    NarrowW cout{};
+    cout.nc = 3; cout.wstride = 3;
+    for (int c = 0; c < 3; ++c) cout.w[c] = W[p.i_cout] + c;
+    const float *HClast = ws + p.o_hc[p.n_col - 1];
+    launch_narrow_backward(GCR, kLdNarrow, p.R, cout, dA, kWidth, 0, s);
+    launch_dw(HClast, kWidth, kWidth, GCR, kLdNarrow, 3, p.R, gW[p.i_cout], 3, gB[p.i_cout], 4, s);
+    const float *Hlast = ws + p.o_h[p.n_trunk - 1];
+    for (int l = p.n_col - 1; l >= 0; --l) {
+        const float *Wl = W[p.n_trunk + l];
+        float *gWl = gW[p.n_trunk + l], *gBl = gB[p.n_trunk + l];
+        launch_act_rows_backward(act, 4, ws + p.o_zc[l], dA, dB, N, kWidth, kWidth, s);
+        if (l > 0) {
+            launch_dw(ws + p.o_hc[l - 1], kWidth, kWidth, dB, kWidth, kWidth, p.R, gWl, kWidth, gBl, 4, s);
+            launch_pack(Wl, 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wp, s);                 // W^T
+        } else {
+            launch_dw(ws + p.o_xa, p.ldxa, p.Ca, dB, kWidth, kWidth, p.R, gWl, kWidth, gBl, 4, s);
+            launch_dw(Hlast, kWidth, kWidth, dB, kWidth, kWidth, p.R, gWl + (size_t)p.Ca * kWidth, kWidth, nullptr, 4, s);
+            launch_pack(Wl, 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wp, s);              // (feature rows of W)^T
+        }
+        // the small colour inputs (encodings, detached normal) carry no parameters: only the feature segment propagates
+        launch_rows_gemm(dB, p.R, kWidth, kWidth, wp, 32, kWidth, kWidth, nullptr, 4, dA, kWidth, 0, ctx->cus, s);
+    }
+    // distance / aux heads
+    NarrowW heads{};
+    heads.nc = 2; heads.wstride = 1;
+    heads.w[0] = W[p.i_ddf]; heads.w[1] = W[p.i_aux];
+    launch_narrow_backward(GZH, kLdNarrow, p.R, heads, dA, kWidth, 1, s);
+    launch_dw(Hlast, kWidth, kWidth, GZH, kLdNarrow, 1, p.R, gW[p.i_ddf], 1, gB[p.i_ddf], 4, s);
+    launch_dw(Hlast, kWidth, kWidth, GZH + 1, kLdNarrow, 1, p.R, gW[p.i_aux], 1, gB[p.i_aux], 4, s);
+    // distance trunk
+    for (int l = p.n_trunk - 1; l >= 0; --l) {
+        const bool wide = l > 0 && in_skips(f.d, l - 1);
+        launch_act_rows_backward(act, 4, ws + p.o_z[l], dA, dB, N, kWidth, kWidth, s);
+        if (l == 0) {
+            launch_dw(PEs, kLdPe, p.Cpe, dB, kWidth, kWidth, p.R, gW[0], kWidth, gB[0], 4, s);
+            break;
+        }
+        if (wide) {
+            launch_dw(PEs, kLdPe, p.Cpe, dB, kWidth, kWidth, p.R, gW[l], kWidth, gB[l], 4, s);
+            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dB, kWidth, kWidth, p.R, gW[l] + (size_t)p.Cpe * kWidth, kWidth, nullptr, 4, s);
+        } else {
+            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dB, kWidth, kWidth, p.R, gW[l], kWidth, gB[l], 4, s);
+        }
+        launch_pack(W[l], 1, kWidth, 0, wide ? p.Cpe : 0, kWidth, kWidth, kWidth, wp, s);
+        launch_rows_gemm(dB, p.R, kWidth, kWidth, wp, 32, kWidth, kWidth, nullptr, 4, dA, kWidth, 0, ctx->cus, s);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neddf_composite_backward(neddf_ctx *ctx, const float *dists, const float *density, const float *color, int64_t n_rays, int S,
+                             float max_dist, const float *g_weight, const float *g_depth, const float *g_color, const float *g_trans,
+                             float *g_density, float *g_color_out, void *stream)
+{
+    if (!ctx) return NEDDF_EINVAL;
+    if (n_rays <= 0) return 0;
+    if (!dists || !density || !color || !g_density || !g_color_out || S < 2) return fail(ctx, NEDDF_EINVAL, "bad argument");
+    (void)hipSetDevice(ctx->device);
+    launch_composite_backward(dists, density, color, n_rays, S, max_dist, g_weight, g_depth, g_color, g_trans, g_density, g_color_out,
+                              (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

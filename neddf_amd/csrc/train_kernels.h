@@ -1,0 +1,70 @@
+// train_kernels.h -- launchers of the training-step kernels (train_kernels.hip).
+#pragma once
+#include "kernels.h"
+
+namespace neddf {
+
+// per-point record kept between the forward and the backward pass (float index)
+enum { TP_ZD0 = 0,   // raw distance head rows (value, d/dx, d/dy, d/dz)
+       TP_ZA0 = 4,   // raw aux head rows
+       TP_D = 8, TP_RHO = 9, TP_AUX = 10, TP_U = 11, TP_DGN = 12, TP_DDDT = 13,
+       TP_DG0 = 14,  // distance gradient (3)
+       TP_ND0 = 17,  // normalised distance gradient (3)
+       TP_AGG0 = 20  // aux-gradient gradient (3)
+};
+constexpr int kTrainPt = 24;
+
+struct TrainPointArgs {
+    int64_t N;
+    EncodeDesc enc;
+    int density_activation;
+    float d_near, aux_grad_scale, distance_range_max;
+    float penalty_weight[6];
+    int penalty_has[6];
+    // forward
+    const float *ZH; int ldh;             // raw head rows [4N, ldh]: col 0 distance head, col 1 aux head
+    const float *PEu; int ldpe;           // unscaled position encoding rows [4N, ldpe]
+    const float *Ed; int ldd;             // direction encoding [N, ldd]
+    float *XA; int ldxa;                  // colour-trunk small input rows [4N, ldxa] = [embed_pos | embed_dir | normal]
+    float *PT;                            // [N, kTrainPt]
+    const float *CR; int ldc;             // colour rows [4N, ldc] (cols 0..2)
+    float *distance, *density, *aux_grad, *color, *penalty;      // outputs [N] / [N,3]
+    // backward
+    const float *g_distance, *g_density, *g_aux, *g_color, *g_penalty;
+    float *GZH;                           // [4N, ldh]
+    float *GCR;                           // [4N, ldc]
+};
+
+// logical M[k][n] = src[(k_off + k) * sk + (n_off + n) * sn] for k < kcount, n < ncount (0 elsewhere), packed into the
+// fragment-major layout of kernels.h LayerW for nout (128 or 256) output columns and roundup(kcount, 8) / 8 super-steps
+void launch_pack(const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, float *dst, hipStream_t s);
+
+void launch_rows_gemm(const float *X, int64_t R, int ldx, int kcols, const float *wp, int ksteps, int nout, int ncols_valid,
+                      const float *bias, int bias_period, float *Y, int ldy, int accumulate, int cus, hipStream_t s);
+void launch_dw(const float *X, int ldx, int K, const float *G, int ldg, int nout, int64_t R, float *dW, int ldw, float *db,
+               int bias_period, hipStream_t s);
+void launch_act_rows(int kind, int period, const float *Z, float *H, int64_t n_groups, int ncols, int ld, hipStream_t s);
+void launch_act_rows_backward(int kind, int period, const float *Z, const float *dH, float *dZ, int64_t n_groups, int ncols, int ld,
+                              hipStream_t s);
+void launch_pe_rows(const float *pos, const float *dir, const float *var, int64_t N, const EncodeDesc &enc, float *PEs, float *PEu, int ld,
+                    float *Ed, int ldd, hipStream_t s);
+// Y[R, ldy] cols 0..nc-1 = X[R, 256] . w_c (+ b_c on rows r % bias_period == 0); column c of the weights is wcol[c][k * wstride]
+struct NarrowW {
+    int nc;
+    const float *w[4];
+    int wstride;
+    const float *b[4];        // device pointers to the scalar biases (or NULL)
+};
+void launch_narrow_forward(const float *X, int ldx, int64_t R, const NarrowW &w, int bias_period, float *Y, int ldy, hipStream_t s);
+// dX[R, ldx] (+)= sum_c G[r, c] * w_c[k]
+void launch_narrow_backward(const float *G, int ldg, int64_t R, const NarrowW &w, float *dX, int ldx, int accumulate, hipStream_t s);
+
+void launch_point_forward(const TrainPointArgs &a, hipStream_t s);
+void launch_penalty_forward(const TrainPointArgs &a, hipStream_t s);
+void launch_point_backward(const TrainPointArgs &a, hipStream_t s);
+void launch_copy_cols(const float *src, int lds_, int c0, float *dst, int ldd, int d0, int64_t R, int ncols, int accumulate, hipStream_t s);
+void launch_composite_backward(const float *dists, const float *dens, const float *col, int64_t n, int S, float max_dist,
+                               const float *g_weight, const float *g_depth, const float *g_color, const float *g_trans, float *g_dens,
+                               float *g_col, hipStream_t s);
+
+}  // namespace neddf

@@ -1,0 +1,614 @@
+// train_kernels.hip -- building blocks of the training step.
+//
+// The training path is deliberately UNFUSED in round 1: one kernel per layer with
+// row-major activation matrices in HBM ([4N, C]: value + Jacobian rows of N sample
+// points), so that the forward pass leaves behind exactly what the hand-written
+// backward passes of the reference need (neddf/nn_module/with_grad/*.py backward
+// staticmethods).  All dense work -- forward layers, dX = dZ W^T and the weight
+// gradient dW = X^T dZ -- runs on the same fp32 MFMA tile engine as the fused
+// inference kernels; the elementwise pieces reuse device_math.h.  Training batches
+// are ~10^5 points, two orders of magnitude below a rendered frame, so the extra
+// HBM round trips (8 KB per point and layer) are affordable while the gradients
+// are being pinned against the reference's autograd.
+#include "kernels.h"
+#include "device_math.h"
+#include "tile_engine.h"
+#include "train_kernels.h"
+
+namespace neddf {
+
+// ----------------------------------------------------------------------------
+// Y[R, ldy] (+)= X[R, 0:kcols] x Wpacked (+ bias on rows r % bias_period == 0).
+// X columns beyond kcols up to 8*ksteps are treated as zero; K is consumed in
+// chunks of 256 columns through the LDS tile.
+template <int NT>
+__global__ __launch_bounds__(kThreads, 1) void rows_gemm_kernel(const float *X, int64_t R, int ldx, int kcols, const float *wp,
+                                                                int ksteps, int ncols_valid, const float *bias, int bias_period,
+                                                                float *Y, int ldy, int accumulate)
+{
+    constexpr int MT = 4, ROWS = MT * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *act = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *act_lane = act + (lane & 31) * kActLd + 4 * (lane >> 5);
+    const int64_t ntiles = (R + ROWS - 1) / ROWS;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * ROWS;
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[mt][t][q] = 0.f;
+        for (int S0 = 0; S0 < ksteps; S0 += 32) {
+            const int nS = ksteps - S0 < 32 ? ksteps - S0 : 32;
+            const int c0 = 8 * S0, nc = 8 * nS;
+            __syncthreads();
+            for (int i = tid; i < ROWS * nc; i += kThreads) {
+                int r = i / nc, c = i - r * nc;
+                float v = 0.f;
+                if (r0 + r < R && c0 + c < kcols) v = X[(r0 + r) * ldx + c0 + c];
+                act[r * kActLd + c] = v;
+            }
+            __syncthreads();
+            const f32x4v *wl = (const f32x4v *)wp + ((size_t)wave * NT * ksteps + S0) * 64 + lane;
+            f32x4v a[MT], b[NT];
+            for (int S = 0; S < nS; ++S) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[t] = wl[((size_t)t * ksteps + S) * 64];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4v *)(act_lane + mt * 32 * kActLd + 8 * S);
+                dense_mfma<MT, NT>(acc, a, b);
+            }
+        }
+        const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = (wave * NT + t) * 32 + j;
+                if (col >= ncols_valid) continue;
+                const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    int64_t row = r0 + mt * 32 + 8 * (q >> 2) + 4 * h + (q & 3);
+                    if (row < R) {
+                        float v = acc[mt][t][q];
+                        if (bias && (row % bias_period) == 0) v += bv;
+                        float *y = Y + row * ldy + col;
+                        *y = accumulate ? *y + v : v;
+                    }
+                }
+            }
+    }
+}
+
+void launch_rows_gemm(const float *X, int64_t R, int ldx, int kcols, const float *wp, int ksteps, int nout, int ncols_valid,
+                      const float *bias, int bias_period, float *Y, int ldy, int accumulate, int cus, hipStream_t s)
+{
+    if (R <= 0) return;
+    size_t lds = (size_t)(128 * kActLd) * sizeof(float);
+    static bool once = ((void)hipFuncSetAttribute((const void *)rows_gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * kActLd * sizeof(float))),
+                        (void)hipFuncSetAttribute((const void *)rows_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * kActLd * sizeof(float))), true);
+    (void)once;
+    int64_t tiles = (R + 127) / 128;
+    int grid = (int)(tiles < cus ? tiles : cus);
+    if (nout == 256) hipLaunchKernelGGL((rows_gemm_kernel<2>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kcols, wp, ksteps, ncols_valid, bias, bias_period, Y, ldy, accumulate);
+    else hipLaunchKernelGGL((rows_gemm_kernel<1>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kcols, wp, ksteps, ncols_valid, bias, bias_period, Y, ldy, accumulate);
+}
+
+// ----------------------------------------------------------------------------
+// dW[K, ldw] += X[R, 0:K]^T x G[R, 0:nout]   (LinearGradFunction.backward, linear.py:75-82: x^T dLdy + J^T dLdG
+// is one product over the stacked value + Jacobian rows), and db[n] += sum over rows r % bias_period == 0 of G[r, n].
+// One workgroup per (32-row slab of K, row split); wave w owns 64 output columns.  MFMA operands: A[i = k][kk = row],
+// B[kk = row][j = n], both read straight from the row-major matrices (lanes along a row: coalesced).
+__global__ __launch_bounds__(kThreads) void dw_kernel(const float *X, int ldx, int K, const float *G, int ldg, int nout, int64_t R,
+                                                      int64_t rows_per_split, float *dW, int ldw, float *db, int bias_period)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k0 = blockIdx.x * 32;
+    const int64_t rb = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t re = rb + rows_per_split < R ? rb + rows_per_split : R;
+    const int i = lane & 31, h = lane >> 5;
+    const int n0 = wave * 64;
+    if (n0 >= nout) return;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    const bool kin = k0 + i < K;
+    const bool c0in = n0 + i < nout, n1 = n0 + 32 + i < nout;
+    float bsum0 = 0.f, bsum1 = 0.f;
+    for (int64_t rr = rb; rr < re; rr += 2) {               // each MFMA contracts rows rr and rr + 1 (wave-uniform trip count)
+        const int64_t r = rr + h;
+        const bool rin = r < re;
+        float a = (rin && kin) ? X[r * ldx + k0 + i] : 0.f;
+        float b0 = (rin && c0in) ? G[r * ldg + n0 + i] : 0.f;
+        float b1 = (rin && n1) ? G[r * ldg + n0 + 32 + i] : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+        if (db && blockIdx.x == 0 && rin && (r % bias_period) == 0) { bsum0 += b0; bsum1 += b1; }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (!(t == 0 ? c0in : n1)) continue;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            int k = k0 + 8 * (q >> 2) + 4 * h + (q & 3);
+            if (k < K) atomicAdd(&dW[(size_t)k * ldw + n0 + 32 * t + i], acc[t][q]);
+        }
+    }
+    if (db && blockIdx.x == 0) {
+        bsum0 += __shfl_xor(bsum0, 32, 64);
+        bsum1 += __shfl_xor(bsum1, 32, 64);
+        if (h == 0) {
+            if (c0in) atomicAdd(&db[n0 + i], bsum0);
+            if (n1) atomicAdd(&db[n0 + 32 + i], bsum1);
+        }
+    }
+}
+
+void launch_dw(const float *X, int ldx, int K, const float *G, int ldg, int nout, int64_t R, float *dW, int ldw, float *db,
+               int bias_period, hipStream_t s)
+{
+    if (R <= 0 || K <= 0) return;
+    int splits = (int)((R + 4095) / 4096);
+    if (splits > 64) splits = 64;
+    int64_t rps = ((R + splits - 1) / splits + 1) & ~(int64_t)1;     // even, so that row pairs never straddle a split
+    hipLaunchKernelGGL(dw_kernel, dim3((K + 31) / 32, splits), dim3(kThreads), 0, s, X, ldx, K, G, ldg, nout, R, rps, dW, ldw, db, bias_period);
+}
+
+// ----------------------------------------------------------------------------
+// second derivative of the hidden activations as the reference's backward passes define it
+template <int KIND>
+__device__ __forceinline__ void act_grad2(float x, float &dy, float &d2)
+{
+    if (KIND == 0) { dy = (x >= 0.f) ? 1.f : 0.f; d2 = 0.f; }            // relu.py backward: mask only
+    else if (KIND == 1) { dy = (x < 0.f) ? 0.01f : 1.f; d2 = 0.f; }      // leaky_relu.py backward: scale only
+    else {                                                                 // tanh_exp.py:43-51
+        float ex = fast_exp(x), tx = tanh_nonneg(ex);
+        float t2 = fmaf(tx, tx, -1.0f);
+        bool big = x > 20.0f;
+        dy = big ? 1.0f : fmaf(-(x * ex), t2, tx);
+        d2 = big ? 0.0f : ex * (-x + 2 * ex * x * tx - 2) * t2;
+    }
+}
+
+// H = a(Z) on (value, Jacobian) row groups: rows 4p .. 4p+3 (period 4) or plain rows (period 1)
+__global__ void act_rows_kernel(int kind, int period, const float *Z, float *H, int64_t n_groups, int ncols, int ld)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_groups * ncols) return;
+    int64_t p = i / ncols;
+    int c = (int)(i - p * ncols);
+    const float *z = Z + p * period * ld + c;
+    float *o = H + p * period * ld + c;
+    float y, dy;
+    if (kind == 0) act_grad<0>(z[0], y, dy); else if (kind == 1) act_grad<1>(z[0], y, dy); else act_grad<2>(z[0], y, dy);
+    if (period == 1) {
+        o[0] = kind == 0 ? act_val<0>(z[0]) : kind == 1 ? act_val<1>(z[0]) : act_val<2>(z[0]);
+        return;
+    }
+    o[0] = y;
+    for (int r = 1; r < 4; ++r) o[r * ld] = dy * z[r * ld];
+}
+
+// {ReLU,LeakyReLU,TanhExp}GradFunction.backward: dLdx = dLdy y' + sum_i dLdG_i J_i y'', dLdJ_i = dLdG_i y'
+__global__ void act_rows_backward_kernel(int kind, int period, const float *Z, const float *dH, float *dZ, int64_t n_groups, int ncols,
+                                         int ld)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_groups * ncols) return;
+    int64_t p = i / ncols;
+    int c = (int)(i - p * ncols);
+    const float *z = Z + p * period * ld + c;
+    const float *g = dH + p * period * ld + c;
+    float *o = dZ + p * period * ld + c;
+    float dy, d2;
+    if (kind == 0) act_grad2<0>(z[0], dy, d2); else if (kind == 1) act_grad2<1>(z[0], dy, d2); else act_grad2<2>(z[0], dy, d2);
+    if (period == 1) { o[0] = g[0] * dy; return; }
+    float s = 0.f;
+    for (int r = 1; r < 4; ++r) { s += g[r * ld] * z[r * ld]; o[r * ld] = g[r * ld] * dy; }
+    o[0] = g[0] * dy + s * d2;
+}
+
+void launch_act_rows(int kind, int period, const float *Z, float *H, int64_t n_groups, int ncols, int ld, hipStream_t s)
+{
+    int64_t t = n_groups * ncols;
+    if (t > 0) hipLaunchKernelGGL(act_rows_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, kind, period, Z, H, n_groups, ncols, ld);
+}
+void launch_act_rows_backward(int kind, int period, const float *Z, const float *dH, float *dZ, int64_t n_groups, int ncols, int ld,
+                              hipStream_t s)
+{
+    int64_t t = n_groups * ncols;
+    if (t > 0) hipLaunchKernelGGL(act_rows_backward_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, kind, period, Z, dH, dZ, n_groups, ncols, ld);
+}
+
+// ----------------------------------------------------------------------------
+// positional encodings as row matrices in the REFERENCE feature order (sin half c = e*3+d, cos half 3E + c), so that
+// weight-gradient rows line up with the reference's weight rows: PEs / PEu [4N, ld] (value + Jacobian rows), Ed [N, ldd]
+__global__ void pe_rows_kernel(const float *pos, const float *dir, const float *var, int64_t N, EncodeDesc enc, float *PEs, float *PEu,
+                               int ld, float *Ed, int ldd)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K3 = 3 * enc.E, K3d = 3 * enc.Ed;
+    if (i >= N * (K3 + K3d)) return;
+    int64_t n = i / (K3 + K3d);
+    int q = (int)(i - n * (K3 + K3d));
+    if (q < K3) {
+        int e = q / 3, d = q - 3 * e;
+        float vs, vc, js, jc, us, uc, ujs, ujc;
+        pe_pair<true>(e, pos[n * 3 + d], var[n * 3 + d], enc.lowpass[e], vs, vc, js, jc);
+        pe_pair<false>(e, pos[n * 3 + d], var[n * 3 + d], enc.lowpass[e], us, uc, ujs, ujc);
+        for (int r = 0; r < 4; ++r) {
+            float *ps = PEs + (n * 4 + r) * ld, *pu = PEu + (n * 4 + r) * ld;
+            bool on = r == 1 + d;
+            ps[q] = r == 0 ? vs : (on ? js : 0.f);  ps[K3 + q] = r == 0 ? vc : (on ? jc : 0.f);
+            pu[q] = r == 0 ? us : (on ? ujs : 0.f); pu[K3 + q] = r == 0 ? uc : (on ? ujc : 0.f);
+        }
+    } else {
+        q -= K3;
+        int e = q / 3, d = q - 3 * e;
+        float sn, cs;
+        sincosf((float)(1 << e) * dir[n * 3 + d], &sn, &cs);
+        Ed[n * ldd + q] = sn;
+        Ed[n * ldd + K3d + q] = cs;
+    }
+}
+
+void launch_pe_rows(const float *pos, const float *dir, const float *var, int64_t N, const EncodeDesc &enc, float *PEs, float *PEu, int ld,
+                    float *Ed, int ldd, hipStream_t s)
+{
+    int64_t t = N * (3 * enc.E + 3 * enc.Ed);
+    if (t > 0) hipLaunchKernelGGL(pe_rows_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, pos, dir, var, N, enc, PEs, PEu, ld, Ed, ldd);
+}
+
+// ----------------------------------------------------------------------------
+// heads + density (neddf.py:220-241) on the raw head rows ZH[4N, ldh] (col 0 = ddf_out, col 1 = aux_out, biases included
+// on the value row); writes the per-point record PT[N, kTrainPt] and the small-input part of the colour trunk's input,
+// XA[4N, ldxa] = [embed_pos rows | embed_dir | norm_dir.detach()] (neddf.py:243-253; the features follow as a second segment)
+__global__ void point_forward_kernel(TrainPointArgs a)
+{
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= a.N) return;
+    const float *zh = a.ZH + n * 4 * a.ldh;
+    float zd[4], za[4];
+    for (int r = 0; r < 4; ++r) { zd[r] = zh[r * a.ldh]; za[r] = zh[r * a.ldh + 1]; }
+    float sp, dsp, sg, dsg;
+    softplus_grad(zd[0], sp, dsp);
+    sigmoid_grad(za[0], sg, dsg);
+    float D = sp + a.d_near;
+    float dg[3] = { dsp * zd[1], dsp * zd[2], dsp * zd[3] };
+    float aux = a.aux_grad_scale * sg;
+    float q2 = dg[0] * dg[0] + dg[1] * dg[1] + dg[2] * dg[2];
+    float dgn = sqrtf(q2), dDdt = sqrtf(q2 + aux * aux);
+    float Dinv = 1.0f / D;
+    float u = Dinv * (1 - dDdt);
+    float rho = act_val_rt(a.density_activation, u);
+    float ninv = 1.0f / (dgn + 1e-7f);
+    float *pt = a.PT + n * kTrainPt;
+    pt[TP_ZD0] = zd[0]; pt[TP_ZD0 + 1] = zd[1]; pt[TP_ZD0 + 2] = zd[2]; pt[TP_ZD0 + 3] = zd[3];
+    pt[TP_ZA0] = za[0]; pt[TP_ZA0 + 1] = za[1]; pt[TP_ZA0 + 2] = za[2]; pt[TP_ZA0 + 3] = za[3];
+    pt[TP_D] = D; pt[TP_RHO] = rho; pt[TP_AUX] = aux; pt[TP_U] = u; pt[TP_DGN] = dgn; pt[TP_DDDT] = dDdt;
+    for (int i = 0; i < 3; ++i) {
+        pt[TP_DG0 + i] = dg[i];
+        pt[TP_ND0 + i] = ninv * dg[i];
+        pt[TP_AGG0 + i] = a.aux_grad_scale * (dsg * za[1 + i]);
+    }
+    if (a.distance) a.distance[n] = D;
+    if (a.density) a.density[n] = rho;
+    if (a.aux_grad) a.aux_grad[n] = aux;
+    // colour input rows
+    const int Cpe = 6 * a.enc.E, Cdir = 6 * a.enc.Ed;
+    for (int r = 0; r < 4; ++r) {
+        float *x = a.XA + (n * 4 + r) * a.ldxa;
+        const float *pu = a.PEu + (n * 4 + r) * a.ldpe;
+        for (int c = 0; c < Cpe; ++c) x[c] = pu[c];
+        for (int c = 0; c < Cdir; ++c) x[Cpe + c] = r == 0 ? a.Ed[n * a.ldd + c] : 0.f;
+        for (int c = 0; c < 3; ++c) x[Cpe + Cdir + c] = r == 0 ? ninv * dg[c] : 0.f;
+        for (int c = Cpe + Cdir + 3; c < a.ldxa; ++c) x[c] = 0.f;
+    }
+}
+
+// field penalties (neddf.py:260-300) from the colour rows CR[4N, ldc] (cols 0..2) + the per-point record
+__global__ void penalty_forward_kernel(TrainPointArgs a)
+{
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= a.N) return;
+    const float *pt = a.PT + n * kTrainPt;
+    const float *cr = a.CR + n * 4 * a.ldc;
+    float c[4][3];
+    for (int r = 0; r < 4; ++r)
+        for (int k = 0; k < 3; ++k) c[r][k] = cr[r * a.ldc + k];
+    float D = pt[TP_D], aux = pt[TP_AUX], Dinv = 1.0f / D;
+    float pen[6];
+    float d2 = pt[TP_AGG0] * pt[TP_ND0] + pt[TP_AGG0 + 1] * pt[TP_ND0 + 1] + pt[TP_AGG0 + 2] * pt[TP_ND0 + 2];
+    float rest = 3 * aux * Dinv;
+    pen[0] = (aux * pt[TP_DGN] * D) * ((d2 - rest) * (d2 - rest));
+    float t1 = fmaxf(-1.0f + pt[TP_DDDT], 0.f);
+    pen[1] = t1 * t1;
+    float a1 = fmaxf(-4.6f - pt[TP_ZD0], 0.f), a2 = fmaxf(-a.distance_range_max + pt[TP_ZD0], 0.f);
+    pen[2] = (a1 + a2) * (a1 + a2);
+    float b1 = fmaxf(-4.6f - pt[TP_ZA0], 0.f), b2 = fmaxf(-4.6f + pt[TP_ZA0], 0.f);
+    pen[3] = (b1 + b2) * (b1 + b2);
+    pen[4] = 0.f; pen[5] = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        float c1 = fmaxf(-0.0f - c[0][k], 0.f), c2 = fmaxf(-1.0f + c[0][k], 0.f);
+        pen[4] += (c1 + c2) * (c1 + c2);
+        float s = c[1][k] * pt[TP_DG0] + c[2][k] * pt[TP_DG0 + 1] + c[3][k] * pt[TP_DG0 + 2];
+        pen[5] += s * s;
+    }
+    float tot = 0.f;
+    for (int k = 0; k < 6; ++k) tot += a.penalty_has[k] ? pen[k] * a.penalty_weight[k] : pen[k];
+    if (a.penalty) a.penalty[n] = tot;
+    if (a.color) { a.color[n * 3] = c[0][0]; a.color[n * 3 + 1] = c[0][1]; a.color[n * 3 + 2] = c[0][2]; }
+}
+
+// reverse of the two kernels above: upstream gradients of (distance, density, color, fields_penalty, aux_grad) ->
+// gradients of the raw head rows GZH[4N, ldh] (cols 0, 1) and of the colour rows GCR[4N, ldc] (cols 0..2)
+__global__ void point_backward_kernel(TrainPointArgs a)
+{
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= a.N) return;
+    const float *pt = a.PT + n * kTrainPt;
+    const float *cr = a.CR + n * 4 * a.ldc;
+    float c[4][3];
+    for (int r = 0; r < 4; ++r)
+        for (int k = 0; k < 3; ++k) c[r][k] = cr[r * a.ldc + k];
+    const float zd0 = pt[TP_ZD0], za0 = pt[TP_ZA0];
+    const float zdJ[3] = { pt[TP_ZD0 + 1], pt[TP_ZD0 + 2], pt[TP_ZD0 + 3] }, zaJ[3] = { pt[TP_ZA0 + 1], pt[TP_ZA0 + 2], pt[TP_ZA0 + 3] };
+    const float D = pt[TP_D], aux = pt[TP_AUX], dgn = pt[TP_DGN], dDdt = pt[TP_DDDT], u = pt[TP_U];
+    const float dg[3] = { pt[TP_DG0], pt[TP_DG0 + 1], pt[TP_DG0 + 2] }, nd[3] = { pt[TP_ND0], pt[TP_ND0 + 1], pt[TP_ND0 + 2] };
+    const float agg[3] = { pt[TP_AGG0], pt[TP_AGG0 + 1], pt[TP_AGG0 + 2] };
+    const float Dinv = 1.0f / D, s_ = a.aux_grad_scale;
+    float sp, dsp, sg, dsg;
+    softplus_grad(zd0, sp, dsp);
+    sigmoid_grad(za0, sg, dsg);
+    const float gP = a.g_penalty ? a.g_penalty[n] : 0.f;
+    float gpen[6];
+    for (int k = 0; k < 6; ++k) gpen[k] = a.penalty_has[k] ? gP * a.penalty_weight[k] : gP;
+    float g_c[4][3] = {};
+    float g_zd0 = 0.f, g_za0 = 0.f, g_aux = a.g_aux ? a.g_aux[n] : 0.f, g_dDdt = 0.f, g_D = a.g_distance ? a.g_distance[n] : 0.f;
+    float g_agg[3], g_nd[3], g_dg[3] = { 0.f, 0.f, 0.f };
+    // pen0 = scale.detach() * (d2 - rest)^2, d2 = sum agg*nd, rest = 3*aux*Dinv.detach()
+    float d2 = agg[0] * nd[0] + agg[1] * nd[1] + agg[2] * nd[2];
+    float rest = 3 * aux * Dinv;
+    float g_d2 = gpen[0] * (aux * dgn * D) * 2 * (d2 - rest);
+    g_aux += -g_d2 * 3 * Dinv;
+    for (int i = 0; i < 3; ++i) { g_agg[i] = g_d2 * nd[i]; g_nd[i] = g_d2 * agg[i]; }
+    // pen1 = relu(dDdt - 1)^2
+    g_dDdt += gpen[1] * 2 * fmaxf(dDdt - 1.0f, 0.f);
+    // pen2, pen3: range penalties on the raw head outputs
+    {
+        float a1 = -4.6f - zd0, a2 = zd0 - a.distance_range_max;
+        float t = fmaxf(a1, 0.f) + fmaxf(a2, 0.f);
+        g_zd0 += gpen[2] * 2 * t * ((a2 > 0.f ? 1.f : 0.f) - (a1 > 0.f ? 1.f : 0.f));
+        float b1 = -4.6f - za0, b2 = za0 - 4.6f;
+        float t2 = fmaxf(b1, 0.f) + fmaxf(b2, 0.f);
+        g_za0 += gpen[3] * 2 * t2 * ((b2 > 0.f ? 1.f : 0.f) - (b1 > 0.f ? 1.f : 0.f));
+    }
+    // pen4 (colour range), pen5 (colour constraint, distance_grad detached), colour itself
+    for (int k = 0; k < 3; ++k) {
+        float c1 = -c[0][k], c2 = c[0][k] - 1.0f;
+        float t = fmaxf(c1, 0.f) + fmaxf(c2, 0.f);
+        g_c[0][k] = (a.g_color ? a.g_color[n * 3 + k] : 0.f) + gpen[4] * 2 * t * ((c2 > 0.f ? 1.f : 0.f) - (c1 > 0.f ? 1.f : 0.f));
+        float sk = c[1][k] * dg[0] + c[2][k] * dg[1] + c[3][k] * dg[2];
+        for (int i = 0; i < 3; ++i) g_c[1 + i][k] = gpen[5] * 2 * sk * dg[i];
+    }
+    // density = act(u), u = Dinv (1 - dDdt)
+    float g_rho = a.g_density ? a.g_density[n] : 0.f;
+    float dact;
+    if (a.density_activation == 0) dact = u > 0.f ? 1.f : 0.f;                       // F.relu
+    else if (a.density_activation == 1) dact = u > 0.f ? 1.f : 0.01f;                // F.leaky_relu
+    else { float yy; act_grad<2>(u, yy, dact); }                                     // tanhExp backward (nn_module/tanh_exp.py:52-54)
+    float g_u = g_rho * dact;
+    float g_Dinv = g_u * (1 - dDdt);
+    g_dDdt += -g_u * Dinv;
+    g_D += -g_Dinv * Dinv * Dinv;
+    // dDdt = ||(dg, aux)||, nd = dg / (||dg|| + 1e-7)
+    if (dDdt > 0.f) {
+        for (int i = 0; i < 3; ++i) g_dg[i] += g_dDdt * dg[i] / dDdt;
+        g_aux += g_dDdt * aux / dDdt;
+    }
+    float ninv = 1.0f / (dgn + 1e-7f);
+    float g_ninv = 0.f;
+    for (int i = 0; i < 3; ++i) { g_dg[i] += g_nd[i] * ninv; g_ninv += g_nd[i] * dg[i]; }
+    float g_dgn = -g_ninv * ninv * ninv;
+    if (dgn > 0.f) for (int i = 0; i < 3; ++i) g_dg[i] += g_dgn * dg[i] / dgn;
+    // SigmoidGradFunction.backward (sigmoid.py:76-81) with dLdy = s*g_aux, dLdG_i = s*g_agg_i
+    float g_sg = s_ * g_aux;
+    float gG[3] = { s_ * g_agg[0], s_ * g_agg[1], s_ * g_agg[2] };
+    float d2s = dsg * (1.0f - 2 * sg);
+    g_za0 += g_sg * dsg + d2s * (zaJ[0] * gG[0] + zaJ[1] * gG[1] + zaJ[2] * gG[2]);
+    float g_za[3] = { gG[0] * dsg, gG[1] * dsg, gG[2] * dsg };
+    // SoftplusGradFunction.backward (softplus.py:81-87) with dLdy = g_D, dLdG_i = g_dg_i
+    float d2p = zd0 > 20.0f ? 0.f : (1 - dsp) * dsp;
+    g_zd0 += g_D * dsp + d2p * (zdJ[0] * g_dg[0] + zdJ[1] * g_dg[1] + zdJ[2] * g_dg[2]);
+    float g_zd[3] = { g_dg[0] * dsp, g_dg[1] * dsp, g_dg[2] * dsp };
+    float *gz = a.GZH + n * 4 * a.ldh;
+    gz[0] = g_zd0; gz[1] = g_za0;
+    for (int i = 0; i < 3; ++i) { gz[(1 + i) * a.ldh] = g_zd[i]; gz[(1 + i) * a.ldh + 1] = g_za[i]; }
+    float *gc = a.GCR + n * 4 * a.ldc;
+    for (int r = 0; r < 4; ++r)
+        for (int k = 0; k < 3; ++k) gc[r * a.ldc + k] = g_c[r][k];
+}
+
+void launch_point_forward(const TrainPointArgs &a, hipStream_t s)
+{
+    if (a.N > 0) hipLaunchKernelGGL(point_forward_kernel, dim3((unsigned)((a.N + 127) / 128)), dim3(128), 0, s, a);
+}
+void launch_penalty_forward(const TrainPointArgs &a, hipStream_t s)
+{
+    if (a.N > 0) hipLaunchKernelGGL(penalty_forward_kernel, dim3((unsigned)((a.N + 127) / 128)), dim3(128), 0, s, a);
+}
+void launch_point_backward(const TrainPointArgs &a, hipStream_t s)
+{
+    if (a.N > 0) hipLaunchKernelGGL(point_backward_kernel, dim3((unsigned)((a.N + 127) / 128)), dim3(128), 0, s, a);
+}
+
+// ----------------------------------------------------------------------------
+// small matrix utilities
+__global__ void copy_cols_kernel(const float *src, int lds_, int c0, float *dst, int ldd, int d0, int64_t R, int ncols, int accumulate)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * ncols) return;
+    int64_t r = i / ncols;
+    int c = (int)(i - r * ncols);
+    float v = src[r * lds_ + c0 + c];
+    float *d = dst + r * ldd + d0 + c;
+    *d = accumulate ? *d + v : v;
+}
+void launch_copy_cols(const float *src, int lds_, int c0, float *dst, int ldd, int d0, int64_t R, int ncols, int accumulate, hipStream_t s)
+{
+    int64_t t = R * ncols;
+    if (t > 0) hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, src, lds_, c0, dst, ldd, d0, R, ncols, accumulate);
+}
+
+// ----------------------------------------------------------------------------
+// on-device weight packing (the parameters live in torch tensors and change every optimiser step)
+__global__ void pack_kernel(const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, int ks, float *dst)
+{
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int NT = nout / 128;
+    if (idx >= (int64_t)ks * 8 * nout) return;
+    int r = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    int64_t rest = idx >> 8;
+    int S = (int)(rest % ks);
+    int wt = (int)(rest / ks);          // wave * NT + t
+    int n = wt * 32 + (lane & 31);
+    int k = 8 * S + 4 * (lane >> 5) + r;
+    (void)NT;
+    dst[idx] = (k < kcount && n < ncount) ? src[(int64_t)(k_off + k) * sk + (int64_t)(n_off + n) * sn] : 0.f;
+}
+void launch_pack(const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, float *dst, hipStream_t s)
+{
+    int ks = (kcount + 7) / 8;
+    int64_t t = (int64_t)ks * 8 * nout;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, src, sk, sn, k_off, n_off, kcount, ncount, nout, ks, dst);
+}
+
+// narrow heads (1..4 output columns from a 256-wide input): one wavefront per row
+__global__ __launch_bounds__(256) void narrow_forward_kernel(const float *X, int ldx, int64_t R, NarrowW w, int bias_period, float *Y, int ldy)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const f32x4v x = *(const f32x4v *)(X + r * ldx + 4 * lane);
+    for (int c = 0; c < w.nc; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s = fmaf(x[q], w.w[c][(size_t)(4 * lane + q) * w.wstride], s);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) Y[r * ldy + c] = s + ((w.b[c] && (r % bias_period) == 0) ? w.b[c][0] : 0.f);
+    }
+}
+void launch_narrow_forward(const float *X, int ldx, int64_t R, const NarrowW &w, int bias_period, float *Y, int ldy, hipStream_t s)
+{
+    if (R > 0) hipLaunchKernelGGL(narrow_forward_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, X, ldx, R, w, bias_period, Y, ldy);
+}
+__global__ void narrow_backward_kernel(const float *G, int ldg, int64_t R, NarrowW w, float *dX, int ldx, int accumulate)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * kWidth) return;
+    int64_t r = i >> 8;
+    int k = (int)(i & 255);
+    float s = 0.f;
+    for (int c = 0; c < w.nc; ++c) s = fmaf(G[r * ldg + c], w.w[c][(size_t)k * w.wstride], s);
+    float *d = dX + r * ldx + k;
+    *d = accumulate ? *d + s : s;
+}
+void launch_narrow_backward(const float *G, int ldg, int64_t R, const NarrowW &w, float *dX, int ldx, int accumulate, hipStream_t s)
+{
+    int64_t t = R * kWidth;
+    if (t > 0) hipLaunchKernelGGL(narrow_backward_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, G, ldg, R, w, dX, ldx, accumulate);
+}
+
+// ----------------------------------------------------------------------------
+// integrate_volume_render backward (base_neural_render.py:148-171), one wavefront per ray.
+// w_j = o_j T_j, T_j = prod_{k<j} a_k, a_k = 1 - o_k + 1e-7, o_k = 1 - exp(-rho_k delta_k).
+// With q_j = gw_j + gC . c_j + gd t_j the quantity each weight is dotted with, and gT_end = gT + gd max_dist:
+//   dL/do_j = T_j q_j - (sum_{m>j} o_m T_m q_m + gT_end T_end) / a_j ;  dL/drho_j = dL/do_j * delta_j (1 - o_j)
+// The suffix sum is a reversed wave scan (fp64 like the forward product).
+__global__ __launch_bounds__(256) void composite_backward_kernel(const float *dists, const float *dens, const float *col, int64_t n, int S,
+                                                                 float max_dist, const float *g_weight, const float *g_depth,
+                                                                 const float *g_color, const float *g_trans, float *g_dens, float *g_col)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const float *d = dists + b * S, *r = dens + b * S, *c = col + b * S * 3;
+    const float gd = g_depth ? g_depth[b] : 0.f, gT = g_trans ? g_trans[b] : 0.f;
+    const float gc0 = g_color ? g_color[3 * b] : 0.f, gc1 = g_color ? g_color[3 * b + 1] : 0.f, gc2 = g_color ? g_color[3 * b + 2] : 0.f;
+    const int nchunk = (S - 1 + 63) / 64;
+    // pass 1: T_end
+    double carry = 1.0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        int j = ch * 64 + lane;
+        bool on = j < S - 1;
+        float o = on ? 1.0f - expf(-r[j] * (d[j + 1] - d[j])) : 0.f;
+        double aj = on ? (double)(1.0f - o + 1e-7f) : 1.0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { double t = __shfl_up(aj, off, 64); if (lane >= off) aj *= t; }
+        carry *= __shfl(aj, 63, 64);
+    }
+    const double Tend = (double)(float)carry;
+    double suffix = (double)(gT + gd * max_dist) * Tend;      // sum_{m>j} o_m T_m q_m + gT_end T_end, for j beyond this chunk
+    // pass 2: chunks in reverse; recompute T_j by a forward scan inside each chunk from the chunk's entry value
+    for (int ch = nchunk - 1; ch >= 0; --ch) {
+        // entry transmittance of this chunk = product of all a_k before it (rounded per element like cumprod)
+        double entry = 1.0;
+        for (int cc = 0; cc < ch; ++cc) {
+            int j = cc * 64 + lane;
+            float o = 1.0f - expf(-r[j] * (d[j + 1] - d[j]));
+            double aj = (double)(1.0f - o + 1e-7f);
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { double t = __shfl_up(aj, off, 64); if (lane >= off) aj *= t; }
+            entry *= __shfl(aj, 63, 64);
+        }
+        int j = ch * 64 + lane;
+        bool on = j < S - 1;
+        float dj = on ? d[j] : 0.f, delta = on ? d[j + 1] - dj : 0.f;
+        float e = on ? expf(-r[j] * delta) : 1.f;
+        float o = 1.0f - e;
+        float af = 1.0f - o + 1e-7f;
+        double aj = on ? (double)af : 1.0, incl = aj;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { double t = __shfl_up(incl, off, 64); if (lane >= off) incl *= t; }
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0;
+        float Tj = (float)(excl * entry);
+        float q = 0.f;
+        if (on) q = (g_weight ? g_weight[b * (S - 1) + j] : 0.f) + gc0 * c[3 * j] + gc1 * c[3 * j + 1] + gc2 * c[3 * j + 2] + gd * dj;
+        double term = on ? (double)(o * Tj) * (double)q : 0.0;
+        // exclusive suffix sum within the chunk (lanes above this one) + what lies beyond the chunk
+        double inc = term;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { double t = __shfl_down(inc, off, 64); if (lane + off < 64) inc += t; }
+        double after = inc - term + suffix;
+        if (on) {
+            float go = Tj * q - (float)(after / (double)af);
+            g_dens[b * S + j] = go * delta * e;
+            g_col[(b * S + j) * 3 + 0] = o * Tj * gc0;
+            g_col[(b * S + j) * 3 + 1] = o * Tj * gc1;
+            g_col[(b * S + j) * 3 + 2] = o * Tj * gc2;
+        }
+        suffix += __shfl(inc, 0, 64);
+    }
+    if (lane == 0) {        // the last sample only closes the last interval: no gradient (densities[:, :-1], colors[:, :-1])
+        g_dens[b * S + S - 1] = 0.f;
+        g_col[(b * S + S - 1) * 3 + 0] = 0.f; g_col[(b * S + S - 1) * 3 + 1] = 0.f; g_col[(b * S + S - 1) * 3 + 2] = 0.f;
+    }
+}
+
+void launch_composite_backward(const float *dists, const float *dens, const float *col, int64_t n, int S, float max_dist,
+                               const float *g_weight, const float *g_depth, const float *g_color, const float *g_trans, float *g_dens,
+                               float *g_col, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(composite_backward_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, dists, dens, col, n, S, max_dist,
+                                  g_weight, g_depth, g_color, g_trans, g_dens, g_col);
+}
+
+}  // namespace neddf

@@ -99,7 +99,12 @@ class NeRFRender(BaseNeuralRender):
     def integrate_volume_render(self, dists: Tensor, densities: Tensor, colors: Tensor) -> Dict[str, Tensor]:
         """base_neural_render.py:117-172: weight [B,S-1], depth [B], color [B,3], transmittance [B]."""
         ctx = Context.get(dists.device)
-        out, flag = ctx.composite(dists, densities, colors, self.max_dist)
+        if torch.is_grad_enabled() and (densities.requires_grad or colors.requires_grad):
+            from .autograd import CompositeFunction
+            w, depth, color, trans, flag = CompositeFunction.apply(ctx, self.max_dist, dists.detach(), densities, colors)
+            out = dict(weight=w, depth=depth, color=color, transmittance=trans)
+        else:
+            out, flag = ctx.composite(dists, densities, colors, self.max_dist)
         assert int(flag.item()) == 0, "NaN weight in integrate_volume_render"      # reference asserts (:155)
         return out
 
@@ -137,8 +142,10 @@ class NeRFRender(BaseNeuralRender):
     def render_rays(self, uv: Tensor, camera: Camera) -> Dict[str, Tensor]:
         """nerf_render.py:109-188.  Keys: weight, depth, color, transmittance[, fields_penalty] + *_coarse."""
         uv = uv.to(camera.device)
-        ctx = self._ctx(uv.device)
         B = uv.shape[0]
+        if torch.is_grad_enabled() and isinstance(self.network_fine, NeDDF) and any(p.requires_grad for p in self.parameters()):
+            return self._render_rays_with_grad(uv, camera)
+        ctx = self._ctx(uv.device)
         U_c = self._rand(B, self.sample_coarse + 1, uv.device)       # draw order is part of the contract
         U_f = self._rand(B, self.sample_fine + 1, uv.device)
         o = self._render(ctx, uv, camera, U_c, U_f, full=True)
@@ -146,6 +153,40 @@ class NeRFRender(BaseNeuralRender):
         order = ["weight", "depth", "color", "transmittance", "fields_penalty", "weight_coarse", "depth_coarse",
                  "color_coarse", "transmittance_coarse", "fields_penalty_coarse"]
         return {k: o[k] for k in order if k in o}
+
+    def _render_rays_with_grad(self, uv: Tensor, camera: Camera) -> Dict[str, Tensor]:
+        """render_rays as the training step needs it (nerf_render.py:109-188 under autograd): the samplers run as in
+        inference, the two field evaluations and the two volume integrals are autograd nodes (autograd.py)."""
+        from .ray import Sampling
+        ctx = Context.get(uv.device)
+        B = uv.shape[0]
+        p = self._params()
+        U_c = self._rand(B, self.sample_coarse + 1, uv.device)
+        U_f = self._rand(B, self.sample_fine + 1, uv.device)
+        radius = p.ray_radius if p.cone_sampling else None
+        with torch.no_grad():
+            rd, ro = ctx.raygen(uv, camera.descriptor())
+            dists_c = ctx.sample_coarse(U_c, self.dist_near, self.dist_far)
+            smp_c = Sampling(*ctx.sampling(rd, ro, dists_c, radius))
+        val_c = self.network_coarse(smp_c)
+        integ_c = self.integrate_volume_render(dists_c, val_c["density"], val_c["color"])
+        for key in val_c:
+            if "penalty" in key:
+                delta = dists_c[:, 1:] - dists_c[:, :-1]
+                integ_c[key] = torch.sum(delta * val_c[key].reshape(B, -1)[:, :-1], dim=1)
+        with torch.no_grad():
+            # sanitises the coarse weights in place, as the reference does under set_grad_enabled(False)
+            dists_f = ctx.importance_resample(dists_c, integ_c["weight"].detach(), U_f, True)
+            smp_f = Sampling(*ctx.sampling(rd, ro, dists_f, radius))
+        val_f = self.network_fine(smp_f)
+        integ = self.integrate_volume_render(dists_f, val_f["density"], val_f["color"])
+        for key in val_f:
+            if "penalty" in key:
+                delta = dists_f[:, 1:] - dists_f[:, :-1]
+                integ[key] = torch.sum(delta * val_f[key].reshape(B, -1)[:, :-1], dim=1)
+        for key in list(integ_c):
+            integ["{}_coarse".format(key)] = integ_c[key]
+        return integ
 
     # ------------------------------------------------------------- render_image
     def render_image(self, width: int, height: int, camera: Camera, target_types: Iterable[RenderTarget],

@@ -18,6 +18,14 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _inference():
+    """This file covers the fused inference kernels; with autograd enabled NeDDF modules take the training path
+    (tests/test_gpu_train.py)."""
+    with torch.no_grad():
+        yield
+
+
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
