@@ -4,7 +4,7 @@ Fields behind the reference project's plugin surface (`neddf.render`,
 libneddf_hip.so (hand-written gfx950 HIP kernels, C ABI in include/neddf_hip.h);
 this package is the thin host side.  Import is GPU-free; the library is loaded
 on first use and there is no CPU fallback."""
-from . import camera, config, dataset, metrics, network, nn_module, ray, render, trainer  # noqa: F401
+from . import camera, config, dataset, logger, loss, metrics, network, nn_module, ray, render, trainer  # noqa: F401
 from ._lib import Context, NeddfError, load  # noqa: F401
 from .camera import Camera, PinholeCalib  # noqa: F401
 from .network import NeDDF, NeDDFField, NeRF, NeRFField, NeuS  # noqa: F401

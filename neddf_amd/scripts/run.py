@@ -1,0 +1,77 @@
+"""`python neddf/scripts/run.py [group=name ...] [a.b.c=value ...]` -- training entry with the command line of the
+reference's neddf/scripts/run.py:13-40 (a hydra app over config/): the config groups of config/config.yaml's defaults
+list are composed with PyYAML, `group=name` picks another file of a group, dotted keys override single values, and --
+as hydra does -- the run executes inside a fresh outputs/<date>/<time>/ directory holding .hydra/config.yaml (which is
+what run_eval.py later reads), models/, render/ and log/."""
+import datetime
+import os
+import random
+import sys
+from pathlib import Path
+from typing import Any, Dict, List
+
+import numpy as np
+import torch
+import yaml
+
+from neddf_amd.config import instantiate
+
+CONFIG_DIR = Path(__file__).resolve().parents[2] / "config"
+
+
+def compose(overrides: List[str], config_dir: Path = CONFIG_DIR) -> Dict[str, Any]:
+    root = yaml.safe_load(open(config_dir / "config.yaml"))
+    groups = {}
+    for entry in root.get("defaults", []):
+        (group, name), = entry.items()
+        groups[group] = name
+    values = []
+    for ov in overrides:
+        key, _, val = ov.partition("=")
+        if not _:
+            raise SystemExit("override must be key=value: %r" % ov)
+        if key in groups and "." not in key:
+            groups[key] = val
+        else:
+            values.append((key, yaml.safe_load(val)))
+    cfg: Dict[str, Any] = {}
+    for group, name in groups.items():
+        path = config_dir / group / (name + ".yaml")
+        if not path.is_file():
+            raise SystemExit("no config %s" % path)
+        cfg[group] = yaml.safe_load(open(path))
+    for key, val in values:
+        node = cfg
+        parts = key.split(".")
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = val
+    return cfg
+
+
+def main(argv=None) -> None:
+    argv = sys.argv[1:] if argv is None else argv
+    cfg = compose(argv)
+    cwd = Path.cwd()
+    cfg["dataset"]["dataset_dir"] = str(cwd / cfg["dataset"]["dataset_dir"])
+    now = datetime.datetime.now()
+    run_dir = cwd / "outputs" / now.strftime("%Y-%m-%d") / now.strftime("%H-%M-%S")
+    (run_dir / ".hydra").mkdir(parents=True)
+    yaml.safe_dump(cfg, open(run_dir / ".hydra" / "config.yaml", "w"), sort_keys=False)
+    yaml.safe_dump(list(argv), open(run_dir / ".hydra" / "overrides.yaml", "w"))
+    os.chdir(run_dir)
+    trainer = instantiate(cfg["trainer"], global_config=cfg, _recursive_=False)
+    trainer.run_train()
+
+
+def seed_everything(seed: int = 3408) -> None:
+    """run.py:30-38"""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed(seed)
+
+
+if __name__ == "__main__":
+    seed_everything()
+    main()

@@ -1,12 +1,12 @@
-"""Evaluation half of the reference trainer -- host-side mirror of
-neddf/trainer/{base_trainer,nerf_trainer}.py restricted to what
-neddf/scripts/run_eval.py needs: construct from the frozen run config, load a
-checkpoint, render every test view, write the PNGs, print PSNR/SSIM.
-Training (losses, optimiser, backward) is out of scope and
-raises.
+"""Trainer -- host-side mirror of neddf/trainer/{base_trainer,nerf_trainer}.py: construct from the run config,
+train (random pixel batches -> render_rays -> losses -> backward -> Adam, exponential LR decay per epoch, periodic
+field slices / test renders / checkpoints) and evaluate (render every view, PNGs, PSNR/SSIM).  The per-step device
+work -- both field evaluations, both volume integrals and their backward passes -- is HIP kernels (autograd.py);
+the optimiser is torch.optim.Adam on the parameter tensors the kernels read in place.
 """
+import math
 from pathlib import Path
-from typing import Any, List
+from typing import Any, Dict, List
 
 import numpy as np
 import torch
@@ -14,11 +14,16 @@ import torch
 from .camera import Camera, PinholeCalib
 from .config import instantiate, to_plain
 from .dataset import imwrite_bgr
+from .logger import NeRFTBLogger
 from .metrics import peak_signal_noise_ratio, structural_similarity
 
 
 def _get(cfg: Any, key: str) -> Any:
     return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
+
+
+def _has(cfg: Any, key: str) -> bool:
+    return key in cfg if isinstance(cfg, dict) else hasattr(cfg, key)
 
 
 class BaseTrainer:
@@ -38,7 +43,8 @@ class BaseTrainer:
         self.camera_calib = PinholeCalib(self.dataset[0]["camera_calib_params"]).to(self.device)
         self.cameras: List[Camera] = [Camera(self.camera_calib, self.dataset[i]["camera_params"]).to(self.device)
                                       for i in range(len(self.dataset))]
-        # loss functions are training-only (config.loss is read but never instantiated here)
+        loss_cfg = _get(self.config, "loss") if _has(self.config, "loss") else {"functions": []}
+        self.loss_functions = [instantiate(f).to(self.device) for f in _get(loss_cfg, "functions")]     # base_trainer.py:110-113
 
     def load_pretrained_model(self, model_path: Path) -> None:
         """base_trainer.py:115-121"""
@@ -71,14 +77,102 @@ class BaseTrainer:
             print("rendering from camera {}".format(camera_id))
             self.render_test(output_dir, camera_id, 1)
 
+    def render_field_slices(self, output_field_dir: Path, epoch: int = 0) -> None:
+        """base_trainer.py:190-204"""
+        images = self.neural_render.render_field_slice()
+        for key in images:
+            imwrite_bgr(Path(output_field_dir) / "field_{}_{:04}.png".format(key, epoch), images[key])
+
+    def construct_ground_truth(self, camera_id: int, us_int: torch.Tensor, vs_int: torch.Tensor,
+                               loss_types: List[str]) -> Dict[str, torch.Tensor]:
+        """base_trainer.py:206-246: targets of the selected pixels (rgb / 256, mask / 256, zero penalty)."""
+        targets: Dict[str, torch.Tensor] = {}
+        us, vs = us_int.cpu().numpy().astype(np.int64), vs_int.cpu().numpy().astype(np.int64)
+        if "ColorLoss" in loss_types:
+            rgb = self.dataset[camera_id]["rgb_images"]
+            targets["color"] = torch.from_numpy(((1.0 / 256) * rgb[vs, us, :]).astype(np.float32)).to(self.device)
+        if "MaskBCELoss" in loss_types or "MaskMSELoss" in loss_types:
+            mask = self.dataset[camera_id]["mask_images"]
+            targets["mask"] = torch.from_numpy(((1.0 / 256) * mask[vs, us]).astype(np.float32)).to(self.device)
+        if "FieldsConstraintLoss" in loss_types:
+            targets["fields_penalty"] = torch.zeros(us_int.shape, dtype=torch.float32)
+        return targets
+
     def run_train(self) -> None:
-        raise NotImplementedError("training is outside the accelerated path (DESIGN.md section 8)")
+        raise NotImplementedError()
+
+    def run_train_step(self, camera_id: int) -> float:
+        raise NotImplementedError()
 
 
 class NeRFTrainer(BaseTrainer):
-    """nerf_trainer.py:23-45 (renderer construction; optimiser/scheduler/logger are training-only)."""
+    """nerf_trainer.py:23-140"""
 
     def __init__(self, **kwargs: Any) -> None:
         super().__init__(**kwargs)
         self.neural_render = instantiate(_get(self.config, "render"), network_config=to_plain(_get(self.config, "network")),
                                          _recursive_=False).to(self.device)
+        self.optimizer = torch.optim.Adam(self.neural_render.get_parameters_list(), lr=self.optimizer_lr,
+                                          weight_decay=self.optimizer_weight_decay)
+        self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=self.scheduler_lr)
+        self.logger = None      # created by the first training step: evaluation runs leave no ./log behind
+
+    def run_train(self) -> None:
+        """nerf_trainer.py:47-79: epochs over a random permutation of the frames, outputs under the working directory
+        (models/, render/)."""
+        Path("models").mkdir(parents=True)
+        render_dir = Path("render")
+        frame_length = len(self.dataset)
+        self.neural_render.set_iter(0)
+        for epoch in range(0, self.epoch_max + 1):
+            print("epoch: ", epoch)
+            camera_ids = np.random.permutation(frame_length)
+            for camera_id in camera_ids:
+                self.run_train_step(int(camera_id))
+                self.neural_render.next_iter()
+            self.scheduler.step()
+            if epoch % self.epoch_save_fields == 0:
+                output_field_dir = render_dir / "fields"
+                output_field_dir.mkdir(parents=True, exist_ok=True)
+                self.render_field_slices(output_field_dir, epoch)
+            if epoch % self.epoch_test_rendering == 0:
+                print("test rendering...")
+                output_dir = render_dir / "{:04}".format(epoch)
+                output_dir.mkdir(parents=True)
+                self.render_test(output_dir, int(camera_ids[0]), downsampling=3)
+            if epoch % self.epoch_save_model == 0:
+                torch.save(self.neural_render.state_dict(), "models/model_{:0=5}.pth".format(epoch))
+
+    def run_train_step(self, camera_id: int) -> float:
+        """nerf_trainer.py:81-140; RNG draw order: u pixels, v pixels, then render_rays' own draws."""
+        if self.logger is None:
+            self.logger = NeRFTBLogger()
+        self.logger.write_batchstart()
+        self.optimizer.zero_grad()
+        rgb = self.dataset[camera_id]["rgb_images"]
+        camera = self.cameras[camera_id]
+        camera.update_transform()
+        h, w = rgb.shape[0], rgb.shape[1]
+        us_int = (torch.rand(self.batch_size) * (w - 1)).to(torch.int16).to(self.device)
+        vs_int = (torch.rand(self.batch_size) * (h - 1)).to(torch.int16).to(self.device)
+        uv = torch.stack([us_int, vs_int], 1)
+        with torch.enable_grad():
+            render_result = self.neural_render.render_rays(uv, camera)
+            loss_types = [type(func).__name__ for func in self.loss_functions]
+            targets = self.construct_ground_truth(camera_id, us_int, vs_int, loss_types)
+            loss_dict: Dict[str, torch.Tensor] = {}
+            for loss_function in self.loss_functions:
+                loss_dict.update(loss_function(render_result, targets))
+            loss = torch.sum(torch.stack(list(loss_dict.values())))
+            loss.backward()
+        loss_float = float(loss.item())
+        mse = float(torch.mean(torch.square(render_result["color"] - targets["color"])).item())
+        psnr = 10 * math.log10(1.0 / mse)
+        self.logger.write(loss_float, psnr, loss_dict)
+        del loss
+        del loss_dict
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        self.logger.write_batchend()
+        self.logger.next()
+        return loss_float
