@@ -27,11 +27,14 @@
 extern "C" {
 #endif
 
-#define NEDDF_ABI_VERSION 1
+#define NEDDF_ABI_VERSION 2
 
 enum { NEDDF_OK = 0, NEDDF_EINVAL = -1, NEDDF_EHIP = -2, NEDDF_EUNSUPPORTED = -3, NEDDF_ENOFIELD = -4 };
 enum { NEDDF_FIELD_NEDDF = 0, NEDDF_FIELD_NERF = 1, NEDDF_FIELD_NEUS = 2 };
 enum { NEDDF_ACT_RELU = 0, NEDDF_ACT_LEAKY = 1, NEDDF_ACT_TANHEXP = 2 };
+/* operand type of the 256-wide dense layers: fp32 (exact, the parity path) or bf16 weights + bf16 activations with
+ * fp32 accumulation on v_mfma_f32_32x32x16_bf16 (BASELINE.json configs[4]); heads, biases, encodings stay fp32 */
+enum { NEDDF_DTYPE_F32 = 0, NEDDF_DTYPE_BF16 = 1 };
 enum { NEDDF_SLOT_COARSE = 0, NEDDF_SLOT_FINE = 1, NEDDF_NUM_SLOTS = 4 };
 /* uv element types accepted by neddf_raygen (the reference takes int64 in
  * render_image, int16 in training, float in its tests) */
@@ -62,6 +65,7 @@ typedef struct {
      * range_color, constraints_color; has[i]==0 leaves the term unweighted. */
     float penalty_weight[6];
     int penalty_has[6];
+    int weight_dtype;         /* NEDDF_DTYPE_*; bf16 is implemented for NeDDF and NeuS fields */
 } neddf_field_desc;
 
 /* Pinhole camera: Camera.R / Camera.T (camera.py:117-118) and
@@ -79,6 +83,12 @@ typedef struct {
     float dist_near, dist_far, max_dist;
     int cone_sampling;        /* sampling_type == "cone" */
     double ray_radius;        /* 1/1111/sqrt(12), nerf_render.py:144-145 */
+    /* forward-facing scenes (not in the reference, see neddf_rays_to_ndc): when ndc_rays != 0 the samples are taken
+     * along normalised-device-coordinate rays (dist_near / dist_far are then NDC depths, usually 0 and 1) while the
+     * field still receives the world-space unit viewing direction */
+    int ndc_rays;
+    int ndc_width, ndc_height;
+    float ndc_near;
 } neddf_render_params;
 
 int neddf_abi_version(void);
@@ -119,6 +129,16 @@ int neddf_sample_coarse(neddf_ctx *ctx, const float *d_U, int64_t n_rays, int S1
 int neddf_sampling(neddf_ctx *ctx, const float *d_ray_dir, const float *d_ray_orig, const float *d_dists,
                    int64_t n_rays, int S, double ray_radius, float *d_pos, float *d_dir, float *d_var,
                    void *stream);
+/* The same with a separate viewing direction [n_rays,3] copied to d_dir (NDC rays: positions follow the NDC ray,
+ * the field sees the world-space direction). */
+int neddf_sampling_view(neddf_ctx *ctx, const float *d_ray_dir, const float *d_ray_orig, const float *d_view_dir,
+                        const float *d_dists, int64_t n_rays, int S, double ray_radius, float *d_pos, float *d_dir,
+                        float *d_var, void *stream);
+/* World-space rays -> normalised-device-coordinate rays of a width x height pinhole view with focal lengths fx, fy and
+ * near plane z = -near (Mildenhall et al. 2020, appendix C; the reference has no NDC code -- parity is pinned on the
+ * projective identity NDC(o + t d) = o' + t' d', t' = 1 - oz_near / (oz_near + t dz), checked in tests). */
+int neddf_rays_to_ndc(neddf_ctx *ctx, const float *d_ray_dir, const float *d_ray_orig, int64_t n_rays, int width, int height,
+                      float fx, float fy, float near_plane, float *d_ndc_dir, float *d_ndc_orig, void *stream);
 /* NeDDF.forward (neddf.py:162-309) / NeRF.forward (nerf.py:107-165) on N
  * sample points (pos/dir/var [N,3]).  Any output pointer may be NULL.
  * NeRF fields produce density and color only; NeuS fields (neus.py:101-162) return the sdf in d_distance. */

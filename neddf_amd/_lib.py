@@ -11,10 +11,11 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libneddf_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 FIELD_NEDDF, FIELD_NERF, FIELD_NEUS = 0, 1, 2
 ACT = {"ReLU": 0, "LeakyReLU": 1, "tanhExp": 2}
+DTYPE = {"fp32": 0, "bf16": 1}
 SLOT_COARSE, SLOT_FINE, SLOT_GENERIC = 0, 1, 2
 OUT_MINIMAL, OUT_FULL = 0, 1
 UV_TYPES = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.int16: 3}
@@ -35,7 +36,7 @@ class FieldDesc(C.Structure):
                 ("layer_count", C.c_int), ("layer_width", C.c_int), ("col_layer_count", C.c_int),
                 ("col_layer_width", C.c_int), ("n_skips", C.c_int), ("skips", C.c_int * 8),
                 ("activation", C.c_int), ("density_activation", C.c_int), ("d_near", C.c_float),
-                ("penalty_weight", C.c_float * 6), ("penalty_has", C.c_int * 6)]
+                ("penalty_weight", C.c_float * 6), ("penalty_has", C.c_int * 6), ("weight_dtype", C.c_int)]
 
 
 class CameraDesc(C.Structure):
@@ -45,7 +46,8 @@ class CameraDesc(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("sample_coarse", C.c_int), ("sample_fine", C.c_int), ("dist_near", C.c_float),
                 ("dist_far", C.c_float), ("max_dist", C.c_float), ("cone_sampling", C.c_int),
-                ("ray_radius", C.c_double)]
+                ("ray_radius", C.c_double), ("ndc_rays", C.c_int), ("ndc_width", C.c_int), ("ndc_height", C.c_int),
+                ("ndc_near", C.c_float)]
 
 
 class RenderOutputs(C.Structure):
@@ -66,6 +68,8 @@ SYMBOLS = [
     ("neddf_raygen", C.c_int, [_vp, _vp, C.c_int, _i64, C.POINTER(CameraDesc), _vp, _vp, _vp]),
     ("neddf_sample_coarse", C.c_int, [_vp, _vp, _i64, C.c_int, C.c_float, C.c_float, _vp, _vp]),
     ("neddf_sampling", C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_double, _vp, _vp, _vp, _vp]),
+    ("neddf_sampling_view", C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_double, _vp, _vp, _vp, _vp]),
+    ("neddf_rays_to_ndc", C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp]),
     ("neddf_field_forward", C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("neddf_composite", C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("neddf_integrate_penalty", C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp, _vp]),
@@ -191,17 +195,31 @@ class Context:
         self.check(self.lib.neddf_sample_coarse(self.h, _ptr(U), U.shape[0], U.shape[1], near, far, _ptr(out), self.stream()))
         return out
 
-    def sampling(self, ray_dir, ray_orig, dists, ray_radius):
+    def sampling(self, ray_dir, ray_orig, dists, ray_radius, view_dir=None):
         require_device(dists, "dists")
         ray_dir, ray_orig, dists = f32c(ray_dir), f32c(ray_orig), f32c(dists)
         B, S = dists.shape
         pos = torch.empty(B, S, 3, device=dists.device, dtype=torch.float32)
         d = torch.empty_like(pos)
         var = torch.empty_like(pos)
-        self.check(self.lib.neddf_sampling(self.h, _ptr(ray_dir), _ptr(ray_orig), _ptr(dists), B, S,
-                                           -1.0 if ray_radius is None else float(ray_radius), _ptr(pos), _ptr(d), _ptr(var),
-                                           self.stream()))
+        radius = -1.0 if ray_radius is None else float(ray_radius)
+        if view_dir is None:
+            self.check(self.lib.neddf_sampling(self.h, _ptr(ray_dir), _ptr(ray_orig), _ptr(dists), B, S, radius, _ptr(pos),
+                                               _ptr(d), _ptr(var), self.stream()))
+        else:
+            view_dir = f32c(view_dir)
+            self.check(self.lib.neddf_sampling_view(self.h, _ptr(ray_dir), _ptr(ray_orig), _ptr(view_dir), _ptr(dists), B, S,
+                                                    radius, _ptr(pos), _ptr(d), _ptr(var), self.stream()))
         return pos, d, var
+
+    def rays_to_ndc(self, ray_dir, ray_orig, width, height, fx, fy, near):
+        """World-space rays -> NDC rays (forward-facing scenes; not a reference function)."""
+        require_device(ray_dir, "ray_dir")
+        ray_dir, ray_orig = f32c(ray_dir), f32c(ray_orig)
+        nd, no = torch.empty_like(ray_dir), torch.empty_like(ray_orig)
+        self.check(self.lib.neddf_rays_to_ndc(self.h, _ptr(ray_dir), _ptr(ray_orig), ray_dir.shape[0], int(width), int(height),
+                                              float(fx), float(fy), float(near), _ptr(nd), _ptr(no), self.stream()))
+        return nd, no
 
     def field_forward(self, slot, pos, dir, var, out_mode, want):
         """want: iterable of output names; returns dict of flat tensors."""

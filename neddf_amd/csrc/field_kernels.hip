@@ -37,8 +37,8 @@ namespace neddf {
 // [col0, col0+2*KH) as [sin half | cos half] (sampling.py:55-71 weights,
 // with_grad/positional_encoding.py:55-87 values + Jacobian for J_in = I3).
 // Region must be pre-zeroed.  GRADSCALE selects embed_pos_scaled (neddf.py:200-204).
-template <bool ROWS4, bool GRADSCALE>
-__device__ __forceinline__ void encode_pos(float *act, int col0, const EncodeDesc &enc, const float *lp, const float *pos,
+template <bool ROWS4, bool GRADSCALE, class Ops = OpsF32>
+__device__ __forceinline__ void encode_pos(typename Ops::act_t *act, int col0, const EncodeDesc &enc, const float *lp, const float *pos,
                                            const float *var, int64_t p0, int64_t N, int P, int tid, bool use_var = true)
 {
     const int K3 = 3 * enc.E, KH = enc.KH;
@@ -48,23 +48,24 @@ __device__ __forceinline__ void encode_pos(float *act, int col0, const EncodeDes
         int64_t gp = p0 + p < N ? p0 + p : N - 1;
         float vs, vc, js, jc;
         pe_pair<GRADSCALE>(e, pos[gp * 3 + d], use_var ? var[gp * 3 + d] : 0.0f, lp[e], vs, vc, js, jc);
+        constexpr int LD = Ops::kLd;
         if (ROWS4) {
-            float *r0 = act + (4 * p) * kActLd + col0 + q;
-            r0[0] = vs;
-            r0[KH] = vc;
-            r0[(1 + d) * kActLd] = js;
-            r0[(1 + d) * kActLd + KH] = jc;
+            typename Ops::act_t *r0 = act + (4 * p) * LD + col0 + q;
+            Ops::put(r0, vs);
+            Ops::put(r0 + KH, vc);
+            Ops::put(r0 + (1 + d) * LD, js);
+            Ops::put(r0 + (1 + d) * LD + KH, jc);
         } else {
-            float *r0 = act + p * kActLd + col0 + q;
-            r0[0] = vs;
-            r0[KH] = vc;
+            typename Ops::act_t *r0 = act + p * LD + col0 + q;
+            Ops::put(r0, vs);
+            Ops::put(r0 + KH, vc);
         }
     }
 }
 
 // PositionalEncoding of the view direction (positional_encoding.py:51-65), value rows only.
-template <bool ROWS4>
-__device__ __forceinline__ void encode_dir(float *act, int col0, const EncodeDesc &enc, const float *dir, int64_t p0,
+template <bool ROWS4, class Ops = OpsF32>
+__device__ __forceinline__ void encode_dir(typename Ops::act_t *act, int col0, const EncodeDesc &enc, const float *dir, int64_t p0,
                                            int64_t N, int P, int tid)
 {
     const int K3 = 3 * enc.Ed, KD = enc.KD;
@@ -74,9 +75,9 @@ __device__ __forceinline__ void encode_dir(float *act, int col0, const EncodeDes
         int64_t gp = p0 + p < N ? p0 + p : N - 1;
         float sn, cs;
         sincosf((float)(1 << e) * dir[gp * 3 + d], &sn, &cs);
-        float *r0 = act + (ROWS4 ? 4 * p : p) * kActLd + col0 + q;
-        r0[0] = sn;
-        r0[KD] = cs;
+        typename Ops::act_t *r0 = act + (ROWS4 ? 4 * p : p) * Ops::kLd + col0 + q;
+        Ops::put(r0, sn);
+        Ops::put(r0 + KD, cs);
     }
 }
 
@@ -101,37 +102,39 @@ __device__ __forceinline__ int sched_next(int *sched, int flags, int64_t tile)
 
 // ----------------------------------------------------------------------------
 // NeDDF distance trunk
-template <int MT, int WPS>
+template <int MT, int WPS, class Ops>
 __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs a)
 {
-    constexpr int NT = 2, ROWS = MT * 32, P = MT * 8;
+    typedef typename Ops::act_t act_t;
+    typedef typename Ops::frag frag;
+    constexpr int NT = 2, ROWS = MT * 32, P = MT * 8, LD = Ops::kLd;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *act = smem;
-    float *hd = smem + ROWS * kActLd;       // [HSPLIT][2][ROWS] head dot products
+    act_t *act = (act_t *)smem;
+    float *hd = (float *)(act + ROWS * LD);  // [HSPLIT][2][ROWS] head dot products
     float *lp = hd + 6 * ROWS;              // [16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *act_lane = act + (lane & 31) * kActLd + 4 * (lane >> 5);
+    const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
     float *scratch = a.scratch + (size_t)blockIdx.x * kStashFloatsPerWg * kMaxStash;
     if (tid == 0) {
 #pragma unroll
         for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
     }
-    const int kin = 2 * a.enc.KH;
+    const int kin = Ops::kStep * a.layer[0].ksteps;          // encoding columns incl. zero padding
     const int64_t ntiles = (a.n_points + P - 1) / P;
 
     int *ctl = (int *)(lp + 12);
     int64_t tile = sched_begin(a.sched, a.sched_flags, ctl, tid);
     while (tile < ntiles) {
         const int64_t p0 = tile * P;
-        LayerPre<NT> pre;
-        layer_prefetch<NT>(pre, a.layer[0].wp, a.layer[0].bias, a.layer[0].ksteps, wave, lane);
-        zero_cols(act, ROWS, kin, tid);
+        LayerPre<NT, Ops> pre;
+        layer_prefetch<NT, Ops>(pre, a.layer[0].wp, a.layer[0].bias, a.layer[0].ksteps, wave, lane);
+        zero_cols<Ops>(act, ROWS, kin, tid);
         __syncthreads();
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);     // consumed at the end of this tile
         if (!(a.sched_flags & 32)) {
-            if (a.neus) encode_pos<true, false>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid, false);   // plain PE (neus.py:118)
-            else encode_pos<true, true>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
+            if (a.neus) encode_pos<true, false, Ops>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid, false);   // plain PE (neus.py:118)
+            else encode_pos<true, true, Ops>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
         }
         __syncthreads();
 
@@ -143,21 +146,21 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
         const bool in_regs = REG_STASH && a.n_stash == 1;
         f32x16 held[REG_STASH ? MT : 1][REG_STASH ? NT : 1];
         for (int s = 0; s < a.n_stash; ++s) {
-            const f32x4v *wl = (const f32x4v *)a.stash[s].wp + (size_t)wave * NT * a.stash[s].ksteps * 64 + lane;
+            const frag *wl = (const frag *)a.stash[s].wp + (size_t)wave * NT * a.stash[s].ksteps * 64 + lane;
             if constexpr (REG_STASH) {
                 if (in_regs) {
                     acc_init<MT, NT, true>(held, nullptr, wave, lane);
-                    dense<MT, NT>(held, act_lane + a.stash[s].col0, wl, a.stash[s].ksteps);
+                    dense<MT, NT, Ops>(held, act_lane + a.stash[s].col0, wl, a.stash[s].ksteps);
                     continue;
                 }
             }
             acc_init<MT, NT, true>(acc, nullptr, wave, lane);
-            dense<MT, NT>(acc, act_lane + a.stash[s].col0, wl, a.stash[s].ksteps);
+            dense<MT, NT, Ops>(acc, act_lane + a.stash[s].col0, wl, a.stash[s].ksteps);
             stash_store<MT, NT>(acc, scratch + (size_t)s * kStashFloatsPerWg, wave, lane);
         }
         for (int l = 0; l < a.n_layers; ++l) {      // neddf.py:214-216
             const LayerW &L = a.layer[l];
-            acc_init_pre<MT, NT, true>(acc, pre);
+            acc_init_pre<MT, NT, true, Ops>(acc, pre);
             if (L.stash >= 0) {
                 bool done = false;
                 if constexpr (REG_STASH) {
@@ -171,12 +174,12 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
                 }
                 if (!done) stash_add<MT, NT>(acc, scratch + (size_t)L.stash * kStashFloatsPerWg, wave, lane);
             }
-            const f32x4v *wl = (const f32x4v *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane;
-            if (!(a.sched_flags & 8)) dense_pre<MT, NT>(acc, act_lane, wl, L.ksteps, pre);
+            const frag *wl = (const frag *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane;
+            if (!(a.sched_flags & 8)) dense_pre<MT, NT, Ops>(acc, act_lane, wl, L.ksteps, pre);
             if (l + 1 < a.n_layers)                 // next layer's first fragments fly during the epilogue
-                layer_prefetch<NT>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
+                layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
             if (!(a.sched_flags & 64)) __syncthreads();   // every wave finished reading the previous activations
-            if (!(a.sched_flags & 4)) epilogue_rt<MT, NT, true>(acc, act, a.activation, wave, lane);
+            if (!(a.sched_flags & 4)) epilogue_rt<MT, NT, true, Ops>(acc, act, a.activation, wave, lane);
             if (!(a.sched_flags & 64)) __syncthreads();
         }
         if (a.sched_flags & 16) {                   // ablation: skip heads / hand-off
@@ -188,13 +191,13 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
         if (a.neus) {       // NeuS: sdf = feature 0 of the last activated layer, normal = its Jacobian rows (neus.py:132-145)
             if (tid < P && p0 + tid < a.n_points) {
                 const int64_t gp = p0 + tid;
-                float sdf = act[(4 * tid) * kActLd];
+                float sdf = Ops::get(act + (4 * tid) * LD);
                 float ex = expf(-a.neus_v10 * sdf);
                 float den = 1 + ex;
                 float rho = a.neus_v10 * ex * (1.0f / (den * den));          // neus.py:153-156
                 float *pa = a.ptaux + gp * kPtAux;
-                f32x4v v0 = { sdf, rho, 0.f, act[(4 * tid + 1) * kActLd] };
-                f32x4v v1 = { act[(4 * tid + 2) * kActLd], act[(4 * tid + 3) * kActLd], 0.f, 0.f };
+                f32x4v v0 = { sdf, rho, 0.f, Ops::get(act + (4 * tid + 1) * LD) };
+                f32x4v v1 = { Ops::get(act + (4 * tid + 2) * LD), Ops::get(act + (4 * tid + 3) * LD), 0.f, 0.f };
                 ((f32x4v *)pa)[0] = v0; ((f32x4v *)pa)[1] = v1;
                 if (a.distance) a.distance[gp] = sdf;
                 if (a.density) a.density[gp] = rho;
@@ -207,11 +210,13 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
             int part = idx / (2 * ROWS), pr = idx - part * 2 * ROWS;
             int head = pr / ROWS, row = pr - head * ROWS;
             const f32x4v *w = (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out) + part * KQ;
-            const f32x4v *ar = (const f32x4v *)(act + row * kActLd) + part * KQ;
+            const act_t *ar = act + row * LD + 4 * part * KQ;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
             for (int k = 0; k < KQ; ++k) {
-                f32x4v x = ar[k], ww = w[k];
+                float x[4];
+                Ops::load4(ar + 4 * k, x);
+                f32x4v ww = w[k];
                 s0 = fmaf(x[0], ww[0], s0); s1 = fmaf(x[1], ww[1], s1);
                 s2 = fmaf(x[2], ww[2], s2); s3 = fmaf(x[3], ww[3], s3);
             }
@@ -252,13 +257,16 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
         }
         // hand the trunk features to the colour kernel (value row, or all four rows in full mode)
         {
+            // 16-byte chunks; the feature matrix has the element type of the activations
+            constexpr int CE = 16 / sizeof(act_t), CPR = kWidth / CE;
+            act_t *features = (act_t *)a.features;
             const int fr = a.feat_rows;
-            for (int idx = tid; idx < P * fr * 64; idx += kThreads) {
-                int r = idx >> 6, c4 = idx & 63;
+            for (int idx = tid; idx < P * fr * CPR; idx += kThreads) {
+                int r = idx / CPR, c4 = idx - r * CPR;
                 int p = r / fr, rr = r - p * fr;
                 if (p0 + p < a.n_points) {
-                    f32x4v v = *(const f32x4v *)(act + (4 * p + rr) * kActLd + 4 * c4);
-                    *(f32x4v *)(a.features + ((size_t)(p0 + p) * fr + rr) * kWidth + 4 * c4) = v;
+                    f32x4v v = *(const f32x4v *)(act + (4 * p + rr) * LD + CE * c4);
+                    *(f32x4v *)(features + ((size_t)(p0 + p) * fr + rr) * kWidth + CE * c4) = v;
                 }
             }
         }
@@ -272,21 +280,23 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
 // NeDDF colour trunk.  ROWS4 = false: eval-minimal, one row per point (the
 // colour Jacobian is dead code in eval); ROWS4 = true:
 // full mode with Jacobian rows + field penalties (neddf.py:244-300).
-template <bool ROWS4, int MT, int WPS>
+template <bool ROWS4, int MT, int WPS, class Ops>
 __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs a)
 {
-    constexpr int NT = 2, ROWS = MT * 32, P = ROWS4 ? MT * 8 : ROWS, RPP = ROWS4 ? 4 : 1;
+    typedef typename Ops::act_t act_t;
+    typedef typename Ops::frag frag;
+    constexpr int NT = 2, ROWS = MT * 32, P = ROWS4 ? MT * 8 : ROWS, RPP = ROWS4 ? 4 : 1, LD = Ops::kLd;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *act = smem;
-    float *hd = smem + ROWS * kActLd;       // [2][ROWS][3] partial colour dots
+    act_t *act = (act_t *)smem;
+    float *hd = (float *)(act + ROWS * LD);  // [2][ROWS][3] partial colour dots
     float *lp = hd + 2 * ROWS * 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *act_lane = act + (lane & 31) * kActLd + 4 * (lane >> 5);
+    const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
     if (tid == 0) {
 #pragma unroll
         for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
     }
-    const int ka = 8 * a.ksteps_a;
+    const int ka = Ops::kStep * a.ksteps_a;
     const int c_dir = 2 * a.enc.KH, c_n = c_dir + 2 * a.enc.KD;
     const int64_t ntiles = (a.n_points + P - 1) / P;
 
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
     while (tile < ntiles) {
         const int64_t p0 = tile * P;
         // layer 0, small-input segment: [embed_pos | embed_dir | norm_dir] (neddf.py:243)
-        zero_cols(act, ROWS, ka, tid);
+        zero_cols<Ops>(act, ROWS, ka, tid);
         __syncthreads();
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
@@ -303,33 +313,34 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
             for (int i = tid; i < P * 3; i += kThreads) {
                 int p = i / 3, d = i - 3 * p;
                 int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
-                act[(RPP * p) * kActLd + d] = a.pos[gp * 3 + d];
-                act[(RPP * p) * kActLd + 3 + d] = a.ptaux[gp * kPtAux + PA_N0 + d];
+                Ops::put(act + (RPP * p) * LD + d, a.pos[gp * 3 + d]);
+                Ops::put(act + (RPP * p) * LD + 3 + d, a.ptaux[gp * kPtAux + PA_N0 + d]);
             }
-            encode_dir<ROWS4>(act, 8, a.enc, a.dir, p0, a.n_points, P, tid);
+            encode_dir<ROWS4, Ops>(act, 8, a.enc, a.dir, p0, a.n_points, P, tid);
         } else {
-            encode_pos<ROWS4, false>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
-            encode_dir<ROWS4>(act, c_dir, a.enc, a.dir, p0, a.n_points, P, tid);
+            encode_pos<ROWS4, false, Ops>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
+            encode_dir<ROWS4, Ops>(act, c_dir, a.enc, a.dir, p0, a.n_points, P, tid);
             for (int i = tid; i < P * 3; i += kThreads) {
                 int p = i / 3, d = i - 3 * p;
                 int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
-                act[(RPP * p) * kActLd + c_n + d] = a.ptaux[gp * kPtAux + PA_N0 + d];
+                Ops::put(act + (RPP * p) * LD + c_n + d, a.ptaux[gp * kPtAux + PA_N0 + d]);
             }
         }
         __syncthreads();
         f32x16 acc[MT][NT];
         // layer 0, feature segment: in the eval-minimal 64-row tile the trunk features are requested now
         // (global -> VGPR) and land in LDS after the small-input dense; the other variants lack the registers
-        constexpr int NF = ROWS * 64 / kThreads;
+        constexpr int CE = 16 / sizeof(act_t), CPR = kWidth / CE;     // 16-byte chunks per feature row
+        constexpr int NF = ROWS * CPR / kThreads;
         constexpr bool FPRE = (MT == 2) && !ROWS4;
         f32x4v fpre[FPRE ? NF : 1];
         auto feature_src = [&](int idx) {
-            int r = idx >> 6, c4 = idx & 63;
+            int r = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
             int64_t grow = p0 * RPP + r;
             int64_t last = a.n_points * RPP - 1;
             if (grow > last) grow = last;
             int64_t src = ROWS4 ? grow : grow * a.feat_rows;      // value row of [n][feat_rows][256]
-            return (const f32x4v *)(a.features + (size_t)src * kWidth + 4 * c4);
+            return (const f32x4v *)((const act_t *)a.features + (size_t)src * kWidth + CE * c4);
         };
         if constexpr (FPRE) {
 #pragma unroll
@@ -337,40 +348,41 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
             __builtin_amdgcn_sched_barrier(0);
         }
         acc_init<MT, NT, ROWS4>(acc, a.layer[0].bias, wave, lane);
-        dense<MT, NT>(acc, act_lane, (const f32x4v *)a.wp_a + (size_t)wave * NT * a.ksteps_a * 64 + lane, a.ksteps_a);
-        LayerPre<NT> pre;
-        layer_prefetch<NT>(pre, a.layer[0].wp, nullptr, a.layer[0].ksteps, wave, lane);
+        dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wp_a + (size_t)wave * NT * a.ksteps_a * 64 + lane, a.ksteps_a);
+        LayerPre<NT, Ops> pre;
+        layer_prefetch<NT, Ops>(pre, a.layer[0].wp, nullptr, a.layer[0].ksteps, wave, lane);
         __syncthreads();
         if constexpr (FPRE) {
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
                 int idx = tid + i * kThreads;
-                *(f32x4v *)(act + (idx >> 6) * kActLd + 4 * (idx & 63)) = fpre[i];
+                *(f32x4v *)(act + ((unsigned)idx / CPR) * LD + CE * ((unsigned)idx % CPR)) = fpre[i];
             }
         } else {
-            for (int idx = tid; idx < ROWS * 64; idx += kThreads)
-                *(f32x4v *)(act + (idx >> 6) * kActLd + 4 * (idx & 63)) = *feature_src(idx);
+            for (int idx = tid; idx < ROWS * CPR; idx += kThreads)
+                *(f32x4v *)(act + ((unsigned)idx / CPR) * LD + CE * ((unsigned)idx % CPR)) = *feature_src(idx);
         }
         __syncthreads();
         for (int l = 0; l < a.n_layers; ++l) {                     // neddf.py:254-256
             const LayerW &L = a.layer[l];
-            if (l > 0) acc_init_pre<MT, NT, ROWS4>(acc, pre);
-            dense_pre<MT, NT>(acc, act_lane, (const f32x4v *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane, L.ksteps, pre);
+            if (l > 0) acc_init_pre<MT, NT, ROWS4, Ops>(acc, pre);
+            dense_pre<MT, NT, Ops>(acc, act_lane, (const frag *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane, L.ksteps, pre);
             if (l + 1 < a.n_layers)
-                layer_prefetch<NT>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
+                layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
             __syncthreads();
-            epilogue_rt<MT, NT, ROWS4>(acc, act, a.activation, wave, lane);
+            epilogue_rt<MT, NT, ROWS4, Ops>(acc, act, a.activation, wave, lane);
             __syncthreads();
         }
         // layer_col_out 256 -> 3 (neddf.py:257), no output activation; two k-halves per row
         for (int idx = tid; idx < 2 * ROWS; idx += kThreads) {
             int half = idx / ROWS, row = idx - half * ROWS;
-            const f32x4v *ar = (const f32x4v *)(act + row * kActLd + half * 128);
+            const act_t *ar = act + row * LD + half * 128;
             const float *w = a.w_out + half * 128 * 3;
             float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll 4
             for (int k = 0; k < 32; ++k) {
-                f32x4v x = ar[k];
+                float x[4];
+                Ops::load4(ar + 4 * k, x);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     c0 = fmaf(x[u], w[(4 * k + u) * 3 + 0], c0);
@@ -584,7 +596,9 @@ void launch_linear_grad(const float *x, const float *J, int64_t n, int cin, int 
 }
 
 // ----------------------------------------------------------------------------
-size_t field_lds_bytes(int mt) { return (size_t)(mt * 32 * kActLd + 2 * mt * 32 * 3 + 16) * sizeof(float); }
+template <class Ops>
+static size_t lds_bytes(int mt) { return (size_t)mt * 32 * Ops::kLd * sizeof(typename Ops::act_t) + (size_t)(2 * mt * 32 * 3 + 16) * sizeof(float); }
+size_t field_lds_bytes(int mt) { return lds_bytes<OpsF32>(mt); }
 
 // Tile geometry: MT = 4 -> one workgroup per CU (133 KB LDS, 128-row tiles, each weight fragment feeds 4 M-tiles);
 // MT = 2 -> two workgroups per CU (2 x 67 KB), so one workgroup's VALU epilogue overlaps the other's MFMA stream.
@@ -607,29 +621,43 @@ static void set_lds(const void *fn, size_t bytes)
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+template <class Ops>
+static void launch_ddf_t(const DdfArgs &a, int grid, hipStream_t s)
+{
+    static bool once = (set_lds((const void *)ddf_trunk_kernel<4, 1, Ops>, lds_bytes<Ops>(4)),
+                        set_lds((const void *)ddf_trunk_kernel<2, 2, Ops>, lds_bytes<Ops>(2)), true);
+    (void)once;
+    if (tile_mt() == 2) hipLaunchKernelGGL((ddf_trunk_kernel<2, 2, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a);
+    else hipLaunchKernelGGL((ddf_trunk_kernel<4, 1, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(4), s, a);
+}
+
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
 {
-    static bool once = (set_lds((const void *)ddf_trunk_kernel<4, 1>, field_lds_bytes(4)),
-                        set_lds((const void *)ddf_trunk_kernel<2, 2>, field_lds_bytes(2)), true);
+    if (a.bf16) launch_ddf_t<OpsBF16>(a, grid, s);
+    else launch_ddf_t<OpsF32>(a, grid, s);
+}
+
+template <class Ops>
+static void launch_col_t(const ColArgs &a, int grid, bool rows4, hipStream_t s)
+{
+    static bool once = (set_lds((const void *)col_trunk_kernel<false, 4, 1, Ops>, lds_bytes<Ops>(4)),
+                        set_lds((const void *)col_trunk_kernel<true, 4, 1, Ops>, lds_bytes<Ops>(4)),
+                        set_lds((const void *)col_trunk_kernel<false, 2, 2, Ops>, lds_bytes<Ops>(2)),
+                        set_lds((const void *)col_trunk_kernel<true, 2, 2, Ops>, lds_bytes<Ops>(2)), true);
     (void)once;
-    if (tile_mt() == 2) hipLaunchKernelGGL((ddf_trunk_kernel<2, 2>), dim3(grid), dim3(kThreads), field_lds_bytes(2), s, a);
-    else hipLaunchKernelGGL((ddf_trunk_kernel<4, 1>), dim3(grid), dim3(kThreads), field_lds_bytes(4), s, a);
+    if (tile_mt() == 2) {
+        if (rows4) hipLaunchKernelGGL((col_trunk_kernel<true, 2, 2, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a);
+        else hipLaunchKernelGGL((col_trunk_kernel<false, 2, 2, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a);
+    } else {
+        if (rows4) hipLaunchKernelGGL((col_trunk_kernel<true, 4, 1, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(4), s, a);
+        else hipLaunchKernelGGL((col_trunk_kernel<false, 4, 1, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(4), s, a);
+    }
 }
 
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 {
-    static bool once = (set_lds((const void *)col_trunk_kernel<false, 4, 1>, field_lds_bytes(4)),
-                        set_lds((const void *)col_trunk_kernel<true, 4, 1>, field_lds_bytes(4)),
-                        set_lds((const void *)col_trunk_kernel<false, 2, 2>, field_lds_bytes(2)),
-                        set_lds((const void *)col_trunk_kernel<true, 2, 2>, field_lds_bytes(2)), true);
-    (void)once;
-    if (tile_mt() == 2) {
-        if (rows4) hipLaunchKernelGGL((col_trunk_kernel<true, 2, 2>), dim3(grid), dim3(kThreads), field_lds_bytes(2), s, a);
-        else hipLaunchKernelGGL((col_trunk_kernel<false, 2, 2>), dim3(grid), dim3(kThreads), field_lds_bytes(2), s, a);
-    } else {
-        if (rows4) hipLaunchKernelGGL((col_trunk_kernel<true, 4, 1>), dim3(grid), dim3(kThreads), field_lds_bytes(4), s, a);
-        else hipLaunchKernelGGL((col_trunk_kernel<false, 4, 1>), dim3(grid), dim3(kThreads), field_lds_bytes(4), s, a);
-    }
+    if (a.bf16) launch_col_t<OpsBF16>(a, grid, rows4, s);
+    else launch_col_t<OpsF32>(a, grid, rows4, s);
 }
 
 void launch_nerf(const NerfArgs &a, int grid, hipStream_t s)

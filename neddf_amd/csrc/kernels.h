@@ -58,6 +58,7 @@ struct DdfArgs {
     const float *w_ddf_out, *w_aux_out;   // [256] each
     float b_ddf_out, b_aux_out;
     float d_near, aux_grad_scale;
+    int bf16;                             // operands: 0 fp32 weights/activations (32x32x2 f32 MFMA), 1 bf16 (32x32x16 bf16 MFMA)
     int neus;                             // 1: NeuS sdf trunk (neus.py:118-145): plain PE, no heads, sdf = feature 0
     float neus_v10;                       // variance * 10
     float *scratch;                       // per-workgroup stash area
@@ -78,6 +79,7 @@ struct ColArgs {
     int activation;
     int mode;                             // 0 NeDDF inputs [embed_pos | embed_dir | normal], 1 NeuS inputs [pos | gradient | embed_dir]
     int final_act;                        // activation id applied to the 3 outputs (NeuS, neus.py:150-152) or -1
+    int bf16;                             // as DdfArgs::bf16
     int ksteps_a;                         // super-steps of layer 0's small-input segment [pe_pos | pe_dir | normal]
     const float *wp_a;                    // its packed weights
     LayerW layer[kMaxLayers];             // layer[0] = feature segment of layer 0
@@ -130,8 +132,10 @@ int field_wgs_per_cu();
 
 void launch_raygen(const void *uv, int uv_type, int64_t n, const CameraArg &cam, float *dir, float *orig, hipStream_t s);
 void launch_sample_coarse(const float *U, int64_t n, int S1, float near_, float far_, float *dists, hipStream_t s);
-void launch_sampling(const float *rd, const float *ro, const float *dists, int64_t n, int S, double radius,
+void launch_sampling(const float *rd, const float *ro, const float *view, const float *dists, int64_t n, int S, double radius,
                      float *pos, float *dir, float *var, hipStream_t s);
+void launch_ndc(const float *rd, const float *ro, int64_t n, float width, float height, float fx, float fy, float near_, float *nd,
+                float *no, hipStream_t s);
 void launch_composite(const float *dists, const float *dens, const float *col, int64_t n, int S, float max_dist,
                       float *w, float *depth, float *color, float *trans, int *nan_flag, hipStream_t s);
 void launch_integrate_penalty(const float *dists, const float *pen, int64_t n, int S, float *out, hipStream_t s);

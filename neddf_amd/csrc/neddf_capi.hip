@@ -40,21 +40,40 @@ struct Src {
     float at(int k, int n) const { return transposed ? w[(size_t)n * rows + k] : w[(size_t)k * cols + n]; }
 };
 
-// fragment-major packing, see kernels.h LayerW
-static size_t pack_layer(std::vector<float> &blob, const Src &src, const std::vector<int> &kmap, int nout)
+// round-to-nearest-even fp32 -> bf16 bit pattern (what v_cvt_pk_bf16_f32 does on the device)
+static inline uint16_t bf16_bits(float f)
 {
-    const int ks = (int)kmap.size() / 8, NT = nout / 128;
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);      // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// fragment-major packing, see kernels.h LayerW.  kmap (engine column -> reference weight row, -1 = zero) is padded to
+// a whole number of super-steps: 8 k-values for fp32 fragments (4 floats per lane half), 16 for bf16 (8 per lane half).
+static size_t pack_layer(std::vector<float> &blob, const Src &src, std::vector<int> kmap, int nout, int bf16, int *ksteps_out)
+{
+    const int step = bf16 ? 16 : 8, half = step / 2, NT = nout / 128;
+    while (kmap.size() % step) kmap.push_back(-1);
+    const int ks = (int)kmap.size() / step;
+    if (ksteps_out) *ksteps_out = ks;
     size_t off = roundup((int)blob.size(), 64);
-    blob.resize(off + (size_t)ks * 8 * nout, 0.f);
+    const size_t elems = (size_t)ks * step * nout;
+    blob.resize(off + (bf16 ? elems / 2 : elems), 0.f);
     float *dst = blob.data() + off;
+    uint16_t *dst16 = (uint16_t *)dst;
     for (int w = 0; w < kWaves; ++w)
         for (int t = 0; t < NT; ++t)
             for (int S = 0; S < ks; ++S)
                 for (int lane = 0; lane < 64; ++lane)
-                    for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < half; ++r) {
                         int n = (w * NT + t) * 32 + (lane & 31);
-                        int k = kmap[8 * S + 4 * (lane >> 5) + r];
-                        dst[((((size_t)(w * NT + t) * ks + S) * 64 + lane) * 4) + r] = k < 0 ? 0.f : src.at(k, n);
+                        int k = kmap[step * S + half * (lane >> 5) + r];
+                        float v = k < 0 ? 0.f : src.at(k, n);
+                        size_t at = ((((size_t)(w * NT + t) * ks + S) * 64 + lane) * half) + r;
+                        if (bf16) dst16[at] = bf16_bits(v);
+                        else dst[at] = v;
                     }
     return off;
 }
@@ -81,6 +100,7 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     const neddf_field_desc &d = f.d;
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n_trunk = d.layer_count - 1, n_col = d.col_layer_count - 1;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
+    const int bf16 = d.weight_dtype == NEDDF_DTYPE_BF16;
     if (n_tensors != n_trunk + n_col + 3) return fail(ctx, NEDDF_EINVAL, "NeDDF: wrong tensor count");
     if (n_trunk < 1 || n_trunk > kMaxLayers || n_col < 1 || n_col > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeDDF: layer count out of range");
     for (int i = 0; i < d.n_skips; ++i)
@@ -102,13 +122,11 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
         a.layer[l].stash = -1;
         if (l == 0) km = pe;
         else for (int k = 0; k < kWidth; ++k) km.push_back(wide ? Cpe + k : k);
-        o_wp[l] = pack_layer(blob, src, km, kWidth);
-        a.layer[l].ksteps = (int)km.size() / 8;
+        o_wp[l] = pack_layer(blob, src, km, kWidth, bf16, &a.layer[l].ksteps);
         if (wide) {
             if (a.n_stash >= kMaxStash) return fail(ctx, NEDDF_EUNSUPPORTED, "NeDDF: too many skip connections");
-            o_st.push_back(pack_layer(blob, src, pe, kWidth));
+            o_st.push_back(pack_layer(blob, src, pe, kWidth, bf16, &a.stash[a.n_stash].ksteps));
             a.stash[a.n_stash].col0 = 0;
-            a.stash[a.n_stash].ksteps = (int)pe.size() / 8;
             a.layer[l].stash = a.n_stash++;
         }
         o_b[l] = put(blob, B[l], kWidth);
@@ -121,18 +139,15 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     enc_map(ka, E, KH, 0);
     enc_map(ka, Ed, KD, Cpe);
     for (int k = 0; k < 3; ++k) ka.push_back(Cpe + Cdir + k);
-    while (ka.size() % 8) ka.push_back(-1);
     std::vector<size_t> c_wp(n_col), c_b(n_col);
     Src s0{ W[n_trunk], Cpe + Cdir + 3 + kWidth, kWidth, false };
-    size_t o_wa = pack_layer(blob, s0, ka, kWidth);
-    c.ksteps_a = (int)ka.size() / 8;
+    size_t o_wa = pack_layer(blob, s0, ka, kWidth, bf16, &c.ksteps_a);
     c.n_layers = n_col;
     for (int l = 0; l < n_col; ++l) {
         std::vector<int> km;
         for (int k = 0; k < kWidth; ++k) km.push_back(l == 0 ? Cpe + Cdir + 3 + k : k);
         Src src{ W[n_trunk + l], l == 0 ? Cpe + Cdir + 3 + kWidth : kWidth, kWidth, false };
-        c_wp[l] = pack_layer(blob, src, km, kWidth);
-        c.layer[l].ksteps = 32;
+        c_wp[l] = pack_layer(blob, src, km, kWidth, bf16, &c.layer[l].ksteps);
         c.layer[l].stash = -1;
         c_b[l] = put(blob, B[n_trunk + l], kWidth);
     }
@@ -151,6 +166,7 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     a.activation = c.activation = d.activation;
     a.density_activation = d.density_activation;
     a.d_near = d.d_near;
+    a.bf16 = c.bf16 = bf16;
     c.final_act = -1;
     for (int k = 0; k < 6; ++k) { c.penalty_weight[k] = d.penalty_weight[k]; c.penalty_has[k] = d.penalty_has[k]; }
     return 0;
@@ -163,6 +179,7 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     const neddf_field_desc &d = f.d;
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n_sdf = d.layer_count, n_col = d.col_layer_count;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
+    const int bf16 = d.weight_dtype == NEDDF_DTYPE_BF16;
     if (n_tensors != n_sdf + n_col + 2) return fail(ctx, NEDDF_EINVAL, "NeuS: wrong tensor count");
     if (n_sdf < 1 || n_sdf > kMaxLayers || n_col < 1 || n_col > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: layer count out of range");
     if (d.activation == NEDDF_ACT_LEAKY) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: activation must be ReLU or tanhExp");
@@ -185,15 +202,13 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
         a.layer[l].stash = -1;
         if (l == 0) km = pe;
         else for (int k = 0; k < kWidth; ++k) km.push_back(k);       // cat([hx, embed_pos]): hidden state first
-        o_wp[l] = pack_layer(blob, src, km, kWidth);
-        a.layer[l].ksteps = (int)km.size() / 8;
+        o_wp[l] = pack_layer(blob, src, km, kWidth, bf16, &a.layer[l].ksteps);
         if (wide) {
             if (a.n_stash >= kMaxStash) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: too many skip connections");
             std::vector<int> ps;
             enc_map(ps, E, KH, kWidth);
-            o_st.push_back(pack_layer(blob, src, ps, kWidth));
+            o_st.push_back(pack_layer(blob, src, ps, kWidth, bf16, &a.stash[a.n_stash].ksteps));
             a.stash[a.n_stash].col0 = 0;
-            a.stash[a.n_stash].ksteps = (int)ps.size() / 8;
             a.layer[l].stash = a.n_stash++;
         }
         o_b[l] = put(blob, B[l], kWidth);
@@ -204,19 +219,16 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     for (int k = 0; k < 3; ++k) ka.push_back(3 + Cdir + k);
     ka.push_back(-1); ka.push_back(-1);
     enc_map(ka, Ed, KD, 3);
-    while (ka.size() % 8) ka.push_back(-1);
     const int in_col = 6 + Cdir + kWidth;
     Src s0{ W[n_sdf], in_col, kWidth, true };
-    size_t o_wa = pack_layer(blob, s0, ka, kWidth);
-    c.ksteps_a = (int)ka.size() / 8;
+    size_t o_wa = pack_layer(blob, s0, ka, kWidth, bf16, &c.ksteps_a);
     c.n_layers = n_col;
     std::vector<size_t> c_wp(n_col), c_b(n_col);
     for (int l = 0; l < n_col; ++l) {
         std::vector<int> km;
         for (int k = 0; k < kWidth; ++k) km.push_back(l == 0 ? 6 + Cdir + k : k);
         Src src{ W[n_sdf + l], l == 0 ? in_col : kWidth, kWidth, true };
-        c_wp[l] = pack_layer(blob, src, km, kWidth);
-        c.layer[l].ksteps = 32;
+        c_wp[l] = pack_layer(blob, src, km, kWidth, bf16, &c.layer[l].ksteps);
         c.layer[l].stash = -1;
         c_b[l] = put(blob, B[n_sdf + l], kWidth);
     }
@@ -235,6 +247,7 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     c.w_out = base + o_cout;
     a.activation = c.activation = d.activation;
     a.neus = 1;
+    a.bf16 = c.bf16 = bf16;
     a.neus_v10 = W[n_sdf + n_col + 1][0] * 10.0f;
     c.mode = 1;
     c.final_act = d.activation;
@@ -246,6 +259,8 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     const neddf_field_desc &d = f.d;
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n = d.layer_count;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
+    const int bf16 = 0;
+    if (d.weight_dtype != NEDDF_DTYPE_F32) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: bf16 operands are implemented for NeDDF and NeuS fields");
     if (n_tensors != n + 3) return fail(ctx, NEDDF_EINVAL, "NeRF: wrong tensor count");
     if (n < 1 || n > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: layer count out of range");
     for (int i = 0; i < d.n_skips; ++i)
@@ -266,15 +281,13 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
         a.layer[l].stash = -1;
         if (l == 0) km = pe;
         else for (int k = 0; k < kWidth; ++k) km.push_back(k);       // cat([hx, embed_pos]): hidden state first
-        o_wp[l] = pack_layer(blob, src, km, kWidth);
-        a.layer[l].ksteps = (int)km.size() / 8;
+        o_wp[l] = pack_layer(blob, src, km, kWidth, bf16, &a.layer[l].ksteps);
         if (wide) {
             if (a.n_stash >= kMaxStash - 1) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: too many skip connections");
             std::vector<int> ps;
             enc_map(ps, E, KH, kWidth);
-            o_st.push_back(pack_layer(blob, src, ps, kWidth));
+            o_st.push_back(pack_layer(blob, src, ps, kWidth, bf16, &a.stash[a.n_stash].ksteps));
             a.stash[a.n_stash].col0 = 0;
-            a.stash[a.n_stash].ksteps = (int)ps.size() / 8;
             a.layer[l].stash = a.n_stash++;
         }
         o_b[l] = put(blob, B[l], kWidth);
@@ -287,8 +300,8 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     for (int k = 0; k < kWidth; ++k) km.push_back(k);
     enc_map(kd, Ed, KD, kWidth);
     while (kd.size() % 8) kd.push_back(-1);
-    size_t o_c0 = pack_layer(blob, sc, km, kWidth / 2);
-    size_t o_c0s = pack_layer(blob, sc, kd, kWidth / 2);
+    size_t o_c0 = pack_layer(blob, sc, km, kWidth / 2, 0, nullptr);
+    size_t o_c0s = pack_layer(blob, sc, kd, kWidth / 2, 0, nullptr);
     a.col_stash = a.n_stash;
     a.stash[a.n_stash].col0 = 2 * KH;
     a.stash[a.n_stash].ksteps = (int)kd.size() / 8;
@@ -470,6 +483,7 @@ int neddf_set_field(neddf_ctx *ctx, int slot, const neddf_field_desc *desc, cons
     if (desc->n_skips < 0 || desc->n_skips > 8) return fail(ctx, NEDDF_EINVAL, "bad n_skips");
     if (desc->activation < 0 || desc->activation > 2 || desc->density_activation < 0 || desc->density_activation > 2)
         return fail(ctx, NEDDF_EINVAL, "bad activation id");
+    if (desc->weight_dtype != NEDDF_DTYPE_F32 && desc->weight_dtype != NEDDF_DTYPE_BF16) return fail(ctx, NEDDF_EINVAL, "bad weight_dtype");
     Field &f = ctx->field[slot];
     HIPCHK(hipDeviceSynchronize());
     f.valid = false;
@@ -525,7 +539,28 @@ int neddf_sampling(neddf_ctx *ctx, const float *rd, const float *ro, const float
 {
     if (!ctx || !rd || !ro || !dists || !pos || !dir || !var) return NEDDF_EINVAL;
     if (radius >= 0.0 && S < 2) return fail(ctx, NEDDF_EINVAL, "cone sampling needs at least 2 samples");
-    launch_sampling(rd, ro, dists, n, S, radius, pos, dir, var, (hipStream_t)stream);
+    launch_sampling(rd, ro, nullptr, dists, n, S, radius, pos, dir, var, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neddf_sampling_view(neddf_ctx *ctx, const float *rd, const float *ro, const float *view, const float *dists, int64_t n, int S,
+                        double radius, float *pos, float *dir, float *var, void *stream)
+{
+    if (!ctx || !rd || !ro || !view || !dists || !pos || !dir || !var) return NEDDF_EINVAL;
+    if (radius >= 0.0 && S < 2) return fail(ctx, NEDDF_EINVAL, "cone sampling needs at least 2 samples");
+    launch_sampling(rd, ro, view, dists, n, S, radius, pos, dir, var, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neddf_rays_to_ndc(neddf_ctx *ctx, const float *rd, const float *ro, int64_t n, int width, int height, float fx, float fy,
+                      float near_plane, float *nd, float *no, void *stream)
+{
+    if (!ctx) return NEDDF_EINVAL;
+    if (n <= 0) return 0;
+    if (!rd || !ro || !nd || !no || width < 1 || height < 1 || !(fx > 0.f) || !(fy > 0.f)) return fail(ctx, NEDDF_EINVAL, "rays_to_ndc: bad argument");
+    launch_ndc(rd, ro, n, (float)width, (float)height, fx, fy, near_plane, nd, no, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -581,11 +616,11 @@ struct Carver {
 
 static size_t carve_bytes(size_t n_floats) { return (n_floats * sizeof(float) + 255) & ~(size_t)255; }
 
-static int render_pass(neddf_ctx *ctx, int slot, const float *rd, const float *ro, const float *dists, int64_t B, int S,
+static int render_pass(neddf_ctx *ctx, int slot, const float *rd, const float *ro, const float *view, const float *dists, int64_t B, int S,
                        const neddf_render_params *rp, float *pos, float *dir, float *var, float *dens, float *col, float *pen,
                        float *w_out, float *depth, float *color, float *trans, float *pen_out, int *nan_flag, hipStream_t s)
 {
-    launch_sampling(rd, ro, dists, B, S, rp->cone_sampling ? rp->ray_radius : -1.0, pos, dir, var, s);
+    launch_sampling(rd, ro, view, dists, B, S, rp->cone_sampling ? rp->ray_radius : -1.0, pos, dir, var, s);
     const bool want_pen = pen_out && ctx->field[slot].d.kind == NEDDF_FIELD_NEDDF;
     int rc = field_forward(ctx, slot, pos, dir, var, B * S, want_pen ? NEDDF_OUT_FULL : NEDDF_OUT_MINIMAL, nullptr, dens, col,
                            want_pen ? pen : nullptr, nullptr, s);
@@ -607,7 +642,7 @@ int neddf_render_rays(neddf_ctx *ctx, const void *uv, int uv_type, int64_t B, co
     if (!ctx->field[NEDDF_SLOT_COARSE].valid || !ctx->field[NEDDF_SLOT_FINE].valid) return fail(ctx, NEDDF_ENOFIELD, "render_rays needs coarse and fine fields");
     size_t need = 2 * carve_bytes(B * 3) + carve_bytes(B * Sc1) + carve_bytes(B * S2) + 3 * carve_bytes(B * S2 * 3) +
                   2 * carve_bytes(B * S2) + carve_bytes(B * S2 * 3) + carve_bytes(B * (Sc1 - 1)) + carve_bytes(B * (S2 - 1)) +
-                  6 * carve_bytes(B * 3);
+                  8 * carve_bytes(B * 3);
     // the arena is also used by field_forward as a colour sink only when colour is not requested; never the case here
     if (int rc = ensure(ctx, ctx->arena, need)) return rc;
     Carver cv{ (char *)ctx->arena.p };
@@ -627,12 +662,18 @@ int neddf_render_rays(neddf_ctx *ctx, const void *uv, int uv_type, int64_t B, co
     int *nan_flag = out->nan_flag ? out->nan_flag : flags;
 
     launch_raygen(uv, uv_type, B, cam_arg(cam), rd, ro, s);
+    const float *view = nullptr;
+    if (rp->ndc_rays) {         // positions follow the NDC ray, the field keeps the world-space viewing direction
+        float *nd = cv.take(B * 3), *no = cv.take(B * 3);
+        launch_ndc(rd, ro, B, (float)rp->ndc_width, (float)rp->ndc_height, cam->calib[0], cam->calib[1], rp->ndc_near, nd, no, s);
+        view = rd; rd = nd; ro = no;
+    }
     launch_sample_coarse(Uc, B, Sc1, rp->dist_near, rp->dist_far, dc, s);
-    int rc = render_pass(ctx, NEDDF_SLOT_COARSE, rd, ro, dc, B, Sc1, rp, pos, dir, var, dens, col, pen, wc, depth_c, color_c,
+    int rc = render_pass(ctx, NEDDF_SLOT_COARSE, rd, ro, view, dc, B, Sc1, rp, pos, dir, var, dens, col, pen, wc, depth_c, color_c,
                          trans_c, out->fields_penalty_coarse, nan_flag, s);
     if (rc) return rc;
     launch_resample(dc, wc, Uf, B, Sc1, Sf1, 1, df, nullptr, flags + 1, s);
-    rc = render_pass(ctx, NEDDF_SLOT_FINE, rd, ro, df, B, S2, rp, pos, dir, var, dens, col, pen, out->weight, depth, color, trans,
+    rc = render_pass(ctx, NEDDF_SLOT_FINE, rd, ro, view, df, B, S2, rp, pos, dir, var, dens, col, pen, out->weight, depth, color, trans,
                      out->fields_penalty, nan_flag, s);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
@@ -649,7 +690,7 @@ int neddf_render_rays_single(neddf_ctx *ctx, int slot, const void *uv, int uv_ty
     hipStream_t s = (hipStream_t)stream;
     if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");
     size_t need = 2 * carve_bytes(B * 3) + carve_bytes(B * S1) + 3 * carve_bytes(B * S1 * 3) + 2 * carve_bytes(B * S1) +
-                  carve_bytes(B * S1 * 3) + 3 * carve_bytes(B * 3);
+                  carve_bytes(B * S1 * 3) + 5 * carve_bytes(B * 3);
     if (int rc = ensure(ctx, ctx->arena, need)) return rc;
     Carver cv{ (char *)ctx->arena.p };
     float *rd = cv.take(B * 3), *ro = cv.take(B * 3);
@@ -661,8 +702,14 @@ int neddf_render_rays_single(neddf_ctx *ctx, int slot, const void *uv, int uv_ty
     float *trans = out->transmittance ? out->transmittance : cv.take(B);
     int *nan_flag = out->nan_flag ? out->nan_flag : (int *)ctx->flags.p;
     launch_raygen(uv, uv_type, B, cam_arg(cam), rd, ro, s);
+    const float *view = nullptr;
+    if (rp->ndc_rays) {
+        float *nd = cv.take(B * 3), *no = cv.take(B * 3);
+        launch_ndc(rd, ro, B, (float)rp->ndc_width, (float)rp->ndc_height, cam->calib[0], cam->calib[1], rp->ndc_near, nd, no, s);
+        view = rd; rd = nd; ro = no;
+    }
     launch_sample_coarse(U, B, S1, rp->dist_near, rp->dist_far, dc, s);
-    int rc = render_pass(ctx, slot, rd, ro, dc, B, S1, rp, pos, dir, var, dens, col, pen, out->weight, depth, color, trans,
+    int rc = render_pass(ctx, slot, rd, ro, view, dc, B, S1, rp, pos, dir, var, dens, col, pen, out->weight, depth, color, trans,
                          out->fields_penalty, nan_flag, s);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
@@ -707,7 +754,7 @@ int neddf_op_linear_grad(neddf_ctx *ctx, const float *x, const float *J, const f
     std::vector<int> km;
     for (int k = 0; k < roundup(Cin, 8); ++k) km.push_back(k < Cin ? k : -1);
     Src src{ W, Cin, Cout, false };
-    size_t o_w = pack_layer(blob, src, km, Cout);
+    size_t o_w = pack_layer(blob, src, km, Cout, 0, nullptr);
     std::vector<float> zeros(Cout, 0.f);
     size_t o_b = put(blob, b ? b : zeros.data(), Cout);
     if (int rc = ensure(ctx, ctx->features, blob.size() * sizeof(float))) return rc;

@@ -73,7 +73,7 @@ void launch_sample_coarse(const float *U, int64_t n, int S1, float near_, float 
 
 // Ray.get_sampling_cones ray.py:128-194 / get_sampling_points ray.py:88-126
 template <bool CONE>
-__global__ void sampling_kernel(const float *rd, const float *ro, const float *dists, int64_t n, int S, float r2,
+__global__ void sampling_kernel(const float *rd, const float *ro, const float *view, const float *dists, int64_t n, int S, float r2,
                                 float *pos, float *dir, float *var)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,21 +99,52 @@ __global__ void sampling_kernel(const float *rd, const float *ro, const float *d
         float dd = rd[3 * b + k];
         float dsq = dd * dd;
         pos[3 * i + k] = ro[3 * b + k] + dd * t_mu;
-        dir[3 * i + k] = dd;
+        dir[3 * i + k] = view ? view[3 * b + k] : dd;      // NDC rays: the field sees the world-space viewing direction
         var[3 * i + k] = CONE ? t_var * dsq + r_var * (1.0f - dsq) : 0.0f;
     }
 }
 
-void launch_sampling(const float *rd, const float *ro, const float *dists, int64_t n, int S, double radius,
+void launch_sampling(const float *rd, const float *ro, const float *view, const float *dists, int64_t n, int S, double radius,
                      float *pos, float *dir, float *var, hipStream_t s)
 {
     int64_t total = n * S;
     if (total <= 0) return;
     dim3 g((unsigned)((total + 255) / 256)), b(256);
     if (radius >= 0.0)
-        hipLaunchKernelGGL(sampling_kernel<true>, g, b, 0, s, rd, ro, dists, n, S, (float)(radius * radius), pos, dir, var);
+        hipLaunchKernelGGL(sampling_kernel<true>, g, b, 0, s, rd, ro, view, dists, n, S, (float)(radius * radius), pos, dir, var);
     else
-        hipLaunchKernelGGL(sampling_kernel<false>, g, b, 0, s, rd, ro, dists, n, S, 0.f, pos, dir, var);
+        hipLaunchKernelGGL(sampling_kernel<false>, g, b, 0, s, rd, ro, view, dists, n, S, 0.f, pos, dir, var);
+}
+
+// Normalised-device-coordinate rays for forward-facing captures (BASELINE.json configs[4]).  NOT in the reference
+// (it has no NDC/LLFF code): this is the published construction of the original NeRF paper (Mildenhall et al. 2020,
+// appendix C): shift the origin to the near plane z = -near, then map the frustum to the cube,
+//   o' = (-fx/(W/2) ox/oz, -fy/(H/2) oy/oz, 1 + 2 near/oz),
+//   d' = (-fx/(W/2) (dx/dz - ox/oz), -fy/(H/2) (dy/dz - oy/oz), -2 near/oz),
+// so that o' + t' d', t' in [0, 1], sweeps the ray from the near plane to infinity.
+__global__ void ndc_kernel(const float *rd, const float *ro, int64_t n, float sx, float sy, float near_, float *nd, float *no)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float dx = rd[3 * i], dy = rd[3 * i + 1], dz = rd[3 * i + 2];
+    float ox = ro[3 * i], oy = ro[3 * i + 1], oz = ro[3 * i + 2];
+    float t = -(near_ + oz) / dz;
+    ox = ox + t * dx; oy = oy + t * dy; oz = oz + t * dz;
+    float ozi = 1.0f / oz, dzi = 1.0f / dz;
+    no[3 * i] = -sx * (ox * ozi);
+    no[3 * i + 1] = -sy * (oy * ozi);
+    no[3 * i + 2] = 1.0f + 2.0f * near_ * ozi;
+    nd[3 * i] = -sx * (dx * dzi - ox * ozi);
+    nd[3 * i + 1] = -sy * (dy * dzi - oy * ozi);
+    nd[3 * i + 2] = -2.0f * near_ * ozi;
+}
+
+void launch_ndc(const float *rd, const float *ro, int64_t n, float width, float height, float fx, float fy, float near_, float *nd,
+                float *no, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(ndc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rd, ro, n, fx / (0.5f * width), fy / (0.5f * height),
+                       near_, nd, no);
 }
 
 // ----------------------------------------------------------------------------

@@ -1,6 +1,15 @@
 // tile_engine.h -- the MFMA tile engine shared by the fused field kernels
 // (field_kernels.hip) and the layer-by-layer training kernels (train_kernels.hip).
 // See the header of field_kernels.hip for the design.
+//
+// The engine is written once over an operand policy `Ops`:
+//   OpsF32   activations fp32 in LDS, weights fp32, v_mfma_f32_32x32x2_f32 (exact fp32; the parity path)
+//   OpsBF16  activations bf16 in LDS, weights bf16, v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+//            (BASELINE.json configs[4]: "bf16 MLP weights on MFMA"; 16x the fp32 matrix rate)
+// Both read one 16-byte fragment per lane per super-step for A (ds_read_b128) and for B
+// (global_load_dwordx4); a super-step covers Ops::kStep values of k, lane half h = lane>>5
+// holding k = kStep*S + (kStep/2)*h ... +kStep/2-1 -- the same mapping for A and B, which is all
+// the contraction needs.
 #pragma once
 #include "kernels.h"
 #include "device_math.h"
@@ -9,47 +18,102 @@ namespace neddf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
+struct OpsF32 {
+    typedef float act_t;
+    typedef f32x4v frag;
+    static constexpr int kLd = kActLd;       // LDS row stride in elements (260 floats: conflict-free ds_read_b128)
+    static constexpr int kStep = 8;          // k values per super-step
+    static constexpr int kSub = 4;           // MFMA instructions per fragment
+    static __device__ __forceinline__ void put(act_t *p, float v) { *p = v; }
+    static __device__ __forceinline__ float get(const act_t *p) { return *p; }
+    static __device__ __forceinline__ void load4(const act_t *p, float (&x)[4])
+    {
+        f32x4v v = *(const f32x4v *)p;
+        x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3];
+    }
+    static __device__ __forceinline__ f32x16 mfma(const frag &a, const frag &b, const f32x16 &c, int r)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], c, 0, 0, 0);
+    }
+};
+
+struct OpsBF16 {
+    typedef unsigned short act_t;            // bf16 bit pattern
+    typedef bf16x8 frag;
+    static constexpr int kLd = 264;          // 528 B rows: same bank pattern as the fp32 tile (row stride = 4 dwords mod 64)
+    static constexpr int kStep = 16;
+    static constexpr int kSub = 1;
+    static __device__ __forceinline__ unsigned short cvt(float v)       // round to nearest even (v_cvt_pk_bf16_f32)
+    {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 in = { v, v };
+        bf16x2 o = __builtin_convertvector(in, bf16x2);
+        return __builtin_bit_cast(unsigned int, o) & 0xffffu;
+    }
+    static __device__ __forceinline__ void put(act_t *p, float v) { *p = cvt(v); }
+    static __device__ __forceinline__ float get(const act_t *p) { return __builtin_bit_cast(float, (unsigned int)*p << 16); }
+    static __device__ __forceinline__ void load4(const act_t *p, float (&x)[4])
+    {
+        u16x4 v = *(const u16x4 *)p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = __builtin_bit_cast(float, (unsigned int)v[i] << 16);
+    }
+    static __device__ __forceinline__ f32x16 mfma(const frag &a, const frag &b, const f32x16 &c, int)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+// per-lane base of the A fragments of M-tile 0
+template <class Ops>
+__device__ __forceinline__ const typename Ops::act_t *act_lane_ptr(const typename Ops::act_t *act, int lane)
+{
+    return act + (lane & 31) * Ops::kLd + (Ops::kStep / 2) * (lane >> 5);
+}
 
 // ----------------------------------------------------------------------------
-// dense: acc[mt][t] += act[rows, k0 .. k0+8*ksteps) x Wpacked
-template <int MT, int NT>
-__device__ __forceinline__ void dense_load(f32x4v (&a)[MT], f32x4v (&b)[NT], const float *act_lane, const f32x4v *wl, int ksteps, int S)
+// dense: acc[mt][t] += act[rows, k0 .. k0+kStep*ksteps) x Wpacked
+template <int MT, int NT, class Ops = OpsF32>
+__device__ __forceinline__ void dense_load(typename Ops::frag (&a)[MT], typename Ops::frag (&b)[NT], const typename Ops::act_t *act_lane,
+                                           const typename Ops::frag *wl, int ksteps, int S)
 {
 #pragma unroll
     for (int t = 0; t < NT; ++t) b[t] = wl[((size_t)t * ksteps + S) * 64];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4v *)(act_lane + mt * 32 * kActLd + 8 * S);
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const typename Ops::frag *)(act_lane + mt * 32 * Ops::kLd + Ops::kStep * S);
 }
 
-template <int MT, int NT>
-__device__ __forceinline__ void dense_mfma(f32x16 (&acc)[MT][NT], const f32x4v (&a)[MT], const f32x4v (&b)[NT])
+template <int MT, int NT, class Ops = OpsF32>
+__device__ __forceinline__ void dense_mfma(f32x16 (&acc)[MT][NT], const typename Ops::frag (&a)[MT], const typename Ops::frag (&b)[NT])
 {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < Ops::kSub; ++r)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][r], b[t][r], acc[mt][t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) acc[mt][t] = Ops::mfma(a[mt], b[t], acc[mt][t], r);
 }
 
 // Software pipeline, ping-pong operand registers: the operands of super-step
-// S+1 are requested (global -> VGPR for B, LDS -> VGPR for A) before the 32
-// MFMAs (2048 cycles) of super-step S issue.
+// S+1 are requested (global -> VGPR for B, LDS -> VGPR for A) before the MFMAs
+// of super-step S issue.
 // Operands that do not depend on the previous layer's activations (first weight
 // fragments + bias) are requested BEFORE the activation epilogue / barriers of the
 // previous layer, so their L2 latency is off the critical path.
-template <int NT>
+template <int NT, class Ops = OpsF32>
 struct LayerPre {
-    f32x4v b[NT];
+    typename Ops::frag b[NT];
     float bias[NT];
 };
 
-template <int NT>
-__device__ __forceinline__ void layer_prefetch(LayerPre<NT> &p, const float *wp, const float *bias, int ksteps, int wave, int lane)
+template <int NT, class Ops = OpsF32>
+__device__ __forceinline__ void layer_prefetch(LayerPre<NT, Ops> &p, const void *wp, const float *bias, int ksteps, int wave, int lane)
 {
-    const f32x4v *wl = (const f32x4v *)wp + (size_t)wave * NT * ksteps * 64 + lane;
+    const typename Ops::frag *wl = (const typename Ops::frag *)wp + (size_t)wave * NT * ksteps * 64 + lane;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         p.b[t] = wl[(size_t)t * ksteps * 64];
@@ -58,8 +122,8 @@ __device__ __forceinline__ void layer_prefetch(LayerPre<NT> &p, const float *wp,
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MT, int NT, bool ROWS4>
-__device__ __forceinline__ void acc_init_pre(f32x16 (&acc)[MT][NT], const LayerPre<NT> &p)
+template <int MT, int NT, bool ROWS4, class Ops = OpsF32>
+__device__ __forceinline__ void acc_init_pre(f32x16 (&acc)[MT][NT], const LayerPre<NT, Ops> &p)
 {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -69,48 +133,44 @@ __device__ __forceinline__ void acc_init_pre(f32x16 (&acc)[MT][NT], const LayerP
             for (int q = 0; q < 16; ++q) acc[mt][t][q] = (ROWS4 && (q & 3)) ? 0.f : p.bias[t];
 }
 
-template <int MT, int NT>
-__device__ __forceinline__ void dense_pre(f32x16 (&acc)[MT][NT], const float *act_lane, const f32x4v *wl, int ksteps,
-                                          const LayerPre<NT> &p)
+template <int MT, int NT, class Ops = OpsF32>
+__device__ __forceinline__ void dense_pipeline(f32x16 (&acc)[MT][NT], typename Ops::frag (&a0)[MT], typename Ops::frag (&b0)[NT],
+                                               const typename Ops::act_t *act_lane, const typename Ops::frag *wl, int ksteps)
 {
-    f32x4v a0[MT], b0[NT], a1[MT], b1[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) b0[t] = p.b[t];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a0[mt] = *(const f32x4v *)(act_lane + mt * 32 * kActLd);
+    typename Ops::frag a1[MT], b1[NT];
     for (int S = 0; S < ksteps; S += 2) {
         const bool more = S + 1 < ksteps;
-        dense_load<MT, NT>(a1, b1, act_lane, wl, ksteps, more ? S + 1 : S);
-        __builtin_amdgcn_sched_barrier(0);
-        dense_mfma<MT, NT>(acc, a0, b0);
+        dense_load<MT, NT, Ops>(a1, b1, act_lane, wl, ksteps, more ? S + 1 : S);
+        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
+        dense_mfma<MT, NT, Ops>(acc, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            dense_load<MT, NT>(a0, b0, act_lane, wl, ksteps, S + 2 < ksteps ? S + 2 : S);
+            dense_load<MT, NT, Ops>(a0, b0, act_lane, wl, ksteps, S + 2 < ksteps ? S + 2 : S);
             __builtin_amdgcn_sched_barrier(0);
-            dense_mfma<MT, NT>(acc, a1, b1);
+            dense_mfma<MT, NT, Ops>(acc, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
-template <int MT, int NT>
-__device__ __forceinline__ void dense(f32x16 (&acc)[MT][NT], const float *act_lane, const f32x4v *wl, int ksteps)
+template <int MT, int NT, class Ops = OpsF32>
+__device__ __forceinline__ void dense_pre(f32x16 (&acc)[MT][NT], const typename Ops::act_t *act_lane, const typename Ops::frag *wl,
+                                          int ksteps, const LayerPre<NT, Ops> &p)
 {
-    f32x4v a0[MT], b0[NT], a1[MT], b1[NT];
-    dense_load<MT, NT>(a0, b0, act_lane, wl, ksteps, 0);
-    for (int S = 0; S < ksteps; S += 2) {
-        const bool more = S + 1 < ksteps;
-        dense_load<MT, NT>(a1, b1, act_lane, wl, ksteps, more ? S + 1 : S);
-        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
-        dense_mfma<MT, NT>(acc, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            dense_load<MT, NT>(a0, b0, act_lane, wl, ksteps, S + 2 < ksteps ? S + 2 : S);
-            __builtin_amdgcn_sched_barrier(0);
-            dense_mfma<MT, NT>(acc, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+    typename Ops::frag a0[MT], b0[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b0[t] = p.b[t];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a0[mt] = *(const typename Ops::frag *)(act_lane + mt * 32 * Ops::kLd);
+    dense_pipeline<MT, NT, Ops>(acc, a0, b0, act_lane, wl, ksteps);
+}
+
+template <int MT, int NT, class Ops = OpsF32>
+__device__ __forceinline__ void dense(f32x16 (&acc)[MT][NT], const typename Ops::act_t *act_lane, const typename Ops::frag *wl, int ksteps)
+{
+    typename Ops::frag a0[MT], b0[NT];
+    dense_load<MT, NT, Ops>(a0, b0, act_lane, wl, ksteps, 0);
+    dense_pipeline<MT, NT, Ops>(acc, a0, b0, act_lane, wl, ksteps);
 }
 
 template <int MT, int NT, bool ROWS4>
@@ -158,47 +218,49 @@ __device__ __forceinline__ void stash_add(f32x16 (&acc)[MT][NT], const float *sl
 }
 
 // activation epilogue: registers -> LDS activations (columns [0, NT*128))
-template <int MT, int NT, bool ROWS4, int KIND>
-__device__ __forceinline__ void epilogue(const f32x16 (&acc)[MT][NT], float *act, int wave, int lane)
+template <int MT, int NT, bool ROWS4, int KIND, class Ops = OpsF32>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[MT][NT], typename Ops::act_t *act, int wave, int lane)
 {
+    constexpr int LD = Ops::kLd;
     const int j = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            float *o = act + (mt * 32 + 4 * h) * kActLd + (wave * NT + t) * 32 + j;
+            typename Ops::act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (ROWS4) {
                     float y, dy;
                     act_grad<KIND>(acc[mt][t][4 * g], y, dy);
-                    o[(8 * g + 0) * kActLd] = y;
-                    o[(8 * g + 1) * kActLd] = dy * acc[mt][t][4 * g + 1];
-                    o[(8 * g + 2) * kActLd] = dy * acc[mt][t][4 * g + 2];
-                    o[(8 * g + 3) * kActLd] = dy * acc[mt][t][4 * g + 3];
+                    Ops::put(o + (8 * g + 0) * LD, y);
+                    Ops::put(o + (8 * g + 1) * LD, dy * acc[mt][t][4 * g + 1]);
+                    Ops::put(o + (8 * g + 2) * LD, dy * acc[mt][t][4 * g + 2]);
+                    Ops::put(o + (8 * g + 3) * LD, dy * acc[mt][t][4 * g + 3]);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[(8 * g + r) * kActLd] = act_val<KIND>(acc[mt][t][4 * g + r]);
+                    for (int r = 0; r < 4; ++r) Ops::put(o + (8 * g + r) * LD, act_val<KIND>(acc[mt][t][4 * g + r]));
                 }
             }
         }
 }
 
-template <int MT, int NT, bool ROWS4>
-__device__ __forceinline__ void epilogue_rt(const f32x16 (&acc)[MT][NT], float *act, int kind, int wave, int lane)
+template <int MT, int NT, bool ROWS4, class Ops = OpsF32>
+__device__ __forceinline__ void epilogue_rt(const f32x16 (&acc)[MT][NT], typename Ops::act_t *act, int kind, int wave, int lane)
 {
-    if (kind == 0) epilogue<MT, NT, ROWS4, 0>(acc, act, wave, lane);
-    else if (kind == 1) epilogue<MT, NT, ROWS4, 1>(acc, act, wave, lane);
-    else epilogue<MT, NT, ROWS4, 2>(acc, act, wave, lane);
+    if (kind == 0) epilogue<MT, NT, ROWS4, 0, Ops>(acc, act, wave, lane);
+    else if (kind == 1) epilogue<MT, NT, ROWS4, 1, Ops>(acc, act, wave, lane);
+    else epilogue<MT, NT, ROWS4, 2, Ops>(acc, act, wave, lane);
 }
 
 // ----------------------------------------------------------------------------
 // input encodings
-__device__ __forceinline__ void zero_cols(float *act, int rows, int ncols, int tid)
+template <class Ops = OpsF32>
+__device__ __forceinline__ void zero_cols(typename Ops::act_t *act, int rows, int ncols, int tid)
 {
     for (int i = tid; i < rows * ncols; i += kThreads) {
         int r = i / ncols, c = i - r * ncols;
-        act[r * kActLd + c] = 0.f;
+        act[r * Ops::kLd + c] = 0;
     }
 }
 

@@ -13,7 +13,7 @@ from typing import Dict, List, Optional
 import torch
 from torch import Tensor, nn
 
-from ._lib import ACT, FIELD_NEDDF, FIELD_NERF, FIELD_NEUS, OUT_FULL, OUT_MINIMAL, PENALTY_KEYS, SLOT_GENERIC, Context, FieldDesc
+from ._lib import ACT, DTYPE, FIELD_NEDDF, FIELD_NERF, FIELD_NEUS, OUT_FULL, OUT_MINIMAL, PENALTY_KEYS, SLOT_GENERIC, Context, FieldDesc
 from .ray import Sampling
 
 
@@ -63,6 +63,9 @@ class BaseNeuralField(ABC, nn.Module):
     def __init__(self) -> None:
         super().__init__()
         self._slot = SLOT_GENERIC
+        # operand type of the 256-wide dense layers (not a reference keyword): "fp32" = exact fp32 MFMA, the parity path;
+        # "bf16" = bf16 weights and activations with fp32 accumulation (BASELINE.json configs[4]); NeDDF / NeuS only
+        self.weight_dtype = "fp32"
 
     @property
     def device(self) -> torch.device:
@@ -103,14 +106,16 @@ class BaseNeuralField(ABC, nn.Module):
         """Pack + upload the parameters into `slot` if they changed since the last upload.  weights=False (training
         step: the kernels read the live parameter tensors) only makes sure the slot describes this architecture."""
         ws, bs = self._tensors()
-        sig = (id(self), slot, tuple((t.data_ptr(), t._version) for t in ws + bs))
+        sig = (id(self), slot, tuple((t.data_ptr(), t._version) for t in ws + bs), self.weight_dtype)
         have = ctx.slot_owner.get(slot)
         if not weights and have is not None and have[:2] == sig[:2]:
             pass
         elif have != sig:
             hw = [t.detach().to("cpu", torch.float32).contiguous() for t in ws]
             hb = [t.detach().to("cpu", torch.float32).contiguous() for t in bs]
-            ctx.set_field(slot, self._descriptor(), hw, hb, sig)
+            desc = self._descriptor()
+            desc.weight_dtype = DTYPE[self.weight_dtype]
+            ctx.set_field(slot, desc, hw, hb, sig)
         ags, drm, lp = self._iter_state()
         ctx.set_iter(slot, ags, drm, lp)
 
@@ -317,14 +322,17 @@ class NeuS(BaseNeuralField):
         dummy = torch.zeros(1)
         return [m.weight for m in mods] + [self.variance.reshape(1)], [m.bias for m in mods] + [dummy]
 
-    def upload(self, ctx: Context, slot: int) -> None:
+    def upload(self, ctx: Context, slot: int, weights: bool = True) -> None:
         # `variance.reshape(1)` is a fresh view each call: key the upload on the parameter itself
         ws, bs = self._tensors()
-        sig = (id(self), slot, tuple((t.data_ptr(), t._version) for t in ws[:-1] + bs[:-1]), self.variance.data_ptr(), self.variance._version)
+        sig = (id(self), slot, tuple((t.data_ptr(), t._version) for t in ws[:-1] + bs[:-1]), self.variance.data_ptr(), self.variance._version,
+               self.weight_dtype)
         if ctx.slot_owner.get(slot) != sig:
             hw = [t.detach().to("cpu", torch.float32).contiguous() for t in ws]
             hb = [t.detach().to("cpu", torch.float32).contiguous() for t in bs]
-            ctx.set_field(slot, self._descriptor(), hw, hb, sig)
+            desc = self._descriptor()
+            desc.weight_dtype = DTYPE[self.weight_dtype]
+            ctx.set_field(slot, desc, hw, hb, sig)
 
     def _iter_state(self):
         return 1.1, 2.0, [1.0] * self.pe_pos.embed_dim

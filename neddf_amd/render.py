@@ -40,6 +40,10 @@ class NeRFRender(BaseNeuralRender):
                    base_neural_render.py:75 -- same seed => same samples) or
                    "device" (draw on the HIP device; faster, not seed-compatible)
     rays_per_call  rays handed to one neddf_render_rays call by render_image
+    ray_space      "world" (the reference) or "ndc": forward-facing captures sampled along normalised-device-coordinate
+                   rays of an ndc_width x ndc_height view with near plane ndc_near (original NeRF paper, appendix C;
+                   the reference has no such mode).  dist_near / dist_far are then NDC depths (0 and 1) and the fields
+                   still receive the world-space viewing direction.  Use sampling_type="point" with it.
     """
 
     def __init__(self, network_config: Any, sample_coarse: int = 128, sample_fine: int = 128, dist_near: float = 2.0,
@@ -54,6 +58,8 @@ class NeRFRender(BaseNeuralRender):
         self.sampling_type = sampling_type
         self.rng = "torch_cpu"
         self.rays_per_call = 1 << 16
+        self.ray_space = "world"
+        self.ndc_width, self.ndc_height, self.ndc_near = 0, 0, 1.0
 
     # ------------------------------------------------------------------ helpers
     def get_network(self) -> BaseNeuralField:
@@ -77,6 +83,13 @@ class NeRFRender(BaseNeuralRender):
         p.dist_near, p.dist_far, p.max_dist = self.dist_near, self.dist_far, self.max_dist
         p.cone_sampling = int(self.sampling_type == "cone")
         p.ray_radius = 1.0 / 1111 / math.sqrt(12)      # nerf_render.py:144-145
+        if self.ray_space not in ("world", "ndc"):
+            raise ValueError("ray_space must be 'world' or 'ndc'")
+        p.ndc_rays = int(self.ray_space == "ndc")
+        if p.ndc_rays:
+            if self.ndc_width < 1 or self.ndc_height < 1:
+                raise ValueError("ray_space='ndc' needs ndc_width / ndc_height (the full image size)")
+            p.ndc_width, p.ndc_height, p.ndc_near = int(self.ndc_width), int(self.ndc_height), float(self.ndc_near)
         return p
 
     def _ctx(self, device) -> Context:
@@ -165,9 +178,14 @@ class NeRFRender(BaseNeuralRender):
         U_f = self._rand(B, self.sample_fine + 1, uv.device)
         radius = p.ray_radius if p.cone_sampling else None
         with torch.no_grad():
-            rd, ro = ctx.raygen(uv, camera.descriptor())
+            cam = camera.descriptor()
+            rd, ro = ctx.raygen(uv, cam)
+            view = None
+            if p.ndc_rays:
+                view = rd
+                rd, ro = ctx.rays_to_ndc(rd, ro, p.ndc_width, p.ndc_height, cam.calib[0], cam.calib[1], p.ndc_near)
             dists_c = ctx.sample_coarse(U_c, self.dist_near, self.dist_far)
-            smp_c = Sampling(*ctx.sampling(rd, ro, dists_c, radius))
+            smp_c = Sampling(*ctx.sampling(rd, ro, dists_c, radius, view))
         val_c = self.network_coarse(smp_c)
         integ_c = self.integrate_volume_render(dists_c, val_c["density"], val_c["color"])
         for key in val_c:
@@ -177,7 +195,7 @@ class NeRFRender(BaseNeuralRender):
         with torch.no_grad():
             # sanitises the coarse weights in place, as the reference does under set_grad_enabled(False)
             dists_f = ctx.importance_resample(dists_c, integ_c["weight"].detach(), U_f, True)
-            smp_f = Sampling(*ctx.sampling(rd, ro, dists_f, radius))
+            smp_f = Sampling(*ctx.sampling(rd, ro, dists_f, radius, view))
         val_f = self.network_fine(smp_f)
         integ = self.integrate_volume_render(dists_f, val_f["density"], val_f["color"])
         for key in val_f:

@@ -87,6 +87,31 @@ void orc_sampling_points(const float *ray_dir, const float *ray_orig, const floa
             }
 }
 
+/* World rays -> normalised-device-coordinate rays (BASELINE.json configs[4]).  NOT in the reference, which has no
+ * NDC/LLFF code ("parity unpinned" for this function): restated from the published construction, Mildenhall et al.,
+ * "NeRF", ECCV 2020, appendix C -- shift the origin to the near plane z = -near, then
+ *   o' = (-fx/(W/2) ox/oz, -fy/(H/2) oy/oz, 1 + 2 near/oz)
+ *   d' = (-fx/(W/2) (dx/dz - ox/oz), -fy/(H/2) (dy/dz - oy/oz), -2 near/oz).
+ * Pinned in tests by the projective identity it is derived from (points of the world ray map onto the NDC ray). */
+void orc_rays_to_ndc(const float *ray_dir, const float *ray_orig, int B, int width, int height, float fx, float fy, float near_,
+                     float *ndc_dir, float *ndc_orig)
+{
+    const float sx = fx / (0.5f * (float)width), sy = fy / (0.5f * (float)height);
+    for (int b = 0; b < B; ++b) {
+        float dx = ray_dir[3 * b], dy = ray_dir[3 * b + 1], dz = ray_dir[3 * b + 2];
+        float ox = ray_orig[3 * b], oy = ray_orig[3 * b + 1], oz = ray_orig[3 * b + 2];
+        float t = -(near_ + oz) / dz;
+        ox = ox + t * dx; oy = oy + t * dy; oz = oz + t * dz;
+        float ozi = 1.0f / oz, dzi = 1.0f / dz;
+        ndc_orig[3 * b] = -sx * (ox * ozi);
+        ndc_orig[3 * b + 1] = -sy * (oy * ozi);
+        ndc_orig[3 * b + 2] = 1.0f + 2.0f * near_ * ozi;
+        ndc_dir[3 * b] = -sx * (dx * dzi - ox * ozi);
+        ndc_dir[3 * b + 1] = -sy * (dy * dzi - oy * ozi);
+        ndc_dir[3 * b + 2] = -2.0f * near_ * ozi;
+    }
+}
+
 /* Ray.get_sampling_cones ray.py:128-194 (mip-NeRF conical frustum moments). */
 void orc_sampling_cones(const float *ray_dir, const float *ray_orig, const float *dists, int B, int S,
                         double ray_radius, float *pos, float *dir, float *var)
@@ -452,6 +477,25 @@ static int orc_in_skips(const int *skips, int n, int id)
  * cache feeds ORC_PB*4 activation rows (the per-row arithmetic and its order
  * are those of a point-at-a-time evaluation). */
 #define ORC_PB 8
+
+/* bf16-operand emulation (BASELINE.json configs[4]; NOT a reference code path -- the reference is fp32 only).  When
+ * on, every value that the HIP bf16 kernels feed to the matrix unit as an A operand (encodings, activations and their
+ * Jacobian rows, the colour trunk's normal input) is rounded to bfloat16 (nearest even) exactly where those kernels
+ * round it; the caller rounds the 256-wide layers' weights.  Products and sums stay fp32, like the MFMA's. */
+static int g_orc_bf16 = 0;
+void orc_set_bf16(int on) { g_orc_bf16 = on; }
+float orc_bf16_round(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return x;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&x, &u, 4);
+    return x;
+}
+static inline float orc_q(float x) { return g_orc_bf16 ? orc_bf16_round(x) : x; }
+
 void orc_neddf_forward(const orc_neddf_t *net, const float *pos, const float *dir, const float *var, int N,
                        float *distance, float *density, float *color, float *penalty, float *aux_grad_out)
 {
@@ -491,18 +535,18 @@ void orc_neddf_forward(const orc_neddf_t *net, const float *pos, const float *di
                         float sn = sinf(ph), cs = cosf(ph);
                         float s1 = gs * lp * w;
                         float s2 = lp * w;
-                        ps[c] = s1 * sn;           ps[3 * E + c] = s1 * cs;
-                        pu[c] = s2 * sn;           pu[3 * E + c] = s2 * cs;
+                        ps[c] = orc_q(s1 * sn);    ps[3 * E + c] = orc_q(s1 * cs);
+                        pu[c] = orc_q(s2 * sn);    pu[3 * E + c] = orc_q(s2 * cs);
                         float g1 = f * s1 * 1.0f, g2 = f * s2 * 1.0f;
-                        ps[(1 + d) * Cpe + c] = g1 * cs;  ps[(1 + d) * Cpe + 3 * E + c] = -g1 * sn;
-                        pu[(1 + d) * Cpe + c] = g2 * cs;  pu[(1 + d) * Cpe + 3 * E + c] = -g2 * sn;
+                        ps[(1 + d) * Cpe + c] = orc_q(g1 * cs);  ps[(1 + d) * Cpe + 3 * E + c] = orc_q(-g1 * sn);
+                        pu[(1 + d) * Cpe + c] = orc_q(g2 * cs);  pu[(1 + d) * Cpe + 3 * E + c] = orc_q(-g2 * sn);
                     }
                 }
                 for (int e = 0; e < Ed; ++e)
                     for (int d = 0; d < 3; ++d) {    /* :210, PositionalEncoding */
                         float ph = ldexpf(1.0f, e) * dir[3 * (n0 + p) + d];
-                        pe_d[p * Cdir + e * 3 + d] = sinf(ph);
-                        pe_d[p * Cdir + 3 * Ed + e * 3 + d] = cosf(ph);
+                        pe_d[p * Cdir + e * 3 + d] = orc_q(sinf(ph));
+                        pe_d[p * Cdir + 3 * Ed + e * 3 + d] = orc_q(cosf(ph));
                     }
             }
             /* :212-219 distance trunk with (value, Jacobian) rows */
@@ -517,8 +561,8 @@ void orc_neddf_forward(const orc_neddf_t *net, const float *pos, const float *di
                     for (int j = 0; j < W; ++j) {
                         float y, dy;
                         orc_act_grad(net->activation, o0[j], &y, &dy);
-                        o0[j] = y;
-                        for (int r = 1; r < 4; ++r) o0[r * LD + j] = dy * o0[r * LD + j];
+                        o0[j] = orc_q(y);
+                        for (int r = 1; r < 4; ++r) o0[r * LD + j] = orc_q(dy * o0[r * LD + j]);
                     }
                 }
                 cin = W;
@@ -558,7 +602,7 @@ void orc_neddf_forward(const orc_neddf_t *net, const float *pos, const float *di
                     memcpy(row + Cpe + Cdir + 3, h + (4 * p + r) * LD + (cin - W), sizeof(float) * W);
                 }
                 memcpy(c_in + (4 * p) * LD + Cpe, pe_d + p * Cdir, sizeof(float) * Cdir);
-                for (int i = 0; i < 3; ++i) c_in[(4 * p) * LD + Cpe + Cdir + i] = nd_[p][i];
+                for (int i = 0; i < 3; ++i) c_in[(4 * p) * LD + Cpe + Cdir + i] = orc_q(nd_[p][i]);
             }
             float *ci = c_in, *co = h;
             int ccin = in_col;
@@ -569,8 +613,8 @@ void orc_neddf_forward(const orc_neddf_t *net, const float *pos, const float *di
                     for (int j = 0; j < Wc; ++j) {
                         float y, dy;
                         orc_act_grad(net->activation, o0[j], &y, &dy);
-                        o0[j] = y;
-                        for (int r = 1; r < 4; ++r) o0[r * LD + j] = dy * o0[r * LD + j];
+                        o0[j] = orc_q(y);
+                        for (int r = 1; r < 4; ++r) o0[r * LD + j] = orc_q(dy * o0[r * LD + j]);
                     }
                 }
                 ccin = Wc;

@@ -198,14 +198,24 @@ def pe(x, scale, E):
 
 
 # ---------------------------------------------------------------------- fields
+def bf16_round(a):
+    """fp32 -> nearest-even bfloat16 -> fp32 (numpy), the rounding of v_cvt_pk_bf16_f32."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
 class NeDDFOracle:
     """Mirrors NeDDF(...) ctor keywords (neddf.py:52-66) + a numpy state dict."""
 
     def __init__(self, state, embed_pos_rank=10, embed_dir_rank=4, ddf_layer_count=8, ddf_layer_width=256,
                  col_layer_count=8, col_layer_width=256, activation_type="tanhExp",
                  density_activation_type="ReLU", d_near=0.01, lowpass_alpha_offset=10.0, skips=None,
-                 penalty_weight=None):
+                 penalty_weight=None, bf16=False):
+        """bf16=True emulates the bf16-operand kernels (BASELINE.json configs[4], not a reference code path): the
+        weights of the 256-wide layers and every matrix-unit A operand are rounded to bfloat16, arithmetic stays fp32."""
         self.cfg = dict(E=embed_pos_rank, Ed=embed_dir_rank)
+        self.bf16 = bool(bf16)
         self.lowpass_alpha_offset = lowpass_alpha_offset
         if skips is None:
             skips = [4]
@@ -213,6 +223,10 @@ class NeDDFOracle:
             penalty_weight = {"constraints_aux_grad": 0.05, "constraints_dDdt": 0.05,
                               "constraints_color": 0.01, "range_distance": 1.0, "range_aux_grad": 1.0}
         self._keep = {k: _f32(v) for k, v in state.items()}
+        if self.bf16:
+            for k in list(self._keep):
+                if k.startswith(("layers_ddf.", "layers_col.")) and k.endswith(".weight"):
+                    self._keep[k] = bf16_round(self._keep[k])
         s = _NeDDF()
         s.embed_pos_rank, s.embed_dir_rank = embed_pos_rank, embed_dir_rank
         s.n_ddf, s.ddf_width = ddf_layer_count - 1, ddf_layer_width
@@ -253,8 +267,12 @@ class NeDDFOracle:
         o = dict(distance=np.empty(N, np.float32), density=np.empty(N, np.float32),
                  color=np.empty((N, 3), np.float32), fields_penalty=np.empty(N, np.float32),
                  aux_grad=np.empty(N, np.float32))
-        lib().orc_neddf_forward(C.byref(self.s), _p(pos), _p(dir), _p(var), N, _p(o["distance"]),
-                                _p(o["density"]), _p(o["color"]), _p(o["fields_penalty"]), _p(o["aux_grad"]))
+        lib().orc_set_bf16(int(self.bf16))
+        try:
+            lib().orc_neddf_forward(C.byref(self.s), _p(pos), _p(dir), _p(var), N, _p(o["distance"]),
+                                    _p(o["density"]), _p(o["color"]), _p(o["fields_penalty"]), _p(o["aux_grad"]))
+        finally:
+            lib().orc_set_bf16(0)
         return {k: v.reshape(shp + ((3,) if k == "color" else ())) for k, v in o.items()}
 
 
@@ -330,18 +348,37 @@ class NeuSOracle:
         return dict(sdf=sdf.reshape(shp), density=dens.reshape(shp), color=col.reshape(shp + (3,)))
 
 
+def rays_to_ndc(ray_dir, ray_orig, width, height, fx, fy, near):
+    """World rays -> NDC rays (not a reference function; see orc_rays_to_ndc)."""
+    ray_dir, ray_orig = _f32(ray_dir), _f32(ray_orig)
+    nd, no = np.empty_like(ray_dir), np.empty_like(ray_orig)
+    lib().orc_rays_to_ndc(_p(ray_dir), _p(ray_orig), ray_dir.shape[0], int(width), int(height), C.c_float(fx), C.c_float(fy),
+                          C.c_float(near), _p(nd), _p(no))
+    return nd, no
+
+
 def render_rays(field_coarse, field_fine, uv, R, T, calib, u_coarse, u_fine, dist_near, dist_far, max_dist,
-                sampling_type="cone"):
-    """NeRFRender.render_rays nerf_render.py:109-188 with the uniforms given explicitly."""
+                sampling_type="cone", ndc=None):
+    """NeRFRender.render_rays nerf_render.py:109-188 with the uniforms given explicitly.  ndc = (width, height, near)
+    samples along NDC rays while the fields keep the world-space viewing direction (not a reference mode)."""
     ray_radius = 1.0 / 1111 / math.sqrt(12) if sampling_type == "cone" else None
     rd, ro = create_rays(uv, R, T, calib)
+    if ndc is not None:
+        view = rd
+        rd, ro = rays_to_ndc(rd, ro, ndc[0], ndc[1], calib[0], calib[1], ndc[2])
+
+        def sample_fn(rd_, ro_, d_, rr_):     # positions along the NDC ray, direction = world-space view direction
+            pos, _, var = sampling(rd_, ro_, d_, rr_)
+            return pos, np.broadcast_to(view[:, None, :], pos.shape).astype(np.float32).copy(), var
+    else:
+        sample_fn = sampling
     dc = sample_coarse(u_coarse, dist_near, dist_far)
-    vc = field_coarse.forward(*sampling(rd, ro, dc, ray_radius))
+    vc = field_coarse.forward(*sample_fn(rd, ro, dc, ray_radius))
     ic = integrate(dc, vc["density"], vc["color"], max_dist)
     if "fields_penalty" in vc:
         ic["fields_penalty"] = integrate_penalty(dc, vc["fields_penalty"])
     df, _, _ = sample_pdf(dc, ic["weight"], u_fine, True)
-    vf = field_fine.forward(*sampling(rd, ro, df, ray_radius))
+    vf = field_fine.forward(*sample_fn(rd, ro, df, ray_radius))
     out = integrate(df, vf["density"], vf["color"], max_dist)
     if "fields_penalty" in vf:
         out["fields_penalty"] = integrate_penalty(df, vf["fields_penalty"])

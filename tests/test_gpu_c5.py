@@ -1,0 +1,214 @@
+"""BASELINE.json configs[4]: forward-facing NDC rays + bf16 MLP operands on the bf16 MFMA.
+
+The reference has neither (fp32 only, no NDC/LLFF code), so parity here is pinned differently ("parity
+unpinned" items): the NDC construction against the CPU restatement of the published formula (itself checked on the
+projective identity in tests/test_oracle.py), and the bf16 kernels against the oracle's bf16 emulation, which rounds
+weights and matrix-unit inputs to bfloat16 at the same places and keeps fp32 arithmetic elsewhere.  The distance to
+the fp32 result is reported and bounded loosely (north_star states 1e-4 for fp32 only)."""
+import numpy as np
+import pytest
+import torch
+from conftest import BUNNY_CFG, assert_close, golden
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _inference():
+    with torch.no_grad():
+        yield
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ctx(dev):
+    from neddf_amd import Context
+    return Context.get(dev)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def _rays(n, seed):
+    rng = np.random.default_rng(seed)
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    d[:, 2] = -np.abs(d[:, 2]) - 0.5
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = rng.uniform(-0.3, 0.3, (n, 3)).astype(np.float32)
+    return d, o
+
+
+def test_rays_to_ndc_bit_exact(ctx, dev, orc):
+    d, o = _rays(1000, 1)
+    nd, no = ctx.rays_to_ndc(T(d, dev), T(o, dev), 1008, 756, 815.1, 809.3, 1.0)
+    rd, ro = orc.rays_to_ndc(d, o, 1008, 756, 815.1, 809.3, 1.0)
+    assert np.array_equal(N(nd), rd) and np.array_equal(N(no), ro)       # +,-,*,/ only
+    e = ctx.rays_to_ndc(T(d[:0], dev), T(o[:0], dev), 8, 8, 1.0, 1.0, 1.0)
+    assert e[0].shape == (0, 3)
+
+
+def test_sampling_with_view_direction(ctx, dev, orc):
+    d, o = _rays(33, 2)
+    view, _ = _rays(33, 3)
+    dists = np.sort(np.random.default_rng(4).uniform(0, 1, (33, 17)).astype(np.float32), axis=1)
+    pos, sd, var = ctx.sampling(T(d, dev), T(o, dev), T(dists, dev), None, T(view, dev))
+    rpos, _, rvar = orc.sampling(d, o, dists, None)
+    assert np.array_equal(N(pos), rpos) and np.array_equal(N(var), rvar)
+    assert np.array_equal(N(sd), np.broadcast_to(view[:, None, :], (33, 17, 3)))
+
+
+def _net(dev, weights, dtype, mode="full", cfg=BUNNY_CFG):
+    import neddf_amd
+    net = neddf_amd.NeDDF(**cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    net.to(dev)
+    net.set_iter(-1)
+    net.weight_dtype = dtype
+    net.output_mode = mode
+    return net
+
+
+@pytest.mark.parametrize("mode", ["full", "minimal"])
+def test_bf16_field_against_bf16_emulation(dev, orc, bunny_weights, mode):
+    """bf16 kernels vs the oracle with the same roundings: what remains is fp32 summation order inside the MFMA plus
+    the occasional activation that lands on the other side of a bf16 rounding boundary."""
+    from neddf_amd import Sampling
+    pos, d, var = synth.random_sampling(40, 33, seed=21)         # 1320 points: ragged last tile
+    net = _net(dev, bunny_weights, "bf16", mode)
+    o = net(Sampling(T(pos, dev), T(d, dev), T(var, dev)))
+    emu = orc.NeDDFOracle(bunny_weights, bf16=True, **BUNNY_CFG).forward(pos, d, var)
+    f32 = orc.NeDDFOracle(bunny_weights, **BUNNY_CFG).forward(pos, d, var)
+    keys = ("distance", "density", "color", "aux_grad") + (("fields_penalty",) if mode == "full" else ())
+    for k in keys:
+        a = N(o[k])
+        scale = np.abs(f32[k]).max()
+        err_emu = np.abs(a - emu[k]).max() / scale
+        err_f32 = np.abs(a - f32[k]).max() / scale
+        print("%-14s vs bf16 emulation %.2e, vs fp32 %.2e (of max |value| %.3g)" % (k, err_emu, err_f32, scale))
+        # rounding to bf16 makes the network discontinuous: a 1e-7 difference in summation order that pushes one
+        # activation across a rounding boundary is amplified layer by layer up to the bf16 noise floor, so a deep
+        # network is tracked by the emulation only to a fraction of that floor (the shallow test below is the tight one)
+        assert err_emu < {"fields_penalty": 5e-2, "color": 2e-2}.get(k, 5e-3), (k, err_emu)
+        assert err_f32 < (0.2 if k == "fields_penalty" else 3e-2), (k, err_f32)
+    # and the fp32 path is untouched by the dtype switch on the same module
+    net.weight_dtype = "fp32"
+    o32 = net(Sampling(T(pos, dev), T(d, dev), T(var, dev)))
+    assert_close(N(o32["distance"]), f32["distance"], 1e-4, 1e-5, "fp32 after bf16")
+
+
+def test_bf16_single_layer_tight(dev, orc):
+    """One trunk layer and one colour layer: no room for rounding differences to cascade, so the kernel must match the
+    emulation to fp32 accuracy except where a single activation rounds the other way (<= 2^-8 of one of 256 terms)."""
+    from neddf_amd import Sampling
+    for act in ("ReLU", "tanhExp"):
+        cfg = dict(embed_pos_rank=10, embed_dir_rank=4, ddf_layer_count=2, ddf_layer_width=256, col_layer_count=2,
+                   col_layer_width=256, d_near=0.01, activation_type=act, density_activation_type="ReLU",
+                   lowpass_alpha_offset=10, skips=[], penalty_weight={"constraints_dDdt": 0.5})
+        w = synth.neddf_state(ddf_layer_count=2, col_layer_count=2, skips=(), seed=5)
+        pos, d, var = synth.random_sampling(16, 24, seed=9)
+        net = _net(dev, w, "bf16", "full", cfg)
+        o = net(Sampling(T(pos, dev), T(d, dev), T(var, dev)))
+        emu = orc.NeDDFOracle(w, bf16=True, **cfg).forward(pos, d, var)
+        f32 = orc.NeDDFOracle(w, **cfg).forward(pos, d, var)
+        for k in ("distance", "density", "color", "aux_grad"):
+            scale = np.abs(emu[k]).max()
+            err = np.abs(N(o[k]) - emu[k]).max() / scale
+            gap = np.abs(f32[k] - emu[k]).max() / scale
+            print("%s %-9s kernel vs emulation %.2e (emulation vs fp32 %.2e)" % (act, k, err, gap))
+            assert err < 2e-4, (act, k, err)
+            assert gap > 10 * err or gap < 1e-6, (act, k, err, gap)      # the test can tell bf16 from fp32
+
+
+def test_bf16_other_architectures(dev, orc):
+    """ReLU activations, two skip connections, small encodings (column padding differs between the operand types)."""
+    from neddf_amd import Sampling
+    cfg = dict(embed_pos_rank=5, embed_dir_rank=2, ddf_layer_count=6, ddf_layer_width=256, col_layer_count=3, col_layer_width=256,
+               d_near=0.01, activation_type="ReLU", density_activation_type="ReLU", lowpass_alpha_offset=10, skips=[1, 3],
+               penalty_weight={"constraints_dDdt": 0.5})
+    w = synth.neddf_state(embed_pos_rank=5, embed_dir_rank=2, ddf_layer_count=6, col_layer_count=3, skips=(1, 3), seed=77)
+    pos, d, var = synth.random_sampling(9, 14, seed=8)
+    net = _net(dev, w, "bf16", "full", cfg)
+    o = net(Sampling(T(pos, dev), T(d, dev), T(var, dev)))
+    emu = orc.NeDDFOracle(w, bf16=True, **cfg).forward(pos, d, var)
+    for k in ("distance", "density", "color", "aux_grad"):
+        scale = np.abs(emu[k]).max()
+        assert np.abs(N(o[k]) - emu[k]).max() / scale < 1e-2, k
+
+
+def test_bf16_neus_close_to_fp32(dev):
+    """NeuS shares the trunk kernels; bf16 is checked against its own fp32 result."""
+    import neddf_amd
+    from neddf_amd import Sampling
+    w = synth.neus_state()
+    net = neddf_amd.NeuS()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+    net.to(dev)
+    pos, d, var = synth.random_sampling(6, 30, seed=5, cone=False)
+    s = Sampling(T(pos, dev), T(d, dev), T(var, dev))
+    a = net(s)
+    net.weight_dtype = "bf16"
+    b = net(s)
+    for k in a:
+        scale = float(a[k].abs().max())
+        # random-weight NeuS colours are small sums of large cancelling terms: loose bound there
+        assert float((a[k] - b[k]).abs().max()) / scale < (0.25 if k == "color" else 5e-2), k
+        assert not torch.equal(a[k], b[k])
+
+
+def test_bf16_nerf_is_refused(dev):
+    import neddf_amd
+    from neddf_amd import Sampling
+    net = neddf_amd.NeRF().to(dev)
+    net.weight_dtype = "bf16"
+    pos, d, var = synth.random_sampling(2, 4, seed=1)
+    with pytest.raises(neddf_amd.NeddfError):
+        net(Sampling(T(pos, dev), T(d, dev), T(var, dev)))
+
+
+def test_render_rays_ndc_bf16_end_to_end(dev, orc, bunny_weights):
+    """configs[4] end to end on 48 rays: NDC rays + point sampling + bf16 fields through neddf_render_rays vs the
+    oracle's restatement with the same uniforms (bf16 emulation) -- and the fp32 variant of the same NDC render at 1e-4."""
+    import neddf_amd
+    g = golden("bunny_stages.npz")
+    W, H, near = 400, 400, 1.0
+    rng = np.random.default_rng(12)
+    uv = rng.integers(40, 360, (48, 2)).astype(np.int64)
+    # a forward-facing pose: camera at the origin region looking down -z (identity rotation)
+    R, Tr = np.eye(3, dtype=np.float32), np.array([0.05, -0.02, 0.1], np.float32)
+    calib = g["calib"].astype(np.float32)
+    u_c, u_f = rng.uniform(0, 1, (48, 65)).astype(np.float32), rng.uniform(0, 1, (48, 129)).astype(np.float32)
+    cfg = dict(BUNNY_CFG, _target_="neddf.network.NeDDF")
+    r = neddf_amd.NeRFRender(cfg, sample_coarse=64, sample_fine=128, dist_near=0.0, dist_far=1.0, max_dist=1.0,
+                             use_coarse_network=False, sampling_type="point")
+    r.network_fine.load_state_dict({k: torch.from_numpy(v) for k, v in bunny_weights.items()})
+    r.to(dev)
+    r.set_iter(-1)
+    r.ray_space, r.ndc_width, r.ndc_height, r.ndc_near = "ndc", W, H, near
+    cam = neddf_amd.Camera(neddf_amd.PinholeCalib(calib.astype(np.float64)), None).to(dev)
+    cam.R, cam.T = T(R, dev), T(Tr, dev)
+    for dtype, tol in (("fp32", 1e-4), ("bf16", 2e-2)):
+        r.network_fine.weight_dtype = dtype
+        o = r._render(r._ctx(dev), T(uv, dev), cam, T(u_c, dev), T(u_f, dev), full=True)
+        assert int(o["_nan"].item()) == 0
+        net = orc.NeDDFOracle(bunny_weights, bf16=(dtype == "bf16"), **BUNNY_CFG)
+        ref = orc.render_rays(net, net, uv, R, Tr, calib, u_c, u_f, 0.0, 1.0, 1.0, "point", ndc=(W, H, near))
+        for k in ("color", "depth", "transmittance", "color_coarse", "depth_coarse", "transmittance_coarse"):
+            assert_close(N(o[k]), ref[k], tol, tol * 0.1 + 1e-5, "%s %s" % (dtype, k))

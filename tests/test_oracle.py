@@ -192,3 +192,40 @@ def test_neus_synth(name):
     o = net.forward(g["pos"], g["dir"])
     for k in ("sdf", "density", "color"):
         assert_close(o[k], g["eval_" + k], 1e-4, 1e-5, "%s %s" % (name, k))
+
+
+# ----------------------------------------------------------------- configs[4]: NDC rays, bf16 operands (not in the reference)
+def test_ndc_rays_projective_identity():
+    """The reference has no NDC code, so the restatement is pinned on what it is derived from (NeRF paper, appendix C):
+    a world point o_n + t d (o_n = the ray's intersection with the near plane) maps to o' + t' d' with
+    t' = 1 - o_n,z / (o_n,z + t d_z) under the perspective map (x, y, z) -> (-fx/(W/2) x/z, -fy/(H/2) y/z, 1 + 2 near/z)."""
+    rng = np.random.default_rng(0)
+    B, W, H, fx, fy, near = 64, 1008, 756, 815.1, 809.3, 1.0
+    d = rng.standard_normal((B, 3)).astype(np.float32)
+    d[:, 2] = -np.abs(d[:, 2]) - 0.5
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = rng.uniform(-0.2, 0.2, (B, 3)).astype(np.float32)
+    nd, no = orc.rays_to_ndc(d, o, W, H, fx, fy, near)
+    d64, o64 = d.astype(np.float64), o.astype(np.float64)
+    on = o64 + (-(near + o64[:, 2]) / d64[:, 2])[:, None] * d64
+    for t in (0.0, 0.25, 2.0, 40.0, 1e4):
+        p = on + t * d64
+        want = np.stack([-fx / (W / 2) * p[:, 0] / p[:, 2], -fy / (H / 2) * p[:, 1] / p[:, 2], 1 + 2 * near / p[:, 2]], 1)
+        tp = 1 - on[:, 2] / (on[:, 2] + t * d64[:, 2])
+        assert np.abs(no + tp[:, None] * nd - want).max() < 2e-6
+    assert np.abs(no[:, 2] + 1).max() < 1e-6            # the NDC origin sits on the near face z' = -1
+    assert np.abs(no[:, 2] + nd[:, 2] - 1).max() < 1e-6  # and t' = 1 is the far face z' = +1
+
+
+def test_bf16_rounding_and_emulation(bunny_weights):
+    """bf16 emulation of configs[4]: nearest-even rounding, and how far it moves the field outputs from fp32."""
+    x = np.array([1.0, 1.00390625, 1.005859375, 1.01171875, -2.5e-3, 65535.0, 0.0], np.float32)
+    want = np.array([1.0, 1.0, 1.0078125, 1.015625, -2.50244140625e-3, 65536.0, 0.0], np.float32)
+    assert np.array_equal(orc.bf16_round(x), want)      # ties go to the even mantissa (1.00390625 -> 1.0, 1.01171875 -> 1.015625)
+    pos, d, var = synth.random_sampling(4, 16, seed=5)
+    a = orc.NeDDFOracle(bunny_weights, **BUNNY_CFG).forward(pos, d, var)
+    b = orc.NeDDFOracle(bunny_weights, bf16=True, **BUNNY_CFG).forward(pos, d, var)
+    assert np.abs(a["distance"] - b["distance"]).max() < 1e-2 and np.abs(a["color"] - b["color"]).max() < 2e-2
+    assert np.abs(a["distance"] - b["distance"]).max() > 1e-5          # the mode is actually on
+    c = orc.NeDDFOracle(bunny_weights, **BUNNY_CFG).forward(pos, d, var)
+    assert all(np.array_equal(a[k], c[k]) for k in a)                  # ... and off again afterwards
