@@ -39,6 +39,9 @@ DDF_FLOP_PER_POINT = 2 * (4 * (423936 + 256) + 256)
 #   colour trunk (value row only): 343*256 + 2*256*256 + 256*3 MACs
 COL_FLOP_PER_POINT = 2 * (219648 + 768)
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16, v_mfma_f32_32x32x16_bf16
+# BASELINE.json configs[4] ("LLFF fern forward-facing, NDC rays, bf16 MLP weights"): fern at the customary 1/4 scale
+C5_WIDTH, C5_HEIGHT, C5_FOCAL, C5_NEAR = 1008, 756, 815.13, 1.0
 
 
 def view_pose(i):
@@ -109,9 +112,17 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
-                    help="c2 = BASELINE configs[1] (headline, default); c3 = configs[2], 65 coarse + 129 importance samples")
+    ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2",
+                    help="c2 = BASELINE configs[1] (headline, default); c3 = configs[2], 65 coarse + 129 importance samples; "
+                         "c5 = configs[4], 1008x756 forward-facing view, NDC rays, hierarchical sampling, bf16 operands")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default=None,
+                    help="operand type of the 256-wide layers (default f32; c5 defaults to bf16)")
     args = ap.parse_args()
+    if args.dtype is None:
+        args.dtype = "bf16" if args.workload == "c5" else "f32"
+    global WIDTH, HEIGHT
+    if args.workload == "c5":
+        WIDTH, HEIGHT = C5_WIDTH, C5_HEIGHT
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -132,9 +143,15 @@ def main():
     import neddf_amd
     from neddf_amd.parallel import gather_pixels, pack_pixels
     render, weights = build_render(dev)
+    render.network_fine.weight_dtype = {"f32": "fp32", "bf16": "bf16"}[args.dtype]
     fx = 0.5 * WIDTH / math.tan(0.5 * CAMERA_ANGLE_X)
     calib = np.array([fx, fx, WIDTH / 2.0, HEIGHT / 2.0])
     R, T = view_pose(rank)
+    if args.workload == "c5":       # forward-facing: camera near the origin looking down -z, NDC depths 0..1, point samples
+        calib = np.array([C5_FOCAL, C5_FOCAL, WIDTH / 2.0, HEIGHT / 2.0])
+        R, T = np.eye(3, dtype=np.float32), np.array([0.05 * rank, -0.02, 0.1], np.float32)
+        render.sampling_type, render.dist_near, render.dist_far, render.max_dist = "point", 0.0, 1.0, 1.0
+        render.ray_space, render.ndc_width, render.ndc_height, render.ndc_near = "ndc", WIDTH, HEIGHT, C5_NEAR
     cam = neddf_amd.Camera(neddf_amd.PinholeCalib(calib), None).to(dev)
     cam.R, cam.T = torch.from_numpy(R).to(dev), torch.from_numpy(T).to(dev)
     n_rays = WIDTH * HEIGHT
@@ -146,12 +163,12 @@ def main():
     uv_all = torch.stack([idx % WIDTH, idx // WIDTH], 1)
     samples_per_ray = SAMPLES if args.workload == "c2" else 65 + 194
 
-    if args.workload == "c3":
+    if args.workload in ("c3", "c5"):
         U_c = torch.rand(n_rays, 65, device=dev)
         U_f = torch.rand(n_rays, 129, device=dev)
 
     def step():
-        if args.workload == "c3":
+        if args.workload in ("c3", "c5"):
             parts = {k: [] for k in keys}
             for lo in range(0, n_rays, render.rays_per_call):
                 hi = min(n_rays, lo + render.rays_per_call)
@@ -192,28 +209,37 @@ def main():
         pts = n_rays * samples_per_ray * args.steps               # field evaluations on this rank
         ddf_s = tm["ddf_ms"] / 1e3
         achieved = pts * DDF_FLOP_PER_POINT / ddf_s / 1e12 if ddf_s > 0 else 0.0
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
         line = {
-            "metric": "rendered rays/sec (800x800, 128 samples/ray)" if args.workload == "c2" else
-                      "rendered rays/sec (800x800, 65 coarse + 194 fine hierarchical samples/ray)",
+            "metric": {"c2": "rendered rays/sec (800x800, 128 samples/ray)",
+                       "c3": "rendered rays/sec (800x800, 65 coarse + 194 fine hierarchical samples/ray)",
+                       "c5": "rendered rays/sec (1008x756 forward-facing NDC view, 65 coarse + 194 fine samples/ray)"}[args.workload],
             "value": n_rays * world * args.steps / elapsed,
             "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: 800x800 view, 128 stratified cone samples/ray, NeDDF "
-                                   "(8x256 distance trunk with Jacobian rows + 4x256 colour trunk) fp32, 1 view per GPU "
-                                   "per step, synthetic poses, shipped bunny_smoke weights",
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": {"c2": "BASELINE.json configs[1]: 800x800 view, 128 stratified cone samples/ray, NeDDF "
+                                          "(8x256 distance trunk with Jacobian rows + 4x256 colour trunk) %s, 1 view per GPU "
+                                          "per step, synthetic poses, shipped bunny_smoke weights" % args.dtype,
+                                    "c3": "BASELINE.json configs[2]: as configs[1] with render_rays' hierarchical sampling "
+                                          "(65 coarse + 129 importance samples merged to 194), %s" % args.dtype,
+                                    "c5": "BASELINE.json configs[4]: 1008x756 forward-facing view (fern at 1/4 scale), NDC rays, "
+                                          "point samples, hierarchical 65 + 194, NeDDF with %s operands" % args.dtype}[args.workload],
                        "rays_per_step_per_gpu": n_rays, "samples_per_ray": samples_per_ray, "workload_id": args.workload, "parallelism": "ray-parallel x%d" % world},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
                          "kernel": "neddf::ddf_trunk_kernel", "launches": tm["ddf_launches"],
                          "avg_launch_ms": tm["ddf_ms"] / max(tm["ddf_launches"], 1),
                          "flop_per_point": DDF_FLOP_PER_POINT,
                          "colour_kernel": {"avg_launch_ms": tm["col_ms"] / max(tm["col_launches"], 1),
                                            "achieved": (pts * COL_FLOP_PER_POINT / (tm["col_ms"] / 1e3) / 1e12) if tm["col_ms"] > 0 else 0.0}},
         }
-        try:        # HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)
+        try:        # HBM bytes per launch (PMC passes exist for the headline fp32 workload only)
+            if args.dtype != "f32" or args.workload != "c2":
+                raise KeyError("no PMC pass for this workload")
+            # HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             ent = next(v for k, v in pmc.items() if "ddf_trunk_kernel" in k)
             line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
@@ -221,7 +247,7 @@ def main():
             line["roofline"]["algorithmic_hbm_bytes_per_launch"] = ent["algorithmic_bytes_per_launch"]
         except Exception:
             pass
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != "c5":
             line["cpu_baseline"] = cpu_baseline(weights, R, T, calib.astype(np.float32))
         nan = int(res["_nan"].item()) if isinstance(res, dict) else 0
         assert nan == 0

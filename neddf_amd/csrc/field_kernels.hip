@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
         // Early partials of skip layers (neddf.py:217-219).  With one skip connection (every shipped
         // config) and the 64-row tile the partial stays in registers until its layer; otherwise it is
         // parked in the per-workgroup global scratch.
-        constexpr bool REG_STASH = (MT == 2);
+        constexpr bool REG_STASH = (MT == 2) && (WPS <= 2);     // denser packings of a CU have no registers to spare
         const bool in_regs = REG_STASH && a.n_stash == 1;
         f32x16 held[REG_STASH ? MT : 1][REG_STASH ? NT : 1];
         for (int s = 0; s < a.n_stash; ++s) {
@@ -611,7 +611,18 @@ static int tile_mt()
     }
     return g_mt;
 }
-int field_wgs_per_cu() { return tile_mt() == 2 ? 2 : 1; }
+// bf16 tiles are half the LDS bytes: NEDDF_BF16_WPS (2, 3 or 4; experiment knob) workgroups share a CU
+static int bf16_wps()
+{
+    static int v = 0;
+    if (!v) {
+        const char *e = getenv("NEDDF_BF16_WPS");
+        v = e ? atoi(e) : 2;
+        if (v < 2 || v > 4) v = 2;
+    }
+    return v;
+}
+int field_wgs_per_cu(int bf16) { return tile_mt() == 2 ? (bf16 ? bf16_wps() : 2) : 1; }
 int ddf_points_per_tile() { return tile_mt() * 8; }
 int col_points_per_tile(bool rows4) { return rows4 ? tile_mt() * 8 : tile_mt() * 32; }
 int nerf_points_per_tile() { return tile_mt() * 32; }
@@ -627,8 +638,16 @@ static void launch_ddf_t(const DdfArgs &a, int grid, hipStream_t s)
     static bool once = (set_lds((const void *)ddf_trunk_kernel<4, 1, Ops>, lds_bytes<Ops>(4)),
                         set_lds((const void *)ddf_trunk_kernel<2, 2, Ops>, lds_bytes<Ops>(2)), true);
     (void)once;
-    if (tile_mt() == 2) hipLaunchKernelGGL((ddf_trunk_kernel<2, 2, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a);
-    else hipLaunchKernelGGL((ddf_trunk_kernel<4, 1, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(4), s, a);
+    if (tile_mt() == 2) {
+        if constexpr (sizeof(typename Ops::act_t) == 2) {
+            static bool once2 = (set_lds((const void *)ddf_trunk_kernel<2, 3, Ops>, lds_bytes<Ops>(2)),
+                                 set_lds((const void *)ddf_trunk_kernel<2, 4, Ops>, lds_bytes<Ops>(2)), true);
+            (void)once2;
+            if (bf16_wps() == 3) { hipLaunchKernelGGL((ddf_trunk_kernel<2, 3, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a); return; }
+            if (bf16_wps() == 4) { hipLaunchKernelGGL((ddf_trunk_kernel<2, 4, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a); return; }
+        }
+        hipLaunchKernelGGL((ddf_trunk_kernel<2, 2, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a);
+    } else hipLaunchKernelGGL((ddf_trunk_kernel<4, 1, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(4), s, a);
 }
 
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)

@@ -128,7 +128,7 @@ void launch_nerf(const NerfArgs &a, int grid, hipStream_t s);
 int ddf_points_per_tile();
 int col_points_per_tile(bool rows4);
 int nerf_points_per_tile();
-int field_wgs_per_cu();
+int field_wgs_per_cu(int bf16 = 0);
 
 void launch_raygen(const void *uv, int uv_type, int64_t n, const CameraArg &cam, float *dir, float *orig, hipStream_t s);
 void launch_sample_coarse(const float *U, int64_t n, int S1, float near_, float far_, float *dists, hipStream_t s);

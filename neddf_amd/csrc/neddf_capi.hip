@@ -348,7 +348,8 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     if (N <= 0) return 0;
     Field &f = ctx->field[slot];
     const int grid_cap = ctx->cus * field_wgs_per_cu();
-    if (int rc = ensure(ctx, ctx->scratch, (size_t)grid_cap * kMaxStash * kStashFloatsPerWg * sizeof(float))) return rc;
+    const int grid_cap_ddf = ctx->cus * field_wgs_per_cu(f.d.weight_dtype == NEDDF_DTYPE_BF16);
+    if (int rc = ensure(ctx, ctx->scratch, (size_t)grid_cap_ddf * kMaxStash * kStashFloatsPerWg * sizeof(float))) return rc;
     if (f.d.kind == NEDDF_FIELD_NERF) {
         NerfArgs a = f.nerf;
         fill_enc(a.enc, f);
@@ -393,7 +394,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         a.sched_flags = sched_flags();
         HIPCHK(hipMemsetAsync(a.sched, 0, kSchedInts * sizeof(int), s));
         tick(ctx, s, 0, true);
-        launch_ddf(a, (int)(tiles < grid_cap ? tiles : grid_cap), s);
+        launch_ddf(a, (int)(tiles < grid_cap_ddf ? tiles : grid_cap_ddf), s);
         tick(ctx, s, 0, false);
         if (color || full) {
             ColArgs c = f.col;

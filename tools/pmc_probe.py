@@ -16,6 +16,7 @@ import math  # noqa: E402
 
 dev = torch.device("cuda:0")
 render, _ = bench.build_render(dev)
+render.network_fine.weight_dtype = os.environ.get("NEDDF_PROBE_DTYPE", "fp32")      # "bf16": the configs[4] kernels
 fx = 0.5 * 800 / math.tan(0.5 * bench.CAMERA_ANGLE_X)
 R, T = bench.view_pose(0)
 cam = neddf_amd.Camera(neddf_amd.PinholeCalib(np.array([fx, fx, 400.0, 400.0])), None).to(dev)
