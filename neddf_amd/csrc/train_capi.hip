@@ -96,18 +96,19 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     for (int l = 0; l < p.n_trunk; ++l) {
         float *Z = ws + p.o_z[l], *H = ws + p.o_h[l];
         const bool wide = l > 0 && in_skips(f.d, l - 1);
+        const int kpe = (p.Cpe + 3) & ~3;       // loaded width of the encoding matrix (pad columns are zero)
         if (l == 0) {
             launch_pack(W[0], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp, s);
-            launch_rows_gemm(PEs, p.R, kLdPe, p.Cpe, wp, (p.Cpe + 7) / 8, kWidth, kWidth, B[0], 4, Z, kWidth, 0, ctx->cus, s);
-        } else {
-            launch_pack(W[l], kWidth, 1, wide ? p.Cpe : 0, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, 32, kWidth, kWidth, B[l], 4, Z, kWidth, 0, ctx->cus, s);
-            if (wide) {      // hx = cat([embed_pos_scaled, hx]): the encoding feeds rows 0 .. Cpe-1
-                launch_pack(W[l], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp2, s);
-                launch_rows_gemm(PEs, p.R, kLdPe, p.Cpe, wp2, (p.Cpe + 7) / 8, kWidth, kWidth, nullptr, 4, Z, kWidth, 1, ctx->cus, s);
-            }
+            launch_rows_gemm(PEs, p.R, kLdPe, kpe, wp, (p.Cpe + 7) / 8, B[0], 4, Z, kWidth, 0, act, H, ctx->cus, s);
+        } else if (!wide) {
+            launch_pack(W[l], kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
+            launch_rows_gemm(ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, 32, B[l], 4, Z, kWidth, 0, act, H, ctx->cus, s);
+        } else {            // hx = cat([embed_pos_scaled, hx]): the encoding feeds rows 0 .. Cpe-1 of the weight
+            launch_pack(W[l], kWidth, 1, p.Cpe, 0, kWidth, kWidth, kWidth, wp, s);
+            launch_rows_gemm(ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, 32, B[l], 4, Z, kWidth, 0, -1, nullptr, ctx->cus, s);
+            launch_pack(W[l], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp2, s);
+            launch_rows_gemm(PEs, p.R, kLdPe, kpe, wp2, (p.Cpe + 7) / 8, nullptr, 4, Z, kWidth, 1, act, H, ctx->cus, s);
         }
-        launch_act_rows(act, 4, Z, H, N, kWidth, kWidth, s);
     }
     const float *Hlast = ws + p.o_h[p.n_trunk - 1];
     NarrowW heads{};
@@ -124,14 +125,13 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
         const float *Wl = W[p.n_trunk + l], *Bl = B[p.n_trunk + l];
         if (l == 0) {
             launch_pack(Wl, kWidth, 1, 0, 0, p.Ca, kWidth, kWidth, wp, s);
-            launch_rows_gemm(ws + p.o_xa, p.R, p.ldxa, p.Ca, wp, (p.Ca + 7) / 8, kWidth, kWidth, Bl, 4, Z, kWidth, 0, ctx->cus, s);
+            launch_rows_gemm(ws + p.o_xa, p.R, p.ldxa, p.ldxa, wp, (p.Ca + 7) / 8, Bl, 4, Z, kWidth, 0, -1, nullptr, ctx->cus, s);
             launch_pack(Wl, kWidth, 1, p.Ca, 0, kWidth, kWidth, kWidth, wp2, s);
-            launch_rows_gemm(Hlast, p.R, kWidth, kWidth, wp2, 32, kWidth, kWidth, nullptr, 4, Z, kWidth, 1, ctx->cus, s);
+            launch_rows_gemm(Hlast, p.R, kWidth, kWidth, wp2, 32, nullptr, 4, Z, kWidth, 1, act, H, ctx->cus, s);
         } else {
             launch_pack(Wl, kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(ws + p.o_hc[l - 1], p.R, kWidth, kWidth, wp, 32, kWidth, kWidth, Bl, 4, Z, kWidth, 0, ctx->cus, s);
+            launch_rows_gemm(ws + p.o_hc[l - 1], p.R, kWidth, kWidth, wp, 32, Bl, 4, Z, kWidth, 0, act, H, ctx->cus, s);
         }
-        launch_act_rows(act, 4, Z, H, N, kWidth, kWidth, s);
     }
     NarrowW cout{};
     cout.nc = 3; cout.wstride = 3;
@@ -173,46 +173,51 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     for (int c = 0; c < 3; ++c) cout.w[c] = W[p.i_cout] + c;
     const float *HClast = ws + p.o_hc[p.n_col - 1];
     launch_narrow_backward(GCR, kLdNarrow, p.R, cout, dA, kWidth, 0, s);
-    launch_dw(HClast, kWidth, kWidth, GCR, kLdNarrow, 3, p.R, gW[p.i_cout], 3, gB[p.i_cout], 4, s);
+    {
+        float *wc[3] = { gW[p.i_cout], gW[p.i_cout] + 1, gW[p.i_cout] + 2 }, *bc[3] = { gB[p.i_cout], gB[p.i_cout] + 1, gB[p.i_cout] + 2 };
+        launch_narrow_dw(HClast, kWidth, GCR, kLdNarrow, p.R, 3, wc, 3, bc, 4, s);
+    }
     const float *Hlast = ws + p.o_h[p.n_trunk - 1];
     for (int l = p.n_col - 1; l >= 0; --l) {
         const float *Wl = W[p.n_trunk + l];
         float *gWl = gW[p.n_trunk + l], *gBl = gB[p.n_trunk + l];
         launch_act_rows_backward(act, 4, ws + p.o_zc[l], dA, dB, N, kWidth, kWidth, s);
         if (l > 0) {
-            launch_dw(ws + p.o_hc[l - 1], kWidth, kWidth, dB, kWidth, kWidth, p.R, gWl, kWidth, gBl, 4, s);
+            launch_dw(ws + p.o_hc[l - 1], kWidth, kWidth, dB, kWidth, kWidth, p.R, gWl, kWidth, gBl, 4, ctx->cus, s);
             launch_pack(Wl, 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wp, s);                 // W^T
         } else {
-            launch_dw(ws + p.o_xa, p.ldxa, p.Ca, dB, kWidth, kWidth, p.R, gWl, kWidth, gBl, 4, s);
-            launch_dw(Hlast, kWidth, kWidth, dB, kWidth, kWidth, p.R, gWl + (size_t)p.Ca * kWidth, kWidth, nullptr, 4, s);
+            launch_dw(ws + p.o_xa, p.ldxa, p.Ca, dB, kWidth, kWidth, p.R, gWl, kWidth, gBl, 4, ctx->cus, s);
+            launch_dw(Hlast, kWidth, kWidth, dB, kWidth, kWidth, p.R, gWl + (size_t)p.Ca * kWidth, kWidth, nullptr, 4, ctx->cus, s);
             launch_pack(Wl, 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wp, s);              // (feature rows of W)^T
         }
         // the small colour inputs (encodings, detached normal) carry no parameters: only the feature segment propagates
-        launch_rows_gemm(dB, p.R, kWidth, kWidth, wp, 32, kWidth, kWidth, nullptr, 4, dA, kWidth, 0, ctx->cus, s);
+        launch_rows_gemm(dB, p.R, kWidth, kWidth, wp, 32, nullptr, 4, dA, kWidth, 0, -1, nullptr, ctx->cus, s);
     }
     // distance / aux heads
     NarrowW heads{};
     heads.nc = 2; heads.wstride = 1;
     heads.w[0] = W[p.i_ddf]; heads.w[1] = W[p.i_aux];
     launch_narrow_backward(GZH, kLdNarrow, p.R, heads, dA, kWidth, 1, s);
-    launch_dw(Hlast, kWidth, kWidth, GZH, kLdNarrow, 1, p.R, gW[p.i_ddf], 1, gB[p.i_ddf], 4, s);
-    launch_dw(Hlast, kWidth, kWidth, GZH + 1, kLdNarrow, 1, p.R, gW[p.i_aux], 1, gB[p.i_aux], 4, s);
+    {
+        float *wh[2] = { gW[p.i_ddf], gW[p.i_aux] }, *bh[2] = { gB[p.i_ddf], gB[p.i_aux] };
+        launch_narrow_dw(Hlast, kWidth, GZH, kLdNarrow, p.R, 2, wh, 1, bh, 4, s);
+    }
     // distance trunk
     for (int l = p.n_trunk - 1; l >= 0; --l) {
         const bool wide = l > 0 && in_skips(f.d, l - 1);
         launch_act_rows_backward(act, 4, ws + p.o_z[l], dA, dB, N, kWidth, kWidth, s);
         if (l == 0) {
-            launch_dw(PEs, kLdPe, p.Cpe, dB, kWidth, kWidth, p.R, gW[0], kWidth, gB[0], 4, s);
+            launch_dw(PEs, kLdPe, p.Cpe, dB, kWidth, kWidth, p.R, gW[0], kWidth, gB[0], 4, ctx->cus, s);
             break;
         }
         if (wide) {
-            launch_dw(PEs, kLdPe, p.Cpe, dB, kWidth, kWidth, p.R, gW[l], kWidth, gB[l], 4, s);
-            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dB, kWidth, kWidth, p.R, gW[l] + (size_t)p.Cpe * kWidth, kWidth, nullptr, 4, s);
+            launch_dw(PEs, kLdPe, p.Cpe, dB, kWidth, kWidth, p.R, gW[l], kWidth, gB[l], 4, ctx->cus, s);
+            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dB, kWidth, kWidth, p.R, gW[l] + (size_t)p.Cpe * kWidth, kWidth, nullptr, 4, ctx->cus, s);
         } else {
-            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dB, kWidth, kWidth, p.R, gW[l], kWidth, gB[l], 4, s);
+            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dB, kWidth, kWidth, p.R, gW[l], kWidth, gB[l], 4, ctx->cus, s);
         }
         launch_pack(W[l], 1, kWidth, 0, wide ? p.Cpe : 0, kWidth, kWidth, kWidth, wp, s);
-        launch_rows_gemm(dB, p.R, kWidth, kWidth, wp, 32, kWidth, kWidth, nullptr, 4, dA, kWidth, 0, ctx->cus, s);
+        launch_rows_gemm(dB, p.R, kWidth, kWidth, wp, 32, nullptr, 4, dA, kWidth, 0, -1, nullptr, ctx->cus, s);
     }
     HIPCHK(hipGetLastError());
     return 0;

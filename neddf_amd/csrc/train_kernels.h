@@ -39,10 +39,15 @@ struct TrainPointArgs {
 // fragment-major layout of kernels.h LayerW for nout (128 or 256) output columns and roundup(kcount, 8) / 8 super-steps
 void launch_pack(const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, float *dst, hipStream_t s);
 
-void launch_rows_gemm(const float *X, int64_t R, int ldx, int kcols, const float *wp, int ksteps, int nout, int ncols_valid,
-                      const float *bias, int bias_period, float *Y, int ldy, int accumulate, int cus, hipStream_t s);
+// Y[R,256] (+)= X[R, 0:kload) x Wpacked (+ bias); kload = loaded width (multiple of 4, <= ldx, zero beyond the logical K);
+// act_kind >= 0 with H != NULL additionally writes H = a(Y) on (value, Jacobian) row groups
+void launch_rows_gemm(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias, int bias_period,
+                      float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s);
 void launch_dw(const float *X, int ldx, int K, const float *G, int ldg, int nout, int64_t R, float *dW, int ldw, float *db,
-               int bias_period, hipStream_t s);
+               int bias_period, int cus, hipStream_t s);
+// heads (1..4 output columns, input width 256): column c of the weight gradient is w[c][k * wstride], b[c] its bias gradient
+void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t R, int nc, float *const *w, int wstride, float *const *b,
+                      int bias_period, hipStream_t s);
 void launch_act_rows(int kind, int period, const float *Z, float *H, int64_t n_groups, int ncols, int ld, hipStream_t s);
 void launch_act_rows_backward(int kind, int period, const float *Z, const float *dH, float *dZ, int64_t n_groups, int ncols, int ld,
                               hipStream_t s);

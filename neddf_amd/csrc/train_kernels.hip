@@ -18,87 +18,272 @@
 namespace neddf {
 
 // ----------------------------------------------------------------------------
-// Y[R, ldy] (+)= X[R, 0:kcols] x Wpacked (+ bias on rows r % bias_period == 0).
-// X columns beyond kcols up to 8*ksteps are treated as zero; K is consumed in
-// chunks of 256 columns through the LDS tile.
-template <int NT>
-__global__ __launch_bounds__(kThreads, 1) void rows_gemm_kernel(const float *X, int64_t R, int ldx, int kcols, const float *wp,
-                                                                int ksteps, int ncols_valid, const float *bias, int bias_period,
-                                                                float *Y, int ldy, int accumulate)
+// Y[R, 256] (+)= X[R, 0:kload) x Wpacked (+ bias on rows r % bias_period == 0), optionally followed by the activation on
+// (value, Jacobian) row groups: H = a(Y) (LinearGradFunction.forward + the activation's forward in one pass).
+// 64-row tiles, two workgroups per CU (one's loads / stores overlap the other's MFMAs).  The next tile's rows are
+// requested (global -> VGPR) before the MFMAs of the current tile issue; results go back through the LDS tile so that
+// every global access of the epilogue is a full 16-byte-per-lane row segment, and the activation sees the four rows
+// of a point in one thread.
+template <bool ACT>
+__global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps,
+                                                                const float *bias, int bias_period, float *Y, int ldy, int accumulate,
+                                                                int act_kind, float *H)
 {
-    constexpr int MT = 4, ROWS = MT * 32;
+    constexpr int MT = 2, NT = 2, ROWS = MT * 32, NPF = ROWS * (kWidth / 4) / kThreads;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *act = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *act_lane = act + (lane & 31) * kActLd + 4 * (lane >> 5);
+    const float *act_lane = act_lane_ptr<OpsF32>(act, lane);
+    const f32x4v *wl = (const f32x4v *)wp + (size_t)wave * NT * ksteps * 64 + lane;
     const int64_t ntiles = (R + ROWS - 1) / ROWS;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int c4n = kload >> 2, total = ROWS * c4n, kpack = 8 * ksteps;
+    f32x4v pf[NPF];
+    auto fetch = [&](int64_t tile) {
         const int64_t r0 = tile * ROWS;
-        f32x16 acc[MT][NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[mt][t][q] = 0.f;
-        for (int S0 = 0; S0 < ksteps; S0 += 32) {
-            const int nS = ksteps - S0 < 32 ? ksteps - S0 : 32;
-            const int c0 = 8 * S0, nc = 8 * nS;
-            __syncthreads();
-            for (int i = tid; i < ROWS * nc; i += kThreads) {
-                int r = i / nc, c = i - r * nc;
-                float v = 0.f;
-                if (r0 + r < R && c0 + c < kcols) v = X[(r0 + r) * ldx + c0 + c];
-                act[r * kActLd + c] = v;
+        for (int i = 0; i < NPF; ++i) {
+            int idx = tid + i * kThreads;
+            f32x4v v = { 0.f, 0.f, 0.f, 0.f };
+            if (idx < total) {
+                int r = idx / c4n, c = idx - r * c4n;
+                if (r0 + r < R) v = *(const f32x4v *)(X + (r0 + r) * ldx + 4 * c);
             }
-            __syncthreads();
-            const f32x4v *wl = (const f32x4v *)wp + ((size_t)wave * NT * ksteps + S0) * 64 + lane;
-            f32x4v a[MT], b[NT];
-            for (int S = 0; S < nS; ++S) {
+            pf[i] = v;
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * ROWS;
+        __syncthreads();                // the previous tile's epilogue is done with the LDS tile
 #pragma unroll
-                for (int t = 0; t < NT; ++t) b[t] = wl[((size_t)t * ksteps + S) * 64];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4v *)(act_lane + mt * 32 * kActLd + 8 * S);
-                dense_mfma<MT, NT>(acc, a, b);
+        for (int i = 0; i < NPF; ++i) {
+            int idx = tid + i * kThreads;
+            if (idx < total) {
+                int r = idx / c4n, c = idx - r * c4n;
+                *(f32x4v *)(act + r * kActLd + 4 * c) = pf[i];
             }
         }
+        for (int i = tid; i < ROWS * (kpack - kload); i += kThreads) {      // packed width beyond the loaded width
+            int w = kpack - kload, r = i / w, c = i - r * w;
+            act[r * kActLd + kload + c] = 0.f;
+        }
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[MT][NT];
+        if (bias_period == 4) acc_init<MT, NT, true>(acc, bias, wave, lane);
+        else acc_init<MT, NT, false>(acc, bias, wave, lane);
+        dense<MT, NT>(acc, act_lane, wl, ksteps);
+        __syncthreads();                // every wave finished reading the A operands
         const int j = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int col = (wave * NT + t) * 32 + j;
-                if (col >= ncols_valid) continue;
-                const float bv = bias ? bias[col] : 0.f;
+                float *o = act + (mt * 32 + 4 * h) * kActLd + (wave * NT + t) * 32 + j;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    int64_t row = r0 + mt * 32 + 8 * (q >> 2) + 4 * h + (q & 3);
-                    if (row < R) {
-                        float v = acc[mt][t][q];
-                        if (bias && (row % bias_period) == 0) v += bv;
-                        float *y = Y + row * ldy + col;
-                        *y = accumulate ? *y + v : v;
-                    }
+                for (int q = 0; q < 16; ++q) o[(8 * (q >> 2) + (q & 3)) * kActLd] = acc[mt][t][q];
+            }
+        __syncthreads();
+        // items: (4-row group, 4 columns); rows of a group are consecutive rows of the tile
+        for (int it = tid; it < (ROWS / 4) * (kWidth / 4); it += kThreads) {
+            const int grp = it >> 6, c4 = it & 63;
+            const int64_t row = r0 + 4 * grp;
+            if (row >= R) continue;
+            f32x4v z[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                z[r] = *(const f32x4v *)(act + (4 * grp + r) * kActLd + 4 * c4);
+                if (row + r < R) {
+                    float *yp = Y + (row + r) * ldy + 4 * c4;
+                    if (accumulate) z[r] += *(const f32x4v *)yp;
+                    *(f32x4v *)yp = z[r];
                 }
             }
+            if (ACT) {          // period-4 groups: row 0 value, rows 1..3 Jacobian
+                f32x4v y, dy;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float yy, dd;
+                    if (act_kind == 0) act_grad<0>(z[0][u], yy, dd); else if (act_kind == 1) act_grad<1>(z[0][u], yy, dd); else act_grad<2>(z[0][u], yy, dd);
+                    y[u] = yy; dy[u] = dd;
+                }
+                *(f32x4v *)(H + row * ldy + 4 * c4) = y;
+#pragma unroll
+                for (int r = 1; r < 4; ++r) *(f32x4v *)(H + (row + r) * ldy + 4 * c4) = dy * z[r];
+            }
+        }
     }
 }
 
-void launch_rows_gemm(const float *X, int64_t R, int ldx, int kcols, const float *wp, int ksteps, int nout, int ncols_valid,
-                      const float *bias, int bias_period, float *Y, int ldy, int accumulate, int cus, hipStream_t s)
+void launch_rows_gemm(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias, int bias_period,
+                      float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s)
 {
     if (R <= 0) return;
-    size_t lds = (size_t)(128 * kActLd) * sizeof(float);
-    static bool once = ((void)hipFuncSetAttribute((const void *)rows_gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * kActLd * sizeof(float))),
-                        (void)hipFuncSetAttribute((const void *)rows_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * kActLd * sizeof(float))), true);
+    const size_t lds = (size_t)(64 * kActLd) * sizeof(float);
+    static bool once = ((void)hipFuncSetAttribute((const void *)rows_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * kActLd * sizeof(float))),
+                        (void)hipFuncSetAttribute((const void *)rows_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * kActLd * sizeof(float))), true);
     (void)once;
-    int64_t tiles = (R + 127) / 128;
-    int grid = (int)(tiles < cus ? tiles : cus);
-    if (nout == 256) hipLaunchKernelGGL((rows_gemm_kernel<2>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kcols, wp, ksteps, ncols_valid, bias, bias_period, Y, ldy, accumulate);
-    else hipLaunchKernelGGL((rows_gemm_kernel<1>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kcols, wp, ksteps, ncols_valid, bias, bias_period, Y, ldy, accumulate);
+    int64_t tiles = (R + 63) / 64;
+    int grid = (int)(tiles < 2 * cus ? tiles : 2 * cus);
+    if (act_kind >= 0 && H)
+        hipLaunchKernelGGL((rows_gemm_kernel<true>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, bias_period, Y, ldy, accumulate, act_kind, H);
+    else
+        hipLaunchKernelGGL((rows_gemm_kernel<false>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, bias_period, Y, ldy, accumulate, -1, nullptr);
 }
 
 // ----------------------------------------------------------------------------
+// dW[K, 256] += X[R, 0:K]^T x G[R, 0:256], db[n] += sum over rows r % bias_period == 0 of G[r, n]
+// (LinearGradFunction.backward, linear.py:75-82: x^T dLdy + J^T dLdG is one product over the stacked value + Jacobian rows).
+// Each workgroup owns a contiguous range of rows and the WHOLE K x 256 output in accumulators (wave w: all K-tiles x output
+// columns [64w, 64w+64)), so X and G are read from HBM exactly once; 32-row chunks are staged through LDS with the next
+// chunk in flight (global -> VGPR) during the MFMAs.  The contraction index of v_mfma_f32_32x32x2_f32 is the row:
+// A[i = k][kk = row parity], B[kk][j = n]; LDS row strides are 32 mod 64 floats so the two row parities hit disjoint banks.
+template <int KT>
+__global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, int ldx, int K, const float *G, int ldg, int64_t R,
+                                                              int64_t rows_per_wg, float *dW, int ldw, float *db, int bias_period)
+{
+    constexpr int RC = 32, KP = 32 * KT, LDX = ((KP + 32) % 64 == 32) ? KP + 32 : KP + 64, LDG = kWidth + 32;
+    constexpr int XPF = (RC * (KP / 4) + kThreads - 1) / kThreads, GPF = RC * (kWidth / 4) / kThreads;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Xs = smem, *Gs = smem + RC * LDX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int n0 = wave * 64;
+    const int64_t rb = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t re = rb + rows_per_wg < R ? rb + rows_per_wg : R;
+    if (rb >= re) return;
+    const int k4 = (K + 3) >> 2;                 // float4 columns actually present (ldx >= 4 * k4)
+    f32x16 acc[KT][2];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[kt][t][q] = 0.f;
+    float bs0 = 0.f, bs1 = 0.f;
+    f32x4v xp[XPF], gp[GPF];
+    auto fetch = [&](int64_t c0) {
+#pragma unroll
+        for (int i = 0; i < XPF; ++i) {
+            int idx = tid + i * kThreads, r = idx / (KP / 4), c = idx - r * (KP / 4);
+            f32x4v v = { 0.f, 0.f, 0.f, 0.f };
+            if (r < RC && c < k4 && c0 + r < re) v = *(const f32x4v *)(X + (c0 + r) * ldx + 4 * c);
+            xp[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < GPF; ++i) {
+            int idx = tid + i * kThreads, r = idx >> 6, c = idx & 63;
+            f32x4v v = { 0.f, 0.f, 0.f, 0.f };
+            if (c0 + r < re) v = *(const f32x4v *)(G + (c0 + r) * ldg + 4 * c);
+            gp[i] = v;
+        }
+    };
+    fetch(rb);
+    for (int64_t c0 = rb; c0 < re; c0 += RC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < XPF; ++i) {
+            int idx = tid + i * kThreads, r = idx / (KP / 4), c = idx - r * (KP / 4);
+            if (r < RC) *(f32x4v *)(Xs + r * LDX + 4 * c) = xp[i];
+        }
+#pragma unroll
+        for (int i = 0; i < GPF; ++i) {
+            int idx = tid + i * kThreads;
+            *(f32x4v *)(Gs + (idx >> 6) * LDG + 4 * (idx & 63)) = gp[i];
+        }
+        __syncthreads();
+        if (c0 + RC < re) fetch(c0 + RC);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 4
+        for (int rp = 0; rp < RC / 2; ++rp) {
+            const int r = 2 * rp + h;
+            float b0 = Gs[r * LDG + n0 + j], b1 = Gs[r * LDG + n0 + 32 + j];
+            float a[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) a[kt] = Xs[r * LDX + 32 * kt + j];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                acc[kt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], b0, acc[kt][0], 0, 0, 0);
+                acc[kt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], b1, acc[kt][1], 0, 0, 0);
+            }
+            if (db && ((c0 + r) % bias_period) == 0) { bs0 += b0; bs1 += b1; }      // rows past `re` are zero in LDS
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int k = 32 * kt + 8 * (q >> 2) + 4 * h + (q & 3);
+                if (k < K) atomicAdd(&dW[(size_t)k * ldw + n0 + 32 * t + j], acc[kt][t][q]);
+            }
+    if (db) {
+        bs0 += __shfl_xor(bs0, 32, 64);
+        bs1 += __shfl_xor(bs1, 32, 64);
+        if (h == 0) { atomicAdd(&db[n0 + j], bs0); atomicAdd(&db[n0 + 32 + j], bs1); }
+    }
+}
+
+template <int KT>
+static void launch_dw_tile(const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int ldw, float *db,
+                           int bias_period, int cus, hipStream_t s)
+{
+    constexpr int KP = 32 * KT, LDX = ((KP + 32) % 64 == 32) ? KP + 32 : KP + 64, LDG = kWidth + 32;
+    const size_t lds = (size_t)32 * (LDX + LDG) * sizeof(float);
+    static bool once = ((void)hipFuncSetAttribute((const void *)dw_tile_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32 * (LDX + LDG) * sizeof(float))), true);
+    (void)once;
+    int64_t chunks = (R + 31) / 32;
+    int grid = (int)(chunks < cus ? chunks : cus);
+    int64_t rows_per_wg = ((chunks + grid - 1) / grid) * 32;
+    hipLaunchKernelGGL((dw_tile_kernel<KT>), dim3(grid), dim3(kThreads), lds, s, X, ldx, K, G, ldg, R, rows_per_wg, dW, ldw, db, bias_period);
+}
+
+// Heads with 1..4 output columns: dW_c[k] += sum_r X[r, k] G[r, c], db_c += sum over value rows of G[r, c].
+// One thread per input feature k, rows strided over workgroups; X is streamed once, fully coalesced (HBM-bound).
+struct NarrowGrad {
+    int nc;
+    float *w[4];          // column c of the weight gradient: w[c][k * wstride]
+    int wstride;
+    float *b[4];          // scalar bias gradients (or NULL)
+};
+__global__ __launch_bounds__(kThreads) void narrow_dw_kernel(const float *X, int ldx, const float *G, int ldg, int64_t R, int64_t rows_per_wg,
+                                                             NarrowGrad o, int bias_period)
+{
+    const int k = threadIdx.x;
+    const int64_t rb = (int64_t)blockIdx.x * rows_per_wg, re = rb + rows_per_wg < R ? rb + rows_per_wg : R;
+    float acc[4] = { 0.f, 0.f, 0.f, 0.f }, bs[4] = { 0.f, 0.f, 0.f, 0.f };
+    for (int64_t r = rb; r < re; ++r) {
+        const float x = X[r * ldx + k];
+        const bool vr = (r % bias_period) == 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < o.nc) {
+                float g = G[r * ldg + c];
+                acc[c] = fmaf(x, g, acc[c]);
+                if (vr) bs[c] += g;
+            }
+    }
+    for (int c = 0; c < o.nc; ++c) {
+        atomicAdd(&o.w[c][(size_t)k * o.wstride], acc[c]);
+        if (k == 0 && o.b[c]) atomicAdd(o.b[c], bs[c]);
+    }
+}
+void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t R, int nc, float *const *w, int wstride, float *const *b,
+                      int bias_period, hipStream_t s)
+{
+    if (R <= 0) return;
+    NarrowGrad o{};
+    o.nc = nc; o.wstride = wstride;
+    for (int c = 0; c < nc; ++c) { o.w[c] = w[c]; o.b[c] = b ? b[c] : nullptr; }
+    int grid = (int)((R + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    int64_t rows_per_wg = (R + grid - 1) / grid;
+    hipLaunchKernelGGL(narrow_dw_kernel, dim3(grid), dim3(kThreads), 0, s, X, ldx, G, ldg, R, rows_per_wg, o, bias_period);
+}
+
+// narrow outputs (heads: 1..3 columns): one workgroup per (32-row slab of K, row split)
 // dW[K, ldw] += X[R, 0:K]^T x G[R, 0:nout]   (LinearGradFunction.backward, linear.py:75-82: x^T dLdy + J^T dLdG
 // is one product over the stacked value + Jacobian rows), and db[n] += sum over rows r % bias_period == 0 of G[r, n].
 // One workgroup per (32-row slab of K, row split); wave w owns 64 output columns.  MFMA operands: A[i = k][kk = row],
@@ -151,9 +336,15 @@ __global__ __launch_bounds__(kThreads) void dw_kernel(const float *X, int ldx, i
 }
 
 void launch_dw(const float *X, int ldx, int K, const float *G, int ldg, int nout, int64_t R, float *dW, int ldw, float *db,
-               int bias_period, hipStream_t s)
+               int bias_period, int cus, hipStream_t s)
 {
     if (R <= 0 || K <= 0) return;
+    if (nout == kWidth && K <= kWidth && (ldx & 3) == 0 && (ldg & 3) == 0 && ldx >= ((K + 3) & ~3)) {
+        if (K <= 64) launch_dw_tile<2>(X, ldx, K, G, ldg, R, dW, ldw, db, bias_period, cus, s);
+        else if (K <= 96) launch_dw_tile<3>(X, ldx, K, G, ldg, R, dW, ldw, db, bias_period, cus, s);
+        else launch_dw_tile<8>(X, ldx, K, G, ldg, R, dW, ldw, db, bias_period, cus, s);
+        return;
+    }
     int splits = (int)((R + 4095) / 4096);
     if (splits > 64) splits = 64;
     int64_t rps = ((R + splits - 1) / splits + 1) & ~(int64_t)1;     // even, so that row pairs never straddle a split
@@ -237,6 +428,9 @@ __global__ void pe_rows_kernel(const float *pos, const float *dir, const float *
     if (i >= N * (K3 + K3d)) return;
     int64_t n = i / (K3 + K3d);
     int q = (int)(i - n * (K3 + K3d));
+    if (q == 0)         // pad columns up to the leading dimension are read by the vectorised GEMM loads: keep them zero
+        for (int r = 0; r < 4; ++r)
+            for (int c = 2 * K3; c < ld; ++c) { PEs[(n * 4 + r) * ld + c] = 0.f; PEu[(n * 4 + r) * ld + c] = 0.f; }
     if (q < K3) {
         int e = q / 3, d = q - 3 * e;
         float vs, vc, js, jc, us, uc, ujs, ujc;
