@@ -24,9 +24,22 @@ __device__ __forceinline__ float tanh_nonneg(float u)
     return u < 0.3f ? poly : big;
 }
 
-template <int KIND>
+// Reduced-cost tanhExp for the bf16-operand kernels (results are rounded to 8 mantissa bits anyway): no small-argument
+// polynomial, no x > 20 branch (tanh saturates to exactly 1 there; the clamp keeps x e^x finite).  11 VALU instructions
+// instead of 23 -- in those kernels the matrix pipe and the VALU hardly overlap, so every instruction is wall time.
+__device__ __forceinline__ void tanhexp_grad_fast(float x, float &y, float &dy)
+{
+    float ex = fast_exp(fminf(x, 40.0f));
+    float e2 = __builtin_amdgcn_exp2f(ex * 2.8853900817779268f);
+    float tx = fmaf(-2.0f, __builtin_amdgcn_rcpf(e2 + 1.0f), 1.0f);
+    y = x * tx;
+    dy = fmaf(-(x * ex), fmaf(tx, tx, -1.0f), tx);
+}
+
+template <int KIND, bool FAST = false>
 __device__ __forceinline__ void act_grad(float x, float &y, float &dy)
 {
+    if (FAST && KIND == 2) { tanhexp_grad_fast(x, y, dy); return; }
     if (KIND == 0) {            // relu.py:36-38, mask = x >= 0
         float m = (x >= 0.f) ? 1.f : 0.f;
         y = x * m; dy = m;
@@ -44,9 +57,14 @@ __device__ __forceinline__ void act_grad(float x, float &y, float &dy)
     }
 }
 
-template <int KIND>
+template <int KIND, bool FAST = false>
 __device__ __forceinline__ float act_val(float x)
 {
+    if (FAST && KIND == 2) {
+        float ex = fast_exp(fminf(x, 40.0f));
+        float e2 = __builtin_amdgcn_exp2f(ex * 2.8853900817779268f);
+        return x * fmaf(-2.0f, __builtin_amdgcn_rcpf(e2 + 1.0f), 1.0f);
+    }
     if (KIND == 0) return x > 0.f ? x : 0.f;            // F.relu
     if (KIND == 1) return x > 0.f ? x : 0.01f * x;       // F.leaky_relu
     float t = x * tanh_nonneg(fast_exp(x));              // nn_module/tanh_exp.py:28-31
@@ -81,14 +99,23 @@ __device__ __forceinline__ void sigmoid_grad(float a, float &y, float &dy)
 // weight w = exp(-0.5 4^e var) (sampling.py:55-71), values s*sin / s*cos and the
 // non-zero Jacobian entries +-2^e s cos/sin (with_grad/positional_encoding.py:55-87).
 // GRADSCALE selects embed_pos_scaled: s = (1/(0.5*2^e)) * lowpass * w (neddf.py:193-204).
-template <bool GRADSCALE>
+// hardware sine / cosine (v_sin_f32 / v_cos_f32 take revolutions); |error| ~ 4e-5 at the largest arguments used here
+__device__ __forceinline__ void fast_sincos(float x, float &sn, float &cs)
+{
+    float r = x * 0.15915494309189535f;
+    sn = __builtin_amdgcn_sinf(r);
+    cs = __builtin_amdgcn_cosf(r);
+}
+
+template <bool GRADSCALE, bool FAST = false>
 __device__ __forceinline__ void pe_pair(int e, float x, float v, float lowpass, float &vs, float &vc, float &js, float &jc)
 {
     float f = (float)(1 << e);
-    float w = expf(-0.5f * (f * f) * v);
+    float w = FAST ? fast_exp(-0.5f * (f * f) * v) : expf(-0.5f * (f * f) * v);
     float s = GRADSCALE ? ((1.0f / (0.5f * f)) * lowpass) * w : lowpass * w;
     float sn, cs;
-    sincosf(f * x, &sn, &cs);
+    if (FAST) fast_sincos(f * x, sn, cs);
+    else sincosf(f * x, &sn, &cs);
     vs = s * sn;
     vc = s * cs;
     float g = f * s;

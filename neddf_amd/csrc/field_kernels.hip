@@ -47,7 +47,7 @@ __device__ __forceinline__ void encode_pos(typename Ops::act_t *act, int col0, c
         int e = q / 3, d = q - 3 * e;
         int64_t gp = p0 + p < N ? p0 + p : N - 1;
         float vs, vc, js, jc;
-        pe_pair<GRADSCALE>(e, pos[gp * 3 + d], use_var ? var[gp * 3 + d] : 0.0f, lp[e], vs, vc, js, jc);
+        pe_pair<GRADSCALE, Ops::kFast>(e, pos[gp * 3 + d], use_var ? var[gp * 3 + d] : 0.0f, lp[e], vs, vc, js, jc);
         constexpr int LD = Ops::kLd;
         if (ROWS4) {
             typename Ops::act_t *r0 = act + (4 * p) * LD + col0 + q;
@@ -74,7 +74,8 @@ __device__ __forceinline__ void encode_dir(typename Ops::act_t *act, int col0, c
         int e = q / 3, d = q - 3 * e;
         int64_t gp = p0 + p < N ? p0 + p : N - 1;
         float sn, cs;
-        sincosf((float)(1 << e) * dir[gp * 3 + d], &sn, &cs);
+        if (Ops::kFast) fast_sincos((float)(1 << e) * dir[gp * 3 + d], sn, cs);
+        else sincosf((float)(1 << e) * dir[gp * 3 + d], &sn, &cs);
         typename Ops::act_t *r0 = act + (ROWS4 ? 4 * p : p) * Ops::kLd + col0 + q;
         Ops::put(r0, sn);
         Ops::put(r0 + KD, cs);

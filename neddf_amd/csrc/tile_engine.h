@@ -27,6 +27,7 @@ struct OpsF32 {
     static constexpr int kLd = kActLd;       // LDS row stride in elements (260 floats: conflict-free ds_read_b128)
     static constexpr int kStep = 8;          // k values per super-step
     static constexpr int kSub = 4;           // MFMA instructions per fragment
+    static constexpr bool kFast = false;     // reference-exact elementwise math
     static __device__ __forceinline__ void put(act_t *p, float v) { *p = v; }
     static __device__ __forceinline__ float get(const act_t *p) { return *p; }
     static __device__ __forceinline__ void load4(const act_t *p, float (&x)[4])
@@ -46,6 +47,7 @@ struct OpsBF16 {
     static constexpr int kLd = 264;          // 528 B rows: same bank pattern as the fp32 tile (row stride = 4 dwords mod 64)
     static constexpr int kStep = 16;
     static constexpr int kSub = 1;
+    static constexpr bool kFast = true;      // reduced-cost elementwise math (device_math.h), invisible after bf16 rounding
     static __device__ __forceinline__ unsigned short cvt(float v)       // round to nearest even (v_cvt_pk_bf16_f32)
     {
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -232,14 +234,14 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[MT][NT], typename O
             for (int g = 0; g < 4; ++g) {
                 if (ROWS4) {
                     float y, dy;
-                    act_grad<KIND>(acc[mt][t][4 * g], y, dy);
+                    act_grad<KIND, Ops::kFast>(acc[mt][t][4 * g], y, dy);
                     Ops::put(o + (8 * g + 0) * LD, y);
                     Ops::put(o + (8 * g + 1) * LD, dy * acc[mt][t][4 * g + 1]);
                     Ops::put(o + (8 * g + 2) * LD, dy * acc[mt][t][4 * g + 2]);
                     Ops::put(o + (8 * g + 3) * LD, dy * acc[mt][t][4 * g + 3]);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Ops::put(o + (8 * g + r) * LD, act_val<KIND>(acc[mt][t][4 * g + r]));
+                    for (int r = 0; r < 4; ++r) Ops::put(o + (8 * g + r) * LD, act_val<KIND, Ops::kFast>(acc[mt][t][4 * g + r]));
                 }
             }
         }
