@@ -116,8 +116,9 @@ def test_bf16_field_against_bf16_emulation(dev, orc, bunny_weights, mode):
 
 def test_bf16_single_layer_tight(dev, orc):
     """One trunk layer and one colour layer: no room for rounding differences to cascade, so the kernel must match the
-    emulation closely: what differs is the hardware sine/cosine of the bf16 path (|err| ~ 4e-5 on the encodings, so
-    about 1 % of them round to the neighbouring bf16) and single activations rounding the other way."""
+    emulation closely: what differs is the reduced-cost elementwise math of the bf16 path (hardware sine/cosine with
+    |err| ~ 4e-5 on the encodings, tanhExp without the small-argument polynomial), which moves about 1 % of the values
+    to the neighbouring bf16, and single activations rounding the other way."""
     from neddf_amd import Sampling
     for act in ("ReLU", "tanhExp"):
         cfg = dict(embed_pos_rank=10, embed_dir_rank=4, ddf_layer_count=2, ddf_layer_width=256, col_layer_count=2,
@@ -134,7 +135,7 @@ def test_bf16_single_layer_tight(dev, orc):
             err = np.abs(N(o[k]) - emu[k]).max() / scale
             gap = np.abs(f32[k] - emu[k]).max() / scale
             print("%s %-9s kernel vs emulation %.2e (emulation vs fp32 %.2e)" % (act, k, err, gap))
-            assert err < (4e-3 if k == "density" else 1e-3), (act, k, err)
+            assert err < (4e-3 if k == "density" else 2e-3), (act, k, err)
             assert gap > 2 * err or gap < 1e-6, (act, k, err, gap)      # the test can tell bf16 from fp32
 
 
