@@ -229,7 +229,8 @@ int neddf_get_timings(neddf_ctx *ctx, float *ms, int n);
  * The reference trains through torch autograd over its with_grad modules
  * (the modules under neddf/nn_module/with_grad: each has a hand-written backward for the
  * (value, Jacobian) pair).  These entry points are that forward + backward for one NeDDF
- * network on N sample points.  The parameters are DEVICE fp32 arrays in the reference's
+ * network on N sample points.  NeRF fields (nerf.py:107-165; plain torch autograd in the reference) are
+ * supported through the same calls: only density and color are produced / consumed, nn.Linear layout.  The parameters are DEVICE fp32 arrays in the reference's
  * state-dict layout and order (see neddf_set_field); gradients are ACCUMULATED into d_gW / d_gB
  * (same shapes).  The slot supplies the architecture and the set_iter state; the weights it was
  * loaded with are not used here.  `d_workspace` (neddf_train_workspace_floats floats, caller-owned)

@@ -346,8 +346,9 @@ class Context:
                 raise NeddfError("%s must be contiguous float32 device tensors" % what)
         return (_fp * len(tensors))(*[C.cast(t.data_ptr(), _fp) for t in tensors])
 
-    def train_field_forward(self, slot, weights, biases, pos, dir, var):
-        """NeDDF.forward keeping the activations: returns (workspace, distance, density, color, penalty, aux_grad)."""
+    def train_field_forward(self, slot, weights, biases, pos, dir, var, radiance_only=False):
+        """Field forward keeping the activations: returns (workspace, distance, density, color, penalty, aux_grad);
+        radiance_only (NeRF fields): distance, penalty and aux_grad are None."""
         require_device(pos, "sample positions")
         pos, dir, var = f32c(pos).reshape(-1, 3), f32c(dir).reshape(-1, 3), f32c(var).reshape(-1, 3)
         N = pos.shape[0]
@@ -355,16 +356,18 @@ class Context:
         if n_ws < 0:
             raise NeddfError("libneddf_hip: %s" % self.lib.neddf_last_error(self.h).decode())
         dev = pos.device
-        ws = torch.empty(max(int(n_ws), 1), device=dev, dtype=torch.float32)
-        out = [torch.empty(N, device=dev, dtype=torch.float32) for _ in range(2)]
-        color = torch.empty(N, 3, device=dev, dtype=torch.float32)
-        pen = torch.empty(N, device=dev, dtype=torch.float32)
-        aux = torch.empty(N, device=dev, dtype=torch.float32)
+
+        def buf(*shape):
+            return torch.empty(*shape, device=dev, dtype=torch.float32)
+
+        ws = buf(max(int(n_ws), 1))
+        density, color = buf(N), buf(N, 3)
+        distance, pen, aux = (None, None, None) if radiance_only else (buf(N), buf(N), buf(N))
         wa, ba = self._dev_ptrs(weights, "weights"), self._dev_ptrs(biases, "biases")
         self.check(self.lib.neddf_train_field_forward(self.h, slot, wa, ba, len(weights), _ptr(pos), _ptr(dir), _ptr(var), N,
-                                                      _ptr(ws), _ptr(out[0]), _ptr(out[1]), _ptr(color), _ptr(pen), _ptr(aux),
+                                                      _ptr(ws), _ptr(distance), _ptr(density), _ptr(color), _ptr(pen), _ptr(aux),
                                                       self.stream()))
-        return ws, out[0], out[1], color, pen, aux
+        return ws, distance, density, color, pen, aux
 
     def train_field_backward(self, slot, weights, biases, N, ws, g_distance, g_density, g_color, g_penalty, g_aux):
         """Returns (grad_weights, grad_biases) in the layout of `weights` / `biases`."""

@@ -46,6 +46,34 @@ class FieldFunction(torch.autograd.Function):
         return (None,) * 7 + tuple(gw) + tuple(gb)
 
 
+class RadianceFieldFunction(torch.autograd.Function):
+    """NeRF.forward (nerf.py:107-165) on [N,3] samples -> density, color.  The reference differentiates this network
+    with plain torch autograd over nn.Linear; here forward and backward are the same HIP building blocks as NeDDF's
+    (value rows only), one autograd node for the whole field."""
+
+    @staticmethod
+    def forward(ctx, hip: Context, slot: int, iter_state, n_tensors: int, pos: Tensor, dir: Tensor, var: Tensor,
+                *params: Tensor) -> Tuple[Tensor, Tensor]:
+        weights = [p.detach() for p in params[:n_tensors]]
+        biases = [p.detach() for p in params[n_tensors:]]
+        hip.set_iter(slot, *iter_state)
+        ws, _, density, color, _, _ = hip.train_field_forward(slot, weights, biases, pos, dir, var, radiance_only=True)
+        ctx.hip, ctx.slot, ctx.iter_state, ctx.n_tensors, ctx.n_points = hip, slot, iter_state, n_tensors, density.shape[0]
+        ctx.save_for_backward(ws, *params)
+        return density, color
+
+    @staticmethod
+    def backward(ctx, g_density, g_color):
+        ws, *params = ctx.saved_tensors
+        n = ctx.n_tensors
+        weights = [p.detach() for p in params[:n]]
+        biases = [p.detach() for p in params[n:]]
+        ctx.hip.set_iter(ctx.slot, *ctx.iter_state)
+        with torch.cuda.device(ws.device):
+            gw, gb = ctx.hip.train_field_backward(ctx.slot, weights, biases, ctx.n_points, ws, None, g_density, g_color, None, None)
+        return (None,) * 7 + tuple(gw) + tuple(gb)
+
+
 class CompositeFunction(torch.autograd.Function):
     """integrate_volume_render (base_neural_render.py:117-172) -> weight, depth, color, transmittance."""
 

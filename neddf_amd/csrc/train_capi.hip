@@ -24,7 +24,7 @@ int make_plan(neddf_ctx *ctx, int slot, int64_t N, int n_tensors, Plan &p)
 {
     if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");
     const Field &f = ctx->field[slot];
-    if (f.d.kind != NEDDF_FIELD_NEDDF) return fail(ctx, NEDDF_EUNSUPPORTED, "the training step is implemented for NeDDF fields");
+    if (f.d.kind != NEDDF_FIELD_NEDDF) return fail(ctx, NEDDF_EUNSUPPORTED, "the training step is implemented for NeDDF and NeRF fields");
     p.E = f.d.embed_pos_rank; p.Ed = f.d.embed_dir_rank;
     p.Cpe = 6 * p.E; p.Cdir = 6 * p.Ed; p.Ca = p.Cpe + p.Cdir + 3; p.ldxa = roundup(p.Ca, 8);
     p.n_trunk = f.d.layer_count - 1; p.n_col = f.d.col_layer_count - 1;
@@ -59,6 +59,145 @@ void point_args(TrainPointArgs &a, const Field &f, const Plan &p, float *ws)
 
 constexpr size_t kPackFloats = (size_t)kWidth * kWidth;        // one packed 256 x 256 segment
 
+// ---- plain NeRF field (nerf.py:107-165): value rows only, nn.Linear weights [out, in] -------------------------------
+struct NerfPlan {
+    int E, Ed, Cpe, Cdir, n, i_dens, i_c0, i_c1, in_c0;
+    int64_t N;
+    size_t o_pe, o_ed, o_zd, o_zc, o_hc, o_z[kMaxLayers], o_h[kMaxLayers], total;
+};
+
+int make_nerf_plan(neddf_ctx *ctx, int slot, int64_t N, int n_tensors, NerfPlan &p)
+{
+    const Field &f = ctx->field[slot];
+    p.E = f.d.embed_pos_rank; p.Ed = f.d.embed_dir_rank;
+    p.Cpe = 6 * p.E; p.Cdir = 6 * p.Ed; p.n = f.d.layer_count;
+    p.i_dens = p.n; p.i_c0 = p.n + 1; p.i_c1 = p.n + 2; p.in_c0 = kWidth + p.Cdir;
+    if (n_tensors >= 0 && n_tensors != p.n + 3) return fail(ctx, NEDDF_EINVAL, "NeRF: wrong tensor count");
+    p.N = N;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += (n + 63) & ~(size_t)63; return at; };
+    p.o_pe = take((size_t)N * kLdPe);
+    p.o_ed = take((size_t)N * kLdDir);
+    p.o_zd = take((size_t)N * kLdNarrow);
+    p.o_zc = take((size_t)N * kWidth);
+    p.o_hc = take((size_t)N * kWidth);
+    for (int l = 0; l < p.n; ++l) { p.o_z[l] = take((size_t)N * kWidth); p.o_h[l] = take((size_t)N * kWidth); }
+    p.total = o;
+    return 0;
+}
+
+int nerf_forward(neddf_ctx *ctx, int slot, const float *const *W, const float *const *B, int n_tensors, const float *pos, const float *dir,
+                 const float *var, int64_t N, float *ws, float *density, float *color, hipStream_t s)
+{
+    NerfPlan p;
+    if (int rc = make_nerf_plan(ctx, slot, N, n_tensors, p)) return rc;
+    const Field &f = ctx->field[slot];
+    const int act = f.d.activation, cus = ctx->cus;
+    if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->ttmp, ((size_t)N * kLdNarrow + kWidth) * sizeof(float))) return rc;
+    float *wp = (float *)ctx->tpack.p, *wp2 = wp + kPackFloats;
+    float *CR = (float *)ctx->ttmp.p, *bias_c0 = CR + (size_t)N * kLdNarrow;
+    float *PE = ws + p.o_pe, *Ed = ws + p.o_ed;
+    EncodeDesc enc;
+    fill_enc(enc, f);
+    launch_pe_values(pos, dir, var, N, enc, PE, kLdPe, Ed, kLdDir, s);
+    const int kpe = (p.Cpe + 3) & ~3, kdir = (p.Cdir + 3) & ~3;
+    for (int l = 0; l < p.n; ++l) {             // nerf.py:151-155
+        float *Z = ws + p.o_z[l], *H = ws + p.o_h[l];
+        const bool wide = l > 0 && in_skips(f.d, l - 1);
+        const int in_total = l == 0 ? p.Cpe : (wide ? kWidth + p.Cpe : kWidth);
+        if (l == 0) {
+            launch_pack(W[0], 1, in_total, 0, 0, p.Cpe, kWidth, kWidth, wp, s);
+            launch_rows_gemm(PE, N, kLdPe, kpe, wp, (p.Cpe + 7) / 8, B[0], 1, Z, kWidth, 0, act, H, cus, s);
+        } else if (!wide) {
+            launch_pack(W[l], 1, in_total, 0, 0, kWidth, kWidth, kWidth, wp, s);
+            launch_rows_gemm(ws + p.o_h[l - 1], N, kWidth, kWidth, wp, 32, B[l], 1, Z, kWidth, 0, act, H, cus, s);
+        } else {        // cat([hx, embed_pos]): the hidden state feeds input columns 0..255, the encoding 256..
+            launch_pack(W[l], 1, in_total, 0, 0, kWidth, kWidth, kWidth, wp, s);
+            launch_rows_gemm(ws + p.o_h[l - 1], N, kWidth, kWidth, wp, 32, B[l], 1, Z, kWidth, 0, -1, nullptr, cus, s);
+            launch_pack(W[l], 1, in_total, kWidth, 0, p.Cpe, kWidth, kWidth, wp2, s);
+            launch_rows_gemm(PE, N, kLdPe, kpe, wp2, (p.Cpe + 7) / 8, nullptr, 1, Z, kWidth, 1, act, H, cus, s);
+        }
+    }
+    const float *Hlast = ws + p.o_h[p.n - 1];
+    NarrowW dens{};
+    dens.nc = 1; dens.wstride = 1; dens.kcount = kWidth;
+    dens.w[0] = W[p.i_dens]; dens.b[0] = B[p.i_dens];
+    launch_narrow_forward(Hlast, kWidth, N, dens, 1, ws + p.o_zd, kLdNarrow, s);
+    if (density) launch_density_head(f.d.density_activation, ws + p.o_zd, kLdNarrow, N, nullptr, density, 1, s);
+    // colour head: Linear(256 + dir, 128) -> ReLU -> Linear(128, 3); the 128 outputs are computed as 256 with zero weights
+    HIPCHK(hipMemsetAsync(bias_c0, 0, kWidth * sizeof(float), s));
+    HIPCHK(hipMemcpyAsync(bias_c0, B[p.i_c0], (kWidth / 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
+    launch_pack(W[p.i_c0], 1, p.in_c0, 0, 0, kWidth, kWidth / 2, kWidth, wp, s);
+    launch_rows_gemm(Hlast, N, kWidth, kWidth, wp, 32, bias_c0, 1, ws + p.o_zc, kWidth, 0, -1, nullptr, cus, s);
+    launch_pack(W[p.i_c0], 1, p.in_c0, kWidth, 0, p.Cdir, kWidth / 2, kWidth, wp2, s);
+    launch_rows_gemm(Ed, N, kLdDir, kdir, wp2, (p.Cdir + 7) / 8, nullptr, 1, ws + p.o_zc, kWidth, 1, NEDDF_ACT_RELU, ws + p.o_hc, cus, s);
+    NarrowW c1{};
+    c1.nc = 3; c1.wstride = 1; c1.kcount = kWidth / 2;
+    for (int c = 0; c < 3; ++c) { c1.w[c] = W[p.i_c1] + c * (kWidth / 2); c1.b[c] = B[p.i_c1] + c; }
+    launch_narrow_forward(ws + p.o_hc, kWidth, N, c1, 1, CR, kLdNarrow, s);
+    if (color) launch_copy3(CR, kLdNarrow, color, 3, N, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int nerf_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors, int64_t N, float *ws, const float *g_density,
+                  const float *g_color, float *const *gW, float *const *gB, hipStream_t s)
+{
+    NerfPlan p;
+    if (int rc = make_nerf_plan(ctx, slot, N, n_tensors, p)) return rc;
+    const Field &f = ctx->field[slot];
+    const int act = f.d.activation, cus = ctx->cus, half = kWidth / 2;
+    if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->ttmp, (size_t)N * (2 * kWidth + 2 * kLdNarrow) * sizeof(float))) return rc;
+    float *wp = (float *)ctx->tpack.p;
+    float *dA = (float *)ctx->ttmp.p, *dB = dA + (size_t)N * kWidth, *GC = dB + (size_t)N * kWidth, *GD = GC + (size_t)N * kLdNarrow;
+    const float *PE = ws + p.o_pe, *Ed = ws + p.o_ed, *Hlast = ws + p.o_h[p.n - 1];
+    HIPCHK(hipMemsetAsync(GC, 0, (size_t)N * 2 * kLdNarrow * sizeof(float), s));      // GC and GD
+    if (g_color) launch_copy3(g_color, 3, GC, kLdNarrow, N, s);
+    // colour head, second layer
+    NarrowW c1{};
+    c1.nc = 3; c1.wstride = 1; c1.kcount = half;
+    for (int c = 0; c < 3; ++c) c1.w[c] = W[p.i_c1] + c * half;
+    launch_narrow_backward(GC, kLdNarrow, N, c1, dA, kWidth, 0, s);
+    {
+        float *wc[3] = { gW[p.i_c1], gW[p.i_c1] + half, gW[p.i_c1] + 2 * half }, *bc[3] = { gB[p.i_c1], gB[p.i_c1] + 1, gB[p.i_c1] + 2 };
+        launch_narrow_dw(ws + p.o_hc, kWidth, GC, kLdNarrow, N, 3, wc, 1, bc, 1, half, s);
+    }
+    // ReLU, first layer (weights [128, 256 + dir])
+    launch_act_rows_backward(NEDDF_ACT_RELU, 1, ws + p.o_zc, dA, dB, N, kWidth, kWidth, s);
+    launch_dw(Hlast, kWidth, kWidth, dB, kWidth, N, gW[p.i_c0], 1, p.in_c0, half, gB[p.i_c0], 1, cus, s);
+    launch_dw(Ed, kLdDir, p.Cdir, dB, kWidth, N, gW[p.i_c0] + kWidth, 1, p.in_c0, half, nullptr, 1, cus, s);
+    launch_pack(W[p.i_c0], p.in_c0, 1, 0, 0, half, kWidth, kWidth, wp, s);                // rows = the 128 outputs, columns = hidden inputs
+    launch_rows_gemm(dB, N, kWidth, half, wp, half / 8, nullptr, 1, dA, kWidth, 0, -1, nullptr, cus, s);
+    // density head
+    if (g_density) launch_density_head(f.d.density_activation, ws + p.o_zd, kLdNarrow, N, g_density, GD, kLdNarrow, s);
+    NarrowW dens{};
+    dens.nc = 1; dens.wstride = 1; dens.kcount = kWidth;
+    dens.w[0] = W[p.i_dens];
+    launch_narrow_backward(GD, kLdNarrow, N, dens, dA, kWidth, 1, s);
+    {
+        float *wd[1] = { gW[p.i_dens] }, *bd[1] = { gB[p.i_dens] };
+        launch_narrow_dw(Hlast, kWidth, GD, kLdNarrow, N, 1, wd, 1, bd, 1, kWidth, s);
+    }
+    // trunk
+    for (int l = p.n - 1; l >= 0; --l) {
+        const bool wide = l > 0 && in_skips(f.d, l - 1);
+        const int in_total = l == 0 ? p.Cpe : (wide ? kWidth + p.Cpe : kWidth);
+        launch_act_rows_backward(act, 1, ws + p.o_z[l], dA, dB, N, kWidth, kWidth, s);
+        if (l == 0) {
+            launch_dw(PE, kLdPe, p.Cpe, dB, kWidth, N, gW[0], 1, in_total, kWidth, gB[0], 1, cus, s);
+            break;
+        }
+        launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dB, kWidth, N, gW[l], 1, in_total, kWidth, gB[l], 1, cus, s);
+        if (wide) launch_dw(PE, kLdPe, p.Cpe, dB, kWidth, N, gW[l] + kWidth, 1, in_total, kWidth, nullptr, 1, cus, s);
+        launch_pack(W[l], in_total, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
+        launch_rows_gemm(dB, N, kWidth, kWidth, wp, 32, nullptr, 1, dA, kWidth, 0, -1, nullptr, cus, s);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -66,6 +205,11 @@ extern "C" {
 int64_t neddf_train_workspace_floats(neddf_ctx *ctx, int slot, int64_t n_points)
 {
     if (!ctx || n_points < 0) return -1;
+    if (slot >= 0 && slot < NEDDF_NUM_SLOTS && ctx->field[slot].valid && ctx->field[slot].d.kind == NEDDF_FIELD_NERF) {
+        NerfPlan np;
+        if (make_nerf_plan(ctx, slot, n_points, -1, np)) return -1;
+        return (int64_t)np.total;
+    }
     Plan p;
     if (make_plan(ctx, slot, n_points, -1, p)) return -1;
     return (int64_t)p.total;
@@ -80,6 +224,8 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     if (!W || !B || !pos || !dir || !var || !ws) return fail(ctx, NEDDF_EINVAL, "null argument");
     (void)hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
+    if (slot >= 0 && slot < NEDDF_NUM_SLOTS && ctx->field[slot].valid && ctx->field[slot].d.kind == NEDDF_FIELD_NERF)
+        return nerf_forward(ctx, slot, W, B, n_tensors, pos, dir, var, N, ws, density, color, s);
     Plan p;
     if (int rc = make_plan(ctx, slot, N, n_tensors, p)) return rc;
     const Field &f = ctx->field[slot];
@@ -112,7 +258,7 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     }
     const float *Hlast = ws + p.o_h[p.n_trunk - 1];
     NarrowW heads{};
-    heads.nc = 2; heads.wstride = 1;
+    heads.nc = 2; heads.wstride = 1; heads.kcount = kWidth;
     heads.w[0] = W[p.i_ddf]; heads.w[1] = W[p.i_aux];
     heads.b[0] = B[p.i_ddf]; heads.b[1] = B[p.i_aux];
     launch_narrow_forward(Hlast, kWidth, p.R, heads, 4, ZH, kLdNarrow, s);
@@ -134,7 +280,7 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
         }
     }
     NarrowW cout{};
-    cout.nc = 3; cout.wstride = 3;
+    cout.nc = 3; cout.wstride = 3; cout.kcount = kWidth;
     for (int c = 0; c < 3; ++c) { cout.w[c] = W[p.i_cout] + c; cout.b[c] = B[p.i_cout] + c; }
     launch_narrow_forward(ws + p.o_hc[p.n_col - 1], kWidth, p.R, cout, 4, ws + p.o_cr, kLdNarrow, s);
     a.color = color; a.penalty = penalty;
@@ -152,11 +298,13 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     if (!W || !B || !ws_ || !gW || !gB) return fail(ctx, NEDDF_EINVAL, "null argument");
     (void)hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
+    float *ws = const_cast<float *>(ws_);
+    if (slot >= 0 && slot < NEDDF_NUM_SLOTS && ctx->field[slot].valid && ctx->field[slot].d.kind == NEDDF_FIELD_NERF)
+        return nerf_backward(ctx, slot, W, n_tensors, N, ws, g_density, g_color, gW, gB, s);
     Plan p;
     if (int rc = make_plan(ctx, slot, N, n_tensors, p)) return rc;
     const Field &f = ctx->field[slot];
     const int act = f.d.activation;
-    float *ws = const_cast<float *>(ws_);
     if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ttmp, (size_t)p.R * (2 * kWidth + 2 * kLdNarrow) * sizeof(float))) return rc;
     float *wp = (float *)ctx->tpack.p;
@@ -169,13 +317,13 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     launch_point_backward(a, s);
     // colour head: LinearGradFunction.backward (linear.py:62-88) on [HC | JC] rows
     NarrowW cout{};
-    cout.nc = 3; cout.wstride = 3;
+    cout.nc = 3; cout.wstride = 3; cout.kcount = kWidth;
     for (int c = 0; c < 3; ++c) cout.w[c] = W[p.i_cout] + c;
     const float *HClast = ws + p.o_hc[p.n_col - 1];
     launch_narrow_backward(GCR, kLdNarrow, p.R, cout, dA, kWidth, 0, s);
     {
         float *wc[3] = { gW[p.i_cout], gW[p.i_cout] + 1, gW[p.i_cout] + 2 }, *bc[3] = { gB[p.i_cout], gB[p.i_cout] + 1, gB[p.i_cout] + 2 };
-        launch_narrow_dw(HClast, kWidth, GCR, kLdNarrow, p.R, 3, wc, 3, bc, 4, s);
+        launch_narrow_dw(HClast, kWidth, GCR, kLdNarrow, p.R, 3, wc, 3, bc, 4, kWidth, s);
     }
     const float *Hlast = ws + p.o_h[p.n_trunk - 1];
     for (int l = p.n_col - 1; l >= 0; --l) {
@@ -183,11 +331,11 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         float *gWl = gW[p.n_trunk + l], *gBl = gB[p.n_trunk + l];
         launch_act_rows_backward(act, 4, ws + p.o_zc[l], dA, dB, N, kWidth, kWidth, s);
         if (l > 0) {
-            launch_dw(ws + p.o_hc[l - 1], kWidth, kWidth, dB, kWidth, kWidth, p.R, gWl, kWidth, gBl, 4, ctx->cus, s);
+            launch_dw(ws + p.o_hc[l - 1], kWidth, kWidth, dB, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s);
             launch_pack(Wl, 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wp, s);                 // W^T
         } else {
-            launch_dw(ws + p.o_xa, p.ldxa, p.Ca, dB, kWidth, kWidth, p.R, gWl, kWidth, gBl, 4, ctx->cus, s);
-            launch_dw(Hlast, kWidth, kWidth, dB, kWidth, kWidth, p.R, gWl + (size_t)p.Ca * kWidth, kWidth, nullptr, 4, ctx->cus, s);
+            launch_dw(ws + p.o_xa, p.ldxa, p.Ca, dB, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s);
+            launch_dw(Hlast, kWidth, kWidth, dB, kWidth, p.R, gWl + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s);
             launch_pack(Wl, 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wp, s);              // (feature rows of W)^T
         }
         // the small colour inputs (encodings, detached normal) carry no parameters: only the feature segment propagates
@@ -195,26 +343,26 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     }
     // distance / aux heads
     NarrowW heads{};
-    heads.nc = 2; heads.wstride = 1;
+    heads.nc = 2; heads.wstride = 1; heads.kcount = kWidth;
     heads.w[0] = W[p.i_ddf]; heads.w[1] = W[p.i_aux];
     launch_narrow_backward(GZH, kLdNarrow, p.R, heads, dA, kWidth, 1, s);
     {
         float *wh[2] = { gW[p.i_ddf], gW[p.i_aux] }, *bh[2] = { gB[p.i_ddf], gB[p.i_aux] };
-        launch_narrow_dw(Hlast, kWidth, GZH, kLdNarrow, p.R, 2, wh, 1, bh, 4, s);
+        launch_narrow_dw(Hlast, kWidth, GZH, kLdNarrow, p.R, 2, wh, 1, bh, 4, kWidth, s);
     }
     // distance trunk
     for (int l = p.n_trunk - 1; l >= 0; --l) {
         const bool wide = l > 0 && in_skips(f.d, l - 1);
         launch_act_rows_backward(act, 4, ws + p.o_z[l], dA, dB, N, kWidth, kWidth, s);
         if (l == 0) {
-            launch_dw(PEs, kLdPe, p.Cpe, dB, kWidth, kWidth, p.R, gW[0], kWidth, gB[0], 4, ctx->cus, s);
+            launch_dw(PEs, kLdPe, p.Cpe, dB, kWidth, p.R, gW[0], kWidth, 1, kWidth, gB[0], 4, ctx->cus, s);
             break;
         }
         if (wide) {
-            launch_dw(PEs, kLdPe, p.Cpe, dB, kWidth, kWidth, p.R, gW[l], kWidth, gB[l], 4, ctx->cus, s);
-            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dB, kWidth, kWidth, p.R, gW[l] + (size_t)p.Cpe * kWidth, kWidth, nullptr, 4, ctx->cus, s);
+            launch_dw(PEs, kLdPe, p.Cpe, dB, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s);
+            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dB, kWidth, p.R, gW[l] + (size_t)p.Cpe * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s);
         } else {
-            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dB, kWidth, kWidth, p.R, gW[l], kWidth, gB[l], 4, ctx->cus, s);
+            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dB, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s);
         }
         launch_pack(W[l], 1, kWidth, 0, wide ? p.Cpe : 0, kWidth, kWidth, kWidth, wp, s);
         launch_rows_gemm(dB, p.R, kWidth, kWidth, wp, 32, nullptr, 4, dA, kWidth, 0, -1, nullptr, ctx->cus, s);

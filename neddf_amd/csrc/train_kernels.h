@@ -43,11 +43,16 @@ void launch_pack(const float *src, int64_t sk, int64_t sn, int k_off, int n_off,
 // act_kind >= 0 with H != NULL additionally writes H = a(Y) on (value, Jacobian) row groups
 void launch_rows_gemm(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias, int bias_period,
                       float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s);
-void launch_dw(const float *X, int ldx, int K, const float *G, int ldg, int nout, int64_t R, float *dW, int ldw, float *db,
+// dW[k * sk + n * sn] += sum_r X[r, k] G[r, n], k < K <= 256, n < nvalid <= 256; db[n] += sum over rows r % bias_period == 0 of G[r, n]
+void launch_dw(const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
                int bias_period, int cus, hipStream_t s);
 // heads (1..4 output columns, input width 256): column c of the weight gradient is w[c][k * wstride], b[c] its bias gradient
 void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t R, int nc, float *const *w, int wstride, float *const *b,
-                      int bias_period, hipStream_t s);
+                      int bias_period, int kcount, hipStream_t s);
+void launch_pe_values(const float *pos, const float *dir, const float *var, int64_t N, const EncodeDesc &enc, float *PE, int ld, float *Ed, int ldd,
+                      hipStream_t s);
+void launch_density_head(int kind, const float *z, int ldz, int64_t N, const float *g, float *out, int ldo, hipStream_t s);
+void launch_copy3(const float *in, int ldi, float *out, int ldo, int64_t N, hipStream_t s);
 void launch_act_rows(int kind, int period, const float *Z, float *H, int64_t n_groups, int ncols, int ld, hipStream_t s);
 void launch_act_rows_backward(int kind, int period, const float *Z, const float *dH, float *dZ, int64_t n_groups, int ncols, int ld,
                               hipStream_t s);
@@ -59,6 +64,7 @@ struct NarrowW {
     const float *w[4];
     int wstride;
     const float *b[4];        // device pointers to the scalar biases (or NULL)
+    int kcount;               // input features present (<= 256; columns beyond are not read)
 };
 void launch_narrow_forward(const float *X, int ldx, int64_t R, const NarrowW &w, int bias_period, float *Y, int ldy, hipStream_t s);
 // dX[R, ldx] (+)= sum_c G[r, c] * w_c[k]
@@ -67,7 +73,6 @@ void launch_narrow_backward(const float *G, int ldg, int64_t R, const NarrowW &w
 void launch_point_forward(const TrainPointArgs &a, hipStream_t s);
 void launch_penalty_forward(const TrainPointArgs &a, hipStream_t s);
 void launch_point_backward(const TrainPointArgs &a, hipStream_t s);
-void launch_copy_cols(const float *src, int lds_, int c0, float *dst, int ldd, int d0, int64_t R, int ncols, int accumulate, hipStream_t s);
 void launch_composite_backward(const float *dists, const float *dens, const float *col, int64_t n, int S, float max_dist,
                                const float *g_weight, const float *g_depth, const float *g_color, const float *g_trans, float *g_dens,
                                float *g_col, hipStream_t s);

@@ -101,7 +101,16 @@ __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, 
                     *(f32x4v *)yp = z[r];
                 }
             }
-            if (ACT) {          // period-4 groups: row 0 value, rows 1..3 Jacobian
+            if (ACT && bias_period != 4) {          // plain rows (NeRF): H = a(Y) elementwise
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (row + r >= R) break;
+                    f32x4v y;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) y[u] = act_val_rt(act_kind, z[r][u]);
+                    *(f32x4v *)(H + (row + r) * ldy + 4 * c4) = y;
+                }
+            } else if (ACT) {   // period-4 groups: row 0 value, rows 1..3 Jacobian
                 f32x4v y, dy;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -142,7 +151,8 @@ void launch_rows_gemm(const float *X, int64_t R, int ldx, int kload, const float
 // A[i = k][kk = row parity], B[kk][j = n]; LDS row strides are 32 mod 64 floats so the two row parities hit disjoint banks.
 template <int KT>
 __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, int ldx, int K, const float *G, int ldg, int64_t R,
-                                                              int64_t rows_per_wg, float *dW, int ldw, float *db, int bias_period)
+                                                              int64_t rows_per_wg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
+                                                              int bias_period)
 {
     constexpr int RC = 32, KP = 32 * KT, LDX = ((KP + 32) % 64 == 32) ? KP + 32 : KP + 64, LDG = kWidth + 32;
     constexpr int XPF = (RC * (KP / 4) + kThreads - 1) / kThreads, GPF = RC * (kWidth / 4) / kThreads;
@@ -216,19 +226,22 @@ __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, in
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                int k = 32 * kt + 8 * (q >> 2) + 4 * h + (q & 3);
-                if (k < K) atomicAdd(&dW[(size_t)k * ldw + n0 + 32 * t + j], acc[kt][t][q]);
+                int k = 32 * kt + 8 * (q >> 2) + 4 * h + (q & 3), n = n0 + 32 * t + j;
+                if (k < K && n < nvalid) atomicAdd(&dW[k * sk + n * sn], acc[kt][t][q]);
             }
     if (db) {
         bs0 += __shfl_xor(bs0, 32, 64);
         bs1 += __shfl_xor(bs1, 32, 64);
-        if (h == 0) { atomicAdd(&db[n0 + j], bs0); atomicAdd(&db[n0 + 32 + j], bs1); }
+        if (h == 0) {
+            if (n0 + j < nvalid) atomicAdd(&db[n0 + j], bs0);
+            if (n0 + 32 + j < nvalid) atomicAdd(&db[n0 + 32 + j], bs1);
+        }
     }
 }
 
 template <int KT>
-static void launch_dw_tile(const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int ldw, float *db,
-                           int bias_period, int cus, hipStream_t s)
+static void launch_dw_tile(const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid,
+                           float *db, int bias_period, int cus, hipStream_t s)
 {
     constexpr int KP = 32 * KT, LDX = ((KP + 32) % 64 == 32) ? KP + 32 : KP + 64, LDG = kWidth + 32;
     const size_t lds = (size_t)32 * (LDX + LDG) * sizeof(float);
@@ -237,7 +250,7 @@ static void launch_dw_tile(const float *X, int ldx, int K, const float *G, int l
     int64_t chunks = (R + 31) / 32;
     int grid = (int)(chunks < cus ? chunks : cus);
     int64_t rows_per_wg = ((chunks + grid - 1) / grid) * 32;
-    hipLaunchKernelGGL((dw_tile_kernel<KT>), dim3(grid), dim3(kThreads), lds, s, X, ldx, K, G, ldg, R, rows_per_wg, dW, ldw, db, bias_period);
+    hipLaunchKernelGGL((dw_tile_kernel<KT>), dim3(grid), dim3(kThreads), lds, s, X, ldx, K, G, ldg, R, rows_per_wg, dW, sk, sn, nvalid, db, bias_period);
 }
 
 // Heads with 1..4 output columns: dW_c[k] += sum_r X[r, k] G[r, c], db_c += sum over value rows of G[r, c].
@@ -247,6 +260,7 @@ struct NarrowGrad {
     float *w[4];          // column c of the weight gradient: w[c][k * wstride]
     int wstride;
     float *b[4];          // scalar bias gradients (or NULL)
+    int kcount;           // input features present (<= 256)
 };
 __global__ __launch_bounds__(kThreads) void narrow_dw_kernel(const float *X, int ldx, const float *G, int ldg, int64_t R, int64_t rows_per_wg,
                                                              NarrowGrad o, int bias_period)
@@ -266,16 +280,16 @@ __global__ __launch_bounds__(kThreads) void narrow_dw_kernel(const float *X, int
             }
     }
     for (int c = 0; c < o.nc; ++c) {
-        atomicAdd(&o.w[c][(size_t)k * o.wstride], acc[c]);
+        if (k < o.kcount) atomicAdd(&o.w[c][(size_t)k * o.wstride], acc[c]);
         if (k == 0 && o.b[c]) atomicAdd(o.b[c], bs[c]);
     }
 }
 void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t R, int nc, float *const *w, int wstride, float *const *b,
-                      int bias_period, hipStream_t s)
+                      int bias_period, int kcount, hipStream_t s)
 {
     if (R <= 0) return;
     NarrowGrad o{};
-    o.nc = nc; o.wstride = wstride;
+    o.nc = nc; o.wstride = wstride; o.kcount = kcount;
     for (int c = 0; c < nc; ++c) { o.w[c] = w[c]; o.b[c] = b ? b[c] : nullptr; }
     int grid = (int)((R + 255) / 256);
     if (grid > 4096) grid = 4096;
@@ -283,72 +297,15 @@ void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t 
     hipLaunchKernelGGL(narrow_dw_kernel, dim3(grid), dim3(kThreads), 0, s, X, ldx, G, ldg, R, rows_per_wg, o, bias_period);
 }
 
-// narrow outputs (heads: 1..3 columns): one workgroup per (32-row slab of K, row split)
-// dW[K, ldw] += X[R, 0:K]^T x G[R, 0:nout]   (LinearGradFunction.backward, linear.py:75-82: x^T dLdy + J^T dLdG
-// is one product over the stacked value + Jacobian rows), and db[n] += sum over rows r % bias_period == 0 of G[r, n].
-// One workgroup per (32-row slab of K, row split); wave w owns 64 output columns.  MFMA operands: A[i = k][kk = row],
-// B[kk = row][j = n], both read straight from the row-major matrices (lanes along a row: coalesced).
-__global__ __launch_bounds__(kThreads) void dw_kernel(const float *X, int ldx, int K, const float *G, int ldg, int nout, int64_t R,
-                                                      int64_t rows_per_split, float *dW, int ldw, float *db, int bias_period)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k0 = blockIdx.x * 32;
-    const int64_t rb = (int64_t)blockIdx.y * rows_per_split;
-    const int64_t re = rb + rows_per_split < R ? rb + rows_per_split : R;
-    const int i = lane & 31, h = lane >> 5;
-    const int n0 = wave * 64;
-    if (n0 >= nout) return;
-    f32x16 acc[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
-    const bool kin = k0 + i < K;
-    const bool c0in = n0 + i < nout, n1 = n0 + 32 + i < nout;
-    float bsum0 = 0.f, bsum1 = 0.f;
-    for (int64_t rr = rb; rr < re; rr += 2) {               // each MFMA contracts rows rr and rr + 1 (wave-uniform trip count)
-        const int64_t r = rr + h;
-        const bool rin = r < re;
-        float a = (rin && kin) ? X[r * ldx + k0 + i] : 0.f;
-        float b0 = (rin && c0in) ? G[r * ldg + n0 + i] : 0.f;
-        float b1 = (rin && n1) ? G[r * ldg + n0 + 32 + i] : 0.f;
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
-        if (db && blockIdx.x == 0 && rin && (r % bias_period) == 0) { bsum0 += b0; bsum1 += b1; }
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (!(t == 0 ? c0in : n1)) continue;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            int k = k0 + 8 * (q >> 2) + 4 * h + (q & 3);
-            if (k < K) atomicAdd(&dW[(size_t)k * ldw + n0 + 32 * t + i], acc[t][q]);
-        }
-    }
-    if (db && blockIdx.x == 0) {
-        bsum0 += __shfl_xor(bsum0, 32, 64);
-        bsum1 += __shfl_xor(bsum1, 32, 64);
-        if (h == 0) {
-            if (c0in) atomicAdd(&db[n0 + i], bsum0);
-            if (n1) atomicAdd(&db[n0 + 32 + i], bsum1);
-        }
-    }
-}
-
-void launch_dw(const float *X, int ldx, int K, const float *G, int ldg, int nout, int64_t R, float *dW, int ldw, float *db,
+// dW[k * sk + n * sn] += sum_r X[r, k] G[r, n] for k < K <= 256, n < nvalid <= 256 (G has 256 columns, the rest zero);
+// (sk, sn) = (256, 1) for LinearGradLayer weights [in, out], (1, in_total) for nn.Linear weights [out, in]
+void launch_dw(const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
                int bias_period, int cus, hipStream_t s)
 {
     if (R <= 0 || K <= 0) return;
-    if (nout == kWidth && K <= kWidth && (ldx & 3) == 0 && (ldg & 3) == 0 && ldx >= ((K + 3) & ~3)) {
-        if (K <= 64) launch_dw_tile<2>(X, ldx, K, G, ldg, R, dW, ldw, db, bias_period, cus, s);
-        else if (K <= 96) launch_dw_tile<3>(X, ldx, K, G, ldg, R, dW, ldw, db, bias_period, cus, s);
-        else launch_dw_tile<8>(X, ldx, K, G, ldg, R, dW, ldw, db, bias_period, cus, s);
-        return;
-    }
-    int splits = (int)((R + 4095) / 4096);
-    if (splits > 64) splits = 64;
-    int64_t rps = ((R + splits - 1) / splits + 1) & ~(int64_t)1;     // even, so that row pairs never straddle a split
-    hipLaunchKernelGGL(dw_kernel, dim3((K + 31) / 32, splits), dim3(kThreads), 0, s, X, ldx, K, G, ldg, nout, R, rps, dW, ldw, db, bias_period);
+    if (K <= 64) launch_dw_tile<2>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
+    else if (K <= 96) launch_dw_tile<3>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
+    else launch_dw_tile<8>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
 }
 
 // ----------------------------------------------------------------------------
@@ -398,8 +355,15 @@ __global__ void act_rows_backward_kernel(int kind, int period, const float *Z, c
     const float *g = dH + p * period * ld + c;
     float *o = dZ + p * period * ld + c;
     float dy, d2;
+    if (period == 1) {          // plain activations of NeRF (F.relu / F.leaky_relu / tanhExp, nerf.py:71-79): derivative at 0 is torch's
+        const float x = z[0];
+        if (kind == 0) dy = x > 0.f ? 1.f : 0.f;
+        else if (kind == 1) dy = x > 0.f ? 1.f : 0.01f;
+        else act_grad2<2>(x, dy, d2);
+        o[0] = g[0] * dy;
+        return;
+    }
     if (kind == 0) act_grad2<0>(z[0], dy, d2); else if (kind == 1) act_grad2<1>(z[0], dy, d2); else act_grad2<2>(z[0], dy, d2);
-    if (period == 1) { o[0] = g[0] * dy; return; }
     float s = 0.f;
     for (int r = 1; r < 4; ++r) { s += g[r * ld] * z[r * ld]; o[r * ld] = g[r * ld] * dy; }
     o[0] = g[0] * dy + s * d2;
@@ -643,21 +607,72 @@ void launch_point_backward(const TrainPointArgs &a, hipStream_t s)
 }
 
 // ----------------------------------------------------------------------------
-// small matrix utilities
-__global__ void copy_cols_kernel(const float *src, int lds_, int c0, float *dst, int ldd, int d0, int64_t R, int ncols, int accumulate)
+// NeRF field (nerf.py:139-165), value rows only: encodings as row matrices in the reference feature order with zero pad
+// columns, and the density head's activation forward / backward
+__global__ void pe_values_kernel(const float *pos, const float *dir, const float *var, int64_t N, EncodeDesc enc, float *PE, int ld, float *Ed,
+                                 int ldd)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R * ncols) return;
-    int64_t r = i / ncols;
-    int c = (int)(i - r * ncols);
-    float v = src[r * lds_ + c0 + c];
-    float *d = dst + r * ldd + d0 + c;
-    *d = accumulate ? *d + v : v;
+    const int K3 = 3 * enc.E, K3d = 3 * enc.Ed;
+    if (i >= N * (K3 + K3d)) return;
+    int64_t n = i / (K3 + K3d);
+    int q = (int)(i - n * (K3 + K3d));
+    if (q == 0) {
+        for (int c = 2 * K3; c < ld; ++c) PE[n * ld + c] = 0.f;
+        for (int c = 2 * K3d; c < ldd; ++c) Ed[n * ldd + c] = 0.f;
+    }
+    if (q < K3) {
+        int e = q / 3, d = q - 3 * e;
+        float vs, vc, js, jc;
+        pe_pair<false>(e, pos[n * 3 + d], var[n * 3 + d], enc.lowpass[e], vs, vc, js, jc);
+        PE[n * ld + q] = vs;
+        PE[n * ld + K3 + q] = vc;
+    } else {
+        q -= K3;
+        int e = q / 3, d = q - 3 * e;
+        float sn, cs;
+        sincosf((float)(1 << e) * dir[n * 3 + d], &sn, &cs);
+        Ed[n * ldd + q] = sn;
+        Ed[n * ldd + K3d + q] = cs;
+    }
 }
-void launch_copy_cols(const float *src, int lds_, int c0, float *dst, int ldd, int d0, int64_t R, int ncols, int accumulate, hipStream_t s)
+void launch_pe_values(const float *pos, const float *dir, const float *var, int64_t N, const EncodeDesc &enc, float *PE, int ld, float *Ed, int ldd,
+                      hipStream_t s)
 {
-    int64_t t = R * ncols;
-    if (t > 0) hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, src, lds_, c0, dst, ldd, d0, R, ncols, accumulate);
+    int64_t t = N * (3 * enc.E + 3 * enc.Ed);
+    if (t > 0) hipLaunchKernelGGL(pe_values_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, pos, dir, var, N, enc, PE, ld, Ed, ldd);
+}
+
+// density = density_activation(z) (forward, g == NULL) or g_z = g_density * density_activation'(z) (backward)
+__global__ void density_head_kernel(int kind, const float *z, int ldz, int64_t N, const float *g, float *out, int ldo)
+{
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float x = z[n * ldz];
+    if (!g) { out[n * ldo] = act_val_rt(kind, x); return; }
+    float dy, d2;
+    if (kind == 0) dy = x > 0.f ? 1.f : 0.f;
+    else if (kind == 1) dy = x > 0.f ? 1.f : 0.01f;
+    else act_grad2<2>(x, dy, d2);
+    out[n * ldo] = g[n] * dy;
+}
+void launch_density_head(int kind, const float *z, int ldz, int64_t N, const float *g, float *out, int ldo, hipStream_t s)
+{
+    if (N > 0) hipLaunchKernelGGL(density_head_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, kind, z, ldz, N, g, out, ldo);
+}
+
+// out[n, 0:3] = in[n, 0:3] with different leading dimensions (colour head output / upstream gradient staging)
+__global__ void copy3_kernel(const float *in, int ldi, float *out, int ldo, int64_t N)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * 3) return;
+    int64_t n = i / 3;
+    int c = (int)(i - 3 * n);
+    out[n * ldo + c] = in[n * ldi + c];
+}
+void launch_copy3(const float *in, int ldi, float *out, int ldo, int64_t N, hipStream_t s)
+{
+    if (N > 0) hipLaunchKernelGGL(copy3_kernel, dim3((unsigned)((N * 3 + 255) / 256)), dim3(256), 0, s, in, ldi, out, ldo, N);
 }
 
 // ----------------------------------------------------------------------------
@@ -693,7 +708,8 @@ __global__ __launch_bounds__(256) void narrow_forward_kernel(const float *X, int
     for (int c = 0; c < w.nc; ++c) {
         float s = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s = fmaf(x[q], w.w[c][(size_t)(4 * lane + q) * w.wstride], s);
+        for (int q = 0; q < 4; ++q)
+            if (4 * lane + q < w.kcount) s = fmaf(x[q], w.w[c][(size_t)(4 * lane + q) * w.wstride], s);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
         if (lane == 0) Y[r * ldy + c] = s + ((w.b[c] && (r % bias_period) == 0) ? w.b[c][0] : 0.f);
@@ -710,7 +726,8 @@ __global__ void narrow_backward_kernel(const float *G, int ldg, int64_t R, Narro
     int64_t r = i >> 8;
     int k = (int)(i & 255);
     float s = 0.f;
-    for (int c = 0; c < w.nc; ++c) s = fmaf(G[r * ldg + c], w.w[c][(size_t)k * w.wstride], s);
+    if (k < w.kcount)
+        for (int c = 0; c < w.nc; ++c) s = fmaf(G[r * ldg + c], w.w[c][(size_t)k * w.wstride], s);
     float *d = dX + r * ldx + k;
     *d = accumulate ? *d + s : s;
 }

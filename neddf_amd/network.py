@@ -6,6 +6,7 @@ checkpoints written by the reference load unchanged; `forward(sampling)` keeps
 the reference signature and dict keys but the computation is the fused HIP
 field kernels (csrc/field_kernels.hip) reached through the C ABI.
 """
+import itertools
 import math
 from abc import ABC, abstractmethod
 from typing import Dict, List, Optional
@@ -59,10 +60,14 @@ class LinearGradLayer(nn.Module):
         nn.init.xavier_normal_(self.weight)
 
 
+_module_ids = itertools.count(1)
+
+
 class BaseNeuralField(ABC, nn.Module):
     def __init__(self) -> None:
         super().__init__()
         self._slot = SLOT_GENERIC
+        self._uid = next(_module_ids)        # identity in upload signatures (id() values are recycled by the allocator)
         # operand type of the 256-wide dense layers (not a reference keyword): "fp32" = exact fp32 MFMA, the parity path;
         # "bf16" = bf16 weights and activations with fp32 accumulation (BASELINE.json configs[4]); NeDDF / NeuS only
         self.weight_dtype = "fp32"
@@ -106,15 +111,15 @@ class BaseNeuralField(ABC, nn.Module):
         """Pack + upload the parameters into `slot` if they changed since the last upload.  weights=False (training
         step: the kernels read the live parameter tensors) only makes sure the slot describes this architecture."""
         ws, bs = self._tensors()
-        sig = (id(self), slot, tuple((t.data_ptr(), t._version) for t in ws + bs), self.weight_dtype)
+        desc = self._descriptor()
+        desc.weight_dtype = DTYPE[self.weight_dtype]
+        sig = (self._uid, slot, bytes(desc), tuple((t.data_ptr(), t._version) for t in ws + bs))
         have = ctx.slot_owner.get(slot)
-        if not weights and have is not None and have[:2] == sig[:2]:
-            pass
+        if not weights and have is not None and have[:3] == sig[:3]:
+            pass            # same module, same architecture: the training kernels do not read the slot's weights
         elif have != sig:
             hw = [t.detach().to("cpu", torch.float32).contiguous() for t in ws]
             hb = [t.detach().to("cpu", torch.float32).contiguous() for t in bs]
-            desc = self._descriptor()
-            desc.weight_dtype = DTYPE[self.weight_dtype]
             ctx.set_field(slot, desc, hw, hb, sig)
         ags, drm, lp = self._iter_state()
         ctx.set_iter(slot, ags, drm, lp)
@@ -270,7 +275,18 @@ class NeRF(BaseNeuralField):
         return 1.1, 2.0, lowpass_scale(self.lowpass_alpha, self.pe_pos.embed_dim)
 
     def forward(self, sampling: Sampling) -> Dict[str, Tensor]:
-        """density [B,S], color [B,S,3] (nerf.py:161-164)."""
+        """density [B,S], color [B,S,3] (nerf.py:161-164); with autograd enabled and trainable parameters the outputs
+        carry the graph (one node over the HIP forward / backward kernels), under torch.no_grad() the fused kernel runs."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .autograd import RadianceFieldFunction
+            pos = sampling.sample_pos
+            ctx = Context.get(pos.device)
+            self.upload(ctx, self._slot, weights=False)
+            ws, bs = self._tensors()
+            B, S = pos.shape[0], pos.shape[1]
+            density, color = RadianceFieldFunction.apply(ctx, self._slot, self._iter_state(), len(ws), pos.detach(),
+                                                         sampling.sample_dir.detach(), sampling.diag_variance.detach(), *ws, *bs)
+            return {"density": density.view(B, S), "color": color.view(B, S, 3)}
         return self._run(sampling, OUT_MINIMAL, ("density", "color"))
 
     def set_iter(self, iter: int) -> None:
@@ -325,13 +341,13 @@ class NeuS(BaseNeuralField):
     def upload(self, ctx: Context, slot: int, weights: bool = True) -> None:
         # `variance.reshape(1)` is a fresh view each call: key the upload on the parameter itself
         ws, bs = self._tensors()
-        sig = (id(self), slot, tuple((t.data_ptr(), t._version) for t in ws[:-1] + bs[:-1]), self.variance.data_ptr(), self.variance._version,
-               self.weight_dtype)
+        desc = self._descriptor()
+        desc.weight_dtype = DTYPE[self.weight_dtype]
+        sig = (self._uid, slot, bytes(desc), tuple((t.data_ptr(), t._version) for t in ws[:-1] + bs[:-1]), self.variance.data_ptr(),
+               self.variance._version)
         if ctx.slot_owner.get(slot) != sig:
             hw = [t.detach().to("cpu", torch.float32).contiguous() for t in ws]
             hb = [t.detach().to("cpu", torch.float32).contiguous() for t in bs]
-            desc = self._descriptor()
-            desc.weight_dtype = DTYPE[self.weight_dtype]
             ctx.set_field(slot, desc, hw, hb, sig)
 
     def _iter_state(self):

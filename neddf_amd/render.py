@@ -14,7 +14,7 @@ from torch import Tensor, nn
 from ._lib import SLOT_COARSE, SLOT_FINE, Context, NeddfError, RenderParams
 from .camera import Camera
 from .config import instantiate
-from .network import BaseNeuralField, NeDDF
+from .network import BaseNeuralField, NeDDF, NeRF
 
 RenderTarget = str          # Literal["color", "depth", "transmittance"]
 SamplingType = str          # Literal["point", "cone"]
@@ -53,6 +53,11 @@ class NeRFRender(BaseNeuralRender):
         self.use_coarse_network = use_coarse_network
         self.network_fine: BaseNeuralField = instantiate(network_config)
         self.network_coarse: BaseNeuralField = instantiate(network_config) if use_coarse_network else self.network_fine
+        # library slots the modules work in when called directly (training step, stage API); render_rays' fused path
+        # loads SLOT_COARSE / SLOT_FINE itself
+        self.network_fine._slot = SLOT_FINE
+        if use_coarse_network:
+            self.network_coarse._slot = SLOT_COARSE
         self.sample_coarse, self.sample_fine = sample_coarse, sample_fine
         self.dist_near, self.dist_far, self.max_dist = dist_near, dist_far, max_dist
         self.sampling_type = sampling_type
@@ -156,7 +161,7 @@ class NeRFRender(BaseNeuralRender):
         """nerf_render.py:109-188.  Keys: weight, depth, color, transmittance[, fields_penalty] + *_coarse."""
         uv = uv.to(camera.device)
         B = uv.shape[0]
-        if torch.is_grad_enabled() and isinstance(self.network_fine, NeDDF) and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and isinstance(self.network_fine, (NeDDF, NeRF)) and any(p.requires_grad for p in self.parameters()):
             return self._render_rays_with_grad(uv, camera)
         ctx = self._ctx(uv.device)
         U_c = self._rand(B, self.sample_coarse + 1, uv.device)       # draw order is part of the contract

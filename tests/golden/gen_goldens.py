@@ -491,7 +491,98 @@ def gen_train():
     save("train_step.npz", **arrs)
 
 
+def _grad_records(arrs, prefix, module, proj_seed, full=()):
+    proj = np.random.default_rng(proj_seed)
+    names = []
+    for k, p_ in module.named_parameters():
+        gnp = npy(p_.grad)
+        names.append(k)
+        arrs[prefix + "gnorm_" + k] = np.float64(np.linalg.norm(gnp.astype(np.float64)))
+        arrs[prefix + "gproj_" + k] = np.float64(np.sum(gnp.astype(np.float64) * proj.standard_normal(gnp.shape)))
+        if k in full:
+            arrs[prefix + "grad_" + k] = gnp
+    arrs[prefix + "param_names"] = np.array(json.dumps(names))
+
+
+def gen_train_nerf():
+    """NeRF fields under the reference's plain torch autograd (nerf.py:107-165): (a) two configurations on 40 points with
+    random upstream gradients, (b) one training step of a two-network NeRFRender (config/render/nerf_render.yaml:
+    use_coarse_network, point sampling) with ColorLoss + MaskBCELoss (config/loss/nerf_loss.yaml) on 10 rays."""
+    from neddf.loss import ColorLoss, MaskBCELoss
+    arrs = {}
+    full = ("layers.0.weight", "layers.7.bias", "outL_density.weight", "outL_density.bias", "outL_color.0.bias",
+            "outL_color.2.weight", "outL_color.2.bias")       # the large matrices are pinned by norm + random projection
+    rng = np.random.default_rng(2024)
+    for tag, act, dact, it, shape in (("relu", "ReLU", "ReLU", -1, (2, 20)), ("tanhexp", "tanhExp", "LeakyReLU", 1500, (2, 20)),
+                                      ("relu250", "ReLU", "ReLU", 500, (10, 25))):      # 250 rows: ragged GEMM tiles
+        net = NeRF(activation_type=act, density_activation_type=dact)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_state(seed=11).items()})
+        net.set_iter(it)
+        pos, dd, var = synth.random_sampling(shape[0], shape[1], seed=41, cone=True)
+        ups = {"density": torch.from_numpy(rng.standard_normal(shape).astype(np.float32)),
+               "color": torch.from_numpy(rng.standard_normal(shape + (3,)).astype(np.float32))}
+        with torch.enable_grad():
+            net.zero_grad()
+            o = net(Sampling(torch.from_numpy(pos), torch.from_numpy(dd), torch.from_numpy(var)))
+            sum((o[k] * ups[k]).sum() for k in ups).backward()
+        pre = "fb_%s_" % tag
+        arrs.update({pre + "pos": pos, pre + "dir": dd, pre + "var": var, pre + "iteration": np.int32(it)})
+        for k in ups:
+            arrs[pre + "g_" + k] = npy(ups[k])
+            arrs[pre + "out_" + k] = npy(o[k])
+        _grad_records(arrs, pre, net, 456, full)
+
+    # embed_pos_rank 4 (top frequency 8): the sample positions of this build and of the reference differ in the last bit
+    # (ray direction = R . normalised pixel direction, summed in a different order), and with rank 10 the 512x frequency
+    # plus the ReLU kinks of random weights turn that into 1e-2 differences of the early-layer gradients -- a property of
+    # the inputs, not of either implementation (the rank-10 field is pinned on identical positions by the fb_* records)
+    ncfg = {"_target_": "neddf.network.NeRF", "embed_pos_rank": 4, "embed_dir_rank": 4, "layer_count": 8, "layer_width": 256,
+            "activation_type": "ReLU", "density_activation_type": "ReLU", "lowpass_alpha_offset": 10, "skips": [4]}
+    render = NeRFRender(network_config=ncfg, sample_coarse=24, sample_fine=40, dist_near=2.0, dist_far=6.0, max_dist=6.0,
+                        use_coarse_network=True, sampling_type="point")
+    render.network_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_state(embed_pos_rank=4, seed=11).items()})
+    render.network_fine.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_state(embed_pos_rank=4, seed=12).items()})
+    render.set_iter(500)
+    tf = json.load(open(os.path.join(REF, "data/bunny_smoke/transforms_test.json")))
+    cam, calib = make_camera(400, 400, tf["frames"][5], tf["camera_angle_x"])
+    cam.update_transform()
+    # MaskBCELoss is -log(clamp(1 - T, 1e-6, 1 - 1e-6)): for a ray whose 1 - T sits at the clamp the gradient jumps between 0
+    # and ~1e6, so fp32-level differences in T would decide the whole step.  Keep rays that are clearly inside.
+    cand = torch.from_numpy(rng.integers(120, 280, (200, 2)).astype(np.int16))
+    torch.manual_seed(5)
+    with torch.no_grad():
+        pre_out = render.render_rays(cand, cam)
+    ok = ((1 - pre_out["transmittance"]) > 1e-2) & ((1 - pre_out["transmittance_coarse"]) > 1e-2) & \
+         (pre_out["transmittance"] > 1e-2) & (pre_out["transmittance_coarse"] > 1e-2)
+    assert int(ok.sum()) >= 10, int(ok.sum())
+    uv = cand[ok][:10].contiguous()
+    target = {"color": torch.from_numpy(rng.uniform(0, 1, (10, 3)).astype(np.float32)),
+              "mask": torch.from_numpy((rng.uniform(0, 1, 10) > 0.5).astype(np.float32))}
+    losses = [ColorLoss(weight=1.0, weight_coarse=0.1), MaskBCELoss(weight=0.05, weight_coarse=0.005)]
+    torch.manual_seed(21)
+    with torch.enable_grad():
+        render.zero_grad()
+        out = render.render_rays(uv, cam)
+        ld = {}
+        for f in losses:
+            ld.update(f(out, target))
+        loss = torch.sum(torch.stack(list(ld.values())))
+        loss.backward()
+    arrs.update(uv=npy(uv), R=npy(cam.R), T=npy(cam.T), calib=calib, target_color=npy(target["color"]), target_mask=npy(target["mask"]),
+                loss=npy(loss), iteration=np.int32(500), seed=np.int32(21))
+    for k, v in ld.items():
+        arrs["loss_" + k] = npy(v)
+    for k, v in out.items():
+        arrs["out_" + k] = npy(v)
+    _grad_records(arrs, "coarse_", render.network_coarse, 123, full)
+    _grad_records(arrs, "fine_", render.network_fine, 124, full)
+    save("train_nerf.npz", **arrs)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "train_nerf":
+        gen_train_nerf()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "train":
         gen_train()
         sys.exit(0)
@@ -504,3 +595,4 @@ if __name__ == "__main__":
     gen_render_edges(r)
     gen_neus()
     gen_train()
+    gen_train_nerf()
