@@ -106,15 +106,78 @@ def cpu_baseline(weights, R, T, calib, budget_s=20.0):
                       "5.15 MFLOP/point)" % (n_rays, {k: round(v, 1) for k, v in sorted(sweep.items())}, best)}
 
 
+def train_workload(args, dev):
+    """One training step of the reference's configuration (config/trainer/neddf_trainer.yaml: 1024 rays, 64 + 128 samples, the
+    three losses of config/loss/neddf_loss.yaml, Adam) on synthetic targets; uniforms drawn on the device."""
+    import neddf_amd
+    from neddf_amd.loss import ColorLoss, FieldsConstraintLoss, MaskBCELoss
+    from conftest import BUNNY_CFG, golden
+    rays = 1024
+    wts = golden("bunny_weights.npz")
+    cfg = dict(BUNNY_CFG, density_activation_type="ReLU", _target_="neddf.network.NeDDF")      # config/network/neddf.yaml default
+    render = neddf_amd.NeRFRender(cfg, sample_coarse=64, sample_fine=128, dist_near=2.0, dist_far=6.0, max_dist=6.0,
+                                  use_coarse_network=False, sampling_type="cone")
+    render.network_fine.load_state_dict({k: torch.from_numpy(wts[k]) for k in wts.files})
+    render.to(dev)
+    render.set_iter(1500)
+    render.rng = "device"
+    fx = 0.5 * 400 / math.tan(0.5 * CAMERA_ANGLE_X)
+    R, T = view_pose(0)
+    cam = neddf_amd.Camera(neddf_amd.PinholeCalib(np.array([fx, fx, 200.0, 200.0])), None).to(dev)
+    cam.R, cam.T = torch.from_numpy(R).to(dev), torch.from_numpy(T).to(dev)
+    losses = [ColorLoss(1.0, 0.1), MaskBCELoss(0.05, 0.005), FieldsConstraintLoss(0.01, 0.01)]
+    opt = torch.optim.Adam(render.get_parameters_list(), lr=5e-4)
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    uv = (torch.rand(rays, 2, generator=gen) * 120 + 140).to(torch.int16).to(dev)
+    target = {"color": torch.rand(rays, 3, generator=gen).to(dev), "mask": (torch.rand(rays, generator=gen) > 0.5).float().to(dev),
+              "fields_penalty": torch.zeros(rays, device=dev)}
+
+    def step():
+        opt.zero_grad()
+        out = render.render_rays(uv, cam)
+        ld = {}
+        for f in losses:
+            ld.update(f(out, target))
+        loss = torch.sum(torch.stack(list(ld.values())))
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pts = rays * (65 + 194)
+    # forward GEMMs (Jacobian rows everywhere, as the reference trains) + dX + dW: 3 x 2 x 4 x 644 096 MACs per point, minus the
+    # input gradients of the first layers of both trunks, which are never needed
+    flop = pts * (3 * 2 * 4 * 644096 - 2 * 4 * (60 * 256 + 87 * 256))
+    achieved = flop * args.steps / elapsed / 1e12
+    return {"metric": "training rays/sec (1024-ray steps, 65 coarse + 194 fine samples, NeDDF fp32)", "value": rays * args.steps / elapsed,
+            "unit": "rays/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "training step: render_rays with autograd -> ColorLoss + MaskBCELoss + FieldsConstraintLoss -> backward -> "
+                                   "Adam, shipped bunny_smoke weights, synthetic targets", "rays_per_step_per_gpu": rays,
+                       "samples_per_ray": 65 + 194, "workload_id": "train", "parallelism": "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "whole step (forward + dX + dW GEMMs of both passes over wall time)"},
+            "final_loss": float(loss.item())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c3", "c5", "train"], default="c2",
                     help="c2 = BASELINE configs[1] (headline, default); c3 = configs[2], 65 coarse + 129 importance samples; "
-                         "c5 = configs[4], 1008x756 forward-facing view, NDC rays, hierarchical sampling, bf16 operands")
+                         "c5 = configs[4], 1008x756 forward-facing view, NDC rays, hierarchical sampling, bf16 operands; "
+                         "train = one training step (SURVEY 8f item 2): 1024 rays x (65 + 194) samples, losses, backward, Adam")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default=None,
                     help="operand type of the 256-wide layers (default f32; c5 defaults to bf16)")
     args = ap.parse_args()
@@ -142,6 +205,11 @@ def main():
 
     import neddf_amd
     from neddf_amd.parallel import gather_pixels, pack_pixels
+    if args.workload == "train":
+        assert world == 1, "the training step is benchmarked on one GPU (the reference has no data-parallel training)"
+        line = train_workload(args, dev)
+        print(json.dumps(line), flush=True)
+        return
     render, weights = build_render(dev)
     render.network_fine.weight_dtype = {"f32": "fp32", "bf16": "bf16"}[args.dtype]
     fx = 0.5 * WIDTH / math.tan(0.5 * CAMERA_ANGLE_X)

@@ -53,7 +53,6 @@ void launch_pe_values(const float *pos, const float *dir, const float *var, int6
                       hipStream_t s);
 void launch_density_head(int kind, const float *z, int ldz, int64_t N, const float *g, float *out, int ldo, hipStream_t s);
 void launch_copy3(const float *in, int ldi, float *out, int ldo, int64_t N, hipStream_t s);
-void launch_act_rows(int kind, int period, const float *Z, float *H, int64_t n_groups, int ncols, int ld, hipStream_t s);
 void launch_act_rows_backward(int kind, int period, const float *Z, const float *dH, float *dZ, int64_t n_groups, int ncols, int ld,
                               hipStream_t s);
 void launch_pe_rows(const float *pos, const float *dir, const float *var, int64_t N, const EncodeDesc &enc, float *PEs, float *PEu, int ld,

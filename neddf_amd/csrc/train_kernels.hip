@@ -324,25 +324,6 @@ __device__ __forceinline__ void act_grad2(float x, float &dy, float &d2)
     }
 }
 
-// H = a(Z) on (value, Jacobian) row groups: rows 4p .. 4p+3 (period 4) or plain rows (period 1)
-__global__ void act_rows_kernel(int kind, int period, const float *Z, float *H, int64_t n_groups, int ncols, int ld)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_groups * ncols) return;
-    int64_t p = i / ncols;
-    int c = (int)(i - p * ncols);
-    const float *z = Z + p * period * ld + c;
-    float *o = H + p * period * ld + c;
-    float y, dy;
-    if (kind == 0) act_grad<0>(z[0], y, dy); else if (kind == 1) act_grad<1>(z[0], y, dy); else act_grad<2>(z[0], y, dy);
-    if (period == 1) {
-        o[0] = kind == 0 ? act_val<0>(z[0]) : kind == 1 ? act_val<1>(z[0]) : act_val<2>(z[0]);
-        return;
-    }
-    o[0] = y;
-    for (int r = 1; r < 4; ++r) o[r * ld] = dy * z[r * ld];
-}
-
 // {ReLU,LeakyReLU,TanhExp}GradFunction.backward: dLdx = dLdy y' + sum_i dLdG_i J_i y'', dLdJ_i = dLdG_i y'
 __global__ void act_rows_backward_kernel(int kind, int period, const float *Z, const float *dH, float *dZ, int64_t n_groups, int ncols,
                                          int ld)
@@ -369,11 +350,6 @@ __global__ void act_rows_backward_kernel(int kind, int period, const float *Z, c
     o[0] = g[0] * dy + s * d2;
 }
 
-void launch_act_rows(int kind, int period, const float *Z, float *H, int64_t n_groups, int ncols, int ld, hipStream_t s)
-{
-    int64_t t = n_groups * ncols;
-    if (t > 0) hipLaunchKernelGGL(act_rows_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, kind, period, Z, H, n_groups, ncols, ld);
-}
 void launch_act_rows_backward(int kind, int period, const float *Z, const float *dH, float *dZ, int64_t n_groups, int ncols, int ld,
                               hipStream_t s)
 {
