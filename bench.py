@@ -106,11 +106,13 @@ def cpu_baseline(weights, R, T, calib, budget_s=20.0):
                       "5.15 MFLOP/point)" % (n_rays, {k: round(v, 1) for k, v in sorted(sweep.items())}, best)}
 
 
-def train_workload(args, dev):
+def train_workload(args, dev, world=1, rank=0, use_dist=False):
     """One training step of the reference's configuration (config/trainer/neddf_trainer.yaml: 1024 rays, 64 + 128 samples, the
-    three losses of config/loss/neddf_loss.yaml, Adam) on synthetic targets; uniforms drawn on the device."""
+    three losses of config/loss/neddf_loss.yaml, Adam) on synthetic targets; uniforms drawn on the device.  With N ranks the
+    step is data-parallel: 1024 rays per rank (weak scaling), one all-reduce of the flattened gradients per step."""
     import neddf_amd
     from neddf_amd.loss import ColorLoss, FieldsConstraintLoss, MaskBCELoss
+    from neddf_amd.parallel import average_gradients
     from conftest import BUNNY_CFG, golden
     rays = 1024
     wts = golden("bunny_weights.npz")
@@ -127,7 +129,7 @@ def train_workload(args, dev):
     cam.R, cam.T = torch.from_numpy(R).to(dev), torch.from_numpy(T).to(dev)
     losses = [ColorLoss(1.0, 0.1), MaskBCELoss(0.05, 0.005), FieldsConstraintLoss(0.01, 0.01)]
     opt = torch.optim.Adam(render.get_parameters_list(), lr=5e-4)
-    gen = torch.Generator(device="cpu").manual_seed(1)
+    gen = torch.Generator(device="cpu").manual_seed(1 + rank)
     uv = (torch.rand(rays, 2, generator=gen) * 120 + 140).to(torch.int16).to(dev)
     target = {"color": torch.rand(rays, 3, generator=gen).to(dev), "mask": (torch.rand(rays, generator=gen) > 0.5).float().to(dev),
               "fields_penalty": torch.zeros(rays, device=dev)}
@@ -140,31 +142,43 @@ def train_workload(args, dev):
             ld.update(f(out, target))
         loss = torch.sum(torch.stack(list(ld.values())))
         loss.backward()
+        if use_dist:
+            average_gradients(render.get_parameters_list(), force_collective=True)
         opt.step()
         return loss
 
+    def sync():
+        if use_dist:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(max(args.warmup, 1)):
         step()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
-    pts = rays * (65 + 194)
+    if use_dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    pts = rays * (65 + 194) * world
     # forward GEMMs (Jacobian rows everywhere, as the reference trains) + dX + dW: 3 x 2 x 4 x 644 096 MACs per point, minus the
     # input gradients of the first layers of both trunks, which are never needed
     flop = pts * (3 * 2 * 4 * 644096 - 2 * 4 * (60 * 256 + 87 * 256))
     achieved = flop * args.steps / elapsed / 1e12
-    return {"metric": "training rays/sec (1024-ray steps, 65 coarse + 194 fine samples, NeDDF fp32)", "value": rays * args.steps / elapsed,
-            "unit": "rays/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3,
+    return {"metric": "training rays/sec (1024-ray steps, 65 coarse + 194 fine samples, NeDDF fp32)", "value": rays * world * args.steps / elapsed,
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "training step: render_rays with autograd -> ColorLoss + MaskBCELoss + FieldsConstraintLoss -> backward -> "
                                    "Adam, shipped bunny_smoke weights, synthetic targets", "rays_per_step_per_gpu": rays,
-                       "samples_per_ray": 65 + 194, "workload_id": "train", "parallelism": "single GPU"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "whole step (forward + dX + dW GEMMs of both passes over wall time)"},
+                       "samples_per_ray": 65 + 194, "workload_id": "train",
+                       "parallelism": "data-parallel x%d, one gradient all-reduce per step" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved / world, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / world / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "per GPU, whole step (forward + dX + dW GEMMs of both passes over wall time)"},
             "final_loss": float(loss.item())}
 
 
@@ -206,9 +220,13 @@ def main():
     import neddf_amd
     from neddf_amd.parallel import gather_pixels, pack_pixels
     if args.workload == "train":
-        assert world == 1, "the training step is benchmarked on one GPU (the reference has no data-parallel training)"
-        line = train_workload(args, dev)
-        print(json.dumps(line), flush=True)
+        line = train_workload(args, dev, world, rank, use_dist)
+        if use_dist:
+            torch.distributed.destroy_process_group()
+        if rank == 0:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+            print(json.dumps(line), flush=True)
         return
     render, weights = build_render(dev)
     render.network_fine.weight_dtype = {"f32": "fp32", "bf16": "bf16"}[args.dtype]

@@ -155,27 +155,26 @@ int nerf_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors
     const float *PE = ws + p.o_pe, *Ed = ws + p.o_ed, *Hlast = ws + p.o_h[p.n - 1];
     HIPCHK(hipMemsetAsync(GC, 0, (size_t)N * 2 * kLdNarrow * sizeof(float), s));      // GC and GD
     if (g_color) launch_copy3(g_color, 3, GC, kLdNarrow, N, s);
-    // colour head, second layer
+    // colour head, second layer + the ReLU in front of it (dA = dZ of the first colour layer; the padded columns stay zero)
     NarrowW c1{};
     c1.nc = 3; c1.wstride = 1; c1.kcount = half;
     for (int c = 0; c < 3; ++c) c1.w[c] = W[p.i_c1] + c * half;
-    launch_narrow_backward(GC, kLdNarrow, N, c1, dA, kWidth, 0, s);
+    launch_narrow_backward_act(GC, kLdNarrow, N, c1, nullptr, 0, NEDDF_ACT_RELU, 1, ws + p.o_zc, dA, kWidth, s);
     {
         float *wc[3] = { gW[p.i_c1], gW[p.i_c1] + half, gW[p.i_c1] + 2 * half }, *bc[3] = { gB[p.i_c1], gB[p.i_c1] + 1, gB[p.i_c1] + 2 };
         launch_narrow_dw(ws + p.o_hc, kWidth, GC, kLdNarrow, N, 3, wc, 1, bc, 1, half, s);
     }
-    // ReLU, first layer (weights [128, 256 + dir])
-    launch_act_rows_backward(NEDDF_ACT_RELU, 1, ws + p.o_zc, dA, dB, N, kWidth, kWidth, s);
-    launch_dw(Hlast, kWidth, kWidth, dB, kWidth, N, gW[p.i_c0], 1, p.in_c0, half, gB[p.i_c0], 1, cus, s);
-    launch_dw(Ed, kLdDir, p.Cdir, dB, kWidth, N, gW[p.i_c0] + kWidth, 1, p.in_c0, half, nullptr, 1, cus, s);
+    // first colour layer (weights [128, 256 + dir])
+    launch_dw(Hlast, kWidth, kWidth, dA, kWidth, N, gW[p.i_c0], 1, p.in_c0, half, gB[p.i_c0], 1, cus, s);
+    launch_dw(Ed, kLdDir, p.Cdir, dA, kWidth, N, gW[p.i_c0] + kWidth, 1, p.in_c0, half, nullptr, 1, cus, s);
     launch_pack(W[p.i_c0], p.in_c0, 1, 0, 0, half, kWidth, kWidth, wp, s);                // rows = the 128 outputs, columns = hidden inputs
-    launch_rows_gemm(dB, N, kWidth, half, wp, half / 8, nullptr, 1, dA, kWidth, 0, -1, nullptr, cus, s);
-    // density head
+    launch_rows_gemm(dA, N, kWidth, half, wp, half / 8, nullptr, 1, dB, kWidth, 0, -1, nullptr, cus, s);
+    // density head, then the last trunk activation: dA = dZ of the last trunk layer
     if (g_density) launch_density_head(f.d.density_activation, ws + p.o_zd, kLdNarrow, N, g_density, GD, kLdNarrow, s);
     NarrowW dens{};
     dens.nc = 1; dens.wstride = 1; dens.kcount = kWidth;
     dens.w[0] = W[p.i_dens];
-    launch_narrow_backward(GD, kLdNarrow, N, dens, dA, kWidth, 1, s);
+    launch_narrow_backward_act(GD, kLdNarrow, N, dens, dB, 1, act, 1, ws + p.o_z[p.n - 1], dA, kWidth, s);
     {
         float *wd[1] = { gW[p.i_dens] }, *bd[1] = { gB[p.i_dens] };
         launch_narrow_dw(Hlast, kWidth, GD, kLdNarrow, N, 1, wd, 1, bd, 1, kWidth, s);
@@ -184,15 +183,15 @@ int nerf_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors
     for (int l = p.n - 1; l >= 0; --l) {
         const bool wide = l > 0 && in_skips(f.d, l - 1);
         const int in_total = l == 0 ? p.Cpe : (wide ? kWidth + p.Cpe : kWidth);
-        launch_act_rows_backward(act, 1, ws + p.o_z[l], dA, dB, N, kWidth, kWidth, s);
         if (l == 0) {
-            launch_dw(PE, kLdPe, p.Cpe, dB, kWidth, N, gW[0], 1, in_total, kWidth, gB[0], 1, cus, s);
+            launch_dw(PE, kLdPe, p.Cpe, dA, kWidth, N, gW[0], 1, in_total, kWidth, gB[0], 1, cus, s);
             break;
         }
-        launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dB, kWidth, N, gW[l], 1, in_total, kWidth, gB[l], 1, cus, s);
-        if (wide) launch_dw(PE, kLdPe, p.Cpe, dB, kWidth, N, gW[l] + kWidth, 1, in_total, kWidth, nullptr, 1, cus, s);
+        launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, N, gW[l], 1, in_total, kWidth, gB[l], 1, cus, s);
+        if (wide) launch_dw(PE, kLdPe, p.Cpe, dA, kWidth, N, gW[l] + kWidth, 1, in_total, kWidth, nullptr, 1, cus, s);
         launch_pack(W[l], in_total, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
-        launch_rows_gemm(dB, N, kWidth, kWidth, wp, 32, nullptr, 1, dA, kWidth, 0, -1, nullptr, cus, s);
+        launch_rows_gemm_actback(dA, N, kWidth, kWidth, wp, 32, 1, act, ws + p.o_z[l - 1], dB, kWidth, cus, s);
+        float *t = dA; dA = dB; dB = t;
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -315,12 +314,14 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     a.g_distance = g_distance; a.g_density = g_density; a.g_color = g_color; a.g_penalty = g_penalty; a.g_aux = g_aux_grad;
     a.GZH = GZH; a.GCR = GCR;
     launch_point_backward(a, s);
+    // Every activation backward is fused into the kernel that produces its upstream gradient: dA always holds dZ of the layer
+    // in flight, the input-gradient GEMM of layer l writes dZ of layer l-1 straight away (no dH round trip through HBM).
     // colour head: LinearGradFunction.backward (linear.py:62-88) on [HC | JC] rows
     NarrowW cout{};
     cout.nc = 3; cout.wstride = 3; cout.kcount = kWidth;
     for (int c = 0; c < 3; ++c) cout.w[c] = W[p.i_cout] + c;
     const float *HClast = ws + p.o_hc[p.n_col - 1];
-    launch_narrow_backward(GCR, kLdNarrow, p.R, cout, dA, kWidth, 0, s);
+    launch_narrow_backward_act(GCR, kLdNarrow, p.R, cout, nullptr, 0, act, 4, ws + p.o_zc[p.n_col - 1], dA, kWidth, s);
     {
         float *wc[3] = { gW[p.i_cout], gW[p.i_cout] + 1, gW[p.i_cout] + 2 }, *bc[3] = { gB[p.i_cout], gB[p.i_cout] + 1, gB[p.i_cout] + 2 };
         launch_narrow_dw(HClast, kWidth, GCR, kLdNarrow, p.R, 3, wc, 3, bc, 4, kWidth, s);
@@ -329,23 +330,24 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     for (int l = p.n_col - 1; l >= 0; --l) {
         const float *Wl = W[p.n_trunk + l];
         float *gWl = gW[p.n_trunk + l], *gBl = gB[p.n_trunk + l];
-        launch_act_rows_backward(act, 4, ws + p.o_zc[l], dA, dB, N, kWidth, kWidth, s);
         if (l > 0) {
-            launch_dw(ws + p.o_hc[l - 1], kWidth, kWidth, dB, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s);
+            launch_dw(ws + p.o_hc[l - 1], kWidth, kWidth, dA, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s);
             launch_pack(Wl, 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wp, s);                 // W^T
+            launch_rows_gemm_actback(dA, p.R, kWidth, kWidth, wp, 32, 4, act, ws + p.o_zc[l - 1], dB, kWidth, ctx->cus, s);
         } else {
-            launch_dw(ws + p.o_xa, p.ldxa, p.Ca, dB, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s);
-            launch_dw(Hlast, kWidth, kWidth, dB, kWidth, p.R, gWl + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s);
+            launch_dw(ws + p.o_xa, p.ldxa, p.Ca, dA, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s);
+            launch_dw(Hlast, kWidth, kWidth, dA, kWidth, p.R, gWl + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s);
             launch_pack(Wl, 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wp, s);              // (feature rows of W)^T
+            // the small colour inputs (encodings, detached normal) carry no parameters: only the feature segment propagates
+            launch_rows_gemm(dA, p.R, kWidth, kWidth, wp, 32, nullptr, 4, dB, kWidth, 0, -1, nullptr, ctx->cus, s);
         }
-        // the small colour inputs (encodings, detached normal) carry no parameters: only the feature segment propagates
-        launch_rows_gemm(dB, p.R, kWidth, kWidth, wp, 32, nullptr, 4, dA, kWidth, 0, -1, nullptr, ctx->cus, s);
+        float *t = dA; dA = dB; dB = t;
     }
-    // distance / aux heads
+    // dA = gradient of the trunk features from the colour trunk; add the distance / aux heads, then the last trunk activation
     NarrowW heads{};
     heads.nc = 2; heads.wstride = 1; heads.kcount = kWidth;
     heads.w[0] = W[p.i_ddf]; heads.w[1] = W[p.i_aux];
-    launch_narrow_backward(GZH, kLdNarrow, p.R, heads, dA, kWidth, 1, s);
+    launch_narrow_backward_act(GZH, kLdNarrow, p.R, heads, dA, 1, act, 4, ws + p.o_z[p.n_trunk - 1], dA, kWidth, s);
     {
         float *wh[2] = { gW[p.i_ddf], gW[p.i_aux] }, *bh[2] = { gB[p.i_ddf], gB[p.i_aux] };
         launch_narrow_dw(Hlast, kWidth, GZH, kLdNarrow, p.R, 2, wh, 1, bh, 4, kWidth, s);
@@ -353,19 +355,19 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     // distance trunk
     for (int l = p.n_trunk - 1; l >= 0; --l) {
         const bool wide = l > 0 && in_skips(f.d, l - 1);
-        launch_act_rows_backward(act, 4, ws + p.o_z[l], dA, dB, N, kWidth, kWidth, s);
         if (l == 0) {
-            launch_dw(PEs, kLdPe, p.Cpe, dB, kWidth, p.R, gW[0], kWidth, 1, kWidth, gB[0], 4, ctx->cus, s);
+            launch_dw(PEs, kLdPe, p.Cpe, dA, kWidth, p.R, gW[0], kWidth, 1, kWidth, gB[0], 4, ctx->cus, s);
             break;
         }
         if (wide) {
-            launch_dw(PEs, kLdPe, p.Cpe, dB, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s);
-            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dB, kWidth, p.R, gW[l] + (size_t)p.Cpe * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s);
+            launch_dw(PEs, kLdPe, p.Cpe, dA, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s);
+            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l] + (size_t)p.Cpe * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s);
         } else {
-            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dB, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s);
+            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s);
         }
         launch_pack(W[l], 1, kWidth, 0, wide ? p.Cpe : 0, kWidth, kWidth, kWidth, wp, s);
-        launch_rows_gemm(dB, p.R, kWidth, kWidth, wp, 32, nullptr, 4, dA, kWidth, 0, -1, nullptr, ctx->cus, s);
+        launch_rows_gemm_actback(dA, p.R, kWidth, kWidth, wp, 32, 4, act, ws + p.o_z[l - 1], dB, kWidth, ctx->cus, s);
+        float *t = dA; dA = dB; dB = t;
     }
     HIPCHK(hipGetLastError());
     return 0;

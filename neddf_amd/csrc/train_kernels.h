@@ -44,6 +44,10 @@ void launch_pack(const float *src, int64_t sk, int64_t sn, int k_off, int n_off,
 void launch_rows_gemm(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias, int bias_period,
                       float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s);
 // dW[k * sk + n * sn] += sum_r X[r, k] G[r, n], k < K <= 256, n < nvalid <= 256; db[n] += sum over rows r % bias_period == 0 of G[r, n]
+// dZ[R,256] = activation backward (pre-activations Zprev, row period, kind) of X[R, 0:kload) x Wpacked: the input-gradient GEMM of
+// a layer fused with the backward of the previous layer's activation
+void launch_rows_gemm_actback(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, int period, int act_kind,
+                              const float *Zprev, float *dZ, int ldy, int cus, hipStream_t s);
 void launch_dw(const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
                int bias_period, int cus, hipStream_t s);
 // heads (1..4 output columns, input width 256): column c of the weight gradient is w[c][k * wstride], b[c] its bias gradient
@@ -53,8 +57,6 @@ void launch_pe_values(const float *pos, const float *dir, const float *var, int6
                       hipStream_t s);
 void launch_density_head(int kind, const float *z, int ldz, int64_t N, const float *g, float *out, int ldo, hipStream_t s);
 void launch_copy3(const float *in, int ldi, float *out, int ldo, int64_t N, hipStream_t s);
-void launch_act_rows_backward(int kind, int period, const float *Z, const float *dH, float *dZ, int64_t n_groups, int ncols, int ld,
-                              hipStream_t s);
 void launch_pe_rows(const float *pos, const float *dir, const float *var, int64_t N, const EncodeDesc &enc, float *PEs, float *PEu, int ld,
                     float *Ed, int ldd, hipStream_t s);
 // Y[R, ldy] cols 0..nc-1 = X[R, 256] . w_c (+ b_c on rows r % bias_period == 0); column c of the weights is wcol[c][k * wstride]
@@ -69,6 +71,9 @@ void launch_narrow_forward(const float *X, int ldx, int64_t R, const NarrowW &w,
 // dX[R, ldx] (+)= sum_c G[r, c] * w_c[k]
 void launch_narrow_backward(const float *G, int ldg, int64_t R, const NarrowW &w, float *dX, int ldx, int accumulate, hipStream_t s);
 
+// dZ = activation backward (Zprev) of ((accumulate ? dH : 0) + sum_c G[., c] w_c); dH and dZ may alias
+void launch_narrow_backward_act(const float *G, int ldg, int64_t R, const NarrowW &w, const float *dH, int accumulate, int act_kind, int period,
+                                const float *Zprev, float *dZ, int ld, hipStream_t s);
 void launch_point_forward(const TrainPointArgs &a, hipStream_t s);
 void launch_penalty_forward(const TrainPointArgs &a, hipStream_t s);
 void launch_point_backward(const TrainPointArgs &a, hipStream_t s);

@@ -18,13 +18,60 @@
 namespace neddf {
 
 // ----------------------------------------------------------------------------
+// second derivative of the hidden activations as the reference's backward passes define it
+template <int KIND>
+__device__ __forceinline__ void act_grad2(float x, float &dy, float &d2)
+{
+    if (KIND == 0) { dy = (x >= 0.f) ? 1.f : 0.f; d2 = 0.f; }            // relu.py backward: mask only
+    else if (KIND == 1) { dy = (x < 0.f) ? 0.01f : 1.f; d2 = 0.f; }      // leaky_relu.py backward: scale only
+    else {                                                                 // tanh_exp.py:43-51
+        float ex = fast_exp(x), tx = tanh_nonneg(ex);
+        float t2 = fmaf(tx, tx, -1.0f);
+        bool big = x > 20.0f;
+        dy = big ? 1.0f : fmaf(-(x * ex), t2, tx);
+        d2 = big ? 0.0f : ex * (-x + 2 * ex * x * tx - 2) * t2;
+    }
+}
+
+// Backward of one activation on a 4-row group of 4 columns, in place on g (the upstream gradient of the group):
+// period 4 = {ReLU,LeakyReLU,TanhExp}GradFunction.backward (dLdx = dLdy y' + sum_i dLdG_i J_i y'', dLdJ_i = dLdG_i y');
+// period 1 = the plain activations of NeRF (F.relu / F.leaky_relu / tanhExp, nerf.py:71-79; derivative at 0 as torch's)
+__device__ __forceinline__ void act_backward_group(int kind, int period, const f32x4v (&z)[4], f32x4v (&g)[4])
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (period == 4) {
+            float dy, d2;
+            if (kind == 0) act_grad2<0>(z[0][u], dy, d2); else if (kind == 1) act_grad2<1>(z[0][u], dy, d2); else act_grad2<2>(z[0][u], dy, d2);
+            float s = g[1][u] * z[1][u];
+            s += g[2][u] * z[2][u];
+            s += g[3][u] * z[3][u];
+            g[0][u] = g[0][u] * dy + s * d2;
+            g[1][u] *= dy; g[2][u] *= dy; g[3][u] *= dy;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = z[r][u];
+                float dy, d2;
+                if (kind == 0) dy = x > 0.f ? 1.f : 0.f;
+                else if (kind == 1) dy = x > 0.f ? 1.f : 0.01f;
+                else act_grad2<2>(x, dy, d2);
+                g[r][u] *= dy;
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
 // Y[R, 256] (+)= X[R, 0:kload) x Wpacked (+ bias on rows r % bias_period == 0), optionally followed by the activation on
 // (value, Jacobian) row groups: H = a(Y) (LinearGradFunction.forward + the activation's forward in one pass).
 // 64-row tiles, two workgroups per CU (one's loads / stores overlap the other's MFMAs).  The next tile's rows are
 // requested (global -> VGPR) before the MFMAs of the current tile issue; results go back through the LDS tile so that
 // every global access of the epilogue is a full 16-byte-per-lane row segment, and the activation sees the four rows
 // of a point in one thread.
-template <bool ACT>
+// MODE 0: plain; 1: also H = a(Y) (forward); 2: Y = activation backward of the product with the pre-activations Zp = H
+// (the dX GEMM of layer l immediately followed by the backward of layer l-1's activation: dZ_{l-1}, no dH round trip)
+template <int MODE>
 __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps,
                                                                 const float *bias, int bias_period, float *Y, int ldy, int accumulate,
                                                                 int act_kind, float *H)
@@ -92,6 +139,20 @@ __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, 
             const int64_t row = r0 + 4 * grp;
             if (row >= R) continue;
             f32x4v z[4];
+            if (MODE == 2) {
+                f32x4v zp[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    z[r] = *(const f32x4v *)(act + (4 * grp + r) * kActLd + 4 * c4);
+                    const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
+                    zp[r] = row + r < R ? *(const f32x4v *)(H + (row + r) * ldy + 4 * c4) : zero;
+                }
+                act_backward_group(act_kind, bias_period, zp, z);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row + r < R) *(f32x4v *)(Y + (row + r) * ldy + 4 * c4) = z[r];
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 z[r] = *(const f32x4v *)(act + (4 * grp + r) * kActLd + 4 * c4);
@@ -101,6 +162,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, 
                     *(f32x4v *)yp = z[r];
                 }
             }
+            constexpr bool ACT = MODE == 1;
             if (ACT && bias_period != 4) {          // plain rows (NeRF): H = a(Y) elementwise
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -126,20 +188,35 @@ __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, 
     }
 }
 
-void launch_rows_gemm(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias, int bias_period,
-                      float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s)
+static void launch_rows_gemm_mode(int mode, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias,
+                                  int period, float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s)
 {
     if (R <= 0) return;
     const size_t lds = (size_t)(64 * kActLd) * sizeof(float);
-    static bool once = ((void)hipFuncSetAttribute((const void *)rows_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * kActLd * sizeof(float))),
-                        (void)hipFuncSetAttribute((const void *)rows_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * kActLd * sizeof(float))), true);
+    static bool once = ((void)hipFuncSetAttribute((const void *)rows_gemm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * kActLd * sizeof(float))),
+                        (void)hipFuncSetAttribute((const void *)rows_gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * kActLd * sizeof(float))),
+                        (void)hipFuncSetAttribute((const void *)rows_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * kActLd * sizeof(float))), true);
     (void)once;
     int64_t tiles = (R + 63) / 64;
     int grid = (int)(tiles < 2 * cus ? tiles : 2 * cus);
-    if (act_kind >= 0 && H)
-        hipLaunchKernelGGL((rows_gemm_kernel<true>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, bias_period, Y, ldy, accumulate, act_kind, H);
+    if (mode == 1)
+        hipLaunchKernelGGL((rows_gemm_kernel<1>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, act_kind, H);
+    else if (mode == 2)
+        hipLaunchKernelGGL((rows_gemm_kernel<2>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, 0, act_kind, H);
     else
-        hipLaunchKernelGGL((rows_gemm_kernel<false>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, bias_period, Y, ldy, accumulate, -1, nullptr);
+        hipLaunchKernelGGL((rows_gemm_kernel<0>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, -1, nullptr);
+}
+
+void launch_rows_gemm(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias, int bias_period,
+                      float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s)
+{
+    launch_rows_gemm_mode((act_kind >= 0 && H) ? 1 : 0, X, R, ldx, kload, wp, ksteps, bias, bias_period, Y, ldy, accumulate, act_kind, H, cus, s);
+}
+
+void launch_rows_gemm_actback(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, int period, int act_kind,
+                              const float *Zprev, float *dZ, int ldy, int cus, hipStream_t s)
+{
+    launch_rows_gemm_mode(2, X, R, ldx, kload, wp, ksteps, nullptr, period, dZ, ldy, 0, act_kind, const_cast<float *>(Zprev), cus, s);
 }
 
 // ----------------------------------------------------------------------------
@@ -306,55 +383,6 @@ void launch_dw(const float *X, int ldx, int K, const float *G, int ldg, int64_t 
     if (K <= 64) launch_dw_tile<2>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
     else if (K <= 96) launch_dw_tile<3>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
     else launch_dw_tile<8>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
-}
-
-// ----------------------------------------------------------------------------
-// second derivative of the hidden activations as the reference's backward passes define it
-template <int KIND>
-__device__ __forceinline__ void act_grad2(float x, float &dy, float &d2)
-{
-    if (KIND == 0) { dy = (x >= 0.f) ? 1.f : 0.f; d2 = 0.f; }            // relu.py backward: mask only
-    else if (KIND == 1) { dy = (x < 0.f) ? 0.01f : 1.f; d2 = 0.f; }      // leaky_relu.py backward: scale only
-    else {                                                                 // tanh_exp.py:43-51
-        float ex = fast_exp(x), tx = tanh_nonneg(ex);
-        float t2 = fmaf(tx, tx, -1.0f);
-        bool big = x > 20.0f;
-        dy = big ? 1.0f : fmaf(-(x * ex), t2, tx);
-        d2 = big ? 0.0f : ex * (-x + 2 * ex * x * tx - 2) * t2;
-    }
-}
-
-// {ReLU,LeakyReLU,TanhExp}GradFunction.backward: dLdx = dLdy y' + sum_i dLdG_i J_i y'', dLdJ_i = dLdG_i y'
-__global__ void act_rows_backward_kernel(int kind, int period, const float *Z, const float *dH, float *dZ, int64_t n_groups, int ncols,
-                                         int ld)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_groups * ncols) return;
-    int64_t p = i / ncols;
-    int c = (int)(i - p * ncols);
-    const float *z = Z + p * period * ld + c;
-    const float *g = dH + p * period * ld + c;
-    float *o = dZ + p * period * ld + c;
-    float dy, d2;
-    if (period == 1) {          // plain activations of NeRF (F.relu / F.leaky_relu / tanhExp, nerf.py:71-79): derivative at 0 is torch's
-        const float x = z[0];
-        if (kind == 0) dy = x > 0.f ? 1.f : 0.f;
-        else if (kind == 1) dy = x > 0.f ? 1.f : 0.01f;
-        else act_grad2<2>(x, dy, d2);
-        o[0] = g[0] * dy;
-        return;
-    }
-    if (kind == 0) act_grad2<0>(z[0], dy, d2); else if (kind == 1) act_grad2<1>(z[0], dy, d2); else act_grad2<2>(z[0], dy, d2);
-    float s = 0.f;
-    for (int r = 1; r < 4; ++r) { s += g[r * ld] * z[r * ld]; o[r * ld] = g[r * ld] * dy; }
-    o[0] = g[0] * dy + s * d2;
-}
-
-void launch_act_rows_backward(int kind, int period, const float *Z, const float *dH, float *dZ, int64_t n_groups, int ncols, int ld,
-                              hipStream_t s)
-{
-    int64_t t = n_groups * ncols;
-    if (t > 0) hipLaunchKernelGGL(act_rows_backward_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, kind, period, Z, dH, dZ, n_groups, ncols, ld);
 }
 
 // ----------------------------------------------------------------------------
@@ -711,6 +739,44 @@ void launch_narrow_backward(const float *G, int ldg, int64_t R, const NarrowW &w
 {
     int64_t t = R * kWidth;
     if (t > 0) hipLaunchKernelGGL(narrow_backward_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, G, ldg, R, w, dX, ldx, accumulate);
+}
+
+// The same followed by the backward of the activation that produced the head's input: one thread per (4-row group, 4 columns);
+// dZ = act_backward(Zprev, (accumulate ? dH : 0) + sum_c G[., c] w_c).  dH and dZ may alias.
+__global__ void narrow_backward_act_kernel(const float *G, int ldg, int64_t R, NarrowW w, const float *dH, int accumulate, int act_kind,
+                                           int period, const float *Zprev, float *dZ, int ld)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t groups = (R + 3) >> 2;
+    if (i >= groups * (kWidth / 4)) return;
+    const int64_t row = (i >> 6) * 4;
+    const int c4 = (int)(i & 63);
+    f32x4v g[4], z[4];
+    const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool in = row + r < R;
+        g[r] = (accumulate && in) ? *(const f32x4v *)(dH + (row + r) * ld + 4 * c4) : zero;
+        z[r] = in ? *(const f32x4v *)(Zprev + (row + r) * ld + 4 * c4) : zero;
+        if (in)
+            for (int c = 0; c < w.nc; ++c) {
+                const float gv = G[(row + r) * ldg + c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (4 * c4 + u < w.kcount) g[r][u] = fmaf(gv, w.w[c][(size_t)(4 * c4 + u) * w.wstride], g[r][u]);
+            }
+    }
+    act_backward_group(act_kind, period, z, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (row + r < R) *(f32x4v *)(dZ + (row + r) * ld + 4 * c4) = g[r];
+}
+void launch_narrow_backward_act(const float *G, int ldg, int64_t R, const NarrowW &w, const float *dH, int accumulate, int act_kind, int period,
+                                const float *Zprev, float *dZ, int ld, hipStream_t s)
+{
+    int64_t t = ((R + 3) >> 2) * (kWidth / 4);
+    if (t > 0) hipLaunchKernelGGL(narrow_backward_act_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, G, ldg, R, w, dH, accumulate,
+                                  act_kind, period, Zprev, dZ, ld);
 }
 
 // ----------------------------------------------------------------------------

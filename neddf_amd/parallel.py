@@ -8,6 +8,13 @@ into ONE [n,5] tensor so a view costs one RCCL all-gather (12.8 MB at 800x800)
 over xGMI.  No all-reduce anywhere.  The reference has no multi-GPU code; this
 module is new.
 
+Training (also new: the reference trains on one device) is data-parallel over
+rays: every rank runs the training step on its own random pixel batch with
+replicated parameters, and the one exchange per step is a single all-reduce of
+the flattened gradients (2.6 MB for the shipped NeDDF) -- one bucket, because
+with 26 small tensors the latency of xGMI's point-to-point ring dominates, not
+its bandwidth.
+
 One process per GPU (torch.distributed, backend "nccl" = RCCL on ROCm; "gloo"
 on CPU for the tests).
 """
@@ -72,3 +79,28 @@ def render_image_sharded(render, width: int, height: int, camera, target_types: 
     parts = render.render_image(width, height, camera, keys, downsampling, chunk, pixel_range=(lo, hi))
     full = gather_pixels(pack_pixels(parts, keys), n, group)
     return {k: v.reshape(h, w, -1) for k, v in unpack_pixels(full, keys).items()}
+
+
+def average_gradients(params: Iterable[Tensor], group=None, force_collective: bool = False) -> None:
+    """Replace every parameter's .grad by its mean over the ranks with ONE all-reduce of the flattened gradients.
+    Parameters without a gradient on this rank contribute zeros (all ranks must hold the same parameter list)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return
+    world = dist.get_world_size(group)
+    if world == 1 and not force_collective:
+        return
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(world)
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off:off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n

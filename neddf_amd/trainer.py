@@ -16,6 +16,7 @@ from .config import instantiate, to_plain
 from .dataset import imwrite_bgr
 from .logger import NeRFTBLogger
 from .metrics import peak_signal_noise_ratio, structural_similarity
+from .parallel import average_gradients
 
 
 def _get(cfg: Any, key: str) -> Any:
@@ -165,6 +166,8 @@ class NeRFTrainer(BaseTrainer):
                 loss_dict.update(loss_function(render_result, targets))
             loss = torch.sum(torch.stack(list(loss_dict.values())))
             loss.backward()
+        # data-parallel runs (torch.distributed initialised by the launcher): every rank drew its own pixels, one all-reduce
+        average_gradients(self.neural_render.get_parameters_list())
         loss_float = float(loss.item())
         mse = float(torch.mean(torch.square(render_result["color"] - targets["color"])).item())
         psnr = 10 * math.log10(1.0 / mse)

@@ -176,7 +176,7 @@ def test_shard_range_covers_everything():
 _WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from neddf_amd.parallel import gather_pixels, pack_pixels, shard_range, unpack_pixels, render_image_sharded
+from neddf_amd.parallel import average_gradients, gather_pixels, pack_pixels, shard_range, unpack_pixels, render_image_sharded
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
 rank = dist.get_rank()
 n = 12 * 10 + 1                                   # odd: slabs of different length
@@ -194,6 +194,16 @@ img = render_image_sharded(FakeRender(), 11, 11, None, ["color", "depth"])
 idx = torch.arange(121, dtype=torch.float32)
 assert img["color"].shape == (11, 11, 3) and img["depth"].shape == (11, 11, 1)
 assert torch.equal(img["color"].reshape(-1, 3)[:, 1], idx * 2) and torch.equal(img["depth"].reshape(-1), idx + 0.5)
+# data-parallel training: one all-reduce replaces every gradient by the mean over ranks (missing gradients count as zero)
+torch.manual_seed(0)
+ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2))]
+ps[0].grad = torch.full((3, 4), float(rank + 1))
+ps[1].grad = torch.arange(5, dtype=torch.float32) * (1 if rank == 0 else -1)
+if rank == 0:
+    ps[2].grad = torch.ones(2, 2)
+average_gradients(ps)
+assert torch.equal(ps[0].grad, torch.full((3, 4), 1.5)) and torch.equal(ps[1].grad, torch.zeros(5))
+assert torch.equal(ps[2].grad, torch.full((2, 2), 0.5))
 dist.barrier()
 print("rank", rank, "ok")
 '''
