@@ -488,6 +488,31 @@ def gen_train():
         arrs["fb_gproj_" + k] = np.float64(np.sum(gnp.astype(np.float64) * proj.standard_normal(gnp.shape)))
         if k in full:
             arrs["fb_grad_" + k] = gnp
+    # further architectures at field level (synthetic weights): ReLU / LeakyReLU hidden activations (zero second derivative),
+    # LeakyReLU / tanhExp density, other encoding ranks (padding of the GEMM operands), two skip connections
+    for tag, kw in (("relu", dict(embed_pos_rank=6, embed_dir_rank=3, ddf_layer_count=6, col_layer_count=3, skips=[1, 3],
+                                  activation_type="ReLU", density_activation_type="LeakyReLU")),
+                    ("leaky", dict(embed_pos_rank=10, embed_dir_rank=4, ddf_layer_count=8, col_layer_count=4, skips=[4],
+                                   activation_type="LeakyReLU", density_activation_type="tanhExp"))):
+        net = NeDDF(ddf_layer_width=256, col_layer_width=256, d_near=0.01, lowpass_alpha_offset=10,
+                    penalty_weight={"constraints_aux_grad": 0.05, "constraints_dDdt": 0.5, "range_color": 0.1}, **kw)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.neddf_state(
+            embed_pos_rank=kw["embed_pos_rank"], embed_dir_rank=kw["embed_dir_rank"], ddf_layer_count=kw["ddf_layer_count"],
+            col_layer_count=kw["col_layer_count"], skips=tuple(kw["skips"]), seed=23).items()})
+        net.set_iter(2500)
+        pos, dd, var = synth.random_sampling(3, 11, seed=37, cone=True)
+        ups = {k: torch.from_numpy(rng.standard_normal((3, 11) + ((3,) if k == "color" else ())).astype(np.float32))
+               for k in ("distance", "density", "color", "fields_penalty", "aux_grad")}
+        with torch.enable_grad():
+            net.zero_grad()
+            o = net(Sampling(torch.from_numpy(pos), torch.from_numpy(dd), torch.from_numpy(var)))
+            sum((o[k] * ups[k]).sum() for k in ups).backward()
+        pre = "fx_%s_" % tag
+        arrs.update({pre + "pos": pos, pre + "dir": dd, pre + "var": var})
+        for k in ups:
+            arrs[pre + "g_" + k] = npy(ups[k])
+            arrs[pre + "out_" + k] = npy(o[k])
+        _grad_records(arrs, pre, net, 789, ("layers_ddf.0.weight", "layers_ddf.0.bias", "layer_aux_out.weight", "layer_col_out.bias"))
     save("train_step.npz", **arrs)
 
 
