@@ -345,16 +345,23 @@ __global__ __launch_bounds__(kThreads) void narrow_dw_kernel(const float *X, int
     const int k = threadIdx.x;
     const int64_t rb = (int64_t)blockIdx.x * rows_per_wg, re = rb + rows_per_wg < R ? rb + rows_per_wg : R;
     float acc[4] = { 0.f, 0.f, 0.f, 0.f }, bs[4] = { 0.f, 0.f, 0.f, 0.f };
-    for (int64_t r = rb; r < re; ++r) {
-        const float x = X[r * ldx + k];
-        const bool vr = (r % bias_period) == 0;
+    for (int64_t r0 = rb; r0 < re; r0 += 4) {           // four independent row loads in flight
+        float x[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c < o.nc) {
-                float g = G[r * ldg + c];
-                acc[c] = fmaf(x, g, acc[c]);
-                if (vr) bs[c] += g;
-            }
+        for (int u = 0; u < 4; ++u) x[u] = r0 + u < re ? X[(r0 + u) * ldx + k] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = r0 + u;
+            if (r >= re) break;
+            const bool vr = (r % bias_period) == 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < o.nc) {
+                    float g = G[r * ldg + c];
+                    acc[c] = fmaf(x[u], g, acc[c]);
+                    if (vr) bs[c] += g;
+                }
+        }
     }
     for (int c = 0; c < o.nc; ++c) {
         if (k < o.kcount) atomicAdd(&o.w[c][(size_t)k * o.wstride], acc[c]);
@@ -462,16 +469,23 @@ __global__ void point_forward_kernel(TrainPointArgs a)
     if (a.distance) a.distance[n] = D;
     if (a.density) a.density[n] = rho;
     if (a.aux_grad) a.aux_grad[n] = aux;
-    // colour input rows
+}
+
+// colour-trunk small-input rows XA[4N, ldxa] = [embed_pos rows | embed_dir | norm_dir.detach() | 0] (neddf.py:243-253), one thread per
+// element so that reads and writes run along rows; the normal comes from the per-point record written above
+__global__ void xa_fill_kernel(TrainPointArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N * 4 * a.ldxa) return;
+    const int64_t row = i / a.ldxa;
+    const int c = (int)(i - row * a.ldxa), r = (int)(row & 3);
+    const int64_t n = row >> 2;
     const int Cpe = 6 * a.enc.E, Cdir = 6 * a.enc.Ed;
-    for (int r = 0; r < 4; ++r) {
-        float *x = a.XA + (n * 4 + r) * a.ldxa;
-        const float *pu = a.PEu + (n * 4 + r) * a.ldpe;
-        for (int c = 0; c < Cpe; ++c) x[c] = pu[c];
-        for (int c = 0; c < Cdir; ++c) x[Cpe + c] = r == 0 ? a.Ed[n * a.ldd + c] : 0.f;
-        for (int c = 0; c < 3; ++c) x[Cpe + Cdir + c] = r == 0 ? ninv * dg[c] : 0.f;
-        for (int c = Cpe + Cdir + 3; c < a.ldxa; ++c) x[c] = 0.f;
-    }
+    float v = 0.f;
+    if (c < Cpe) v = a.PEu[row * a.ldpe + c];
+    else if (r == 0 && c < Cpe + Cdir) v = a.Ed[n * a.ldd + c - Cpe];
+    else if (r == 0 && c < Cpe + Cdir + 3) v = a.PT[n * kTrainPt + TP_ND0 + c - Cpe - Cdir];
+    a.XA[i] = v;
 }
 
 // field penalties (neddf.py:260-300) from the colour rows CR[4N, ldc] (cols 0..2) + the per-point record
@@ -599,7 +613,10 @@ __global__ void point_backward_kernel(TrainPointArgs a)
 
 void launch_point_forward(const TrainPointArgs &a, hipStream_t s)
 {
-    if (a.N > 0) hipLaunchKernelGGL(point_forward_kernel, dim3((unsigned)((a.N + 127) / 128)), dim3(128), 0, s, a);
+    if (a.N <= 0) return;
+    hipLaunchKernelGGL(point_forward_kernel, dim3((unsigned)((a.N + 127) / 128)), dim3(128), 0, s, a);
+    const int64_t t = a.N * 4 * a.ldxa;
+    hipLaunchKernelGGL(xa_fill_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, a);
 }
 void launch_penalty_forward(const TrainPointArgs &a, hipStream_t s)
 {
@@ -706,22 +723,39 @@ void launch_pack(const float *src, int64_t sk, int64_t sn, int k_off, int n_off,
 __global__ __launch_bounds__(256) void narrow_forward_kernel(const float *X, int ldx, int64_t R, NarrowW w, int bias_period, float *Y, int ldy)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= R) return;
-    const f32x4v x = *(const f32x4v *)(X + r * ldx + 4 * lane);
-    for (int c = 0; c < w.nc; ++c) {
-        float s = 0.f;
+    float wv[4][4];                 // this lane's four input features of every output column
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (4 * lane + q < w.kcount) s = fmaf(x[q], w.w[c][(size_t)(4 * lane + q) * w.wstride], s);
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) Y[r * ldy + c] = s + ((w.b[c] && (r % bias_period) == 0) ? w.b[c][0] : 0.f);
+        for (int q = 0; q < 4; ++q) wv[c][q] = (c < w.nc && 4 * lane + q < w.kcount) ? w.w[c][(size_t)(4 * lane + q) * w.wstride] : 0.f;
+    const int64_t nw = (int64_t)gridDim.x * 4, w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int64_t base = w0 * 4; base < R; base += nw * 4) {         // four rows per wave per pass
+        f32x4v x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
+            x[u] = base + u < R ? *(const f32x4v *)(X + (base + u) * ldx + 4 * lane) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (base + u >= R) break;
+            for (int c = 0; c < w.nc; ++c) {
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s = fmaf(x[u][q], wv[c][q], s);
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+                if (lane == 0) Y[(base + u) * ldy + c] = s + ((w.b[c] && ((base + u) % bias_period) == 0) ? w.b[c][0] : 0.f);
+            }
+        }
     }
 }
 void launch_narrow_forward(const float *X, int ldx, int64_t R, const NarrowW &w, int bias_period, float *Y, int ldy, hipStream_t s)
 {
-    if (R > 0) hipLaunchKernelGGL(narrow_forward_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, X, ldx, R, w, bias_period, Y, ldy);
+    if (R <= 0) return;
+    int64_t wgs = (R + 15) / 16;
+    if (wgs > 8192) wgs = 8192;
+    hipLaunchKernelGGL(narrow_forward_kernel, dim3((unsigned)wgs), dim3(256), 0, s, X, ldx, R, w, bias_period, Y, ldy);
 }
 __global__ void narrow_backward_kernel(const float *G, int ldg, int64_t R, NarrowW w, float *dX, int ldx, int accumulate)
 {
