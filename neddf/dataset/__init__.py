@@ -1,1 +1,1 @@
-from neddf_amd.dataset import BaseDataset, NeRFSyntheticDataset  # noqa: F401
+from neddf_amd.dataset import BaseDataset, LLFFDataset, NeRFSyntheticDataset  # noqa: F401

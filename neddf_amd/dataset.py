@@ -95,3 +95,72 @@ class NeRFSyntheticDataset(BaseDataset):
     def __getitem__(self, item: int) -> Dict[str, ndarray]:
         return {"camera_calib_params": self.camera_calib_params, "camera_params": self.camera_params[item, :],
                 "rgb_images": self.rgb_images[item], "mask_images": self.mask_images[item]}
+
+
+class LLFFDataset(BaseDataset):
+    """Forward-facing captures in the LLFF layout (`poses_bounds.npy` + `images[_<factor>]/`), the data BASELINE.json
+    configs[4] names.  The reference has no such reader; this follows the published
+    preprocessing of the original NeRF release for these scenes:
+
+      * `poses_bounds.npy` rows = 3x5 camera-to-world matrix [R | t | (h, w, f)] + (near, far) depth bounds, rotation
+        columns in LLFF order (down, right, back) -> (right, up, back) as every other pose in this package;
+      * the scene is rescaled so that the nearest depth bound becomes 1 / bd_factor (bd_factor 0.75), which is what makes
+        near plane 1.0 valid for NDC rays (NeRFRender.ray_space = "ndc");
+      * poses are recentred on their average (mean position; mean viewing direction and up vector re-orthogonalised);
+      * every `hold`-th view (default 8) is the test split, the rest the training split.
+
+    Items have the keys of the other datasets: camera_calib_params [fx, fy, cx, cy], camera_params (rotation vector +
+    translation), rgb_images (BGR float, 0..255), mask_images (all 255: real photographs have no alpha)."""
+
+    def __init__(self, dataset_dir: str, data_split: str, use_depth: bool = False, use_mask: bool = False, factor: int = 1,
+                 bd_factor: float = 0.75, hold: int = 8) -> None:
+        self.factor, self.bd_factor, self.hold = factor, bd_factor, hold
+        self.bounds: ndarray = np.zeros((0, 2))
+        super().__init__(dataset_dir, data_split, use_depth, use_mask)
+
+    @staticmethod
+    def recenter(c2w: ndarray) -> ndarray:
+        """[n,3,4] camera-to-world matrices expressed in the frame of their average pose."""
+        center = c2w[:, :, 3].mean(0)
+        back = c2w[:, :, 2].sum(0)
+        back /= np.linalg.norm(back)
+        up = c2w[:, :, 1].sum(0)
+        right = np.cross(up, back)
+        right /= np.linalg.norm(right)
+        up = np.cross(back, right)
+        avg = np.eye(4)
+        avg[:3, :] = np.stack([right, up, back, center], 1)
+        inv = np.linalg.inv(avg)
+        full = np.tile(np.eye(4), (c2w.shape[0], 1, 1))
+        full[:, :3, :] = c2w
+        return (inv @ full)[:, :3, :]
+
+    def load_data(self) -> None:
+        arr = np.load(self.dataset_dir / "poses_bounds.npy")
+        poses = arr[:, :15].reshape(-1, 3, 5).astype(np.float64)
+        bounds = arr[:, 15:17].astype(np.float64)
+        img_dir = self.dataset_dir / ("images" if self.factor == 1 else "images_{}".format(self.factor))
+        files = sorted(f for f in img_dir.iterdir() if f.suffix.lower() in (".png", ".jpg", ".jpeg"))
+        assert len(files) == poses.shape[0], "{} images for {} poses".format(len(files), poses.shape[0])
+        c2w = np.concatenate([poses[:, :, 1:2], -poses[:, :, 0:1], poses[:, :, 2:4]], 2)       # (down, right, back) -> (right, up, back)
+        scale = 1.0 / (bounds.min() * self.bd_factor)
+        c2w[:, :, 3] *= scale
+        bounds = bounds * scale
+        c2w = self.recenter(c2w)
+        ids = [i for i in range(len(files)) if (i % self.hold == 0) == (self.data_split == "test")]
+        rgb = [imread_unchanged_bgr(files[i])[:, :, :3].astype(np.float32) for i in ids]
+        h, w = rgb[0].shape[:2]
+        focal = float(poses[0, 2, 4]) * w / float(poses[0, 1, 4])       # stored for the full-resolution width
+        params = np.zeros((len(ids), 6), np.float32)
+        for k, i in enumerate(ids):
+            params[k, :3] = Rotation.from_matrix(c2w[i, :, :3]).as_rotvec()
+            params[k, 3:] = c2w[i, :, 3]
+        self.camera_calib_params = np.array([focal, focal, 0.5 * w, 0.5 * h])
+        self.camera_params = params
+        self.rgb_images = np.stack(rgb, 0)
+        self.mask_images = 255 * np.ones(self.rgb_images.shape[:3], np.uint8)
+        self.bounds = bounds[ids]
+
+    def __getitem__(self, item: int) -> Dict[str, ndarray]:
+        return {"camera_calib_params": self.camera_calib_params, "camera_params": self.camera_params[item, :],
+                "rgb_images": self.rgb_images[item], "mask_images": self.mask_images[item]}

@@ -48,7 +48,7 @@ class NeRFRender(BaseNeuralRender):
 
     def __init__(self, network_config: Any, sample_coarse: int = 128, sample_fine: int = 128, dist_near: float = 2.0,
                  dist_far: float = 6.0, max_dist: float = 6.0, use_coarse_network: bool = True,
-                 sampling_type: SamplingType = "point") -> None:
+                 sampling_type: SamplingType = "point", ray_space: str = "world", ndc_near: float = 1.0) -> None:
         super().__init__()
         self.use_coarse_network = use_coarse_network
         self.network_fine: BaseNeuralField = instantiate(network_config)
@@ -63,8 +63,8 @@ class NeRFRender(BaseNeuralRender):
         self.sampling_type = sampling_type
         self.rng = "torch_cpu"
         self.rays_per_call = 1 << 16
-        self.ray_space = "world"
-        self.ndc_width, self.ndc_height, self.ndc_near = 0, 0, 1.0
+        self.ray_space = ray_space          # the two keywords after sampling_type are not reference keywords
+        self.ndc_width, self.ndc_height, self.ndc_near = 0, 0, ndc_near
 
     # ------------------------------------------------------------------ helpers
     def get_network(self) -> BaseNeuralField:

@@ -113,6 +113,8 @@ class NeRFTrainer(BaseTrainer):
         super().__init__(**kwargs)
         self.neural_render = instantiate(_get(self.config, "render"), network_config=to_plain(_get(self.config, "network")),
                                          _recursive_=False).to(self.device)
+        if getattr(self.neural_render, "ray_space", "world") == "ndc":      # forward-facing data: NDC of the full image
+            self.neural_render.ndc_width, self.neural_render.ndc_height = self.dataset.image_width, self.dataset.image_height
         self.optimizer = torch.optim.Adam(self.neural_render.get_parameters_list(), lr=self.optimizer_lr,
                                           weight_decay=self.optimizer_weight_decay)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=self.scheduler_lr)

@@ -214,3 +214,35 @@ def test_render_rays_ndc_bf16_end_to_end(dev, orc, bunny_weights):
         ref = orc.render_rays(net, net, uv, R, Tr, calib, u_c, u_f, 0.0, 1.0, 1.0, "point", ndc=(W, H, near))
         for k in ("color", "depth", "transmittance", "color_coarse", "depth_coarse", "transmittance_coarse"):
             assert_close(N(o[k]), ref[k], tol, tol * 0.1 + 1e-5, "%s %s" % (dtype, k))
+
+
+def test_llff_ndc_training_and_eval_flow(dev, tmp_path, monkeypatch, capsys):
+    """configs[4] as a workflow: LLFF-layout dataset -> scripts/run.py with NDC rays and a NeRF network pair (one epoch) ->
+    scripts/run_eval.py on the result."""
+    from PIL import Image
+    from scipy.spatial.transform import Rotation
+    from neddf_amd.scripts import run, run_eval
+    root = tmp_path / "data" / "fern"
+    (root / "images_4").mkdir(parents=True)
+    rng = np.random.default_rng(4)
+    rows = []
+    for i in range(9):
+        Rm = Rotation.from_euler("xyz", rng.normal(0, 0.05, 3)).as_matrix()
+        t = rng.normal(0, 0.3, 3) + np.array([0.0, 0.0, 3.0])
+        llff = np.concatenate([-Rm[:, 1:2], Rm[:, 0:1], Rm[:, 2:3], t[:, None], np.array([[64.0], [80.0], [260.0]])], 1)
+        rows.append(np.concatenate([llff.reshape(-1), [2.0, 20.0]]))
+        Image.fromarray(rng.integers(0, 256, (16, 20, 3), dtype=np.uint8)).save(root / "images_4" / ("img_%03d.png" % i))
+    np.save(root / "poses_bounds.npy", np.stack(rows))
+    monkeypatch.chdir(tmp_path)
+    run.seed_everything()
+    run.main(["trainer=test", "dataset=llff_fern", "dataset.dataset_dir=data/fern/", "render=llff_render", "network=nerf", "loss=nerf_loss",
+              "trainer.batch_size=16", "trainer.epoch_max=0", "trainer.epoch_save_model=1", "render.sample_coarse=16",
+              "render.sample_fine=24"])
+    rd = next((tmp_path / "outputs").glob("*/*"))
+    assert (rd / "models" / "model_00000.pth").is_file() and len(list((rd / "render" / "0000").glob("*_rgb.png"))) == 1
+    monkeypatch.chdir(tmp_path)
+    with torch.enable_grad():
+        pass
+    run_eval.main([str(rd), "--epoch", "0"])
+    out = capsys.readouterr().out
+    assert out.count("psnr:") == 2 and (rd / "eval" / "001_depth.png").is_file()
