@@ -472,3 +472,27 @@ def test_llff_dataset_reader(tmp_path):
     assert np.array_equal(item["rgb_images"], img[:, :, ::-1].astype(np.float32)) and (item["mask_images"] == 255).all()
     import neddf.dataset
     assert neddf.dataset.LLFFDataset is LLFFDataset
+
+
+def test_capi_rejects_null_context_without_touching_a_device():
+    """Every compute entry point returns NEDDF_EINVAL for a NULL context (no HIP call is made): the error path of the C ABI
+    is exercised on the CPU box too."""
+    import ctypes as C
+    from neddf_amd import _lib
+    lib = _lib.load()
+    skip = {"neddf_abi_version", "neddf_create", "neddf_destroy", "neddf_last_error", "neddf_device_cus"}
+    for name, res, args in _lib.SYMBOLS:
+        if name in skip:
+            continue
+        call = []
+        for a in args:
+            if a in (C.c_int, C.c_int64):
+                call.append(a(0))
+            elif a in (C.c_float, C.c_double):
+                call.append(a(0.0))
+            else:
+                call.append(None)          # every pointer argument, the context first
+        rc = getattr(lib, name)(*call)
+        assert rc == -1, (name, rc)
+    assert lib.neddf_last_error(None) is not None
+    assert lib.neddf_device_cus(None) == 0
