@@ -107,7 +107,7 @@ template <int MT, int WPS, class Ops>
 __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs a)
 {
     typedef typename Ops::act_t act_t;
-    typedef typename Ops::frag frag;
+    typedef typename Ops::bfrag frag;            // weight fragments
     constexpr int NT = 2, ROWS = MT * 32, P = MT * 8, LD = Ops::kLd;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     act_t *act = (act_t *)smem;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
         // Early partials of skip layers (neddf.py:217-219).  With one skip connection (every shipped
         // config) and the 64-row tile the partial stays in registers until its layer; otherwise it is
         // parked in the per-workgroup global scratch.
-        constexpr bool REG_STASH = (MT == 2) && (WPS <= 2);     // denser packings of a CU have no registers to spare
+        constexpr bool REG_STASH = (MT == 2) && (WPS <= 2) && !Ops::kLean;     // denser packings of a CU have no registers to spare
         const bool in_regs = REG_STASH && a.n_stash == 1;
         f32x16 held[REG_STASH ? MT : 1][REG_STASH ? NT : 1];
         for (int s = 0; s < a.n_stash; ++s) {
@@ -258,16 +258,16 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
         }
         // hand the trunk features to the colour kernel (value row, or all four rows in full mode)
         {
-            // 16-byte chunks; the feature matrix has the element type of the activations
-            constexpr int CE = 16 / sizeof(act_t), CPR = kWidth / CE;
+            // 16-byte chunks; the feature matrix has the element type (and the planes) of the activations, planes packed densely
+            constexpr int CE = 16 / sizeof(act_t), CPP = kWidth / CE, CPR = Ops::kPlanes * CPP;
             act_t *features = (act_t *)a.features;
             const int fr = a.feat_rows;
             for (int idx = tid; idx < P * fr * CPR; idx += kThreads) {
-                int r = idx / CPR, c4 = idx - r * CPR;
+                int r = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
                 int p = r / fr, rr = r - p * fr;
                 if (p0 + p < a.n_points) {
-                    f32x4v v = *(const f32x4v *)(act + (4 * p + rr) * LD + CE * c4);
-                    *(f32x4v *)(features + ((size_t)(p0 + p) * fr + rr) * kWidth + CE * c4) = v;
+                    f32x4v v = *(const f32x4v *)(act + (4 * p + rr) * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));
+                    *(f32x4v *)(features + ((size_t)(p0 + p) * fr + rr) * (Ops::kPlanes * kWidth) + CE * c4) = v;
                 }
             }
         }
@@ -285,7 +285,7 @@ template <bool ROWS4, int MT, int WPS, class Ops>
 __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs a)
 {
     typedef typename Ops::act_t act_t;
-    typedef typename Ops::frag frag;
+    typedef typename Ops::bfrag frag;            // weight fragments
     constexpr int NT = 2, ROWS = MT * 32, P = ROWS4 ? MT * 8 : ROWS, RPP = ROWS4 ? 4 : 1, LD = Ops::kLd;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     act_t *act = (act_t *)smem;
@@ -331,9 +331,13 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
         f32x16 acc[MT][NT];
         // layer 0, feature segment: in the eval-minimal 64-row tile the trunk features are requested now
         // (global -> VGPR) and land in LDS after the small-input dense; the other variants lack the registers
-        constexpr int CE = 16 / sizeof(act_t), CPR = kWidth / CE;     // 16-byte chunks per feature row
+        constexpr int CE = 16 / sizeof(act_t), CPP = kWidth / CE, CPR = Ops::kPlanes * CPP;     // 16-byte chunks per feature row
         constexpr int NF = ROWS * CPR / kThreads;
-        constexpr bool FPRE = (MT == 2) && !ROWS4;
+        auto lds_chunk = [&](int idx) {     // chunk idx of the tile -> its place in LDS (planes are kPlane elements apart)
+            const int r = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
+            return (f32x4v *)(act + r * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));
+        };
+        constexpr bool FPRE = (MT == 2) && !ROWS4 && !Ops::kLean;
         f32x4v fpre[FPRE ? NF : 1];
         auto feature_src = [&](int idx) {
             int r = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
             int64_t last = a.n_points * RPP - 1;
             if (grow > last) grow = last;
             int64_t src = ROWS4 ? grow : grow * a.feat_rows;      // value row of [n][feat_rows][256]
-            return (const f32x4v *)((const act_t *)a.features + (size_t)src * kWidth + CE * c4);
+            return (const f32x4v *)((const act_t *)a.features + (size_t)src * (Ops::kPlanes * kWidth) + CE * c4);
         };
         if constexpr (FPRE) {
 #pragma unroll
@@ -357,11 +361,11 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
                 int idx = tid + i * kThreads;
-                *(f32x4v *)(act + ((unsigned)idx / CPR) * LD + CE * ((unsigned)idx % CPR)) = fpre[i];
+                *lds_chunk(idx) = fpre[i];
             }
         } else {
             for (int idx = tid; idx < ROWS * CPR; idx += kThreads)
-                *(f32x4v *)(act + ((unsigned)idx / CPR) * LD + CE * ((unsigned)idx % CPR)) = *feature_src(idx);
+                *lds_chunk(idx) = *feature_src(idx);
         }
         __syncthreads();
         for (int l = 0; l < a.n_layers; ++l) {                     // neddf.py:254-256
@@ -623,9 +627,9 @@ static int bf16_wps()
     }
     return v;
 }
-int field_wgs_per_cu(int bf16) { return tile_mt() == 2 ? (bf16 ? bf16_wps() : 2) : 1; }
-int ddf_points_per_tile() { return tile_mt() * 8; }
-int col_points_per_tile(bool rows4) { return rows4 ? tile_mt() * 8 : tile_mt() * 32; }
+int field_wgs_per_cu(int bf16) { return tile_mt() == 2 ? (bf16 == 1 ? bf16_wps() : 2) : 1; }
+int ddf_points_per_tile(int) { return tile_mt() * 8; }
+int col_points_per_tile(bool rows4, int) { return rows4 ? tile_mt() * 8 : tile_mt() * 32; }
 int nerf_points_per_tile() { return tile_mt() * 32; }
 
 static void set_lds(const void *fn, size_t bytes)
@@ -640,7 +644,7 @@ static void launch_ddf_t(const DdfArgs &a, int grid, hipStream_t s)
                         set_lds((const void *)ddf_trunk_kernel<2, 2, Ops>, lds_bytes<Ops>(2)), true);
     (void)once;
     if (tile_mt() == 2) {
-        if constexpr (sizeof(typename Ops::act_t) == 2) {
+        if constexpr (sizeof(typename Ops::act_t) == 2 && Ops::kPlanes == 1) {
             static bool once2 = (set_lds((const void *)ddf_trunk_kernel<2, 3, Ops>, lds_bytes<Ops>(2)),
                                  set_lds((const void *)ddf_trunk_kernel<2, 4, Ops>, lds_bytes<Ops>(2)), true);
             (void)once2;
@@ -653,7 +657,8 @@ static void launch_ddf_t(const DdfArgs &a, int grid, hipStream_t s)
 
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
 {
-    if (a.bf16) launch_ddf_t<OpsBF16>(a, grid, s);
+    if (a.bf16 == 2) launch_ddf_t<OpsBF16Split>(a, grid, s);
+    else if (a.bf16) launch_ddf_t<OpsBF16>(a, grid, s);
     else launch_ddf_t<OpsF32>(a, grid, s);
 }
 
@@ -676,7 +681,8 @@ static void launch_col_t(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 {
-    if (a.bf16) launch_col_t<OpsBF16>(a, grid, rows4, s);
+    if (a.bf16 == 2) launch_col_t<OpsBF16Split>(a, grid, rows4, s);
+    else if (a.bf16) launch_col_t<OpsBF16>(a, grid, rows4, s);
     else launch_col_t<OpsF32>(a, grid, rows4, s);
 }
 

@@ -54,15 +54,17 @@ static inline uint16_t bf16_bits(float f)
 // a whole number of super-steps: 8 k-values for fp32 fragments (4 floats per lane half), 16 for bf16 (8 per lane half).
 static size_t pack_layer(std::vector<float> &blob, const Src &src, std::vector<int> kmap, int nout, int bf16, int *ksteps_out)
 {
-    const int step = bf16 ? 16 : 8, half = step / 2, NT = nout / 128;
+    // bf16 == 2: three bf16 planes (h, m, l with w = h + m + l to 24 bits) per fragment, 48 bytes per lane and super-step
+    const int step = bf16 ? 16 : 8, half = step / 2, NT = nout / 128, planes = bf16 == 2 ? 3 : 1;
     while (kmap.size() % step) kmap.push_back(-1);
     const int ks = (int)kmap.size() / step;
     if (ksteps_out) *ksteps_out = ks;
     size_t off = roundup((int)blob.size(), 64);
     const size_t elems = (size_t)ks * step * nout;
-    blob.resize(off + (bf16 ? elems / 2 : elems), 0.f);
+    blob.resize(off + (bf16 ? elems * planes / 2 : elems), 0.f);
     float *dst = blob.data() + off;
     uint16_t *dst16 = (uint16_t *)dst;
+    auto bf16_f = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
     for (int w = 0; w < kWaves; ++w)
         for (int t = 0; t < NT; ++t)
             for (int S = 0; S < ks; ++S)
@@ -71,9 +73,17 @@ static size_t pack_layer(std::vector<float> &blob, const Src &src, std::vector<i
                         int n = (w * NT + t) * 32 + (lane & 31);
                         int k = kmap[step * S + half * (lane >> 5) + r];
                         float v = k < 0 ? 0.f : src.at(k, n);
-                        size_t at = ((((size_t)(w * NT + t) * ks + S) * 64 + lane) * half) + r;
-                        if (bf16) dst16[at] = bf16_bits(v);
-                        else dst[at] = v;
+                        size_t frag = (((size_t)(w * NT + t) * ks + S) * 64 + lane);
+                        if (bf16 == 2) {
+                            uint16_t h = bf16_bits(v);
+                            float r1 = v - bf16_f(h);
+                            uint16_t m = bf16_bits(r1);
+                            uint16_t l = bf16_bits(r1 - bf16_f(m));
+                            dst16[(frag * 3 + 0) * half + r] = h;
+                            dst16[(frag * 3 + 1) * half + r] = m;
+                            dst16[(frag * 3 + 2) * half + r] = l;
+                        } else if (bf16) dst16[frag * half + r] = bf16_bits(v);
+                        else dst[frag * half + r] = v;
                     }
     return off;
 }
@@ -100,7 +110,7 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     const neddf_field_desc &d = f.d;
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n_trunk = d.layer_count - 1, n_col = d.col_layer_count - 1;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
-    const int bf16 = d.weight_dtype == NEDDF_DTYPE_BF16;
+    const int bf16 = d.weight_dtype;      // 0 fp32, 1 bf16, 2 split bf16
     if (n_tensors != n_trunk + n_col + 3) return fail(ctx, NEDDF_EINVAL, "NeDDF: wrong tensor count");
     if (n_trunk < 1 || n_trunk > kMaxLayers || n_col < 1 || n_col > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeDDF: layer count out of range");
     for (int i = 0; i < d.n_skips; ++i)
@@ -179,7 +189,7 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     const neddf_field_desc &d = f.d;
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n_sdf = d.layer_count, n_col = d.col_layer_count;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
-    const int bf16 = d.weight_dtype == NEDDF_DTYPE_BF16;
+    const int bf16 = d.weight_dtype;
     if (n_tensors != n_sdf + n_col + 2) return fail(ctx, NEDDF_EINVAL, "NeuS: wrong tensor count");
     if (n_sdf < 1 || n_sdf > kMaxLayers || n_col < 1 || n_col > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: layer count out of range");
     if (d.activation == NEDDF_ACT_LEAKY) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: activation must be ReLU or tanhExp");
@@ -348,7 +358,9 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     if (N <= 0) return 0;
     Field &f = ctx->field[slot];
     const int grid_cap = ctx->cus * field_wgs_per_cu();
-    const int grid_cap_ddf = ctx->cus * field_wgs_per_cu(f.d.weight_dtype == NEDDF_DTYPE_BF16);
+    const int dt = f.d.weight_dtype;
+    const int grid_cap_ddf = ctx->cus * field_wgs_per_cu(dt);
+    const int grid_cap_col = grid_cap;
     if (int rc = ensure(ctx, ctx->scratch, (size_t)grid_cap_ddf * kMaxStash * kStashFloatsPerWg * sizeof(float))) return rc;
     if (f.d.kind == NEDDF_FIELD_NERF) {
         NerfArgs a = f.nerf;
@@ -372,6 +384,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     const int fr = full ? 4 : 1;
     const int64_t chunk_cap = full ? (1 << 19) : (1 << 21);
     const int64_t chunk = N < chunk_cap ? N : chunk_cap;
+    // activations' element type and planes: fp32 1024 B, bf16 512 B, split bf16 (two planes) 1024 B per row
     if (int rc = ensure(ctx, ctx->features, (size_t)chunk * fr * kWidth * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ptaux, (size_t)chunk * kPtAux * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->sched, 2 * kSchedInts * sizeof(int))) return rc;
@@ -389,7 +402,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         a.distance = distance ? distance + off : nullptr;
         a.density = density ? density + off : nullptr;
         a.aux_grad = aux ? aux + off : nullptr;
-        int64_t tiles = (n + ddf_points_per_tile() - 1) / ddf_points_per_tile();
+        int64_t tiles = (n + ddf_points_per_tile(dt) - 1) / ddf_points_per_tile(dt);
         a.sched = (int *)ctx->sched.p;
         a.sched_flags = sched_flags();
         HIPCHK(hipMemsetAsync(a.sched, 0, kSchedInts * sizeof(int), s));
@@ -408,13 +421,13 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
                 if (int rc = ensure(ctx, ctx->arena, (size_t)chunk * 3 * sizeof(float))) return rc;
                 c.color = (float *)ctx->arena.p;
             }
-            int ppt = col_points_per_tile(full);
+            int ppt = col_points_per_tile(full, dt);
             int64_t ctiles = (n + ppt - 1) / ppt;
             c.sched = (int *)ctx->sched.p + kSchedInts;
             c.sched_flags = sched_flags();
             HIPCHK(hipMemsetAsync(c.sched, 0, kSchedInts * sizeof(int), s));
             tick(ctx, s, 1, true);
-            launch_col(c, (int)(ctiles < grid_cap ? ctiles : grid_cap), full, s);
+            launch_col(c, (int)(ctiles < grid_cap_col ? ctiles : grid_cap_col), full, s);
             tick(ctx, s, 1, false);
         }
     }
@@ -484,7 +497,7 @@ int neddf_set_field(neddf_ctx *ctx, int slot, const neddf_field_desc *desc, cons
     if (desc->n_skips < 0 || desc->n_skips > 8) return fail(ctx, NEDDF_EINVAL, "bad n_skips");
     if (desc->activation < 0 || desc->activation > 2 || desc->density_activation < 0 || desc->density_activation > 2)
         return fail(ctx, NEDDF_EINVAL, "bad activation id");
-    if (desc->weight_dtype != NEDDF_DTYPE_F32 && desc->weight_dtype != NEDDF_DTYPE_BF16) return fail(ctx, NEDDF_EINVAL, "bad weight_dtype");
+    if (desc->weight_dtype < NEDDF_DTYPE_F32 || desc->weight_dtype > NEDDF_DTYPE_BF16_SPLIT) return fail(ctx, NEDDF_EINVAL, "bad weight_dtype");
     Field &f = ctx->field[slot];
     HIPCHK(hipDeviceSynchronize());
     f.valid = false;

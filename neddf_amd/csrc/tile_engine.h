@@ -6,6 +6,10 @@
 //   OpsF32   activations fp32 in LDS, weights fp32, v_mfma_f32_32x32x2_f32 (exact fp32; the parity path)
 //   OpsBF16  activations bf16 in LDS, weights bf16, v_mfma_f32_32x32x16_bf16 with fp32 accumulation
 //            (BASELINE.json configs[4]: "bf16 MLP weights on MFMA"; 16x the fp32 matrix rate)
+//   OpsBF16Split  fp32-grade contraction on the bf16 matrix pipe: weights split into three bf16 terms (24 bits), activations
+//            into two (16 bits, rounded), a.w accumulated from the five products above 2^-24, each exact in the fp32
+//            accumulator.  5 MFMAs at 1/16 of the fp32 MFMA's cost each: 3.2x the fp32 matrix rate, errors within a small
+//            factor of the fp32 MFMA path's
 // Both read one 16-byte fragment per lane per super-step for A (ds_read_b128) and for B
 // (global_load_dwordx4); a super-step covers Ops::kStep values of k, lane half h = lane>>5
 // holding k = kStep*S + (kStep/2)*h ... +kStep/2-1 -- the same mapping for A and B, which is all
@@ -24,10 +28,16 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 struct OpsF32 {
     typedef float act_t;
     typedef f32x4v frag;
+    typedef frag afrag;                      // activation (A) and weight (B) fragments have the same type
+    typedef frag bfrag;
     static constexpr int kLd = kActLd;       // LDS row stride in elements (260 floats: conflict-free ds_read_b128)
     static constexpr int kStep = 8;          // k values per super-step
     static constexpr int kSub = 4;           // MFMA instructions per fragment
     static constexpr bool kFast = false;     // reference-exact elementwise math
+    static constexpr int kPlanes = 1, kPlane = 0;
+    static constexpr bool kLean = false;     // room for register-resident extras (skip partial, feature prefetch)
+    static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
+    static __device__ __forceinline__ void zero(act_t *p) { *p = 0.f; }
     static __device__ __forceinline__ void put(act_t *p, float v) { *p = v; }
     static __device__ __forceinline__ float get(const act_t *p) { return *p; }
     static __device__ __forceinline__ void load4(const act_t *p, float (&x)[4])
@@ -44,10 +54,16 @@ struct OpsF32 {
 struct OpsBF16 {
     typedef unsigned short act_t;            // bf16 bit pattern
     typedef bf16x8 frag;
+    typedef frag afrag;
+    typedef frag bfrag;
     static constexpr int kLd = 264;          // 528 B rows: same bank pattern as the fp32 tile (row stride = 4 dwords mod 64)
     static constexpr int kStep = 16;
     static constexpr int kSub = 1;
     static constexpr bool kFast = true;      // reduced-cost elementwise math (device_math.h), invisible after bf16 rounding
+    static constexpr int kPlanes = 1, kPlane = 0;
+    static constexpr bool kLean = false;
+    static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
+    static __device__ __forceinline__ void zero(act_t *p) { *p = 0; }
     static __device__ __forceinline__ unsigned short cvt(float v)       // round to nearest even (v_cvt_pk_bf16_f32)
     {
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -70,6 +86,59 @@ struct OpsBF16 {
     }
 };
 
+struct frag2 {
+    bf16x8 h, m;
+};
+struct frag3 {
+    bf16x8 h, m, l;
+};
+
+// Split-bf16 operands: activations a = h + m (16 mantissa bits, m rounded to nearest), weights w = h + m + l (24 bits),
+// a.w from the five products above 2^-24 (h.l, m.m, m.h, h.m, h.h), smallest first, each exact in the fp32 accumulator.
+// Two activation planes per row make the LDS tile the size of the fp32 one (two workgroups per CU).
+struct OpsBF16Split {
+    typedef unsigned short act_t;
+    typedef frag2 afrag;
+    typedef frag3 bfrag;
+    static constexpr int kPlanes = 2, kPlane = 264;      // a row = [h plane | m plane], 264 elements apart
+    static constexpr int kLd = 2 * 264;                  // 1056 B = 8 dwords mod 64
+    static constexpr int kStep = 16;
+    static constexpr int kSub = 5;
+    static constexpr bool kFast = false;
+    static constexpr bool kLean = true;      // 5 operand planes in flight per super-step: no registers to spare at 2 workgroups/CU
+    static __device__ __forceinline__ float f(unsigned short b) { return __builtin_bit_cast(float, (unsigned int)b << 16); }
+    static __device__ __forceinline__ void put(act_t *p, float v)
+    {
+        const unsigned int hb = __builtin_bit_cast(unsigned int, v) & 0xffff0000u;      // leading 8 bits: truncation, remainder exact
+        p[0] = (unsigned short)(hb >> 16);
+        p[kPlane] = OpsBF16::cvt(v - __builtin_bit_cast(float, hb));                    // next 8 bits, rounded to nearest even
+    }
+    static __device__ __forceinline__ void zero(act_t *p) { p[0] = 0; p[kPlane] = 0; }
+    static __device__ __forceinline__ float get(const act_t *p) { return f(p[kPlane]) + f(p[0]); }
+    static __device__ __forceinline__ void load4(const act_t *p, float (&x)[4])
+    {
+        u16x4 h = *(const u16x4 *)p, m = *(const u16x4 *)(p + kPlane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = f(m[i]) + f(h[i]);
+    }
+    static __device__ __forceinline__ afrag load_a(const act_t *p)
+    {
+        afrag a;
+        a.h = *(const bf16x8 *)p; a.m = *(const bf16x8 *)(p + kPlane);
+        return a;
+    }
+    static __device__ __forceinline__ f32x16 mfma(const afrag &a, const bfrag &b, const f32x16 &c, int r)
+    {
+        switch (r) {
+        case 0: return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c, 0, 0, 0);
+        case 1: return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, c, 0, 0, 0);
+        case 2: return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, c, 0, 0, 0);
+        case 3: return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, c, 0, 0, 0);
+        default: return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
+        }
+    }
+};
+
 // per-lane base of the A fragments of M-tile 0
 template <class Ops>
 __device__ __forceinline__ const typename Ops::act_t *act_lane_ptr(const typename Ops::act_t *act, int lane)
@@ -80,17 +149,17 @@ __device__ __forceinline__ const typename Ops::act_t *act_lane_ptr(const typenam
 // ----------------------------------------------------------------------------
 // dense: acc[mt][t] += act[rows, k0 .. k0+kStep*ksteps) x Wpacked
 template <int MT, int NT, class Ops = OpsF32>
-__device__ __forceinline__ void dense_load(typename Ops::frag (&a)[MT], typename Ops::frag (&b)[NT], const typename Ops::act_t *act_lane,
-                                           const typename Ops::frag *wl, int ksteps, int S)
+__device__ __forceinline__ void dense_load(typename Ops::afrag (&a)[MT], typename Ops::bfrag (&b)[NT], const typename Ops::act_t *act_lane,
+                                           const typename Ops::bfrag *wl, int ksteps, int S)
 {
 #pragma unroll
     for (int t = 0; t < NT; ++t) b[t] = wl[((size_t)t * ksteps + S) * 64];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const typename Ops::frag *)(act_lane + mt * 32 * Ops::kLd + Ops::kStep * S);
+    for (int mt = 0; mt < MT; ++mt) a[mt] = Ops::load_a(act_lane + mt * 32 * Ops::kLd + Ops::kStep * S);
 }
 
 template <int MT, int NT, class Ops = OpsF32>
-__device__ __forceinline__ void dense_mfma(f32x16 (&acc)[MT][NT], const typename Ops::frag (&a)[MT], const typename Ops::frag (&b)[NT])
+__device__ __forceinline__ void dense_mfma(f32x16 (&acc)[MT][NT], const typename Ops::afrag (&a)[MT], const typename Ops::bfrag (&b)[NT])
 {
 #pragma unroll
     for (int r = 0; r < Ops::kSub; ++r)
@@ -108,14 +177,14 @@ __device__ __forceinline__ void dense_mfma(f32x16 (&acc)[MT][NT], const typename
 // previous layer, so their L2 latency is off the critical path.
 template <int NT, class Ops = OpsF32>
 struct LayerPre {
-    typename Ops::frag b[NT];
+    typename Ops::bfrag b[NT];
     float bias[NT];
 };
 
 template <int NT, class Ops = OpsF32>
 __device__ __forceinline__ void layer_prefetch(LayerPre<NT, Ops> &p, const void *wp, const float *bias, int ksteps, int wave, int lane)
 {
-    const typename Ops::frag *wl = (const typename Ops::frag *)wp + (size_t)wave * NT * ksteps * 64 + lane;
+    const typename Ops::bfrag *wl = (const typename Ops::bfrag *)wp + (size_t)wave * NT * ksteps * 64 + lane;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         p.b[t] = wl[(size_t)t * ksteps * 64];
@@ -136,10 +205,11 @@ __device__ __forceinline__ void acc_init_pre(f32x16 (&acc)[MT][NT], const LayerP
 }
 
 template <int MT, int NT, class Ops = OpsF32>
-__device__ __forceinline__ void dense_pipeline(f32x16 (&acc)[MT][NT], typename Ops::frag (&a0)[MT], typename Ops::frag (&b0)[NT],
-                                               const typename Ops::act_t *act_lane, const typename Ops::frag *wl, int ksteps)
+__device__ __forceinline__ void dense_pipeline(f32x16 (&acc)[MT][NT], typename Ops::afrag (&a0)[MT], typename Ops::bfrag (&b0)[NT],
+                                               const typename Ops::act_t *act_lane, const typename Ops::bfrag *wl, int ksteps)
 {
-    typename Ops::frag a1[MT], b1[NT];
+    typename Ops::afrag a1[MT];
+    typename Ops::bfrag b1[NT];
     for (int S = 0; S < ksteps; S += 2) {
         const bool more = S + 1 < ksteps;
         dense_load<MT, NT, Ops>(a1, b1, act_lane, wl, ksteps, more ? S + 1 : S);
@@ -156,21 +226,23 @@ __device__ __forceinline__ void dense_pipeline(f32x16 (&acc)[MT][NT], typename O
 }
 
 template <int MT, int NT, class Ops = OpsF32>
-__device__ __forceinline__ void dense_pre(f32x16 (&acc)[MT][NT], const typename Ops::act_t *act_lane, const typename Ops::frag *wl,
+__device__ __forceinline__ void dense_pre(f32x16 (&acc)[MT][NT], const typename Ops::act_t *act_lane, const typename Ops::bfrag *wl,
                                           int ksteps, const LayerPre<NT, Ops> &p)
 {
-    typename Ops::frag a0[MT], b0[NT];
+    typename Ops::afrag a0[MT];
+    typename Ops::bfrag b0[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) b0[t] = p.b[t];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a0[mt] = *(const typename Ops::frag *)(act_lane + mt * 32 * Ops::kLd);
+    for (int mt = 0; mt < MT; ++mt) a0[mt] = Ops::load_a(act_lane + mt * 32 * Ops::kLd);
     dense_pipeline<MT, NT, Ops>(acc, a0, b0, act_lane, wl, ksteps);
 }
 
 template <int MT, int NT, class Ops = OpsF32>
-__device__ __forceinline__ void dense(f32x16 (&acc)[MT][NT], const typename Ops::act_t *act_lane, const typename Ops::frag *wl, int ksteps)
+__device__ __forceinline__ void dense(f32x16 (&acc)[MT][NT], const typename Ops::act_t *act_lane, const typename Ops::bfrag *wl, int ksteps)
 {
-    typename Ops::frag a0[MT], b0[NT];
+    typename Ops::afrag a0[MT];
+    typename Ops::bfrag b0[NT];
     dense_load<MT, NT, Ops>(a0, b0, act_lane, wl, ksteps, 0);
     dense_pipeline<MT, NT, Ops>(acc, a0, b0, act_lane, wl, ksteps);
 }
@@ -262,7 +334,7 @@ __device__ __forceinline__ void zero_cols(typename Ops::act_t *act, int rows, in
 {
     for (int i = tid; i < rows * ncols; i += kThreads) {
         int r = i / ncols, c = i - r * ncols;
-        act[r * Ops::kLd + c] = 0;
+        Ops::zero(act + r * Ops::kLd + c);
     }
 }
 

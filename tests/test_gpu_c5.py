@@ -246,3 +246,61 @@ def test_llff_ndc_training_and_eval_flow(dev, tmp_path, monkeypatch, capsys):
     run_eval.main([str(rd), "--epoch", "0"])
     out = capsys.readouterr().out
     assert out.count("psnr:") == 2 and (rd / "eval" / "001_depth.png").is_file()
+
+
+# ------------------------------------------------------------------ split-bf16 operands (fp32 data on the bf16 matrix pipe)
+@pytest.mark.parametrize("mode", ["full", "minimal"])
+def test_bf16_split_field_meets_the_fp32_gate(dev, orc, bunny_weights, mode):
+    """weight_dtype = "bf16_split": weights split into three bf16 terms, activations into two, five products per multiply-add,
+    fp32 accumulation.  Held to the SAME tolerances as the fp32 path (tests/test_gpu_parity.py) against the fp32 oracle."""
+    from neddf_amd import Sampling
+    pos, d, var = synth.random_sampling(40, 33, seed=21)
+    net = _net(dev, bunny_weights, "bf16_split", mode)
+    s = Sampling(T(pos, dev), T(d, dev), T(var, dev))
+    o = net(s)
+    ref = orc.NeDDFOracle(bunny_weights, **BUNNY_CFG).forward(pos, d, var)
+    net.weight_dtype = "fp32"
+    o32 = net(s)
+    tol = {"distance": (1e-4, 1e-6), "aux_grad": (1e-4, 1e-6), "color": (1e-4, 2e-5), "density": (1e-4, 3e-4), "fields_penalty": (2e-3, 1e-5)}
+    for k in o:
+        assert_close(N(o[k]), ref[k], *tol[k], "bf16_split " + k)
+        scale = np.abs(ref[k]).max()
+        print("%-14s bf16_split vs oracle %.2e, fp32 MFMA vs oracle %.2e (of max |value|)" % (
+            k, np.abs(N(o[k]) - ref[k]).max() / scale, np.abs(N(o32[k]) - ref[k]).max() / scale))
+
+
+def test_bf16_split_render_rays_end_to_end(dev, bunny_weights, bunny_stages):
+    """The golden 64-ray render of the reference (tests/test_gpu_parity.py::test_render_rays_end_to_end) with split-bf16 fields."""
+    import neddf_amd
+    g = bunny_stages
+    cfg = dict(BUNNY_CFG, _target_="neddf.network.NeDDF")
+    r = neddf_amd.NeRFRender(cfg, sample_coarse=64, sample_fine=128, dist_near=2.0, dist_far=6.0, max_dist=6.0,
+                             use_coarse_network=False, sampling_type="cone")
+    r.network_fine.load_state_dict({k: torch.from_numpy(v) for k, v in bunny_weights.items()})
+    r.to(dev)
+    r.set_iter(-1)
+    r.network_fine.weight_dtype = "bf16_split"
+    cam = neddf_amd.Camera(neddf_amd.PinholeCalib(g["calib"].astype(np.float64)), None).to(dev)
+    cam.R, cam.T = T(g["R"], dev), T(g["T"], dev)
+    o = r._render(r._ctx(dev), T(g["uv"], dev), cam, T(g["u_coarse"], dev), T(g["u_fine"], dev), full=True)
+    assert int(o["_nan"].item()) == 0
+    for k in ("color", "depth", "transmittance", "color_coarse", "depth_coarse", "transmittance_coarse"):
+        assert_close(N(o[k]), g["out_" + k], 1e-4, 1e-5, k)
+    mse = float(np.mean((N(o["color"]) - g["out_color"]) ** 2))
+    assert 10 * np.log10(1.0 / max(mse, 1e-20)) > 80.0
+
+
+def test_bf16_split_neus_and_other_ranks(dev):
+    import neddf_amd
+    from neddf_amd import Sampling
+    w = synth.neus_state()
+    net = neddf_amd.NeuS()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+    net.to(dev)
+    pos, d, var = synth.random_sampling(6, 30, seed=5, cone=False)
+    s = Sampling(T(pos, dev), T(d, dev), T(var, dev))
+    a = net(s)
+    net.weight_dtype = "bf16_split"
+    b = net(s)
+    for k in a:
+        assert_close(N(b[k]), N(a[k]), 1e-4, 2e-5, "NeuS " + k)
