@@ -34,6 +34,7 @@ struct OpsF32 {
     static constexpr int kStep = 8;          // k values per super-step
     static constexpr int kSub = 4;           // MFMA instructions per fragment
     static constexpr bool kFast = false;     // reference-exact elementwise math
+    static constexpr bool kFastAct = false;
     static constexpr int kPlanes = 1, kPlane = 0;
     static constexpr bool kLean = false;     // room for register-resident extras (skip partial, feature prefetch)
     static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
@@ -60,6 +61,7 @@ struct OpsBF16 {
     static constexpr int kStep = 16;
     static constexpr int kSub = 1;
     static constexpr bool kFast = true;      // reduced-cost elementwise math (device_math.h), invisible after bf16 rounding
+    static constexpr bool kFastAct = true;
     static constexpr int kPlanes = 1, kPlane = 0;
     static constexpr bool kLean = false;
     static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
@@ -104,7 +106,9 @@ struct OpsBF16Split {
     static constexpr int kLd = 2 * 264;                  // 1056 B = 8 dwords mod 64
     static constexpr int kStep = 16;
     static constexpr int kSub = 5;
-    static constexpr bool kFast = false;
+    static constexpr bool kFast = false;     // encodings with the accurate sin / cos / exp
+    static constexpr bool kFastAct = true;   // tanhExp without the small-argument polynomial: |error| ~ 1e-7 absolute, far below
+                                             // the 16-bit activation rounding that follows
     static constexpr bool kLean = true;      // 5 operand planes in flight per super-step: no registers to spare at 2 workgroups/CU
     static __device__ __forceinline__ float f(unsigned short b) { return __builtin_bit_cast(float, (unsigned int)b << 16); }
     static __device__ __forceinline__ void put(act_t *p, float v)
@@ -306,14 +310,14 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[MT][NT], typename O
             for (int g = 0; g < 4; ++g) {
                 if (ROWS4) {
                     float y, dy;
-                    act_grad<KIND, Ops::kFast>(acc[mt][t][4 * g], y, dy);
+                    act_grad<KIND, Ops::kFastAct>(acc[mt][t][4 * g], y, dy);
                     Ops::put(o + (8 * g + 0) * LD, y);
                     Ops::put(o + (8 * g + 1) * LD, dy * acc[mt][t][4 * g + 1]);
                     Ops::put(o + (8 * g + 2) * LD, dy * acc[mt][t][4 * g + 2]);
                     Ops::put(o + (8 * g + 3) * LD, dy * acc[mt][t][4 * g + 3]);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Ops::put(o + (8 * g + r) * LD, act_val<KIND, Ops::kFast>(acc[mt][t][4 * g + r]));
+                    for (int r = 0; r < 4; ++r) Ops::put(o + (8 * g + r) * LD, act_val<KIND, Ops::kFastAct>(acc[mt][t][4 * g + r]));
                 }
             }
         }
