@@ -69,7 +69,7 @@ typedef struct {
      * range_color, constraints_color; has[i]==0 leaves the term unweighted. */
     float penalty_weight[6];
     int penalty_has[6];
-    int weight_dtype;         /* NEDDF_DTYPE_*; the bf16 variants are implemented for NeDDF and NeuS fields */
+    int weight_dtype;         /* NEDDF_DTYPE_* */
 } neddf_field_desc;
 
 /* Pinhole camera: Camera.R / Camera.T (camera.py:117-118) and

@@ -448,44 +448,46 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
 
 // ----------------------------------------------------------------------------
 // plain NeRF field (nerf.py:139-165): value rows only, 128 points per tile
-template <int MT, int WPS>
+template <int MT, int WPS, class Ops>
 __global__ __launch_bounds__(kThreads, WPS) void nerf_kernel(const NerfArgs a)
 {
-    constexpr int NT = 2, ROWS = MT * 32, P = ROWS;
+    typedef typename Ops::act_t act_t;
+    typedef typename Ops::bfrag frag;            // weight fragments
+    constexpr int NT = 2, ROWS = MT * 32, P = ROWS, LD = Ops::kLd;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *act = smem;
-    float *hd = smem + ROWS * kActLd;       // [2][ROWS][3]
+    act_t *act = (act_t *)smem;
+    float *hd = (float *)(act + ROWS * LD);  // [2][ROWS][3]
     float *lp = hd + 2 * ROWS * 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *act_lane = act + (lane & 31) * kActLd + 4 * (lane >> 5);
+    const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
     float *scratch = a.scratch + (size_t)blockIdx.x * kStashFloatsPerWg * kMaxStash;
     if (tid == 0) {
 #pragma unroll
         for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
     }
-    const int c_dir = 2 * a.enc.KH;
-    const int kin = c_dir + ((2 * a.enc.KD + 7) & ~7);
+    const int c_dir = a.stash[a.col_stash].col0;                            // first column of the direction encoding
+    const int kin = c_dir + Ops::kStep * a.stash[a.col_stash].ksteps;
     const int64_t ntiles = (a.n_points + P - 1) / P;
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t p0 = tile * P;
-        zero_cols(act, ROWS, kin, tid);
+        zero_cols<Ops>(act, ROWS, kin, tid);
         __syncthreads();
-        encode_pos<false, false>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
-        encode_dir<false>(act, c_dir, a.enc, a.dir, p0, a.n_points, P, tid);
+        encode_pos<false, false, Ops>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
+        encode_dir<false, Ops>(act, c_dir, a.enc, a.dir, p0, a.n_points, P, tid);
         __syncthreads();
         f32x16 acc[MT][NT];
         for (int s = 0; s < a.n_stash; ++s) {
-            const f32x4v *wl = (const f32x4v *)a.stash[s].wp;
+            const frag *wl = (const frag *)a.stash[s].wp;
             float *slot = scratch + (size_t)s * kStashFloatsPerWg;
             if (s == a.col_stash) {         // colour head's view-direction segment: 128 outputs, NT = 1
                 f32x16 acc1[MT][1];
                 acc_init<MT, 1, false>(acc1, nullptr, wave, lane);
-                dense<MT, 1>(acc1, act_lane + a.stash[s].col0, wl + (size_t)wave * a.stash[s].ksteps * 64 + lane, a.stash[s].ksteps);
+                dense<MT, 1, Ops>(acc1, act_lane + a.stash[s].col0, wl + (size_t)wave * a.stash[s].ksteps * 64 + lane, a.stash[s].ksteps);
                 stash_store<MT, 1>(acc1, slot, wave, lane);
             } else {                        // skip layers: cat([hx, embed_pos]) (nerf.py:154-155)
                 acc_init<MT, NT, false>(acc, nullptr, wave, lane);
-                dense<MT, NT>(acc, act_lane + a.stash[s].col0, wl + (size_t)wave * NT * a.stash[s].ksteps * 64 + lane, a.stash[s].ksteps);
+                dense<MT, NT, Ops>(acc, act_lane + a.stash[s].col0, wl + (size_t)wave * NT * a.stash[s].ksteps * 64 + lane, a.stash[s].ksteps);
                 stash_store<MT, NT>(acc, slot, wave, lane);
             }
         }
@@ -493,19 +495,21 @@ __global__ __launch_bounds__(kThreads, WPS) void nerf_kernel(const NerfArgs a)
             const LayerW &L = a.layer[l];
             acc_init<MT, NT, false>(acc, L.bias, wave, lane);
             if (L.stash >= 0) stash_add<MT, NT>(acc, scratch + (size_t)L.stash * kStashFloatsPerWg, wave, lane);
-            dense<MT, NT>(acc, act_lane, (const f32x4v *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane, L.ksteps);
+            dense<MT, NT, Ops>(acc, act_lane, (const frag *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane, L.ksteps);
             __syncthreads();
-            epilogue_rt<MT, NT, false>(acc, act, a.activation, wave, lane);
+            epilogue_rt<MT, NT, false, Ops>(acc, act, a.activation, wave, lane);
             __syncthreads();
         }
         // density head (nerf.py:156)
         if (tid < ROWS) {
-            const f32x4v *ar = (const f32x4v *)(act + tid * kActLd);
+            const act_t *ar = act + tid * LD;
             const f32x4v *w = (const f32x4v *)a.w_density;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
             for (int k = 0; k < kWidth / 4; ++k) {
-                f32x4v x = ar[k], ww = w[k];
+                float x[4];
+                Ops::load4(ar + 4 * k, x);
+                f32x4v ww = w[k];
                 s0 = fmaf(x[0], ww[0], s0); s1 = fmaf(x[1], ww[1], s1);
                 s2 = fmaf(x[2], ww[2], s2); s3 = fmaf(x[3], ww[3], s3);
             }
@@ -517,18 +521,19 @@ __global__ __launch_bounds__(kThreads, WPS) void nerf_kernel(const NerfArgs a)
             f32x16 acc1[MT][1];
             acc_init<MT, 1, false>(acc1, a.col0.bias, wave, lane);
             stash_add<MT, 1>(acc1, scratch + (size_t)a.col_stash * kStashFloatsPerWg, wave, lane);
-            dense<MT, 1>(acc1, act_lane, (const f32x4v *)a.col0.wp + (size_t)wave * a.col0.ksteps * 64 + lane, a.col0.ksteps);
+            dense<MT, 1, Ops>(acc1, act_lane, (const frag *)a.col0.wp + (size_t)wave * a.col0.ksteps * 64 + lane, a.col0.ksteps);
             __syncthreads();
-            epilogue<MT, 1, false, 0>(acc1, act, wave, lane);
+            epilogue<MT, 1, false, 0, Ops>(acc1, act, wave, lane);
             __syncthreads();
         }
         for (int idx = tid; idx < 2 * ROWS; idx += kThreads) {
             int half = idx / ROWS, row = idx - half * ROWS;
-            const f32x4v *ar = (const f32x4v *)(act + row * kActLd + half * 64);
+            const act_t *ar = act + row * LD + half * 64;
             float c[3] = { 0.f, 0.f, 0.f };
 #pragma unroll 4
             for (int k = 0; k < 16; ++k) {
-                f32x4v x = ar[k];
+                float x[4];
+                Ops::load4(ar + 4 * k, x);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -686,13 +691,21 @@ void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)
     else launch_col_t<OpsF32>(a, grid, rows4, s);
 }
 
+template <class Ops>
+static void launch_nerf_t(const NerfArgs &a, int grid, hipStream_t s)
+{
+    static bool once = (set_lds((const void *)nerf_kernel<4, 1, Ops>, lds_bytes<Ops>(4)),
+                        set_lds((const void *)nerf_kernel<2, 2, Ops>, lds_bytes<Ops>(2)), true);
+    (void)once;
+    if (tile_mt() == 2) hipLaunchKernelGGL((nerf_kernel<2, 2, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a);
+    else hipLaunchKernelGGL((nerf_kernel<4, 1, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(4), s, a);
+}
+
 void launch_nerf(const NerfArgs &a, int grid, hipStream_t s)
 {
-    static bool once = (set_lds((const void *)nerf_kernel<4, 1>, field_lds_bytes(4)),
-                        set_lds((const void *)nerf_kernel<2, 2>, field_lds_bytes(2)), true);
-    (void)once;
-    if (tile_mt() == 2) hipLaunchKernelGGL((nerf_kernel<2, 2>), dim3(grid), dim3(kThreads), field_lds_bytes(2), s, a);
-    else hipLaunchKernelGGL((nerf_kernel<4, 1>), dim3(grid), dim3(kThreads), field_lds_bytes(4), s, a);
+    if (a.bf16 == 2) launch_nerf_t<OpsBF16Split>(a, grid, s);
+    else if (a.bf16) launch_nerf_t<OpsBF16>(a, grid, s);
+    else launch_nerf_t<OpsF32>(a, grid, s);
 }
 
 }  // namespace neddf

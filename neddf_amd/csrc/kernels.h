@@ -113,6 +113,7 @@ struct NerfArgs {
     LayerW col0;                          // outL_color.0: 256(+dir) -> 128
     const float *w_col1;                  // [3][128] (nn.Linear layout)
     float b_col1[3];
+    int bf16;                             // as DdfArgs::bf16
     float *scratch;
     float *density, *color;
 };

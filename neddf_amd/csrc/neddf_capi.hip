@@ -269,8 +269,7 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     const neddf_field_desc &d = f.d;
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n = d.layer_count;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
-    const int bf16 = 0;
-    if (d.weight_dtype != NEDDF_DTYPE_F32) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: bf16 operands are implemented for NeDDF and NeuS fields");
+    const int bf16 = d.weight_dtype, step = bf16 ? 16 : 8;
     if (n_tensors != n + 3) return fail(ctx, NEDDF_EINVAL, "NeRF: wrong tensor count");
     if (n < 1 || n > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: layer count out of range");
     for (int i = 0; i < d.n_skips; ++i)
@@ -309,12 +308,10 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     std::vector<int> km, kd;
     for (int k = 0; k < kWidth; ++k) km.push_back(k);
     enc_map(kd, Ed, KD, kWidth);
-    while (kd.size() % 8) kd.push_back(-1);
-    size_t o_c0 = pack_layer(blob, sc, km, kWidth / 2, 0, nullptr);
-    size_t o_c0s = pack_layer(blob, sc, kd, kWidth / 2, 0, nullptr);
+    size_t o_c0 = pack_layer(blob, sc, km, kWidth / 2, bf16, &a.col0.ksteps);
     a.col_stash = a.n_stash;
-    a.stash[a.n_stash].col0 = 2 * KH;
-    a.stash[a.n_stash].ksteps = (int)kd.size() / 8;
+    size_t o_c0s = pack_layer(blob, sc, kd, kWidth / 2, bf16, &a.stash[a.n_stash].ksteps);
+    a.stash[a.n_stash].col0 = roundup(2 * KH, step);          // direction encoding: first super-step boundary after the position encoding
     a.n_stash++;
     size_t o_c0b = put(blob, B[n + 1], kWidth / 2);
     size_t o_c1 = put(blob, W[n + 2], 3 * (kWidth / 2));
@@ -327,10 +324,11 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     for (int s = 0; s + 1 < a.n_stash; ++s) a.stash[s].wp = base + o_st[s];
     a.stash[a.col_stash].wp = base + o_c0s;
     a.w_density = base + o_wd;
-    a.col0.wp = base + o_c0; a.col0.bias = base + o_c0b; a.col0.ksteps = 32; a.col0.stash = a.col_stash;
+    a.col0.wp = base + o_c0; a.col0.bias = base + o_c0b; a.col0.stash = a.col_stash;
     a.w_col1 = base + o_c1;
     a.activation = d.activation;
     a.density_activation = d.density_activation;
+    a.bf16 = bf16;
     return 0;
 }
 

@@ -175,14 +175,25 @@ def test_bf16_neus_close_to_fp32(dev):
         assert not torch.equal(a[k], b[k])
 
 
-def test_bf16_nerf_is_refused(dev):
+@pytest.mark.parametrize("act,dact", [("ReLU", "ReLU"), ("tanhExp", "LeakyReLU")])
+def test_nerf_field_operand_policies(dev, orc, act, dact):
+    """The plain NeRF field kernel under the three operand policies: split-bf16 meets the fp32 gate, bf16 stays within 1e-2."""
     import neddf_amd
     from neddf_amd import Sampling
-    net = neddf_amd.NeRF().to(dev)
-    net.weight_dtype = "bf16"
-    pos, d, var = synth.random_sampling(2, 4, seed=1)
-    with pytest.raises(neddf_amd.NeddfError):
-        net(Sampling(T(pos, dev), T(d, dev), T(var, dev)))
+    w = synth.nerf_state(seed=11)
+    net = neddf_amd.NeRF(activation_type=act, density_activation_type=dact)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    net.to(dev)
+    net.set_iter(-1)
+    pos, d, var = synth.random_sampling(7, 50, seed=3)
+    s = Sampling(T(pos, dev), T(d, dev), T(var, dev))
+    ref = orc.NeRFOracle(w, activation_type=act, density_activation_type=dact).forward(pos, d, var)
+    for dtype, rtol, atol in (("fp32", 1e-4, 2e-5), ("bf16_split", 1e-4, 1e-4), ("bf16", 3e-2, 3e-2)):
+        net.weight_dtype = dtype
+        o = net(s)
+        for k in ("density", "color"):
+            scale = np.abs(ref[k]).max()
+            assert_close(N(o[k]) / scale, ref[k] / scale, rtol, atol, "%s %s" % (dtype, k))
 
 
 def test_render_rays_ndc_bf16_end_to_end(dev, orc, bunny_weights):

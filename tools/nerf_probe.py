@@ -22,15 +22,19 @@ def run(net, label, flop):
         net(smp)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
-    print("%-28s %8.2f ms  %6.2f Mpoints/s  %6.1f TFLOP/s (algorithmic %.3f MFLOP/point)" % (label, dt * 1e3, N / dt / 1e6, N * flop / dt / 1e12, flop / 1e6))
+    print("%-36s %8.2f ms  %6.2f Mpoints/s  %6.1f TFLOP/s (algorithmic %.3f MFLOP/point)" % (label, dt * 1e3, N / dt / 1e6, N * flop / dt / 1e12, flop / 1e6))
 
-nerf = neddf_amd.NeRF()
-nerf.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_state().items()}); nerf.to(dev); nerf.set_iter(-1)
-run(nerf, "NeRF 8x256 (value only)", 2 * 525952)
 w = golden("bunny_weights.npz")
-net = neddf_amd.NeDDF(**BUNNY_CFG)
-net.load_state_dict({k: torch.from_numpy(w[k]) for k in w.files}); net.to(dev); net.set_iter(-1)
-net.output_mode = "minimal"
-run(net, "NeDDF eval-minimal", 2 * (4 * (423936 + 256) + 256 + 219648 + 768))
-net.output_mode = "full"
-run(net, "NeDDF full (with penalties)", 2 * 4 * (423936 + 512 + 219648 + 768))
+for dtype in ("fp32", "bf16_split", "bf16"):
+    with torch.no_grad():
+        nerf = neddf_amd.NeRF()
+        nerf.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_state().items()}); nerf.to(dev); nerf.set_iter(-1)
+        nerf.weight_dtype = dtype
+        run(nerf, "NeRF 8x256 (value only) " + dtype, 2 * 525952)
+        net = neddf_amd.NeDDF(**BUNNY_CFG)
+        net.load_state_dict({k: torch.from_numpy(w[k]) for k in w.files}); net.to(dev); net.set_iter(-1)
+        net.weight_dtype = dtype
+        net.output_mode = "minimal"
+        run(net, "NeDDF eval-minimal " + dtype, 2 * (4 * (423936 + 256) + 256 + 219648 + 768))
+        net.output_mode = "full"
+        run(net, "NeDDF full (penalties) " + dtype, 2 * 4 * (423936 + 512 + 219648 + 768))
