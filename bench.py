@@ -192,9 +192,9 @@ def main():
                     help="c2 = BASELINE configs[1] (headline, default); c3 = configs[2], 65 coarse + 129 importance samples; "
                          "c5 = configs[4], 1008x756 forward-facing view, NDC rays, hierarchical sampling, bf16 operands; "
                          "train = one training step (SURVEY 8f item 2): 1024 rays x (65 + 194) samples, losses, backward, Adam")
-    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16_split"], default=None,
-                    help="operand type of the 256-wide layers (default f32 = fp32 MFMA; c5 defaults to bf16; bf16_split = fp32 data, "
-                         "split-bf16 operands (weights 3 terms, activations 2), five bf16 MFMAs per multiply-add)")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f16_split"], default=None,
+                    help="operand type of the 256-wide layers (default f32 = fp32 MFMA; c5 defaults to bf16; f16_split = fp32 data, "
+                         "operands split into two fp16 terms, three fp16 MFMAs per multiply-add)")
     args = ap.parse_args()
     if args.dtype is None:
         args.dtype = "bf16" if args.workload == "c5" else "f32"
@@ -230,7 +230,7 @@ def main():
             print(json.dumps(line), flush=True)
         return
     render, weights = build_render(dev)
-    render.network_fine.weight_dtype = {"f32": "fp32", "bf16": "bf16", "bf16_split": "bf16_split"}[args.dtype]
+    render.network_fine.weight_dtype = {"f32": "fp32", "bf16": "bf16", "f16_split": "f16_split"}[args.dtype]
     fx = 0.5 * WIDTH / math.tan(0.5 * CAMERA_ANGLE_X)
     calib = np.array([fx, fx, WIDTH / 2.0, HEIGHT / 2.0])
     R, T = view_pose(rank)
@@ -299,8 +299,8 @@ def main():
         peak = PEAK_FP32_MFMA_TFLOPS
         if args.dtype == "bf16":
             peak = PEAK_BF16_MFMA_TFLOPS
-        elif args.dtype == "bf16_split":  # five bf16 products per multiply-add: the algorithmic flops are priced at a fifth of the bf16 peak
-            peak = PEAK_BF16_MFMA_TFLOPS / 5
+        elif args.dtype == "f16_split":   # three fp16 products per multiply-add (fp16 and bf16 MFMA run at the same rate)
+            peak = PEAK_BF16_MFMA_TFLOPS / 3
         line = {
             "metric": {"c2": "rendered rays/sec (800x800, 128 samples/ray)",
                        "c3": "rendered rays/sec (800x800, 65 coarse + 194 fine hierarchical samples/ray)",

@@ -35,10 +35,10 @@ enum { NEDDF_ACT_RELU = 0, NEDDF_ACT_LEAKY = 1, NEDDF_ACT_TANHEXP = 2 };
 /* operand type of the 256-wide dense layers: fp32 (exact, the parity path) or bf16 weights + bf16 activations with
  * fp32 accumulation on v_mfma_f32_32x32x16_bf16 (BASELINE.json configs[4]); heads, biases, encodings stay fp32 */
 enum { NEDDF_DTYPE_F32 = 0, NEDDF_DTYPE_BF16 = 1,
-       /* fp32 weights and activations contracted on the bf16 matrix pipe: weights split into three bf16 terms (24 bits),
-        * activations into two (16 bits), the five products above 2^-24 accumulated in fp32.  Errors ~3e-5 of an output's range;
-        * meets the 1e-4 parity gate of the fp32 path at 1.7x its throughput */
-       NEDDF_DTYPE_BF16_SPLIT = 2 };
+       /* fp32 weights and activations contracted on the fp16 matrix instructions: every operand split into two fp16 terms
+        * (21-22 bits), the three products above 2^-22 accumulated in fp32; weights pre-scaled by 2^10 to stay in fp16's normal
+        * range.  Errors at the level of the fp32 MFMA path's own, 2.5x its throughput; operands beyond +-65504 saturate */
+       NEDDF_DTYPE_F16_SPLIT = 2 };
 enum { NEDDF_SLOT_COARSE = 0, NEDDF_SLOT_FINE = 1, NEDDF_NUM_SLOTS = 4 };
 /* uv element types accepted by neddf_raygen (the reference takes int64 in
  * render_image, int16 in training, float in its tests) */

@@ -15,7 +15,7 @@ ABI_VERSION = 2
 
 FIELD_NEDDF, FIELD_NERF, FIELD_NEUS = 0, 1, 2
 ACT = {"ReLU": 0, "LeakyReLU": 1, "tanhExp": 2}
-DTYPE = {"fp32": 0, "bf16": 1, "bf16_split": 2}
+DTYPE = {"fp32": 0, "bf16": 1, "f16_split": 2}
 SLOT_COARSE, SLOT_FINE, SLOT_GENERIC = 0, 1, 2
 OUT_MINIMAL, OUT_FULL = 0, 1
 UV_TYPES = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.int16: 3}

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
             for (int i = 0; i < NF; ++i) fpre[i] = *feature_src(tid + i * kThreads);
             __builtin_amdgcn_sched_barrier(0);
         }
-        acc_init<MT, NT, ROWS4>(acc, a.layer[0].bias, wave, lane);
+        acc_init<MT, NT, ROWS4>(acc, a.layer[0].bias, wave, lane, Ops::kWScale);
         dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wp_a + (size_t)wave * NT * a.ksteps_a * 64 + lane, a.ksteps_a);
         LayerPre<NT, Ops> pre;
         layer_prefetch<NT, Ops>(pre, a.layer[0].wp, nullptr, a.layer[0].ksteps, wave, lane);
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(kThreads, WPS) void nerf_kernel(const NerfArgs a)
         }
         for (int l = 0; l < a.n_layers; ++l) {
             const LayerW &L = a.layer[l];
-            acc_init<MT, NT, false>(acc, L.bias, wave, lane);
+            acc_init<MT, NT, false>(acc, L.bias, wave, lane, Ops::kWScale);
             if (L.stash >= 0) stash_add<MT, NT>(acc, scratch + (size_t)L.stash * kStashFloatsPerWg, wave, lane);
             dense<MT, NT, Ops>(acc, act_lane, (const frag *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane, L.ksteps);
             __syncthreads();
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(kThreads, WPS) void nerf_kernel(const NerfArgs a)
         // colour head: Linear(256+dir, 128) -> ReLU -> Linear(128, 3) (nerf.py:99-103,158-159)
         {
             f32x16 acc1[MT][1];
-            acc_init<MT, 1, false>(acc1, a.col0.bias, wave, lane);
+            acc_init<MT, 1, false>(acc1, a.col0.bias, wave, lane, Ops::kWScale);
             stash_add<MT, 1>(acc1, scratch + (size_t)a.col_stash * kStashFloatsPerWg, wave, lane);
             dense<MT, 1, Ops>(acc1, act_lane, (const frag *)a.col0.wp + (size_t)wave * a.col0.ksteps * 64 + lane, a.col0.ksteps);
             __syncthreads();
@@ -662,7 +662,7 @@ static void launch_ddf_t(const DdfArgs &a, int grid, hipStream_t s)
 
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
 {
-    if (a.bf16 == 2) launch_ddf_t<OpsBF16Split>(a, grid, s);
+    if (a.bf16 == 2) launch_ddf_t<OpsF16Split>(a, grid, s);
     else if (a.bf16) launch_ddf_t<OpsBF16>(a, grid, s);
     else launch_ddf_t<OpsF32>(a, grid, s);
 }
@@ -686,7 +686,7 @@ static void launch_col_t(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 {
-    if (a.bf16 == 2) launch_col_t<OpsBF16Split>(a, grid, rows4, s);
+    if (a.bf16 == 2) launch_col_t<OpsF16Split>(a, grid, rows4, s);
     else if (a.bf16) launch_col_t<OpsBF16>(a, grid, rows4, s);
     else launch_col_t<OpsF32>(a, grid, rows4, s);
 }
@@ -703,7 +703,7 @@ static void launch_nerf_t(const NerfArgs &a, int grid, hipStream_t s)
 
 void launch_nerf(const NerfArgs &a, int grid, hipStream_t s)
 {
-    if (a.bf16 == 2) launch_nerf_t<OpsBF16Split>(a, grid, s);
+    if (a.bf16 == 2) launch_nerf_t<OpsF16Split>(a, grid, s);
     else if (a.bf16) launch_nerf_t<OpsBF16>(a, grid, s);
     else launch_nerf_t<OpsF32>(a, grid, s);
 }

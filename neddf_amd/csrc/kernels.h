@@ -58,7 +58,7 @@ struct DdfArgs {
     const float *w_ddf_out, *w_aux_out;   // [256] each
     float b_ddf_out, b_aux_out;
     float d_near, aux_grad_scale;
-    int bf16;                             // operands: 0 fp32 (32x32x2 f32 MFMA), 1 bf16, 2 split bf16 (32x32x16 bf16 MFMA, five products per multiply-add), see tile_engine.h
+    int bf16;                             // operands: 0 fp32 (32x32x2 f32 MFMA), 1 bf16, 2 split fp16 (three fp16 products per multiply-add), see tile_engine.h
     int neus;                             // 1: NeuS sdf trunk (neus.py:118-145): plain PE, no heads, sdf = feature 0
     float neus_v10;                       // variance * 10
     float *scratch;                       // per-workgroup stash area

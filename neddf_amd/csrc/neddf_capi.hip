@@ -50,12 +50,41 @@ static inline uint16_t bf16_bits(float f)
     return (uint16_t)(u >> 16);
 }
 
+// fp32 -> IEEE half bit pattern, round to nearest even (toward_zero = false) or toward zero (true; never overflows to inf)
+static inline uint16_t f16_bits(float f, bool toward_zero)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) return (uint16_t)(sign | (u > 0x7f800000u ? 0x7e00u : (toward_zero ? 0x7bffu : 0x7c00u)));
+    if (u >= 0x477ff000u) {                                     // >= 65520: beyond the largest half
+        if (toward_zero || u < 0x477ff000u) return (uint16_t)(sign | 0x7bffu);
+        return (uint16_t)(sign | (toward_zero ? 0x7bffu : 0x7c00u));
+    }
+    if (u < 0x33000000u) return (uint16_t)sign;                 // < 2^-25: rounds to zero
+    int e = (int)(u >> 23) - 127;
+    uint32_t man = (u & 0x7fffffu) | 0x800000u;                 // 24-bit significand
+    int shift = e >= -14 ? 13 : 13 + (-14 - e);                 // bits dropped (subnormal halves drop more)
+    uint32_t q = man >> shift, rem = man & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+    if (!toward_zero && (rem > halfway || (rem == halfway && (q & 1)))) ++q;
+    uint32_t h = e >= -14 ? (uint32_t)((e + 15) << 10) + (q - 0x400u) : q;      // q carries into the exponent on overflow
+    return (uint16_t)(sign | h);
+}
+
+static inline float f16_value(uint16_t h)
+{
+    const int e = (h >> 10) & 31, m = h & 0x3ff;
+    float v = e == 0 ? ldexpf((float)m, -24) : ldexpf((float)(m | 0x400), e - 25);
+    return (h & 0x8000) ? -v : v;
+}
+
 // fragment-major packing, see kernels.h LayerW.  kmap (engine column -> reference weight row, -1 = zero) is padded to
 // a whole number of super-steps: 8 k-values for fp32 fragments (4 floats per lane half), 16 for bf16 (8 per lane half).
 static size_t pack_layer(std::vector<float> &blob, const Src &src, std::vector<int> kmap, int nout, int bf16, int *ksteps_out)
 {
-    // bf16 == 2: three bf16 planes (h, m, l with w = h + m + l to 24 bits) per fragment, 48 bytes per lane and super-step
-    const int step = bf16 ? 16 : 8, half = step / 2, NT = nout / 128, planes = bf16 == 2 ? 3 : 1;
+    // bf16 == 2 (split fp16): two fp16 planes of 2^10 w (h toward zero, m = remainder to nearest), 32 bytes per lane and super-step
+    const int step = bf16 ? 16 : 8, half = step / 2, NT = nout / 128, planes = bf16 == 2 ? 2 : 1;
     while (kmap.size() % step) kmap.push_back(-1);
     const int ks = (int)kmap.size() / step;
     if (ksteps_out) *ksteps_out = ks;
@@ -64,7 +93,6 @@ static size_t pack_layer(std::vector<float> &blob, const Src &src, std::vector<i
     blob.resize(off + (bf16 ? elems * planes / 2 : elems), 0.f);
     float *dst = blob.data() + off;
     uint16_t *dst16 = (uint16_t *)dst;
-    auto bf16_f = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
     for (int w = 0; w < kWaves; ++w)
         for (int t = 0; t < NT; ++t)
             for (int S = 0; S < ks; ++S)
@@ -75,13 +103,10 @@ static size_t pack_layer(std::vector<float> &blob, const Src &src, std::vector<i
                         float v = k < 0 ? 0.f : src.at(k, n);
                         size_t frag = (((size_t)(w * NT + t) * ks + S) * 64 + lane);
                         if (bf16 == 2) {
-                            uint16_t h = bf16_bits(v);
-                            float r1 = v - bf16_f(h);
-                            uint16_t m = bf16_bits(r1);
-                            uint16_t l = bf16_bits(r1 - bf16_f(m));
-                            dst16[(frag * 3 + 0) * half + r] = h;
-                            dst16[(frag * 3 + 1) * half + r] = m;
-                            dst16[(frag * 3 + 2) * half + r] = l;
+                            const float sv = v * 1024.0f;
+                            uint16_t h = f16_bits(sv, true);
+                            dst16[(frag * 2 + 0) * half + r] = h;
+                            dst16[(frag * 2 + 1) * half + r] = f16_bits(sv - f16_value(h), false);
                         } else if (bf16) dst16[frag * half + r] = bf16_bits(v);
                         else dst[frag * half + r] = v;
                     }
@@ -110,7 +135,7 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     const neddf_field_desc &d = f.d;
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n_trunk = d.layer_count - 1, n_col = d.col_layer_count - 1;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
-    const int bf16 = d.weight_dtype;      // 0 fp32, 1 bf16, 2 split bf16
+    const int bf16 = d.weight_dtype;      // 0 fp32, 1 bf16, 2 split fp16
     if (n_tensors != n_trunk + n_col + 3) return fail(ctx, NEDDF_EINVAL, "NeDDF: wrong tensor count");
     if (n_trunk < 1 || n_trunk > kMaxLayers || n_col < 1 || n_col > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeDDF: layer count out of range");
     for (int i = 0; i < d.n_skips; ++i)
@@ -495,7 +520,7 @@ int neddf_set_field(neddf_ctx *ctx, int slot, const neddf_field_desc *desc, cons
     if (desc->n_skips < 0 || desc->n_skips > 8) return fail(ctx, NEDDF_EINVAL, "bad n_skips");
     if (desc->activation < 0 || desc->activation > 2 || desc->density_activation < 0 || desc->density_activation > 2)
         return fail(ctx, NEDDF_EINVAL, "bad activation id");
-    if (desc->weight_dtype < NEDDF_DTYPE_F32 || desc->weight_dtype > NEDDF_DTYPE_BF16_SPLIT) return fail(ctx, NEDDF_EINVAL, "bad weight_dtype");
+    if (desc->weight_dtype < NEDDF_DTYPE_F32 || desc->weight_dtype > NEDDF_DTYPE_F16_SPLIT) return fail(ctx, NEDDF_EINVAL, "bad weight_dtype");
     Field &f = ctx->field[slot];
     HIPCHK(hipDeviceSynchronize());
     f.valid = false;

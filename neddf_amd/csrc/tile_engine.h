@@ -6,10 +6,9 @@
 //   OpsF32   activations fp32 in LDS, weights fp32, v_mfma_f32_32x32x2_f32 (exact fp32; the parity path)
 //   OpsBF16  activations bf16 in LDS, weights bf16, v_mfma_f32_32x32x16_bf16 with fp32 accumulation
 //            (BASELINE.json configs[4]: "bf16 MLP weights on MFMA"; 16x the fp32 matrix rate)
-//   OpsBF16Split  fp32-grade contraction on the bf16 matrix pipe: weights split into three bf16 terms (24 bits), activations
-//            into two (16 bits, rounded), a.w accumulated from the five products above 2^-24, each exact in the fp32
-//            accumulator.  5 MFMAs at 1/16 of the fp32 MFMA's cost each: 3.2x the fp32 matrix rate, errors within a small
-//            factor of the fp32 MFMA path's
+//   OpsF16Split  fp32 data on the fp16 matrix instructions: every operand split into two fp16 terms (21-22 bits), a.w
+//            accumulated from the three products above 2^-22 in fp32.  3 MFMAs at 1/16 of the fp32 MFMA's cost each: 5.3x
+//            the fp32 matrix rate, errors at the level of the fp32 MFMA path's own
 // Both read one 16-byte fragment per lane per super-step for A (ds_read_b128) and for B
 // (global_load_dwordx4); a super-step covers Ops::kStep values of k, lane half h = lane>>5
 // holding k = kStep*S + (kStep/2)*h ... +kStep/2-1 -- the same mapping for A and B, which is all
@@ -37,6 +36,7 @@ struct OpsF32 {
     static constexpr bool kFastAct = false;
     static constexpr int kPlanes = 1, kPlane = 0;
     static constexpr bool kLean = false;     // room for register-resident extras (skip partial, feature prefetch)
+    static constexpr float kWScale = 1.0f;   // packed weights = kWScale * w
     static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
     static __device__ __forceinline__ void zero(act_t *p) { *p = 0.f; }
     static __device__ __forceinline__ void put(act_t *p, float v) { *p = v; }
@@ -64,6 +64,7 @@ struct OpsBF16 {
     static constexpr bool kFastAct = true;
     static constexpr int kPlanes = 1, kPlane = 0;
     static constexpr bool kLean = false;
+    static constexpr float kWScale = 1.0f;
     static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
     static __device__ __forceinline__ void zero(act_t *p) { *p = 0; }
     static __device__ __forceinline__ unsigned short cvt(float v)       // round to nearest even (v_cvt_pk_bf16_f32)
@@ -88,34 +89,37 @@ struct OpsBF16 {
     }
 };
 
-struct frag2 {
-    bf16x8 h, m;
-};
-struct frag3 {
-    bf16x8 h, m, l;
+// Split-fp16 operands: fp16 carries 11 mantissa bits, so TWO terms per operand (a = h + m, h rounded toward zero -- which
+// also saturates instead of overflowing --, m the remainder rounded to nearest) hold 21-22 bits, and a.w needs only the
+// three products above 2^-22 (m.h, h.m, h.h).  Weights are scaled by 2^10 on the host so that their second term stays in
+// fp16's normal range; the accumulators are scaled back (exactly) on their way into the activation.  3 MFMAs at 1/16 of
+// the fp32 MFMA's cost: 5.3x the fp32 matrix rate, errors at the fp32 MFMA path's level.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct hfrag2 {
+    f16x8 h, m;
 };
 
-// Split-bf16 operands: activations a = h + m (16 mantissa bits, m rounded to nearest), weights w = h + m + l (24 bits),
-// a.w from the five products above 2^-24 (h.l, m.m, m.h, h.m, h.h), smallest first, each exact in the fp32 accumulator.
-// Two activation planes per row make the LDS tile the size of the fp32 one (two workgroups per CU).
-struct OpsBF16Split {
+struct OpsF16Split {
     typedef unsigned short act_t;
-    typedef frag2 afrag;
-    typedef frag3 bfrag;
-    static constexpr int kPlanes = 2, kPlane = 264;      // a row = [h plane | m plane], 264 elements apart
-    static constexpr int kLd = 2 * 264;                  // 1056 B = 8 dwords mod 64
+    typedef hfrag2 afrag;
+    typedef hfrag2 bfrag;
+    static constexpr int kPlanes = 2, kPlane = 264;
+    static constexpr int kLd = 2 * 264;
     static constexpr int kStep = 16;
-    static constexpr int kSub = 5;
-    static constexpr bool kFast = false;     // encodings with the accurate sin / cos / exp
-    static constexpr bool kFastAct = true;   // tanhExp without the small-argument polynomial: |error| ~ 1e-7 absolute, far below
-                                             // the 16-bit activation rounding that follows
-    static constexpr bool kLean = true;      // 5 operand planes in flight per super-step: no registers to spare at 2 workgroups/CU
-    static __device__ __forceinline__ float f(unsigned short b) { return __builtin_bit_cast(float, (unsigned int)b << 16); }
+    static constexpr int kSub = 3;
+    static constexpr bool kFast = false;
+    static constexpr bool kFastAct = false;
+    static constexpr bool kLean = false;                 // measured: register-resident skip partial / feature prefetch pay off here too
+    static constexpr float kWScale = 1024.0f;            // weights are packed as 2^10 w
+    static __device__ __forceinline__ float f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
     static __device__ __forceinline__ void put(act_t *p, float v)
     {
-        const unsigned int hb = __builtin_bit_cast(unsigned int, v) & 0xffff0000u;      // leading 8 bits: truncation, remainder exact
-        p[0] = (unsigned short)(hb >> 16);
-        p[kPlane] = OpsBF16::cvt(v - __builtin_bit_cast(float, hb));                    // next 8 bits, rounded to nearest even
+        typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+        h2 t = __builtin_amdgcn_cvt_pkrtz(v, v);            // toward zero: |h| <= |v| and +-65504 at most, never inf
+        const _Float16 h = (_Float16)t[0];
+        const _Float16 m = (_Float16)__builtin_amdgcn_fmed3f(v - (float)h, -65504.0f, 65504.0f);
+        p[0] = __builtin_bit_cast(unsigned short, h);
+        p[kPlane] = __builtin_bit_cast(unsigned short, m);
     }
     static __device__ __forceinline__ void zero(act_t *p) { p[0] = 0; p[kPlane] = 0; }
     static __device__ __forceinline__ float get(const act_t *p) { return f(p[kPlane]) + f(p[0]); }
@@ -128,17 +132,15 @@ struct OpsBF16Split {
     static __device__ __forceinline__ afrag load_a(const act_t *p)
     {
         afrag a;
-        a.h = *(const bf16x8 *)p; a.m = *(const bf16x8 *)(p + kPlane);
+        a.h = *(const f16x8 *)p; a.m = *(const f16x8 *)(p + kPlane);
         return a;
     }
     static __device__ __forceinline__ f32x16 mfma(const afrag &a, const bfrag &b, const f32x16 &c, int r)
     {
         switch (r) {
-        case 0: return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c, 0, 0, 0);
-        case 1: return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, c, 0, 0, 0);
-        case 2: return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, c, 0, 0, 0);
-        case 3: return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, c, 0, 0, 0);
-        default: return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
+        case 0: return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.m, b.h, c, 0, 0, 0);
+        case 1: return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.m, c, 0, 0, 0);
+        default: return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h, c, 0, 0, 0);
         }
     }
 };
@@ -192,7 +194,7 @@ __device__ __forceinline__ void layer_prefetch(LayerPre<NT, Ops> &p, const void 
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         p.b[t] = wl[(size_t)t * ksteps * 64];
-        p.bias[t] = bias ? bias[(wave * NT + t) * 32 + (lane & 31)] : 0.f;
+        p.bias[t] = bias ? Ops::kWScale * bias[(wave * NT + t) * 32 + (lane & 31)] : 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -252,11 +254,11 @@ __device__ __forceinline__ void dense(f32x16 (&acc)[MT][NT], const typename Ops:
 }
 
 template <int MT, int NT, bool ROWS4>
-__device__ __forceinline__ void acc_init(f32x16 (&acc)[MT][NT], const float *bias, int wave, int lane)
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[MT][NT], const float *bias, int wave, int lane, float scale = 1.0f)
 {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        float bv = bias ? bias[(wave * NT + t) * 32 + (lane & 31)] : 0.f;
+        float bv = bias ? scale * bias[(wave * NT + t) * 32 + (lane & 31)] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -308,16 +310,22 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[MT][NT], typename O
             typename Ops::act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                float z[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    z[r] = acc[mt][t][4 * g + r];
+                    if constexpr (Ops::kWScale != 1.0f) z[r] *= (1.0f / Ops::kWScale);      // exact: a power of two
+                }
                 if (ROWS4) {
                     float y, dy;
-                    act_grad<KIND, Ops::kFastAct>(acc[mt][t][4 * g], y, dy);
+                    act_grad<KIND, Ops::kFastAct>(z[0], y, dy);
                     Ops::put(o + (8 * g + 0) * LD, y);
-                    Ops::put(o + (8 * g + 1) * LD, dy * acc[mt][t][4 * g + 1]);
-                    Ops::put(o + (8 * g + 2) * LD, dy * acc[mt][t][4 * g + 2]);
-                    Ops::put(o + (8 * g + 3) * LD, dy * acc[mt][t][4 * g + 3]);
+                    Ops::put(o + (8 * g + 1) * LD, dy * z[1]);
+                    Ops::put(o + (8 * g + 2) * LD, dy * z[2]);
+                    Ops::put(o + (8 * g + 3) * LD, dy * z[3]);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Ops::put(o + (8 * g + r) * LD, act_val<KIND, Ops::kFastAct>(acc[mt][t][4 * g + r]));
+                    for (int r = 0; r < 4; ++r) Ops::put(o + (8 * g + r) * LD, act_val<KIND, Ops::kFastAct>(z[r]));
                 }
             }
         }

@@ -188,7 +188,7 @@ def test_nerf_field_operand_policies(dev, orc, act, dact):
     pos, d, var = synth.random_sampling(7, 50, seed=3)
     s = Sampling(T(pos, dev), T(d, dev), T(var, dev))
     ref = orc.NeRFOracle(w, activation_type=act, density_activation_type=dact).forward(pos, d, var)
-    for dtype, rtol, atol in (("fp32", 1e-4, 2e-5), ("bf16_split", 1e-4, 1e-4), ("bf16", 3e-2, 3e-2)):
+    for dtype, rtol, atol in (("fp32", 1e-4, 2e-5), ("f16_split", 1e-4, 2e-5), ("bf16", 3e-2, 3e-2)):
         net.weight_dtype = dtype
         o = net(s)
         for k in ("density", "color"):
@@ -259,14 +259,15 @@ def test_llff_ndc_training_and_eval_flow(dev, tmp_path, monkeypatch, capsys):
     assert out.count("psnr:") == 2 and (rd / "eval" / "001_depth.png").is_file()
 
 
-# ------------------------------------------------------------------ split-bf16 operands (fp32 data on the bf16 matrix pipe)
+# ------------------------------------------------------------------ split-fp16 operands (fp32 data on the fp16 matrix instructions)
+@pytest.mark.parametrize("dtype", ["f16_split"])
 @pytest.mark.parametrize("mode", ["full", "minimal"])
-def test_bf16_split_field_meets_the_fp32_gate(dev, orc, bunny_weights, mode):
-    """weight_dtype = "bf16_split": weights split into three bf16 terms, activations into two, five products per multiply-add,
-    fp32 accumulation.  Held to the SAME tolerances as the fp32 path (tests/test_gpu_parity.py) against the fp32 oracle."""
+def test_split_operand_fields_meet_the_fp32_gate(dev, orc, bunny_weights, mode, dtype):
+    """weight_dtype = "f16_split": every operand split into two fp16 terms, three products per multiply-add, fp32
+    accumulation.  Held to the SAME tolerances as the fp32 path (tests/test_gpu_parity.py) against the fp32 oracle."""
     from neddf_amd import Sampling
     pos, d, var = synth.random_sampling(40, 33, seed=21)
-    net = _net(dev, bunny_weights, "bf16_split", mode)
+    net = _net(dev, bunny_weights, dtype, mode)
     s = Sampling(T(pos, dev), T(d, dev), T(var, dev))
     o = net(s)
     ref = orc.NeDDFOracle(bunny_weights, **BUNNY_CFG).forward(pos, d, var)
@@ -274,13 +275,14 @@ def test_bf16_split_field_meets_the_fp32_gate(dev, orc, bunny_weights, mode):
     o32 = net(s)
     tol = {"distance": (1e-4, 1e-6), "aux_grad": (1e-4, 1e-6), "color": (1e-4, 2e-5), "density": (1e-4, 3e-4), "fields_penalty": (2e-3, 1e-5)}
     for k in o:
-        assert_close(N(o[k]), ref[k], *tol[k], "bf16_split " + k)
+        assert_close(N(o[k]), ref[k], *tol[k], dtype + " " + k)
         scale = np.abs(ref[k]).max()
-        print("%-14s bf16_split vs oracle %.2e, fp32 MFMA vs oracle %.2e (of max |value|)" % (
-            k, np.abs(N(o[k]) - ref[k]).max() / scale, np.abs(N(o32[k]) - ref[k]).max() / scale))
+        print("%-10s %-14s vs oracle %.2e, fp32 MFMA vs oracle %.2e (of max |value|)" % (
+            dtype, k, np.abs(N(o[k]) - ref[k]).max() / scale, np.abs(N(o32[k]) - ref[k]).max() / scale))
 
 
-def test_bf16_split_render_rays_end_to_end(dev, bunny_weights, bunny_stages):
+@pytest.mark.parametrize("dtype", ["f16_split"])
+def test_split_operand_render_rays_end_to_end(dev, bunny_weights, bunny_stages, dtype):
     """The golden 64-ray render of the reference (tests/test_gpu_parity.py::test_render_rays_end_to_end) with split-bf16 fields."""
     import neddf_amd
     g = bunny_stages
@@ -290,7 +292,7 @@ def test_bf16_split_render_rays_end_to_end(dev, bunny_weights, bunny_stages):
     r.network_fine.load_state_dict({k: torch.from_numpy(v) for k, v in bunny_weights.items()})
     r.to(dev)
     r.set_iter(-1)
-    r.network_fine.weight_dtype = "bf16_split"
+    r.network_fine.weight_dtype = dtype
     cam = neddf_amd.Camera(neddf_amd.PinholeCalib(g["calib"].astype(np.float64)), None).to(dev)
     cam.R, cam.T = T(g["R"], dev), T(g["T"], dev)
     o = r._render(r._ctx(dev), T(g["uv"], dev), cam, T(g["u_coarse"], dev), T(g["u_fine"], dev), full=True)
@@ -301,7 +303,8 @@ def test_bf16_split_render_rays_end_to_end(dev, bunny_weights, bunny_stages):
     assert 10 * np.log10(1.0 / max(mse, 1e-20)) > 80.0
 
 
-def test_bf16_split_neus_and_other_ranks(dev):
+@pytest.mark.parametrize("dtype", ["f16_split"])
+def test_split_operand_neus(dev, dtype):
     import neddf_amd
     from neddf_amd import Sampling
     w = synth.neus_state()
@@ -311,7 +314,25 @@ def test_bf16_split_neus_and_other_ranks(dev):
     pos, d, var = synth.random_sampling(6, 30, seed=5, cone=False)
     s = Sampling(T(pos, dev), T(d, dev), T(var, dev))
     a = net(s)
-    net.weight_dtype = "bf16_split"
+    net.weight_dtype = dtype
     b = net(s)
     for k in a:
         assert_close(N(b[k]), N(a[k]), 1e-4, 2e-5, "NeuS " + k)
+
+
+def test_split_operands_saturate_instead_of_overflowing(dev):
+    """fp16 terms top out at 65504: activations beyond that saturate (the result is no longer accurate, but stays finite)."""
+    import neddf_amd
+    from neddf_amd import Sampling
+    w = {k: (v * (40.0 if k.endswith("weight") and k.startswith("layers.") else 1.0)).astype(np.float32)
+         for k, v in synth.nerf_state(seed=11).items()}
+    net = neddf_amd.NeRF(activation_type="ReLU", density_activation_type="ReLU")
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    net.to(dev)
+    pos, d, var = synth.random_sampling(4, 20, seed=3)
+    s = Sampling(T(pos, dev), T(d, dev), T(var, dev))
+    ref = net(s)
+    assert float(ref["density"].abs().max()) > 1e6            # the fp32 path really is far outside fp16's range here
+    net.weight_dtype = "f16_split"
+    o = net(s)
+    assert torch.isfinite(o["density"]).all() and torch.isfinite(o["color"]).all()

@@ -25,7 +25,7 @@ def run(net, label, flop):
     print("%-36s %8.2f ms  %6.2f Mpoints/s  %6.1f TFLOP/s (algorithmic %.3f MFLOP/point)" % (label, dt * 1e3, N / dt / 1e6, N * flop / dt / 1e12, flop / 1e6))
 
 w = golden("bunny_weights.npz")
-for dtype in ("fp32", "bf16_split", "bf16"):
+for dtype in ("fp32", "f16_split", "bf16"):
     with torch.no_grad():
         nerf = neddf_amd.NeRF()
         nerf.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_state().items()}); nerf.to(dev); nerf.set_iter(-1)
