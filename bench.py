@@ -338,6 +338,20 @@ def main():
             line["roofline"]["algorithmic_hbm_bytes_per_launch"] = ent["algorithmic_bytes_per_launch"]
         except Exception:
             pass
+        if world == 1 and args.workload == "c2" and args.dtype == "f32":
+            # supplementary: the same workload under the split-fp16 operand policy (fp32 data, fp32-level errors);
+            # `value` above stays the exact fp32 MFMA path
+            render.network_fine.weight_dtype = "f16_split"
+            step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            line["alt_operand_policy"] = {"dtype": "f16_split (fp32 operands as two fp16 terms, three fp16 MFMAs per multiply-add, fp32 accumulation)",
+                                          "value": n_rays * 2 / (time.perf_counter() - t1), "unit": "rays/s", "steps": 2,
+                                          "parity": "same 1e-4 gates as the fp32 path (tests/test_gpu_c5.py)"}
+            render.network_fine.weight_dtype = "fp32"
         if world == 1 and not args.no_cpu_baseline and args.workload != "c5":
             line["cpu_baseline"] = cpu_baseline(weights, R, T, calib.astype(np.float32))
         nan = int(res["_nan"].item()) if isinstance(res, dict) else 0
