@@ -123,6 +123,7 @@ def train_workload(args, dev, world=1, rank=0, use_dist=False):
     render.to(dev)
     render.set_iter(1500)
     render.rng = "device"
+    render.network_fine.weight_dtype = {"f32": "fp32", "f16_split": "f16_split"}[args.dtype]
     fx = 0.5 * 400 / math.tan(0.5 * CAMERA_ANGLE_X)
     R, T = view_pose(0)
     cam = neddf_amd.Camera(neddf_amd.PinholeCalib(np.array([fx, fx, 200.0, 200.0])), None).to(dev)
@@ -171,7 +172,7 @@ def train_workload(args, dev, world=1, rank=0, use_dist=False):
     achieved = flop * args.steps / elapsed / 1e12
     return {"metric": "training rays/sec (1024-ray steps, 65 coarse + 194 fine samples, NeDDF fp32)", "value": rays * world * args.steps / elapsed,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "training step: render_rays with autograd -> ColorLoss + MaskBCELoss + FieldsConstraintLoss -> backward -> "
                                    "Adam, shipped bunny_smoke weights, synthetic targets", "rays_per_step_per_gpu": rays,
                        "samples_per_ray": 65 + 194, "workload_id": "train",

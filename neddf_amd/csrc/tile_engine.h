@@ -39,6 +39,7 @@ struct OpsF32 {
     static constexpr float kWScale = 1.0f;   // packed weights = kWScale * w
     static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
     static __device__ __forceinline__ void zero(act_t *p) { *p = 0.f; }
+    static __device__ __forceinline__ void put4(act_t *p, const f32x4v &v) { *(f32x4v *)p = v; }     // 4 consecutive columns
     static __device__ __forceinline__ void put(act_t *p, float v) { *p = v; }
     static __device__ __forceinline__ float get(const act_t *p) { return *p; }
     static __device__ __forceinline__ void load4(const act_t *p, float (&x)[4])
@@ -122,6 +123,20 @@ struct OpsF16Split {
         p[kPlane] = __builtin_bit_cast(unsigned short, m);
     }
     static __device__ __forceinline__ void zero(act_t *p) { p[0] = 0; p[kPlane] = 0; }
+    static __device__ __forceinline__ void put4(act_t *p, const f32x4v &v)                               // 4 consecutive columns
+    {
+        typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        f16x4 h, m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h2 t = __builtin_amdgcn_cvt_pkrtz(v[i], v[i]);
+            h[i] = (_Float16)t[0];
+            m[i] = (_Float16)__builtin_amdgcn_fmed3f(v[i] - (float)h[i], -65504.0f, 65504.0f);
+        }
+        *(f16x4 *)p = h;
+        *(f16x4 *)(p + kPlane) = m;
+    }
     static __device__ __forceinline__ float get(const act_t *p) { return f(p[kPlane]) + f(p[0]); }
     static __device__ __forceinline__ void load4(const act_t *p, float (&x)[4])
     {

@@ -93,6 +93,7 @@ int nerf_forward(neddf_ctx *ctx, int slot, const float *const *W, const float *c
     if (int rc = make_nerf_plan(ctx, slot, N, n_tensors, p)) return rc;
     const Field &f = ctx->field[slot];
     const int act = f.d.activation, cus = ctx->cus;
+    const int sp = f.d.weight_dtype == NEDDF_DTYPE_F16_SPLIT;
     if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ttmp, ((size_t)N * kLdNarrow + kWidth) * sizeof(float))) return rc;
     float *wp = (float *)ctx->tpack.p, *wp2 = wp + kPackFloats;
@@ -107,16 +108,16 @@ int nerf_forward(neddf_ctx *ctx, int slot, const float *const *W, const float *c
         const bool wide = l > 0 && in_skips(f.d, l - 1);
         const int in_total = l == 0 ? p.Cpe : (wide ? kWidth + p.Cpe : kWidth);
         if (l == 0) {
-            launch_pack(W[0], 1, in_total, 0, 0, p.Cpe, kWidth, kWidth, wp, s);
-            launch_rows_gemm(PE, N, kLdPe, kpe, wp, (p.Cpe + 7) / 8, B[0], 1, Z, kWidth, 0, act, H, cus, s);
+            launch_pack(sp, W[0], 1, in_total, 0, 0, p.Cpe, kWidth, kWidth, wp, s);
+            launch_rows_gemm(sp, PE, N, kLdPe, kpe, wp, gemm_ksteps(p.Cpe, sp), B[0], 1, Z, kWidth, 0, act, H, cus, s);
         } else if (!wide) {
-            launch_pack(W[l], 1, in_total, 0, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(ws + p.o_h[l - 1], N, kWidth, kWidth, wp, 32, B[l], 1, Z, kWidth, 0, act, H, cus, s);
+            launch_pack(sp, W[l], 1, in_total, 0, 0, kWidth, kWidth, kWidth, wp, s);
+            launch_rows_gemm(sp, ws + p.o_h[l - 1], N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 1, Z, kWidth, 0, act, H, cus, s);
         } else {        // cat([hx, embed_pos]): the hidden state feeds input columns 0..255, the encoding 256..
-            launch_pack(W[l], 1, in_total, 0, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(ws + p.o_h[l - 1], N, kWidth, kWidth, wp, 32, B[l], 1, Z, kWidth, 0, -1, nullptr, cus, s);
-            launch_pack(W[l], 1, in_total, kWidth, 0, p.Cpe, kWidth, kWidth, wp2, s);
-            launch_rows_gemm(PE, N, kLdPe, kpe, wp2, (p.Cpe + 7) / 8, nullptr, 1, Z, kWidth, 1, act, H, cus, s);
+            launch_pack(sp, W[l], 1, in_total, 0, 0, kWidth, kWidth, kWidth, wp, s);
+            launch_rows_gemm(sp, ws + p.o_h[l - 1], N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 1, Z, kWidth, 0, -1, nullptr, cus, s);
+            launch_pack(sp, W[l], 1, in_total, kWidth, 0, p.Cpe, kWidth, kWidth, wp2, s);
+            launch_rows_gemm(sp, PE, N, kLdPe, kpe, wp2, gemm_ksteps(p.Cpe, sp), nullptr, 1, Z, kWidth, 1, act, H, cus, s);
         }
     }
     const float *Hlast = ws + p.o_h[p.n - 1];
@@ -128,10 +129,10 @@ int nerf_forward(neddf_ctx *ctx, int slot, const float *const *W, const float *c
     // colour head: Linear(256 + dir, 128) -> ReLU -> Linear(128, 3); the 128 outputs are computed as 256 with zero weights
     HIPCHK(hipMemsetAsync(bias_c0, 0, kWidth * sizeof(float), s));
     HIPCHK(hipMemcpyAsync(bias_c0, B[p.i_c0], (kWidth / 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
-    launch_pack(W[p.i_c0], 1, p.in_c0, 0, 0, kWidth, kWidth / 2, kWidth, wp, s);
-    launch_rows_gemm(Hlast, N, kWidth, kWidth, wp, 32, bias_c0, 1, ws + p.o_zc, kWidth, 0, -1, nullptr, cus, s);
-    launch_pack(W[p.i_c0], 1, p.in_c0, kWidth, 0, p.Cdir, kWidth / 2, kWidth, wp2, s);
-    launch_rows_gemm(Ed, N, kLdDir, kdir, wp2, (p.Cdir + 7) / 8, nullptr, 1, ws + p.o_zc, kWidth, 1, NEDDF_ACT_RELU, ws + p.o_hc, cus, s);
+    launch_pack(sp, W[p.i_c0], 1, p.in_c0, 0, 0, kWidth, kWidth / 2, kWidth, wp, s);
+    launch_rows_gemm(sp, Hlast, N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), bias_c0, 1, ws + p.o_zc, kWidth, 0, -1, nullptr, cus, s);
+    launch_pack(sp, W[p.i_c0], 1, p.in_c0, kWidth, 0, p.Cdir, kWidth / 2, kWidth, wp2, s);
+    launch_rows_gemm(sp, Ed, N, kLdDir, kdir, wp2, gemm_ksteps(p.Cdir, sp), nullptr, 1, ws + p.o_zc, kWidth, 1, NEDDF_ACT_RELU, ws + p.o_hc, cus, s);
     NarrowW c1{};
     c1.nc = 3; c1.wstride = 1; c1.kcount = kWidth / 2;
     for (int c = 0; c < 3; ++c) { c1.w[c] = W[p.i_c1] + c * (kWidth / 2); c1.b[c] = B[p.i_c1] + c; }
@@ -148,6 +149,7 @@ int nerf_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors
     if (int rc = make_nerf_plan(ctx, slot, N, n_tensors, p)) return rc;
     const Field &f = ctx->field[slot];
     const int act = f.d.activation, cus = ctx->cus, half = kWidth / 2;
+    const int sp = f.d.weight_dtype == NEDDF_DTYPE_F16_SPLIT;
     if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ttmp, (size_t)N * (2 * kWidth + 2 * kLdNarrow) * sizeof(float))) return rc;
     float *wp = (float *)ctx->tpack.p;
@@ -165,10 +167,10 @@ int nerf_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors
         launch_narrow_dw(ws + p.o_hc, kWidth, GC, kLdNarrow, N, 3, wc, 1, bc, 1, half, s);
     }
     // first colour layer (weights [128, 256 + dir])
-    launch_dw(Hlast, kWidth, kWidth, dA, kWidth, N, gW[p.i_c0], 1, p.in_c0, half, gB[p.i_c0], 1, cus, s);
-    launch_dw(Ed, kLdDir, p.Cdir, dA, kWidth, N, gW[p.i_c0] + kWidth, 1, p.in_c0, half, nullptr, 1, cus, s);
-    launch_pack(W[p.i_c0], p.in_c0, 1, 0, 0, half, kWidth, kWidth, wp, s);                // rows = the 128 outputs, columns = hidden inputs
-    launch_rows_gemm(dA, N, kWidth, half, wp, half / 8, nullptr, 1, dB, kWidth, 0, -1, nullptr, cus, s);
+    launch_dw(sp, Hlast, kWidth, kWidth, dA, kWidth, N, gW[p.i_c0], 1, p.in_c0, half, gB[p.i_c0], 1, cus, s);
+    launch_dw(sp, Ed, kLdDir, p.Cdir, dA, kWidth, N, gW[p.i_c0] + kWidth, 1, p.in_c0, half, nullptr, 1, cus, s);
+    launch_pack(sp, W[p.i_c0], p.in_c0, 1, 0, 0, half, kWidth, kWidth, wp, s);                // rows = the 128 outputs, columns = hidden inputs
+    launch_rows_gemm(sp, dA, N, kWidth, half, wp, gemm_ksteps(half, sp), nullptr, 1, dB, kWidth, 0, -1, nullptr, cus, s);
     // density head, then the last trunk activation: dA = dZ of the last trunk layer
     if (g_density) launch_density_head(f.d.density_activation, ws + p.o_zd, kLdNarrow, N, g_density, GD, kLdNarrow, s);
     NarrowW dens{};
@@ -184,13 +186,13 @@ int nerf_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors
         const bool wide = l > 0 && in_skips(f.d, l - 1);
         const int in_total = l == 0 ? p.Cpe : (wide ? kWidth + p.Cpe : kWidth);
         if (l == 0) {
-            launch_dw(PE, kLdPe, p.Cpe, dA, kWidth, N, gW[0], 1, in_total, kWidth, gB[0], 1, cus, s);
+            launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, N, gW[0], 1, in_total, kWidth, gB[0], 1, cus, s);
             break;
         }
-        launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, N, gW[l], 1, in_total, kWidth, gB[l], 1, cus, s);
-        if (wide) launch_dw(PE, kLdPe, p.Cpe, dA, kWidth, N, gW[l] + kWidth, 1, in_total, kWidth, nullptr, 1, cus, s);
-        launch_pack(W[l], in_total, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
-        launch_rows_gemm_actback(dA, N, kWidth, kWidth, wp, 32, 1, act, ws + p.o_z[l - 1], dB, kWidth, cus, s);
+        launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, N, gW[l], 1, in_total, kWidth, gB[l], 1, cus, s);
+        if (wide) launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, N, gW[l] + kWidth, 1, in_total, kWidth, nullptr, 1, cus, s);
+        launch_pack(sp, W[l], in_total, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
+        launch_rows_gemm_actback(sp, dA, N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 1, act, ws + p.o_z[l - 1], dB, kWidth, cus, s);
         float *t = dA; dA = dB; dB = t;
     }
     HIPCHK(hipGetLastError());
@@ -229,6 +231,7 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     if (int rc = make_plan(ctx, slot, N, n_tensors, p)) return rc;
     const Field &f = ctx->field[slot];
     const int act = f.d.activation;
+    const int sp = f.d.weight_dtype == NEDDF_DTYPE_F16_SPLIT;      // GEMM operands as two fp16 terms (tile_engine.h)
     if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ttmp, ((size_t)p.R * (kLdPe + kLdNarrow) + (size_t)N * kLdDir) * sizeof(float))) return rc;
     float *wp = (float *)ctx->tpack.p, *wp2 = wp + kPackFloats;
@@ -243,16 +246,16 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
         const bool wide = l > 0 && in_skips(f.d, l - 1);
         const int kpe = (p.Cpe + 3) & ~3;       // loaded width of the encoding matrix (pad columns are zero)
         if (l == 0) {
-            launch_pack(W[0], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp, s);
-            launch_rows_gemm(PEs, p.R, kLdPe, kpe, wp, (p.Cpe + 7) / 8, B[0], 4, Z, kWidth, 0, act, H, ctx->cus, s);
+            launch_pack(sp, W[0], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp, s);
+            launch_rows_gemm(sp, PEs, p.R, kLdPe, kpe, wp, gemm_ksteps(p.Cpe, sp), B[0], 4, Z, kWidth, 0, act, H, ctx->cus, s);
         } else if (!wide) {
-            launch_pack(W[l], kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, 32, B[l], 4, Z, kWidth, 0, act, H, ctx->cus, s);
+            launch_pack(sp, W[l], kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
+            launch_rows_gemm(sp, ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 4, Z, kWidth, 0, act, H, ctx->cus, s);
         } else {            // hx = cat([embed_pos_scaled, hx]): the encoding feeds rows 0 .. Cpe-1 of the weight
-            launch_pack(W[l], kWidth, 1, p.Cpe, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, 32, B[l], 4, Z, kWidth, 0, -1, nullptr, ctx->cus, s);
-            launch_pack(W[l], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp2, s);
-            launch_rows_gemm(PEs, p.R, kLdPe, kpe, wp2, (p.Cpe + 7) / 8, nullptr, 4, Z, kWidth, 1, act, H, ctx->cus, s);
+            launch_pack(sp, W[l], kWidth, 1, p.Cpe, 0, kWidth, kWidth, kWidth, wp, s);
+            launch_rows_gemm(sp, ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 4, Z, kWidth, 0, -1, nullptr, ctx->cus, s);
+            launch_pack(sp, W[l], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp2, s);
+            launch_rows_gemm(sp, PEs, p.R, kLdPe, kpe, wp2, gemm_ksteps(p.Cpe, sp), nullptr, 4, Z, kWidth, 1, act, H, ctx->cus, s);
         }
     }
     const float *Hlast = ws + p.o_h[p.n_trunk - 1];
@@ -269,13 +272,13 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
         float *Z = ws + p.o_zc[l], *H = ws + p.o_hc[l];
         const float *Wl = W[p.n_trunk + l], *Bl = B[p.n_trunk + l];
         if (l == 0) {
-            launch_pack(Wl, kWidth, 1, 0, 0, p.Ca, kWidth, kWidth, wp, s);
-            launch_rows_gemm(ws + p.o_xa, p.R, p.ldxa, p.ldxa, wp, (p.Ca + 7) / 8, Bl, 4, Z, kWidth, 0, -1, nullptr, ctx->cus, s);
-            launch_pack(Wl, kWidth, 1, p.Ca, 0, kWidth, kWidth, kWidth, wp2, s);
-            launch_rows_gemm(Hlast, p.R, kWidth, kWidth, wp2, 32, nullptr, 4, Z, kWidth, 1, act, H, ctx->cus, s);
+            launch_pack(sp, Wl, kWidth, 1, 0, 0, p.Ca, kWidth, kWidth, wp, s);
+            launch_rows_gemm(sp, ws + p.o_xa, p.R, p.ldxa, p.ldxa, wp, gemm_ksteps(p.Ca, sp), Bl, 4, Z, kWidth, 0, -1, nullptr, ctx->cus, s);
+            launch_pack(sp, Wl, kWidth, 1, p.Ca, 0, kWidth, kWidth, kWidth, wp2, s);
+            launch_rows_gemm(sp, Hlast, p.R, kWidth, kWidth, wp2, gemm_ksteps(kWidth, sp), nullptr, 4, Z, kWidth, 1, act, H, ctx->cus, s);
         } else {
-            launch_pack(Wl, kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(ws + p.o_hc[l - 1], p.R, kWidth, kWidth, wp, 32, Bl, 4, Z, kWidth, 0, act, H, ctx->cus, s);
+            launch_pack(sp, Wl, kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
+            launch_rows_gemm(sp, ws + p.o_hc[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), Bl, 4, Z, kWidth, 0, act, H, ctx->cus, s);
         }
     }
     NarrowW cout{};
@@ -304,6 +307,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     if (int rc = make_plan(ctx, slot, N, n_tensors, p)) return rc;
     const Field &f = ctx->field[slot];
     const int act = f.d.activation;
+    const int sp = f.d.weight_dtype == NEDDF_DTYPE_F16_SPLIT;      // GEMM operands as two fp16 terms (tile_engine.h)
     if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ttmp, (size_t)p.R * (2 * kWidth + 2 * kLdNarrow) * sizeof(float))) return rc;
     float *wp = (float *)ctx->tpack.p;
@@ -331,15 +335,15 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         const float *Wl = W[p.n_trunk + l];
         float *gWl = gW[p.n_trunk + l], *gBl = gB[p.n_trunk + l];
         if (l > 0) {
-            launch_dw(ws + p.o_hc[l - 1], kWidth, kWidth, dA, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s);
-            launch_pack(Wl, 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wp, s);                 // W^T
-            launch_rows_gemm_actback(dA, p.R, kWidth, kWidth, wp, 32, 4, act, ws + p.o_zc[l - 1], dB, kWidth, ctx->cus, s);
+            launch_dw(sp, ws + p.o_hc[l - 1], kWidth, kWidth, dA, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s);
+            launch_pack(sp, Wl, 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wp, s);                 // W^T
+            launch_rows_gemm_actback(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 4, act, ws + p.o_zc[l - 1], dB, kWidth, ctx->cus, s);
         } else {
-            launch_dw(ws + p.o_xa, p.ldxa, p.Ca, dA, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s);
-            launch_dw(Hlast, kWidth, kWidth, dA, kWidth, p.R, gWl + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s);
-            launch_pack(Wl, 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wp, s);              // (feature rows of W)^T
+            launch_dw(sp, ws + p.o_xa, p.ldxa, p.Ca, dA, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s);
+            launch_dw(sp, Hlast, kWidth, kWidth, dA, kWidth, p.R, gWl + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s);
+            launch_pack(sp, Wl, 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wp, s);              // (feature rows of W)^T
             // the small colour inputs (encodings, detached normal) carry no parameters: only the feature segment propagates
-            launch_rows_gemm(dA, p.R, kWidth, kWidth, wp, 32, nullptr, 4, dB, kWidth, 0, -1, nullptr, ctx->cus, s);
+            launch_rows_gemm(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), nullptr, 4, dB, kWidth, 0, -1, nullptr, ctx->cus, s);
         }
         float *t = dA; dA = dB; dB = t;
     }
@@ -356,17 +360,17 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     for (int l = p.n_trunk - 1; l >= 0; --l) {
         const bool wide = l > 0 && in_skips(f.d, l - 1);
         if (l == 0) {
-            launch_dw(PEs, kLdPe, p.Cpe, dA, kWidth, p.R, gW[0], kWidth, 1, kWidth, gB[0], 4, ctx->cus, s);
+            launch_dw(sp, PEs, kLdPe, p.Cpe, dA, kWidth, p.R, gW[0], kWidth, 1, kWidth, gB[0], 4, ctx->cus, s);
             break;
         }
         if (wide) {
-            launch_dw(PEs, kLdPe, p.Cpe, dA, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s);
-            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l] + (size_t)p.Cpe * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s);
+            launch_dw(sp, PEs, kLdPe, p.Cpe, dA, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s);
+            launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l] + (size_t)p.Cpe * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s);
         } else {
-            launch_dw(ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s);
+            launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s);
         }
-        launch_pack(W[l], 1, kWidth, 0, wide ? p.Cpe : 0, kWidth, kWidth, kWidth, wp, s);
-        launch_rows_gemm_actback(dA, p.R, kWidth, kWidth, wp, 32, 4, act, ws + p.o_z[l - 1], dB, kWidth, ctx->cus, s);
+        launch_pack(sp, W[l], 1, kWidth, 0, wide ? p.Cpe : 0, kWidth, kWidth, kWidth, wp, s);
+        launch_rows_gemm_actback(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 4, act, ws + p.o_z[l - 1], dB, kWidth, ctx->cus, s);
         float *t = dA; dA = dB; dB = t;
     }
     HIPCHK(hipGetLastError());

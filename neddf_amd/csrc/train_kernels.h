@@ -37,18 +37,21 @@ struct TrainPointArgs {
 
 // logical M[k][n] = src[(k_off + k) * sk + (n_off + n) * sn] for k < kcount, n < ncount (0 elsewhere), packed into the
 // fragment-major layout of kernels.h LayerW for nout (128 or 256) output columns and roundup(kcount, 8) / 8 super-steps
-void launch_pack(const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, float *dst, hipStream_t s);
+// split != 0: split-fp16 fragments (tile_engine.h OpsF16Split), roundup(kcount, 16) / 16 super-steps
+void launch_pack(int split, const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, float *dst,
+                 hipStream_t s);
+inline int gemm_ksteps(int K, int split) { return split ? (K + 15) / 16 : (K + 7) / 8; }
 
 // Y[R,256] (+)= X[R, 0:kload) x Wpacked (+ bias); kload = loaded width (multiple of 4, <= ldx, zero beyond the logical K);
 // act_kind >= 0 with H != NULL additionally writes H = a(Y) on (value, Jacobian) row groups
-void launch_rows_gemm(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias, int bias_period,
+void launch_rows_gemm(int split, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias, int bias_period,
                       float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s);
 // dW[k * sk + n * sn] += sum_r X[r, k] G[r, n], k < K <= 256, n < nvalid <= 256; db[n] += sum over rows r % bias_period == 0 of G[r, n]
 // dZ[R,256] = activation backward (pre-activations Zprev, row period, kind) of X[R, 0:kload) x Wpacked: the input-gradient GEMM of
 // a layer fused with the backward of the previous layer's activation
-void launch_rows_gemm_actback(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, int period, int act_kind,
+void launch_rows_gemm_actback(int split, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, int period, int act_kind,
                               const float *Zprev, float *dZ, int ldy, int cus, hipStream_t s);
-void launch_dw(const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
+void launch_dw(int split, const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
                int bias_period, int cus, hipStream_t s);
 // heads (1..4 output columns, input width 256): column c of the weight gradient is w[c][k * wstride], b[c] its bias gradient
 void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t R, int nc, float *const *w, int wstride, float *const *b,

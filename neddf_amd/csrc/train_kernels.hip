@@ -71,19 +71,23 @@ __device__ __forceinline__ void act_backward_group(int kind, int period, const f
 // of a point in one thread.
 // MODE 0: plain; 1: also H = a(Y) (forward); 2: Y = activation backward of the product with the pre-activations Zp = H
 // (the dX GEMM of layer l immediately followed by the backward of layer l-1's activation: dZ_{l-1}, no dH round trip)
-template <int MODE>
+// Ops = OpsF32 (exact fp32 MFMA) or OpsF16Split (fp32 operands as two fp16 terms, tile_engine.h): the operand tile in LDS has
+// the policy's layout, the result tile that the epilogue reads back is always fp32 [64][kActLd] in the same LDS bytes.
+template <int MODE, class Ops>
 __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps,
                                                                 const float *bias, int bias_period, float *Y, int ldy, int accumulate,
                                                                 int act_kind, float *H)
 {
-    constexpr int MT = 2, NT = 2, ROWS = MT * 32, NPF = ROWS * (kWidth / 4) / kThreads;
+    typedef typename Ops::act_t act_t;
+    constexpr int MT = 2, NT = 2, ROWS = MT * 32, NPF = ROWS * (kWidth / 4) / kThreads, LD = Ops::kLd;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *act = smem;
+    float *act = smem;                       // result tile (fp32)
+    act_t *opd = (act_t *)smem;              // operand tile (policy layout)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *act_lane = act_lane_ptr<OpsF32>(act, lane);
-    const f32x4v *wl = (const f32x4v *)wp + (size_t)wave * NT * ksteps * 64 + lane;
+    const act_t *act_lane = act_lane_ptr<Ops>(opd, lane);
+    const typename Ops::bfrag *wl = (const typename Ops::bfrag *)wp + (size_t)wave * NT * ksteps * 64 + lane;
     const int64_t ntiles = (R + ROWS - 1) / ROWS;
-    const int c4n = kload >> 2, total = ROWS * c4n, kpack = 8 * ksteps;
+    const int c4n = kload >> 2, total = ROWS * c4n, kpack = Ops::kStep * ksteps;
     f32x4v pf[NPF];
     auto fetch = [&](int64_t tile) {
         const int64_t r0 = tile * ROWS;
@@ -108,20 +112,20 @@ __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, 
             int idx = tid + i * kThreads;
             if (idx < total) {
                 int r = idx / c4n, c = idx - r * c4n;
-                *(f32x4v *)(act + r * kActLd + 4 * c) = pf[i];
+                Ops::put4(opd + r * LD + 4 * c, pf[i]);
             }
         }
         for (int i = tid; i < ROWS * (kpack - kload); i += kThreads) {      // packed width beyond the loaded width
             int w = kpack - kload, r = i / w, c = i - r * w;
-            act[r * kActLd + kload + c] = 0.f;
+            Ops::zero(opd + r * LD + kload + c);
         }
         __syncthreads();
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[MT][NT];
-        if (bias_period == 4) acc_init<MT, NT, true>(acc, bias, wave, lane);
-        else acc_init<MT, NT, false>(acc, bias, wave, lane);
-        dense<MT, NT>(acc, act_lane, wl, ksteps);
+        if (bias_period == 4) acc_init<MT, NT, true>(acc, bias, wave, lane, Ops::kWScale);
+        else acc_init<MT, NT, false>(acc, bias, wave, lane, Ops::kWScale);
+        dense<MT, NT, Ops>(acc, act_lane, wl, ksteps);
         __syncthreads();                // every wave finished reading the A operands
         const int j = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, 
             for (int t = 0; t < NT; ++t) {
                 float *o = act + (mt * 32 + 4 * h) * kActLd + (wave * NT + t) * 32 + j;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) o[(8 * (q >> 2) + (q & 3)) * kActLd] = acc[mt][t][q];
+                for (int q = 0; q < 16; ++q) o[(8 * (q >> 2) + (q & 3)) * kActLd] = acc[mt][t][q] * (1.0f / Ops::kWScale);
             }
         __syncthreads();
         // items: (4-row group, 4 columns); rows of a group are consecutive rows of the tile
@@ -188,35 +192,46 @@ __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, 
     }
 }
 
-static void launch_rows_gemm_mode(int mode, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias,
-                                  int period, float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s)
+template <class Ops>
+static void launch_rows_gemm_ops(int mode, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias,
+                                 int period, float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s)
 {
-    if (R <= 0) return;
-    const size_t lds = (size_t)(64 * kActLd) * sizeof(float);
-    static bool once = ((void)hipFuncSetAttribute((const void *)rows_gemm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * kActLd * sizeof(float))),
-                        (void)hipFuncSetAttribute((const void *)rows_gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * kActLd * sizeof(float))),
-                        (void)hipFuncSetAttribute((const void *)rows_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * kActLd * sizeof(float))), true);
+    constexpr size_t kOpd = (size_t)64 * Ops::kLd * sizeof(typename Ops::act_t), kRes = (size_t)64 * kActLd * sizeof(float);
+    constexpr size_t lds = kOpd > kRes ? kOpd : kRes;
+    static bool once = ((void)hipFuncSetAttribute((const void *)rows_gemm_kernel<0, Ops>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                        (void)hipFuncSetAttribute((const void *)rows_gemm_kernel<1, Ops>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                        (void)hipFuncSetAttribute((const void *)rows_gemm_kernel<2, Ops>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     int64_t tiles = (R + 63) / 64;
     int grid = (int)(tiles < 2 * cus ? tiles : 2 * cus);
     if (mode == 1)
-        hipLaunchKernelGGL((rows_gemm_kernel<1>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, act_kind, H);
+        hipLaunchKernelGGL((rows_gemm_kernel<1, Ops>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, act_kind, H);
     else if (mode == 2)
-        hipLaunchKernelGGL((rows_gemm_kernel<2>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, 0, act_kind, H);
+        hipLaunchKernelGGL((rows_gemm_kernel<2, Ops>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, 0, act_kind, H);
     else
-        hipLaunchKernelGGL((rows_gemm_kernel<0>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, -1, nullptr);
+        hipLaunchKernelGGL((rows_gemm_kernel<0, Ops>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, -1, nullptr);
 }
 
-void launch_rows_gemm(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias, int bias_period,
+static void launch_rows_gemm_mode(int mode, int split, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps,
+                                  const float *bias, int period, float *Y, int ldy, int accumulate, int act_kind, float *H, int cus,
+                                  hipStream_t s)
+{
+    if (R <= 0) return;
+    if (split) launch_rows_gemm_ops<OpsF16Split>(mode, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, act_kind, H, cus, s);
+    else launch_rows_gemm_ops<OpsF32>(mode, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, act_kind, H, cus, s);
+}
+
+void launch_rows_gemm(int split, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias, int bias_period,
                       float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s)
 {
-    launch_rows_gemm_mode((act_kind >= 0 && H) ? 1 : 0, X, R, ldx, kload, wp, ksteps, bias, bias_period, Y, ldy, accumulate, act_kind, H, cus, s);
+    launch_rows_gemm_mode((act_kind >= 0 && H) ? 1 : 0, split, X, R, ldx, kload, wp, ksteps, bias, bias_period, Y, ldy, accumulate, act_kind, H,
+                          cus, s);
 }
 
-void launch_rows_gemm_actback(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, int period, int act_kind,
+void launch_rows_gemm_actback(int split, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, int period, int act_kind,
                               const float *Zprev, float *dZ, int ldy, int cus, hipStream_t s)
 {
-    launch_rows_gemm_mode(2, X, R, ldx, kload, wp, ksteps, nullptr, period, dZ, ldy, 0, act_kind, const_cast<float *>(Zprev), cus, s);
+    launch_rows_gemm_mode(2, split, X, R, ldx, kload, wp, ksteps, nullptr, period, dZ, ldy, 0, act_kind, const_cast<float *>(Zprev), cus, s);
 }
 
 // ----------------------------------------------------------------------------
@@ -381,12 +396,133 @@ void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t 
     hipLaunchKernelGGL(narrow_dw_kernel, dim3(grid), dim3(kThreads), 0, s, X, ldx, G, ldg, R, rows_per_wg, o, bias_period);
 }
 
+// The same product with split-fp16 operands (tile_engine.h OpsF16Split; three fp16 MFMAs per multiply-add).  The contraction
+// index of v_mfma_f32_32x32x16_f16 is the ROW, eight consecutive rows per lane, so both matrices are staged TRANSPOSED in LDS
+// ([column][row], two fp16 planes each): thread c owns column c, loads it one row at a time (a wave reads 256 contiguous
+// bytes of a row), splits in registers and stores eight rows per 16-byte LDS write.  32-row chunks, next chunk in flight
+// during the MFMAs, whole K x 256 output in accumulators as in dw_tile_kernel.
+template <int KT>
+__global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, int ldx, int K, const float *G, int ldg, int64_t R,
+                                                               int64_t rows_per_wg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
+                                                               int bias_period)
+{
+    constexpr int RC = 32, LDT = RC + 8;            // halves per transposed column: 80 B, 16-byte aligned row octets
+    constexpr int KP = 32 * KT;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16 *Xh = (_Float16 *)smem, *Xm = Xh + KP * LDT, *Gh = Xm + KP * LDT, *Gm = Gh + kWidth * LDT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int n0 = wave * 64;
+    const int64_t rb = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t re = rb + rows_per_wg < R ? rb + rows_per_wg : R;
+    if (rb >= re) return;
+    f32x16 acc[KT][2];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[kt][t][q] = 0.f;
+    float bsum = 0.f;
+    const bool xcol = tid < KP && tid < K;          // thread tid stages column tid of X (if any) and column tid of G
+    float xr[RC], gr[RC];
+    auto fetch = [&](int64_t c0) {
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+            const bool in = c0 + r < re;
+            xr[r] = (in && xcol) ? X[(c0 + r) * ldx + tid] : 0.f;
+            gr[r] = in ? G[(c0 + r) * ldg + tid] : 0.f;
+        }
+    };
+    auto stage = [&](const float (&v)[RC], _Float16 *ph, _Float16 *pm) {        // column tid: 32 rows -> 4 + 4 LDS writes of 8 halves
+#pragma unroll
+        for (int o = 0; o < RC / 8; ++o) {
+            h8 vh, vm;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float x = v[8 * o + i];
+                h2 t = __builtin_amdgcn_cvt_pkrtz(x, x);
+                vh[i] = (_Float16)t[0];
+                vm[i] = (_Float16)__builtin_amdgcn_fmed3f(x - (float)vh[i], -65504.0f, 65504.0f);
+            }
+            *(h8 *)(ph + tid * LDT + 8 * o) = vh;
+            *(h8 *)(pm + tid * LDT + 8 * o) = vm;
+        }
+    };
+    fetch(rb);
+    for (int64_t c0 = rb; c0 < re; c0 += RC) {
+        __syncthreads();
+        if (tid < KP) stage(xr, Xh, Xm);
+        stage(gr, Gh, Gm);
+        if (db) {
+#pragma unroll
+            for (int r = 0; r < RC; ++r)
+                if (((c0 + r) % bias_period) == 0) bsum += gr[r];      // rows past `re` are zero
+        }
+        __syncthreads();
+        if (c0 + RC < re) fetch(c0 + RC);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int S = 0; S < RC / 16; ++S) {
+            const int ro = 16 * S + 8 * h;
+            h8 bh[2], bm[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bh[t] = *(const h8 *)(Gh + (n0 + 32 * t + j) * LDT + ro);
+                bm[t] = *(const h8 *)(Gm + (n0 + 32 * t + j) * LDT + ro);
+            }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const h8 ah = *(const h8 *)(Xh + (32 * kt + j) * LDT + ro), am = *(const h8 *)(Xm + (32 * kt + j) * LDT + ro);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc[kt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh[t], acc[kt][t], 0, 0, 0);
+                    acc[kt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm[t], acc[kt][t], 0, 0, 0);
+                    acc[kt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[t], acc[kt][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int k = 32 * kt + 8 * (q >> 2) + 4 * h + (q & 3), n = n0 + 32 * t + j;
+                if (k < K && n < nvalid) atomicAdd(&dW[k * sk + n * sn], acc[kt][t][q]);
+            }
+    if (db && tid < nvalid) atomicAdd(&db[tid], bsum);
+}
+
+template <int KT>
+static void launch_dw_split(const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid,
+                            float *db, int bias_period, int cus, hipStream_t s)
+{
+    const size_t lds = (size_t)2 * (32 * KT + kWidth) * 40 * sizeof(_Float16);
+    static bool once = ((void)hipFuncSetAttribute((const void *)dw_split_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)((size_t)2 * (32 * KT + kWidth) * 40 * sizeof(_Float16))), true);
+    (void)once;
+    int64_t chunks = (R + 31) / 32;
+    int grid = (int)(chunks < cus ? chunks : cus);
+    int64_t rows_per_wg = ((chunks + grid - 1) / grid) * 32;
+    hipLaunchKernelGGL((dw_split_kernel<KT>), dim3(grid), dim3(kThreads), lds, s, X, ldx, K, G, ldg, R, rows_per_wg, dW, sk, sn, nvalid, db,
+                       bias_period);
+}
+
 // dW[k * sk + n * sn] += sum_r X[r, k] G[r, n] for k < K <= 256, n < nvalid <= 256 (G has 256 columns, the rest zero);
 // (sk, sn) = (256, 1) for LinearGradLayer weights [in, out], (1, in_total) for nn.Linear weights [out, in]
-void launch_dw(const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
-               int bias_period, int cus, hipStream_t s)
+void launch_dw(int split, const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid,
+               float *db, int bias_period, int cus, hipStream_t s)
 {
     if (R <= 0 || K <= 0) return;
+    if (split) {
+        if (K <= 64) launch_dw_split<2>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
+        else if (K <= 96) launch_dw_split<3>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
+        else launch_dw_split<8>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
+        return;
+    }
     if (K <= 64) launch_dw_tile<2>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
     else if (K <= 96) launch_dw_tile<3>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
     else launch_dw_tile<8>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
@@ -701,7 +837,6 @@ void launch_copy3(const float *in, int ldi, float *out, int ldo, int64_t N, hipS
 __global__ void pack_kernel(const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, int ks, float *dst)
 {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int NT = nout / 128;
     if (idx >= (int64_t)ks * 8 * nout) return;
     int r = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
     int64_t rest = idx >> 8;
@@ -709,11 +844,40 @@ __global__ void pack_kernel(const float *src, int64_t sk, int64_t sn, int k_off,
     int wt = (int)(rest / ks);          // wave * NT + t
     int n = wt * 32 + (lane & 31);
     int k = 8 * S + 4 * (lane >> 5) + r;
-    (void)NT;
     dst[idx] = (k < kcount && n < ncount) ? src[(int64_t)(k_off + k) * sk + (int64_t)(n_off + n) * sn] : 0.f;
 }
-void launch_pack(const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, float *dst, hipStream_t s)
+// the same matrix as split-fp16 fragments (OpsF16Split: 16 k-values per super-step, planes h / m of 2^10 w)
+__global__ void pack_split_kernel(const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, int ks,
+                                  unsigned short *dst)
 {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)ks * 16 * nout) return;
+    int r = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    int64_t frag = idx >> 3;            // ((wave * NT + t) * ks + S) * 64 + lane
+    int64_t rest = idx >> 9;
+    int S = (int)(rest % ks);
+    int wt = (int)(rest / ks);
+    int n = wt * 32 + (lane & 31);
+    int k = 16 * S + 8 * (lane >> 5) + r;
+    float w = (k < kcount && n < ncount) ? src[(int64_t)(k_off + k) * sk + (int64_t)(n_off + n) * sn] : 0.f;
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    const float sv = w * OpsF16Split::kWScale;
+    h2 t = __builtin_amdgcn_cvt_pkrtz(sv, sv);
+    const _Float16 h = (_Float16)t[0];
+    const _Float16 m = (_Float16)(sv - (float)h);
+    dst[(frag * 2 + 0) * 8 + r] = __builtin_bit_cast(unsigned short, h);
+    dst[(frag * 2 + 1) * 8 + r] = __builtin_bit_cast(unsigned short, m);
+}
+void launch_pack(int split, const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, float *dst,
+                 hipStream_t s)
+{
+    if (split) {
+        int ks = (kcount + 15) / 16;
+        int64_t t = (int64_t)ks * 16 * nout;
+        hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, src, sk, sn, k_off, n_off, kcount, ncount, nout, ks,
+                           (unsigned short *)dst);
+        return;
+    }
     int ks = (kcount + 7) / 8;
     int64_t t = (int64_t)ks * 8 * nout;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, src, sk, sn, k_off, n_off, kcount, ncount, nout, ks, dst);

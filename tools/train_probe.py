@@ -29,6 +29,7 @@ def main():
     r.to(dev)
     r.set_iter(1500)
     r.rng = "device"
+    r.network_fine.weight_dtype = os.environ.get("NEDDF_PROBE_DTYPE", "fp32")       # "f16_split": split-fp16 GEMM operands
     cam = neddf_amd.Camera(neddf_amd.PinholeCalib(g["calib"].astype(np.float64)), None).to(dev)
     cam.R, cam.T = torch.from_numpy(g["R"]).to(dev), torch.from_numpy(g["T"]).to(dev)
     losses = [ColorLoss(1.0, 0.1), MaskBCELoss(0.05, 0.005), FieldsConstraintLoss(0.01, 0.01)]
