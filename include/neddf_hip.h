@@ -234,7 +234,13 @@ int neddf_get_timings(neddf_ctx *ctx, float *ms, int n);
  * (the modules under neddf/nn_module/with_grad: each has a hand-written backward for the
  * (value, Jacobian) pair).  These entry points are that forward + backward for one NeDDF
  * network on N sample points.  NeRF fields (nerf.py:107-165; plain torch autograd in the reference) are
- * supported through the same calls: only density and color are produced / consumed, nn.Linear layout.  The parameters are DEVICE fp32 arrays in the reference's
+ * supported through the same calls: only density and color are produced / consumed, nn.Linear layout.
+ * NeuS fields (neus.py:101-162) likewise: d_distance / d_g_distance carry the sdf, penalty and aux_grad are
+ * not touched, d_var is ignored; the last tensor is `variance` (1 element, its bias slot is not read or
+ * written).  The reference differentiates NeuS twice (the normal is torch.autograd.grad(create_graph=True));
+ * here that is the reverse pass over the (value, Jacobian) rows of the sdf trunk, with the second derivative
+ * of tanhExp that torch derives from the plain Function's backward (nn_module/tanh_exp.py:36-60).
+ * The parameters are DEVICE fp32 arrays in the reference's
  * state-dict layout and order (see neddf_set_field); gradients are ACCUMULATED into d_gW / d_gB
  * (same shapes).  The slot supplies the architecture and the set_iter state; the weights it was
  * loaded with are not used here.  `d_workspace` (neddf_train_workspace_floats floats, caller-owned)

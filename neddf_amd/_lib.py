@@ -346,9 +346,10 @@ class Context:
                 raise NeddfError("%s must be contiguous float32 device tensors" % what)
         return (_fp * len(tensors))(*[C.cast(t.data_ptr(), _fp) for t in tensors])
 
-    def train_field_forward(self, slot, weights, biases, pos, dir, var, radiance_only=False):
+    def train_field_forward(self, slot, weights, biases, pos, dir, var, radiance_only=False, sdf=False):
         """Field forward keeping the activations: returns (workspace, distance, density, color, penalty, aux_grad);
-        radiance_only (NeRF fields): distance, penalty and aux_grad are None."""
+        radiance_only (NeRF fields): distance, penalty and aux_grad are None; sdf (NeuS fields): `distance` is the
+        sdf, penalty and aux_grad are None."""
         require_device(pos, "sample positions")
         pos, dir, var = f32c(pos).reshape(-1, 3), f32c(dir).reshape(-1, 3), f32c(var).reshape(-1, 3)
         N = pos.shape[0]
@@ -362,7 +363,7 @@ class Context:
 
         ws = buf(max(int(n_ws), 1))
         density, color = buf(N), buf(N, 3)
-        distance, pen, aux = (None, None, None) if radiance_only else (buf(N), buf(N), buf(N))
+        distance, pen, aux = (None, None, None) if radiance_only else ((buf(N), None, None) if sdf else (buf(N), buf(N), buf(N)))
         wa, ba = self._dev_ptrs(weights, "weights"), self._dev_ptrs(biases, "biases")
         self.check(self.lib.neddf_train_field_forward(self.h, slot, wa, ba, len(weights), _ptr(pos), _ptr(dir), _ptr(var), N,
                                                       _ptr(ws), _ptr(distance), _ptr(density), _ptr(color), _ptr(pen), _ptr(aux),

@@ -74,6 +74,33 @@ class RadianceFieldFunction(torch.autograd.Function):
         return (None,) * 7 + tuple(gw) + tuple(gb)
 
 
+class SdfFieldFunction(torch.autograd.Function):
+    """NeuS.forward (neus.py:101-162) on [N,3] samples -> sdf, density, color.  The reference takes the normal with
+    torch.autograd.grad(create_graph=True), so its parameter gradients are a double backward; here the normal is the
+    Jacobian rows of the sdf trunk and the backward is the ordinary reverse pass over (value, Jacobian) rows.  `params` =
+    weights (..., variance as a 1-element tensor) followed by biases (..., an unused 1-element tensor)."""
+
+    @staticmethod
+    def forward(ctx, hip: Context, slot: int, n_tensors: int, pos: Tensor, dir: Tensor, *params: Tensor) -> Tuple[Tensor, ...]:
+        weights = [p.detach() for p in params[:n_tensors]]
+        biases = [p.detach() for p in params[n_tensors:]]
+        ws, sdf, density, color, _, _ = hip.train_field_forward(slot, weights, biases, pos, dir, torch.zeros_like(pos),
+                                                                radiance_only=False, sdf=True)
+        ctx.hip, ctx.slot, ctx.n_tensors, ctx.n_points = hip, slot, n_tensors, sdf.shape[0]
+        ctx.save_for_backward(ws, *params)
+        return sdf, density, color
+
+    @staticmethod
+    def backward(ctx, g_sdf, g_density, g_color):
+        ws, *params = ctx.saved_tensors
+        n = ctx.n_tensors
+        weights = [p.detach() for p in params[:n]]
+        biases = [p.detach() for p in params[n:]]
+        with torch.cuda.device(ws.device):
+            gw, gb = ctx.hip.train_field_backward(ctx.slot, weights, biases, ctx.n_points, ws, g_sdf, g_density, g_color, None, None)
+        return (None,) * 5 + tuple(gw) + tuple(gb[:-1]) + (None,)
+
+
 class CompositeFunction(torch.autograd.Function):
     """integrate_volume_render (base_neural_render.py:117-172) -> weight, depth, color, transmittance."""
 

@@ -24,7 +24,7 @@ int make_plan(neddf_ctx *ctx, int slot, int64_t N, int n_tensors, Plan &p)
 {
     if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");
     const Field &f = ctx->field[slot];
-    if (f.d.kind != NEDDF_FIELD_NEDDF) return fail(ctx, NEDDF_EUNSUPPORTED, "the training step is implemented for NeDDF and NeRF fields");
+    if (f.d.kind != NEDDF_FIELD_NEDDF) return fail(ctx, NEDDF_EUNSUPPORTED, "unknown field kind");
     p.E = f.d.embed_pos_rank; p.Ed = f.d.embed_dir_rank;
     p.Cpe = 6 * p.E; p.Cdir = 6 * p.Ed; p.Ca = p.Cpe + p.Cdir + 3; p.ldxa = roundup(p.Ca, 8);
     p.n_trunk = f.d.layer_count - 1; p.n_col = f.d.col_layer_count - 1;
@@ -199,6 +199,182 @@ int nerf_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors
     return 0;
 }
 
+
+// ---- NeuS (neus.py:101-162) ---------------------------------------------------------------------------------------------
+// sdf trunk on (value, Jacobian) row groups (the reference's torch.autograd.grad normal is the Jacobian of feature 0, so its
+// double backward is the ordinary backward of those rows), colour trunk on value rows; nn.Linear weights [out, in].
+// Tensor order as neddf_set_field: layers_sdf.0..n-1, layers_col.0..m, variance (1 element; its bias slot is unused).
+static_assert(kActTanhExp == NEDDF_ACT_TANHEXP, "activation ids");
+struct NeusPlan {
+    int E, Ed, Cpe, Cdir, Ca, ldxa, n_sdf, n_col, i_cout, i_var, in_c0;
+    int64_t N, R;
+    size_t o_pe, o_ed, o_xa, o_zo, o_z[kMaxLayers], o_h[kMaxLayers], o_zc[kMaxLayers], o_hc[kMaxLayers], total;
+};
+
+int make_neus_plan(neddf_ctx *ctx, int slot, int64_t N, int n_tensors, NeusPlan &p)
+{
+    const Field &f = ctx->field[slot];
+    p.E = f.d.embed_pos_rank; p.Ed = f.d.embed_dir_rank;
+    p.Cpe = 6 * p.E; p.Cdir = 6 * p.Ed; p.Ca = 6 + p.Cdir; p.ldxa = roundup(p.Ca, 8);
+    p.n_sdf = f.d.layer_count; p.n_col = f.d.col_layer_count;
+    p.i_cout = p.n_sdf + p.n_col; p.i_var = p.i_cout + 1; p.in_c0 = p.Ca + kWidth;
+    if (n_tensors >= 0 && n_tensors != p.n_sdf + p.n_col + 2) return fail(ctx, NEDDF_EINVAL, "NeuS: wrong tensor count");
+    p.N = N; p.R = 4 * N;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += (n + 63) & ~(size_t)63; return at; };
+    p.o_pe = take((size_t)p.R * kLdPe);
+    p.o_ed = take((size_t)N * kLdDir);
+    p.o_xa = take((size_t)N * p.ldxa);
+    p.o_zo = take((size_t)N * kLdNarrow);
+    for (int l = 0; l < p.n_sdf; ++l) { p.o_z[l] = take((size_t)p.R * kWidth); p.o_h[l] = take((size_t)p.R * kWidth); }
+    for (int l = 0; l < p.n_col; ++l) { p.o_zc[l] = take((size_t)N * kWidth); p.o_hc[l] = take((size_t)N * kWidth); }
+    p.total = o;
+    return 0;
+}
+
+void neus_point_args(NeusPointArgs &a, const Field &f, const NeusPlan &p, const float *const *W, float *ws)
+{
+    a = NeusPointArgs{};
+    a.N = p.N; a.act = f.d.activation; a.Cdir = p.Cdir;
+    a.variance = W[p.i_var];
+    a.Ed = ws + p.o_ed; a.ldd = kLdDir;
+    a.Hlast = ws + p.o_h[p.n_sdf - 1]; a.Zlast = ws + p.o_z[p.n_sdf - 1];
+    a.XA = ws + p.o_xa; a.ldxa = p.ldxa;
+    a.ZC = ws + p.o_zo; a.ldc = kLdNarrow;
+}
+
+int neus_forward(neddf_ctx *ctx, int slot, const float *const *W, const float *const *B, int n_tensors, const float *pos, const float *dir,
+                 int64_t N, float *ws, float *sdf, float *density, float *color, hipStream_t s)
+{
+    NeusPlan p;
+    if (int rc = make_neus_plan(ctx, slot, N, n_tensors, p)) return rc;
+    const Field &f = ctx->field[slot];
+    const int act = f.d.activation, cus = ctx->cus;
+    const int sp = f.d.weight_dtype == NEDDF_DTYPE_F16_SPLIT;
+    if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->ttmp, ((size_t)p.R * kLdPe + (size_t)N * 4) * sizeof(float))) return rc;
+    float *wp = (float *)ctx->tpack.p, *wp2 = wp + kPackFloats;
+    float *PEs = (float *)ctx->ttmp.p, *var0 = PEs + (size_t)p.R * kLdPe;
+    float *PE = ws + p.o_pe, *Ed = ws + p.o_ed;
+    // plain PositionalEncoding (neus.py:118-119): no variance weights, no low-pass schedule
+    HIPCHK(hipMemsetAsync(var0, 0, (size_t)N * 3 * sizeof(float), s));
+    EncodeDesc enc;
+    fill_enc(enc, f);
+    for (int i = 0; i < 10; ++i) enc.lowpass[i] = 1.0f;
+    launch_pe_rows(pos, dir, var0, N, enc, PEs, PE, kLdPe, Ed, kLdDir, s);
+    const int kpe = (p.Cpe + 3) & ~3;
+    for (int l = 0; l < p.n_sdf; ++l) {             // neus.py:121-125
+        float *Z = ws + p.o_z[l], *H = ws + p.o_h[l];
+        const bool wide = l > 0 && in_skips(f.d, l - 1);
+        const int in_total = l == 0 ? p.Cpe : (wide ? kWidth + p.Cpe : kWidth);
+        if (l == 0) {
+            launch_pack(sp, W[0], 1, in_total, 0, 0, p.Cpe, kWidth, kWidth, wp, s);
+            launch_rows_gemm(sp, PE, p.R, kLdPe, kpe, wp, gemm_ksteps(p.Cpe, sp), B[0], 4, Z, kWidth, 0, act, H, cus, s);
+        } else if (!wide) {
+            launch_pack(sp, W[l], 1, in_total, 0, 0, kWidth, kWidth, kWidth, wp, s);
+            launch_rows_gemm(sp, ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 4, Z, kWidth, 0, act, H, cus, s);
+        } else {        // cat([hx, embed_pos]): hidden state first
+            launch_pack(sp, W[l], 1, in_total, 0, 0, kWidth, kWidth, kWidth, wp, s);
+            launch_rows_gemm(sp, ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 4, Z, kWidth, 0, -1, nullptr, cus, s);
+            launch_pack(sp, W[l], 1, in_total, kWidth, 0, p.Cpe, kWidth, kWidth, wp2, s);
+            launch_rows_gemm(sp, PE, p.R, kLdPe, kpe, wp2, gemm_ksteps(p.Cpe, sp), nullptr, 4, Z, kWidth, 1, act, H, cus, s);
+        }
+    }
+    NeusPointArgs a;
+    neus_point_args(a, f, p, W, ws);
+    a.pos = pos; a.sdf = sdf; a.density = density; a.color = color;
+    launch_neus_head_forward(a, s);
+    // colour trunk on value rows (neus.py:146-152): the features are the value rows of the last sdf layer (row stride 4 x 256)
+    const float *Hlast = ws + p.o_h[p.n_sdf - 1];
+    for (int l = 0; l < p.n_col; ++l) {
+        float *Z = ws + p.o_zc[l], *H = ws + p.o_hc[l];
+        const float *Wl = W[p.n_sdf + l], *Bl = B[p.n_sdf + l];
+        if (l == 0) {
+            launch_pack(sp, Wl, 1, p.in_c0, 0, 0, p.Ca, kWidth, kWidth, wp, s);
+            launch_rows_gemm(sp, ws + p.o_xa, N, p.ldxa, p.ldxa, wp, gemm_ksteps(p.Ca, sp), Bl, 1, Z, kWidth, 0, -1, nullptr, cus, s);
+            launch_pack(sp, Wl, 1, p.in_c0, p.Ca, 0, kWidth, kWidth, kWidth, wp2, s);
+            launch_rows_gemm(sp, Hlast, N, 4 * kWidth, kWidth, wp2, gemm_ksteps(kWidth, sp), nullptr, 1, Z, kWidth, 1, act, H, cus, s);
+        } else {
+            launch_pack(sp, Wl, 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wp, s);
+            launch_rows_gemm(sp, ws + p.o_hc[l - 1], N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), Bl, 1, Z, kWidth, 0, act, H, cus, s);
+        }
+    }
+    NarrowW cout{};
+    cout.nc = 3; cout.wstride = 1; cout.kcount = kWidth;
+    for (int c = 0; c < 3; ++c) { cout.w[c] = W[p.i_cout] + c * kWidth; cout.b[c] = B[p.i_cout] + c; }
+    launch_narrow_forward(ws + p.o_hc[p.n_col - 1], kWidth, N, cout, 1, ws + p.o_zo, kLdNarrow, s);
+    if (color) launch_neus_color_forward(a, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int neus_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors, int64_t N, float *ws, const float *g_sdf,
+                  const float *g_density, const float *g_color, float *const *gW, float *const *gB, hipStream_t s)
+{
+    NeusPlan p;
+    if (int rc = make_neus_plan(ctx, slot, N, n_tensors, p)) return rc;
+    const Field &f = ctx->field[slot];
+    const int act = f.d.activation, act4 = neus_backward_act_kind(act), cus = ctx->cus;
+    const int sp = f.d.weight_dtype == NEDDF_DTYPE_F16_SPLIT;
+    if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->ttmp, ((size_t)p.R * 2 * kWidth + (size_t)N * 2 * kLdNarrow) * sizeof(float))) return rc;
+    float *wp = (float *)ctx->tpack.p;
+    float *dA = (float *)ctx->ttmp.p, *dB = dA + (size_t)p.R * kWidth, *GC = dB + (size_t)p.R * kWidth, *DG = GC + (size_t)N * kLdNarrow;
+    const float *PE = ws + p.o_pe, *Hlast = ws + p.o_h[p.n_sdf - 1];
+    NeusPointArgs a;
+    neus_point_args(a, f, p, W, ws);
+    a.g_sdf = g_sdf; a.g_density = g_density; a.g_color = g_color;
+    a.GC = GC; a.g_variance = gW[p.i_var];
+    launch_neus_color_backward(a, s);               // GC = g_color a'(ZC); variance gradient
+    // colour trunk, value rows ([N, 256] matrices; dA holds dZ of the layer in flight)
+    NarrowW cout{};
+    cout.nc = 3; cout.wstride = 1; cout.kcount = kWidth;
+    for (int c = 0; c < 3; ++c) cout.w[c] = W[p.i_cout] + c * kWidth;
+    launch_narrow_backward_act(GC, kLdNarrow, N, cout, nullptr, 0, act, 1, ws + p.o_zc[p.n_col - 1], dA, kWidth, s);
+    {
+        float *wc[3] = { gW[p.i_cout], gW[p.i_cout] + kWidth, gW[p.i_cout] + 2 * kWidth }, *bc[3] = { gB[p.i_cout], gB[p.i_cout] + 1, gB[p.i_cout] + 2 };
+        launch_narrow_dw(ws + p.o_hc[p.n_col - 1], kWidth, GC, kLdNarrow, N, 3, wc, 1, bc, 1, kWidth, s);
+    }
+    for (int l = p.n_col - 1; l >= 1; --l) {
+        const float *Wl = W[p.n_sdf + l];
+        launch_dw(sp, ws + p.o_hc[l - 1], kWidth, kWidth, dA, kWidth, N, gW[p.n_sdf + l], 1, kWidth, kWidth, gB[p.n_sdf + l], 1, cus, s);
+        launch_pack(sp, Wl, kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);                // rows = outputs, columns = inputs
+        launch_rows_gemm_actback(sp, dA, N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 1, act, ws + p.o_zc[l - 1], dB, kWidth, cus, s);
+        float *t = dA; dA = dB; dB = t;
+    }
+    {   // first colour layer: weights [256, pos 3 | embed_dir | gradient 3 | features 256]
+        const float *W0 = W[p.n_sdf];
+        float *gW0 = gW[p.n_sdf];
+        launch_dw(sp, ws + p.o_xa, p.ldxa, p.Ca, dA, kWidth, N, gW0, 1, p.in_c0, kWidth, gB[p.n_sdf], 1, cus, s);
+        launch_dw(sp, Hlast, 4 * kWidth, kWidth, dA, kWidth, N, gW0 + p.Ca, 1, p.in_c0, kWidth, nullptr, 1, cus, s);
+        // of the small inputs only the normal depends on parameters: DG[n, k] = dA[n, :] . W0[:, 3 + Cdir + k]
+        NarrowW wn{};
+        wn.nc = 3; wn.wstride = p.in_c0; wn.kcount = kWidth;
+        for (int c = 0; c < 3; ++c) wn.w[c] = W0 + 3 + p.Cdir + c;
+        launch_narrow_forward(dA, kWidth, N, wn, 1, DG, kLdNarrow, s);
+        launch_pack(sp, W0, p.in_c0, 1, 0, p.Ca, kWidth, kWidth, kWidth, wp, s);
+        launch_rows_gemm(sp, dA, N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), nullptr, 1, dB, kWidth, 0, -1, nullptr, cus, s);   // dF
+    }
+    // heads: dZ of the last sdf layer on (value, Jacobian) rows
+    a.dF = dB; a.DG = DG; a.lddg = kLdNarrow; a.dZ = dA;
+    launch_neus_head_backward(a, s);
+    for (int l = p.n_sdf - 1; l >= 0; --l) {
+        const bool wide = l > 0 && in_skips(f.d, l - 1);
+        const int in_total = l == 0 ? p.Cpe : (wide ? kWidth + p.Cpe : kWidth);
+        if (l == 0) {
+            launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, p.R, gW[0], 1, in_total, kWidth, gB[0], 4, cus, s);
+            break;
+        }
+        launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l], 1, in_total, kWidth, gB[l], 4, cus, s);
+        if (wide) launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, p.R, gW[l] + kWidth, 1, in_total, kWidth, nullptr, 4, cus, s);
+        launch_pack(sp, W[l], in_total, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
+        launch_rows_gemm_actback(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 4, act4, ws + p.o_z[l - 1], dB, kWidth, cus, s);
+        float *t = dA; dA = dB; dB = t;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -209,6 +385,11 @@ int64_t neddf_train_workspace_floats(neddf_ctx *ctx, int slot, int64_t n_points)
     if (slot >= 0 && slot < NEDDF_NUM_SLOTS && ctx->field[slot].valid && ctx->field[slot].d.kind == NEDDF_FIELD_NERF) {
         NerfPlan np;
         if (make_nerf_plan(ctx, slot, n_points, -1, np)) return -1;
+        return (int64_t)np.total;
+    }
+    if (slot >= 0 && slot < NEDDF_NUM_SLOTS && ctx->field[slot].valid && ctx->field[slot].d.kind == NEDDF_FIELD_NEUS) {
+        NeusPlan np;
+        if (make_neus_plan(ctx, slot, n_points, -1, np)) return -1;
         return (int64_t)np.total;
     }
     Plan p;
@@ -227,6 +408,8 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     hipStream_t s = (hipStream_t)stream;
     if (slot >= 0 && slot < NEDDF_NUM_SLOTS && ctx->field[slot].valid && ctx->field[slot].d.kind == NEDDF_FIELD_NERF)
         return nerf_forward(ctx, slot, W, B, n_tensors, pos, dir, var, N, ws, density, color, s);
+    if (slot >= 0 && slot < NEDDF_NUM_SLOTS && ctx->field[slot].valid && ctx->field[slot].d.kind == NEDDF_FIELD_NEUS)
+        return neus_forward(ctx, slot, W, B, n_tensors, pos, dir, N, ws, distance, density, color, s);
     Plan p;
     if (int rc = make_plan(ctx, slot, N, n_tensors, p)) return rc;
     const Field &f = ctx->field[slot];
@@ -303,6 +486,8 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     float *ws = const_cast<float *>(ws_);
     if (slot >= 0 && slot < NEDDF_NUM_SLOTS && ctx->field[slot].valid && ctx->field[slot].d.kind == NEDDF_FIELD_NERF)
         return nerf_backward(ctx, slot, W, n_tensors, N, ws, g_density, g_color, gW, gB, s);
+    if (slot >= 0 && slot < NEDDF_NUM_SLOTS && ctx->field[slot].valid && ctx->field[slot].d.kind == NEDDF_FIELD_NEUS)
+        return neus_backward(ctx, slot, W, n_tensors, N, ws, g_distance, g_density, g_color, gW, gB, s);
     Plan p;
     if (int rc = make_plan(ctx, slot, N, n_tensors, p)) return rc;
     const Field &f = ctx->field[slot];

@@ -77,6 +77,33 @@ void launch_narrow_backward(const float *G, int ldg, int64_t R, const NarrowW &w
 // dZ = activation backward (Zprev) of ((accumulate ? dH : 0) + sum_c G[., c] w_c); dH and dZ may alias
 void launch_narrow_backward_act(const float *G, int ldg, int64_t R, const NarrowW &w, const float *dH, int accumulate, int act_kind, int period,
                                 const float *Zprev, float *dZ, int ld, hipStream_t s);
+// NeuS heads (train_kernels.hip "NeuS"): per-point pieces between the sdf trunk and the colour trunk
+constexpr int kActTanhExp = 2;                 // = NEDDF_ACT_TANHEXP (include/neddf_hip.h; checked in train_capi.hip)
+struct NeusPointArgs {
+    int64_t N;
+    int act;                              // hidden activation (also applied to the colour outputs)
+    int Cdir;                             // 6 * embed_dir_rank
+    const float *variance;                // device scalar (the `variance` parameter)
+    const float *pos;                     // [N, 3]
+    const float *Ed; int ldd;             // direction encoding [N, ldd]
+    const float *Hlast, *Zlast;           // last sdf layer, activated / pre-activation, [4N, 256] (value + Jacobian rows)
+    float *XA; int ldxa;                  // colour-trunk small input [N, ldxa] = [pos | embed_dir | gradient | 0]
+    const float *ZC; int ldc;             // raw colour rows [N, ldc] (cols 0..2)
+    float *sdf, *density, *color;         // outputs [N], [N], [N, 3]
+    // backward
+    const float *g_sdf, *g_density, *g_color;
+    float *GC;                            // [N, ldc]: gradient of the raw colour rows
+    const float *dF;                      // [N, 256]: gradient of the features from the colour trunk
+    const float *DG; int lddg;            // [N, lddg] (cols 0..2): gradient of the normal from the colour trunk
+    float *dZ;                            // [4N, 256]
+    float *g_variance;                    // accumulated
+};
+void launch_neus_head_forward(const NeusPointArgs &a, hipStream_t s);
+void launch_neus_color_forward(const NeusPointArgs &a, hipStream_t s);
+void launch_neus_color_backward(const NeusPointArgs &a, hipStream_t s);
+void launch_neus_head_backward(const NeusPointArgs &a, hipStream_t s);
+// activation id for the backward of NeuS' (value, Jacobian) rows: tanhExp maps to the reference's double-backward form
+int neus_backward_act_kind(int act);
 void launch_point_forward(const TrainPointArgs &a, hipStream_t s);
 void launch_penalty_forward(const TrainPointArgs &a, hipStream_t s);
 void launch_point_backward(const TrainPointArgs &a, hipStream_t s);

@@ -29,9 +29,14 @@ __device__ __forceinline__ void act_grad2(float x, float &dy, float &d2)
         float t2 = fmaf(tx, tx, -1.0f);
         bool big = x > 20.0f;
         dy = big ? 1.0f : fmaf(-(x * ex), t2, tx);
-        d2 = big ? 0.0f : ex * (-x + 2 * ex * x * tx - 2) * t2;
+        if (KIND == 2) d2 = big ? 0.0f : ex * (-x + 2 * ex * x * tx - 2) * t2;
+        // KIND 3: what torch's double backward makes of the plain tanhExp Function (nn_module/tanh_exp.py:36-60), which NeuS
+        // differentiates twice (neus.py:136-145): its backward computes tx - x ex (tx^2 - 1) from the saved x, ex, tx, and only
+        // x carries a graph, so the derivative of y' it propagates is -ex (tx^2 - 1), not y''.  Kept, for identical gradients.
+        else d2 = big ? 0.0f : -ex * t2;
     }
 }
+constexpr int kActTanhExpPlain2 = 3;       // backward-only kind id: tanhExp with the second derivative above
 
 // Backward of one activation on a 4-row group of 4 columns, in place on g (the upstream gradient of the group):
 // period 4 = {ReLU,LeakyReLU,TanhExp}GradFunction.backward (dLdx = dLdy y' + sum_i dLdG_i J_i y'', dLdJ_i = dLdG_i y');
@@ -42,7 +47,8 @@ __device__ __forceinline__ void act_backward_group(int kind, int period, const f
     for (int u = 0; u < 4; ++u) {
         if (period == 4) {
             float dy, d2;
-            if (kind == 0) act_grad2<0>(z[0][u], dy, d2); else if (kind == 1) act_grad2<1>(z[0][u], dy, d2); else act_grad2<2>(z[0][u], dy, d2);
+            if (kind == 0) act_grad2<0>(z[0][u], dy, d2); else if (kind == 1) act_grad2<1>(z[0][u], dy, d2);
+            else if (kind == 2) act_grad2<2>(z[0][u], dy, d2); else act_grad2<3>(z[0][u], dy, d2);
             float s = g[1][u] * z[1][u];
             s += g[2][u] * z[2][u];
             s += g[3][u] * z[3][u];
@@ -832,6 +838,123 @@ void launch_copy3(const float *in, int ldi, float *out, int ldo, int64_t N, hipS
     if (N > 0) hipLaunchKernelGGL(copy3_kernel, dim3((unsigned)((N * 3 + 255) / 256)), dim3(256), 0, s, in, ldi, out, ldo, N);
 }
 
+// ----------------------------------------------------------------------------
+// NeuS (neus.py:118-156).  The sdf trunk runs on (value, Jacobian) row groups like NeDDF's distance trunk; sdf is feature 0
+// of the last activated layer and the normal ("gradients", torch.autograd.grad in the reference) its three Jacobian rows.
+__device__ __forceinline__ void neus_density(float v10, float sdf, float &rho, float &drho_ds, float &drho_dv10)
+{
+    const float ex = expf(-v10 * sdf);                     // neus.py:153-156
+    const float den = 1.0f + ex, r = 1.0f / (den * den);
+    rho = v10 * ex * r;
+    const float q = ex * (1.0f - ex) * r / den;            // e (1 - e) / (1 + e)^3
+    drho_ds = -v10 * v10 * q;
+    drho_dv10 = ex * r - v10 * sdf * q;
+}
+
+// XA[N, ldxa] = [pos | embed_dir | gradient | 0] (the small-input segment of the colour trunk, neus.py:146-149), sdf, density
+__global__ void neus_head_forward_kernel(NeusPointArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N * a.ldxa) return;
+    const int64_t n = i / a.ldxa;
+    const int c = (int)(i - n * a.ldxa);
+    const float *h = a.Hlast + n * 4 * kWidth;
+    float v = 0.f;
+    if (c < 3) v = a.pos[n * 3 + c];
+    else if (c < 3 + a.Cdir) v = a.Ed[n * a.ldd + c - 3];
+    else if (c < 6 + a.Cdir) v = h[(1 + c - 3 - a.Cdir) * kWidth];
+    a.XA[i] = v;
+    if (c == 0) {
+        const float sdf = h[0];
+        float rho, ds, dv;
+        neus_density(10.0f * a.variance[0], sdf, rho, ds, dv);
+        if (a.sdf) a.sdf[n] = sdf;
+        if (a.density) a.density[n] = rho;
+    }
+}
+void launch_neus_head_forward(const NeusPointArgs &a, hipStream_t s)
+{
+    int64_t t = a.N * a.ldxa;
+    if (t > 0) hipLaunchKernelGGL(neus_head_forward_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// colour = activation(ZC) on the three outputs (neus.py:150-152: the activation follows every colour layer, the last included)
+__global__ void neus_color_forward_kernel(NeusPointArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N * 3) return;
+    const int64_t n = i / 3;
+    const int c = (int)(i - 3 * n);
+    a.color[i] = act_val_rt(a.act, a.ZC[n * a.ldc + c]);
+}
+void launch_neus_color_forward(const NeusPointArgs &a, hipStream_t s)
+{
+    if (a.N > 0) hipLaunchKernelGGL(neus_color_forward_kernel, dim3((unsigned)((a.N * 3 + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// GC[N, ldc] = g_color * activation'(ZC) (cols 0..2, col 3 = 0); g_variance += 10 sum_n g_density drho/d(10 variance)
+__global__ __launch_bounds__(256) void neus_color_backward_kernel(NeusPointArgs a)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float gv = 0.f;
+    if (n < a.N) {
+        float *gc = a.GC + n * a.ldc;
+        for (int c = 0; c < 3; ++c) {
+            const float x = a.ZC[n * a.ldc + c];
+            float dy, d2;
+            if (a.act == 0) dy = x > 0.f ? 1.f : 0.f;
+            else if (a.act == 1) dy = x > 0.f ? 1.f : 0.01f;
+            else act_grad2<2>(x, dy, d2);
+            gc[c] = a.g_color ? a.g_color[n * 3 + c] * dy : 0.f;
+        }
+        for (int c = 3; c < a.ldc; ++c) gc[c] = 0.f;
+        if (a.g_density) {
+            float rho, ds, dv;
+            neus_density(10.0f * a.variance[0], a.Hlast[n * 4 * kWidth], rho, ds, dv);
+            gv = 10.0f * a.g_density[n] * dv;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) gv += __shfl_xor(gv, off, 64);
+    if ((threadIdx.x & 63) == 0 && gv != 0.f) atomicAdd(a.g_variance, gv);
+}
+void launch_neus_color_backward(const NeusPointArgs &a, hipStream_t s)
+{
+    if (a.N > 0) hipLaunchKernelGGL(neus_color_backward_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// dZ[4N, 256] of the last sdf layer: the colour trunk's gradient of the features (dF, value rows) and of the normal (DG, feature 0
+// of the Jacobian rows), the upstream gradients of sdf and density (feature 0 of the value row), through the last activation.
+__global__ void neus_head_backward_kernel(NeusPointArgs a, int act_kind)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N * (kWidth / 4)) return;
+    const int64_t n = i >> 6;
+    const int c4 = (int)(i & 63);
+    const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
+    f32x4v g[4] = { *(const f32x4v *)(a.dF + n * kWidth + 4 * c4), zero, zero, zero }, z[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[r] = *(const f32x4v *)(a.Zlast + (n * 4 + r) * kWidth + 4 * c4);
+    if (c4 == 0) {
+        float gs = a.g_sdf ? a.g_sdf[n] : 0.f;
+        if (a.g_density) {
+            float rho, ds, dv;
+            neus_density(10.0f * a.variance[0], a.Hlast[n * 4 * kWidth], rho, ds, dv);
+            gs = fmaf(a.g_density[n], ds, gs);
+        }
+        g[0][0] += gs;
+        for (int k = 0; k < 3; ++k) g[1 + k][0] = a.DG[n * a.lddg + k];
+    }
+    act_backward_group(act_kind, 4, z, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *(f32x4v *)(a.dZ + (n * 4 + r) * kWidth + 4 * c4) = g[r];
+}
+int neus_backward_act_kind(int act) { return act == kActTanhExp ? kActTanhExpPlain2 : act; }
+void launch_neus_head_backward(const NeusPointArgs &a, hipStream_t s)
+{
+    int64_t t = a.N * (kWidth / 4);
+    if (t > 0) hipLaunchKernelGGL(neus_head_backward_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, a, neus_backward_act_kind(a.act));
+}
 // ----------------------------------------------------------------------------
 // on-device weight packing (the parameters live in torch tensors and change every optimiser step)
 __global__ void pack_kernel(const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, int ks, float *dst)

@@ -14,7 +14,7 @@ from torch import Tensor, nn
 from ._lib import SLOT_COARSE, SLOT_FINE, Context, NeddfError, RenderParams
 from .camera import Camera
 from .config import instantiate
-from .network import BaseNeuralField, NeDDF, NeRF
+from .network import BaseNeuralField, NeDDF
 
 RenderTarget = str          # Literal["color", "depth", "transmittance"]
 SamplingType = str          # Literal["point", "cone"]
@@ -161,7 +161,7 @@ class NeRFRender(BaseNeuralRender):
         """nerf_render.py:109-188.  Keys: weight, depth, color, transmittance[, fields_penalty] + *_coarse."""
         uv = uv.to(camera.device)
         B = uv.shape[0]
-        if torch.is_grad_enabled() and isinstance(self.network_fine, (NeDDF, NeRF)) and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return self._render_rays_with_grad(uv, camera)
         ctx = self._ctx(uv.device)
         U_c = self._rand(B, self.sample_coarse + 1, uv.device)       # draw order is part of the contract

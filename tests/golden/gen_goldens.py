@@ -604,6 +604,47 @@ def gen_train_nerf():
     save("train_nerf.npz", **arrs)
 
 
+def gen_train_neus():
+    """NeuS fields under the reference's autograd (neus.py:101-162: the normal comes from torch.autograd.grad with
+    create_graph=True, so the parameter gradients below are a double backward) on 40 and 250 points with random upstream
+    gradients on sdf, density and colour."""
+    arrs = {}
+    rng = np.random.default_rng(2025)
+    cases = {
+        "relu": (dict(embed_pos_rank=6, embed_dir_rank=4, sdf_layer_count=8, sdf_layer_width=256, col_layer_count=8,
+                      col_layer_width=256, init_variance=0.3, activation_type="ReLU", skips=[4]), (2, 20)),
+        "tanhexp": (dict(embed_pos_rank=10, embed_dir_rank=3, sdf_layer_count=6, sdf_layer_width=256, col_layer_count=3,
+                         col_layer_width=256, init_variance=0.7, activation_type="tanhExp", skips=[2]), (2, 20)),
+        "relu250": (dict(embed_pos_rank=6, embed_dir_rank=4, sdf_layer_count=8, sdf_layer_width=256, col_layer_count=8,
+                         col_layer_width=256, init_variance=0.3, activation_type="ReLU", skips=[4]), (10, 25)),
+    }
+    for tag, (kw, shape) in cases.items():
+        net = NeuS(**kw)
+        sd = synth.neus_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["sdf_layer_count"], kw["sdf_layer_width"],
+                              kw["col_layer_count"], kw["col_layer_width"], tuple(kw["skips"]), kw["init_variance"], seed=13)
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        pos, dd, var = synth.random_sampling(shape[0], shape[1], seed=43, cone=False)
+        ups = {"sdf": torch.from_numpy(rng.standard_normal(shape).astype(np.float32)),
+               "density": torch.from_numpy(rng.standard_normal(shape).astype(np.float32)),
+               "color": torch.from_numpy(rng.standard_normal(shape + (3,)).astype(np.float32))}
+        with torch.enable_grad():
+            net.zero_grad()
+            o = net(Sampling(torch.from_numpy(pos.copy()), torch.from_numpy(dd), torch.from_numpy(var)))
+            sum((o[k] * ups[k]).sum() for k in ups).backward()
+        pre = "fb_%s_" % tag
+        arrs.update({pre + "pos": pos, pre + "dir": dd, pre + "var": var, pre + "config": np.array(json.dumps(kw))})
+        for k in ups:
+            arrs[pre + "g_" + k] = npy(ups[k])
+            arrs[pre + "out_" + k] = npy(o[k])
+        n_sdf, n_col = kw["sdf_layer_count"], kw["col_layer_count"]
+        full = ("variance", "layers_sdf.0.weight", "layers_sdf.%d.bias" % (n_sdf - 1), "layers_col.0.bias",
+                "layers_col.%d.weight" % n_col, "layers_col.%d.bias" % n_col)
+        _grad_records(arrs, pre, net, 457, full)
+        for k, p_ in net.named_parameters():
+            print(tag, k, float(p_.grad.abs().max()))
+    save("train_neus.npz", **arrs)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train_nerf":
         gen_train_nerf()
@@ -614,6 +655,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "neus":
         gen_neus()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "train_neus":
+        gen_train_neus()
+        sys.exit(0)
     r = gen_bunny()
     gen_ops()
     gen_fields()
@@ -621,3 +665,4 @@ if __name__ == "__main__":
     gen_neus()
     gen_train()
     gen_train_nerf()
+    gen_train_neus()
