@@ -86,9 +86,15 @@ __device__ __forceinline__ void encode_dir(typename Ops::act_t *act, int col0, c
 // Tile scheduling: tiles are pulled from a global queue (one atomicAdd per tile,
 // issued a whole tile ahead of its use) instead of a static stride, so workgroups
 // that progress unevenly (two share a CU) do not unbalance the launch tail.
-// sched_flags (NEDDF_SCHED, debug): bit 1 = dynamic queue (default on); bits 2..5
-// switch off phases of the distance kernel for timing ablations (results invalid).
+// sched_flags (NEDDF_SCHED): bit 1 = dynamic queue (default on).  Bits 2..6 switch off phases of the distance
+// kernel for timing ablations (results invalid); they exist only in builds with -DNEDDF_ABLATE (`make ABLATE=1`, used
+// by tools/ablate_probe.py) and compile to nothing in the shipped library.
 // ctl[0] = next tile index, written by thread 0.
+#ifdef NEDDF_ABLATE
+#define NEDDF_ABL(flags, bit) ((flags) & (bit))
+#else
+#define NEDDF_ABL(flags, bit) 0
+#endif
 __device__ __forceinline__ int64_t sched_begin(int *sched, int flags, int *ctl, int tid)
 {
     if (tid == 0) ctl[0] = (flags & 2) ? atomicAdd(&sched[0], 1) : (int)blockIdx.x;
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
         __syncthreads();
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);     // consumed at the end of this tile
-        if (!(a.sched_flags & 32)) {
+        if (!(NEDDF_ABL(a.sched_flags, 32))) {
             if (a.neus) encode_pos<true, false, Ops>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid, false);   // plain PE (neus.py:118)
             else encode_pos<true, true, Ops>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
         }
@@ -176,14 +182,14 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
                 if (!done) stash_add<MT, NT>(acc, scratch + (size_t)L.stash * kStashFloatsPerWg, wave, lane);
             }
             const frag *wl = (const frag *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane;
-            if (!(a.sched_flags & 8)) dense_pre<MT, NT, Ops>(acc, act_lane, wl, L.ksteps, pre);
+            if (!(NEDDF_ABL(a.sched_flags, 8))) dense_pre<MT, NT, Ops>(acc, act_lane, wl, L.ksteps, pre);
             if (l + 1 < a.n_layers)                 // next layer's first fragments fly during the epilogue
                 layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
-            if (!(a.sched_flags & 64)) __syncthreads();   // every wave finished reading the previous activations
-            if (!(a.sched_flags & 4)) epilogue_rt<MT, NT, true, Ops>(acc, act, a.activation, wave, lane);
-            if (!(a.sched_flags & 64)) __syncthreads();
+            if (!(NEDDF_ABL(a.sched_flags, 64))) __syncthreads();   // every wave finished reading the previous activations
+            if (!(NEDDF_ABL(a.sched_flags, 4))) epilogue_rt<MT, NT, true, Ops>(acc, act, a.activation, wave, lane);
+            if (!(NEDDF_ABL(a.sched_flags, 64))) __syncthreads();
         }
-        if (a.sched_flags & 16) {                   // ablation: skip heads / hand-off
+        if (NEDDF_ABL(a.sched_flags, 16)) {                   // ablation: skip heads / hand-off
             if (tid == 0) ctl[0] = next_tile;
             __syncthreads();
             tile = ctl[0];

@@ -63,7 +63,7 @@ struct DdfArgs {
     float neus_v10;                       // variance * 10
     float *scratch;                       // per-workgroup stash area
     int *sched;                           // [0] tile queue head (zeroed before each launch)
-    int sched_flags;                      // bit 1: dynamic tile queue; bits 2..5: timing ablations (debug)
+    int sched_flags;                      // bit 1: dynamic tile queue; higher bits: timing ablations, -DNEDDF_ABLATE builds only
     float *features;                      // [n_points][feat_rows][256]
     int feat_rows;                        // 1 (value row) or 4 (value + Jacobian rows)
     float *ptaux;                         // [n_points][kPtAux]

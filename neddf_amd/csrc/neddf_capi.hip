@@ -19,13 +19,18 @@ using namespace neddf;
 
 static char g_err[256] = "no context";
 
-// NEDDF_SCHED (debug/ablation): bit 1 dynamic tile queue (default on); bits 2..5 phase ablations of the distance kernel
+// NEDDF_SCHED: bit 1 dynamic tile queue (default on).  The phase-ablation bits of the distance kernel are honoured only by
+// -DNEDDF_ABLATE builds (field_kernels.hip); the shipped library masks them off.
 static int sched_flags()
 {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("NEDDF_SCHED");
-        v = e ? atoi(e) & 126 : 2;      // bits 2..5: timing ablations of the distance kernel (results invalid)
+#ifdef NEDDF_ABLATE
+        v = e ? atoi(e) & 126 : 2;
+#else
+        v = e ? atoi(e) & 2 : 2;
+#endif
     }
     return v;
 }

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Timing ablation of the distance-trunk kernel (NEDDF_SCHED bits, see field_kernels.hip); results are invalid by design."""
+"""Timing ablation of the distance-trunk kernel (NEDDF_SCHED bits, see field_kernels.hip); results are invalid by design.
+Needs a library built with the ablation switches: `make -C neddf_amd/csrc clean && make -C neddf_amd/csrc ABLATE=1`
+(the shipped build compiles them out); rebuild without ABLATE afterwards."""
 import os, sys, math
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
