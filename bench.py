@@ -170,7 +170,8 @@ def train_workload(args, dev, world=1, rank=0, use_dist=False):
     # input gradients of the first layers of both trunks, which are never needed
     flop = pts * (3 * 2 * 4 * 644096 - 2 * 4 * (60 * 256 + 87 * 256))
     achieved = flop * args.steps / elapsed / 1e12
-    return {"metric": "training rays/sec (1024-ray steps, 65 coarse + 194 fine samples, NeDDF fp32)", "value": rays * world * args.steps / elapsed,
+    return {"metric": "training rays/sec (1024-ray steps, 65 coarse + 194 fine samples, NeDDF %s)" % ("fp32" if args.dtype == "f32" else args.dtype),
+            "value": rays * world * args.steps / elapsed,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "training step: render_rays with autograd -> ColorLoss + MaskBCELoss + FieldsConstraintLoss -> backward -> "

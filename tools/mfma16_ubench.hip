@@ -52,7 +52,6 @@ __global__ __launch_bounds__(256, WPS) void k(const void *w, float *out, int ite
         for (int S = 0; S < ksteps; S += D + 1) {
 #pragma unroll
             for (int u = 0; u <= D; ++u) {
-                constexpr int dummy = 0; (void)dummy;
                 const int slot = (u + D) % (D + 1);
                 int Sn = S + u + D;
                 if (Sn >= ksteps) Sn -= ksteps;
