@@ -37,6 +37,7 @@ struct neddf_ctx {
     Field field[NEDDF_NUM_SLOTS];
     DevBuf features, ptaux, scratch, arena, flags, sched;
     DevBuf tpack, ttmp;          // training step: packed weights of the layer in flight, gradient ping-pong buffers
+    DevBuf tamax;                // training step: max |dZ| of every gradient matrix of a backward pass (split-fp16 operand range)
     bool timing = false;
     std::vector<EventPair> events;
     std::vector<EventPair> pool;

@@ -504,7 +504,7 @@ void neddf_destroy(neddf_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto &f : ctx->field) if (f.blob.p) (void)hipFree(f.blob.p);
-    for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags, &ctx->sched, &ctx->tpack, &ctx->ttmp })
+    for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags, &ctx->sched, &ctx->tpack, &ctx->ttmp, &ctx->tamax })
         if (b->p) (void)hipFree(b->p);
     for (auto &e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : ctx->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

@@ -59,6 +59,26 @@ void point_args(TrainPointArgs &a, const Field &f, const Plan &p, float *ws)
 
 constexpr size_t kPackFloats = (size_t)kWidth * kWidth;        // one packed 256 x 256 segment
 
+// One device scalar per gradient matrix of a backward pass: its producer leaves max |dZ| there, the split-fp16 GEMMs that consume
+// it scale their operand by the matching power of two (train_kernels.hip operand_scale).  NULL slots under the fp32 policy.
+constexpr int kAmaxSlots = 4 * kMaxLayers + 8;
+struct AmaxSlots {
+    float *base = nullptr;
+    float *dw_tmp = nullptr;        // [256, 256] scratch of the scaled weight-gradient products (launch_dw)
+    int next = 0;
+    float *take() { return base ? base + next++ : nullptr; }
+};
+int amax_begin(neddf_ctx *ctx, int split, AmaxSlots &m, hipStream_t s)
+{
+    m = AmaxSlots{};
+    if (!split) return 0;
+    if (int rc = ensure(ctx, ctx->tamax, (kAmaxSlots + kPackFloats) * sizeof(float))) return rc;
+    HIPCHK(hipMemsetAsync(ctx->tamax.p, 0, kAmaxSlots * sizeof(float), s));
+    m.base = (float *)ctx->tamax.p;
+    m.dw_tmp = m.base + kAmaxSlots;
+    return 0;
+}
+
 // ---- plain NeRF field (nerf.py:107-165): value rows only, nn.Linear weights [out, in] -------------------------------
 struct NerfPlan {
     int E, Ed, Cpe, Cdir, n, i_dens, i_c0, i_c1, in_c0;
@@ -161,22 +181,26 @@ int nerf_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors
     NarrowW c1{};
     c1.nc = 3; c1.wstride = 1; c1.kcount = half;
     for (int c = 0; c < 3; ++c) c1.w[c] = W[p.i_c1] + c * half;
-    launch_narrow_backward_act(GC, kLdNarrow, N, c1, nullptr, 0, NEDDF_ACT_RELU, 1, ws + p.o_zc, dA, kWidth, s);
+    AmaxSlots am;
+    if (int rc = amax_begin(ctx, sp, am, s)) return rc;
+    float *mA = am.take();          // max |dA| of the gradient matrix currently in dA
+    launch_narrow_backward_act(GC, kLdNarrow, N, c1, nullptr, 0, NEDDF_ACT_RELU, 1, ws + p.o_zc, dA, kWidth, s, mA);
     {
         float *wc[3] = { gW[p.i_c1], gW[p.i_c1] + half, gW[p.i_c1] + 2 * half }, *bc[3] = { gB[p.i_c1], gB[p.i_c1] + 1, gB[p.i_c1] + 2 };
         launch_narrow_dw(ws + p.o_hc, kWidth, GC, kLdNarrow, N, 3, wc, 1, bc, 1, half, s);
     }
     // first colour layer (weights [128, 256 + dir])
-    launch_dw(sp, Hlast, kWidth, kWidth, dA, kWidth, N, gW[p.i_c0], 1, p.in_c0, half, gB[p.i_c0], 1, cus, s);
-    launch_dw(sp, Ed, kLdDir, p.Cdir, dA, kWidth, N, gW[p.i_c0] + kWidth, 1, p.in_c0, half, nullptr, 1, cus, s);
+    launch_dw(sp, Hlast, kWidth, kWidth, dA, kWidth, N, gW[p.i_c0], 1, p.in_c0, half, gB[p.i_c0], 1, cus, s, mA, am.dw_tmp);
+    launch_dw(sp, Ed, kLdDir, p.Cdir, dA, kWidth, N, gW[p.i_c0] + kWidth, 1, p.in_c0, half, nullptr, 1, cus, s, mA, am.dw_tmp);
     launch_pack(sp, W[p.i_c0], p.in_c0, 1, 0, 0, half, kWidth, kWidth, wp, s);                // rows = the 128 outputs, columns = hidden inputs
-    launch_rows_gemm(sp, dA, N, kWidth, half, wp, gemm_ksteps(half, sp), nullptr, 1, dB, kWidth, 0, -1, nullptr, cus, s);
+    launch_rows_gemm(sp, dA, N, kWidth, half, wp, gemm_ksteps(half, sp), nullptr, 1, dB, kWidth, 0, -1, nullptr, cus, s, mA);
     // density head, then the last trunk activation: dA = dZ of the last trunk layer
     if (g_density) launch_density_head(f.d.density_activation, ws + p.o_zd, kLdNarrow, N, g_density, GD, kLdNarrow, s);
     NarrowW dens{};
     dens.nc = 1; dens.wstride = 1; dens.kcount = kWidth;
     dens.w[0] = W[p.i_dens];
-    launch_narrow_backward_act(GD, kLdNarrow, N, dens, dB, 1, act, 1, ws + p.o_z[p.n - 1], dA, kWidth, s);
+    mA = am.take();
+    launch_narrow_backward_act(GD, kLdNarrow, N, dens, dB, 1, act, 1, ws + p.o_z[p.n - 1], dA, kWidth, s, mA);
     {
         float *wd[1] = { gW[p.i_dens] }, *bd[1] = { gB[p.i_dens] };
         launch_narrow_dw(Hlast, kWidth, GD, kLdNarrow, N, 1, wd, 1, bd, 1, kWidth, s);
@@ -186,14 +210,16 @@ int nerf_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors
         const bool wide = l > 0 && in_skips(f.d, l - 1);
         const int in_total = l == 0 ? p.Cpe : (wide ? kWidth + p.Cpe : kWidth);
         if (l == 0) {
-            launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, N, gW[0], 1, in_total, kWidth, gB[0], 1, cus, s);
+            launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, N, gW[0], 1, in_total, kWidth, gB[0], 1, cus, s, mA, am.dw_tmp);
             break;
         }
-        launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, N, gW[l], 1, in_total, kWidth, gB[l], 1, cus, s);
-        if (wide) launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, N, gW[l] + kWidth, 1, in_total, kWidth, nullptr, 1, cus, s);
+        launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, N, gW[l], 1, in_total, kWidth, gB[l], 1, cus, s, mA, am.dw_tmp);
+        if (wide) launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, N, gW[l] + kWidth, 1, in_total, kWidth, nullptr, 1, cus, s, mA, am.dw_tmp);
         launch_pack(sp, W[l], in_total, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
-        launch_rows_gemm_actback(sp, dA, N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 1, act, ws + p.o_z[l - 1], dB, kWidth, cus, s);
+        float *mB = am.take();
+        launch_rows_gemm_actback(sp, dA, N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 1, act, ws + p.o_z[l - 1], dB, kWidth, cus, s, mA, mB);
         float *t = dA; dA = dB; dB = t;
+        mA = mB;
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -330,46 +356,54 @@ int neus_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors
     NarrowW cout{};
     cout.nc = 3; cout.wstride = 1; cout.kcount = kWidth;
     for (int c = 0; c < 3; ++c) cout.w[c] = W[p.i_cout] + c * kWidth;
-    launch_narrow_backward_act(GC, kLdNarrow, N, cout, nullptr, 0, act, 1, ws + p.o_zc[p.n_col - 1], dA, kWidth, s);
+    AmaxSlots am;
+    if (int rc = amax_begin(ctx, sp, am, s)) return rc;
+    float *mA = am.take();          // max |dA| of the gradient matrix currently in dA
+    launch_narrow_backward_act(GC, kLdNarrow, N, cout, nullptr, 0, act, 1, ws + p.o_zc[p.n_col - 1], dA, kWidth, s, mA);
     {
         float *wc[3] = { gW[p.i_cout], gW[p.i_cout] + kWidth, gW[p.i_cout] + 2 * kWidth }, *bc[3] = { gB[p.i_cout], gB[p.i_cout] + 1, gB[p.i_cout] + 2 };
         launch_narrow_dw(ws + p.o_hc[p.n_col - 1], kWidth, GC, kLdNarrow, N, 3, wc, 1, bc, 1, kWidth, s);
     }
     for (int l = p.n_col - 1; l >= 1; --l) {
         const float *Wl = W[p.n_sdf + l];
-        launch_dw(sp, ws + p.o_hc[l - 1], kWidth, kWidth, dA, kWidth, N, gW[p.n_sdf + l], 1, kWidth, kWidth, gB[p.n_sdf + l], 1, cus, s);
+        launch_dw(sp, ws + p.o_hc[l - 1], kWidth, kWidth, dA, kWidth, N, gW[p.n_sdf + l], 1, kWidth, kWidth, gB[p.n_sdf + l], 1, cus, s, mA, am.dw_tmp);
         launch_pack(sp, Wl, kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);                // rows = outputs, columns = inputs
-        launch_rows_gemm_actback(sp, dA, N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 1, act, ws + p.o_zc[l - 1], dB, kWidth, cus, s);
+        float *mB = am.take();
+        launch_rows_gemm_actback(sp, dA, N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 1, act, ws + p.o_zc[l - 1], dB, kWidth, cus, s, mA, mB);
         float *t = dA; dA = dB; dB = t;
+        mA = mB;
     }
     {   // first colour layer: weights [256, pos 3 | embed_dir | gradient 3 | features 256]
         const float *W0 = W[p.n_sdf];
         float *gW0 = gW[p.n_sdf];
-        launch_dw(sp, ws + p.o_xa, p.ldxa, p.Ca, dA, kWidth, N, gW0, 1, p.in_c0, kWidth, gB[p.n_sdf], 1, cus, s);
-        launch_dw(sp, Hlast, 4 * kWidth, kWidth, dA, kWidth, N, gW0 + p.Ca, 1, p.in_c0, kWidth, nullptr, 1, cus, s);
+        launch_dw(sp, ws + p.o_xa, p.ldxa, p.Ca, dA, kWidth, N, gW0, 1, p.in_c0, kWidth, gB[p.n_sdf], 1, cus, s, mA, am.dw_tmp);
+        launch_dw(sp, Hlast, 4 * kWidth, kWidth, dA, kWidth, N, gW0 + p.Ca, 1, p.in_c0, kWidth, nullptr, 1, cus, s, mA, am.dw_tmp);
         // of the small inputs only the normal depends on parameters: DG[n, k] = dA[n, :] . W0[:, 3 + Cdir + k]
         NarrowW wn{};
         wn.nc = 3; wn.wstride = p.in_c0; wn.kcount = kWidth;
         for (int c = 0; c < 3; ++c) wn.w[c] = W0 + 3 + p.Cdir + c;
         launch_narrow_forward(dA, kWidth, N, wn, 1, DG, kLdNarrow, s);
         launch_pack(sp, W0, p.in_c0, 1, 0, p.Ca, kWidth, kWidth, kWidth, wp, s);
-        launch_rows_gemm(sp, dA, N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), nullptr, 1, dB, kWidth, 0, -1, nullptr, cus, s);   // dF
+        launch_rows_gemm(sp, dA, N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), nullptr, 1, dB, kWidth, 0, -1, nullptr, cus, s, mA);   // dF
     }
     // heads: dZ of the last sdf layer on (value, Jacobian) rows
-    a.dF = dB; a.DG = DG; a.lddg = kLdNarrow; a.dZ = dA;
+    mA = am.take();
+    a.dF = dB; a.DG = DG; a.lddg = kLdNarrow; a.dZ = dA; a.amax_out = mA;
     launch_neus_head_backward(a, s);
     for (int l = p.n_sdf - 1; l >= 0; --l) {
         const bool wide = l > 0 && in_skips(f.d, l - 1);
         const int in_total = l == 0 ? p.Cpe : (wide ? kWidth + p.Cpe : kWidth);
         if (l == 0) {
-            launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, p.R, gW[0], 1, in_total, kWidth, gB[0], 4, cus, s);
+            launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, p.R, gW[0], 1, in_total, kWidth, gB[0], 4, cus, s, mA, am.dw_tmp);
             break;
         }
-        launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l], 1, in_total, kWidth, gB[l], 4, cus, s);
-        if (wide) launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, p.R, gW[l] + kWidth, 1, in_total, kWidth, nullptr, 4, cus, s);
+        launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l], 1, in_total, kWidth, gB[l], 4, cus, s, mA, am.dw_tmp);
+        if (wide) launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, p.R, gW[l] + kWidth, 1, in_total, kWidth, nullptr, 4, cus, s, mA, am.dw_tmp);
         launch_pack(sp, W[l], in_total, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
-        launch_rows_gemm_actback(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 4, act4, ws + p.o_z[l - 1], dB, kWidth, cus, s);
+        float *mB = am.take();
+        launch_rows_gemm_actback(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 4, act4, ws + p.o_z[l - 1], dB, kWidth, cus, s, mA, mB);
         float *t = dA; dA = dB; dB = t;
+        mA = mB;
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -510,7 +544,10 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     cout.nc = 3; cout.wstride = 3; cout.kcount = kWidth;
     for (int c = 0; c < 3; ++c) cout.w[c] = W[p.i_cout] + c;
     const float *HClast = ws + p.o_hc[p.n_col - 1];
-    launch_narrow_backward_act(GCR, kLdNarrow, p.R, cout, nullptr, 0, act, 4, ws + p.o_zc[p.n_col - 1], dA, kWidth, s);
+    AmaxSlots am;
+    if (int rc = amax_begin(ctx, sp, am, s)) return rc;
+    float *mA = am.take();          // max |dA| of the gradient matrix currently in dA
+    launch_narrow_backward_act(GCR, kLdNarrow, p.R, cout, nullptr, 0, act, 4, ws + p.o_zc[p.n_col - 1], dA, kWidth, s, mA);
     {
         float *wc[3] = { gW[p.i_cout], gW[p.i_cout] + 1, gW[p.i_cout] + 2 }, *bc[3] = { gB[p.i_cout], gB[p.i_cout] + 1, gB[p.i_cout] + 2 };
         launch_narrow_dw(HClast, kWidth, GCR, kLdNarrow, p.R, 3, wc, 3, bc, 4, kWidth, s);
@@ -520,15 +557,18 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         const float *Wl = W[p.n_trunk + l];
         float *gWl = gW[p.n_trunk + l], *gBl = gB[p.n_trunk + l];
         if (l > 0) {
-            launch_dw(sp, ws + p.o_hc[l - 1], kWidth, kWidth, dA, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s);
+            launch_dw(sp, ws + p.o_hc[l - 1], kWidth, kWidth, dA, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s, mA, am.dw_tmp);
             launch_pack(sp, Wl, 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wp, s);                 // W^T
-            launch_rows_gemm_actback(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 4, act, ws + p.o_zc[l - 1], dB, kWidth, ctx->cus, s);
+            float *mB = am.take();
+            launch_rows_gemm_actback(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 4, act, ws + p.o_zc[l - 1], dB, kWidth, ctx->cus, s,
+                                     mA, mB);
+            mA = mB;
         } else {
-            launch_dw(sp, ws + p.o_xa, p.ldxa, p.Ca, dA, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s);
-            launch_dw(sp, Hlast, kWidth, kWidth, dA, kWidth, p.R, gWl + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s);
+            launch_dw(sp, ws + p.o_xa, p.ldxa, p.Ca, dA, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s, mA, am.dw_tmp);
+            launch_dw(sp, Hlast, kWidth, kWidth, dA, kWidth, p.R, gWl + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s, mA, am.dw_tmp);
             launch_pack(sp, Wl, 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wp, s);              // (feature rows of W)^T
             // the small colour inputs (encodings, detached normal) carry no parameters: only the feature segment propagates
-            launch_rows_gemm(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), nullptr, 4, dB, kWidth, 0, -1, nullptr, ctx->cus, s);
+            launch_rows_gemm(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), nullptr, 4, dB, kWidth, 0, -1, nullptr, ctx->cus, s, mA);
         }
         float *t = dA; dA = dB; dB = t;
     }
@@ -536,7 +576,8 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     NarrowW heads{};
     heads.nc = 2; heads.wstride = 1; heads.kcount = kWidth;
     heads.w[0] = W[p.i_ddf]; heads.w[1] = W[p.i_aux];
-    launch_narrow_backward_act(GZH, kLdNarrow, p.R, heads, dA, 1, act, 4, ws + p.o_z[p.n_trunk - 1], dA, kWidth, s);
+    mA = am.take();
+    launch_narrow_backward_act(GZH, kLdNarrow, p.R, heads, dA, 1, act, 4, ws + p.o_z[p.n_trunk - 1], dA, kWidth, s, mA);
     {
         float *wh[2] = { gW[p.i_ddf], gW[p.i_aux] }, *bh[2] = { gB[p.i_ddf], gB[p.i_aux] };
         launch_narrow_dw(Hlast, kWidth, GZH, kLdNarrow, p.R, 2, wh, 1, bh, 4, kWidth, s);
@@ -545,18 +586,20 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     for (int l = p.n_trunk - 1; l >= 0; --l) {
         const bool wide = l > 0 && in_skips(f.d, l - 1);
         if (l == 0) {
-            launch_dw(sp, PEs, kLdPe, p.Cpe, dA, kWidth, p.R, gW[0], kWidth, 1, kWidth, gB[0], 4, ctx->cus, s);
+            launch_dw(sp, PEs, kLdPe, p.Cpe, dA, kWidth, p.R, gW[0], kWidth, 1, kWidth, gB[0], 4, ctx->cus, s, mA, am.dw_tmp);
             break;
         }
         if (wide) {
-            launch_dw(sp, PEs, kLdPe, p.Cpe, dA, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s);
-            launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l] + (size_t)p.Cpe * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s);
+            launch_dw(sp, PEs, kLdPe, p.Cpe, dA, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s, mA, am.dw_tmp);
+            launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l] + (size_t)p.Cpe * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s, mA, am.dw_tmp);
         } else {
-            launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s);
+            launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s, mA, am.dw_tmp);
         }
         launch_pack(sp, W[l], 1, kWidth, 0, wide ? p.Cpe : 0, kWidth, kWidth, kWidth, wp, s);
-        launch_rows_gemm_actback(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 4, act, ws + p.o_z[l - 1], dB, kWidth, ctx->cus, s);
+        float *mB = am.take();
+        launch_rows_gemm_actback(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 4, act, ws + p.o_z[l - 1], dB, kWidth, ctx->cus, s, mA, mB);
         float *t = dA; dA = dB; dB = t;
+        mA = mB;
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -44,15 +44,20 @@ inline int gemm_ksteps(int K, int split) { return split ? (K + 15) / 16 : (K + 7
 
 // Y[R,256] (+)= X[R, 0:kload) x Wpacked (+ bias); kload = loaded width (multiple of 4, <= ldx, zero beyond the logical K);
 // act_kind >= 0 with H != NULL additionally writes H = a(Y) on (value, Jacobian) row groups
+// amax_in / amax_out / amax_g (device scalars or NULL): range scaling of gradient operands under the split-fp16 policy -- a kernel that
+// writes a gradient matrix leaves max |dZ| in amax_out, a split-operand GEMM that consumes it scales by the matching power of two
+// (train_kernels.hip operand_scale); ignored by the fp32 MFMA kernels
 void launch_rows_gemm(int split, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias, int bias_period,
-                      float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s);
+                      float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s, const float *amax_in = nullptr);
 // dW[k * sk + n * sn] += sum_r X[r, k] G[r, n], k < K <= 256, n < nvalid <= 256; db[n] += sum over rows r % bias_period == 0 of G[r, n]
 // dZ[R,256] = activation backward (pre-activations Zprev, row period, kind) of X[R, 0:kload) x Wpacked: the input-gradient GEMM of
 // a layer fused with the backward of the previous layer's activation
 void launch_rows_gemm_actback(int split, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, int period, int act_kind,
-                              const float *Zprev, float *dZ, int ldy, int cus, hipStream_t s);
+                              const float *Zprev, float *dZ, int ldy, int cus, hipStream_t s, const float *amax_in = nullptr,
+                              float *amax_out = nullptr);
 void launch_dw(int split, const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
-               int bias_period, int cus, hipStream_t s);
+               int bias_period, int cus, hipStream_t s, const float *amax_g = nullptr, float *scaled_tmp = nullptr);
+// scaled_tmp: [256, 256] floats of scratch, required with amax_g (the scaled product is formed there, then added to dW unscaled)
 // heads (1..4 output columns, input width 256): column c of the weight gradient is w[c][k * wstride], b[c] its bias gradient
 void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t R, int nc, float *const *w, int wstride, float *const *b,
                       int bias_period, int kcount, hipStream_t s);
@@ -76,7 +81,7 @@ void launch_narrow_backward(const float *G, int ldg, int64_t R, const NarrowW &w
 
 // dZ = activation backward (Zprev) of ((accumulate ? dH : 0) + sum_c G[., c] w_c); dH and dZ may alias
 void launch_narrow_backward_act(const float *G, int ldg, int64_t R, const NarrowW &w, const float *dH, int accumulate, int act_kind, int period,
-                                const float *Zprev, float *dZ, int ld, hipStream_t s);
+                                const float *Zprev, float *dZ, int ld, hipStream_t s, float *amax_out = nullptr);
 // NeuS heads (train_kernels.hip "NeuS"): per-point pieces between the sdf trunk and the colour trunk
 constexpr int kActTanhExp = 2;                 // = NEDDF_ACT_TANHEXP (include/neddf_hip.h; checked in train_capi.hip)
 struct NeusPointArgs {
@@ -97,6 +102,7 @@ struct NeusPointArgs {
     const float *DG; int lddg;            // [N, lddg] (cols 0..2): gradient of the normal from the colour trunk
     float *dZ;                            // [4N, 256]
     float *g_variance;                    // accumulated
+    float *amax_out;                      // max |dZ| (range scaling of split-fp16 operands) or NULL
 };
 void launch_neus_head_forward(const NeusPointArgs &a, hipStream_t s);
 void launch_neus_color_forward(const NeusPointArgs &a, hipStream_t s);

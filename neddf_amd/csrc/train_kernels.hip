@@ -69,6 +69,31 @@ __device__ __forceinline__ void act_backward_group(int kind, int period, const f
 }
 
 // ----------------------------------------------------------------------------
+// Operand range of the split-fp16 policy in the backward pass.  Two fp16 terms resolve 2^-24 absolutely, and gradient matrices
+// of a mean-over-rays loss sit at 1e-5 .. 1e-8: unscaled, a product with max |dZ| = 1e-5 is already 2e-3 off (1e-6: 1.5e-2).
+// Every kernel that writes a gradient matrix therefore also leaves max |dZ| in a device scalar (one atomic per wave), and every
+// split-operand GEMM that consumes the matrix multiplies it by the power of two that brings that maximum to [2^13, 2^14) while
+// staging it, and the accumulators by the inverse on the way out -- both exact.  (The fp32 MFMA path needs none of this.)
+__device__ __forceinline__ float operand_scale(const float *amax)
+{
+    if (!amax) return 1.0f;
+    const int e = (int)((__builtin_bit_cast(unsigned int, *amax) >> 23) & 0xffu);       // biased exponent of the maximum
+    if (e == 0 || e == 255) return 1.0f;            // zero / denormal / non-finite: leave the operand alone
+    int shift = 13 + 127 - e;
+    shift = shift > 100 ? 100 : (shift < -100 ? -100 : shift);
+    return __builtin_bit_cast(float, (unsigned int)(127 + shift) << 23);
+}
+__device__ __forceinline__ float pow2_inverse(float p) { return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned int, p)); }
+__device__ __forceinline__ void publish_amax(float *amax_out, float lmax)       // all lanes of the wave call this
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off, 64));
+    // Non-negative floats order like ints.  Hundreds of thousands of waves share the scalar: look first (a stale, smaller value
+    // only costs an unnecessary atomic) so that all but the first few skip the same-address atomic, which serialises in L2.
+    if ((threadIdx.x & 63) == 0 && lmax > *(volatile const float *)amax_out) atomicMax((int *)amax_out, __builtin_bit_cast(int, lmax));
+}
+
+// ----------------------------------------------------------------------------
 // Y[R, 256] (+)= X[R, 0:kload) x Wpacked (+ bias on rows r % bias_period == 0), optionally followed by the activation on
 // (value, Jacobian) row groups: H = a(Y) (LinearGradFunction.forward + the activation's forward in one pass).
 // 64-row tiles, two workgroups per CU (one's loads / stores overlap the other's MFMAs).  The next tile's rows are
@@ -82,10 +107,14 @@ __device__ __forceinline__ void act_backward_group(int kind, int period, const f
 template <int MODE, class Ops>
 __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps,
                                                                 const float *bias, int bias_period, float *Y, int ldy, int accumulate,
-                                                                int act_kind, float *H)
+                                                                int act_kind, float *H, const float *amax_in, float *amax_out)
 {
     typedef typename Ops::act_t act_t;
     constexpr int MT = 2, NT = 2, ROWS = MT * 32, NPF = ROWS * (kWidth / 4) / kThreads, LD = Ops::kLd;
+    constexpr bool SCALED = Ops::kPlanes == 2;       // split-fp16 operands: X is range-scaled (see operand_scale)
+    const float xs = SCALED ? operand_scale(amax_in) : 1.0f;
+    const float unscale = SCALED ? pow2_inverse(xs) * (1.0f / Ops::kWScale) : 1.0f / Ops::kWScale;
+    float lmax = 0.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *act = smem;                       // result tile (fp32)
     act_t *opd = (act_t *)smem;              // operand tile (policy layout)
@@ -118,7 +147,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, 
             int idx = tid + i * kThreads;
             if (idx < total) {
                 int r = idx / c4n, c = idx - r * c4n;
-                Ops::put4(opd + r * LD + 4 * c, pf[i]);
+                Ops::put4(opd + r * LD + 4 * c, SCALED ? pf[i] * xs : pf[i]);
             }
         }
         for (int i = tid; i < ROWS * (kpack - kload); i += kThreads) {      // packed width beyond the loaded width
@@ -140,7 +169,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, 
             for (int t = 0; t < NT; ++t) {
                 float *o = act + (mt * 32 + 4 * h) * kActLd + (wave * NT + t) * 32 + j;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) o[(8 * (q >> 2) + (q & 3)) * kActLd] = acc[mt][t][q] * (1.0f / Ops::kWScale);
+                for (int q = 0; q < 16; ++q) o[(8 * (q >> 2) + (q & 3)) * kActLd] = acc[mt][t][q] * unscale;
             }
         __syncthreads();
         // items: (4-row group, 4 columns); rows of a group are consecutive rows of the tile
@@ -160,7 +189,11 @@ __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, 
                 act_backward_group(act_kind, bias_period, zp, z);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (row + r < R) *(f32x4v *)(Y + (row + r) * ldy + 4 * c4) = z[r];
+                    if (row + r < R) {
+                        *(f32x4v *)(Y + (row + r) * ldy + 4 * c4) = z[r];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) lmax = fmaxf(lmax, fabsf(z[r][u]));
+                    }
                 continue;
             }
 #pragma unroll
@@ -196,11 +229,13 @@ __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, 
             }
         }
     }
+    if (MODE == 2 && amax_out) publish_amax(amax_out, lmax);
 }
 
 template <class Ops>
 static void launch_rows_gemm_ops(int mode, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias,
-                                 int period, float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s)
+                                 int period, float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s,
+                                 const float *amax_in, float *amax_out)
 {
     constexpr size_t kOpd = (size_t)64 * Ops::kLd * sizeof(typename Ops::act_t), kRes = (size_t)64 * kActLd * sizeof(float);
     constexpr size_t lds = kOpd > kRes ? kOpd : kRes;
@@ -211,33 +246,34 @@ static void launch_rows_gemm_ops(int mode, const float *X, int64_t R, int ldx, i
     int64_t tiles = (R + 63) / 64;
     int grid = (int)(tiles < 2 * cus ? tiles : 2 * cus);
     if (mode == 1)
-        hipLaunchKernelGGL((rows_gemm_kernel<1, Ops>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, act_kind, H);
+        hipLaunchKernelGGL((rows_gemm_kernel<1, Ops>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, act_kind, H, amax_in, amax_out);
     else if (mode == 2)
-        hipLaunchKernelGGL((rows_gemm_kernel<2, Ops>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, 0, act_kind, H);
+        hipLaunchKernelGGL((rows_gemm_kernel<2, Ops>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, 0, act_kind, H, amax_in, amax_out);
     else
-        hipLaunchKernelGGL((rows_gemm_kernel<0, Ops>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, -1, nullptr);
+        hipLaunchKernelGGL((rows_gemm_kernel<0, Ops>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, -1, nullptr, amax_in, amax_out);
 }
 
 static void launch_rows_gemm_mode(int mode, int split, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps,
                                   const float *bias, int period, float *Y, int ldy, int accumulate, int act_kind, float *H, int cus,
-                                  hipStream_t s)
+                                  hipStream_t s, const float *amax_in, float *amax_out)
 {
     if (R <= 0) return;
-    if (split) launch_rows_gemm_ops<OpsF16Split>(mode, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, act_kind, H, cus, s);
-    else launch_rows_gemm_ops<OpsF32>(mode, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, act_kind, H, cus, s);
+    if (split) launch_rows_gemm_ops<OpsF16Split>(mode, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, act_kind, H, cus, s, amax_in, amax_out);
+    else launch_rows_gemm_ops<OpsF32>(mode, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, act_kind, H, cus, s, nullptr, amax_out);
 }
 
 void launch_rows_gemm(int split, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias, int bias_period,
-                      float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s)
+                      float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s, const float *amax_in)
 {
     launch_rows_gemm_mode((act_kind >= 0 && H) ? 1 : 0, split, X, R, ldx, kload, wp, ksteps, bias, bias_period, Y, ldy, accumulate, act_kind, H,
-                          cus, s);
+                          cus, s, amax_in, nullptr);
 }
 
 void launch_rows_gemm_actback(int split, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, int period, int act_kind,
-                              const float *Zprev, float *dZ, int ldy, int cus, hipStream_t s)
+                              const float *Zprev, float *dZ, int ldy, int cus, hipStream_t s, const float *amax_in, float *amax_out)
 {
-    launch_rows_gemm_mode(2, split, X, R, ldx, kload, wp, ksteps, nullptr, period, dZ, ldy, 0, act_kind, const_cast<float *>(Zprev), cus, s);
+    launch_rows_gemm_mode(2, split, X, R, ldx, kload, wp, ksteps, nullptr, period, dZ, ldy, 0, act_kind, const_cast<float *>(Zprev), cus, s,
+                          amax_in, amax_out);
 }
 
 // ----------------------------------------------------------------------------
@@ -410,9 +446,10 @@ void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t 
 template <int KT>
 __global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, int ldx, int K, const float *G, int ldg, int64_t R,
                                                                int64_t rows_per_wg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
-                                                               int bias_period)
+                                                               int bias_period, const float *amax_g)
 {
     constexpr int RC = 32, LDT = RC + 8;            // halves per transposed column: 80 B, 16-byte aligned row octets
+    const float gs = operand_scale(amax_g);      // G is a gradient matrix: range-scaled while staged; the launcher undoes it
     constexpr int KP = 32 * KT;
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     typedef __fp16 h2 __attribute__((ext_vector_type(2)));
@@ -441,13 +478,13 @@ __global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, i
             gr[r] = in ? G[(c0 + r) * ldg + tid] : 0.f;
         }
     };
-    auto stage = [&](const float (&v)[RC], _Float16 *ph, _Float16 *pm) {        // column tid: 32 rows -> 4 + 4 LDS writes of 8 halves
+    auto stage = [&](const float (&v)[RC], _Float16 *ph, _Float16 *pm, float scale) {        // column tid: 32 rows -> 4 + 4 LDS writes of 8 halves
 #pragma unroll
         for (int o = 0; o < RC / 8; ++o) {
             h8 vh, vm;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float x = v[8 * o + i];
+                const float x = v[8 * o + i] * scale;
                 h2 t = __builtin_amdgcn_cvt_pkrtz(x, x);
                 vh[i] = (_Float16)t[0];
                 vm[i] = (_Float16)__builtin_amdgcn_fmed3f(x - (float)vh[i], -65504.0f, 65504.0f);
@@ -459,8 +496,8 @@ __global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, i
     fetch(rb);
     for (int64_t c0 = rb; c0 < re; c0 += RC) {
         __syncthreads();
-        if (tid < KP) stage(xr, Xh, Xm);
-        stage(gr, Gh, Gm);
+        if (tid < KP) stage(xr, Xh, Xm, 1.0f);
+        stage(gr, Gh, Gm, gs);
         if (db) {
 #pragma unroll
             for (int r = 0; r < RC; ++r)
@@ -502,9 +539,19 @@ __global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, i
     if (db && tid < nvalid) atomicAdd(&db[tid], bsum);
 }
 
+// dW[k * sk + n * sn] += T[k, n] / scale(amax): the accumulators of dw_split_kernel stay in the accumulation registers this way
+// (scaling them in the kernel moved all 256 of them into VGPRs and spilled)
+__global__ void dw_unscale_add_kernel(const float *T, int K, int nvalid, float *dW, int64_t sk, int64_t sn, const float *amax_g)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * kWidth) return;
+    const int k = i >> 8, n = i & 255;
+    if (n < nvalid) dW[k * sk + n * sn] += T[i] * pow2_inverse(operand_scale(amax_g));
+}
+
 template <int KT>
 static void launch_dw_split(const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid,
-                            float *db, int bias_period, int cus, hipStream_t s)
+                            float *db, int bias_period, int cus, hipStream_t s, const float *amax_g)
 {
     const size_t lds = (size_t)2 * (32 * KT + kWidth) * 40 * sizeof(_Float16);
     static bool once = ((void)hipFuncSetAttribute((const void *)dw_split_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -514,19 +561,25 @@ static void launch_dw_split(const float *X, int ldx, int K, const float *G, int 
     int grid = (int)(chunks < cus ? chunks : cus);
     int64_t rows_per_wg = ((chunks + grid - 1) / grid) * 32;
     hipLaunchKernelGGL((dw_split_kernel<KT>), dim3(grid), dim3(kThreads), lds, s, X, ldx, K, G, ldg, R, rows_per_wg, dW, sk, sn, nvalid, db,
-                       bias_period);
+                       bias_period, amax_g);
 }
 
 // dW[k * sk + n * sn] += sum_r X[r, k] G[r, n] for k < K <= 256, n < nvalid <= 256 (G has 256 columns, the rest zero);
 // (sk, sn) = (256, 1) for LinearGradLayer weights [in, out], (1, in_total) for nn.Linear weights [out, in]
 void launch_dw(int split, const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid,
-               float *db, int bias_period, int cus, hipStream_t s)
+               float *db, int bias_period, int cus, hipStream_t s, const float *amax_g, float *scaled_tmp)
 {
     if (R <= 0 || K <= 0) return;
     if (split) {
-        if (K <= 64) launch_dw_split<2>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
-        else if (K <= 96) launch_dw_split<3>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
-        else launch_dw_split<8>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
+        // with a range-scaled G the product lands in a dense [K, 256] scratch first and is added to dW divided by the scale
+        const bool scaled = amax_g && scaled_tmp;
+        float *out = scaled ? scaled_tmp : dW;
+        const int64_t osk = scaled ? kWidth : sk, osn = scaled ? 1 : sn;
+        if (scaled) (void)hipMemsetAsync(scaled_tmp, 0, (size_t)K * kWidth * sizeof(float), s);
+        if (K <= 64) launch_dw_split<2>(X, ldx, K, G, ldg, R, out, osk, osn, nvalid, db, bias_period, cus, s, scaled ? amax_g : nullptr);
+        else if (K <= 96) launch_dw_split<3>(X, ldx, K, G, ldg, R, out, osk, osn, nvalid, db, bias_period, cus, s, scaled ? amax_g : nullptr);
+        else launch_dw_split<8>(X, ldx, K, G, ldg, R, out, osk, osn, nvalid, db, bias_period, cus, s, scaled ? amax_g : nullptr);
+        if (scaled) hipLaunchKernelGGL(dw_unscale_add_kernel, dim3((K * kWidth + 255) / 256), dim3(256), 0, s, scaled_tmp, K, nvalid, dW, sk, sn, amax_g);
         return;
     }
     if (K <= 64) launch_dw_tile<2>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
@@ -946,8 +999,14 @@ __global__ void neus_head_backward_kernel(NeusPointArgs a, int act_kind)
         for (int k = 0; k < 3; ++k) g[1 + k][0] = a.DG[n * a.lddg + k];
     }
     act_backward_group(act_kind, 4, z, g);
+    float lmax = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) *(f32x4v *)(a.dZ + (n * 4 + r) * kWidth + 4 * c4) = g[r];
+    for (int r = 0; r < 4; ++r) {
+        *(f32x4v *)(a.dZ + (n * 4 + r) * kWidth + 4 * c4) = g[r];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lmax = fmaxf(lmax, fabsf(g[r][u]));
+    }
+    if (a.amax_out) publish_amax(a.amax_out, lmax);     // 64 threads per point: whole waves
 }
 int neus_backward_act_kind(int act) { return act == kActTanhExp ? kActTanhExpPlain2 : act; }
 void launch_neus_head_backward(const NeusPointArgs &a, hipStream_t s)
@@ -1065,11 +1124,13 @@ void launch_narrow_backward(const float *G, int ldg, int64_t R, const NarrowW &w
 // The same followed by the backward of the activation that produced the head's input: one thread per (4-row group, 4 columns);
 // dZ = act_backward(Zprev, (accumulate ? dH : 0) + sum_c G[., c] w_c).  dH and dZ may alias.
 __global__ void narrow_backward_act_kernel(const float *G, int ldg, int64_t R, NarrowW w, const float *dH, int accumulate, int act_kind,
-                                           int period, const float *Zprev, float *dZ, int ld)
+                                           int period, const float *Zprev, float *dZ, int ld, float *amax_out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t groups = (R + 3) >> 2;
-    if (i >= groups * (kWidth / 4)) return;
+    if (i >= groups * (kWidth / 4)) {       // the grid is a whole number of waves of 64-thread row groups: the wave exits as one
+        return;
+    }
     const int64_t row = (i >> 6) * 4;
     const int c4 = (int)(i & 63);
     f32x4v g[4], z[4];
@@ -1088,16 +1149,22 @@ __global__ void narrow_backward_act_kernel(const float *G, int ldg, int64_t R, N
             }
     }
     act_backward_group(act_kind, period, z, g);
+    float lmax = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (row + r < R) *(f32x4v *)(dZ + (row + r) * ld + 4 * c4) = g[r];
+        if (row + r < R) {
+            *(f32x4v *)(dZ + (row + r) * ld + 4 * c4) = g[r];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lmax = fmaxf(lmax, fabsf(g[r][u]));
+        }
+    if (amax_out) publish_amax(amax_out, lmax);     // 64 threads per row group: whole waves reach this point together
 }
 void launch_narrow_backward_act(const float *G, int ldg, int64_t R, const NarrowW &w, const float *dH, int accumulate, int act_kind, int period,
-                                const float *Zprev, float *dZ, int ld, hipStream_t s)
+                                const float *Zprev, float *dZ, int ld, hipStream_t s, float *amax_out)
 {
     int64_t t = ((R + 3) >> 2) * (kWidth / 4);
     if (t > 0) hipLaunchKernelGGL(narrow_backward_act_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, G, ldg, R, w, dH, accumulate,
-                                  act_kind, period, Zprev, dZ, ld);
+                                  act_kind, period, Zprev, dZ, ld, amax_out);
 }
 
 // ----------------------------------------------------------------------------
