@@ -1128,9 +1128,7 @@ __global__ void narrow_backward_act_kernel(const float *G, int ldg, int64_t R, N
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t groups = (R + 3) >> 2;
-    if (i >= groups * (kWidth / 4)) {       // the grid is a whole number of waves of 64-thread row groups: the wave exits as one
-        return;
-    }
+    if (i >= groups * (kWidth / 4)) return;     // 64 threads per row group: a wave leaves as one (publish_amax below needs whole waves)
     const int64_t row = (i >> 6) * 4;
     const int c4 = (int)(i & 63);
     f32x4v g[4], z[4];
