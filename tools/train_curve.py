@@ -3,7 +3,7 @@
 1024-ray steps with the reference's loss set, under the fp32 and the split-fp16 operand policies (same seeds).
 Prints the mean loss per block of steps and the PSNR of a held-out view.
 
-    python tools/train_curve.py [steps] [size]
+    python tools/train_curve.py [steps] [size] [neddf|nerf|neus]
 """
 import json
 import os
@@ -61,7 +61,7 @@ def make_dataset(root, size, n=8):
         json.dump({"camera_angle_x": ANGLE_X, "frames": frames}, open(os.path.join(root, "transforms_%s.json" % split), "w"))
 
 
-def run(dtype, root, steps, size):
+def run(dtype, root, steps, size, network="neddf"):
     from neddf_amd.config import instantiate
     cfg = {"dataset": {"_target_": "neddf.dataset.NeRFSyntheticDataset", "dataset_dir": root, "data_split": "train", "use_depth": False,
                        "use_mask": True},
@@ -73,9 +73,15 @@ def run(dtype, root, steps, size):
            "loss": {"functions": [{"_target_": "neddf.loss.ColorLoss", "weight": 1.0, "weight_coarse": 0.1},
                                   {"_target_": "neddf.loss.MaskBCELoss", "weight": 0.05, "weight_coarse": 0.005},
                                   {"_target_": "neddf.loss.FieldsConstraintLoss", "weight": 0.01, "weight_coarse": 0.01}]}}
+    if network != "neddf":          # the reference's NeRF / NeuS set-up: point samples, colour + mask loss (config/render/nerf_render.yaml)
+        import yaml
+        cfg["network"] = yaml.safe_load(open(os.path.join(ROOT, "config", "network", network + ".yaml")))
+        cfg["render"].update(sampling_type="point", use_coarse_network=network == "nerf")
+        cfg["loss"]["functions"] = cfg["loss"]["functions"][:2]
     torch.manual_seed(3)
     np.random.seed(3)
     tr = instantiate(cfg["trainer"], global_config=cfg, _recursive_=False)
+    tr.neural_render.network_coarse.weight_dtype = dtype
     tr.neural_render.network_fine.weight_dtype = dtype
     tr.neural_render.set_iter(0)
     block, curve, acc = max(steps // 8, 1), [], []
@@ -101,11 +107,12 @@ def run(dtype, root, steps, size):
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 240
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 96
+    network = sys.argv[3] if len(sys.argv) > 3 else "neddf"        # neddf | nerf | neus
     with tempfile.TemporaryDirectory() as root:
         make_dataset(root, size)
         for dtype in ("fp32", "f16_split"):
-            curve, psnr = run(dtype, root, steps, size)
-            print("%-9s loss per block of %d steps: %s   held-out view PSNR %.2f dB" % (dtype, max(steps // 8, 1), " ".join("%.4f" % c for c in curve), psnr))
+            curve, psnr = run(dtype, root, steps, size, network)
+            print("%-5s %-9s loss per block of %d steps: %s   held-out view PSNR %.2f dB" % (network, dtype, max(steps // 8, 1), " ".join("%.4f" % c for c in curve), psnr))
 
 
 if __name__ == "__main__":
