@@ -74,6 +74,86 @@ __global__ __launch_bounds__(256, WPS) void k(const void *w, float *out, int ite
     out[blockIdx.x * 256 + tid] = s;
 }
 
+// Shared weight fragments: ONE workgroup of 8 waves per CU, two row groups of 64 rows (waves 0-3 / 4-7); wave (g, q) owns output
+// columns [64q, 64q+64) of its group's rows, so waves q and q+4 need the same B fragments.  They are fetched from global once per
+// CU in chunks of CH k-steps (all 512 threads, 16 B each per k-step), parked in a two-deep LDS ring in fragment order and read by
+// both row groups with ds_read_b128; one barrier per chunk.  bf16 policy.
+template <int CH>
+__global__ __launch_bounds__(512, 1) void kshared(const void *w, float *out, int iters, int ksteps)
+{
+    constexpr int MT = 2, NT = 2, LD = 264;
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16 *act = smem;                                  // [128][LD]
+    bf16x8 *ring = (bf16x8 *)(smem + 128 * LD);       // [2][8 pairs][CH][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = wave >> 2, q = wave & 3;
+    for (int i = tid; i < 128 * LD; i += 512) act[i] = (u16)(0x3c00 + (i % 7));
+    const u16 *act_lane = act + (g * 64 + (lane & 31)) * LD + 8 * (lane >> 5);
+    const bf16x8 *wg = (const bf16x8 *)w;             // global fragments [(pair * ksteps + S) * 64 + lane]
+    const int pair_ld = wave;                         // this wave stages pair `wave` (8 waves <-> 8 (q, t) pairs)
+    f32x16 acc[MT][NT];
+    for (int mt = 0; mt < MT; ++mt) for (int t = 0; t < NT; ++t) for (int k = 0; k < 16; ++k) acc[mt][t][k] = 0.f;
+    bf16x8 st[CH];
+    auto fetch = [&](int S0) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s) st[s] = wg[((size_t)pair_ld * ksteps + S0 + s) * 64 + lane];
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s) ring[((buf * 8 + pair_ld) * CH + s) * 64 + lane] = st[s];
+    };
+    fetch(0);
+    park(0);
+    __syncthreads();
+    const int chunks = ksteps / CH;
+    for (int it = 0; it < iters; ++it) {
+        for (int c = 0; c < chunks; ++c) {
+            const int buf = c & 1;
+            fetch(((c + 1) % chunks) * CH);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                bf16x8 a[MT], b[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = *(const bf16x8 *)(act_lane + mt * 32 * LD + 16 * ((c * CH + s) % 16));
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[t] = ring[((buf * 8 + q * NT + t) * CH + s) * 64 + lane];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[t], acc[mt][t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            park(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float sum = 0.f;
+    for (int mt = 0; mt < MT; ++mt) for (int t = 0; t < NT; ++t) for (int k = 0; k < 16; ++k) sum += acc[mt][t][k];
+    out[blockIdx.x * 512 + tid] = sum;
+}
+
+template <int CH>
+void run_shared(const char *name, const void *w, float *out)
+{
+    const int ksteps = 48, iters = 300, grid = 256;
+    size_t lds = (size_t)128 * 264 * sizeof(u16) + (size_t)2 * 8 * CH * 64 * 16;
+    (void)hipFuncSetAttribute((const void *)kshared<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((kshared<CH>), dim3(grid), dim3(512), lds, 0, w, out, 10, ksteps);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kshared<CH>), dim3(grid), dim3(512), lds, 0, w, out, iters, ksteps);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    double mfmas = (double)grid * 8 * iters * ksteps * 4.0;
+    double tf = mfmas * (2.0 * 32 * 32 * 16) / ms / 1e9;
+    printf("%-58s %8.2f ms  %7.1f TF of MFMA work = %4.1f %% of 2500\n", name, ms, tf, tf / 25.0);
+    fflush(stdout);
+}
+
 template <class P, int MT, int NT, int MODE, int WPS, int D>
 void run(const char *name, const void *w, float *out)
 {
@@ -119,6 +199,8 @@ int main()
     run<PB, 4, 2, 3, 2, 2>("bf16 MT4 2wg/CU +A+B        distance 2", w, out);
     run<PB, 4, 2, 7, 2, 1>("bf16 MT4 2wg/CU +A+B+barrier distance 1", w, out);
     run<PB, 3, 2, 3, 2, 1>("bf16 MT3 2wg/CU +A+B        distance 1", w, out);
+    run_shared<2>("bf16 8 waves/CU, B shared through LDS, chunks of 2 k-steps", w, out);
+    run_shared<4>("bf16 8 waves/CU, B shared through LDS, chunks of 4 k-steps", w, out);
     printf("split-fp16 policy (12 MFMAs per k-step and wave at MT2 NT2)\n");
     run<PS, 2, 2, 0, 2, 1>("split MT2 2wg/CU mfma only", w, out);
     run<PS, 2, 2, 1, 2, 1>("split MT2 2wg/CU +A          distance 1", w, out);
