@@ -150,9 +150,13 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
         // config) and the 64-row tile the partial stays in registers until its layer; otherwise it is
         // parked in the per-workgroup global scratch.
         constexpr bool REG_STASH = (MT == 2) && (WPS <= 2) && !Ops::kLean;     // denser packings of a CU have no registers to spare
+        // 128-row tiles at two workgroups per CU (16-bit operands: each fetched weight fragment feeds four M-tiles) have neither
+        // the registers for a held partial nor the HBM bandwidth for a parked one: the skip layer re-encodes the positions into
+        // the tile's first columns after its 256-wide product and multiplies them then (three more barriers per tile).
+        constexpr bool REENCODE = (MT == 4) && (WPS == 2);
         const bool in_regs = REG_STASH && a.n_stash == 1;
         f32x16 held[REG_STASH ? MT : 1][REG_STASH ? NT : 1];
-        for (int s = 0; s < a.n_stash; ++s) {
+        for (int s = 0; s < (REENCODE ? 0 : a.n_stash); ++s) {
             const frag *wl = (const frag *)a.stash[s].wp + (size_t)wave * NT * a.stash[s].ksteps * 64 + lane;
             if constexpr (REG_STASH) {
                 if (in_regs) {
@@ -179,10 +183,23 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
                         done = true;
                     }
                 }
-                if (!done) stash_add<MT, NT>(acc, scratch + (size_t)L.stash * kStashFloatsPerWg, wave, lane);
+                if (!done && !REENCODE) stash_add<MT, NT>(acc, scratch + (size_t)L.stash * kStashFloatsPerWg, wave, lane);
             }
             const frag *wl = (const frag *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane;
             if (!(NEDDF_ABL(a.sched_flags, 8))) dense_pre<MT, NT, Ops>(acc, act_lane, wl, L.ksteps, pre);
+            if constexpr (REENCODE) {
+                if (L.stash >= 0) {
+                    const StashW &sw = a.stash[L.stash];
+                    __syncthreads();                        // every wave finished reading the hidden state
+                    zero_cols<Ops>(act, ROWS, kin, tid);
+                    __syncthreads();
+                    if (a.neus) encode_pos<true, false, Ops>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid, false);
+                    else encode_pos<true, true, Ops>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
+                    __syncthreads();
+                    const frag *ws_ = (const frag *)sw.wp + (size_t)wave * NT * sw.ksteps * 64 + lane;
+                    dense<MT, NT, Ops>(acc, act_lane + sw.col0, ws_, sw.ksteps);
+                }
+            }
             if (l + 1 < a.n_layers)                 // next layer's first fragments fly during the epilogue
                 layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
             if (!(NEDDF_ABL(a.sched_flags, 64))) __syncthreads();   // every wave finished reading the previous activations
@@ -638,8 +655,18 @@ static int bf16_wps()
     }
     return v;
 }
+// The bf16 distance trunk runs 128-row tiles at two workgroups per CU (a bf16 tile is half the LDS bytes): every fetched weight
+// fragment then feeds four M-tiles, and the weight stream from L2 is what bounds the 16-bit dense phase (profiles/
+// r01_f16_split_bottleneck.md).  Measured 8.09 ms per 2^21-point launch against 8.81 ms for 64-row tiles; NEDDF_BF16_MT4X2=0
+// selects the latter.
+static bool bf16_mt4x2()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("NEDDF_BF16_MT4X2"); v = ((!e || atoi(e) != 0) && tile_mt() == 2 && bf16_wps() == 2) ? 1 : 0; }
+    return v == 1;
+}
 int field_wgs_per_cu(int bf16) { return tile_mt() == 2 ? (bf16 == 1 ? bf16_wps() : 2) : 1; }
-int ddf_points_per_tile(int) { return tile_mt() * 8; }
+int ddf_points_per_tile(int bf16) { return (bf16 == 1 && bf16_mt4x2()) ? 32 : tile_mt() * 8; }
 int col_points_per_tile(bool rows4, int) { return rows4 ? tile_mt() * 8 : tile_mt() * 32; }
 int nerf_points_per_tile() { return tile_mt() * 32; }
 
@@ -659,6 +686,12 @@ static void launch_ddf_t(const DdfArgs &a, int grid, hipStream_t s)
             static bool once2 = (set_lds((const void *)ddf_trunk_kernel<2, 3, Ops>, lds_bytes<Ops>(2)),
                                  set_lds((const void *)ddf_trunk_kernel<2, 4, Ops>, lds_bytes<Ops>(2)), true);
             (void)once2;
+            if (bf16_mt4x2()) {
+                static bool once3 = (set_lds((const void *)ddf_trunk_kernel<4, 2, Ops>, lds_bytes<Ops>(4)), true);
+                (void)once3;
+                hipLaunchKernelGGL((ddf_trunk_kernel<4, 2, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(4), s, a);
+                return;
+            }
             if (bf16_wps() == 3) { hipLaunchKernelGGL((ddf_trunk_kernel<2, 3, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a); return; }
             if (bf16_wps() == 4) { hipLaunchKernelGGL((ddf_trunk_kernel<2, 4, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a); return; }
         }
