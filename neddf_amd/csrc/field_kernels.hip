@@ -500,15 +500,35 @@ __global__ __launch_bounds__(kThreads, WPS) void nerf_kernel(const NerfArgs a)
         encode_dir<false, Ops>(act, c_dir, a.enc, a.dir, p0, a.n_points, P, tid);
         __syncthreads();
         f32x16 acc[MT][NT];
+        // Early partials (products with the encodings, which only exist in LDS at tile start).  With the 64-row tile and the usual
+        // one skip connection + the colour head's direction segment both stay in registers (64 + 32 per lane) until their layers;
+        // otherwise they are parked in the per-workgroup global scratch (3 KB of HBM traffic per point).
+        constexpr bool REG_STASH = (MT == 2) && (WPS <= 2);
+        const bool in_regs = REG_STASH && a.n_stash == 2;
+        f32x16 held[REG_STASH ? MT : 1][REG_STASH ? NT : 1], held1[REG_STASH ? MT : 1][1];
         for (int s = 0; s < a.n_stash; ++s) {
             const frag *wl = (const frag *)a.stash[s].wp;
             float *slot = scratch + (size_t)s * kStashFloatsPerWg;
             if (s == a.col_stash) {         // colour head's view-direction segment: 128 outputs, NT = 1
+                if constexpr (REG_STASH) {
+                    if (in_regs) {
+                        acc_init<MT, 1, false>(held1, nullptr, wave, lane);
+                        dense<MT, 1, Ops>(held1, act_lane + a.stash[s].col0, wl + (size_t)wave * a.stash[s].ksteps * 64 + lane, a.stash[s].ksteps);
+                        continue;
+                    }
+                }
                 f32x16 acc1[MT][1];
                 acc_init<MT, 1, false>(acc1, nullptr, wave, lane);
                 dense<MT, 1, Ops>(acc1, act_lane + a.stash[s].col0, wl + (size_t)wave * a.stash[s].ksteps * 64 + lane, a.stash[s].ksteps);
                 stash_store<MT, 1>(acc1, slot, wave, lane);
             } else {                        // skip layers: cat([hx, embed_pos]) (nerf.py:154-155)
+                if constexpr (REG_STASH) {
+                    if (in_regs) {
+                        acc_init<MT, NT, false>(held, nullptr, wave, lane);
+                        dense<MT, NT, Ops>(held, act_lane + a.stash[s].col0, wl + (size_t)wave * NT * a.stash[s].ksteps * 64 + lane, a.stash[s].ksteps);
+                        continue;
+                    }
+                }
                 acc_init<MT, NT, false>(acc, nullptr, wave, lane);
                 dense<MT, NT, Ops>(acc, act_lane + a.stash[s].col0, wl + (size_t)wave * NT * a.stash[s].ksteps * 64 + lane, a.stash[s].ksteps);
                 stash_store<MT, NT>(acc, slot, wave, lane);
@@ -517,7 +537,19 @@ __global__ __launch_bounds__(kThreads, WPS) void nerf_kernel(const NerfArgs a)
         for (int l = 0; l < a.n_layers; ++l) {
             const LayerW &L = a.layer[l];
             acc_init<MT, NT, false>(acc, L.bias, wave, lane, Ops::kWScale);
-            if (L.stash >= 0) stash_add<MT, NT>(acc, scratch + (size_t)L.stash * kStashFloatsPerWg, wave, lane);
+            if (L.stash >= 0) {
+                bool done = false;
+                if constexpr (REG_STASH) {
+                    if (in_regs) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[mt][t] += held[mt][t];
+                        done = true;
+                    }
+                }
+                if (!done) stash_add<MT, NT>(acc, scratch + (size_t)L.stash * kStashFloatsPerWg, wave, lane);
+            }
             dense<MT, NT, Ops>(acc, act_lane, (const frag *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane, L.ksteps);
             __syncthreads();
             epilogue_rt<MT, NT, false, Ops>(acc, act, a.activation, wave, lane);
@@ -543,7 +575,15 @@ __global__ __launch_bounds__(kThreads, WPS) void nerf_kernel(const NerfArgs a)
         {
             f32x16 acc1[MT][1];
             acc_init<MT, 1, false>(acc1, a.col0.bias, wave, lane, Ops::kWScale);
-            stash_add<MT, 1>(acc1, scratch + (size_t)a.col_stash * kStashFloatsPerWg, wave, lane);
+            bool done = false;
+            if constexpr (REG_STASH) {
+                if (in_regs) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc1[mt][0] += held1[mt][0];
+                    done = true;
+                }
+            }
+            if (!done) stash_add<MT, 1>(acc1, scratch + (size_t)a.col_stash * kStashFloatsPerWg, wave, lane);
             dense<MT, 1, Ops>(acc1, act_lane, (const frag *)a.col0.wp + (size_t)wave * a.col0.ksteps * 64 + lane, a.col0.ksteps);
             __syncthreads();
             epilogue<MT, 1, false, 0, Ops>(acc1, act, wave, lane);
