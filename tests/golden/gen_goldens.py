@@ -392,6 +392,25 @@ def gen_neus():
             arrs["eval_" + k] = npy(v)
         save(name + ".npz", **arrs)
 
+    # NeRFRender over one NeuS network (point samples): the whole render_rays pipeline with the sdf-derived density
+    kw = cases["neus_relu"]
+    render = NeRFRender(network_config=dict(kw, _target_="neddf.network.NeuS"), sample_coarse=32, sample_fine=48, dist_near=2.0,
+                        dist_far=6.0, max_dist=6.0, use_coarse_network=False, sampling_type="point")
+    sd = synth.neus_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["sdf_layer_count"], kw["sdf_layer_width"],
+                          kw["col_layer_count"], kw["col_layer_width"], tuple(kw["skips"]), kw["init_variance"], seed=17)
+    render.network_fine.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    render.set_iter(-1)
+    calib = np.array([100.0, 100.0, 320.0, 240.0])
+    cam = Camera(PinholeCalib(calib), np.array([0.02, 0.04, 0.06, 0.1, 0.2, 0.3], dtype=np.float32))
+    uv = torch.stack([torch.linspace(40, 600, 24), torch.linspace(30, 450, 24)], 1).to(torch.int64)
+    torch.manual_seed(4)
+    with torch.enable_grad():
+        out = render.render_rays(uv, cam)
+    arrs = dict(uv=npy(uv), R=npy(cam.R), T=npy(cam.T), calib=calib.astype(np.float32), config=np.array(json.dumps(kw)))
+    for k, v in out.items():
+        arrs["out_" + k] = npy(v)
+    save("neus_render_rays.npz", **arrs)
+
 
 def gen_train():
     """One training step of the reference (nerf_trainer.py:81-140) on 12 bunny_smoke rays: render_rays with autograd

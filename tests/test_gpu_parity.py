@@ -658,3 +658,25 @@ def test_neus_synth(dev, orc, name):
     for k in ("sdf", "density", "color"):
         assert_close(N(o[k]), g["eval_" + k], 1e-4, 1e-5, "%s %s vs golden" % (name, k))
         assert_close(N(o[k]), ref[k], 1e-4, 1e-5, "%s %s vs oracle" % (name, k))
+
+
+def test_neus_render_rays(dev):
+    """render_rays over one NeuS network (point samples, sdf-derived density, importance resampling) against the reference
+    renderer on identical weights, rays and torch seed."""
+    import neddf_amd
+    g = golden("neus_render_rays.npz")
+    kw = json.loads(str(g["config"]))
+    r = neddf_amd.NeRFRender(dict(kw, _target_="neddf.network.NeuS"), sample_coarse=32, sample_fine=48, dist_near=2.0, dist_far=6.0,
+                             max_dist=6.0, use_coarse_network=False, sampling_type="point")
+    sd = synth.neus_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["sdf_layer_count"], kw["sdf_layer_width"],
+                          kw["col_layer_count"], kw["col_layer_width"], tuple(kw["skips"]), kw["init_variance"], seed=17)
+    r.network_fine.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    r.to(dev)
+    r.set_iter(-1)
+    cam = make_camera(g, dev)
+    torch.manual_seed(4)
+    o = r.render_rays(torch.from_numpy(g["uv"]).to(dev), cam)
+    assert "fields_penalty" not in o
+    for k in ("color", "depth", "transmittance", "color_coarse", "depth_coarse", "transmittance_coarse"):
+        assert_close(N(o[k]), g["out_" + k], 1e-4, 1e-5, k)
+    assert_close(N(o["weight"]), g["out_weight"], 1e-3, 1e-5, "weight")
