@@ -661,6 +661,48 @@ def gen_train_neus():
         _grad_records(arrs, pre, net, 457, full)
         for k, p_ in net.named_parameters():
             print(tag, k, float(p_.grad.abs().max()))
+
+    # one training step of NeRFRender over a NeuS network (point samples, ColorLoss + MaskBCELoss) on 10 rays
+    from neddf.loss import ColorLoss, MaskBCELoss
+    kw = cases["relu"][0]
+    render = NeRFRender(network_config=dict(kw, _target_="neddf.network.NeuS"), sample_coarse=24, sample_fine=40, dist_near=2.0,
+                        dist_far=6.0, max_dist=6.0, use_coarse_network=False, sampling_type="point")
+    sd = synth.neus_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["sdf_layer_count"], kw["sdf_layer_width"],
+                          kw["col_layer_count"], kw["col_layer_width"], tuple(kw["skips"]), kw["init_variance"], seed=17)
+    render.network_fine.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    render.set_iter(500)
+    tf = json.load(open(os.path.join(REF, "data/bunny_smoke/transforms_test.json")))
+    cam, calib = make_camera(400, 400, tf["frames"][5], tf["camera_angle_x"])
+    cam.update_transform()
+    cand = torch.from_numpy(rng.integers(120, 280, (200, 2)).astype(np.int16))
+    torch.manual_seed(5)
+    with torch.enable_grad():
+        pre_out = render.render_rays(cand, cam)
+    tr_, trc = pre_out["transmittance"].detach(), pre_out["transmittance_coarse"].detach()
+    ok = (tr_ > 1e-2) & (tr_ < 1 - 1e-2) & (trc > 1e-2) & (trc < 1 - 1e-2)     # away from MaskBCELoss's clamp (see gen_train_nerf)
+    assert int(ok.sum()) >= 10, int(ok.sum())
+    uv = cand[ok][:10].contiguous()
+    target = {"color": torch.from_numpy(rng.uniform(0, 1, (10, 3)).astype(np.float32)),
+              "mask": torch.from_numpy((rng.uniform(0, 1, 10) > 0.5).astype(np.float32))}
+    losses = [ColorLoss(weight=1.0, weight_coarse=0.1), MaskBCELoss(weight=0.05, weight_coarse=0.005)]
+    torch.manual_seed(21)
+    with torch.enable_grad():
+        render.zero_grad()
+        out = render.render_rays(uv, cam)
+        ld = {}
+        for f in losses:
+            ld.update(f(out, target))
+        loss = torch.sum(torch.stack(list(ld.values())))
+        loss.backward()
+    arrs.update(step_uv=npy(uv), step_R=npy(cam.R), step_T=npy(cam.T), step_calib=calib, step_target_color=npy(target["color"]),
+                step_target_mask=npy(target["mask"]), step_loss=npy(loss), step_config=np.array(json.dumps(kw)))
+    for k, v in ld.items():
+        arrs["step_loss_" + k] = npy(v)
+    for k, v in out.items():
+        arrs["step_out_" + k] = npy(v)
+    n_sdf, n_col = kw["sdf_layer_count"], kw["col_layer_count"]
+    _grad_records(arrs, "step_", render.network_fine, 458, ("variance", "layers_sdf.0.weight", "layers_sdf.%d.bias" % (n_sdf - 1),
+                                                          "layers_col.0.bias", "layers_col.%d.weight" % n_col, "layers_col.%d.bias" % n_col))
     save("train_neus.npz", **arrs)
 
 
