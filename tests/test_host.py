@@ -496,3 +496,39 @@ def test_capi_rejects_null_context_without_touching_a_device():
         assert rc == -1, (name, rc)
     assert lib.neddf_last_error(None) is not None
     assert lib.neddf_device_cus(None) == 0
+
+
+def test_split_fp16_operand_range_model():
+    """Numerical model of the split-fp16 operand policy (tile_engine.h OpsF16Split) in numpy: x = h + m with h toward zero and m the
+    rounded remainder, three products.  At operand magnitudes around 1 the product is accurate to ~2e-7 of its range; at the
+    magnitudes of training gradients (1e-5 .. 1e-6) two fp16 terms run out of exponent range and the error reaches 1e-3 .. 1e-2,
+    unless the operand is first multiplied by the power of two that brings its maximum to [2^13, 2^14) -- the rule the backward
+    kernels implement (train_kernels.hip operand_scale).  This is the arithmetic behind DESIGN.md section 8's statement."""
+    rng = np.random.default_rng(0)
+
+    def rtz16(x):
+        h = x.astype(np.float16)
+        over = np.abs(h.astype(np.float32)) > np.abs(x)
+        return np.where(over, np.nextafter(h, np.float16(0)), h).astype(np.float16)
+
+    def split(x):
+        h = rtz16(x)
+        return h.astype(np.float64), (x - h.astype(np.float32)).astype(np.float16).astype(np.float64)
+
+    W = (rng.standard_normal((256, 256)) * 0.06).astype(np.float32)
+    wh, wm = split(W * 1024)
+    errs = {}
+    for mag in (1.0, 1e-5, 1e-6):
+        A = (rng.standard_normal((256, 256)) * mag).astype(np.float32)
+        ref = A.astype(np.float64) @ W.astype(np.float64)
+        ah, am = split(A)
+        plain = (am @ wh + ah @ wm + ah @ wh) / 1024
+        e = int(np.floor(np.log2(np.abs(A).max())))
+        sc = 2.0 ** (13 - e)
+        assert 2 ** 13 <= np.abs(A).max() * sc < 2 ** 14
+        ah, am = split((A * np.float32(sc)).astype(np.float32))
+        scaled = (am @ wh + ah @ wm + ah @ wh) / 1024 / sc
+        errs[mag] = (np.abs(plain - ref).max() / np.abs(ref).max(), np.abs(scaled - ref).max() / np.abs(ref).max())
+    assert errs[1.0][0] < 1e-6 and errs[1.0][1] < 1e-6
+    assert errs[1e-5][0] > 5e-4 and errs[1e-6][0] > 5e-3          # unscaled: out of fp16's exponent range
+    assert errs[1e-5][1] < 1e-6 and errs[1e-6][1] < 1e-6          # range-scaled: back at the level of magnitude 1
