@@ -705,8 +705,8 @@ static bool bf16_mt4x2()
     if (v < 0) { const char *e = getenv("NEDDF_BF16_MT4X2"); v = ((!e || atoi(e) != 0) && tile_mt() == 2 && bf16_wps() == 2) ? 1 : 0; }
     return v == 1;
 }
-int field_wgs_per_cu(int bf16) { return tile_mt() == 2 ? (bf16 == 1 ? bf16_wps() : 2) : 1; }
-int ddf_points_per_tile(int bf16) { return (bf16 == 1 && bf16_mt4x2()) ? 32 : tile_mt() * 8; }
+int field_wgs_per_cu(int operands) { return tile_mt() == 2 ? (operands == 1 ? bf16_wps() : 2) : 1; }
+int ddf_points_per_tile(int operands) { return (operands == 1 && bf16_mt4x2()) ? 32 : tile_mt() * 8; }
 int col_points_per_tile(bool rows4, int) { return rows4 ? tile_mt() * 8 : tile_mt() * 32; }
 int nerf_points_per_tile() { return tile_mt() * 32; }
 
@@ -741,8 +741,8 @@ static void launch_ddf_t(const DdfArgs &a, int grid, hipStream_t s)
 
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
 {
-    if (a.bf16 == 2) launch_ddf_t<OpsF16Split>(a, grid, s);
-    else if (a.bf16) launch_ddf_t<OpsBF16>(a, grid, s);
+    if (a.operands == 2) launch_ddf_t<OpsF16Split>(a, grid, s);
+    else if (a.operands) launch_ddf_t<OpsBF16>(a, grid, s);
     else launch_ddf_t<OpsF32>(a, grid, s);
 }
 
@@ -765,8 +765,8 @@ static void launch_col_t(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 {
-    if (a.bf16 == 2) launch_col_t<OpsF16Split>(a, grid, rows4, s);
-    else if (a.bf16) launch_col_t<OpsBF16>(a, grid, rows4, s);
+    if (a.operands == 2) launch_col_t<OpsF16Split>(a, grid, rows4, s);
+    else if (a.operands) launch_col_t<OpsBF16>(a, grid, rows4, s);
     else launch_col_t<OpsF32>(a, grid, rows4, s);
 }
 
@@ -782,8 +782,8 @@ static void launch_nerf_t(const NerfArgs &a, int grid, hipStream_t s)
 
 void launch_nerf(const NerfArgs &a, int grid, hipStream_t s)
 {
-    if (a.bf16 == 2) launch_nerf_t<OpsF16Split>(a, grid, s);
-    else if (a.bf16) launch_nerf_t<OpsBF16>(a, grid, s);
+    if (a.operands == 2) launch_nerf_t<OpsF16Split>(a, grid, s);
+    else if (a.operands) launch_nerf_t<OpsBF16>(a, grid, s);
     else launch_nerf_t<OpsF32>(a, grid, s);
 }
 

@@ -58,7 +58,7 @@ struct DdfArgs {
     const float *w_ddf_out, *w_aux_out;   // [256] each
     float b_ddf_out, b_aux_out;
     float d_near, aux_grad_scale;
-    int bf16;                             // operands: 0 fp32 (32x32x2 f32 MFMA), 1 bf16, 2 split fp16 (three fp16 products per multiply-add), see tile_engine.h
+    int operands;                         // 0 fp32 (32x32x2 f32 MFMA), 1 bf16, 2 split fp16 (three fp16 products per multiply-add), see tile_engine.h
     int neus;                             // 1: NeuS sdf trunk (neus.py:118-145): plain PE, no heads, sdf = feature 0
     float neus_v10;                       // variance * 10
     float *scratch;                       // per-workgroup stash area
@@ -79,7 +79,7 @@ struct ColArgs {
     int activation;
     int mode;                             // 0 NeDDF inputs [embed_pos | embed_dir | normal], 1 NeuS inputs [pos | gradient | embed_dir]
     int final_act;                        // activation id applied to the 3 outputs (NeuS, neus.py:150-152) or -1
-    int bf16;                             // as DdfArgs::bf16
+    int operands;                         // as DdfArgs::operands
     int ksteps_a;                         // super-steps of layer 0's small-input segment [pe_pos | pe_dir | normal]
     const float *wp_a;                    // its packed weights
     LayerW layer[kMaxLayers];             // layer[0] = feature segment of layer 0
@@ -113,7 +113,7 @@ struct NerfArgs {
     LayerW col0;                          // outL_color.0: 256(+dir) -> 128
     const float *w_col1;                  // [3][128] (nn.Linear layout)
     float b_col1[3];
-    int bf16;                             // as DdfArgs::bf16
+    int operands;                         // as DdfArgs::operands
     float *scratch;
     float *density, *color;
 };
@@ -126,10 +126,10 @@ size_t field_lds_bytes(int mt);
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s);
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s);
 void launch_nerf(const NerfArgs &a, int grid, hipStream_t s);
-int ddf_points_per_tile(int bf16 = 0);
-int col_points_per_tile(bool rows4, int bf16 = 0);
+int ddf_points_per_tile(int operands = 0);
+int col_points_per_tile(bool rows4, int operands = 0);
 int nerf_points_per_tile();
-int field_wgs_per_cu(int bf16 = 0);
+int field_wgs_per_cu(int operands = 0);
 
 void launch_raygen(const void *uv, int uv_type, int64_t n, const CameraArg &cam, float *dir, float *orig, hipStream_t s);
 void launch_sample_coarse(const float *U, int64_t n, int S1, float near_, float far_, float *dists, hipStream_t s);

@@ -86,16 +86,16 @@ static inline float f16_value(uint16_t h)
 
 // fragment-major packing, see kernels.h LayerW.  kmap (engine column -> reference weight row, -1 = zero) is padded to
 // a whole number of super-steps: 8 k-values for fp32 fragments (4 floats per lane half), 16 for bf16 (8 per lane half).
-static size_t pack_layer(std::vector<float> &blob, const Src &src, std::vector<int> kmap, int nout, int bf16, int *ksteps_out)
+static size_t pack_layer(std::vector<float> &blob, const Src &src, std::vector<int> kmap, int nout, int operands, int *ksteps_out)
 {
-    // bf16 == 2 (split fp16): two fp16 planes of 2^10 w (h toward zero, m = remainder to nearest), 32 bytes per lane and super-step
-    const int step = bf16 ? 16 : 8, half = step / 2, NT = nout / 128, planes = bf16 == 2 ? 2 : 1;
+    // operands == 2 (split fp16): two fp16 planes of 2^10 w (h toward zero, m = remainder to nearest), 32 bytes per lane and super-step
+    const int step = operands ? 16 : 8, half = step / 2, NT = nout / 128, planes = operands == 2 ? 2 : 1;
     while (kmap.size() % step) kmap.push_back(-1);
     const int ks = (int)kmap.size() / step;
     if (ksteps_out) *ksteps_out = ks;
     size_t off = roundup((int)blob.size(), 64);
     const size_t elems = (size_t)ks * step * nout;
-    blob.resize(off + (bf16 ? elems * planes / 2 : elems), 0.f);
+    blob.resize(off + (operands ? elems * planes / 2 : elems), 0.f);
     float *dst = blob.data() + off;
     uint16_t *dst16 = (uint16_t *)dst;
     for (int w = 0; w < kWaves; ++w)
@@ -107,12 +107,12 @@ static size_t pack_layer(std::vector<float> &blob, const Src &src, std::vector<i
                         int k = kmap[step * S + half * (lane >> 5) + r];
                         float v = k < 0 ? 0.f : src.at(k, n);
                         size_t frag = (((size_t)(w * NT + t) * ks + S) * 64 + lane);
-                        if (bf16 == 2) {
+                        if (operands == 2) {
                             const float sv = v * 1024.0f;
                             uint16_t h = f16_bits(sv, true);
                             dst16[(frag * 2 + 0) * half + r] = h;
                             dst16[(frag * 2 + 1) * half + r] = f16_bits(sv - f16_value(h), false);
-                        } else if (bf16) dst16[frag * half + r] = bf16_bits(v);
+                        } else if (operands) dst16[frag * half + r] = bf16_bits(v);
                         else dst[frag * half + r] = v;
                     }
     return off;
@@ -140,7 +140,7 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     const neddf_field_desc &d = f.d;
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n_trunk = d.layer_count - 1, n_col = d.col_layer_count - 1;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
-    const int bf16 = d.weight_dtype;      // 0 fp32, 1 bf16, 2 split fp16
+    const int operands = d.weight_dtype;      // 0 fp32, 1 bf16, 2 split fp16
     if (n_tensors != n_trunk + n_col + 3) return fail(ctx, NEDDF_EINVAL, "NeDDF: wrong tensor count");
     if (n_trunk < 1 || n_trunk > kMaxLayers || n_col < 1 || n_col > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeDDF: layer count out of range");
     for (int i = 0; i < d.n_skips; ++i)
@@ -162,10 +162,10 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
         a.layer[l].stash = -1;
         if (l == 0) km = pe;
         else for (int k = 0; k < kWidth; ++k) km.push_back(wide ? Cpe + k : k);
-        o_wp[l] = pack_layer(blob, src, km, kWidth, bf16, &a.layer[l].ksteps);
+        o_wp[l] = pack_layer(blob, src, km, kWidth, operands, &a.layer[l].ksteps);
         if (wide) {
             if (a.n_stash >= kMaxStash) return fail(ctx, NEDDF_EUNSUPPORTED, "NeDDF: too many skip connections");
-            o_st.push_back(pack_layer(blob, src, pe, kWidth, bf16, &a.stash[a.n_stash].ksteps));
+            o_st.push_back(pack_layer(blob, src, pe, kWidth, operands, &a.stash[a.n_stash].ksteps));
             a.stash[a.n_stash].col0 = 0;
             a.layer[l].stash = a.n_stash++;
         }
@@ -181,13 +181,13 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     for (int k = 0; k < 3; ++k) ka.push_back(Cpe + Cdir + k);
     std::vector<size_t> c_wp(n_col), c_b(n_col);
     Src s0{ W[n_trunk], Cpe + Cdir + 3 + kWidth, kWidth, false };
-    size_t o_wa = pack_layer(blob, s0, ka, kWidth, bf16, &c.ksteps_a);
+    size_t o_wa = pack_layer(blob, s0, ka, kWidth, operands, &c.ksteps_a);
     c.n_layers = n_col;
     for (int l = 0; l < n_col; ++l) {
         std::vector<int> km;
         for (int k = 0; k < kWidth; ++k) km.push_back(l == 0 ? Cpe + Cdir + 3 + k : k);
         Src src{ W[n_trunk + l], l == 0 ? Cpe + Cdir + 3 + kWidth : kWidth, kWidth, false };
-        c_wp[l] = pack_layer(blob, src, km, kWidth, bf16, &c.layer[l].ksteps);
+        c_wp[l] = pack_layer(blob, src, km, kWidth, operands, &c.layer[l].ksteps);
         c.layer[l].stash = -1;
         c_b[l] = put(blob, B[n_trunk + l], kWidth);
     }
@@ -206,7 +206,7 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     a.activation = c.activation = d.activation;
     a.density_activation = d.density_activation;
     a.d_near = d.d_near;
-    a.bf16 = c.bf16 = bf16;
+    a.operands = c.operands = operands;
     c.final_act = -1;
     for (int k = 0; k < 6; ++k) { c.penalty_weight[k] = d.penalty_weight[k]; c.penalty_has[k] = d.penalty_has[k]; }
     return 0;
@@ -219,7 +219,7 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     const neddf_field_desc &d = f.d;
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n_sdf = d.layer_count, n_col = d.col_layer_count;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
-    const int bf16 = d.weight_dtype;
+    const int operands = d.weight_dtype;
     if (n_tensors != n_sdf + n_col + 2) return fail(ctx, NEDDF_EINVAL, "NeuS: wrong tensor count");
     if (n_sdf < 1 || n_sdf > kMaxLayers || n_col < 1 || n_col > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: layer count out of range");
     if (d.activation == NEDDF_ACT_LEAKY) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: activation must be ReLU or tanhExp");
@@ -242,12 +242,12 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
         a.layer[l].stash = -1;
         if (l == 0) km = pe;
         else for (int k = 0; k < kWidth; ++k) km.push_back(k);       // cat([hx, embed_pos]): hidden state first
-        o_wp[l] = pack_layer(blob, src, km, kWidth, bf16, &a.layer[l].ksteps);
+        o_wp[l] = pack_layer(blob, src, km, kWidth, operands, &a.layer[l].ksteps);
         if (wide) {
             if (a.n_stash >= kMaxStash) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: too many skip connections");
             std::vector<int> ps;
             enc_map(ps, E, KH, kWidth);
-            o_st.push_back(pack_layer(blob, src, ps, kWidth, bf16, &a.stash[a.n_stash].ksteps));
+            o_st.push_back(pack_layer(blob, src, ps, kWidth, operands, &a.stash[a.n_stash].ksteps));
             a.stash[a.n_stash].col0 = 0;
             a.layer[l].stash = a.n_stash++;
         }
@@ -261,14 +261,14 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     enc_map(ka, Ed, KD, 3);
     const int in_col = 6 + Cdir + kWidth;
     Src s0{ W[n_sdf], in_col, kWidth, true };
-    size_t o_wa = pack_layer(blob, s0, ka, kWidth, bf16, &c.ksteps_a);
+    size_t o_wa = pack_layer(blob, s0, ka, kWidth, operands, &c.ksteps_a);
     c.n_layers = n_col;
     std::vector<size_t> c_wp(n_col), c_b(n_col);
     for (int l = 0; l < n_col; ++l) {
         std::vector<int> km;
         for (int k = 0; k < kWidth; ++k) km.push_back(l == 0 ? 6 + Cdir + k : k);
         Src src{ W[n_sdf + l], l == 0 ? in_col : kWidth, kWidth, true };
-        c_wp[l] = pack_layer(blob, src, km, kWidth, bf16, &c.layer[l].ksteps);
+        c_wp[l] = pack_layer(blob, src, km, kWidth, operands, &c.layer[l].ksteps);
         c.layer[l].stash = -1;
         c_b[l] = put(blob, B[n_sdf + l], kWidth);
     }
@@ -287,7 +287,7 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     c.w_out = base + o_cout;
     a.activation = c.activation = d.activation;
     a.neus = 1;
-    a.bf16 = c.bf16 = bf16;
+    a.operands = c.operands = operands;
     a.neus_v10 = W[n_sdf + n_col + 1][0] * 10.0f;
     c.mode = 1;
     c.final_act = d.activation;
@@ -299,7 +299,7 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     const neddf_field_desc &d = f.d;
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n = d.layer_count;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
-    const int bf16 = d.weight_dtype, step = bf16 ? 16 : 8;
+    const int operands = d.weight_dtype, step = operands ? 16 : 8;
     if (n_tensors != n + 3) return fail(ctx, NEDDF_EINVAL, "NeRF: wrong tensor count");
     if (n < 1 || n > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: layer count out of range");
     for (int i = 0; i < d.n_skips; ++i)
@@ -320,12 +320,12 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
         a.layer[l].stash = -1;
         if (l == 0) km = pe;
         else for (int k = 0; k < kWidth; ++k) km.push_back(k);       // cat([hx, embed_pos]): hidden state first
-        o_wp[l] = pack_layer(blob, src, km, kWidth, bf16, &a.layer[l].ksteps);
+        o_wp[l] = pack_layer(blob, src, km, kWidth, operands, &a.layer[l].ksteps);
         if (wide) {
             if (a.n_stash >= kMaxStash - 1) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: too many skip connections");
             std::vector<int> ps;
             enc_map(ps, E, KH, kWidth);
-            o_st.push_back(pack_layer(blob, src, ps, kWidth, bf16, &a.stash[a.n_stash].ksteps));
+            o_st.push_back(pack_layer(blob, src, ps, kWidth, operands, &a.stash[a.n_stash].ksteps));
             a.stash[a.n_stash].col0 = 0;
             a.layer[l].stash = a.n_stash++;
         }
@@ -338,9 +338,9 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     std::vector<int> km, kd;
     for (int k = 0; k < kWidth; ++k) km.push_back(k);
     enc_map(kd, Ed, KD, kWidth);
-    size_t o_c0 = pack_layer(blob, sc, km, kWidth / 2, bf16, &a.col0.ksteps);
+    size_t o_c0 = pack_layer(blob, sc, km, kWidth / 2, operands, &a.col0.ksteps);
     a.col_stash = a.n_stash;
-    size_t o_c0s = pack_layer(blob, sc, kd, kWidth / 2, bf16, &a.stash[a.n_stash].ksteps);
+    size_t o_c0s = pack_layer(blob, sc, kd, kWidth / 2, operands, &a.stash[a.n_stash].ksteps);
     a.stash[a.n_stash].col0 = roundup(2 * KH, step);          // direction encoding: first super-step boundary after the position encoding
     a.n_stash++;
     size_t o_c0b = put(blob, B[n + 1], kWidth / 2);
@@ -358,7 +358,7 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     a.w_col1 = base + o_c1;
     a.activation = d.activation;
     a.density_activation = d.density_activation;
-    a.bf16 = bf16;
+    a.operands = operands;
     return 0;
 }
 
