@@ -329,12 +329,12 @@ def main():
                          "colour_kernel": {"avg_launch_ms": tm["col_ms"] / max(tm["col_launches"], 1),
                                            "achieved": (pts * COL_FLOP_PER_POINT / (tm["col_ms"] / 1e3) / 1e12) if tm["col_ms"] > 0 else 0.0}},
         }
-        try:        # HBM bytes per launch (PMC passes exist for the headline fp32 workload only)
-            if args.dtype != "f32" or args.workload != "c2":
+        try:        # HBM bytes per launch (PMC passes exist for the headline workload under the fp32 and bf16 policies)
+            if args.dtype not in ("f32", "bf16") or args.workload != "c2":
                 raise KeyError("no PMC pass for this workload")
             # HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            ent = next(v for k, v in pmc.items() if "ddf_trunk_kernel" in k)
+            ent = next(v for k, v in pmc.items() if "ddf_trunk_kernel" in k and ("OpsBF16" in k) == (args.dtype == "bf16"))
             line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
             line["roofline"]["traffic_source"] = ent["source"]
             line["roofline"]["algorithmic_hbm_bytes_per_launch"] = ent["algorithmic_bytes_per_launch"]
