@@ -270,11 +270,14 @@ def test_nerf_synth(dev, orc, name):
             assert_close(N(o[k]), g["%s_%s" % (tag, k)], 1e-4, 1e-5, "%s %s %s" % (name, tag, k))
 
 
-def test_field_ragged_sizes_and_chunks(dev, bunny_weights):
-    """Tile tails (N not a multiple of 32/128), N = 1, and batch invariance."""
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "f16_split"])
+def test_field_ragged_sizes_and_chunks(dev, bunny_weights, dtype):
+    """Tile tails (N not a multiple of 16/32/64/128), N = 1, and batch invariance, under every operand policy (the tile shapes
+    differ: 64-row tiles, 128-row tiles for the bf16 distance trunk)."""
     net = neddf_module(BUNNY_CFG, bunny_weights, dev)
     net.set_iter(-1)
     net.output_mode = "minimal"
+    net.weight_dtype = dtype
     from neddf_amd import Sampling
     pos, d, var = synth.random_sampling(1, 1000, seed=9)
     full = net(Sampling(T(pos, dev), T(d, dev), T(var, dev)))
