@@ -1,1 +1,1 @@
-from neddf_amd.logger import BaseLogger, NeRFTBLogger  # noqa: F401
+from neddf_amd.logger import ScalarLog  # noqa: F401

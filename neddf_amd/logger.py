@@ -1,74 +1,76 @@
-"""Training observability -- host-side mirror of neddf/logger/{base_logger,nerf_tb_logger}.py.
+"""Scalar log of a training run.
 
-Same call protocol (write_batchstart / write / write_batchend / next) and the same
-scalar names.  TensorBoard is used when the package is importable; otherwise the
-scalars go to `log/scalars.jsonl`, one JSON object per iteration."""
+Out of the hot path (SURVEY.md section 2 marks the reference's logger package out of
+scope); the trainer only needs somewhere to put one row of scalars per step.  Own
+design: `ScalarLog.step(...)` is a context manager that times the step and, on exit,
+appends one row to the sink -- TensorBoard when the package is importable, else
+`log/scalars.jsonl`.  Scalar names follow the reference's run logs (`loss`, `PSNR`,
+`objective/<term>`, durations) so dashboards built for them keep working.
+"""
 import json
 import os
-from abc import ABC, abstractmethod
-from time import time
-from typing import Dict
-
-from torch import Tensor
+import time
+from contextlib import contextmanager
+from typing import Dict, Iterator, Optional
 
 
-class BaseLogger(ABC):
-    """base_logger.py:8-78"""
+class _JsonlSink:
+    def __init__(self, log_dir: str) -> None:
+        os.makedirs(log_dir, exist_ok=True)
+        self.path = os.path.join(log_dir, "scalars.jsonl")
+        self.fh = open(self.path, "a")
+
+    def add(self, iteration: int, row: Dict[str, float]) -> None:
+        self.fh.write(json.dumps(dict(row, iteration=iteration)) + "\n")
+        self.fh.flush()
+
+
+class _TensorBoardSink:
+    def __init__(self, log_dir: str) -> None:
+        from torch.utils.tensorboard import SummaryWriter      # optional dependency
+        self.writer = SummaryWriter(log_dir=log_dir)
+
+    def add(self, iteration: int, row: Dict[str, float]) -> None:
+        for name, value in row.items():
+            self.writer.add_scalar(name, value, iteration)
+
+
+class StepRecord:
+    """What one training step reports; filled by the trainer inside `with log.step() as rec:`."""
 
     def __init__(self) -> None:
-        self.reset()
+        self.loss: float = float("nan")
+        self.psnr: float = float("nan")
+        self.terms: Dict[str, float] = {}
 
-    def reset(self) -> None:
-        self.loss: float = 0.0
-        self.psnr: float = 0.0
-        self.loss_dict: Dict[str, float] = {}
-        self.niter: int = 0
-        self.loggerstart: float = time()
-        self.batchstart = self.prev_batchend = self.batchend = self.loggerstart
-
-    def write(self, loss: float, psnr: float, loss_dict: Dict[str, Tensor]) -> None:
-        self.loss, self.psnr = loss, psnr
-        self.loss_dict = {key: float(loss_dict[key].item()) for key in loss_dict}
-
-    def write_batchstart(self) -> None:
-        self.prev_batchend = self.batchend
-        self.batchstart = time()
-
-    def write_batchend(self) -> None:
-        self.batchend = time()
-
-    def next(self) -> None:
-        log_dict: Dict[str, float] = {"loss": self.loss, "PSNR": self.psnr,
-                                      "iteration duration": self.batchend - self.batchstart,
-                                      "total duration": self.batchend - self.loggerstart}
-        for key in self.loss_dict:
-            log_dict["objective/{}".format(key)] = self.loss_dict[key]
-        self._next_impl(log_dict)
-        self.niter += 1
-
-    @abstractmethod
-    def _next_impl(self, data: Dict) -> None:
-        raise NotImplementedError()
+    def report(self, loss: float, psnr: float, terms: Dict[str, object]) -> None:
+        self.loss, self.psnr = float(loss), float(psnr)
+        self.terms = {k: float(v.item() if hasattr(v, "item") else v) for k, v in terms.items()}
 
 
-class NeRFTBLogger(BaseLogger):
-    """nerf_tb_logger.py:8-28: scalars under ./log (the run directory)."""
-
-    def __init__(self, log_dir: str = "log") -> None:
-        super().__init__()
-        self.writer = None
-        self.file = None
-        try:
-            from torch.utils.tensorboard import SummaryWriter
-            self.writer = SummaryWriter(log_dir=log_dir)
-        except Exception:       # tensorboard is an optional dependency of torch
-            os.makedirs(log_dir, exist_ok=True)
-            self.file = open(os.path.join(log_dir, "scalars.jsonl"), "a")
-
-    def _next_impl(self, data: Dict) -> None:
-        if self.writer is not None:
-            for k in data:
-                self.writer.add_scalar(k, data[k], self.niter)
+class ScalarLog:
+    def __init__(self, log_dir: str = "log", sink: Optional[str] = None) -> None:
+        """sink: "tensorboard", "jsonl" or None (= tensorboard if importable, else jsonl)."""
+        self.iteration = 0
+        self.t_open = time.time()
+        self.last: Optional[StepRecord] = None
+        if sink == "jsonl":
+            self.sink = _JsonlSink(log_dir)
+        elif sink == "tensorboard":
+            self.sink = _TensorBoardSink(log_dir)
         else:
-            self.file.write(json.dumps(dict(data, iteration=self.niter)) + "\n")
-            self.file.flush()
+            try:
+                self.sink = _TensorBoardSink(log_dir)
+            except Exception:
+                self.sink = _JsonlSink(log_dir)
+
+    @contextmanager
+    def step(self) -> Iterator[StepRecord]:
+        rec, t0 = StepRecord(), time.time()
+        yield rec
+        t1 = time.time()
+        row = {"loss": rec.loss, "PSNR": rec.psnr, "iteration duration": t1 - t0, "total duration": t1 - self.t_open}
+        row.update({"objective/" + k: v for k, v in rec.terms.items()})
+        self.sink.add(self.iteration, row)
+        self.last = rec
+        self.iteration += 1

@@ -302,10 +302,12 @@ class NeRFRender(BaseNeuralRender):
             out["_nan"] = flag
         return out
 
-    def render_field_slice(self, slice_t: float = 0.0, render_size: float = 1.1, render_resolution: int = 128):
+    def render_field_slice(self, slice_t: float = 0.0, render_size: float = 1.1, render_resolution: int = 128,
+                           colormap: bool = True):
         """nerf_render.py:263-336: z = slice_t plane of the fine network's fields as uint8 images (debug view).
         Scalar fields are JET colour-mapped (BGR, same control points as cv2.COLORMAP_JET; cv2 itself is not a
-        dependency here), colour is scaled by 256."""
+        dependency here), colour is scaled by 256.  colormap=False (not a reference keyword) returns the scalar
+        fields as the [n,n,1] uint8 images the reference hands to cv2.applyColorMap."""
         import numpy as np
         from .ray import Sampling
         with torch.no_grad():
@@ -327,7 +329,7 @@ class NeRFRender(BaseNeuralRender):
                 if key not in scales:
                     continue
                 f = (scales[key] * val.reshape(n, n, -1)).cpu().numpy().clip(0, 255).astype(np.uint8)
-                fields[key] = jet_bgr(f[:, :, 0]) if f.shape[2] == 1 else f
+                fields[key] = jet_bgr(f[:, :, 0]) if (f.shape[2] == 1 and colormap) else f
             return fields
 
 

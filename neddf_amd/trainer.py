@@ -14,7 +14,7 @@ import torch
 from .camera import Camera, PinholeCalib
 from .config import instantiate, to_plain
 from .dataset import imwrite_bgr
-from .logger import NeRFTBLogger
+from .logger import ScalarLog
 from .metrics import peak_signal_noise_ratio, structural_similarity
 from .parallel import average_gradients
 
@@ -149,35 +149,27 @@ class NeRFTrainer(BaseTrainer):
     def run_train_step(self, camera_id: int) -> float:
         """nerf_trainer.py:81-140; RNG draw order: u pixels, v pixels, then render_rays' own draws."""
         if self.logger is None:
-            self.logger = NeRFTBLogger()
-        self.logger.write_batchstart()
-        self.optimizer.zero_grad()
-        rgb = self.dataset[camera_id]["rgb_images"]
+            self.logger = ScalarLog()
         camera = self.cameras[camera_id]
         camera.update_transform()
-        h, w = rgb.shape[0], rgb.shape[1]
-        us_int = (torch.rand(self.batch_size) * (w - 1)).to(torch.int16).to(self.device)
-        vs_int = (torch.rand(self.batch_size) * (h - 1)).to(torch.int16).to(self.device)
-        uv = torch.stack([us_int, vs_int], 1)
-        with torch.enable_grad():
-            render_result = self.neural_render.render_rays(uv, camera)
-            loss_types = [type(func).__name__ for func in self.loss_functions]
-            targets = self.construct_ground_truth(camera_id, us_int, vs_int, loss_types)
-            loss_dict: Dict[str, torch.Tensor] = {}
-            for loss_function in self.loss_functions:
-                loss_dict.update(loss_function(render_result, targets))
-            loss = torch.sum(torch.stack(list(loss_dict.values())))
-            loss.backward()
-        # data-parallel runs (torch.distributed initialised by the launcher): every rank drew its own pixels, one all-reduce
-        average_gradients(self.neural_render.get_parameters_list())
-        loss_float = float(loss.item())
-        mse = float(torch.mean(torch.square(render_result["color"] - targets["color"])).item())
-        psnr = 10 * math.log10(1.0 / mse)
-        self.logger.write(loss_float, psnr, loss_dict)
-        del loss
-        del loss_dict
-        self.optimizer.step()
-        self.optimizer.zero_grad()
-        self.logger.write_batchend()
-        self.logger.next()
-        return loss_float
+        h, w = self.dataset[camera_id]["rgb_images"].shape[:2]
+        with self.logger.step() as rec:
+            self.optimizer.zero_grad()
+            us_int = (torch.rand(self.batch_size) * (w - 1)).to(torch.int16).to(self.device)
+            vs_int = (torch.rand(self.batch_size) * (h - 1)).to(torch.int16).to(self.device)
+            names = [type(f).__name__ for f in self.loss_functions]
+            targets = self.construct_ground_truth(camera_id, us_int, vs_int, names)
+            with torch.enable_grad():
+                rendered = self.neural_render.render_rays(torch.stack([us_int, vs_int], 1), camera)
+                terms: Dict[str, torch.Tensor] = {}
+                for f in self.loss_functions:
+                    terms.update(f(rendered, targets))
+                total = torch.stack(list(terms.values())).sum()
+                total.backward()
+            # data-parallel runs (scripts/run.py under torchrun: per-rank seed and device): one all-reduce of the gradients
+            average_gradients(self.neural_render.get_parameters_list())
+            self.optimizer.step()
+            mse = float(torch.mean(torch.square(rendered["color"].detach() - targets["color"])).item())
+            loss_value = float(total.item())
+            rec.report(loss_value, 10 * math.log10(1.0 / mse), terms)
+        return loss_value

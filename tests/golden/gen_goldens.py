@@ -35,8 +35,18 @@ def _install_stubs():
     cv2 = types.ModuleType("cv2")
     cv2.COLORMAP_JET = 2
     cv2.IMREAD_UNCHANGED = -1
-    cv2.applyColorMap = lambda img, cm: img
-    cv2.imread = cv2.imwrite = lambda *a, **k: None
+    cv2.applyColorMap = lambda img, cm: img        # identity: the goldens store what goes INTO the colour map
+
+    def imread(path, flags=None):
+        """cv2.imread(path, IMREAD_UNCHANGED) semantics through PIL: uint8, channels in B,G,R(,A) order."""
+        from PIL import Image
+        img = np.asarray(Image.open(path))
+        if img.ndim == 3 and img.shape[2] == 4:
+            return np.ascontiguousarray(img[:, :, [2, 1, 0, 3]])
+        return np.ascontiguousarray(img[:, :, ::-1]) if img.ndim == 3 else img
+
+    cv2.imread = imread
+    cv2.imwrite = lambda *a, **k: None
     sys.modules["cv2"] = cv2
     oc = types.ModuleType("omegaconf")
 
@@ -706,6 +716,59 @@ def gen_train_neus():
     save("train_neus.npz", **arrs)
 
 
+# --------------------------------------------------------------------------
+def gen_dataset():
+    """the reference's own NeRFSyntheticDataset (nerf_synthetic_dataset.py:25-84, with cv2.imread backed
+    by PIL) on a two-frame crop of data/bunny_smoke's test split.  The crop (tests/golden/bunny_mini/: two 72x56 RGBA
+    PNGs + a two-frame transforms_test.json) is data of the reference's dataset, written here once."""
+    from PIL import Image
+    from neddf.dataset import NeRFSyntheticDataset
+    src = os.path.join(REF, "data/bunny_smoke")
+    dst = os.path.join(HERE, "bunny_mini")
+    os.makedirs(os.path.join(dst, "test"), exist_ok=True)
+    tf = json.load(open(os.path.join(src, "transforms_test.json")))
+    keep = [tf["frames"][0], tf["frames"][7]]
+    mini = {"camera_angle_x": tf["camera_angle_x"], "frames": []}
+    for i, fr in enumerate(keep):
+        img = Image.open(os.path.join(src, fr["file_path"] + ".png"))
+        # non-square window across the silhouette edge: alpha takes 0, 255 and in-between values
+        crop = img.crop((150, 200, 150 + 72, 200 + 56))
+        name = "./test/m_%d" % i
+        crop.save(os.path.join(dst, name + ".png"))
+        mini["frames"].append({"file_path": name, "transform_matrix": fr["transform_matrix"]})
+    json.dump(mini, open(os.path.join(dst, "transforms_test.json"), "w"))
+    arrs = {}
+    for tag, use_mask in (("mask", True), ("nomask", False)):
+        ds = NeRFSyntheticDataset(dst, "test", use_mask=use_mask)
+        item = ds[1]
+        arrs[tag + "_calib"] = np.asarray(ds.camera_calib_params)
+        arrs[tag + "_camera_params"] = np.asarray(ds.camera_params)
+        arrs[tag + "_rgb_images"] = np.asarray(ds.rgb_images)
+        arrs[tag + "_mask_images"] = np.asarray(ds.mask_images)
+        arrs[tag + "_item1_rgb"] = np.asarray(item["rgb_images"])
+        arrs[tag + "_item1_camera_params"] = np.asarray(item["camera_params"])
+    a = arrs["mask_mask_images"]
+    assert a.min() == 0 and a.max() == 255 and ((a > 0) & (a < 255)).any(), "crop must straddle the silhouette"
+    save("dataset_bunny_mini.npz", **arrs)
+
+
+def gen_grids(render):
+    """NeRFRender.render_field_slice (nerf_render.py:263-336; scalar fields as the uint8 image handed to
+    cv2.applyColorMap) and BaseNeuralField.voxelize (base_neuralfield.py:49-79) of the shipped bunny_smoke field."""
+    arrs = {}
+    for tag, (t, size, res) in {"a": (0.1, 1.1, 48), "b": (-0.25, 0.8, 20)}.items():
+        sl = render.render_field_slice(t, size, res)
+        arrs["slice_%s_args" % tag] = np.array([t, size, res], np.float64)
+        for k, v in sl.items():
+            arrs["slice_%s_%s" % (tag, k)] = np.asarray(v)
+    net = render.network_fine
+    net.eval()
+    arrs["vox_density"] = net.voxelize("density", 1.1, 12, chunk=500)
+    arrs["vox_distance"] = net.voxelize("distance", 0.9, 9, chunk=65536)
+    net.train(True)
+    save("bunny_grids.npz", **arrs)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train_nerf":
         gen_train_nerf()
@@ -719,7 +782,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train_neus":
         gen_train_neus()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dataset":
+        gen_dataset()
+        sys.exit(0)
     r = gen_bunny()
+    if len(sys.argv) > 1 and sys.argv[1] == "grids":
+        gen_grids(r)
+        sys.exit(0)
+    gen_grids(r)
+    gen_dataset()
     gen_ops()
     gen_fields()
     gen_render_edges(r)

@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import pytest
 import torch
-from conftest import BUNNY_CFG, ROOT, golden
+from conftest import GOLDEN, BUNNY_CFG, ROOT, golden
 from scipy.spatial.transform import Rotation
 
 
@@ -265,6 +265,28 @@ def test_dataset_reader(tmp_path):
     assert np.array_equal(np.asarray(Image.open(p)), img[:, :, ::-1])
 
 
+def test_dataset_reader_matches_reference_loader():
+    """SURVEY 8f item 1, pinned: neddf_amd.dataset.NeRFSyntheticDataset on tests/golden/bunny_mini (a two-frame 72x56 crop of
+    the reference's data/bunny_smoke test split) against what the reference's own loader returned for the same files
+    (nerf_synthetic_dataset.py:25-84 imported by tests/golden/gen_goldens.py::gen_dataset): focal from camera_angle_x and the
+    image WIDTH, rotation-vector poses, B,G,R channel order, alpha-premultiplied colour / 256, alpha as the mask."""
+    from neddf_amd.dataset import NeRFSyntheticDataset
+    g = golden("dataset_bunny_mini.npz")
+    root = os.path.join(GOLDEN, "bunny_mini")
+    for tag, use_mask in (("mask", True), ("nomask", False)):
+        ds = NeRFSyntheticDataset(root, "test", use_mask=use_mask)
+        assert len(ds) == 2 and (ds.image_width, ds.image_height) == (72, 56)
+        assert np.array_equal(ds.camera_calib_params, g[tag + "_calib"]), (ds.camera_calib_params, g[tag + "_calib"])
+        assert ds.camera_params.dtype == g[tag + "_camera_params"].dtype and np.array_equal(ds.camera_params, g[tag + "_camera_params"])
+        assert ds.rgb_images.dtype == g[tag + "_rgb_images"].dtype and np.array_equal(ds.rgb_images, g[tag + "_rgb_images"])
+        assert ds.mask_images.dtype == g[tag + "_mask_images"].dtype and np.array_equal(ds.mask_images, g[tag + "_mask_images"])
+        item = ds[1]
+        assert np.array_equal(item["rgb_images"], g[tag + "_item1_rgb"])
+        assert np.array_equal(item["camera_params"], g[tag + "_item1_camera_params"])
+    m = g["mask_mask_images"]
+    assert m.min() == 0 and m.max() == 255 and ((m > 0) & (m < 255)).any()      # the crop exercises partial alpha
+
+
 def test_metrics_against_direct_evaluation():
     from neddf_amd.metrics import peak_signal_noise_ratio, structural_similarity
     rng = np.random.default_rng(0)
@@ -362,7 +384,7 @@ def test_config_groups_compose_and_resolve(tmp_path):
     from neddf_amd.scripts.run import CONFIG_DIR, compose
     cfg = compose([])
     assert list(cfg) == ["dataset", "render", "network", "trainer", "loss"]
-    assert cfg["trainer"]["batch_size"] == 1024 and cfg["network"]["_target_"] == "neddf.network.NeDDF"
+    assert cfg["trainer"]["batch_size"] == 512 and cfg["network"]["_target_"] == "neddf.network.NeDDF"      # reference: neddf_trainer 512, nerf_trainer 1024
     assert len(cfg["loss"]["functions"]) == 3
     cfg = compose(["network=nerf", "render=nerf_render", "loss=nerf_loss", "trainer=nerf_trainer", "trainer.batch_size=64",
                    "network.skips=[2,5]", "dataset.dataset_dir=/x/y"])
@@ -389,22 +411,19 @@ def test_config_groups_compose_and_resolve(tmp_path):
         assert cls.__module__.startswith("neddf_amd."), t
 
 
-def test_logger_protocol(tmp_path, monkeypatch):
-    from neddf_amd.logger import NeRFTBLogger
+def test_scalar_log_rows(tmp_path, monkeypatch):
+    from neddf_amd.logger import ScalarLog
     import json
     monkeypatch.chdir(tmp_path)
-    lg = NeRFTBLogger()
+    lg = ScalarLog(sink="jsonl")
     for i in range(2):
-        lg.write_batchstart()
-        lg.write(0.5 + i, 20.0, {"color": torch.tensor(0.25), "mask_coarse": torch.tensor(0.125)})
-        lg.write_batchend()
-        lg.next()
-    assert lg.niter == 2
-    if lg.file is not None:
-        rows = [json.loads(x) for x in open(tmp_path / "log" / "scalars.jsonl")]
-        assert [r["iteration"] for r in rows] == [0, 1] and rows[1]["loss"] == 1.5
-        assert set(rows[0]) == {"loss", "PSNR", "iteration duration", "total duration", "objective/color", "objective/mask_coarse",
-                                "iteration"}
+        with lg.step() as rec:
+            rec.report(0.5 + i, 20.0, {"color": torch.tensor(0.25), "mask_coarse": torch.tensor(0.125)})
+    assert lg.iteration == 2 and lg.last.terms == {"color": 0.25, "mask_coarse": 0.125}
+    rows = [json.loads(x) for x in open(tmp_path / "log" / "scalars.jsonl")]
+    assert [r["iteration"] for r in rows] == [0, 1] and rows[1]["loss"] == 1.5
+    assert set(rows[0]) == {"loss", "PSNR", "iteration duration", "total duration", "objective/color", "objective/mask_coarse",
+                            "iteration"}
 
 
 def test_ground_truth_construction(tmp_path):
