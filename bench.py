@@ -184,6 +184,47 @@ def train_workload(args, dev, world=1, rank=0, use_dist=False):
             "final_loss": float(loss.item())}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU, and pass
+    the ranks' stdout through (rank 0 prints the JSON line)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def psnr_vs_oracle(render, ctx, cam, weights, R, T, calib, U, n_sample=256):
+    """PSNR (data range 1.0) of the HIP path's pixel colours against the CPU oracle on a sample of the benchmarked view's
+    rays with the same uniforms (outside the timed region; BASELINE.json's metric reads "...; PSNR vs ref")."""
+    from conftest import BUNNY_CFG
+    from neddf_amd._lib import SLOT_FINE
+    from oracle import oracle as orc
+    dev = U.device
+    gen = torch.Generator(device="cpu").manual_seed(99)
+    idx = torch.randint(0, WIDTH * HEIGHT, (n_sample,), generator=gen)
+    uv = torch.stack([idx % WIDTH, idx // WIDTH], 1).to(dev)
+    Us = U[idx.to(dev)].contiguous()
+    out = dict(color=torch.empty(n_sample, 3, device=dev), depth=torch.empty(n_sample, device=dev),
+               transmittance=torch.empty(n_sample, device=dev))
+    flag = torch.zeros(1, device=dev, dtype=torch.int32)
+    ctx.render_rays(uv, cam.descriptor(), render._params(), Us, None, dict(out, nan_flag=flag), single_slot=SLOT_FINE)
+    torch.cuda.synchronize()
+    net = orc.NeDDFOracle(weights, **BUNNY_CFG)
+    rd, ro = orc.create_rays(uv.cpu().numpy().astype(np.float32), R, T, calib.astype(np.float32))
+    d = orc.sample_coarse(Us.cpu().numpy(), float(render.dist_near), float(render.dist_far))
+    v = net.forward(*orc.sampling(rd, ro, d, 1.0 / 1111 / math.sqrt(12)))
+    ref = orc.integrate(d, v["density"], v["color"], float(render.max_dist))
+    mse = float(np.mean((out["color"].cpu().numpy().astype(np.float64) - ref["color"].astype(np.float64)) ** 2))
+    worst = {k: float(np.max(np.abs(out[k].cpu().numpy() - ref[k]))) for k in ("color", "depth", "transmittance")}
+    return (10 * math.log10(1.0 / mse) if mse > 0 else float("inf")), worst, n_sample
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,7 +232,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["c2", "c3", "c5", "train"], default="c2",
-                    help="c2 = BASELINE configs[1] (headline, default); c3 = configs[2], 65 coarse + 129 importance samples; "
+                    help="c2 = BASELINE configs[1] (headline, default; with --gpus N > 1 it is configs[3]: N views, rays sharded one "
+                         "view per GPU, RCCL pixel gather); c3 = configs[2], 65 coarse + 129 importance samples; "
                          "c5 = configs[4], 1008x756 forward-facing view, NDC rays, hierarchical sampling, bf16 operands; "
                          "train = one training step (SURVEY 8f item 2): 1024 rays x (65 + 194) samples, losses, backward, Adam")
     ap.add_argument("--dtype", choices=["f32", "bf16", "f16_split"], default=None,
@@ -204,24 +246,35 @@ def main():
     if args.workload == "c5":
         WIDTH, HEIGHT = C5_WIDTH, C5_HEIGHT
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    n_dev = torch.cuda.device_count()
+    # NEDDF_BENCH_SHARE_GPU=1 (test mode for boxes with fewer GPUs than ranks): ranks share devices and the pixel gather is
+    # staged through gloo, because RCCL refuses two ranks on one device.  Never a measurement; the line says so.
+    share = os.environ.get("NEDDF_BENCH_SHARE_GPU") == "1" and world > n_dev
+    assert share or world <= n_dev, "%d ranks but %d HIP devices" % (world, n_dev)
+    local = local % n_dev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # NEDDF_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL communicator, pixel all-gather, max-over-ranks) with one rank
+    # NEDDF_BENCH_FORCE_DIST=1 runs the N > 1 code path (communicator, pixel all-gather, max-over-ranks) with one rank
     use_dist = world > 1 or os.environ.get("NEDDF_BENCH_FORCE_DIST") == "1"
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import neddf_amd
-    from neddf_amd.parallel import gather_pixels, pack_pixels
+    from neddf_amd.parallel import gather_pixels, native_comm, pack_pixels
     if args.workload == "train":
         line = train_workload(args, dev, world, rank, use_dist)
         if use_dist:
@@ -251,29 +304,72 @@ def main():
     idx = torch.arange(n_rays, device=dev)
     uv_all = torch.stack([idx % WIDTH, idx // WIDTH], 1)
     samples_per_ray = SAMPLES if args.workload == "c2" else 65 + 194
+    cam_desc = cam.descriptor()
 
     if args.workload in ("c3", "c5"):
         U_c = torch.rand(n_rays, 65, device=dev)
         U_f = torch.rand(n_rays, 129, device=dev)
 
-    def step():
+    # multi-GPU exchange: the HIP library's own RCCL communicator (neddf_comm_init / neddf_gather_pixels); torch.distributed
+    # only bootstraps it and provides the barrier / max-over-ranks of the timing contract
+    comm = {"world_size": world, "gather": "none (single rank)"}
+    if use_dist:
+        comm["torch_distributed_world_size"] = torch.distributed.get_world_size()
+        comm["backend"] = str(torch.distributed.get_backend())
+        if share:
+            comm["gather"] = "gloo, staged through the host (NEDDF_BENCH_SHARE_GPU test mode: NOT a measurement)"
+        else:
+            try:
+                info = native_comm(ctx)
+                comm.update(gather="neddf_gather_pixels: library-owned RCCL communicator, all-gather on its own stream, "
+                                   "overlapped with the next view's render", rccl_comm_ranks=info["nranks"],
+                            rccl_version=info["rccl_version"])
+            except Exception as e:      # a second RCCL route, never a CPU path: torch.distributed's all_gather_into_tensor
+                comm.update(gather="torch.distributed all_gather_into_tensor (RCCL); library communicator failed: %s" % e)
+    native = use_dist and "rccl_comm_ranks" in comm
+    gathered = [torch.empty(n_rays * world, 5, device=dev) for _ in range(2)] if use_dist else None
+    nan_flags = []
+    state = {"i": 0, "pending": None}
+
+    def render_view():
         if args.workload in ("c3", "c5"):
             parts = {k: [] for k in keys}
             for lo in range(0, n_rays, render.rays_per_call):
                 hi = min(n_rays, lo + render.rays_per_call)
-                o = render._render(ctx, uv_all[lo:hi], cam, U_c[lo:hi], U_f[lo:hi], full=False)
+                o = render._render(ctx, uv_all[lo:hi], cam, U_c[lo:hi], U_f[lo:hi], full=False, cam_desc=cam_desc)
+                nan_flags.append(o["_nan"])
                 for k in keys:
                     parts[k].append(o[k])
-            out = {k: torch.cat(v) for k, v in parts.items()}
-            out["_nan"] = o["_nan"]
-        else:
-            out = render.render_image_single_pass(WIDTH, HEIGHT, cam, SAMPLES, U=U)
-        if use_dist:        # every rank ends with all N views: [N * n_rays, 5]
-            return gather_pixels(pack_pixels(out, keys), n_rays * world, force_collective=True)
+            return {k: torch.cat(v) for k, v in parts.items()}
+        out = render.render_image_single_pass(WIDTH, HEIGHT, cam, SAMPLES, U=U)
+        nan_flags.append(out["_nan"])
         return out
 
+    def step():
+        out = render_view()
+        if not use_dist:
+            return out
+        packed = pack_pixels(out, keys)
+        if native:          # every rank ends with all N views [N * n_rays, 5]; view i's pixels travel while view i+1 renders
+            if state["pending"] is not None:
+                state["pending"].wait()
+            state["pending"] = gather_pixels(packed, n_rays * world, force_collective=True, wait=False, out=gathered[state["i"] & 1])
+            state["i"] += 1
+            return state["pending"]
+        if share:
+            full = gather_pixels(packed.cpu(), n_rays * world, force_collective=True)
+            gathered[0].copy_(full)
+            return gathered[0]
+        full = packed.new_empty(world * n_rays, 5)
+        torch.distributed.all_gather_into_tensor(full, packed)
+        return full
+
     def sync():
+        if state["pending"] is not None:
+            state["pending"].wait()
+            state["pending"] = None
         if use_dist:
+            torch.cuda.synchronize()
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -282,17 +378,24 @@ def main():
     sync()
     ctx.set_timing(True)
     ctx.get_timings()
+    nan_flags.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     sync()
     elapsed = time.perf_counter() - t0
-    tm = ctx.get_timings()
+    stage = ctx.get_stage_timings()
     ctx.set_timing(False)
+    tm = dict(ddf_ms=stage["ddf"][0], col_ms=stage["col"][0], ddf_launches=stage["ddf"][1], col_launches=stage["col"][1])
     if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    nan = int(torch.stack(nan_flags).sum().item()) if nan_flags else 0          # every batch of every step
+    assert nan == 0, "NaN weight in integrate_volume_render"
+    if use_dist and native:       # the gathered frame must hold this rank's own view at its slab
+        mine = res.out[rank * n_rays:(rank + 1) * n_rays] if hasattr(res, "out") else res[rank * n_rays:(rank + 1) * n_rays]
+        assert torch.isfinite(mine).all()
 
     if rank == 0:
         pts = n_rays * samples_per_ray * args.steps               # field evaluations on this rank
@@ -303,6 +406,13 @@ def main():
             peak = PEAK_BF16_MFMA_TFLOPS
         elif args.dtype == "f16_split":   # three fp16 products per multiply-add (fp16 and bf16 MFMA run at the same rate)
             peak = PEAK_BF16_MFMA_TFLOPS / 3
+        c2_name = ("BASELINE.json configs[1]: 800x800 view, 128 stratified cone samples/ray, NeDDF (8x256 distance trunk with "
+                   "Jacobian rows + 4x256 colour trunk) %s, 1 view per GPU per step, synthetic poses, shipped bunny_smoke weights" % args.dtype)
+        if world > 1:
+            c2_name = ("BASELINE.json configs[3]: %d-view batch 800x800 (8 azimuths), rays sharded one view per GPU over %d x MI355X "
+                       "(contiguous slabs of the flat pixel index), RCCL all-gather of the rendered pixels (20 B/ray) so that every "
+                       "rank ends with all %d views; per-GPU work = configs[1] (128 stratified cone samples/ray, NeDDF %s)"
+                       % (world, world, world, args.dtype))
         line = {
             "metric": {"c2": "rendered rays/sec (800x800, 128 samples/ray)",
                        "c3": "rendered rays/sec (800x800, 65 coarse + 194 fine hierarchical samples/ray)",
@@ -313,14 +423,13 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": {"c2": "BASELINE.json configs[1]: 800x800 view, 128 stratified cone samples/ray, NeDDF "
-                                          "(8x256 distance trunk with Jacobian rows + 4x256 colour trunk) %s, 1 view per GPU "
-                                          "per step, synthetic poses, shipped bunny_smoke weights" % args.dtype,
+            "config": {"workload": {"c2": c2_name,
                                     "c3": "BASELINE.json configs[2]: as configs[1] with render_rays' hierarchical sampling "
                                           "(65 coarse + 129 importance samples merged to 194), %s" % args.dtype,
                                     "c5": "BASELINE.json configs[4]: 1008x756 forward-facing view (fern at 1/4 scale), NDC rays, "
                                           "point samples, hierarchical 65 + 194, NeDDF with %s operands" % args.dtype}[args.workload],
-                       "rays_per_step_per_gpu": n_rays, "samples_per_ray": samples_per_ray, "workload_id": args.workload, "parallelism": "ray-parallel x%d" % world},
+                       "rays_per_step_per_gpu": n_rays, "samples_per_ray": samples_per_ray, "workload_id": args.workload,
+                       "parallelism": "ray-parallel x%d" % world, "comm": comm},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,
                          "kernel": "neddf::ddf_trunk_kernel", "launches": tm["ddf_launches"],
@@ -328,6 +437,8 @@ def main():
                          "flop_per_point": DDF_FLOP_PER_POINT,
                          "colour_kernel": {"avg_launch_ms": tm["col_ms"] / max(tm["col_launches"], 1),
                                            "achieved": (pts * COL_FLOP_PER_POINT / (tm["col_ms"] / 1e3) / 1e12) if tm["col_ms"] > 0 else 0.0}},
+            # every stage kernel of the timed region (HIP events on its stream): summed ms per step and launches per step
+            "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stage.items() if v[1]},
         }
         try:        # HBM bytes per launch (PMC passes exist for the headline workload under the fp32 and bf16 policies)
             if args.dtype not in ("f32", "bf16") or args.workload != "c2":
@@ -340,6 +451,14 @@ def main():
             line["roofline"]["algorithmic_hbm_bytes_per_launch"] = ent["algorithmic_bytes_per_launch"]
         except Exception:
             pass
+        if args.workload == "c2":
+            psnr, worst, ns = psnr_vs_oracle(render, ctx, cam, weights, R, T, calib, U)
+            line["psnr_vs_oracle_db"] = psnr
+            line["parity_sample"] = {"rays": ns, "max_abs_err": worst, "oracle": "oracle/neddf_oracle.c (pinned on the reference's goldens)",
+                                     "note": "same rays, same uniforms, outside the timed region"}
+        if world == 1 and args.workload == "c2":
+            # SURVEY 8d counts RNG generation/upload into rays/s; `value` keeps its inputs resident, these two add the draw
+            line["value_incl_rng"] = rng_inclusive(render, cam, n_rays, dev)
         if world == 1 and args.workload == "c2" and args.dtype == "f32":
             # supplementary: the same workload under the split-fp16 operand policy (fp32 data, fp32-level errors);
             # `value` above stays the exact fp32 MFMA path
@@ -356,9 +475,10 @@ def main():
             render.network_fine.weight_dtype = "fp32"
         if world == 1 and not args.no_cpu_baseline and args.workload != "c5":
             line["cpu_baseline"] = cpu_baseline(weights, R, T, calib.astype(np.float32))
-        nan = int(res["_nan"].item()) if isinstance(res, dict) else 0
-        assert nan == 0
     if use_dist:
+        torch.distributed.barrier()
+        if native:
+            ctx.comm_destroy()
         torch.distributed.destroy_process_group()
     if rank == 0:
         # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the last line of stdout
@@ -366,6 +486,25 @@ def main():
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
+
+
+def rng_inclusive(render, cam, n_rays, dev):
+    """One extra step per RNG mode with the uniforms drawn INSIDE the timed region: "device" (torch.rand on the GPU) and
+    "torch_cpu" (the reference's CPU generator, drawn per 65 536-ray batch on the host and uploaded while the previous batch
+    renders -- what the drop-in render_image does)."""
+    res = {}
+    for mode in ("device", "torch_cpu"):
+        render.rng = mode
+        render.render_image_single_pass(WIDTH, HEIGHT, cam, SAMPLES)        # warm the pinned path
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        render.render_image_single_pass(WIDTH, HEIGHT, cam, SAMPLES)
+        torch.cuda.synchronize()
+        res[mode] = n_rays / (time.perf_counter() - t0)
+    render.rng = "device"
+    res["unit"] = "rays/s"
+    res["note"] = "uniforms (128 per ray, 328 MB per view) generated inside the timed region; torch_cpu = host MT19937 + PCIe upload"
+    return res
 
 
 if __name__ == "__main__":

@@ -27,9 +27,11 @@
 extern "C" {
 #endif
 
-#define NEDDF_ABI_VERSION 2
+#define NEDDF_ABI_VERSION 3
 
-enum { NEDDF_OK = 0, NEDDF_EINVAL = -1, NEDDF_EHIP = -2, NEDDF_EUNSUPPORTED = -3, NEDDF_ENOFIELD = -4 };
+enum { NEDDF_OK = 0, NEDDF_EINVAL = -1, NEDDF_EHIP = -2, NEDDF_EUNSUPPORTED = -3, NEDDF_ENOFIELD = -4,
+       NEDDF_ECOMM = -5,      /* RCCL reported an error (message in neddf_last_error) or is not loadable */
+       NEDDF_ETIMEOUT = -6 }; /* neddf_comm_wait_host: the collective did not finish in time; the communicator was aborted */
 enum { NEDDF_FIELD_NEDDF = 0, NEDDF_FIELD_NERF = 1, NEDDF_FIELD_NEUS = 2 };
 enum { NEDDF_ACT_RELU = 0, NEDDF_ACT_LEAKY = 1, NEDDF_ACT_TANHEXP = 2 };
 /* operand type of the 256-wide dense layers: fp32 (exact, the parity path) or bf16 weights + bf16 activations with
@@ -220,14 +222,47 @@ int neddf_render_rays_single(neddf_ctx *ctx, int slot, const void *d_uv, int uv_
                              const neddf_camera *h_cam, const neddf_render_params *params, int S1,
                              const float *d_U, const neddf_render_outputs *out, void *stream);
 
-/* Kernel timing of the field kernels launched on this ctx since the last
- * neddf_get_timings call, measured with hipEvents recorded on the launch
- * stream around each launch (neddf_get_timings synchronises on them).
- * ms[0..2] = summed duration of the distance-trunk / colour-trunk / NeRF kernel
- * launches, ms[3..5] = the corresponding launch counts; n must be >= 6. */
+/* Stage timing: hipEvent pairs recorded on the launch stream around every stage kernel launched through this ctx while
+ * timing is enabled (neddf_set_timing), drained by either getter (both synchronise on the recorded events).
+ * neddf_get_timings: ms[0..2] = summed duration of the distance-trunk / colour-trunk / NeRF kernel launches,
+ * ms[3..5] = the corresponding launch counts; n must be >= 6.
+ * neddf_get_stage_timings: ms[k], launches[k] for every NEDDF_STAGE_* (n_stages >= NEDDF_STAGE_COUNT). */
+enum { NEDDF_STAGE_DDF = 0, NEDDF_STAGE_COL = 1, NEDDF_STAGE_NERF = 2, NEDDF_STAGE_RAYGEN = 3, NEDDF_STAGE_NDC = 4,
+       NEDDF_STAGE_SAMPLE_COARSE = 5, NEDDF_STAGE_SAMPLING = 6, NEDDF_STAGE_COMPOSITE = 7, NEDDF_STAGE_PENALTY = 8,
+       NEDDF_STAGE_RESAMPLE = 9, NEDDF_STAGE_GATHER = 10, NEDDF_STAGE_COUNT = 11 };
 int neddf_set_timing(neddf_ctx *ctx, int enable);
-
 int neddf_get_timings(neddf_ctx *ctx, float *ms, int n);
+int neddf_get_stage_timings(neddf_ctx *ctx, float *ms, int *launches, int n_stages);
+
+/* ---- multi-GPU: rays shard, pixels are gathered ----------------------------
+ * The reference renders on one device; its rays are independent (nerf_render.py:128-188 has no cross-ray term), so
+ * the flat pixel index of a frame (or of several frames) is cut into one contiguous slab per rank and the only
+ * exchange is an all-gather of the rendered pixels over RCCL/xGMI.  One process per GPU, one communicator per ctx.
+ * RCCL is loaded on first use (dlopen "librccl.so.1": in a torch process that is the copy torch already mapped);
+ * a library user that never calls these needs no RCCL.
+ *
+ * Bootstrap: rank 0 calls neddf_comm_unique_id and hands the NEDDF_COMM_ID_BYTES to every rank by any channel the
+ * integrator has (file, socket, MPI, a torch.distributed store); every rank then calls neddf_comm_init -- a blocking
+ * collective over the ranks. */
+#define NEDDF_COMM_ID_BYTES 128
+int neddf_comm_unique_id(neddf_ctx *ctx, void *h_id);
+int neddf_comm_init(neddf_ctx *ctx, int rank, int nranks, const void *h_id);
+/* rank / nranks of the ctx's communicator (0 / 0 without one) and the RCCL version code (e.g. 22606) */
+int neddf_comm_info(neddf_ctx *ctx, int *rank, int *nranks, int *rccl_version);
+int neddf_comm_destroy(neddf_ctx *ctx);
+/* Slab [lo, hi) of range(n_total) that `rank` of `nranks` owns: contiguous, sizes differ by at most one. */
+void neddf_shard_range(int64_t n_total, int rank, int nranks, int64_t *lo, int64_t *hi);
+/* All-gather of the per-rank slabs d_local [hi-lo, channels] (fp32, neddf_shard_range order) into d_all
+ * [n_total, channels] on every rank.  The collective runs on the ctx's own communication stream, ordered after the
+ * work already enqueued on `stream` (the renderer's stream), and returns immediately: the caller keeps rendering the
+ * next view on `stream` while the pixels travel.  d_local and d_all must stay untouched until neddf_comm_wait.
+ * With equal slabs the gather lands directly in d_all; ragged slabs go through a ctx-owned padded staging buffer. */
+int neddf_gather_pixels(neddf_ctx *ctx, const float *d_local, int64_t n_total, int channels, float *d_all, void *stream);
+/* Make `stream` wait (device-side, no host block) for the last neddf_gather_pixels of this ctx. */
+int neddf_comm_wait(neddf_ctx *ctx, void *stream);
+/* Host-side wait with a deadline: 0 when the last gather has completed; on an asynchronous RCCL error NEDDF_ECOMM; after
+ * timeout_ms without completion the communicator is aborted (ncclCommAbort) and NEDDF_ETIMEOUT returned -- a peer died. */
+int neddf_comm_wait_host(neddf_ctx *ctx, int timeout_ms);
 
 /* ---- training step -------------------------------------------
  * The reference trains through torch autograd over its with_grad modules

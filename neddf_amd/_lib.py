@@ -11,13 +11,15 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libneddf_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 FIELD_NEDDF, FIELD_NERF, FIELD_NEUS = 0, 1, 2
 ACT = {"ReLU": 0, "LeakyReLU": 1, "tanhExp": 2}
 DTYPE = {"fp32": 0, "bf16": 1, "f16_split": 2}
 SLOT_COARSE, SLOT_FINE, SLOT_GENERIC = 0, 1, 2
 OUT_MINIMAL, OUT_FULL = 0, 1
+STAGES = ("ddf", "col", "nerf", "raygen", "ndc", "sample_coarse", "sampling", "composite", "penalty", "resample", "gather")
+COMM_ID_BYTES = 128
 UV_TYPES = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.int16: 3}
 PENALTY_KEYS = ("constraints_aux_grad", "constraints_dDdt", "range_distance", "range_aux_grad",
                 "range_color", "constraints_color")     # dict order of neddf.py:260-291
@@ -84,6 +86,15 @@ SYMBOLS = [
     ("neddf_op_linear_grad", C.c_int, [_vp, _vp, _vp, _fp, _fp, _i64, C.c_int, C.c_int, _vp, _vp, _vp]),
     ("neddf_set_timing", C.c_int, [_vp, C.c_int]),
     ("neddf_get_timings", C.c_int, [_vp, _fp, C.c_int]),
+    ("neddf_get_stage_timings", C.c_int, [_vp, _fp, C.POINTER(C.c_int), C.c_int]),
+    ("neddf_comm_unique_id", C.c_int, [_vp, _vp]),
+    ("neddf_comm_init", C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    ("neddf_comm_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("neddf_comm_destroy", C.c_int, [_vp]),
+    ("neddf_shard_range", None, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
+    ("neddf_gather_pixels", C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
+    ("neddf_comm_wait", C.c_int, [_vp, _vp]),
+    ("neddf_comm_wait_host", C.c_int, [_vp, C.c_int]),
     ("neddf_train_workspace_floats", _i64, [_vp, C.c_int, _i64]),
     ("neddf_train_field_forward", C.c_int, [_vp, C.c_int, C.POINTER(_fp), C.POINTER(_fp), C.c_int, _vp, _vp, _vp, _i64, _vp,
                                             _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -150,6 +161,7 @@ class Context:
             raise NeddfError("neddf_create(%d) failed: %s" % (index, self.lib.neddf_last_error(None).decode()))
         self.h = h
         self.slot_owner = {}        # slot -> signature of the field currently loaded
+        self._gather_refs = None
 
     def check(self, rc):
         if rc != 0:
@@ -391,6 +403,51 @@ class Context:
                                                      _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(gs[3]), _ptr(g_density),
                                                      _ptr(g_pc), self.stream()))
         return g_density, g_pc
+
+    def get_stage_timings(self):
+        """{stage: (summed ms, launches)} for every NEDDF_STAGE_* since the last call (drains the same events as get_timings)."""
+        n = len(STAGES)
+        ms, cnt = (C.c_float * n)(), (C.c_int * n)()
+        self.check(self.lib.neddf_get_stage_timings(self.h, ms, cnt, n))
+        return {k: (ms[i], int(cnt[i])) for i, k in enumerate(STAGES)}
+
+    # ------------------------------------------------------------------ multi-GPU (RCCL communicator owned by the library)
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        self.check(self.lib.neddf_comm_unique_id(self.h, buf))
+        return buf.raw
+
+    def comm_init(self, rank, nranks, unique_id):
+        assert len(unique_id) == COMM_ID_BYTES
+        self.check(self.lib.neddf_comm_init(self.h, rank, nranks, C.create_string_buffer(unique_id, COMM_ID_BYTES)))
+
+    def comm_info(self):
+        r, n, v = C.c_int(), C.c_int(), C.c_int()
+        self.check(self.lib.neddf_comm_info(self.h, C.byref(r), C.byref(n), C.byref(v)))
+        return dict(rank=r.value, nranks=n.value, rccl_version=v.value)
+
+    def comm_destroy(self):
+        self.check(self.lib.neddf_comm_destroy(self.h))
+        self._gather_refs = None
+
+    def gather_pixels(self, local, n_total, out=None):
+        """Start the all-gather of this rank's slab [n_rank, C] into out [n_total, C] on the library's communication stream,
+        ordered after the current stream's work; returns `out`.  Nothing may touch local / out until comm_wait()."""
+        require_device(local, "local pixels")
+        local = f32c(local)
+        if out is None:
+            out = torch.empty(n_total, local.shape[1], device=local.device, dtype=torch.float32)
+        self.check(self.lib.neddf_gather_pixels(self.h, _ptr(local), n_total, local.shape[1], _ptr(out), self.stream()))
+        self._gather_refs = (local, out)       # keep both alive (and out of the caching allocator) until the wait
+        return out
+
+    def comm_wait(self):
+        """The current stream waits (on the device) for the last gather."""
+        self.check(self.lib.neddf_comm_wait(self.h, self.stream()))
+        self._gather_refs = None
+
+    def comm_wait_host(self, timeout_ms=60000):
+        self.check(self.lib.neddf_comm_wait_host(self.h, int(timeout_ms)))
 
     def get_timings(self):
         """{'ddf_ms','col_ms','nerf_ms','ddf_launches','col_launches','nerf_launches'} since the last call."""

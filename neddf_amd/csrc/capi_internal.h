@@ -27,7 +27,33 @@ struct Field {
 
 struct EventPair {
     hipEvent_t a, b;
-    int which;
+    int which;                   // NEDDF_STAGE_*
+};
+
+// Multi-GPU state of a context (comm_capi.hip): one RCCL communicator, a communication stream of its own and the event
+// pair that orders it against the caller's compute stream.
+struct CommState {
+    void *comm = nullptr;        // ncclComm_t
+    int rank = 0, nranks = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ready = nullptr;  // recorded on the compute stream: the local slab is complete
+    hipEvent_t done = nullptr;   // recorded on the communication stream: the gathered pixels are complete
+    bool pending = false;
+    DevBuf pad;                  // [nranks * pad_rows * channels] staging for ragged slabs
+};
+
+// Every entry point that launches or allocates runs on the ctx's device and leaves the caller's current device as it
+// found it (a torch process may have another device current).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
 struct neddf_ctx {
@@ -41,7 +67,24 @@ struct neddf_ctx {
     bool timing = false;
     std::vector<EventPair> events;
     std::vector<EventPair> pool;
+    CommState comm;
 };
+
+// hipEvent pair around one stage launch (only while neddf_set_timing is on); `which` = NEDDF_STAGE_*
+static inline void tick(neddf_ctx *ctx, hipStream_t s, int which, bool begin)
+{
+    if (!ctx->timing) return;
+    if (begin) {
+        EventPair e;
+        if (!ctx->pool.empty()) { e = ctx->pool.back(); ctx->pool.pop_back(); }
+        else { (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); }
+        e.which = which;
+        (void)hipEventRecord(e.a, s);
+        ctx->events.push_back(e);
+    } else {
+        (void)hipEventRecord(ctx->events.back().b, s);
+    }
+}
 
 #define HIPCHK(call)                                                                          \
     do {                                                                                      \

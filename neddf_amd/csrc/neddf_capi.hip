@@ -17,7 +17,13 @@ using namespace neddf;
 
 #include "capi_internal.h"
 
+// one stage launch, bracketed by a hipEvent pair while timing is on
+#define STAGE(ctx, stream, which, launch) \
+    do { tick((ctx), (stream), (which), true); launch; tick((ctx), (stream), (which), false); } while (0)
+
 static char g_err[256] = "no context";
+
+void neddf_comm_release(neddf_ctx *ctx);       // comm_capi.hip
 
 // NEDDF_SCHED: bit 1 dynamic tile queue (default on).  The phase-ablation bits of the distance kernel are honoured only by
 // -DNEDDF_ABLATE builds (field_kernels.hip); the shipped library masks them off.
@@ -363,21 +369,6 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
 }
 
 // ---------------------------------------------------------------------------
-static void tick(neddf_ctx *ctx, hipStream_t s, int which, bool begin)
-{
-    if (!ctx->timing) return;
-    if (begin) {
-        EventPair e;
-        if (!ctx->pool.empty()) { e = ctx->pool.back(); ctx->pool.pop_back(); }
-        else { (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); }
-        e.which = which;
-        (void)hipEventRecord(e.a, s);
-        ctx->events.push_back(e);
-    } else {
-        (void)hipEventRecord(ctx->events.back().b, s);
-    }
-}
-
 static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float *dir, const float *var, int64_t N,
                          int out_mode, float *distance, float *density, float *color, float *penalty, float *aux,
                          hipStream_t s)
@@ -402,9 +393,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         a.density = density ? density : (float *)tmp.p;
         a.color = color ? color : (float *)tmp.p + N;
         int64_t tiles = (N + nerf_points_per_tile() - 1) / nerf_points_per_tile();
-        tick(ctx, s, 2, true);
-        launch_nerf(a, (int)(tiles < grid_cap ? tiles : grid_cap), s);
-        tick(ctx, s, 2, false);
+        STAGE(ctx, s, NEDDF_STAGE_NERF, launch_nerf(a, (int)(tiles < grid_cap ? tiles : grid_cap), s));
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -434,9 +423,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         a.sched = (int *)ctx->sched.p;
         a.sched_flags = sched_flags();
         HIPCHK(hipMemsetAsync(a.sched, 0, kSchedInts * sizeof(int), s));
-        tick(ctx, s, 0, true);
-        launch_ddf(a, (int)(tiles < grid_cap_ddf ? tiles : grid_cap_ddf), s);
-        tick(ctx, s, 0, false);
+        STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf(a, (int)(tiles < grid_cap_ddf ? tiles : grid_cap_ddf), s));
         if (color || full) {
             ColArgs c = f.col;
             fill_enc(c.enc, f);
@@ -454,9 +441,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
             c.sched = (int *)ctx->sched.p + kSchedInts;
             c.sched_flags = sched_flags();
             HIPCHK(hipMemsetAsync(c.sched, 0, kSchedInts * sizeof(int), s));
-            tick(ctx, s, 1, true);
-            launch_col(c, (int)(ctiles < grid_cap_col ? ctiles : grid_cap_col), full, s);
-            tick(ctx, s, 1, false);
+            STAGE(ctx, s, NEDDF_STAGE_COL, launch_col(c, (int)(ctiles < grid_cap_col ? ctiles : grid_cap_col), full, s));
         }
     }
     HIPCHK(hipGetLastError());
@@ -482,7 +467,7 @@ int neddf_create(int device, neddf_ctx **out)
     }
     neddf_ctx *ctx = new neddf_ctx();
     ctx->device = device;
-    (void)hipSetDevice(device);
+    DeviceGuard guard_(device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cus = prop.multiProcessorCount;
     if (ctx->cus <= 0) ctx->cus = 256;
@@ -501,8 +486,9 @@ int neddf_create(int device, neddf_ctx **out)
 void neddf_destroy(neddf_ctx *ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard_(ctx->device);
     (void)hipDeviceSynchronize();
+    neddf_comm_release(ctx);
     for (auto &f : ctx->field) if (f.blob.p) (void)hipFree(f.blob.p);
     for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags, &ctx->sched, &ctx->tpack, &ctx->ttmp, &ctx->tamax })
         if (b->p) (void)hipFree(b->p);
@@ -517,7 +503,7 @@ int neddf_set_field(neddf_ctx *ctx, int slot, const neddf_field_desc *desc, cons
 {
     if (!ctx || !desc || !W || !B) return NEDDF_EINVAL;
     if (slot < 0 || slot >= NEDDF_NUM_SLOTS) return fail(ctx, NEDDF_EINVAL, "bad slot");
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard_(ctx->device);
     if (desc->embed_pos_rank < 1 || desc->embed_pos_rank > 10 || desc->embed_dir_rank < 1 || desc->embed_dir_rank > 4)
         return fail(ctx, NEDDF_EUNSUPPORTED, "embed_pos_rank must be in [1,10] and embed_dir_rank in [1,4]");
     if (desc->layer_width != kWidth || (desc->kind != NEDDF_FIELD_NERF && desc->col_layer_width != kWidth))
@@ -563,7 +549,8 @@ int neddf_raygen(neddf_ctx *ctx, const void *uv, int uv_type, int64_t n, const n
 {
     if (!ctx || !uv || !cam || !rd || !ro) return NEDDF_EINVAL;
     if (uv_type < 0 || uv_type > 3) return fail(ctx, NEDDF_EINVAL, "bad uv_type");
-    launch_raygen(uv, uv_type, n, cam_arg(cam), rd, ro, (hipStream_t)stream);
+    DeviceGuard guard_(ctx->device);
+    STAGE(ctx, (hipStream_t)stream, NEDDF_STAGE_RAYGEN, launch_raygen(uv, uv_type, n, cam_arg(cam), rd, ro, (hipStream_t)stream));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -571,7 +558,8 @@ int neddf_raygen(neddf_ctx *ctx, const void *uv, int uv_type, int64_t n, const n
 int neddf_sample_coarse(neddf_ctx *ctx, const float *U, int64_t n, int S1, float near_, float far_, float *dists, void *stream)
 {
     if (!ctx || !U || !dists || S1 < 2) return NEDDF_EINVAL;
-    launch_sample_coarse(U, n, S1, near_, far_, dists, (hipStream_t)stream);
+    DeviceGuard guard_(ctx->device);
+    STAGE(ctx, (hipStream_t)stream, NEDDF_STAGE_SAMPLE_COARSE, launch_sample_coarse(U, n, S1, near_, far_, dists, (hipStream_t)stream));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -581,7 +569,8 @@ int neddf_sampling(neddf_ctx *ctx, const float *rd, const float *ro, const float
 {
     if (!ctx || !rd || !ro || !dists || !pos || !dir || !var) return NEDDF_EINVAL;
     if (radius >= 0.0 && S < 2) return fail(ctx, NEDDF_EINVAL, "cone sampling needs at least 2 samples");
-    launch_sampling(rd, ro, nullptr, dists, n, S, radius, pos, dir, var, (hipStream_t)stream);
+    DeviceGuard guard_(ctx->device);
+    STAGE(ctx, (hipStream_t)stream, NEDDF_STAGE_SAMPLING, launch_sampling(rd, ro, nullptr, dists, n, S, radius, pos, dir, var, (hipStream_t)stream));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -591,7 +580,8 @@ int neddf_sampling_view(neddf_ctx *ctx, const float *rd, const float *ro, const 
 {
     if (!ctx || !rd || !ro || !view || !dists || !pos || !dir || !var) return NEDDF_EINVAL;
     if (radius >= 0.0 && S < 2) return fail(ctx, NEDDF_EINVAL, "cone sampling needs at least 2 samples");
-    launch_sampling(rd, ro, view, dists, n, S, radius, pos, dir, var, (hipStream_t)stream);
+    DeviceGuard guard_(ctx->device);
+    STAGE(ctx, (hipStream_t)stream, NEDDF_STAGE_SAMPLING, launch_sampling(rd, ro, view, dists, n, S, radius, pos, dir, var, (hipStream_t)stream));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -602,7 +592,8 @@ int neddf_rays_to_ndc(neddf_ctx *ctx, const float *rd, const float *ro, int64_t 
     if (!ctx) return NEDDF_EINVAL;
     if (n <= 0) return 0;
     if (!rd || !ro || !nd || !no || width < 1 || height < 1 || !(fx > 0.f) || !(fy > 0.f)) return fail(ctx, NEDDF_EINVAL, "rays_to_ndc: bad argument");
-    launch_ndc(rd, ro, n, (float)width, (float)height, fx, fy, near_plane, nd, no, (hipStream_t)stream);
+    DeviceGuard guard_(ctx->device);
+    STAGE(ctx, (hipStream_t)stream, NEDDF_STAGE_NDC, launch_ndc(rd, ro, n, (float)width, (float)height, fx, fy, near_plane, nd, no, (hipStream_t)stream));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -613,7 +604,7 @@ int neddf_field_forward(neddf_ctx *ctx, int slot, const float *pos, const float 
     if (!ctx) return NEDDF_EINVAL;
     if (N <= 0) return 0;
     if (!pos || !dir || !var) return NEDDF_EINVAL;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard_(ctx->device);
     return field_forward(ctx, slot, pos, dir, var, N, out_mode, distance, density, color, penalty, aux, (hipStream_t)stream);
 }
 
@@ -621,7 +612,8 @@ int neddf_composite(neddf_ctx *ctx, const float *dists, const float *dens, const
                     float *w, float *depth, float *color, float *trans, int *nan_flag, void *stream)
 {
     if (!ctx || !dists || !dens || !col || !depth || !color || !trans || S < 2) return NEDDF_EINVAL;
-    launch_composite(dists, dens, col, n, S, max_dist, w, depth, color, trans, nan_flag, (hipStream_t)stream);
+    DeviceGuard guard_(ctx->device);
+    STAGE(ctx, (hipStream_t)stream, NEDDF_STAGE_COMPOSITE, launch_composite(dists, dens, col, n, S, max_dist, w, depth, color, trans, nan_flag, (hipStream_t)stream));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -629,7 +621,8 @@ int neddf_composite(neddf_ctx *ctx, const float *dists, const float *dens, const
 int neddf_integrate_penalty(neddf_ctx *ctx, const float *dists, const float *pen, int64_t n, int S, float *out, void *stream)
 {
     if (!ctx || !dists || !pen || !out) return NEDDF_EINVAL;
-    launch_integrate_penalty(dists, pen, n, S, out, (hipStream_t)stream);
+    DeviceGuard guard_(ctx->device);
+    STAGE(ctx, (hipStream_t)stream, NEDDF_STAGE_PENALTY, launch_integrate_penalty(dists, pen, n, S, out, (hipStream_t)stream));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -639,7 +632,8 @@ int neddf_importance_resample(neddf_ctx *ctx, const float *dists, float *weights
 {
     if (!ctx || !dists || !weights || !U || !out || n < 2 || nf < 1) return NEDDF_EINVAL;
     if (n + nf > 8192) return fail(ctx, NEDDF_EUNSUPPORTED, "importance_resample: n + n_fine must be <= 8192");
-    launch_resample(dists, weights, U, n_rays, n, nf, cat, out, ids, (int *)ctx->flags.p + 1, (hipStream_t)stream);
+    DeviceGuard guard_(ctx->device);
+    STAGE(ctx, (hipStream_t)stream, NEDDF_STAGE_RESAMPLE, launch_resample(dists, weights, U, n_rays, n, nf, cat, out, ids, (int *)ctx->flags.p + 1, (hipStream_t)stream));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -662,13 +656,13 @@ static int render_pass(neddf_ctx *ctx, int slot, const float *rd, const float *r
                        const neddf_render_params *rp, float *pos, float *dir, float *var, float *dens, float *col, float *pen,
                        float *w_out, float *depth, float *color, float *trans, float *pen_out, int *nan_flag, hipStream_t s)
 {
-    launch_sampling(rd, ro, view, dists, B, S, rp->cone_sampling ? rp->ray_radius : -1.0, pos, dir, var, s);
+    STAGE(ctx, s, NEDDF_STAGE_SAMPLING, launch_sampling(rd, ro, view, dists, B, S, rp->cone_sampling ? rp->ray_radius : -1.0, pos, dir, var, s));
     const bool want_pen = pen_out && ctx->field[slot].d.kind == NEDDF_FIELD_NEDDF;
     int rc = field_forward(ctx, slot, pos, dir, var, B * S, want_pen ? NEDDF_OUT_FULL : NEDDF_OUT_MINIMAL, nullptr, dens, col,
                            want_pen ? pen : nullptr, nullptr, s);
     if (rc) return rc;
-    launch_composite(dists, dens, col, B, S, rp->max_dist, w_out, depth, color, trans, nan_flag, s);
-    if (want_pen) launch_integrate_penalty(dists, pen, B, S, pen_out, s);
+    STAGE(ctx, s, NEDDF_STAGE_COMPOSITE, launch_composite(dists, dens, col, B, S, rp->max_dist, w_out, depth, color, trans, nan_flag, s));
+    if (want_pen) STAGE(ctx, s, NEDDF_STAGE_PENALTY, launch_integrate_penalty(dists, pen, B, S, pen_out, s));
     return 0;
 }
 
@@ -678,7 +672,7 @@ int neddf_render_rays(neddf_ctx *ctx, const void *uv, int uv_type, int64_t B, co
     if (!ctx) return NEDDF_EINVAL;
     if (B <= 0) return 0;           // empty batch: nothing to do (pointers of empty tensors may be NULL)
     if (!uv || !cam || !rp || !Uc || !Uf || !out) return NEDDF_EINVAL;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard_(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     const int Sc1 = rp->sample_coarse + 1, Sf1 = rp->sample_fine + 1, S2 = Sc1 + Sf1;
     if (!ctx->field[NEDDF_SLOT_COARSE].valid || !ctx->field[NEDDF_SLOT_FINE].valid) return fail(ctx, NEDDF_ENOFIELD, "render_rays needs coarse and fine fields");
@@ -703,18 +697,18 @@ int neddf_render_rays(neddf_ctx *ctx, const void *uv, int uv_type, int64_t B, co
     int *flags = (int *)ctx->flags.p;
     int *nan_flag = out->nan_flag ? out->nan_flag : flags;
 
-    launch_raygen(uv, uv_type, B, cam_arg(cam), rd, ro, s);
+    STAGE(ctx, s, NEDDF_STAGE_RAYGEN, launch_raygen(uv, uv_type, B, cam_arg(cam), rd, ro, s));
     const float *view = nullptr;
     if (rp->ndc_rays) {         // positions follow the NDC ray, the field keeps the world-space viewing direction
         float *nd = cv.take(B * 3), *no = cv.take(B * 3);
-        launch_ndc(rd, ro, B, (float)rp->ndc_width, (float)rp->ndc_height, cam->calib[0], cam->calib[1], rp->ndc_near, nd, no, s);
+        STAGE(ctx, s, NEDDF_STAGE_NDC, launch_ndc(rd, ro, B, (float)rp->ndc_width, (float)rp->ndc_height, cam->calib[0], cam->calib[1], rp->ndc_near, nd, no, s));
         view = rd; rd = nd; ro = no;
     }
-    launch_sample_coarse(Uc, B, Sc1, rp->dist_near, rp->dist_far, dc, s);
+    STAGE(ctx, s, NEDDF_STAGE_SAMPLE_COARSE, launch_sample_coarse(Uc, B, Sc1, rp->dist_near, rp->dist_far, dc, s));
     int rc = render_pass(ctx, NEDDF_SLOT_COARSE, rd, ro, view, dc, B, Sc1, rp, pos, dir, var, dens, col, pen, wc, depth_c, color_c,
                          trans_c, out->fields_penalty_coarse, nan_flag, s);
     if (rc) return rc;
-    launch_resample(dc, wc, Uf, B, Sc1, Sf1, 1, df, nullptr, flags + 1, s);
+    STAGE(ctx, s, NEDDF_STAGE_RESAMPLE, launch_resample(dc, wc, Uf, B, Sc1, Sf1, 1, df, nullptr, flags + 1, s));
     rc = render_pass(ctx, NEDDF_SLOT_FINE, rd, ro, view, df, B, S2, rp, pos, dir, var, dens, col, pen, out->weight, depth, color, trans,
                      out->fields_penalty, nan_flag, s);
     if (rc) return rc;
@@ -728,7 +722,7 @@ int neddf_render_rays_single(neddf_ctx *ctx, int slot, const void *uv, int uv_ty
     if (!ctx) return NEDDF_EINVAL;
     if (B <= 0) return 0;
     if (!uv || !cam || !rp || !U || !out || S1 < 2) return NEDDF_EINVAL;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard_(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");
     size_t need = 2 * carve_bytes(B * 3) + carve_bytes(B * S1) + 3 * carve_bytes(B * S1 * 3) + 2 * carve_bytes(B * S1) +
@@ -743,14 +737,14 @@ int neddf_render_rays_single(neddf_ctx *ctx, int slot, const void *uv, int uv_ty
     float *color = out->color ? out->color : cv.take(B * 3);
     float *trans = out->transmittance ? out->transmittance : cv.take(B);
     int *nan_flag = out->nan_flag ? out->nan_flag : (int *)ctx->flags.p;
-    launch_raygen(uv, uv_type, B, cam_arg(cam), rd, ro, s);
+    STAGE(ctx, s, NEDDF_STAGE_RAYGEN, launch_raygen(uv, uv_type, B, cam_arg(cam), rd, ro, s));
     const float *view = nullptr;
     if (rp->ndc_rays) {
         float *nd = cv.take(B * 3), *no = cv.take(B * 3);
-        launch_ndc(rd, ro, B, (float)rp->ndc_width, (float)rp->ndc_height, cam->calib[0], cam->calib[1], rp->ndc_near, nd, no, s);
+        STAGE(ctx, s, NEDDF_STAGE_NDC, launch_ndc(rd, ro, B, (float)rp->ndc_width, (float)rp->ndc_height, cam->calib[0], cam->calib[1], rp->ndc_near, nd, no, s));
         view = rd; rd = nd; ro = no;
     }
-    launch_sample_coarse(U, B, S1, rp->dist_near, rp->dist_far, dc, s);
+    STAGE(ctx, s, NEDDF_STAGE_SAMPLE_COARSE, launch_sample_coarse(U, B, S1, rp->dist_near, rp->dist_far, dc, s));
     int rc = render_pass(ctx, slot, rd, ro, view, dc, B, S1, rp, pos, dir, var, dens, col, pen, out->weight, depth, color, trans,
                          out->fields_penalty, nan_flag, s);
     if (rc) return rc;
@@ -791,7 +785,7 @@ int neddf_op_linear_grad(neddf_ctx *ctx, const float *x, const float *J, const f
     if (!ctx || !x || !J || !W || !y || !G) return NEDDF_EINVAL;
     if (Cin < 1 || Cin > 256 || (Cout != 128 && Cout != 256)) return fail(ctx, NEDDF_EUNSUPPORTED, "op_linear_grad: Cin <= 256, Cout in {128, 256}");
     if (N <= 0) return 0;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard_(ctx->device);
     std::vector<float> blob;
     std::vector<int> km;
     for (int k = 0; k < roundup(Cin, 8); ++k) km.push_back(k < Cin ? k : -1);
@@ -817,20 +811,38 @@ int neddf_set_timing(neddf_ctx *ctx, int enable)
     return 0;
 }
 
-int neddf_get_timings(neddf_ctx *ctx, float *ms, int n)
+static int drain_events(neddf_ctx *ctx, float *ms, int *launches)
 {
-    if (!ctx || !ms || n < 6) return NEDDF_EINVAL;
-    for (int i = 0; i < n; ++i) ms[i] = 0.f;
     for (auto &e : ctx->events) {
         HIPCHK(hipEventSynchronize(e.b));
         float t = 0.f;
         HIPCHK(hipEventElapsedTime(&t, e.a, e.b));
-        ms[e.which] += t;        // [0] distance trunk, [1] colour trunk, [2] NeRF field
-        ms[3 + e.which] += 1.f;  // launch counts
+        ms[e.which] += t;
+        launches[e.which] += 1;
         ctx->pool.push_back(e);
     }
     ctx->events.clear();
     return 0;
+}
+
+int neddf_get_timings(neddf_ctx *ctx, float *ms, int n)
+{
+    if (!ctx || !ms || n < 6) return NEDDF_EINVAL;
+    DeviceGuard guard_(ctx->device);
+    float t[NEDDF_STAGE_COUNT] = { 0 };
+    int c[NEDDF_STAGE_COUNT] = { 0 };
+    for (int i = 0; i < n; ++i) ms[i] = 0.f;
+    if (int rc = drain_events(ctx, t, c)) return rc;
+    for (int k = 0; k < 3; ++k) { ms[k] = t[k]; ms[3 + k] = (float)c[k]; }      // distance trunk, colour trunk, NeRF field
+    return 0;
+}
+
+int neddf_get_stage_timings(neddf_ctx *ctx, float *ms, int *launches, int n_stages)
+{
+    if (!ctx || !ms || !launches || n_stages < NEDDF_STAGE_COUNT) return NEDDF_EINVAL;
+    DeviceGuard guard_(ctx->device);
+    for (int i = 0; i < n_stages; ++i) { ms[i] = 0.f; launches[i] = 0; }
+    return drain_events(ctx, ms, launches);
 }
 
 }  // extern "C"

@@ -438,7 +438,7 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     if (!ctx) return NEDDF_EINVAL;
     if (N <= 0) return 0;
     if (!W || !B || !pos || !dir || !var || !ws) return fail(ctx, NEDDF_EINVAL, "null argument");
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard_(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     if (slot >= 0 && slot < NEDDF_NUM_SLOTS && ctx->field[slot].valid && ctx->field[slot].d.kind == NEDDF_FIELD_NERF)
         return nerf_forward(ctx, slot, W, B, n_tensors, pos, dir, var, N, ws, density, color, s);
@@ -515,7 +515,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     if (!ctx) return NEDDF_EINVAL;
     if (N <= 0) return 0;
     if (!W || !B || !ws_ || !gW || !gB) return fail(ctx, NEDDF_EINVAL, "null argument");
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard_(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     float *ws = const_cast<float *>(ws_);
     if (slot >= 0 && slot < NEDDF_NUM_SLOTS && ctx->field[slot].valid && ctx->field[slot].d.kind == NEDDF_FIELD_NERF)
@@ -612,7 +612,7 @@ int neddf_composite_backward(neddf_ctx *ctx, const float *dists, const float *de
     if (!ctx) return NEDDF_EINVAL;
     if (n_rays <= 0) return 0;
     if (!dists || !density || !color || !g_density || !g_color_out || S < 2) return fail(ctx, NEDDF_EINVAL, "bad argument");
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard_(ctx->device);
     launch_composite_backward(dists, density, color, n_rays, S, max_dist, g_weight, g_depth, g_color, g_trans, g_density, g_color_out,
                               (hipStream_t)stream);
     HIPCHK(hipGetLastError());

@@ -5,7 +5,9 @@ term), so the flat pixel index is cut into contiguous slabs, one per rank, the
 packed weights (2.6 MB) are replicated, and the only exchange is one gather of
 the rendered pixels: colour(3) + depth(1) + transmittance(1) = 20 B/ray, packed
 into ONE [n,5] tensor so a view costs one RCCL all-gather (12.8 MB at 800x800)
-over xGMI.  No all-reduce anywhere.  The reference has no multi-GPU code; this
+over xGMI, issued by the HIP library itself (neddf_gather_pixels: its own
+communicator, its own stream -- the pixels of view i travel while view i+1
+renders).  No all-reduce anywhere.  The reference has no multi-GPU code; this
 module is new.
 
 Training (also new: the reference trains on one device) is data-parallel over
@@ -46,31 +48,79 @@ def unpack_pixels(packed: Tensor, keys: Iterable[str]) -> Dict[str, Tensor]:
     return out
 
 
-def gather_pixels(local: Tensor, n_total: int, group=None, force_collective: bool = False) -> Tensor:
+def native_comm(ctx, group=None):
+    """Make sure `ctx` (the HIP library's context of this rank's device) owns an RCCL communicator spanning `group`:
+    rank 0 creates the unique id (neddf_comm_unique_id), torch.distributed only carries its 128 bytes to the other
+    ranks (bootstrap), every rank joins (neddf_comm_init).  Returns ctx.comm_info()."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    info = ctx.comm_info()
+    if info["nranks"] == world and info["rank"] == rank:
+        return info
+    if info["nranks"]:
+        ctx.comm_destroy()
+    # the id travels as a byte tensor: on the device for an RCCL process group, on the host for gloo
+    on_device = "nccl" in str(dist.get_backend(group))
+    box = torch.zeros(128, dtype=torch.uint8, device=ctx.device if on_device else "cpu")
+    if rank == 0:
+        box.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    ctx.comm_init(rank, world, bytes(box.cpu().numpy().tobytes()))
+    return ctx.comm_info()
+
+
+class PixelGather:
+    """Handle of an all-gather in flight on the library's communication stream (gather_pixels(..., wait=False)).
+    .wait() makes the current stream wait for it and returns the [n_total, C] tensor."""
+
+    def __init__(self, ctx, out: Tensor) -> None:
+        self.ctx, self.out = ctx, out
+
+    def wait(self) -> Tensor:
+        if self.ctx is not None:
+            self.ctx.comm_wait()
+            self.ctx = None
+        return self.out
+
+
+def gather_pixels(local: Tensor, n_total: int, group=None, force_collective: bool = False, wait: bool = True, out: Tensor = None):
     """All-gather per-rank slabs [n_rank, C] (shard_range order) into [n_total, C] on every rank.
-    force_collective runs the collective even for a single rank (used to exercise the RCCL path on one GPU)."""
+
+    Device tensors go through the HIP library's own RCCL communicator (neddf_gather_pixels): the collective runs on a
+    communication stream ordered after the current stream, so with wait=False the caller can keep rendering the next
+    view while the pixels travel and collect them later (returns a PixelGather).  Host tensors (the gloo tests) use
+    torch.distributed.  force_collective runs the collective even for a single rank."""
     world = dist.get_world_size(group)
     if world == 1 and not force_collective:
-        return local
+        return local if wait else PixelGather(None, local)
+    if local.is_cuda:
+        from ._lib import Context
+        ctx = Context.get(local.device)
+        native_comm(ctx, group)
+        if ctx._gather_refs is not None:       # one gather in flight per context: its buffers are released by the wait
+            ctx.comm_wait()
+        res = ctx.gather_pixels(local, n_total, out)
+        handle = PixelGather(ctx, res)
+        return handle.wait() if wait else handle
     sizes = [shard_range(n_total, r, world) for r in range(world)]
     pad = max(hi - lo for lo, hi in sizes)
     buf = local
     if local.shape[0] < pad:
         buf = torch.cat([local, local.new_zeros(pad - local.shape[0], local.shape[1])])
-    out = local.new_empty(world * pad, local.shape[1])
-    dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
-    if all(hi - lo == pad for lo, hi in sizes):
-        return out
-    return torch.cat([out[r * pad:r * pad + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
+    full = local.new_empty(world * pad, local.shape[1])
+    dist.all_gather_into_tensor(full, buf.contiguous(), group=group)
+    if not all(hi - lo == pad for lo, hi in sizes):
+        full = torch.cat([full[r * pad:r * pad + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
+    return full if wait else PixelGather(None, full)
 
 
 def render_image_sharded(render, width: int, height: int, camera, target_types: Iterable[str], downsampling: int = 1,
                          chunk: int = 512, group=None) -> Dict[str, Tensor]:
     """NeRFRender.render_image with the pixel range split over the ranks of
     `group`; every rank returns the full [h, w, C] images.  With the default
-    "torch_cpu" RNG every rank must hold the same torch seed (the uniforms are
-    drawn for the whole frame and sliced), which makes the image independent of
-    the world size."""
+    "torch_cpu" RNG every rank must hold the same torch seed: each rank jumps the
+    generator to its slab's position in the reference's draw order (rng.py) and
+    draws only its own uniforms, which makes the image independent of the world
+    size and the host cost proportional to the slab."""
     keys = list(target_types)
     w, h = width // downsampling, height // downsampling
     n = w * h

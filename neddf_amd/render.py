@@ -15,6 +15,7 @@ from ._lib import SLOT_COARSE, SLOT_FINE, Context, NeddfError, RenderParams
 from .camera import Camera
 from .config import instantiate
 from .network import BaseNeuralField, NeDDF
+from .rng import skip_uniforms
 
 RenderTarget = str          # Literal["color", "depth", "transmittance"]
 SamplingType = str          # Literal["point", "cone"]
@@ -104,8 +105,8 @@ class NeRFRender(BaseNeuralRender):
         return ctx
 
     def _rand(self, rows: int, cols: int, device) -> Tensor:
-        if self.rng == "torch_cpu":
-            return torch.rand(rows, cols).to(device)
+        if self.rng == "torch_cpu":     # page-locked, so the upload overlaps the draw of the next batch
+            return torch.rand(rows, cols, pin_memory=torch.device(device).type == "cuda").to(device, non_blocking=True)
         if self.rng == "device":
             return torch.rand(rows, cols, device=device)
         raise ValueError("rng must be 'torch_cpu' or 'device'")
@@ -138,7 +139,7 @@ class NeRFRender(BaseNeuralRender):
         return out
 
     # -------------------------------------------------------------- render_rays
-    def _render(self, ctx: Context, uv: Tensor, camera: Camera, U_c: Tensor, U_f: Tensor, full: bool) -> Dict[str, Tensor]:
+    def _render(self, ctx: Context, uv: Tensor, camera: Camera, U_c: Tensor, U_f: Tensor, full: bool, cam_desc=None) -> Dict[str, Tensor]:
         B = uv.shape[0]
         dev = uv.device
         S2 = self.sample_coarse + self.sample_fine + 2
@@ -153,7 +154,7 @@ class NeRFRender(BaseNeuralRender):
             if self._has_penalty():
                 o.update(fields_penalty=buf(B), fields_penalty_coarse=buf(B))
         flag = torch.zeros(1, device=dev, dtype=torch.int32)
-        ctx.render_rays(uv, camera.descriptor(), self._params(), U_c, U_f, dict(o, nan_flag=flag))
+        ctx.render_rays(uv, camera.descriptor() if cam_desc is None else cam_desc, self._params(), U_c, U_f, dict(o, nan_flag=flag))
         o["_nan"] = flag
         return o
 
@@ -221,8 +222,9 @@ class NeRFRender(BaseNeuralRender):
         batches of `rays_per_call` regardless of `chunk` (rays are independent).
         pixel_range=(lo, hi) (not in the reference) renders only that slab of the
         row-major pixel index and returns flat [hi-lo, C] tensors -- the unit of
-        multi-GPU ray sharding (neddf_amd/parallel.py); the uniforms are still
-        drawn for the whole frame so the image does not depend on the sharding."""
+        multi-GPU ray sharding (neddf_amd/parallel.py); the slab's uniforms are the
+        ones the whole-frame draw would have given it (generator jump-ahead, rng.py),
+        so the image does not depend on the sharding."""
         target_types = list(target_types)
         with torch.no_grad():
             dev = camera.device
@@ -238,8 +240,10 @@ class NeRFRender(BaseNeuralRender):
             flags = []
             lo, hi = (0, n) if pixel_range is None else pixel_range
 
+            cam_desc = camera.descriptor()          # three device -> host reads: once per image, not per batch
+
             def launch(below, above, U_c, U_f):
-                o = self._render(ctx, uv[below:above], camera, U_c, U_f, full=False)
+                o = self._render(ctx, uv[below:above], camera, U_c, U_f, full=False, cam_desc=cam_desc)
                 flags.append(o["_nan"])
                 for k in target_types:
                     parts[k].append(o[k])
@@ -247,20 +251,26 @@ class NeRFRender(BaseNeuralRender):
             if self.rng == "torch_cpu":
                 # Draw chunk by chunk in the reference's order, but hand rays_per_call rays at a time to the GPU:
                 # launches are asynchronous, so the host draws the next batch while the device renders this one.
-                uc, uf, start, count = [], [], 0, 0
-                for below in range(0, n, chunk):
+                # A slab (pixel_range) starts its draws where the reference's stream would be at its first chunk:
+                # the generator JUMPS there (rng.py, milliseconds) instead of drawing and discarding, so the host
+                # cost of a rank shrinks with the slab; after the slab it jumps to where the whole frame would have
+                # left it, i.e. every rank ends in the reference's generator state.
+                per_ray = self.sample_coarse + 1 + self.sample_fine + 1
+                first = (lo // chunk) * chunk if hi > lo else n      # chunks before the slab are all full
+                skip_uniforms(first * per_ray)
+                uc, uf, start, count, below = [], [], first, 0, first
+                while below < min(n, hi):
                     b = min(n, below + chunk) - below
-                    c_, f_ = torch.rand(b, self.sample_coarse + 1), torch.rand(b, self.sample_fine + 1)
-                    if below + b <= lo or below >= hi:
-                        start = below + b           # outside the requested slab: the draws only advance the generator
-                        continue
-                    uc.append(c_); uf.append(f_); count += b
-                    if count >= self.rays_per_call or below + b >= min(n, hi):
+                    uc.append(torch.rand(b, self.sample_coarse + 1)); uf.append(torch.rand(b, self.sample_fine + 1))
+                    count += b
+                    below += b
+                    if count >= self.rays_per_call or below >= min(n, hi):
                         a0, a1 = max(start, lo), min(start + count, hi)
                         U_c = torch.cat(uc)[a0 - start:a1 - start].to(dev, non_blocking=True)
                         U_f = torch.cat(uf)[a0 - start:a1 - start].to(dev, non_blocking=True)
                         launch(a0, a1, U_c, U_f)
                         uc, uf, start, count = [], [], start + count, 0
+                skip_uniforms((n - below) * per_ray)
             else:
                 for below in range(lo, hi, self.rays_per_call):
                     above = min(hi, below + self.rays_per_call)
@@ -289,15 +299,16 @@ class NeRFRender(BaseNeuralRender):
             uv = torch.stack([idx % width, idx // width], 1)
             n = hi - lo
             ctx = self._ctx(dev)
-            if U is None:
-                U = self._rand(n, samples, dev)
             out = dict(color=torch.empty(n, 3, device=dev), depth=torch.empty(n, device=dev),
                        transmittance=torch.empty(n, device=dev))
             flag = torch.zeros(1, device=dev, dtype=torch.int32)
+            cam_desc = camera.descriptor()
             for below in range(0, n, self.rays_per_call):
                 above = min(n, below + self.rays_per_call)
                 o = {k: v[below:above] for k, v in out.items()}
-                ctx.render_rays(uv[below:above], camera.descriptor(), self._params(), U[below:above], None,
+                # without U the uniforms are drawn per batch: in "torch_cpu" mode the host draws batch k+1 while batch k renders
+                Ub = U[below:above] if U is not None else self._rand(above - below, samples, dev)
+                ctx.render_rays(uv[below:above], cam_desc, self._params(), Ub, None,
                                 dict(o, nan_flag=flag), single_slot=SLOT_FINE)
             out["_nan"] = flag
         return out

@@ -769,6 +769,26 @@ def gen_grids(render):
     save("bunny_grids.npz", **arrs)
 
 
+def gen_config_digests():
+    """Digest of the VALUES of every file under the reference's config/ (canonical JSON of the parsed YAML), so that the
+    shipped config/*.yaml can be checked value for value without the reference tree.  The one deliberate difference is
+    recorded as an exclusion: trainer/test.yaml runs on "cpu" in the reference, this build has no CPU compute path."""
+    import hashlib
+    out = {}
+    root = os.path.join(REF, "config")
+    for d, _, files in os.walk(root):
+        for f in sorted(files):
+            if not f.endswith(".yaml"):
+                continue
+            rel = os.path.relpath(os.path.join(d, f), root)
+            val = yaml.safe_load(open(os.path.join(d, f)))
+            if rel == "trainer/test.yaml":
+                val.pop("device")
+            out[rel] = hashlib.sha256(json.dumps(val, sort_keys=True).encode()).hexdigest()
+    json.dump(out, open(os.path.join(HERE, "config_digests.json"), "w"), indent=1, sort_keys=True)
+    print("wrote config_digests.json (%d files)" % len(out))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train_nerf":
         gen_train_nerf()
@@ -782,6 +802,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train_neus":
         gen_train_neus()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "configs":
+        gen_config_digests()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dataset":
         gen_dataset()
         sys.exit(0)
@@ -791,6 +814,7 @@ if __name__ == "__main__":
         sys.exit(0)
     gen_grids(r)
     gen_dataset()
+    gen_config_digests()
     gen_ops()
     gen_fields()
     gen_render_edges(r)

@@ -1,0 +1,160 @@
+"""Multi-GPU path (BASELINE.json configs[3]) as far as the test box allows.
+
+One MI355X is enough for: the library's RCCL communicator with a forced single rank (neddf_comm_init /
+neddf_gather_pixels / waits / stage timing), and the REAL renderer sharded over several processes -- on a box with
+fewer devices than ranks the processes share cuda:0 and the slabs travel through gloo, because RCCL refuses two ranks on
+one device; with >= 2 devices the same worker uses RCCL end to end (render_image_sharded -> neddf_gather_pixels).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from conftest import ROOT, assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+_SHARD_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+root, port, rank, world, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from conftest import BUNNY_CFG, golden
+import neddf_amd
+from neddf_amd.parallel import gather_pixels, pack_pixels, render_image_sharded, shard_range, unpack_pixels
+n_dev = torch.cuda.device_count()
+rccl = n_dev >= world                               # one device per rank: RCCL end to end
+dev = torch.device("cuda", rank if rccl else 0)
+torch.cuda.set_device(dev)
+if rccl:
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world, device_id=dev)
+else:
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
+g = golden("bunny_image_small.npz")
+wts = golden("bunny_weights.npz")
+r = neddf_amd.NeRFRender(dict(BUNNY_CFG, _target_="neddf.network.NeDDF"), sample_coarse=64, sample_fine=128, dist_near=2.0,
+                         dist_far=6.0, max_dist=6.0, use_coarse_network=False, sampling_type="cone")
+r.network_fine.load_state_dict({k: torch.from_numpy(wts[k]) for k in wts.files})
+r.to(dev); r.set_iter(-1)
+cam = neddf_amd.Camera(neddf_amd.PinholeCalib(g["calib"].astype(np.float64)), None).to(dev)
+cam.R, cam.T = torch.from_numpy(g["R"]).to(dev), torch.from_numpy(g["T"]).to(dev)
+w, h, chunk = int(g["width"]), int(g["height"]), int(g["chunk"])
+keys = ["color", "depth", "transmittance"]
+torch.manual_seed(int(g["seed"]))                  # every rank holds the reference's seed; the slab jumps into the stream
+if rccl:
+    img = render_image_sharded(r, w, h, cam, keys, 1, chunk)
+    info = neddf_amd.Context.get(dev).comm_info()
+    assert info["nranks"] == world and info["rank"] == rank and info["rccl_version"] > 0, info
+else:
+    lo, hi = shard_range(w * h, rank, world)
+    parts = r.render_image(w, h, cam, keys, 1, chunk, pixel_range=(lo, hi))
+    full = gather_pixels(pack_pixels(parts, keys).cpu(), w * h)
+    img = {k: v.reshape(h, w, -1) for k, v in unpack_pixels(full, keys).items()}
+end = torch.rand(4)                                # generator position after the frame
+np.savez(out_path + ".%d.npz" % rank, end=end.numpy(), rccl=np.int32(rccl), **{k: v.cpu().numpy() for k, v in img.items()})
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok", "rccl" if rccl else "gloo-shared-gpu")
+'''
+
+
+def _run_world(tmp_path, world):
+    script = tmp_path / "shard_worker.py"
+    script.write_text(_SHARD_WORKER)
+    port = str(29700 + (os.getpid() * 3 + world) % 1500)
+    out = str(tmp_path / ("img_w%d" % world))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(world), out], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, env=env) for r in range(world)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, logs):
+        assert p.returncode == 0, o
+    return [np.load(out + ".%d.npz" % r) for r in range(world)]
+
+
+def test_sharded_render_is_independent_of_world_size(tmp_path):
+    """render_image's parity mode under ray sharding: for world sizes 1, 2 and 3 every rank ends with the SAME 12x10
+    frame -- bit-identical across world sizes -- which matches the reference's render of that frame and seed
+    (tests/golden/bunny_image_small.npz; chunk 50, so slabs cut through chunks), and every rank leaves the CPU generator
+    where the reference's whole-frame draw leaves it."""
+    g = golden("bunny_image_small.npz")
+    frames = {}
+    for world in (1, 2, 3):
+        res = _run_world(tmp_path, world)
+        for r_, d in enumerate(res):
+            for k in ("color", "depth", "transmittance"):
+                assert np.array_equal(d[k], res[0][k]), (world, r_, k)         # every rank holds the same gathered frame
+            assert np.array_equal(d["end"], res[0]["end"])
+        frames[world] = res[0]
+    for k in ("color", "depth", "transmittance"):
+        assert_close(frames[1][k], g[k], 1e-4, 1e-5, k + " vs reference")
+        for world in (2, 3):
+            assert np.array_equal(frames[world][k], frames[1][k]), (world, k)   # sharding changes nothing, bit for bit
+    for world in (2, 3):
+        assert np.array_equal(frames[world]["end"], frames[1]["end"])
+
+
+def test_library_communicator_single_rank():
+    """neddf_comm_* / neddf_gather_pixels on a 1-rank RCCL communicator: bootstrap, the all-gather on the library's
+    communication stream (equal and ragged shapes are the same thing with one rank; both buffer routes are driven by
+    n_total), device-side and host-side waits, error codes, the gather's entry in the stage timings."""
+    from neddf_amd import Context
+    from neddf_amd._lib import NeddfError
+    dev = torch.device("cuda:0")
+    ctx = Context.get(dev)
+    if ctx.comm_info()["nranks"]:
+        ctx.comm_destroy()
+    with pytest.raises(NeddfError, match="no communicator"):
+        ctx.gather_pixels(torch.zeros(4, 5, device=dev), 4)
+    uid = ctx.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    with pytest.raises(NeddfError, match="rank must be"):
+        ctx.comm_init(1, 1, uid)
+    ctx.comm_init(0, 1, uid)
+    with pytest.raises(NeddfError, match="already has a communicator"):
+        ctx.comm_init(0, 1, uid)
+    info = ctx.comm_info()
+    assert info["rank"] == 0 and info["nranks"] == 1 and info["rccl_version"] >= 20000, info
+    ctx.set_timing(True)
+    ctx.get_stage_timings()
+    side = torch.cuda.Stream(device=dev)
+    for n in (640000, 12345):
+        with torch.cuda.stream(side):               # the gather must order itself after the producer on ITS stream
+            local = torch.rand(n, 5, device=dev)
+            local.mul_(2.0)
+            out = ctx.gather_pixels(local, n)
+            ctx.comm_wait()
+            got = out.clone()
+        side.synchronize()
+        assert torch.equal(got, local)
+        ctx.gather_pixels(local, n, out)
+        ctx.comm_wait_host(20000)
+        assert torch.equal(out, local)
+    st = ctx.get_stage_timings()
+    ctx.set_timing(False)
+    assert st["gather"][1] == 4 and st["gather"][0] > 0.0, st
+    ctx.comm_destroy()
+    assert ctx.comm_info()["nranks"] == 0
+
+
+def test_bench_self_launch_two_ranks_shared_gpu():
+    """`python bench.py --gpus 2` with no launcher must start two ranks itself and print ONE JSON line with n_gpus = 2 and
+    the communicator size in config.comm.  On a box with one device the two ranks share it (NEDDF_BENCH_SHARE_GPU=1: gloo
+    staging instead of RCCL, marked as not-a-measurement); with two devices this is the real configs[3] path."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    if torch.cuda.device_count() < 2:
+        env["NEDDF_BENCH_SHARE_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["comm"]["world_size"] == 2
+    assert line["config"]["comm"]["torch_distributed_world_size"] == 2
+    assert "configs[3]" in line["config"]["workload"] and line["value"] > 0 and line["psnr_vs_oracle_db"] > 80
+    if torch.cuda.device_count() >= 2:
+        assert line["config"]["comm"]["rccl_comm_ranks"] == 2

@@ -178,13 +178,54 @@ _WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 from neddf_amd.parallel import average_gradients, gather_pixels, pack_pixels, shard_range, unpack_pixels, render_image_sharded
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+world = int(sys.argv[4])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=world)
 rank = dist.get_rank()
 n = 12 * 10 + 1                                   # odd: slabs of different length
 full = torch.arange(n * 5, dtype=torch.float32).reshape(n, 5)
-lo, hi = shard_range(n, rank, 2)
+lo, hi = shard_range(n, rank, world)
 out = gather_pixels(full[lo:hi].clone(), n)
 assert torch.equal(out, full), "gather mismatch"
+h = gather_pixels(full[lo:hi].clone(), n, wait=False)
+assert torch.equal(h.wait(), full)
+
+# parity-mode RNG under sharding: the REAL NeRFRender.render_image (device work stubbed out) must hand every rank exactly
+# the uniforms the reference's whole-frame, chunk-by-chunk draw gives its slab -- by jumping the generator, not by drawing
+from neddf_amd.render import NeRFRender
+class Stub(NeRFRender):
+    def __init__(self):
+        torch.nn.Module.__init__(self)
+        self.sample_coarse, self.sample_fine, self.rng, self.rays_per_call = 64, 128, "torch_cpu", 37
+        self.network_coarse = self.network_fine = torch.nn.Linear(1, 1)
+        self.drawn = 0
+    def _ctx(self, dev):
+        return None
+    def _render(self, ctx, uv, camera, U_c, U_f, full, cam_desc=None):
+        self.drawn += U_c.numel() + U_f.numel()
+        return {"color": torch.stack([U_c[:, 0], U_c[:, -1], U_f[:, 7]], 1), "depth": U_f[:, -1].clone(),
+                "_nan": torch.zeros(1, dtype=torch.int32)}
+class Cam:
+    device = torch.device("cpu")
+    def descriptor(self):
+        return None
+W, H, CHUNK = 12, 10, 50                           # the geometry of tests/golden/bunny_image_small.npz
+torch.manual_seed(0)
+uc, uf = [], []
+for b0 in range(0, W * H, CHUNK):                  # nerf_render.py:237-244 + :137 + base_neural_render.py:75
+    b = min(W * H, b0 + CHUNK) - b0
+    uc.append(torch.rand(b, 65)); uf.append(torch.rand(b, 129))
+uc, uf = torch.cat(uc), torch.cat(uf)
+end_state = torch.get_rng_state()
+stub = Stub()
+torch.manual_seed(0)
+img = render_image_sharded(stub, W, H, Cam(), ["color", "depth"], 1, CHUNK)
+assert torch.equal(img["color"].reshape(-1, 3), torch.stack([uc[:, 0], uc[:, -1], uf[:, 7]], 1)), "slab uniforms differ from the reference order"
+assert torch.equal(img["depth"].reshape(-1), uf[:, -1])
+assert torch.equal(torch.get_rng_state(), end_state), "generator must end where the whole-frame draw ends"
+lo, hi = shard_range(W * H, rank, world)
+first = (lo // CHUNK) * CHUNK
+chunks_touched = range(first, min(W * H, ((hi + CHUNK - 1) // CHUNK) * CHUNK), CHUNK)
+assert stub.drawn == (hi - lo) * 194, (stub.drawn, hi - lo)     # only the slab's rows reach the device
 
 class FakeRender:                                  # the HIP renderer replaced by a pure function of the pixel index
     def render_image(self, width, height, camera, keys, downsampling, chunk, pixel_range=None):
@@ -199,23 +240,24 @@ assert torch.equal(img["color"].reshape(-1, 3)[:, 1], idx * 2) and torch.equal(i
 torch.manual_seed(0)
 ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2))]
 ps[0].grad = torch.full((3, 4), float(rank + 1))
-ps[1].grad = torch.arange(5, dtype=torch.float32) * (1 if rank == 0 else -1)
+ps[1].grad = torch.arange(5, dtype=torch.float32) * (rank - (world - 1) / 2)
 if rank == 0:
     ps[2].grad = torch.ones(2, 2)
 average_gradients(ps)
-assert torch.equal(ps[0].grad, torch.full((3, 4), 1.5)) and torch.equal(ps[1].grad, torch.zeros(5))
-assert torch.equal(ps[2].grad, torch.full((2, 2), 0.5))
+assert torch.allclose(ps[0].grad, torch.full((3, 4), (world + 1) / 2)) and torch.allclose(ps[1].grad, torch.zeros(5), atol=1e-6)
+assert torch.allclose(ps[2].grad, torch.full((2, 2), 1.0 / world))
 dist.barrier()
 print("rank", rank, "ok")
 '''
 
 
-def test_sharded_gather_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gather_two_ranks_gloo(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    port = str(29500 + os.getpid() % 2000)
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(2)]
+    port = str(29500 + (os.getpid() * 7 + world) % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(world)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
@@ -326,12 +368,15 @@ def test_render_image_rng_order_and_batching():
         def _ctx(self, dev):
             return None
 
-        def _render(self, ctx, uv, camera, U_c, U_f, full):
+        def _render(self, ctx, uv, camera, U_c, U_f, full, cam_desc=None):
             assert uv.shape[0] == U_c.shape[0] == U_f.shape[0]
             return {"color": torch.cat([U_c[:, :1], U_f[:, :1], uv[:, :1].float()], 1), "_nan": torch.zeros(1, dtype=torch.int32)}
 
     class Cam:
         device = torch.device("cpu")
+
+        def descriptor(self):
+            return None
 
     def reference_draws(n, chunk):
         uc, uf = [], []
@@ -347,12 +392,48 @@ def test_render_image_rng_order_and_batching():
                 r.rays_per_call = rpc
                 torch.manual_seed(1)
                 a, b = reference_draws(20, chunk)
+                after = torch.rand(3)
                 torch.manual_seed(1)
                 img = r.render_image(5, 4, Cam(), ["color"], 1, chunk, pixel_range=pr)["color"].reshape(-1, 3)
+                # a slab jumps the generator over the chunks it does not render: it still ends where the whole frame ends
+                assert torch.equal(torch.rand(3), after), (rpc, chunk, pr)
                 lo, hi = pr if pr else (0, 20)
                 assert torch.equal(img[:, 0], a[lo:hi]) and torch.equal(img[:, 1], b[lo:hi]), (rpc, chunk, pr)
                 assert torch.equal(img[:, 2], (torch.arange(20) % 5).float()[lo:hi])
     assert r.render_image(5, 4, Cam(), ["color"], 1, 6)["color"].shape == (4, 5, 3)
+
+
+def test_generator_jump_ahead_matches_torch():
+    """neddf_amd/rng.py: advancing torch's CPU generator (MT19937) by n outputs with the polynomial jump gives the state
+    -- and therefore the uniforms -- that drawing and discarding torch.rand(n) gives, across block boundaries, from a
+    freshly seeded generator, and over distances of a whole 800x800 frame; a [rows, cols] torch.rand is the serial stream."""
+    from neddf_amd import rng
+    assert rng._char_poly().bit_length() - 1 == 19937
+    for seed, warm, n in ((7, 3, 1), (7, 3, 620), (7, 3, 621), (7, 3, 624), (7, 3, 625), (7, 0, 624), (7, 0, 1249), (3, 50, 100000),
+                          (11, 0, 777777), (5, 9, 12345678)):
+        torch.manual_seed(seed)
+        if warm:
+            torch.rand(warm)
+        jumped = rng.advance_state(torch.get_rng_state(), n)
+        torch.rand(n)
+        want = torch.get_rng_state()
+        assert torch.equal(jumped[8:24 + 624 * 8], want[8:24 + 624 * 8]), (seed, warm, n)     # left, next, the 624 words
+        a = torch.rand(7)
+        torch.set_rng_state(jumped)
+        assert torch.equal(torch.rand(7), a)
+    # distance of a full 800x800 x (65 + 129) frame, checked through the additivity of jumps (drawing 124 M floats is slow)
+    torch.manual_seed(2)
+    st = torch.get_rng_state()
+    total = 640000 * 194
+    one = rng.advance_state(st, total)
+    two = rng.advance_state(rng.advance_state(st, 123456789), total - 123456789)
+    assert torch.equal(one, two)
+    # a 2-D torch.rand consumes the stream row-major, one output per element
+    torch.manual_seed(4)
+    big = torch.rand(3000, 65)
+    torch.manual_seed(4)
+    rng.skip_uniforms(2000 * 65)
+    assert torch.equal(torch.rand(1000, 65), big[2000:])
 
 
 # ------------------------------------------------------------------ training-side host logic
@@ -409,6 +490,22 @@ def test_config_groups_compose_and_resolve(tmp_path):
         mod, name = t.rsplit(".", 1)
         cls = getattr(importlib.import_module(mod), name)
         assert cls.__module__.startswith("neddf_amd."), t
+
+
+def test_shipped_configs_equal_reference_values():
+    """Every config/*.yaml that exists in the reference carries the reference's values (digests of the parsed YAML,
+    tests/golden/gen_goldens.py::gen_config_digests); files without a reference counterpart are extensions."""
+    import hashlib
+    import json
+    import yaml
+    from neddf_amd.scripts.run import CONFIG_DIR
+    want = json.load(open(os.path.join(GOLDEN, "config_digests.json")))
+    assert len(want) >= 10
+    for rel, digest in want.items():
+        val = yaml.safe_load(open(CONFIG_DIR / rel))
+        if rel == "trainer/test.yaml":
+            assert val.pop("device") == "cuda:0"        # the reference's smoke configuration runs on "cpu"
+        assert hashlib.sha256(json.dumps(val, sort_keys=True).encode()).hexdigest() == digest, rel
 
 
 def test_scalar_log_rows(tmp_path, monkeypatch):
@@ -499,7 +596,15 @@ def test_capi_rejects_null_context_without_touching_a_device():
     import ctypes as C
     from neddf_amd import _lib
     lib = _lib.load()
-    skip = {"neddf_abi_version", "neddf_create", "neddf_destroy", "neddf_last_error", "neddf_device_cus"}
+    skip = {"neddf_abi_version", "neddf_create", "neddf_destroy", "neddf_last_error", "neddf_device_cus",
+            "neddf_shard_range"}       # pure arithmetic, no context
+    lo, hi = C.c_int64(), C.c_int64()
+    spans = []
+    for r in range(3):
+        lib.neddf_shard_range(10, r, 3, C.byref(lo), C.byref(hi))
+        spans.append((lo.value, hi.value))
+    from neddf_amd.parallel import shard_range
+    assert spans == [(0, 4), (4, 7), (7, 10)] == [shard_range(10, r, 3) for r in range(3)]      # library and host agree
     for name, res, args in _lib.SYMBOLS:
         if name in skip:
             continue
