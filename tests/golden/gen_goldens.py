@@ -789,6 +789,31 @@ def gen_config_digests():
     print("wrote config_digests.json (%d files)" % len(out))
 
 
+def gen_fp64():
+    """The reference field evaluated in DOUBLE precision (torch default dtype float64: same code, same checkpoint, the
+    stage-golden sample points) -- the yardstick for fp32 noise: density = (1 - |grad D, aux|) / D amplifies rounding, and
+    the reference's own fp32 result differs from this by ~1e-4 abs on a range of +-40."""
+    torch.set_default_dtype(torch.float64)
+    cfg = yaml.safe_load(open(os.path.join(REF, "pretrained/bunny_smoke/.hydra/config.yaml")))
+    rcfg = dict(cfg["render"])
+    rcfg.pop("_target_")
+    render = NeRFRender(network_config=cfg["network"], **rcfg)
+    render.load_state_dict(torch.load(os.path.join(REF, "pretrained/bunny_smoke/models/model_02000.pth"), map_location="cpu"))
+    render.set_iter(-1)
+    render.network_fine.eval()
+    assert next(render.network_fine.parameters()).dtype == torch.float64
+    g = np.load(os.path.join(HERE, "bunny_stages.npz"))
+    arrs = {}
+    for tag in ("c", "f"):
+        smp = Sampling(*(torch.from_numpy(g[tag + "_" + k]).double() for k in ("pos", "dir", "var")))
+        out = render.network_fine(smp)
+        for k in ("density", "distance"):
+            arrs["%s_%s" % (tag, k)] = npy(out[k])
+            assert arrs["%s_%s" % (tag, k)].dtype == np.float64
+    save("bunny_field_fp64.npz", **arrs)
+    torch.set_default_dtype(torch.float32)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train_nerf":
         gen_train_nerf()
@@ -801,6 +826,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "train_neus":
         gen_train_neus()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fp64":
+        gen_fp64()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "configs":
         gen_config_digests()
@@ -822,3 +850,4 @@ if __name__ == "__main__":
     gen_train()
     gen_train_nerf()
     gen_train_neus()
+    gen_fp64()          # last: switches torch's default dtype while it runs

@@ -224,7 +224,16 @@ def test_neddf_bunny_field(dev, orc, bunny_weights, bunny_stages):
             assert_close(N(o["color"]), src["color"], 1e-4, 2e-5, tag + " color vs " + name)
             # (1 - |grad|)/D amplifies fp32 noise: reference fp32-vs-fp64 differs by 5e-5 abs here
             assert_close(N(o["density"]), src["density"], 1e-4, 3e-4, tag + " density vs " + name)
-            assert_close(N(o["fields_penalty"]), src["fields_penalty"], 2e-3, 1e-5, tag + " penalty vs " + name)
+            assert_close(N(o["fields_penalty"]), src["fields_penalty"], 1e-4, 1e-5, tag + " penalty vs " + name)
+        # the same density against the reference evaluated in DOUBLE (tests/golden/gen_goldens.py::gen_fp64): the fp32 reference
+        # itself is ~1.1e-4 away from it; the HIP result must be as close to the exact value as the reference's own fp32 is,
+        # up to a small factor -- this is the fp64-referenced figure behind the 3e-4 abs term of the gate above
+        g64 = golden("bunny_field_fp64.npz")
+        exact = g64[tag + "_density"]
+        e_ref = float(np.abs(g[tag + "_density"].astype(np.float64) - exact).max())
+        e_hip = float(np.abs(N(o["density"]).astype(np.float64) - exact).max())
+        assert e_hip <= 2.5 * e_ref, (tag, e_hip, e_ref)
+        assert float(np.abs(N(o["distance"]).astype(np.float64) - g64[tag + "_distance"]).max()) <= 2e-6
     # minimal mode = same values, no penalty key
     net.output_mode = "minimal"
     o2 = net(smp(g, dev, "f"))
@@ -299,8 +308,8 @@ def test_render_rays_end_to_end(dev, bunny_weights, bunny_stages):
     for k in ("color", "depth", "transmittance", "color_coarse", "depth_coarse", "transmittance_coarse"):
         assert_close(N(o[k]), g["out_" + k], 1e-4, 1e-5, k)
     assert_close(N(o["weight_coarse"]), g["out_weight_coarse"], 1e-4, 1e-5, "weight_coarse")
-    assert_close(N(o["fields_penalty"]), g["out_fields_penalty"], 2e-3, 1e-5, "fields_penalty")
-    assert_close(N(o["fields_penalty_coarse"]), g["out_fields_penalty_coarse"], 2e-3, 1e-5, "fields_penalty_coarse")
+    assert_close(N(o["fields_penalty"]), g["out_fields_penalty"], 1e-4, 1e-5, "fields_penalty")
+    assert_close(N(o["fields_penalty_coarse"]), g["out_fields_penalty_coarse"], 1e-4, 1e-5, "fields_penalty_coarse")
     assert o["weight"].shape == g["out_weight"].shape
     mse = float(np.mean((N(o["color"]) - g["out_color"]) ** 2))
     psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
@@ -610,6 +619,70 @@ def test_full_frame_invariants(dev, bunny_weights):
     merged = torch.sort(torch.cat([df, dc], 1), dim=1)[0]
     assert bool((merged[:, 1:] == merged[:, :-1]).sum(1).ge(65).all())          # each coarse knot appears in df
     assert float(df.min()) >= 2.0 and float(df.max()) <= float(dc.max()) + 1e-6
+
+
+def test_c1_bunny_400x400_vs_oracle(dev, orc, bunny_weights):
+    """BASELINE.json configs[0] geometry on the GPU: 4 096 random rays of the 400x400 bunny_smoke test pose, 65 coarse +
+    194 fine cone samples, shipped checkpoint -- the fused HIP renderer against the CPU oracle on identical uniforms at the
+    north-star tolerance (1e-4 rel fp32 + the 1e-5 abs floor of SURVEY.md N7), PSNR > 120 dB."""
+    g = golden("bunny_stages.npz")
+    r = bunny_render(dev, bunny_weights)
+    cam = make_camera(g, dev)
+    rng = np.random.default_rng(7)
+    idx = rng.choice(400 * 400, 4096, replace=False)
+    uv = np.stack([idx % 400, idx // 400], 1).astype(np.int64)
+    uc = rng.uniform(0, 1, (4096, 65)).astype(np.float32)
+    uf = rng.uniform(0, 1, (4096, 129)).astype(np.float32)
+    o = r._render(r._ctx(dev), T(uv, dev), cam, T(uc, dev), T(uf, dev), full=False)
+    assert int(o["_nan"].item()) == 0
+    onet = orc.NeDDFOracle(bunny_weights, **BUNNY_CFG)
+    ref = orc.render_rays(onet, onet, uv, g["R"], g["T"], g["calib"], uc, uf, 2.0, 6.0, 6.0, "cone")
+    for k in ("color", "depth", "transmittance"):
+        assert_close(N(o[k]), ref[k], 1e-4, 1e-5, "C1 " + k)
+    mse = float(np.mean((N(o["color"]).astype(np.float64) - ref["color"]) ** 2))
+    assert 10 * np.log10(1.0 / max(mse, 1e-30)) > 120.0
+
+
+def test_c3_full_frame_hierarchical_properties(dev, bunny_weights):
+    """BASELINE.json configs[2] at full size: all 640 000 rays of an 800x800 view through render_rays' hierarchical path
+    (65 coarse + 129 importance samples).  Size-independent properties of the importance-resample kernel and the compositor:
+    fine distances sorted, every coarse knot present in the merged set, no NaN anywhere, pixels finite, and the frame is
+    identical when rendered in batches of a different size."""
+    import neddf_amd
+    g = golden("bunny_stages.npz")
+    r = bunny_render(dev, bunny_weights)
+    fx = 0.5 * 800 / np.tan(0.5 * 0.6911112070083618)
+    cam = neddf_amd.Camera(neddf_amd.PinholeCalib(np.array([fx, fx, 400.0, 400.0])), None).to(dev)
+    cam.R, cam.T = T(g["R"], dev), T(g["T"], dev)
+    ctx = r._ctx(dev)
+    n = 640000
+    gen = torch.Generator(device=dev).manual_seed(5)
+    U_c = torch.rand(n, 65, device=dev, generator=gen)
+    U_f = torch.rand(n, 129, device=dev, generator=gen)
+    idx = torch.arange(n, device=dev)
+    uv = torch.stack([idx % 800, idx // 800], 1)
+    color = torch.empty(n, 3, device=dev)
+    trans = torch.empty(n, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    batch = 1 << 16
+    dc, df = torch.empty(batch, 65, device=dev), torch.empty(batch, 194, device=dev)
+    desc = cam.descriptor()
+    for lo in range(0, n, batch):
+        hi = min(n, lo + batch)
+        b = hi - lo
+        ctx.render_rays(uv[lo:hi], desc, r._params(), U_c[lo:hi], U_f[lo:hi],
+                        dict(color=color[lo:hi], transmittance=trans[lo:hi], dists_coarse=dc[:b], dists_fine=df[:b], nan_flag=flag))
+        assert bool((df[:b, 1:] >= df[:b, :-1]).all()), lo
+        merged = torch.sort(torch.cat([df[:b], dc[:b]], 1), dim=1)[0]
+        assert bool((merged[:, 1:] == merged[:, :-1]).sum(1).ge(65).all()), lo          # each coarse knot appears in the fine set
+        assert float(df[:b].min()) >= 2.0 and bool((df[:b].max(1)[0] <= dc[:b].max(1)[0] + 1e-6).all())
+    assert int(flag.item()) == 0
+    assert bool(torch.isfinite(color).all()) and bool(torch.isfinite(trans).all())
+    # batch invariance on a slab that straddles a batch boundary of the loop above
+    lo, hi = batch - 1000, batch + 1000
+    c2 = torch.empty(hi - lo, 3, device=dev)
+    ctx.render_rays(uv[lo:hi], desc, r._params(), U_c[lo:hi], U_f[lo:hi], dict(color=c2, nan_flag=flag))
+    assert torch.equal(c2, color[lo:hi])
 
 
 _RCCL_WORKER = r'''

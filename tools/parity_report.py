@@ -83,6 +83,33 @@ ctx.render_rays(T(g["uv"]), cam.descriptor(), render._params(), T(g["u_coarse"])
 report["bit_exact"]["end_to_end_fine_dists_identical_fraction"] = float(np.mean(dff.cpu().numpy() == g["dists_fine"]))
 report["bit_exact"]["end_to_end_fine_dists_max_abs"] = float(np.abs(dff.cpu().numpy() - g["dists_fine"]).max())
 
+# Where do the non-identical end-to-end fine samples come from?  Stage by stage on the REFERENCE's own intermediate tensors:
+#   A  compositing the reference's coarse field outputs            -> weights vs the reference's weights
+#   B  resampling the reference's weights                          -> identical (above)
+#   C  resampling the weights of A                                 -> fine distances
+#   D  the whole HIP chain (own field outputs)                     -> fine distances (above)
+# so A/C isolate the compositor (its expf and the wave-order sums), D - C is the field's fp32 noise.
+comp, _ = ctx.composite(T(g["dists_coarse"]), T(g["c_density"]), T(g["c_color"]), 6.0)
+wA = comp["weight"].contiguous()
+raw = g["weight_coarse_raw"]
+fA = float(np.mean(wA.cpu().numpy() == raw))
+wA2 = wA.clone()
+dC = ctx.importance_resample(T(g["dists_coarse"]), wA2, T(g["u_fine"]), True)
+val = net(neddf_amd.Sampling(T(g["c_pos"]), T(g["c_dir"]), T(g["c_var"])))
+compF, _ = ctx.composite(T(g["dists_coarse"]), val["density"].reshape(64, 65).contiguous(), val["color"].reshape(64, 65, 3).contiguous(), 6.0)
+report["fine_sample_identity_by_stage"] = {
+    "A_composite_weights_identical_fraction": fA,
+    "A_composite_weights_max_rel": float(np.max(np.abs(wA.cpu().numpy() - raw) / np.maximum(np.abs(raw), 1e-6))),
+    "B_resample_on_reference_weights_identical": bool(np.array_equal(df.cpu().numpy(), g["dists_fine"])),
+    "C_resample_on_A_weights_identical_fraction": float(np.mean(dC.cpu().numpy() == g["dists_fine"])),
+    "C_max_abs": float(np.abs(dC.cpu().numpy() - g["dists_fine"]).max()),
+    "D_end_to_end_identical_fraction": report["bit_exact"]["end_to_end_fine_dists_identical_fraction"],
+    "field_density_identical_fraction": float(np.mean(val["density"].cpu().numpy().reshape(64, 65) == g["c_density"])),
+    "weights_from_own_field_identical_fraction": float(np.mean(compF["weight"].cpu().numpy() == raw)),
+    "reading": "a fine sample is lerp(bins, (u - cdf[i-1]) / (cdf[i] - cdf[i-1])): it moves in its last bits whenever any coarse weight "
+               "of the ray does, without any searchsorted index changing",
+}
+
 # C1 frame (400x400, bunny pose 0): 4096 random rays, HIP vs the CPU oracle on the same uniforms
 rng = np.random.default_rng(7)
 idx = rng.choice(400 * 400, 4096, replace=False)
