@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libneddf_hip.so")
+# NEDDF_LIB_PATH selects another build of the same library (the sanitizer build, `make -C neddf_amd/csrc asan`)
+LIB_PATH = os.environ.get("NEDDF_LIB_PATH") or os.path.join(_HERE, "csrc", "libneddf_hip.so")
 ABI_VERSION = 3
 
 FIELD_NEDDF, FIELD_NERF, FIELD_NEUS = 0, 1, 2

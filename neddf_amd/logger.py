@@ -35,6 +35,11 @@ class _TensorBoardSink:
             self.writer.add_scalar(name, value, iteration)
 
 
+class _NullSink:
+    def add(self, iteration: int, row: Dict[str, float]) -> None:
+        pass
+
+
 class StepRecord:
     """What one training step reports; filled by the trainer inside `with log.step() as rec:`."""
 
@@ -50,11 +55,13 @@ class StepRecord:
 
 class ScalarLog:
     def __init__(self, log_dir: str = "log", sink: Optional[str] = None) -> None:
-        """sink: "tensorboard", "jsonl" or None (= tensorboard if importable, else jsonl)."""
+        """sink: "tensorboard", "jsonl", "null" (ranks that do not write) or None (= tensorboard if importable, else jsonl)."""
         self.iteration = 0
         self.t_open = time.time()
         self.last: Optional[StepRecord] = None
-        if sink == "jsonl":
+        if sink == "null":
+            self.sink = _NullSink()
+        elif sink == "jsonl":
             self.sink = _JsonlSink(log_dir)
         elif sink == "tensorboard":
             self.sink = _TensorBoardSink(log_dir)

@@ -71,6 +71,15 @@ class BaseNeuralField(ABC, nn.Module):
         # operand type of the 256-wide dense layers (not a reference keyword): "fp32" = exact fp32 MFMA, the parity path;
         # "bf16" = bf16 weights and activations with fp32 accumulation (BASELINE.json configs[4]); NeDDF / NeuS only
         self.weight_dtype = "fp32"
+        self._epoch = 0                      # bumped by invalidate(): part of the upload signature
+
+    def invalidate(self) -> None:
+        """Tell the fused inference path that the parameters changed behind autograd's back.  The packed copy in the
+        library is refreshed when a parameter's storage or its version counter changes -- optimiser steps, `copy_`,
+        `load_state_dict`, `.to()` all do that -- but writes through `p.data` (`p.data.mul_()`, EMA / weight surgery code)
+        bump no counter: call this after them, or the renderer keeps the stale packed weights.  (The training kernels
+        read the live tensors and need nothing.)"""
+        self._epoch += 1
 
     @property
     def device(self) -> torch.device:
@@ -113,7 +122,7 @@ class BaseNeuralField(ABC, nn.Module):
         ws, bs = self._tensors()
         desc = self._descriptor()
         desc.weight_dtype = DTYPE[self.weight_dtype]
-        sig = (self._uid, slot, bytes(desc), tuple((t.data_ptr(), t._version) for t in ws + bs))
+        sig = (self._uid, slot, bytes(desc), tuple((t.data_ptr(), t._version) for t in ws + bs), self._epoch)
         have = ctx.slot_owner.get(slot)
         if not weights and have is not None and have[:3] == sig[:3]:
             pass            # same module, same architecture: the training kernels do not read the slot's weights

@@ -50,18 +50,39 @@ def compose(overrides: List[str], config_dir: Path = CONFIG_DIR) -> Dict[str, An
 
 
 def main(argv=None) -> None:
+    """Single process: the reference's behaviour.  Under a launcher (`python -m torch.distributed.run --nproc-per-node N
+    neddf/scripts/run.py ...`; not in the reference, which trains on one device) training is data-parallel over rays: rank r
+    takes device cuda:r and seed 3408 + r (its own cameras / pixels), the gradients are averaged with one all-reduce per
+    step (parallel.average_gradients), and only rank 0 creates the run directory and writes checkpoints, renders and logs."""
     argv = sys.argv[1:] if argv is None else argv
     cfg = compose(argv)
     cwd = Path.cwd()
     cfg["dataset"]["dataset_dir"] = str(cwd / cfg["dataset"]["dataset_dir"])
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        cfg["trainer"]["device"] = "cuda:%d" % local
+        seed_everything(3408 + rank)
     now = datetime.datetime.now()
-    run_dir = cwd / "outputs" / now.strftime("%Y-%m-%d") / now.strftime("%H-%M-%S")
-    (run_dir / ".hydra").mkdir(parents=True)
-    yaml.safe_dump(cfg, open(run_dir / ".hydra" / "config.yaml", "w"), sort_keys=False)
-    yaml.safe_dump(list(argv), open(run_dir / ".hydra" / "overrides.yaml", "w"))
+    run_dir = [str(cwd / "outputs" / now.strftime("%Y-%m-%d") / now.strftime("%H-%M-%S"))]
+    if world > 1:
+        torch.distributed.broadcast_object_list(run_dir, src=0)          # every rank works in rank 0's directory
+    run_dir = Path(run_dir[0])
+    if rank == 0:
+        (run_dir / ".hydra").mkdir(parents=True)
+        yaml.safe_dump(cfg, open(run_dir / ".hydra" / "config.yaml", "w"), sort_keys=False)
+        yaml.safe_dump(list(argv), open(run_dir / ".hydra" / "overrides.yaml", "w"))
+    if world > 1:
+        torch.distributed.barrier()
     os.chdir(run_dir)
     trainer = instantiate(cfg["trainer"], global_config=cfg, _recursive_=False)
+    trainer.writes_outputs = rank == 0
     trainer.run_train()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def seed_everything(seed: int = 3408) -> None:

@@ -119,11 +119,13 @@ class NeRFTrainer(BaseTrainer):
                                           weight_decay=self.optimizer_weight_decay)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=self.scheduler_lr)
         self.logger = None      # created by the first training step: evaluation runs leave no ./log behind
+        self.writes_outputs = True      # data-parallel runs (scripts/run.py under a launcher): rank 0 only
 
     def run_train(self) -> None:
         """nerf_trainer.py:47-79: epochs over a random permutation of the frames, outputs under the working directory
         (models/, render/)."""
-        Path("models").mkdir(parents=True)
+        if self.writes_outputs:
+            Path("models").mkdir(parents=True)
         render_dir = Path("render")
         frame_length = len(self.dataset)
         self.neural_render.set_iter(0)
@@ -134,6 +136,8 @@ class NeRFTrainer(BaseTrainer):
                 self.run_train_step(int(camera_id))
                 self.neural_render.next_iter()
             self.scheduler.step()
+            if not self.writes_outputs:
+                continue
             if epoch % self.epoch_save_fields == 0:
                 output_field_dir = render_dir / "fields"
                 output_field_dir.mkdir(parents=True, exist_ok=True)
@@ -149,7 +153,7 @@ class NeRFTrainer(BaseTrainer):
     def run_train_step(self, camera_id: int) -> float:
         """nerf_trainer.py:81-140; RNG draw order: u pixels, v pixels, then render_rays' own draws."""
         if self.logger is None:
-            self.logger = ScalarLog()
+            self.logger = ScalarLog() if self.writes_outputs else ScalarLog(sink="null")
         camera = self.cameras[camera_id]
         camera.update_transform()
         h, w = self.dataset[camera_id]["rgb_images"].shape[:2]

@@ -158,3 +158,19 @@ def test_bench_self_launch_two_ranks_shared_gpu():
     assert "configs[3]" in line["config"]["workload"] and line["value"] > 0 and line["psnr_vs_oracle_db"] > 80
     if torch.cuda.device_count() >= 2:
         assert line["config"]["comm"]["rccl_comm_ranks"] == 2
+
+
+def test_smoke_under_asan():
+    """smoke() -- weight packing, workspace carving, the fused render_rays orchestration, 64 rays against the oracle -- with the
+    host side of the library under AddressSanitizer + UBSan (the device code is the shipped one)."""
+    csrc = os.path.join(ROOT, "neddf_amd", "csrc")
+    lib = os.path.join(csrc, "libneddf_hip_asan.so")
+    rt = subprocess.run(["make", "-s", "-C", csrc, "print-asan-rt"], capture_output=True, text=True).stdout.strip()
+    if not (os.path.exists(lib) and os.path.exists(rt)):
+        pytest.skip("sanitizer build not present (python -c 'import __graft_entry__ as g; g.build()' makes it)")
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:exitcode=23:protect_shadow_gap=0",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", NEDDF_LIB_PATH=lib)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py"), "smoke-only"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0 and "smoke ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]

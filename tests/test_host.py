@@ -656,3 +656,49 @@ def test_split_fp16_operand_range_model():
     assert errs[1.0][0] < 1e-6 and errs[1.0][1] < 1e-6
     assert errs[1e-5][0] > 5e-4 and errs[1e-6][0] > 5e-3          # unscaled: out of fp16's exponent range
     assert errs[1e-5][1] < 1e-6 and errs[1e-6][1] < 1e-6          # range-scaled: back at the level of magnitude 1
+
+
+_ASAN_SCRIPT = r"""
+import ctypes as C, sys
+sys.path.insert(0, sys.argv[1])
+from neddf_amd import _lib
+assert _lib.LIB_PATH.endswith("libneddf_hip_asan.so"), _lib.LIB_PATH
+lib = _lib.load()
+assert lib.neddf_abi_version() == _lib.ABI_VERSION
+# every entry point with a NULL context and NULL pointers: must return NEDDF_EINVAL without touching memory
+for name, res, args in _lib.SYMBOLS:
+    if name in ("neddf_abi_version", "neddf_create", "neddf_destroy", "neddf_last_error", "neddf_device_cus", "neddf_shard_range"):
+        continue
+    call = [a(0) if a in (C.c_int, C.c_int64) else a(0.0) if a in (C.c_float, C.c_double) else None for a in args]
+    assert getattr(lib, name)(*call) == -1, name
+lib.neddf_destroy(None)
+assert lib.neddf_last_error(None)
+assert lib.neddf_create(0, None) == -1
+h = C.c_void_p()
+rc = lib.neddf_create(10 ** 6, C.byref(h))          # no such device (or no device at all): an error code and a message
+assert rc == -2 and not h.value and b"no HIP device" in lib.neddf_last_error(None), rc
+lo, hi = C.c_int64(), C.c_int64()
+for n, world in ((0, 1), (7, 8), (640000, 8), (640001, 3)):
+    tot = 0
+    for r in range(world):
+        lib.neddf_shard_range(n, r, world, C.byref(lo), C.byref(hi)); tot += hi.value - lo.value
+    assert tot == n
+print("asan ok")
+"""
+
+
+def test_capi_error_paths_under_asan(tmp_path):
+    """The host side of the C ABI under AddressSanitizer + UBSan (`make -C neddf_amd/csrc asan`): the error paths that can
+    run without a GPU.  (The GPU box runs smoke() against the same build: tests/test_gpu_multi.py::test_smoke_under_asan.)"""
+    csrc = os.path.join(ROOT, "neddf_amd", "csrc")
+    subprocess.check_call(["make", "-s", "-C", csrc, "asan"])
+    rt = subprocess.check_output(["make", "-s", "-C", csrc, "print-asan-rt"], text=True).strip()
+    if not os.path.exists(rt):
+        pytest.skip("no AddressSanitizer runtime in this toolchain")
+    script = tmp_path / "asan_paths.py"
+    script.write_text(_ASAN_SCRIPT)
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", NEDDF_LIB_PATH=os.path.join(csrc, "libneddf_hip_asan.so"))
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "asan ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]
