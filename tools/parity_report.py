@@ -19,6 +19,7 @@ from conftest import BUNNY_CFG, golden  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 dev = torch.device("cuda:0")
+torch.set_grad_enabled(False)       # the fused inference path (with autograd on, NeDDF modules take the training kernels)
 
 
 def T(a):
