@@ -29,7 +29,10 @@
 #include "device_math.h"
 #include "tile_engine.h"
 
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <initializer_list>
 
 namespace neddf {
 
@@ -37,12 +40,12 @@ namespace neddf {
 // [col0, col0+2*KH) as [sin half | cos half] (sampling.py:55-71 weights,
 // with_grad/positional_encoding.py:55-87 values + Jacobian for J_in = I3).
 // Region must be pre-zeroed.  GRADSCALE selects embed_pos_scaled (neddf.py:200-204).
-template <bool ROWS4, bool GRADSCALE, class Ops = OpsF32>
+template <bool ROWS4, bool GRADSCALE, class Ops = OpsF32, int THREADS = kThreads>
 __device__ __forceinline__ void encode_pos(typename Ops::act_t *act, int col0, const EncodeDesc &enc, const float *lp, const float *pos,
                                            const float *var, int64_t p0, int64_t N, int P, int tid, bool use_var = true)
 {
     const int K3 = 3 * enc.E, KH = enc.KH;
-    for (int item = tid; item < P * K3; item += kThreads) {
+    for (int item = tid; item < P * K3; item += THREADS) {
         int p = item / K3, q = item - p * K3;
         int e = q / 3, d = q - 3 * e;
         int64_t gp = p0 + p < N ? p0 + p : N - 1;
@@ -64,12 +67,12 @@ __device__ __forceinline__ void encode_pos(typename Ops::act_t *act, int col0, c
 }
 
 // PositionalEncoding of the view direction (positional_encoding.py:51-65), value rows only.
-template <bool ROWS4, class Ops = OpsF32>
+template <bool ROWS4, class Ops = OpsF32, int THREADS = kThreads>
 __device__ __forceinline__ void encode_dir(typename Ops::act_t *act, int col0, const EncodeDesc &enc, const float *dir, int64_t p0,
                                            int64_t N, int P, int tid)
 {
     const int K3 = 3 * enc.Ed, KD = enc.KD;
-    for (int item = tid; item < P * K3; item += kThreads) {
+    for (int item = tid; item < P * K3; item += THREADS) {
         int p = item / K3, q = item - p * K3;
         int e = q / 3, d = q - 3 * e;
         int64_t gp = p0 + p < N ? p0 + p : N - 1;
@@ -109,12 +112,21 @@ __device__ __forceinline__ int sched_next(int *sched, int flags, int64_t tile)
 
 // ----------------------------------------------------------------------------
 // NeDDF distance trunk
-template <int MT, int WPS, class Ops>
-__global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs a)
+// Geometry (MT, WPS, NW): MT*32 rows per tile, WPS workgroups per CU, NW waves per workgroup.  NW = 4: one wave per SIMD,
+// each owning 64 output columns (NT = 2 column tiles).  NW = 8 (16-bit operand policies): two waves per SIMD, each owning 32
+// columns (NT = 1) for ALL rows of a 128-row tile -- every weight fragment a wave fetches feeds four M-tiles, which halves the
+// L2 -> VGPR weight stream per row again; that stream through the per-CU vector cache (64 B/clk) is what paces the 16-bit
+// dense phase (42 B/clk/CU at 64-row tiles).  The packed weights are tile-major (tile = wave * NT + t), so both shapes read
+// the same blob.
+template <int MT, int WPS, class Ops, int NW = kWaves>
+__global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const DdfArgs a)
 {
     typedef typename Ops::act_t act_t;
     typedef typename Ops::bfrag frag;            // weight fragments
-    constexpr int NT = 2, ROWS = MT * 32, P = MT * 8, LD = Ops::kLd;
+    constexpr int NT = 8 / NW, THREADS = 64 * NW, ROWS = MT * 32, P = MT * 8, LD = Ops::kLd;
+    constexpr int REG_BUDGET = 512 / (WPS * NW / 4);        // registers per lane at this occupancy
+    // ping-pong operand registers of the dense pipeline
+    constexpr int OPREGS = 2 * (MT * (int)sizeof(typename Ops::afrag) / 4 + NT * (int)sizeof(typename Ops::bfrag) / 4);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     act_t *act = (act_t *)smem;
     float *hd = (float *)(act + ROWS * LD);  // [HSPLIT][2][ROWS] head dot products
@@ -135,13 +147,13 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
         const int64_t p0 = tile * P;
         LayerPre<NT, Ops> pre;
         layer_prefetch<NT, Ops>(pre, a.layer[0].wp, a.layer[0].bias, a.layer[0].ksteps, wave, lane);
-        zero_cols<Ops>(act, ROWS, kin, tid);
+        zero_cols<Ops, THREADS>(act, ROWS, kin, tid);
         __syncthreads();
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);     // consumed at the end of this tile
         if (!(NEDDF_ABL(a.sched_flags, 32))) {
-            if (a.neus) encode_pos<true, false, Ops>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid, false);   // plain PE (neus.py:118)
-            else encode_pos<true, true, Ops>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
+            if (a.neus) encode_pos<true, false, Ops, THREADS>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid, false);   // plain PE (neus.py:118)
+            else encode_pos<true, true, Ops, THREADS>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
         }
         __syncthreads();
 
@@ -149,11 +161,12 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
         // Early partials of skip layers (neddf.py:217-219).  With one skip connection (every shipped
         // config) and the 64-row tile the partial stays in registers until its layer; otherwise it is
         // parked in the per-workgroup global scratch.
-        constexpr bool REG_STASH = (MT == 2) && (WPS <= 2) && !Ops::kLean;     // denser packings of a CU have no registers to spare
+        constexpr bool REG_STASH = NW == 4 ? (MT == 2) && (WPS <= 2) && !Ops::kLean     // denser packings of a CU have no registers to spare
+                                           : (2 * MT * NT * 16 + OPREGS + 64 <= REG_BUDGET);
         // 128-row tiles at two workgroups per CU (16-bit operands: each fetched weight fragment feeds four M-tiles) have neither
         // the registers for a held partial nor the HBM bandwidth for a parked one: the skip layer re-encodes the positions into
         // the tile's first columns after its 256-wide product and multiplies them then (three more barriers per tile).
-        constexpr bool REENCODE = (MT == 4) && (WPS == 2);
+        constexpr bool REENCODE = (MT == 4) && (NW == 8 ? !REG_STASH : WPS == 2);
         const bool in_regs = REG_STASH && a.n_stash == 1;
         f32x16 held[REG_STASH ? MT : 1][REG_STASH ? NT : 1];
         for (int s = 0; s < (REENCODE ? 0 : a.n_stash); ++s) {
@@ -191,10 +204,10 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
                 if (L.stash >= 0) {
                     const StashW &sw = a.stash[L.stash];
                     __syncthreads();                        // every wave finished reading the hidden state
-                    zero_cols<Ops>(act, ROWS, kin, tid);
+                    zero_cols<Ops, THREADS>(act, ROWS, kin, tid);
                     __syncthreads();
-                    if (a.neus) encode_pos<true, false, Ops>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid, false);
-                    else encode_pos<true, true, Ops>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
+                    if (a.neus) encode_pos<true, false, Ops, THREADS>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid, false);
+                    else encode_pos<true, true, Ops, THREADS>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
                     __syncthreads();
                     const frag *ws_ = (const frag *)sw.wp + (size_t)wave * NT * sw.ksteps * 64 + lane;
                     dense<MT, NT, Ops>(acc, act_lane + sw.col0, ws_, sw.ksteps);
@@ -229,8 +242,8 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
         } else {
         // heads (neddf.py:220-230): ddf_out on all four rows, aux_out likewise (rows 1..3 feed aux_gg);
         // HSPLIT threads share one (row, head) dot product so that all 256 threads work on a 64-row tile
-        constexpr int HSPLIT = (4 * ROWS <= kThreads) ? 2 : 1, KQ = kWidth / 4 / HSPLIT;
-        for (int idx = tid; idx < HSPLIT * 2 * ROWS; idx += kThreads) {
+        constexpr int HSPLIT = (4 * ROWS <= THREADS) ? 2 : 1, KQ = kWidth / 4 / HSPLIT;
+        for (int idx = tid; idx < HSPLIT * 2 * ROWS; idx += THREADS) {
             int part = idx / (2 * ROWS), pr = idx - part * 2 * ROWS;
             int head = pr / ROWS, row = pr - head * ROWS;
             const f32x4v *w = (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out) + part * KQ;
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
             constexpr int CE = 16 / sizeof(act_t), CPP = kWidth / CE, CPR = Ops::kPlanes * CPP;
             act_t *features = (act_t *)a.features;
             const int fr = a.feat_rows;
-            for (int idx = tid; idx < P * fr * CPR; idx += kThreads) {
+            for (int idx = tid; idx < P * fr * CPR; idx += THREADS) {
                 int r = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
                 int p = r / fr, rr = r - p * fr;
                 if (p0 + p < a.n_points) {
@@ -304,12 +317,15 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_trunk_kernel(const DdfArgs 
 // NeDDF colour trunk.  ROWS4 = false: eval-minimal, one row per point (the
 // colour Jacobian is dead code in eval); ROWS4 = true:
 // full mode with Jacobian rows + field penalties (neddf.py:244-300).
-template <bool ROWS4, int MT, int WPS, class Ops>
-__global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs a)
+template <bool ROWS4, int MT, int WPS, class Ops, int NW = kWaves>
+__global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const ColArgs a)
 {
     typedef typename Ops::act_t act_t;
     typedef typename Ops::bfrag frag;            // weight fragments
-    constexpr int NT = 2, ROWS = MT * 32, P = ROWS4 ? MT * 8 : ROWS, RPP = ROWS4 ? 4 : 1, LD = Ops::kLd;
+    constexpr int NT = 8 / NW, THREADS = 64 * NW;        // geometry: see ddf_trunk_kernel
+    constexpr int ROWS = MT * 32, P = ROWS4 ? MT * 8 : ROWS, RPP = ROWS4 ? 4 : 1, LD = Ops::kLd;
+    constexpr int REG_BUDGET = 512 / (WPS * NW / 4);
+    constexpr int OPREGS = 2 * (MT * (int)sizeof(typename Ops::afrag) / 4 + NT * (int)sizeof(typename Ops::bfrag) / 4);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     act_t *act = (act_t *)smem;
     float *hd = (float *)(act + ROWS * LD);  // [2][ROWS][3] partial colour dots
@@ -329,22 +345,22 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
     while (tile < ntiles) {
         const int64_t p0 = tile * P;
         // layer 0, small-input segment: [embed_pos | embed_dir | norm_dir] (neddf.py:243)
-        zero_cols<Ops>(act, ROWS, ka, tid);
+        zero_cols<Ops, THREADS>(act, ROWS, ka, tid);
         __syncthreads();
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
         if (a.mode == 1) {      // NeuS: [pos | gradient | pad | embed_dir] (neus.py:146-149)
-            for (int i = tid; i < P * 3; i += kThreads) {
+            for (int i = tid; i < P * 3; i += THREADS) {
                 int p = i / 3, d = i - 3 * p;
                 int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
                 Ops::put(act + (RPP * p) * LD + d, a.pos[gp * 3 + d]);
                 Ops::put(act + (RPP * p) * LD + 3 + d, a.ptaux[gp * kPtAux + PA_N0 + d]);
             }
-            encode_dir<ROWS4, Ops>(act, 8, a.enc, a.dir, p0, a.n_points, P, tid);
+            encode_dir<ROWS4, Ops, THREADS>(act, 8, a.enc, a.dir, p0, a.n_points, P, tid);
         } else {
-            encode_pos<ROWS4, false, Ops>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
-            encode_dir<ROWS4, Ops>(act, c_dir, a.enc, a.dir, p0, a.n_points, P, tid);
-            for (int i = tid; i < P * 3; i += kThreads) {
+            encode_pos<ROWS4, false, Ops, THREADS>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
+            encode_dir<ROWS4, Ops, THREADS>(act, c_dir, a.enc, a.dir, p0, a.n_points, P, tid);
+            for (int i = tid; i < P * 3; i += THREADS) {
                 int p = i / 3, d = i - 3 * p;
                 int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
                 Ops::put(act + (RPP * p) * LD + c_n + d, a.ptaux[gp * kPtAux + PA_N0 + d]);
@@ -355,12 +371,13 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
         // layer 0, feature segment: in the eval-minimal 64-row tile the trunk features are requested now
         // (global -> VGPR) and land in LDS after the small-input dense; the other variants lack the registers
         constexpr int CE = 16 / sizeof(act_t), CPP = kWidth / CE, CPR = Ops::kPlanes * CPP;     // 16-byte chunks per feature row
-        constexpr int NF = ROWS * CPR / kThreads;
+        constexpr int NF = ROWS * CPR / THREADS;
         auto lds_chunk = [&](int idx) {     // chunk idx of the tile -> its place in LDS (planes are kPlane elements apart)
             const int r = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
             return (f32x4v *)(act + r * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));
         };
-        constexpr bool FPRE = (MT == 2) && !ROWS4 && !Ops::kLean;
+        constexpr bool FPRE = NW == 4 ? (MT == 2) && !ROWS4 && !Ops::kLean
+                                      : !ROWS4 && (MT * NT * 16 + OPREGS + NF * 4 + 64 <= REG_BUDGET);
         f32x4v fpre[FPRE ? NF : 1];
         auto feature_src = [&](int idx) {
             int r = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
@@ -372,7 +389,7 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
         };
         if constexpr (FPRE) {
 #pragma unroll
-            for (int i = 0; i < NF; ++i) fpre[i] = *feature_src(tid + i * kThreads);
+            for (int i = 0; i < NF; ++i) fpre[i] = *feature_src(tid + i * THREADS);
             __builtin_amdgcn_sched_barrier(0);
         }
         acc_init<MT, NT, ROWS4>(acc, a.layer[0].bias, wave, lane, Ops::kWScale);
@@ -383,11 +400,11 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
         if constexpr (FPRE) {
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
-                int idx = tid + i * kThreads;
+                int idx = tid + i * THREADS;
                 *lds_chunk(idx) = fpre[i];
             }
         } else {
-            for (int idx = tid; idx < ROWS * CPR; idx += kThreads)
+            for (int idx = tid; idx < ROWS * CPR; idx += THREADS)
                 *lds_chunk(idx) = *feature_src(idx);
         }
         __syncthreads();
@@ -402,7 +419,7 @@ __global__ __launch_bounds__(kThreads, WPS) void col_trunk_kernel(const ColArgs 
             __syncthreads();
         }
         // layer_col_out 256 -> 3 (neddf.py:257), no output activation; two k-halves per row
-        for (int idx = tid; idx < 2 * ROWS; idx += kThreads) {
+        for (int idx = tid; idx < 2 * ROWS; idx += THREADS) {
             int half = idx / ROWS, row = idx - half * ROWS;
             const act_t *ar = act + row * LD + half * 128;
             const float *w = a.w_out + half * 128 * 3;
@@ -673,101 +690,117 @@ template <class Ops>
 static size_t lds_bytes(int mt) { return (size_t)mt * 32 * Ops::kLd * sizeof(typename Ops::act_t) + (size_t)(2 * mt * 32 * 3 + 16) * sizeof(float); }
 size_t field_lds_bytes(int mt) { return lds_bytes<OpsF32>(mt); }
 
-// Tile geometry: MT = 4 -> one workgroup per CU (133 KB LDS, 128-row tiles, each weight fragment feeds 4 M-tiles);
-// MT = 2 -> two workgroups per CU (2 x 67 KB), so one workgroup's VALU epilogue overlaps the other's MFMA stream.
+// Tile geometry (MT, WPS, NW) per operand policy -- see ddf_trunk_kernel.
+//   fp32        (2, 2, 4): 64-row tiles, two workgroups per CU (one workgroup's VALU epilogue overlaps the other's MFMA stream;
+//               measured on MI355X, C2 workload: 129 TF vs 118 TF for (4, 1, 4)).  NEDDF_TILE_MT=4 selects (4, 1, 4).
+//   bf16        (4, 2, 4): 128-row tiles (half the LDS bytes of fp32) at two workgroups per CU: each fetched weight fragment
+//               feeds four M-tiles (7.78 ms per 2^21-point launch against 8.42 ms for (2, 2, 4)).
+//   split fp16  (2, 2, 4): two fp16 planes = the LDS bytes of fp32, same shape as fp32.
+// NEDDF_BF16_GEO / NEDDF_SPLIT_GEO = "MTxWPSxNW" select another compiled shape.  The eight-wave shapes (NW = 8: two waves per
+// SIMD, 32 columns each, so that a fetched fragment feeds four M-tiles at HALF the per-wave weight stream) were built to test
+// whether the vector-cache weight stream paces the 16-bit dense phase; measured on MI355X (profiles/r02_geometry_sweep.md) they
+// are slower -- bf16 (4, 2, 8) 8.34 ms, (4, 1, 8) 9.03 ms; split fp16 (4, 1, 8) 21.6 ms against 19.9 ms -- so the stream is
+// not the limiter, the un-overlapped VALU epilogue is; they stay selectable for that evidence only.
+struct Geo {
+    int mt, wps, nw;
+};
 static int g_mt = 0;
 static int tile_mt()
 {
     if (!g_mt) {
         const char *e = getenv("NEDDF_TILE_MT");
-        g_mt = (e && atoi(e) == 4) ? 4 : 2;      // measured on MI355X (C2 workload): MT=2 129 TF vs MT=4 118 TF on the distance trunk
+        g_mt = (e && atoi(e) == 4) ? 4 : 2;
     }
     return g_mt;
 }
-// bf16 tiles are half the LDS bytes: NEDDF_BF16_WPS (2, 3 or 4; experiment knob) workgroups share a CU
-static int bf16_wps()
+static Geo parse_geo(const char *env, Geo dflt, std::initializer_list<Geo> allowed)
 {
-    static int v = 0;
-    if (!v) {
-        const char *e = getenv("NEDDF_BF16_WPS");
-        v = e ? atoi(e) : 2;
-        if (v < 2 || v > 4) v = 2;
+    const char *e = getenv(env);
+    if (!e) return dflt;
+    Geo g{ 0, 0, 0 };
+    if (sscanf(e, "%dx%dx%d", &g.mt, &g.wps, &g.nw) != 3) return dflt;
+    for (const Geo &a : allowed) if (a.mt == g.mt && a.wps == g.wps && a.nw == g.nw) return g;
+    fprintf(stderr, "libneddf_hip: %s=%s is not a compiled geometry, using %dx%dx%d\n", env, e, dflt.mt, dflt.wps, dflt.nw);
+    return dflt;
+}
+static Geo geo(int operands)
+{
+    static Geo g[3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+    if (!g[0].mt) {
+        const Geo base = tile_mt() == 2 ? Geo{ 2, 2, 4 } : Geo{ 4, 1, 4 };
+        g[0] = base;
+        g[1] = tile_mt() == 2 ? parse_geo("NEDDF_BF16_GEO", Geo{ 4, 2, 4 }, { { 4, 2, 8 }, { 4, 1, 8 }, { 4, 2, 4 }, { 2, 2, 4 }, { 4, 1, 4 } }) : base;
+        g[2] = tile_mt() == 2 ? parse_geo("NEDDF_SPLIT_GEO", Geo{ 2, 2, 4 }, { { 4, 1, 8 }, { 2, 2, 4 }, { 4, 1, 4 } }) : base;
     }
-    return v;
+    return g[operands < 0 || operands > 2 ? 0 : operands];
 }
-// The bf16 distance trunk runs 128-row tiles at two workgroups per CU (a bf16 tile is half the LDS bytes): every fetched weight
-// fragment then feeds four M-tiles, and the weight stream from L2 is what bounds the 16-bit dense phase (profiles/
-// r01_f16_split_bottleneck.md).  Measured 8.09 ms per 2^21-point launch against 8.81 ms for 64-row tiles; NEDDF_BF16_MT4X2=0
-// selects the latter.
-static bool bf16_mt4x2()
-{
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("NEDDF_BF16_MT4X2"); v = ((!e || atoi(e) != 0) && tile_mt() == 2 && bf16_wps() == 2) ? 1 : 0; }
-    return v == 1;
-}
-int field_wgs_per_cu(int operands) { return tile_mt() == 2 ? (operands == 1 ? bf16_wps() : 2) : 1; }
-int ddf_points_per_tile(int operands) { return (operands == 1 && bf16_mt4x2()) ? 32 : tile_mt() * 8; }
-int col_points_per_tile(bool rows4, int) { return rows4 ? tile_mt() * 8 : tile_mt() * 32; }
+int field_wgs_per_cu(int operands) { return geo(operands).wps; }
+int ddf_points_per_tile(int operands) { return geo(operands).mt * 8; }
+int col_points_per_tile(bool rows4, int operands) { return rows4 ? geo(operands).mt * 8 : geo(operands).mt * 32; }
 int nerf_points_per_tile() { return tile_mt() * 32; }
+int nerf_wgs_per_cu() { return tile_mt() == 2 ? 2 : 1; }
 
 static void set_lds(const void *fn, size_t bytes)
 {
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <class Ops>
-static void launch_ddf_t(const DdfArgs &a, int grid, hipStream_t s)
+template <int MT, int WPS, int NW, class Ops>
+static void launch_ddf_g(const DdfArgs &a, int grid, hipStream_t s)
 {
-    static bool once = (set_lds((const void *)ddf_trunk_kernel<4, 1, Ops>, lds_bytes<Ops>(4)),
-                        set_lds((const void *)ddf_trunk_kernel<2, 2, Ops>, lds_bytes<Ops>(2)), true);
+    static bool once = (set_lds((const void *)ddf_trunk_kernel<MT, WPS, Ops, NW>, lds_bytes<Ops>(MT)), true);
     (void)once;
-    if (tile_mt() == 2) {
-        if constexpr (sizeof(typename Ops::act_t) == 2 && Ops::kPlanes == 1) {
-            static bool once2 = (set_lds((const void *)ddf_trunk_kernel<2, 3, Ops>, lds_bytes<Ops>(2)),
-                                 set_lds((const void *)ddf_trunk_kernel<2, 4, Ops>, lds_bytes<Ops>(2)), true);
-            (void)once2;
-            if (bf16_mt4x2()) {
-                static bool once3 = (set_lds((const void *)ddf_trunk_kernel<4, 2, Ops>, lds_bytes<Ops>(4)), true);
-                (void)once3;
-                hipLaunchKernelGGL((ddf_trunk_kernel<4, 2, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(4), s, a);
-                return;
-            }
-            if (bf16_wps() == 3) { hipLaunchKernelGGL((ddf_trunk_kernel<2, 3, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a); return; }
-            if (bf16_wps() == 4) { hipLaunchKernelGGL((ddf_trunk_kernel<2, 4, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a); return; }
-        }
-        hipLaunchKernelGGL((ddf_trunk_kernel<2, 2, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a);
-    } else hipLaunchKernelGGL((ddf_trunk_kernel<4, 1, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(4), s, a);
+    hipLaunchKernelGGL((ddf_trunk_kernel<MT, WPS, Ops, NW>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a);
 }
+
+template <int MT, int WPS, int NW, class Ops>
+static void launch_col_g(const ColArgs &a, int grid, bool rows4, hipStream_t s)
+{
+    static bool once = (set_lds((const void *)col_trunk_kernel<false, MT, WPS, Ops, NW>, lds_bytes<Ops>(MT)),
+                        set_lds((const void *)col_trunk_kernel<true, MT, WPS, Ops, NW>, lds_bytes<Ops>(MT)), true);
+    (void)once;
+    if (rows4) hipLaunchKernelGGL((col_trunk_kernel<true, MT, WPS, Ops, NW>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a);
+    else hipLaunchKernelGGL((col_trunk_kernel<false, MT, WPS, Ops, NW>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a);
+}
+
+#define NEDDF_GEO_CASE(MT_, WPS_, NW_) if (g.mt == MT_ && g.wps == WPS_ && g.nw == NW_)
 
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
 {
-    if (a.operands == 2) launch_ddf_t<OpsF16Split>(a, grid, s);
-    else if (a.operands) launch_ddf_t<OpsBF16>(a, grid, s);
-    else launch_ddf_t<OpsF32>(a, grid, s);
-}
-
-template <class Ops>
-static void launch_col_t(const ColArgs &a, int grid, bool rows4, hipStream_t s)
-{
-    static bool once = (set_lds((const void *)col_trunk_kernel<false, 4, 1, Ops>, lds_bytes<Ops>(4)),
-                        set_lds((const void *)col_trunk_kernel<true, 4, 1, Ops>, lds_bytes<Ops>(4)),
-                        set_lds((const void *)col_trunk_kernel<false, 2, 2, Ops>, lds_bytes<Ops>(2)),
-                        set_lds((const void *)col_trunk_kernel<true, 2, 2, Ops>, lds_bytes<Ops>(2)), true);
-    (void)once;
-    if (tile_mt() == 2) {
-        if (rows4) hipLaunchKernelGGL((col_trunk_kernel<true, 2, 2, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a);
-        else hipLaunchKernelGGL((col_trunk_kernel<false, 2, 2, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a);
-    } else {
-        if (rows4) hipLaunchKernelGGL((col_trunk_kernel<true, 4, 1, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(4), s, a);
-        else hipLaunchKernelGGL((col_trunk_kernel<false, 4, 1, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(4), s, a);
+    const Geo g = geo(a.operands);
+    if (a.operands == 2) {
+        NEDDF_GEO_CASE(4, 1, 8) return launch_ddf_g<4, 1, 8, OpsF16Split>(a, grid, s);
+        NEDDF_GEO_CASE(2, 2, 4) return launch_ddf_g<2, 2, 4, OpsF16Split>(a, grid, s);
+        return launch_ddf_g<4, 1, 4, OpsF16Split>(a, grid, s);
     }
+    if (a.operands == 1) {
+        NEDDF_GEO_CASE(4, 2, 8) return launch_ddf_g<4, 2, 8, OpsBF16>(a, grid, s);
+        NEDDF_GEO_CASE(4, 1, 8) return launch_ddf_g<4, 1, 8, OpsBF16>(a, grid, s);
+        NEDDF_GEO_CASE(4, 2, 4) return launch_ddf_g<4, 2, 4, OpsBF16>(a, grid, s);
+        NEDDF_GEO_CASE(2, 2, 4) return launch_ddf_g<2, 2, 4, OpsBF16>(a, grid, s);
+        return launch_ddf_g<4, 1, 4, OpsBF16>(a, grid, s);
+    }
+    NEDDF_GEO_CASE(2, 2, 4) return launch_ddf_g<2, 2, 4, OpsF32>(a, grid, s);
+    return launch_ddf_g<4, 1, 4, OpsF32>(a, grid, s);
 }
 
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 {
-    if (a.operands == 2) launch_col_t<OpsF16Split>(a, grid, rows4, s);
-    else if (a.operands) launch_col_t<OpsBF16>(a, grid, rows4, s);
-    else launch_col_t<OpsF32>(a, grid, rows4, s);
+    const Geo g = geo(a.operands);
+    if (a.operands == 2) {
+        NEDDF_GEO_CASE(4, 1, 8) return launch_col_g<4, 1, 8, OpsF16Split>(a, grid, rows4, s);
+        NEDDF_GEO_CASE(2, 2, 4) return launch_col_g<2, 2, 4, OpsF16Split>(a, grid, rows4, s);
+        return launch_col_g<4, 1, 4, OpsF16Split>(a, grid, rows4, s);
+    }
+    if (a.operands == 1) {
+        NEDDF_GEO_CASE(4, 2, 8) return launch_col_g<4, 2, 8, OpsBF16>(a, grid, rows4, s);
+        NEDDF_GEO_CASE(4, 1, 8) return launch_col_g<4, 1, 8, OpsBF16>(a, grid, rows4, s);
+        NEDDF_GEO_CASE(4, 2, 4) return launch_col_g<4, 2, 4, OpsBF16>(a, grid, rows4, s);
+        NEDDF_GEO_CASE(2, 2, 4) return launch_col_g<2, 2, 4, OpsBF16>(a, grid, rows4, s);
+        return launch_col_g<4, 1, 4, OpsBF16>(a, grid, rows4, s);
+    }
+    NEDDF_GEO_CASE(2, 2, 4) return launch_col_g<2, 2, 4, OpsF32>(a, grid, rows4, s);
+    return launch_col_g<4, 1, 4, OpsF32>(a, grid, rows4, s);
 }
 
 template <class Ops>

@@ -129,6 +129,7 @@ void launch_nerf(const NerfArgs &a, int grid, hipStream_t s);
 int ddf_points_per_tile(int operands = 0);
 int col_points_per_tile(bool rows4, int operands = 0);
 int nerf_points_per_tile();
+int nerf_wgs_per_cu();
 int field_wgs_per_cu(int operands = 0);
 
 void launch_raygen(const void *uv, int uv_type, int64_t n, const CameraArg &cam, float *dir, float *orig, hipStream_t s);

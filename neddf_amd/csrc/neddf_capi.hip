@@ -376,11 +376,11 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");
     if (N <= 0) return 0;
     Field &f = ctx->field[slot];
-    const int grid_cap = ctx->cus * field_wgs_per_cu();
+    const int grid_cap = ctx->cus * nerf_wgs_per_cu();
     const int dt = f.d.weight_dtype;
     const int grid_cap_ddf = ctx->cus * field_wgs_per_cu(dt);
-    const int grid_cap_col = grid_cap;
-    if (int rc = ensure(ctx, ctx->scratch, (size_t)grid_cap_ddf * kMaxStash * kStashFloatsPerWg * sizeof(float))) return rc;
+    const int grid_cap_col = grid_cap_ddf;         // the colour trunk runs the distance trunk's tile geometry
+    if (int rc = ensure(ctx, ctx->scratch, (size_t)(grid_cap > grid_cap_ddf ? grid_cap : grid_cap_ddf) * kMaxStash * kStashFloatsPerWg * sizeof(float))) return rc;
     if (f.d.kind == NEDDF_FIELD_NERF) {
         NerfArgs a = f.nerf;
         fill_enc(a.enc, f);

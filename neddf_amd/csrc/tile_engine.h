@@ -356,10 +356,10 @@ __device__ __forceinline__ void epilogue_rt(const f32x16 (&acc)[MT][NT], typenam
 
 // ----------------------------------------------------------------------------
 // input encodings
-template <class Ops = OpsF32>
+template <class Ops = OpsF32, int THREADS = kThreads>
 __device__ __forceinline__ void zero_cols(typename Ops::act_t *act, int rows, int ncols, int tid)
 {
-    for (int i = tid; i < rows * ncols; i += kThreads) {
+    for (int i = tid; i < rows * ncols; i += THREADS) {
         int r = i / ncols, c = i - r * ncols;
         Ops::zero(act + r * Ops::kLd + c);
     }
