@@ -95,6 +95,13 @@ typedef struct {
     int ndc_rays;
     int ndc_width, ndc_height;
     float ndc_near;
+    /* neddf_render_rays on a batch that stands for several render_rays calls of the reference (render_image hands the
+     * library many `chunk`s at once): rays [k*nan_group, (k+1)*nan_group) share sample_pdf's NaN fallback decision
+     * (base_neural_render.py:105-114 decides per call) and fall back to the linspace of group k's first ray.
+     * 0 = the whole batch is one call.  nan_group_offset = index, inside its group, of the batch's first ray (a ray-sharded
+     * slab may begin in the middle of a chunk; the leading partial group then falls back to ITS first ray's linspace). */
+    int nan_group;
+    int nan_group_offset;
 } neddf_render_params;
 
 int neddf_abi_version(void);
@@ -164,8 +171,8 @@ int neddf_integrate_penalty(neddf_ctx *ctx, const float *d_dists, const float *d
  * uniforms d_U [n_rays,n_fine].  d_dists [n_rays,n], d_weights [n_rays,n-1] is
  * sanitised IN PLACE like the reference (:52-55).  d_out [n_rays, n_fine+n]
  * (cat_coarse) or [n_rays,n_fine]; d_ids (int64, may be NULL) receives the
- * searchsorted indices.  The batch-wide NaN fallback (:105-114) is applied on
- * device. */
+ * searchsorted indices.  The NaN fallback (:105-114) is applied on device, batch-wide
+ * (one call of the reference = one call here). */
 int neddf_importance_resample(neddf_ctx *ctx, const float *d_dists, float *d_weights, const float *d_U,
                               int64_t n_rays, int n, int n_fine, int cat_coarse, float *d_out, int64_t *d_ids,
                               void *stream);

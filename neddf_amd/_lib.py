@@ -50,7 +50,7 @@ class RenderParams(C.Structure):
     _fields_ = [("sample_coarse", C.c_int), ("sample_fine", C.c_int), ("dist_near", C.c_float),
                 ("dist_far", C.c_float), ("max_dist", C.c_float), ("cone_sampling", C.c_int),
                 ("ray_radius", C.c_double), ("ndc_rays", C.c_int), ("ndc_width", C.c_int), ("ndc_height", C.c_int),
-                ("ndc_near", C.c_float)]
+                ("ndc_near", C.c_float), ("nan_group", C.c_int), ("nan_group_offset", C.c_int)]
 
 
 class RenderOutputs(C.Structure):

@@ -62,6 +62,7 @@ struct neddf_ctx {
     std::string err;
     Field field[NEDDF_NUM_SLOTS];
     DevBuf features, ptaux, scratch, arena, flags, sched;
+    DevBuf rflags;               // importance resampling: one NaN-fallback flag per group of rays
     DevBuf tpack, ttmp;          // training step: packed weights of the layer in flight, gradient ping-pong buffers
     DevBuf tamax;                // training step: max |dZ| of every gradient matrix of a backward pass (split-fp16 operand range)
     bool timing = false;

@@ -734,9 +734,19 @@ static Geo geo(int operands)
     }
     return g[operands < 0 || operands > 2 ? 0 : operands];
 }
+// The colour trunk follows the distance trunk's shape except under bf16, where its value-row-only epilogue is light enough for
+// the eight-wave shape to pay (1.71 ms against 1.82 ms per 2^21-point launch; NEDDF_BF16_COL_GEO).
+static Geo geo_col(int operands)
+{
+    static Geo g{ 0, 0, 0 };
+    if (operands != 1 || tile_mt() != 2) return geo(operands);
+    if (!g.mt) g = parse_geo("NEDDF_BF16_COL_GEO", Geo{ 4, 2, 8 }, { { 4, 2, 8 }, { 4, 1, 8 }, { 4, 2, 4 }, { 2, 2, 4 }, { 4, 1, 4 } });
+    return g;
+}
 int field_wgs_per_cu(int operands) { return geo(operands).wps; }
+int col_wgs_per_cu(int operands) { return geo_col(operands).wps; }
 int ddf_points_per_tile(int operands) { return geo(operands).mt * 8; }
-int col_points_per_tile(bool rows4, int operands) { return rows4 ? geo(operands).mt * 8 : geo(operands).mt * 32; }
+int col_points_per_tile(bool rows4, int operands) { return rows4 ? geo_col(operands).mt * 8 : geo_col(operands).mt * 32; }
 int nerf_points_per_tile() { return tile_mt() * 32; }
 int nerf_wgs_per_cu() { return tile_mt() == 2 ? 2 : 1; }
 
@@ -786,7 +796,7 @@ void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
 
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 {
-    const Geo g = geo(a.operands);
+    const Geo g = geo_col(a.operands);
     if (a.operands == 2) {
         NEDDF_GEO_CASE(4, 1, 8) return launch_col_g<4, 1, 8, OpsF16Split>(a, grid, rows4, s);
         NEDDF_GEO_CASE(2, 2, 4) return launch_col_g<2, 2, 4, OpsF16Split>(a, grid, rows4, s);

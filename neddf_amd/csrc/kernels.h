@@ -131,6 +131,7 @@ int col_points_per_tile(bool rows4, int operands = 0);
 int nerf_points_per_tile();
 int nerf_wgs_per_cu();
 int field_wgs_per_cu(int operands = 0);
+int col_wgs_per_cu(int operands = 0);
 
 void launch_raygen(const void *uv, int uv_type, int64_t n, const CameraArg &cam, float *dir, float *orig, hipStream_t s);
 void launch_sample_coarse(const float *U, int64_t n, int S1, float near_, float far_, float *dists, hipStream_t s);
@@ -142,7 +143,7 @@ void launch_composite(const float *dists, const float *dens, const float *col, i
                       float *w, float *depth, float *color, float *trans, int *nan_flag, hipStream_t s);
 void launch_integrate_penalty(const float *dists, const float *pen, int64_t n, int S, float *out, hipStream_t s);
 void launch_resample(const float *dists, float *weights, const float *U, int64_t n_rays, int n, int nf, int cat,
-                     float *out, int64_t *ids, int *flag, hipStream_t s);
+                     float *out, int64_t *ids, int *flag, int64_t group, int64_t offset, hipStream_t s);
 
 void launch_linear_grad(const float *x, const float *J, int64_t n, int cin, int cout, int ksteps, const float *wp,
                         const float *bias, float *y, float *G, int grid, hipStream_t s);

@@ -379,7 +379,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     const int grid_cap = ctx->cus * nerf_wgs_per_cu();
     const int dt = f.d.weight_dtype;
     const int grid_cap_ddf = ctx->cus * field_wgs_per_cu(dt);
-    const int grid_cap_col = grid_cap_ddf;         // the colour trunk runs the distance trunk's tile geometry
+    const int grid_cap_col = ctx->cus * col_wgs_per_cu(dt);
     if (int rc = ensure(ctx, ctx->scratch, (size_t)(grid_cap > grid_cap_ddf ? grid_cap : grid_cap_ddf) * kMaxStash * kStashFloatsPerWg * sizeof(float))) return rc;
     if (f.d.kind == NEDDF_FIELD_NERF) {
         NerfArgs a = f.nerf;
@@ -490,7 +490,7 @@ void neddf_destroy(neddf_ctx *ctx)
     (void)hipDeviceSynchronize();
     neddf_comm_release(ctx);
     for (auto &f : ctx->field) if (f.blob.p) (void)hipFree(f.blob.p);
-    for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags, &ctx->sched, &ctx->tpack, &ctx->ttmp, &ctx->tamax })
+    for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags, &ctx->rflags, &ctx->sched, &ctx->tpack, &ctx->ttmp, &ctx->tamax })
         if (b->p) (void)hipFree(b->p);
     for (auto &e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : ctx->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -633,7 +633,7 @@ int neddf_importance_resample(neddf_ctx *ctx, const float *dists, float *weights
     if (!ctx || !dists || !weights || !U || !out || n < 2 || nf < 1) return NEDDF_EINVAL;
     if (n + nf > 8192) return fail(ctx, NEDDF_EUNSUPPORTED, "importance_resample: n + n_fine must be <= 8192");
     DeviceGuard guard_(ctx->device);
-    STAGE(ctx, (hipStream_t)stream, NEDDF_STAGE_RESAMPLE, launch_resample(dists, weights, U, n_rays, n, nf, cat, out, ids, (int *)ctx->flags.p + 1, (hipStream_t)stream));
+    STAGE(ctx, (hipStream_t)stream, NEDDF_STAGE_RESAMPLE, launch_resample(dists, weights, U, n_rays, n, nf, cat, out, ids, (int *)ctx->flags.p + 1, 0, 0, (hipStream_t)stream));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -708,7 +708,11 @@ int neddf_render_rays(neddf_ctx *ctx, const void *uv, int uv_type, int64_t B, co
     int rc = render_pass(ctx, NEDDF_SLOT_COARSE, rd, ro, view, dc, B, Sc1, rp, pos, dir, var, dens, col, pen, wc, depth_c, color_c,
                          trans_c, out->fields_penalty_coarse, nan_flag, s);
     if (rc) return rc;
-    STAGE(ctx, s, NEDDF_STAGE_RESAMPLE, launch_resample(dc, wc, Uf, B, Sc1, Sf1, 1, df, nullptr, flags + 1, s));
+    // the reference takes the NaN-fallback decision of sample_pdf per render_rays call, i.e. per `chunk` rays of render_image
+    const int64_t group = rp->nan_group > 0 ? rp->nan_group : B;
+    const int64_t goff = rp->nan_group > 0 && rp->nan_group_offset > 0 ? rp->nan_group_offset % group : 0;
+    if (int rc = ensure(ctx, ctx->rflags, (size_t)((B + goff + group - 1) / group) * sizeof(int))) return rc;
+    STAGE(ctx, s, NEDDF_STAGE_RESAMPLE, launch_resample(dc, wc, Uf, B, Sc1, Sf1, 1, df, nullptr, (int *)ctx->rflags.p, group, goff, s));
     rc = render_pass(ctx, NEDDF_SLOT_FINE, rd, ro, view, df, B, S2, rp, pos, dir, var, dens, col, pen, out->weight, depth, color, trans,
                      out->fields_penalty, nan_flag, s);
     if (rc) return rc;

@@ -241,8 +241,9 @@ void launch_integrate_penalty(const float *dists, const float *pen, int64_t n, i
 // ----------------------------------------------------------------------------
 // sample_pdf base_neural_render.py:27-115, one wavefront (= one workgroup) per ray.
 // LDS: w[nw] | cdf[n] | sorted[max(npow2, n)]
+// `group` rays share one NaN-fallback decision (the reference decides per sample_pdf call, i.e. per render_rays chunk).
 __global__ __launch_bounds__(64) void resample_kernel(const float *dists, float *weights, const float *U, int n, int nf, int cat,
-                                                      int npow2, float *out, int64_t *ids, int *flag)
+                                                      int npow2, float *out, int64_t *ids, int *flag, int64_t group, int64_t offset)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int nw = n - 1, no = cat ? nf + n : nf;
@@ -323,30 +324,37 @@ __global__ __launch_bounds__(64) void resample_kernel(const float *dists, float 
             __syncthreads();
         }
     for (int j = lane; j < no; j += 64) out[b * no + j] = srt[j];
-    if (__any(bad) && lane == 0) atomicOr(flag, 1);
+    if (__any(bad) && lane == 0) atomicOr(flag + (b + offset) / group, 1);
 }
 
-// batch-wide NaN fallback (:105-114): linspace(dists[0,0], dists[0,-1], no) for every ray
-__global__ void resample_fallback_kernel(const float *dists, int n, int64_t total, int no, float *out, const int *flag)
+// NaN fallback (:105-114): linspace(dists[0,0], dists[0,-1], no) for every ray of a group (= of a sample_pdf call of the
+// reference) in which any sample came out NaN; row 0 is the group's first ray
+__global__ void resample_fallback_kernel(const float *dists, int n, int64_t total, int no, float *out, const int *flag, int64_t group,
+                                         int64_t offset)
 {
-    if (!*flag) return;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    out[i] = linspace_at(dists[0], dists[n - 1], no, (int)(i % no));
+    const int64_t g = (i / no + offset) / group;
+    if (!flag[g]) return;
+    const int64_t r0 = g * group - offset;          // a leading partial group (offset > 0) starts before this batch
+    const float *first = dists + (r0 > 0 ? r0 : 0) * n;
+    out[i] = linspace_at(first[0], first[n - 1], no, (int)(i % no));
 }
 
 void launch_resample(const float *dists, float *weights, const float *U, int64_t n_rays, int n, int nf, int cat,
-                     float *out, int64_t *ids, int *flag, hipStream_t s)
+                     float *out, int64_t *ids, int *flag, int64_t group, int64_t offset, hipStream_t s)
 {
     if (n_rays <= 0) return;
+    if (group <= 0) { group = n_rays; offset = 0; }
+    const int64_t n_groups = (n_rays + offset + group - 1) / group;
     int no = cat ? nf + n : nf;
     int npow2 = 2;
     while (npow2 < no) npow2 <<= 1;
     size_t lds = sizeof(float) * (size_t)((n - 1) + n + (npow2 > n ? npow2 : n));
-    (void)hipMemsetAsync(flag, 0, sizeof(int), s);
-    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)n_rays), dim3(64), lds, s, dists, weights, U, n, nf, cat, npow2, out, ids, flag);
+    (void)hipMemsetAsync(flag, 0, sizeof(int) * n_groups, s);
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)n_rays), dim3(64), lds, s, dists, weights, U, n, nf, cat, npow2, out, ids, flag, group, offset);
     int64_t total = n_rays * no;
-    hipLaunchKernelGGL(resample_fallback_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dists, n, total, no, out, flag);
+    hipLaunchKernelGGL(resample_fallback_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dists, n, total, no, out, flag, group, offset);
 }
 
 }  // namespace neddf

@@ -81,13 +81,15 @@ class NeRFRender(BaseNeuralRender):
         self.network_coarse.set_iter(iter)
         self.network_fine.set_iter(iter)
 
-    def _params(self) -> RenderParams:
+    def _params(self, nan_group: int = 0, nan_group_offset: int = 0) -> RenderParams:
         if self.sampling_type not in ("point", "cone"):
             raise ValueError("sampling_type must be 'point' or 'cone'")
         p = RenderParams()
         p.sample_coarse, p.sample_fine = self.sample_coarse, self.sample_fine
         p.dist_near, p.dist_far, p.max_dist = self.dist_near, self.dist_far, self.max_dist
         p.cone_sampling = int(self.sampling_type == "cone")
+        # rays per sample_pdf NaN-fallback decision (render_image: its chunk) and where in a group this batch starts
+        p.nan_group, p.nan_group_offset = int(nan_group), int(nan_group_offset)
         p.ray_radius = 1.0 / 1111 / math.sqrt(12)      # nerf_render.py:144-145
         if self.ray_space not in ("world", "ndc"):
             raise ValueError("ray_space must be 'world' or 'ndc'")
@@ -139,7 +141,8 @@ class NeRFRender(BaseNeuralRender):
         return out
 
     # -------------------------------------------------------------- render_rays
-    def _render(self, ctx: Context, uv: Tensor, camera: Camera, U_c: Tensor, U_f: Tensor, full: bool, cam_desc=None) -> Dict[str, Tensor]:
+    def _render(self, ctx: Context, uv: Tensor, camera: Camera, U_c: Tensor, U_f: Tensor, full: bool, cam_desc=None,
+                nan_group: int = 0, nan_group_offset: int = 0) -> Dict[str, Tensor]:
         B = uv.shape[0]
         dev = uv.device
         S2 = self.sample_coarse + self.sample_fine + 2
@@ -154,7 +157,7 @@ class NeRFRender(BaseNeuralRender):
             if self._has_penalty():
                 o.update(fields_penalty=buf(B), fields_penalty_coarse=buf(B))
         flag = torch.zeros(1, device=dev, dtype=torch.int32)
-        ctx.render_rays(uv, camera.descriptor() if cam_desc is None else cam_desc, self._params(), U_c, U_f, dict(o, nan_flag=flag))
+        ctx.render_rays(uv, camera.descriptor() if cam_desc is None else cam_desc, self._params(nan_group, nan_group_offset), U_c, U_f, dict(o, nan_flag=flag))
         o["_nan"] = flag
         return o
 
@@ -243,7 +246,10 @@ class NeRFRender(BaseNeuralRender):
             cam_desc = camera.descriptor()          # three device -> host reads: once per image, not per batch
 
             def launch(below, above, U_c, U_f):
-                o = self._render(ctx, uv[below:above], camera, U_c, U_f, full=False, cam_desc=cam_desc)
+                # sample_pdf's NaN fallback keeps the reference's per-chunk granularity: batches start on chunk boundaries,
+                # except a slab's first batch, which may start inside a chunk another rank shares
+                o = self._render(ctx, uv[below:above], camera, U_c, U_f, full=False, cam_desc=cam_desc, nan_group=chunk,
+                                 nan_group_offset=below % chunk)
                 flags.append(o["_nan"])
                 for k in target_types:
                     parts[k].append(o[k])

@@ -685,6 +685,45 @@ def test_c3_full_frame_hierarchical_properties(dev, bunny_weights):
     assert torch.equal(c2, color[lo:hi])
 
 
+def test_nan_fallback_has_chunk_granularity(dev, bunny_weights):
+    """base_neural_render.py:105-114 decides the linspace fallback of sample_pdf per CALL, i.e. per `chunk` rays of render_image.
+    A batch that stands for several chunks (neddf_render_params.nan_group) must fall back only in the chunk that produced a NaN
+    sample, to the linspace of that chunk's first ray, and leave the other chunks exactly as they are without the NaN."""
+    g = golden("bunny_stages.npz")
+    r = bunny_render(dev, bunny_weights)
+    cam = make_camera(g, dev)
+    ctx = r._ctx(dev)
+    gen = torch.Generator(device=dev).manual_seed(21)
+    B, chunk = 50, 16                                         # chunks of 16, 16, 16, 2 rays
+    uv = torch.stack([torch.arange(B, device=dev) * 3 + 120, torch.arange(B, device=dev) * 2 + 150], 1)
+    U_c = torch.rand(B, 65, device=dev, generator=gen)
+    U_f = torch.rand(B, 129, device=dev, generator=gen)
+
+    def run(uf, group, offset=0):
+        dc, df = torch.empty(B, 65, device=dev), torch.empty(B, 194, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        ctx.render_rays(uv, cam.descriptor(), r._params(group, offset), U_c, uf, dict(color=torch.empty(B, 3, device=dev), dists_coarse=dc,
+                                                                                   dists_fine=df, nan_flag=flag))
+        return dc, df
+
+    _, clean = run(U_f, chunk)
+    bad = U_f.clone()
+    bad[21, 5] = float("nan")                                   # ray 21 lives in chunk 1 = rays 16..31
+    dc, df = run(bad, chunk)
+    lin = torch.linspace(float(dc[16, 0]), float(dc[16, -1]), 194, device=dev)
+    assert torch.equal(df[16:32], lin.unsqueeze(0).expand(16, 194)), "chunk 1 must be the linspace of ITS first ray"
+    assert torch.equal(df[:16], clean[:16]) and torch.equal(df[32:], clean[32:]), "other chunks must be untouched"
+    # nan_group = 0: the whole batch is one call of the reference -> every ray falls back to ray 0's linspace
+    dc, df = run(bad, 0)
+    lin0 = torch.linspace(float(dc[0, 0]), float(dc[0, -1]), 194, device=dev)
+    assert torch.equal(df, lin0.unsqueeze(0).expand(B, 194))
+    # a slab that starts 6 rays into a chunk: groups are rays [0,10), [10,26), ...; ray 21 is in the second one
+    dc, df = run(bad, chunk, 6)
+    lin10 = torch.linspace(float(dc[10, 0]), float(dc[10, -1]), 194, device=dev)
+    assert torch.equal(df[10:26], lin10.unsqueeze(0).expand(16, 194))
+    assert torch.equal(df[:10], clean[:10]) and torch.equal(df[26:], clean[26:])
+
+
 _RCCL_WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])

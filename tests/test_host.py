@@ -200,7 +200,7 @@ class Stub(NeRFRender):
         self.drawn = 0
     def _ctx(self, dev):
         return None
-    def _render(self, ctx, uv, camera, U_c, U_f, full, cam_desc=None):
+    def _render(self, ctx, uv, camera, U_c, U_f, full, cam_desc=None, **kw):
         self.drawn += U_c.numel() + U_f.numel()
         return {"color": torch.stack([U_c[:, 0], U_c[:, -1], U_f[:, 7]], 1), "depth": U_f[:, -1].clone(),
                 "_nan": torch.zeros(1, dtype=torch.int32)}
@@ -368,7 +368,7 @@ def test_render_image_rng_order_and_batching():
         def _ctx(self, dev):
             return None
 
-        def _render(self, ctx, uv, camera, U_c, U_f, full, cam_desc=None):
+        def _render(self, ctx, uv, camera, U_c, U_f, full, cam_desc=None, **kw):
             assert uv.shape[0] == U_c.shape[0] == U_f.shape[0]
             return {"color": torch.cat([U_c[:, :1], U_f[:, :1], uv[:, :1].float()], 1), "_nan": torch.zeros(1, dtype=torch.int32)}
 
