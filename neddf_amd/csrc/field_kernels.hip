@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
         // Early partials of skip layers (neddf.py:217-219).  With one skip connection (every shipped
         // config) and the 64-row tile the partial stays in registers until its layer; otherwise it is
         // parked in the per-workgroup global scratch.
-        constexpr bool REG_STASH = NW == 4 ? (MT == 2) && (WPS <= 2) && !Ops::kLean     // denser packings of a CU have no registers to spare
+        constexpr bool REG_STASH = NW == 4 ? ((MT == 2 && WPS <= 2) || (MT == 1 && WPS <= 4)) && !Ops::kLean     // denser packings of a CU have no registers to spare
                                            : (2 * MT * NT * 16 + OPREGS + 64 <= REG_BUDGET);
         // 128-row tiles at two workgroups per CU (16-bit operands: each fetched weight fragment feeds four M-tiles) have neither
         // the registers for a held partial nor the HBM bandwidth for a parked one: the skip layer re-encodes the positions into
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
             const int r = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
             return (f32x4v *)(act + r * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));
         };
-        constexpr bool FPRE = NW == 4 ? (MT == 2) && !ROWS4 && !Ops::kLean
+        constexpr bool FPRE = NW == 4 ? ((MT == 2 && WPS <= 2) || (MT == 1 && WPS <= 4)) && !ROWS4 && !Ops::kLean
                                       : !ROWS4 && (MT * NT * 16 + OPREGS + NF * 4 + 64 <= REG_BUDGET);
         f32x4v fpre[FPRE ? NF : 1];
         auto feature_src = [&](int idx) {
@@ -692,7 +692,9 @@ size_t field_lds_bytes(int mt) { return lds_bytes<OpsF32>(mt); }
 
 // Tile geometry (MT, WPS, NW) per operand policy -- see ddf_trunk_kernel.
 //   fp32        (2, 2, 4): 64-row tiles, two workgroups per CU (one workgroup's VALU epilogue overlaps the other's MFMA stream;
-//               measured on MI355X, C2 workload: 129 TF vs 118 TF for (4, 1, 4)).  NEDDF_TILE_MT=4 selects (4, 1, 4).
+//               measured on MI355X, C2 workload: 134 TF vs 118 TF for (4, 1, 4); 32-row tiles at three / four workgroups
+//               per CU -- more waves to cover barriers and epilogues -- reach 124 / 119 TF: two accumulator tiles per wave
+//               leave the MFMA stream too little independent work).  NEDDF_TILE_MT=4 selects (4, 1, 4).
 //   bf16        (4, 2, 4): 128-row tiles (half the LDS bytes of fp32) at two workgroups per CU: each fetched weight fragment
 //               feeds four M-tiles (7.78 ms per 2^21-point launch against 8.42 ms for (2, 2, 4)).
 //   split fp16  (2, 2, 4): two fp16 planes = the LDS bytes of fp32, same shape as fp32.

@@ -710,16 +710,20 @@ def test_nan_fallback_has_chunk_granularity(dev, bunny_weights):
     bad = U_f.clone()
     bad[21, 5] = float("nan")                                   # ray 21 lives in chunk 1 = rays 16..31
     dc, df = run(bad, chunk)
-    lin = torch.linspace(float(dc[16, 0]), float(dc[16, -1]), 194, device=dev)
-    assert torch.equal(df[16:32], lin.unsqueeze(0).expand(16, 194)), "chunk 1 must be the linspace of ITS first ray"
+    def lin_of(row):            # the reference's fallback runs torch.linspace on the CPU
+        return torch.linspace(float(dc[row, 0]), float(dc[row, -1]), 194).to(dev)
+
+    lin = lin_of(16)
+    assert torch.equal(df[16:32], lin.unsqueeze(0).expand(16, 194)), ("chunk 1 must be the linspace of ITS first ray",
+                                                                     float((df[16:32] - lin).abs().max()), float((df[16:32] - clean[16:32]).abs().max()))
     assert torch.equal(df[:16], clean[:16]) and torch.equal(df[32:], clean[32:]), "other chunks must be untouched"
     # nan_group = 0: the whole batch is one call of the reference -> every ray falls back to ray 0's linspace
     dc, df = run(bad, 0)
-    lin0 = torch.linspace(float(dc[0, 0]), float(dc[0, -1]), 194, device=dev)
+    lin0 = lin_of(0)
     assert torch.equal(df, lin0.unsqueeze(0).expand(B, 194))
     # a slab that starts 6 rays into a chunk: groups are rays [0,10), [10,26), ...; ray 21 is in the second one
     dc, df = run(bad, chunk, 6)
-    lin10 = torch.linspace(float(dc[10, 0]), float(dc[10, -1]), 194, device=dev)
+    lin10 = lin_of(10)
     assert torch.equal(df[10:26], lin10.unsqueeze(0).expand(16, 194))
     assert torch.equal(df[:10], clean[:10]) and torch.equal(df[26:], clean[26:])
 

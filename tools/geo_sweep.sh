@@ -1,5 +1,5 @@
 #!/bin/bash
-# Tile-geometry sweep of the 16-bit operand policies on the headline workload (one line per variant).
+# Tile-geometry sweep on the headline workload (one line per variant): tools/geo_sweep.sh [f32|16bit|all]
 cd "$(dirname "$0")/.."
 run() {  # dtype, env assignment
   out=$(env $2 python bench.py --dtype $1 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1)
@@ -12,9 +12,17 @@ print("%-10s %-28s %9.0f rays/s  ddf %.3f ms (%.0f TF, %.1f%%)  col %.3f ms (%.0
     r["colour_kernel"]["achieved"], d.get("psnr_vs_oracle_db", float("nan"))))
 PY
 }
-run f16_split NEDDF_SPLIT_GEO=4x1x8
-run f16_split NEDDF_SPLIT_GEO=2x2x4
-run bf16 NEDDF_BF16_GEO=4x2x8
-run bf16 NEDDF_BF16_GEO=4x1x8
-run bf16 NEDDF_BF16_GEO=4x2x4
-run bf16 NEDDF_BF16_GEO=2x2x4
+what=${1:-all}
+if [ "$what" = f32 ] || [ "$what" = all ]; then
+  run f32 NEDDF_F32_GEO=2x2x4
+  run f32 NEDDF_F32_GEO=1x4x4
+  run f32 NEDDF_F32_GEO=1x3x4
+fi
+if [ "$what" = 16bit ] || [ "$what" = all ]; then
+  run f16_split NEDDF_SPLIT_GEO=4x1x8
+  run f16_split NEDDF_SPLIT_GEO=2x2x4
+  run bf16 NEDDF_BF16_GEO=4x2x8
+  run bf16 NEDDF_BF16_GEO=4x1x8
+  run bf16 NEDDF_BF16_GEO=4x2x4
+  run bf16 NEDDF_BF16_GEO=2x2x4
+fi
