@@ -29,10 +29,21 @@ __device__ __forceinline__ float tanh_nonneg(float u)
 // instead of 23 -- in those kernels the matrix pipe and the VALU hardly overlap, so every instruction is wall time.
 __device__ __forceinline__ void tanhexp_grad_fast(float x, float &y, float &dy)
 {
-    float ex = fast_exp(fminf(x, 40.0f));
+    // v_med3_f32 clamps in ONE instruction (fminf costs a NaN-quieting v_max in front of its v_min)
+    float ex = fast_exp(__builtin_amdgcn_fmed3f(x, -3.0e38f, 40.0f));
     float e2 = __builtin_amdgcn_exp2f(ex * 2.8853900817779268f);
     float tx = fmaf(-2.0f, __builtin_amdgcn_rcpf(e2 + 1.0f), 1.0f);
     y = x * tx;
+    dy = fmaf(-(x * ex), fmaf(tx, tx, -1.0f), tx);
+}
+
+// the same, returning tanh(e^x) and the derivative so that the caller can form y = x t and the Jacobian products as packed
+// multiplies: (x, z1) * (t, dy) and (z2, z3) * (dy, dy)
+__device__ __forceinline__ void tanhexp_parts_fast(float x, float &tx, float &dy)
+{
+    float ex = fast_exp(__builtin_amdgcn_fmed3f(x, -3.0e38f, 40.0f));
+    float e2 = __builtin_amdgcn_exp2f(ex * 2.8853900817779268f);
+    tx = fmaf(-2.0f, __builtin_amdgcn_rcpf(e2 + 1.0f), 1.0f);
     dy = fmaf(-(x * ex), fmaf(tx, tx, -1.0f), tx);
 }
 
@@ -61,7 +72,7 @@ template <int KIND, bool FAST = false>
 __device__ __forceinline__ float act_val(float x)
 {
     if (FAST && KIND == 2) {
-        float ex = fast_exp(fminf(x, 40.0f));
+        float ex = fast_exp(__builtin_amdgcn_fmed3f(x, -3.0e38f, 40.0f));
         float e2 = __builtin_amdgcn_exp2f(ex * 2.8853900817779268f);
         return x * fmaf(-2.0f, __builtin_amdgcn_rcpf(e2 + 1.0f), 1.0f);
     }

@@ -36,6 +36,7 @@ struct OpsF32 {
     static constexpr bool kFastAct = false;
     static constexpr int kPlanes = 1, kPlane = 0;
     static constexpr bool kLean = false;     // room for register-resident extras (skip partial, feature prefetch)
+    static constexpr bool kPackedRows = false;
     static constexpr float kWScale = 1.0f;   // packed weights = kWScale * w
     static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
     static __device__ __forceinline__ void zero(act_t *p) { *p = 0.f; }
@@ -77,6 +78,17 @@ struct OpsBF16 {
         return __builtin_bit_cast(unsigned int, o) & 0xffffu;
     }
     static __device__ __forceinline__ void put(act_t *p, float v) { *p = cvt(v); }
+    // four values of one column to four consecutive rows: two packed conversions, the upper halves stored with d16_hi
+    static constexpr bool kPackedRows = true;
+    static __device__ __forceinline__ void put_rows4(act_t *p, int ld, float v0, float v1, float v2, float v3)
+    {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const unsigned int a = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){ v0, v1 }, bf16x2));
+        const unsigned int b = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){ v2, v3 }, bf16x2));
+        p[0] = (unsigned short)a; p[ld] = (unsigned short)(a >> 16);
+        p[2 * ld] = (unsigned short)b; p[3 * ld] = (unsigned short)(b >> 16);
+    }
     static __device__ __forceinline__ float get(const act_t *p) { return __builtin_bit_cast(float, (unsigned int)*p << 16); }
     static __device__ __forceinline__ void load4(const act_t *p, float (&x)[4])
     {
@@ -111,6 +123,7 @@ struct OpsF16Split {
     static constexpr bool kFast = false;
     static constexpr bool kFastAct = false;
     static constexpr bool kLean = false;                 // measured: register-resident skip partial / feature prefetch pay off here too
+    static constexpr bool kPackedRows = false;
     static constexpr float kWScale = 1024.0f;            // weights are packed as 2^10 w
     static __device__ __forceinline__ float f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
     static __device__ __forceinline__ void put(act_t *p, float v)
@@ -331,7 +344,29 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[MT][NT], typename O
                     z[r] = acc[mt][t][4 * g + r];
                     if constexpr (Ops::kWScale != 1.0f) z[r] *= (1.0f / Ops::kWScale);      // exact: a power of two
                 }
-                if (ROWS4) {
+                if constexpr (Ops::kPackedRows) {
+                    // 16-bit policies are VALU-bound (profiles/r02_geometry_sweep.md): packed multiplies (x, z1) * (t, y') and
+                    // (z2, z3) * (y', y'), two packed conversions, four 2-byte stores
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    if (ROWS4) {
+                        f32x2 lo, hi;
+                        if constexpr (KIND == 2 && Ops::kFastAct) {
+                            float tx, dy;
+                            tanhexp_parts_fast(z[0], tx, dy);
+                            lo = (f32x2){ z[0], z[1] } * (f32x2){ tx, dy };
+                            hi = (f32x2){ z[2], z[3] } * (f32x2){ dy, dy };
+                        } else {
+                            float y, dy;
+                            act_grad<KIND, Ops::kFastAct>(z[0], y, dy);
+                            lo = (f32x2){ y, dy * z[1] };
+                            hi = (f32x2){ z[2], z[3] } * (f32x2){ dy, dy };
+                        }
+                        Ops::put_rows4(o + (8 * g) * LD, LD, lo[0], lo[1], hi[0], hi[1]);
+                    } else {
+                        Ops::put_rows4(o + (8 * g) * LD, LD, act_val<KIND, Ops::kFastAct>(z[0]), act_val<KIND, Ops::kFastAct>(z[1]),
+                                       act_val<KIND, Ops::kFastAct>(z[2]), act_val<KIND, Ops::kFastAct>(z[3]));
+                    }
+                } else if (ROWS4) {
                     float y, dy;
                     act_grad<KIND, Ops::kFastAct>(z[0], y, dy);
                     Ops::put(o + (8 * g + 0) * LD, y);

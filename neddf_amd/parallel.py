@@ -92,6 +92,14 @@ def gather_pixels(local: Tensor, n_total: int, group=None, force_collective: boo
     world = dist.get_world_size(group)
     if world == 1 and not force_collective:
         return local if wait else PixelGather(None, local)
+    if local.is_cuda and "nccl" not in str(dist.get_backend(group)):
+        # a process group without a device backend (gloo: several test ranks sharing one GPU, where RCCL cannot form a
+        # communicator): stage the slab through the host
+        full = gather_pixels(local.cpu(), n_total, group, force_collective).to(local.device)
+        if out is not None:
+            out.copy_(full)
+            full = out
+        return full if wait else PixelGather(None, full)
     if local.is_cuda:
         from ._lib import Context
         ctx = Context.get(local.device)

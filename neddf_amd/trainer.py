@@ -16,7 +16,7 @@ from .config import instantiate, to_plain
 from .dataset import imwrite_bgr
 from .logger import ScalarLog
 from .metrics import peak_signal_noise_ratio, structural_similarity
-from .parallel import average_gradients
+from .parallel import average_gradients, render_image_sharded
 
 
 def _get(cfg: Any, key: str) -> Any:
@@ -40,6 +40,7 @@ class BaseTrainer:
         self.epoch_max, self.epoch_save_fields = epoch_max, epoch_save_fields
         self.epoch_test_rendering, self.epoch_save_model = epoch_test_rendering, epoch_save_model
         self.scheduler_lr, self.optimizer_lr, self.optimizer_weight_decay = scheduler_lr, optimizer_lr, optimizer_weight_decay
+        self.writes_outputs = True      # multi-rank runs: rank 0 only (scripts/run.py, scripts/run_eval.py set it)
         self.dataset = instantiate(_get(self.config, "dataset"))
         self.camera_calib = PinholeCalib(self.dataset[0]["camera_calib_params"]).to(self.device)
         self.cameras: List[Camera] = [Camera(self.camera_calib, self.dataset[i]["camera_params"]).to(self.device)
@@ -58,7 +59,14 @@ class BaseTrainer:
         camera = self.cameras[camera_id]
         camera.update_transform()
         h, w = rgb_gt.shape[0], rgb_gt.shape[1]
-        images = self.neural_render.render_image(w, h, camera, ["color", "depth"], downsampling, self.chunk)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            # under a launcher (scripts/run_eval.py, BASELINE.json configs[3]): every rank renders a slab of the frame's pixel
+            # index, one all-gather of the pixels, rank 0 writes the files.  Same seed on every rank => the single-GPU image
+            images = render_image_sharded(self.neural_render, w, h, camera, ["color", "depth"], downsampling, self.chunk)
+            if not self.writes_outputs:
+                return
+        else:
+            images = self.neural_render.render_image(w, h, camera, ["color", "depth"], downsampling, self.chunk)
         rgb_np = torch.clamp(images["color"] * 255, 0, 255).detach().cpu().numpy().astype(np.uint8)
         depth_np = torch.clamp((images["depth"] - 2.0) / 4.0 * 50000 / 256, 0, 255).detach().cpu().numpy().astype(np.uint8)
         output_dir = Path(output_dir)
@@ -75,7 +83,8 @@ class BaseTrainer:
         """base_trainer.py:176-188"""
         self.neural_render.set_iter(-1)
         for camera_id in range(len(self.dataset)):
-            print("rendering from camera {}".format(camera_id))
+            if self.writes_outputs:
+                print("rendering from camera {}".format(camera_id))
             self.render_test(output_dir, camera_id, 1)
 
     def render_field_slices(self, output_field_dir: Path, epoch: int = 0) -> None:
@@ -119,7 +128,6 @@ class NeRFTrainer(BaseTrainer):
                                           weight_decay=self.optimizer_weight_decay)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=self.scheduler_lr)
         self.logger = None      # created by the first training step: evaluation runs leave no ./log behind
-        self.writes_outputs = True      # data-parallel runs (scripts/run.py under a launcher): rank 0 only
 
     def run_train(self) -> None:
         """nerf_trainer.py:47-79: epochs over a random permutation of the frames, outputs under the working directory

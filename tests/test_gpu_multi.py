@@ -174,3 +174,45 @@ def test_smoke_under_asan():
                        timeout=900)
     assert p.returncode == 0 and "smoke ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
     assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]
+
+
+def test_run_eval_under_a_launcher_matches_single_process(tmp_path):
+    """BASELINE.json configs[3] through the reference's own CLI: `torch.distributed.run --nproc-per-node 2 neddf/scripts/run_eval.py`
+    (rays of every view sharded over the ranks, pixel all-gather, rank 0 writes) must produce byte-identical PNGs to the
+    single-process run of the same command.  One-GPU boxes: the two ranks share the device and the slabs travel through gloo."""
+    import yaml
+    from conftest import BUNNY_CFG
+    from test_host import _make_dataset
+    wts = golden("bunny_weights.npz")
+    ds_dir = str(tmp_path / "ds")
+    _make_dataset(ds_dir, n=2, w=20, h=16)
+    cfg = {"dataset": {"_target_": "neddf.dataset.NeRFSyntheticDataset", "dataset_dir": ds_dir, "data_split": "train",
+                       "use_depth": False, "use_mask": True},
+           "render": {"_target_": "neddf.render.NeRFRender", "sample_coarse": 64, "sample_fine": 128, "dist_near": 2.0,
+                      "dist_far": 6.0, "max_dist": 6.0, "use_coarse_network": False, "sampling_type": "cone"},
+           "network": dict(BUNNY_CFG, _target_="neddf.network.NeDDF"),
+           "trainer": {"_target_": "neddf.trainer.NeRFTrainer", "device": "cuda:0", "batch_size": 128, "chunk": 100},
+           "loss": {"functions": [{"_target_": "neddf.loss.ColorLoss", "weight": 1.0}]}}
+    sd = {p + k: torch.from_numpy(wts[k]) for k in wts.files for p in ("network_fine.", "network_coarse.")}
+    script = os.path.join(ROOT, "neddf", "scripts", "run_eval.py")
+    outs = {}
+    for tag, launcher in (("one", []), ("two", ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                                "--master-port", str(29900 + os.getpid() % 90)])):
+        run = tmp_path / tag
+        (run / ".hydra").mkdir(parents=True)
+        (run / "models").mkdir()
+        yaml.safe_dump(cfg, open(run / ".hydra" / "config.yaml", "w"))
+        torch.save(sd, run / "models" / "model_00007.pth")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        if torch.cuda.device_count() < 2:
+            env["NEDDF_DIST_BACKEND"] = "gloo"
+        p = subprocess.run([sys.executable] + launcher + [script, str(run), "--epoch", "7"], env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        assert p.stdout.count("psnr:") == 2, p.stdout[-2000:]          # rank 0 only prints
+        outs[tag] = run / "eval"
+    for i in range(2):
+        for suffix in ("rgb", "rgb_gt", "depth"):
+            name = "%03d_%s.png" % (i, suffix)
+            assert (outs["one"] / name).read_bytes() == (outs["two"] / name).read_bytes(), name
