@@ -9,6 +9,8 @@
 #include "capi_internal.h"
 #include "train_kernels.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct Plan {
@@ -449,7 +451,8 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     const Field &f = ctx->field[slot];
     const int act = f.d.activation;
     const int sp = f.d.weight_dtype == NEDDF_DTYPE_F16_SPLIT;      // GEMM operands as two fp16 terms (tile_engine.h)
-    if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
+    // packed weights of a whole layer stack: [layer][256 x 256] + the narrow first-layer / skip segments
+    if (int rc = ensure(ctx, ctx->tpack, (size_t)(kMaxLayers + 2) * kPackFloats * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ttmp, ((size_t)p.R * (kLdPe + kLdNarrow) + (size_t)N * kLdDir) * sizeof(float))) return rc;
     float *wp = (float *)ctx->tpack.p, *wp2 = wp + kPackFloats;
     float *PEu = (float *)ctx->ttmp.p, *Ed = PEu + (size_t)p.R * kLdPe, *ZH = Ed + (size_t)N * kLdDir;
@@ -457,22 +460,51 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     TrainPointArgs a;
     point_args(a, f, p, ws);
     launch_pe_rows(pos, dir, var, N, a.enc, PEs, PEu, kLdPe, Ed, kLdDir, s);
-    // distance trunk (neddf.py:206-218)
-    for (int l = 0; l < p.n_trunk; ++l) {
-        float *Z = ws + p.o_z[l], *H = ws + p.o_h[l];
-        const bool wide = l > 0 && in_skips(f.d, l - 1);
-        const int kpe = (p.Cpe + 3) & ~3;       // loaded width of the encoding matrix (pad columns are zero)
-        if (l == 0) {
-            launch_pack(sp, W[0], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp, s);
-            launch_rows_gemm(sp, PEs, p.R, kLdPe, kpe, wp, gemm_ksteps(p.Cpe, sp), B[0], 4, Z, kWidth, 0, act, H, ctx->cus, s);
-        } else if (!wide) {
-            launch_pack(sp, W[l], kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(sp, ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 4, Z, kWidth, 0, act, H, ctx->cus, s);
-        } else {            // hx = cat([embed_pos_scaled, hx]): the encoding feeds rows 0 .. Cpe-1 of the weight
-            launch_pack(sp, W[l], kWidth, 1, p.Cpe, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(sp, ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 4, Z, kWidth, 0, -1, nullptr, ctx->cus, s);
-            launch_pack(sp, W[l], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp2, s);
-            launch_rows_gemm(sp, PEs, p.R, kLdPe, kpe, wp2, gemm_ksteps(p.Cpe, sp), nullptr, 4, Z, kWidth, 1, act, H, ctx->cus, s);
+    // NEDDF_TRAIN_UNFUSED=1: one GEMM kernel per layer (the round-1 forward), kept for A/B measurements
+    static const bool unfused = [] { const char *e = getenv("NEDDF_TRAIN_UNFUSED"); return e && atoi(e) != 0; }();
+    const int kpe = (p.Cpe + 3) & ~3;       // loaded width of the encoding matrix (pad columns are zero)
+    float *pack_at = wp;
+    auto next_pack = [&]() { float *r = pack_at; pack_at += kPackFloats; return r; };
+    // distance trunk (neddf.py:206-218); the fused kernel holds one skip partial, architectures with more take the per-layer route
+    int n_wide = 0;
+    for (int l = 1; l < p.n_trunk; ++l) n_wide += in_skips(f.d, l - 1) ? 1 : 0;
+    if (!unfused && n_wide <= 1) {
+        MlpForwardArgs m{};
+        m.R = p.R; m.X0 = PEs; m.ld0 = kLdPe; m.kload0 = kpe; m.ksteps0 = gemm_ksteps(p.Cpe, sp);
+        m.n_layers = p.n_trunk; m.skip_layer = -1; m.act_kind = act;
+        float *w0 = next_pack();
+        launch_pack(sp, W[0], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, w0, s);
+        m.wp0 = w0;
+        for (int l = 0; l < p.n_trunk; ++l) {
+            const bool wide = l > 0 && in_skips(f.d, l - 1);
+            m.bias[l] = B[l]; m.Z[l] = ws + p.o_z[l]; m.H[l] = ws + p.o_h[l];
+            if (l == 0) continue;
+            float *wl = next_pack();
+            launch_pack(sp, W[l], kWidth, 1, wide ? p.Cpe : 0, 0, kWidth, kWidth, kWidth, wl, s);
+            m.wp[l] = wl;
+            if (wide) {         // hx = cat([embed_pos_scaled, hx]): the encoding feeds rows 0 .. Cpe-1 of the weight
+                float *wsk = next_pack();
+                launch_pack(sp, W[l], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wsk, s);
+                m.skip_layer = l; m.wp_skip = wsk;
+            }
+        }
+        launch_mlp_forward(sp, m, ctx->cus, s);
+    } else {
+        for (int l = 0; l < p.n_trunk; ++l) {
+            float *Z = ws + p.o_z[l], *H = ws + p.o_h[l];
+            const bool wide = l > 0 && in_skips(f.d, l - 1);
+            if (l == 0) {
+                launch_pack(sp, W[0], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp, s);
+                launch_rows_gemm(sp, PEs, p.R, kLdPe, kpe, wp, gemm_ksteps(p.Cpe, sp), B[0], 4, Z, kWidth, 0, act, H, ctx->cus, s);
+            } else if (!wide) {
+                launch_pack(sp, W[l], kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
+                launch_rows_gemm(sp, ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 4, Z, kWidth, 0, act, H, ctx->cus, s);
+            } else {
+                launch_pack(sp, W[l], kWidth, 1, p.Cpe, 0, kWidth, kWidth, kWidth, wp, s);
+                launch_rows_gemm(sp, ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 4, Z, kWidth, 0, -1, nullptr, ctx->cus, s);
+                launch_pack(sp, W[l], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp2, s);
+                launch_rows_gemm(sp, PEs, p.R, kLdPe, kpe, wp2, gemm_ksteps(p.Cpe, sp), nullptr, 4, Z, kWidth, 1, act, H, ctx->cus, s);
+            }
         }
     }
     const float *Hlast = ws + p.o_h[p.n_trunk - 1];
@@ -485,17 +517,36 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     a.distance = distance; a.density = density; a.aux_grad = aux_grad;
     launch_point_forward(a, s);
     // colour trunk (neddf.py:243-258)
-    for (int l = 0; l < p.n_col; ++l) {
-        float *Z = ws + p.o_zc[l], *H = ws + p.o_hc[l];
-        const float *Wl = W[p.n_trunk + l], *Bl = B[p.n_trunk + l];
-        if (l == 0) {
-            launch_pack(sp, Wl, kWidth, 1, 0, 0, p.Ca, kWidth, kWidth, wp, s);
-            launch_rows_gemm(sp, ws + p.o_xa, p.R, p.ldxa, p.ldxa, wp, gemm_ksteps(p.Ca, sp), Bl, 4, Z, kWidth, 0, -1, nullptr, ctx->cus, s);
-            launch_pack(sp, Wl, kWidth, 1, p.Ca, 0, kWidth, kWidth, kWidth, wp2, s);
-            launch_rows_gemm(sp, Hlast, p.R, kWidth, kWidth, wp2, gemm_ksteps(kWidth, sp), nullptr, 4, Z, kWidth, 1, act, H, ctx->cus, s);
-        } else {
-            launch_pack(sp, Wl, kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(sp, ws + p.o_hc[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), Bl, 4, Z, kWidth, 0, act, H, ctx->cus, s);
+    if (!unfused) {
+        MlpForwardArgs m{};
+        m.R = p.R; m.X0 = ws + p.o_xa; m.ld0 = p.ldxa; m.kload0 = p.ldxa; m.ksteps0 = gemm_ksteps(p.Ca, sp);
+        m.X1 = Hlast; m.n_layers = p.n_col; m.skip_layer = -1; m.act_kind = act;
+        pack_at = wp;           // same stream: the trunk kernel is done with the buffer when these packs run
+        float *w0 = next_pack(), *w1 = next_pack();
+        launch_pack(sp, W[p.n_trunk], kWidth, 1, 0, 0, p.Ca, kWidth, kWidth, w0, s);
+        launch_pack(sp, W[p.n_trunk], kWidth, 1, p.Ca, 0, kWidth, kWidth, kWidth, w1, s);
+        m.wp0 = w0; m.wp1 = w1;
+        for (int l = 0; l < p.n_col; ++l) {
+            m.bias[l] = B[p.n_trunk + l]; m.Z[l] = ws + p.o_zc[l]; m.H[l] = ws + p.o_hc[l];
+            if (l == 0) continue;
+            float *wl = next_pack();
+            launch_pack(sp, W[p.n_trunk + l], kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wl, s);
+            m.wp[l] = wl;
+        }
+        launch_mlp_forward(sp, m, ctx->cus, s);
+    } else {
+        for (int l = 0; l < p.n_col; ++l) {
+            float *Z = ws + p.o_zc[l], *H = ws + p.o_hc[l];
+            const float *Wl = W[p.n_trunk + l], *Bl = B[p.n_trunk + l];
+            if (l == 0) {
+                launch_pack(sp, Wl, kWidth, 1, 0, 0, p.Ca, kWidth, kWidth, wp, s);
+                launch_rows_gemm(sp, ws + p.o_xa, p.R, p.ldxa, p.ldxa, wp, gemm_ksteps(p.Ca, sp), Bl, 4, Z, kWidth, 0, -1, nullptr, ctx->cus, s);
+                launch_pack(sp, Wl, kWidth, 1, p.Ca, 0, kWidth, kWidth, kWidth, wp2, s);
+                launch_rows_gemm(sp, Hlast, p.R, kWidth, kWidth, wp2, gemm_ksteps(kWidth, sp), nullptr, 4, Z, kWidth, 1, act, H, ctx->cus, s);
+            } else {
+                launch_pack(sp, Wl, kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
+                launch_rows_gemm(sp, ws + p.o_hc[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), Bl, 4, Z, kWidth, 0, act, H, ctx->cus, s);
+            }
         }
     }
     NarrowW cout{};

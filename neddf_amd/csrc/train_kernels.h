@@ -49,6 +49,28 @@ inline int gemm_ksteps(int K, int split) { return split ? (K + 15) / 16 : (K + 7
 // (train_kernels.hip operand_scale); ignored by the fp32 MFMA kernels
 void launch_rows_gemm(int split, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, const float *bias, int bias_period,
                       float *Y, int ldy, int accumulate, int act_kind, float *H, int cus, hipStream_t s, const float *amax_in = nullptr);
+// Forward of a whole stack of (value, Jacobian)-row layers in ONE kernel (round 2): the 64-row tile stays in LDS across the layers
+// like in the inference kernels, and every layer leaves its pre-activations Z_l and activations H_l in the workspace from the
+// epilogue (what the hand-written backward passes consume) -- 2 KB of HBM traffic per row and layer instead of the 3 KB of one
+// GEMM kernel per layer (read H_{l-1}, write Z_l, write H_l), and no per-layer launch / fill / drain.
+//   layer 0:  Z_0 = X0[R, 0:kload0) x wp0 (+ X1[R, 256] x wp1) + bias_0        (X1: the colour trunk's 256 trunk features)
+//   layer l:  Z_l = H_{l-1} x wp[l] (+ X0 x wp_skip if l == skip_layer) + bias_l     (skip: cat([X0, h]) of neddf.py:217-219)
+//   H_l = a(Z_l) on (value, 3 Jacobian) row groups; biases on value rows only (linear.py:43-45)
+struct MlpForwardArgs {
+    int64_t R;
+    const float *X0; int ld0, kload0;     // kload0: loaded width, multiple of 4, zero beyond the logical K
+    const float *wp0; int ksteps0;
+    const float *X1; const float *wp1;    // optional second input of layer 0 (ld 256, 256 columns) and its packed weights
+    int n_layers;
+    const float *wp[kMaxLayers];          // [l >= 1] packed 256 x 256
+    const float *bias[kMaxLayers];        // [l >= 0] device pointers, 256 floats
+    int skip_layer;                       // -1, or the layer that also consumes X0
+    const float *wp_skip;                 // its X0 segment (ksteps0 super-steps)
+    float *Z[kMaxLayers], *H[kMaxLayers]; // [R, 256] each
+    int act_kind;
+};
+void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t s);
+
 // dW[k * sk + n * sn] += sum_r X[r, k] G[r, n], k < K <= 256, n < nvalid <= 256; db[n] += sum over rows r % bias_period == 0 of G[r, n]
 // dZ[R,256] = activation backward (pre-activations Zprev, row period, kind) of X[R, 0:kload) x Wpacked: the input-gradient GEMM of
 // a layer fused with the backward of the previous layer's activation

@@ -1,10 +1,11 @@
 // train_kernels.hip -- building blocks of the training step.
 //
-// The training path is deliberately UNFUSED in round 1: one kernel per layer with
-// row-major activation matrices in HBM ([4N, C]: value + Jacobian rows of N sample
+// Activations are row-major matrices in HBM ([4N, C]: value + Jacobian rows of N sample
 // points), so that the forward pass leaves behind exactly what the hand-written
 // backward passes of the reference need (neddf/nn_module/with_grad/*.py backward
-// staticmethods).  All dense work -- forward layers, dX = dZ W^T and the weight
+// staticmethods).  The NeDDF forward runs its two layer stacks fused (mlp_forward_kernel,
+// round 2: the inference tile engine with side stores of Z_l / H_l); the backward pass
+// and the NeRF / NeuS fields are one kernel per layer.  All dense work -- forward layers, dX = dZ W^T and the weight
 // gradient dW = X^T dZ -- runs on the same fp32 MFMA tile engine as the fused
 // inference kernels; the elementwise pieces reuse device_math.h.  Training batches
 // are ~10^5 points, two orders of magnitude below a rendered frame, so the extra
@@ -274,6 +275,134 @@ void launch_rows_gemm_actback(int split, const float *X, int64_t R, int ldx, int
 {
     launch_rows_gemm_mode(2, split, X, R, ldx, kload, wp, ksteps, nullptr, period, dZ, ldy, 0, act_kind, const_cast<float *>(Zprev), cus, s,
                           amax_in, amax_out);
+}
+
+// ----------------------------------------------------------------------------
+// Fused forward of a layer stack (train_kernels.h MlpForwardArgs): the inference tile engine with side stores.
+// 64-row tiles, two workgroups per CU.  The skip layer's X0 product is taken at tile start, while X0 sits in LDS, and held in
+// registers until its layer (as in ddf_trunk_kernel).  Z_l / H_l leave from the accumulator registers: a store instruction
+// covers 2 rows x 32 consecutive columns = two full 128-byte lines.
+// HOLD: the skip partial waits in 64 registers (fp32); otherwise X0 is staged a second time at the skip layer (split fp16: its
+// conversion-heavy epilogue has no registers to spare -- 136 spilled with the partial held)
+template <class Ops, bool HOLD>
+__global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwardArgs a)
+{
+    typedef typename Ops::act_t act_t;
+    typedef typename Ops::bfrag frag;
+    constexpr int MT = 2, NT = 2, ROWS = MT * 32, LD = Ops::kLd;
+    constexpr float unscale = 1.0f / Ops::kWScale;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    act_t *act = (act_t *)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
+    const int64_t ntiles = (a.R + ROWS - 1) / ROWS;
+    const int c4n = a.kload0 >> 2, kpack0 = Ops::kStep * a.ksteps0;
+    auto frags = [&](const float *wp, int ksteps) { return (const frag *)wp + (size_t)wave * NT * ksteps * 64 + lane; };
+    auto stage = [&](const float *X, int ld, int c4cols, int kpack, int64_t r0) {       // X[r0 .. r0+64, 0:4*c4cols) -> LDS, zero padded to kpack
+        for (int idx = tid; idx < ROWS * c4cols; idx += kThreads) {
+            const int r = idx / c4cols, c = idx - r * c4cols;
+            f32x4v v = { 0.f, 0.f, 0.f, 0.f };
+            if (r0 + r < a.R) v = *(const f32x4v *)(X + (r0 + r) * ld + 4 * c);
+            Ops::put4(act + r * LD + 4 * c, v);
+        }
+        const int w = kpack - 4 * c4cols;
+        for (int i = tid; i < ROWS * w; i += kThreads) {
+            const int r = i / w, c = i - r * w;
+            Ops::zero(act + r * LD + 4 * c4cols + c);
+        }
+    };
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * ROWS;
+        __syncthreads();                // the previous tile is done with the LDS tile
+        stage(a.X0, a.ld0, c4n, kpack0, r0);
+        __syncthreads();
+        f32x16 acc[MT][NT], held[HOLD ? MT : 1][HOLD ? NT : 1];
+        if constexpr (HOLD) {
+            if (a.skip_layer >= 0) {
+                acc_init<MT, NT, true>(held, nullptr, wave, lane);
+                dense<MT, NT, Ops>(held, act_lane, frags(a.wp_skip, a.ksteps0), a.ksteps0);
+            }
+        }
+        acc_init<MT, NT, true>(acc, a.bias[0], wave, lane, Ops::kWScale);
+        dense<MT, NT, Ops>(acc, act_lane, frags(a.wp0, a.ksteps0), a.ksteps0);
+        if (a.X1) {
+            __syncthreads();
+            stage(a.X1, kWidth, kWidth / 4, kWidth, r0);
+            __syncthreads();
+            dense<MT, NT, Ops>(acc, act_lane, frags(a.wp1, kWidth / Ops::kStep), kWidth / Ops::kStep);
+        }
+        for (int l = 0; l < a.n_layers; ++l) {
+            if (l > 0) {
+                acc_init<MT, NT, true>(acc, a.bias[l], wave, lane, Ops::kWScale);
+                if constexpr (HOLD) {
+                    if (l == a.skip_layer) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[mt][t] += held[mt][t];
+                    }
+                }
+                dense<MT, NT, Ops>(acc, act_lane, frags(a.wp[l], kWidth / Ops::kStep), kWidth / Ops::kStep);
+                if constexpr (!HOLD) {
+                    if (l == a.skip_layer) {
+                        __syncthreads();            // every wave finished reading the hidden state
+                        stage(a.X0, a.ld0, c4n, kpack0, r0);
+                        __syncthreads();
+                        dense<MT, NT, Ops>(acc, act_lane, frags(a.wp_skip, a.ksteps0), a.ksteps0);
+                    }
+                }
+            }
+            __syncthreads();            // every wave finished reading the previous activations
+            float *Zl = a.Z[l], *Hl = a.H[l];
+            const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int col = (wave * NT + t) * 32 + j;
+                    act_t *o = act + (mt * 32 + 4 * h) * LD + col;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int64_t row = r0 + mt * 32 + 8 * g + 4 * h;      // first of the four rows of this point
+                        float z[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) z[r] = acc[mt][t][4 * g + r] * unscale;
+                        float y, dy;
+                        if (a.act_kind == 0) act_grad<0>(z[0], y, dy); else if (a.act_kind == 1) act_grad<1>(z[0], y, dy); else act_grad<2>(z[0], y, dy);
+                        const float hv[4] = { y, dy * z[1], dy * z[2], dy * z[3] };
+                        if (row < a.R) {            // R is a multiple of 4: a point's rows are all inside or all outside
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                Zl[(row + r) * kWidth + col] = z[r];
+                                Hl[(row + r) * kWidth + col] = hv[r];
+                            }
+                        }
+                        if (l + 1 < a.n_layers) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) Ops::put(o + (8 * g + r) * LD, hv[r]);
+                        }
+                    }
+                }
+            if (l + 1 < a.n_layers) __syncthreads();        // the next layer reads what this epilogue wrote
+        }
+    }
+}
+
+template <class Ops, bool HOLD>
+static void launch_mlp_forward_ops(const MlpForwardArgs &a, int cus, hipStream_t s)
+{
+    constexpr size_t lds = (size_t)64 * Ops::kLd * sizeof(typename Ops::act_t);
+    static bool once = ((void)hipFuncSetAttribute((const void *)mlp_forward_kernel<Ops, HOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    const int64_t tiles = (a.R + 63) / 64;
+    hipLaunchKernelGGL((mlp_forward_kernel<Ops, HOLD>), dim3((unsigned)(tiles < 2 * cus ? tiles : 2 * cus)), dim3(kThreads), lds, s, a);
+}
+
+void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t s)
+{
+    if (a.R <= 0) return;
+    if (split) launch_mlp_forward_ops<OpsF16Split, false>(a, cus, s);
+    else launch_mlp_forward_ops<OpsF32, true>(a, cus, s);
 }
 
 // ----------------------------------------------------------------------------
