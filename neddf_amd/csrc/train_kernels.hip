@@ -16,6 +16,8 @@
 #include "tile_engine.h"
 #include "train_kernels.h"
 
+#include <type_traits>
+
 namespace neddf {
 
 // ----------------------------------------------------------------------------
@@ -282,6 +284,46 @@ void launch_rows_gemm_actback(int split, const float *X, int64_t R, int ldx, int
 // 64-row tiles, two workgroups per CU.  The skip layer's X0 product is taken at tile start, while X0 sits in LDS, and held in
 // registers until its layer (as in ddf_trunk_kernel).  Z_l / H_l leave from the accumulator registers: a store instruction
 // covers 2 rows x 32 consecutive columns = two full 128-byte lines.
+// accumulators -> Z_l (global), H_l = a(Z_l) (global + LDS tile for the next layer)
+template <int KIND, bool FULL, bool LAST, int MT, int NT, class Ops>
+__device__ __forceinline__ void mlp_epilogue(const f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *Zl, float *Hl, int64_t r0,
+                                             int64_t R, int wave, int lane)
+{
+    constexpr int LD = Ops::kLd;
+    constexpr float unscale = 1.0f / Ops::kWScale;
+    const int j = lane & 31, h = lane >> 5;
+    // one 64-bit base per lane; everything else is a compile-time offset from it
+    const int64_t base = (r0 + 4 * h) * kWidth + wave * NT * 32 + j;
+    float *zb = Zl + base, *hb = Hl + base;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            typename Ops::act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float z[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[r] = acc[mt][t][4 * g + r] * unscale;
+                float y, dy;
+                act_grad<KIND>(z[0], y, dy);
+                const float hv[4] = { y, dy * z[1], dy * z[2], dy * z[3] };
+                const int off = (mt * 32 + 8 * g) * kWidth + t * 32;
+                if (FULL || r0 + mt * 32 + 8 * g + 4 * h < R) {     // R is a multiple of 4: a point's rows are all inside or all outside
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        zb[off + r * kWidth] = z[r];
+                        hb[off + r * kWidth] = hv[r];
+                    }
+                }
+                if (!LAST) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Ops::put(o + (8 * g + r) * LD, hv[r]);
+                }
+            }
+        }
+}
+
 // HOLD: the skip partial waits in 64 registers (fp32); otherwise X0 is staged a second time at the skip layer (split fp16: its
 // conversion-heavy epilogue has no registers to spare -- 136 spilled with the partial held)
 template <class Ops, bool HOLD>
@@ -353,36 +395,18 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
                 }
             }
             __syncthreads();            // every wave finished reading the previous activations
-            float *Zl = a.Z[l], *Hl = a.H[l];
-            const int j = lane & 31, h = lane >> 5;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int col = (wave * NT + t) * 32 + j;
-                    act_t *o = act + (mt * 32 + 4 * h) * LD + col;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int64_t row = r0 + mt * 32 + 8 * g + 4 * h;      // first of the four rows of this point
-                        float z[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) z[r] = acc[mt][t][4 * g + r] * unscale;
-                        float y, dy;
-                        if (a.act_kind == 0) act_grad<0>(z[0], y, dy); else if (a.act_kind == 1) act_grad<1>(z[0], y, dy); else act_grad<2>(z[0], y, dy);
-                        const float hv[4] = { y, dy * z[1], dy * z[2], dy * z[3] };
-                        if (row < a.R) {            // R is a multiple of 4: a point's rows are all inside or all outside
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                Zl[(row + r) * kWidth + col] = z[r];
-                                Hl[(row + r) * kWidth + col] = hv[r];
-                            }
-                        }
-                        if (l + 1 < a.n_layers) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) Ops::put(o + (8 * g + r) * LD, hv[r]);
-                        }
-                    }
-                }
+            // one straight-line epilogue per (activation, interior / ragged tile, last layer or not): no per-group branches
+            const bool full = r0 + ROWS <= a.R, last = l + 1 == a.n_layers;
+            auto run = [&](auto kind, auto is_full, auto is_last) {
+                mlp_epilogue<decltype(kind)::value, decltype(is_full)::value, decltype(is_last)::value, MT, NT, Ops>(acc, act, a.Z[l], a.H[l], r0, a.R, wave, lane);
+            };
+            auto by_shape = [&](auto kind) {
+                if (full) { if (last) run(kind, std::true_type{}, std::true_type{}); else run(kind, std::true_type{}, std::false_type{}); }
+                else { if (last) run(kind, std::false_type{}, std::true_type{}); else run(kind, std::false_type{}, std::false_type{}); }
+            };
+            if (a.act_kind == 0) by_shape(std::integral_constant<int, 0>{});
+            else if (a.act_kind == 1) by_shape(std::integral_constant<int, 1>{});
+            else by_shape(std::integral_constant<int, 2>{});
             if (l + 1 < a.n_layers) __syncthreads();        // the next layer reads what this epilogue wrote
         }
     }
