@@ -291,6 +291,36 @@ int neus_forward(neddf_ctx *ctx, int slot, const float *const *W, const float *c
     for (int i = 0; i < 10; ++i) enc.lowpass[i] = 1.0f;
     launch_pe_rows(pos, dir, var0, N, enc, PEs, PE, kLdPe, Ed, kLdDir, s);
     const int kpe = (p.Cpe + 3) & ~3;
+    int n_wide = 0;
+    for (int l = 1; l < p.n_sdf; ++l) n_wide += in_skips(f.d, l - 1) ? 1 : 0;
+    static const bool unfused = [] { const char *e = getenv("NEDDF_TRAIN_UNFUSED"); return e && atoi(e) != 0; }();
+    if (!unfused && n_wide <= 1) {      // the sdf trunk (neus.py:121-125) as one fused layer stack (train_kernels.h MlpForwardArgs)
+        if (int rc = ensure(ctx, ctx->tpack, (size_t)(kMaxLayers + 2) * kPackFloats * sizeof(float))) return rc;
+        wp = (float *)ctx->tpack.p; wp2 = wp + kPackFloats;
+        float *pack_at = wp;
+        auto next_pack = [&]() { float *r = pack_at; pack_at += kPackFloats; return r; };
+        MlpForwardArgs m{};
+        m.R = p.R; m.X0 = PE; m.ld0 = kLdPe; m.kload0 = kpe; m.ksteps0 = gemm_ksteps(p.Cpe, sp);
+        m.n_layers = p.n_sdf; m.skip_layer = -1; m.act_kind = act;
+        float *w0 = next_pack();
+        launch_pack(sp, W[0], 1, p.Cpe, 0, 0, p.Cpe, kWidth, kWidth, w0, s);
+        m.wp0 = w0;
+        for (int l = 0; l < p.n_sdf; ++l) {
+            const bool wide = l > 0 && in_skips(f.d, l - 1);
+            const int in_total = l == 0 ? p.Cpe : (wide ? kWidth + p.Cpe : kWidth);
+            m.bias[l] = B[l]; m.Z[l] = ws + p.o_z[l]; m.H[l] = ws + p.o_h[l];
+            if (l == 0) continue;
+            float *wl = next_pack();
+            launch_pack(sp, W[l], 1, in_total, 0, 0, kWidth, kWidth, kWidth, wl, s);       // cat([hx, embed_pos]): hidden state first
+            m.wp[l] = wl;
+            if (wide) {
+                float *wsk = next_pack();
+                launch_pack(sp, W[l], 1, in_total, kWidth, 0, p.Cpe, kWidth, kWidth, wsk, s);
+                m.skip_layer = l; m.wp_skip = wsk;
+            }
+        }
+        launch_mlp_forward(sp, m, cus, s);
+    } else
     for (int l = 0; l < p.n_sdf; ++l) {             // neus.py:121-125
         float *Z = ws + p.o_z[l], *H = ws + p.o_h[l];
         const bool wide = l > 0 && in_skips(f.d, l - 1);
