@@ -63,6 +63,7 @@ struct neddf_ctx {
     Field field[NEDDF_NUM_SLOTS];
     DevBuf features, ptaux, scratch, arena, flags, sched;
     DevBuf rflags;               // importance resampling: one NaN-fallback flag per group of rays
+    DevBuf rev_scratch;          // reverse-mode distance kernel: per-workgroup y' of every layer + encoding Jacobian
     DevBuf tpack, ttmp;          // training step: packed weights of the layer in flight, gradient ping-pong buffers
     DevBuf tamax;                // training step: max |dZ| of every gradient matrix of a backward pass (split-fp16 operand range)
     bool timing = false;

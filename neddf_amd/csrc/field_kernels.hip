@@ -314,6 +314,279 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
 }
 
 // ----------------------------------------------------------------------------
+// NeDDF distance trunk, eval-minimal, with the distance gradient in REVERSE mode.
+//
+// The reference carries the Jacobian forward through every layer (three extra rows per sample point, neddf.py:206-230) because
+// its training penalties need Jacobians of several outputs.  Rendering needs the gradient of ONE scalar -- the raw distance
+// z_D = w_ddf . h_L -- with respect to the position: density = a((1 - |(grad D, aux)|) / D), normal = grad D / |grad D|
+// (neddf.py:234-241).  For one scalar, reverse mode is the cheaper direction:
+//     forward   h_l = a(z_l), z_l = h_{l-1} W_l + b_l                      value rows only, keep y'_l = a'(z_l)
+//     backward  g_L = w_ddf * y'_L;  g_{l-1} = (g_l W_l^T) * y'_{l-1}        one row per point again
+//     encoding  g_pe = g_0 W_0^T + g_skip (encoding rows of W_skip)^T;  grad_x z_D = sum_c g_pe[c] dPE_c/dx   (20 terms per axis)
+// i.e. two rows of matrix work per point and layer instead of four, on tiles of 64 POINTS (all M-tile rows useful) instead of
+// 16 points x 4 rows: 13 layer-equivalents of MFMA work per 64 points against 29.6.  Same function, same weights; the
+// result differs from the forward-mode Jacobian only in rounding (checked against the oracle and the reference goldens by the
+// same gates).  What it costs: y'_l of the tile (7 x 64 KB) does not fit in LDS next to the activations, so it makes a round trip
+// through a per-workgroup scratch in global memory (written by the forward epilogue, read back -- prefetched a layer ahead --
+// by the backward one); and the activation is evaluated per element instead of once per four accumulator rows.
+// Used when the caller wants no penalties / Jacobian outputs (render_image, render_rays without fields_penalty); the
+// forward-mode kernel above serves the training-mode outputs.
+size_t ddf_rev_scratch_floats_per_wg(int n_layers) { return (size_t)n_layers * kRevPoints * kWidth + (size_t)kRevPoints * 128; }
+__device__ __forceinline__ size_t ddf_rev_scratch_floats_per_wg_dev(int n_layers) { return (size_t)n_layers * kRevPoints * kWidth + (size_t)kRevPoints * 128; }
+
+template <int KIND, bool LAST, int MT, int NT, class Ops>
+__device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *yp, const float *wseed, int wave,
+                                                     int lane)
+{
+    constexpr int LD = Ops::kLd;
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = (wave * NT + t) * 32 + j;
+            typename Ops::act_t *o = act + (mt * 32 + 4 * h) * LD + col;
+            const float ws = LAST ? wseed[col] : 1.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int r = 8 * (q >> 2) + (q & 3);
+                float z = acc[mt][t][q];
+                if constexpr (Ops::kWScale != 1.0f) z *= (1.0f / Ops::kWScale);
+                float y, dy;
+                act_grad<KIND, Ops::kFastAct>(z, y, dy);
+                Ops::put(o + r * LD, y);
+                acc[mt][t][q] = LAST ? ws * dy : dy;     // y' replaces the accumulator (LAST: the seed of the reverse pass, dz_D / dz_L)
+            }
+        }
+    // y' leaves in the accumulators' own fragment order (16 bytes per lane, 1 KiB per wave and store): only this workgroup's
+    // same lanes read it back, so nothing needs it row-major
+    if (!LAST) stash_store<MT, NT>(acc, yp, wave, lane);
+}
+
+template <bool LAST, int MT, int NT, class Ops>
+__device__ __forceinline__ void rev_forward_epilogue_rt(f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *yp, const float *wseed, int kind,
+                                                        int wave, int lane)
+{
+    if (kind == 0) rev_forward_epilogue<0, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane);
+    else if (kind == 1) rev_forward_epilogue<1, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane);
+    else rev_forward_epilogue<2, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane);
+}
+
+template <int WPS, class Ops>
+__global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
+{
+    typedef typename Ops::act_t act_t;
+    typedef typename Ops::bfrag frag;
+    constexpr int MT = 2, NT = 2, ROWS = MT * 32, P = ROWS, LD = Ops::kLd;
+    static_assert(P == kRevPoints, "tile size");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    act_t *act = (act_t *)smem;
+    float *hd = (float *)(act + ROWS * LD);  // [2 parts][2 heads][ROWS] head dot products
+    float *lp = hd + 6 * ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
+    float *yp = a.rev_scratch + (size_t)blockIdx.x * ddf_rev_scratch_floats_per_wg_dev(a.n_layers);
+    float *pj = yp + (size_t)a.n_layers * ROWS * kWidth;        // [ROWS][64] dPE/dx factors: [q] sine half, [32 + q] cosine half
+    float *pv = pj + ROWS * 64;                                  // [ROWS][64] the encoding itself, for the skip layer
+    if (tid == 0) {
+#pragma unroll
+        for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
+    }
+    const int kin = Ops::kStep * a.layer[0].ksteps;
+    const int K3 = 3 * a.enc.E, KH = a.enc.KH;
+    const int64_t ntiles = (a.n_points + P - 1) / P;
+    constexpr int KS = kWidth / Ops::kStep;                     // super-steps of a 256-wide product
+    const int j = lane & 31, h = lane >> 5;
+
+    int *ctl = (int *)(lp + 12);
+    int64_t tile = sched_begin(a.sched, a.sched_flags, ctl, tid);
+    while (tile < ntiles) {
+        const int64_t p0 = tile * P;
+        LayerPre<NT, Ops> pre;
+        layer_prefetch<NT, Ops>(pre, a.layer[0].wp, a.layer[0].bias, a.layer[0].ksteps, wave, lane);
+        zero_cols<Ops>(act, ROWS, kin, tid);
+        __syncthreads();
+        int next_tile = 0;
+        if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
+        // scaled integrated encoding (neddf.py:193-204), value rows; the factors of its Jacobian go to the scratch
+        for (int item = tid; item < P * K3; item += kThreads) {
+            const int p = item / K3, q = item - p * K3;
+            const int e = q / 3, d = q - 3 * e;
+            const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
+            float vs, vc, js, jc;
+            pe_pair<true, Ops::kFast>(e, a.pos[gp * 3 + d], a.var[gp * 3 + d], lp[e], vs, vc, js, jc);
+            Ops::put(act + p * LD + q, vs);
+            Ops::put(act + p * LD + KH + q, vc);
+            pj[p * 64 + q] = js;
+            pj[p * 64 + 32 + q] = jc;
+            pv[p * 64 + q] = vs;
+            pv[p * 64 + 32 + q] = vc;
+        }
+        __syncthreads();
+
+        f32x16 acc[MT][NT];
+        // ---- forward, value rows
+        for (int l = 0; l < a.n_layers; ++l) {
+            const LayerW &L = a.layer[l];
+            acc_init_pre<MT, NT, false, Ops>(acc, pre);
+            dense_pre<MT, NT, Ops>(acc, act_lane, (const frag *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane, L.ksteps, pre);
+            if (L.stash >= 0) {         // cat([encoding, h]) (neddf.py:217-219): the encoding comes back from the scratch into the tile's first columns
+                const StashW &sw = a.stash[L.stash];
+                __syncthreads();                        // every wave finished reading the hidden state
+                for (int i = tid; i < ROWS * (kin / 4); i += kThreads) {
+                    const int r = i / (kin / 4), c = i - r * (kin / 4);
+                    f32x4v v = { 0.f, 0.f, 0.f, 0.f };
+                    if (4 * c < 64) v = *(const f32x4v *)(pv + r * 64 + 4 * c);
+                    // columns [K3, KH) and [KH + K3, 2 KH) of the scratch rows were never written: mask them
+                    float x[4] = { v[0], v[1], v[2], v[3] };
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int cc = 4 * c + u, qq = cc < KH ? cc : cc - KH;
+                        Ops::put(act + r * LD + cc, (cc < 2 * KH && qq < K3) ? x[u] : 0.f);
+                    }
+                }
+                __syncthreads();
+                dense<MT, NT, Ops>(acc, act_lane + sw.col0, (const frag *)sw.wp + (size_t)wave * NT * sw.ksteps * 64 + lane, sw.ksteps);
+            }
+            if (l + 1 < a.n_layers) layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
+            __syncthreads();
+            if (l + 1 < a.n_layers) rev_forward_epilogue_rt<false, MT, NT, Ops>(acc, act, yp + (size_t)l * ROWS * kWidth, nullptr, a.activation, wave, lane);
+            else rev_forward_epilogue_rt<true, MT, NT, Ops>(acc, act, nullptr, a.w_ddf_out, a.activation, wave, lane);
+            __syncthreads();
+        }
+        // ---- heads on the features (value only: the distance gradient comes from the reverse pass, the aux gradient's own
+        // Jacobian is not an eval output), and the feature hand-off to the colour kernel
+        {
+            const int part = tid >> 7, pr = tid & 127, head = pr >> 6, row = pr & 63;      // 2 k-halves x 2 heads x 64 rows = 256 threads
+            const f32x4v *w = (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out) + part * 32;
+            const act_t *ar = act + row * LD + part * 128;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                float x[4];
+                Ops::load4(ar + 4 * k, x);
+                f32x4v ww = w[k];
+                s0 = fmaf(x[0], ww[0], s0); s1 = fmaf(x[1], ww[1], s1);
+                s2 = fmaf(x[2], ww[2], s2); s3 = fmaf(x[3], ww[3], s3);
+            }
+            hd[tid] = (s0 + s1) + (s2 + s3);
+        }
+        {
+            constexpr int CE = 16 / sizeof(act_t), CPP = kWidth / CE, CPR = Ops::kPlanes * CPP;
+            act_t *features = (act_t *)a.features;
+            for (int idx = tid; idx < P * CPR; idx += kThreads) {
+                const int p = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
+                if (p0 + p < a.n_points) {
+                    f32x4v v = *(const f32x4v *)(act + p * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));
+                    *(f32x4v *)(features + (size_t)(p0 + p) * (Ops::kPlanes * kWidth) + CE * c4) = v;
+                }
+            }
+        }
+        __syncthreads();                // the features are consumed: the tile now carries gradients
+        // ---- reverse pass: g_L (held in the accumulators since the last epilogue) -> LDS
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) Ops::put(o + (8 * (q >> 2) + (q & 3)) * LD, acc[mt][t][q]);
+            }
+        __syncthreads();
+        f32x16 gpe[1][1];               // this wave's 32 x 32 block of the encoding gradient: M-tile wave >> 1, N-tile wave & 1
+        acc_init<1, 1, false>(gpe, nullptr, wave, lane);
+        const act_t *pe_lane = act_lane + (wave >> 1) * 32 * LD;
+        for (int l = a.n_layers - 1; l >= 1; --l) {
+            if (l == a.skip_layer)      // cat([encoding, h]): the encoding rows of W_l take their share of g_l
+                dense<1, 1, Ops>(gpe, pe_lane, (const frag *)a.wT_pe_skip + (size_t)(wave & 1) * KS * 64 + lane, KS);
+            // y'_{l-1} of this lane's accumulator positions, requested before the product so that it lands under the MFMAs
+            f32x16 ypre[MT][NT];
+            {
+                const f32x4v *src = (const f32x4v *)(yp + (size_t)(l - 1) * ROWS * kWidth) + (size_t)wave * (MT * NT * 4) * 64 + lane;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4v v = src[((mt * NT + t) * 4 + g) * 64];
+                            ypre[mt][t][4 * g] = v[0]; ypre[mt][t][4 * g + 1] = v[1]; ypre[mt][t][4 * g + 2] = v[2]; ypre[mt][t][4 * g + 3] = v[3];
+                        }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc_init<MT, NT, false>(acc, nullptr, wave, lane);
+            dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
+            __syncthreads();            // every wave finished reading g_l
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        float g = acc[mt][t][q] * ypre[mt][t][q];
+                        if constexpr (Ops::kWScale != 1.0f) g *= (1.0f / Ops::kWScale);
+                        Ops::put(o + (8 * (q >> 2) + (q & 3)) * LD, g);
+                    }
+                }
+            __syncthreads();
+        }
+        dense<1, 1, Ops>(gpe, pe_lane, (const frag *)a.wT_pe0 + (size_t)(wave & 1) * KS * 64 + lane, KS);       // g_0 W_0^T
+        __syncthreads();                // every wave finished reading g_0
+        {
+            act_t *o = act + ((wave >> 1) * 32 + 4 * h) * LD + (wave & 1) * 32 + j;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float g = gpe[0][0][q];
+                if constexpr (Ops::kWScale != 1.0f) g *= (1.0f / Ops::kWScale);
+                Ops::put(o + (8 * (q >> 2) + (q & 3)) * LD, g);
+            }
+        }
+        __syncthreads();
+        // ---- per point: grad_x z_D = sum over the encoding channels of g_pe * dPE/dx, then the head arithmetic (neddf.py:220-241)
+        if (tid < P && p0 + tid < a.n_points) {
+            const int64_t gp = p0 + tid;
+            const act_t *gr = act + tid * LD;
+            const float *pjr = pj + tid * 64;
+            float gz[3] = { 0.f, 0.f, 0.f };
+            for (int e = 0; e < a.enc.E; ++e)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int q = 3 * e + d;
+                    gz[d] = fmaf(Ops::get(gr + q), pjr[q], gz[d]);
+                    gz[d] = fmaf(Ops::get(gr + KH + q), pjr[32 + q], gz[d]);
+                }
+            const float z = (hd[tid] + hd[128 + tid]) + a.b_ddf_out;
+            const float az = (hd[64 + tid] + hd[192 + tid]) + a.b_aux_out;
+            float sp, dsp, t, dsg;
+            softplus_grad(z, sp, dsp);               // softplus.py:38-49
+            const float D = sp + a.d_near;
+            const float dg0 = dsp * gz[0], dg1 = dsp * gz[1], dg2 = dsp * gz[2];
+            sigmoid_grad(az, t, dsg);                // sigmoid.py:38-43
+            const float aux = a.aux_grad_scale * t;
+            const float q2 = dg0 * dg0 + dg1 * dg1 + dg2 * dg2;
+            const float dgn = sqrtf(q2);
+            const float dDdt = sqrtf(q2 + aux * aux);              // neddf.py:234-238
+            const float Dinv = 1.0f / D;
+            const float rho = act_val_rt(a.density_activation, Dinv * (1 - dDdt));   // :239-240
+            const float ninv = 1.0f / (dgn + 1e-7f);               // :241
+            float *pa = a.ptaux + gp * kPtAux;
+            f32x4v v0 = { D, rho, aux, ninv * dg0 };
+            f32x4v v1 = { ninv * dg1, ninv * dg2, z, az };
+            f32x4v v2 = { dg0, dg1, dg2, 0.f };
+            f32x4v v3 = { 0.f, 0.f, dgn, dDdt };
+            ((f32x4v *)pa)[0] = v0; ((f32x4v *)pa)[1] = v1; ((f32x4v *)pa)[2] = v2; ((f32x4v *)pa)[3] = v3;
+            if (a.distance) a.distance[gp] = D;
+            if (a.density) a.density[gp] = rho;
+            if (a.aux_grad) a.aux_grad[gp] = aux;
+        }
+        if (tid == 0) ctl[0] = next_tile;
+        __syncthreads();
+        tile = ctl[0];
+    }
+}
+
+// ----------------------------------------------------------------------------
 // NeDDF colour trunk.  ROWS4 = false: eval-minimal, one row per point (the
 // colour Jacobian is dead code in eval); ROWS4 = true:
 // full mode with Jacobian rows + field penalties (neddf.py:244-300).
@@ -794,6 +1067,19 @@ void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
     }
     NEDDF_GEO_CASE(2, 2, 4) return launch_ddf_g<2, 2, 4, OpsF32>(a, grid, s);
     return launch_ddf_g<4, 1, 4, OpsF32>(a, grid, s);
+}
+
+template <class Ops>
+static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s)
+{
+    static bool once = (set_lds((const void *)ddf_rev_kernel<2, Ops>, lds_bytes<Ops>(2)), true);
+    (void)once;
+    hipLaunchKernelGGL((ddf_rev_kernel<2, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a);
+}
+
+void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s)
+{
+    launch_ddf_rev_t<OpsF32>(a, grid, s);
 }
 
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)

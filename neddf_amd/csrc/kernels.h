@@ -62,6 +62,11 @@ struct DdfArgs {
     int neus;                             // 1: NeuS sdf trunk (neus.py:118-145): plain PE, no heads, sdf = feature 0
     float neus_v10;                       // variance * 10
     float *scratch;                       // per-workgroup stash area
+    // reverse-mode distance gradient (ddf_rev_kernel, eval-minimal): transposed weights and a per-workgroup scratch
+    const float *wT[kMaxLayers];          // [l >= 1] packed (hidden rows of W_l)^T, 256 x 256
+    const float *wT_pe0, *wT_pe_skip;     // packed [256 x 64]: W_0^T and the skip layer's encoding rows^T (engine column order)
+    int skip_layer;                       // trunk layer whose input is cat([encoding, h]), or -1
+    float *rev_scratch;                   // per workgroup: y' of every layer [n_layers][64][256] + encoding Jacobian [64][64]
     int *sched;                           // [0] tile queue head (zeroed before each launch)
     int sched_flags;                      // bit 1: dynamic tile queue; higher bits: timing ablations, -DNEDDF_ABLATE builds only
     float *features;                      // [n_points][feat_rows][256]
@@ -124,6 +129,9 @@ struct CameraArg {
 
 size_t field_lds_bytes(int mt);
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s);
+void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s);
+size_t ddf_rev_scratch_floats_per_wg(int n_layers);
+constexpr int kRevPoints = 64;         // sample points per tile of ddf_rev_kernel
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s);
 void launch_nerf(const NerfArgs &a, int grid, hipStream_t s);
 int ddf_points_per_tile(int operands = 0);

@@ -95,7 +95,7 @@ static inline float f16_value(uint16_t h)
 static size_t pack_layer(std::vector<float> &blob, const Src &src, std::vector<int> kmap, int nout, int operands, int *ksteps_out)
 {
     // operands == 2 (split fp16): two fp16 planes of 2^10 w (h toward zero, m = remainder to nearest), 32 bytes per lane and super-step
-    const int step = operands ? 16 : 8, half = step / 2, NT = nout / 128, planes = operands == 2 ? 2 : 1;
+    const int step = operands ? 16 : 8, half = step / 2, tiles = nout / 32, planes = operands == 2 ? 2 : 1;     // nout: multiple of 32
     while (kmap.size() % step) kmap.push_back(-1);
     const int ks = (int)kmap.size() / step;
     if (ksteps_out) *ksteps_out = ks;
@@ -104,15 +104,14 @@ static size_t pack_layer(std::vector<float> &blob, const Src &src, std::vector<i
     blob.resize(off + (operands ? elems * planes / 2 : elems), 0.f);
     float *dst = blob.data() + off;
     uint16_t *dst16 = (uint16_t *)dst;
-    for (int w = 0; w < kWaves; ++w)
-        for (int t = 0; t < NT; ++t)
+    for (int tile = 0; tile < tiles; ++tile)            // tile-major: tile = wave * NT + t in the kernels
             for (int S = 0; S < ks; ++S)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int r = 0; r < half; ++r) {
-                        int n = (w * NT + t) * 32 + (lane & 31);
+                        int n = tile * 32 + (lane & 31);
                         int k = kmap[step * S + half * (lane >> 5) + r];
-                        float v = k < 0 ? 0.f : src.at(k, n);
-                        size_t frag = (((size_t)(w * NT + t) * ks + S) * 64 + lane);
+                        float v = (k < 0 || n >= src.cols) ? 0.f : src.at(k, n);
+                        size_t frag = (((size_t)tile * ks + S) * 64 + lane);
                         if (operands == 2) {
                             const float sv = v * 1024.0f;
                             uint16_t h = f16_bits(sv, true);
@@ -180,6 +179,35 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     const int i_ddf = n_trunk + n_col, i_aux = i_ddf + 1, i_cout = i_ddf + 2;
     size_t o_wddf = put(blob, W[i_ddf], kWidth), o_waux = put(blob, W[i_aux], kWidth);
     a.b_ddf_out = B[i_ddf][0]; a.b_aux_out = B[i_aux][0];
+    // Reverse-mode distance gradient (ddf_rev_kernel): the transposes.  dL/dH_{l-1} = g_l x (hidden rows of W_l)^T is a dense
+    // product with B[k][n] = W_l[row0 + n][k]; the gradient of the encoding collects g_0 x W_0^T and g_skip x (encoding rows of
+    // W_skip)^T, 64 engine columns wide (same [sin half | cos half] order as the forward encoding in LDS)
+    std::vector<size_t> o_wT(n_trunk, 0);
+    size_t o_wT_pe0 = 0, o_wT_pes = 0;
+    a.skip_layer = -1;
+    {
+        std::vector<int> kall;
+        for (int k = 0; k < kWidth; ++k) kall.push_back(k);
+        struct TSrc { const float *w; int row0; };
+        for (int l = 1; l < n_trunk; ++l) {
+            const bool wide = in_skips(d, l - 1);
+            // logical B[k][n] = W_l[(wide ? Cpe : 0) + n][k], W_l row-major [in][256]  ==  Src "transposed" with rows = 256
+            Src st{ W[l] + (size_t)(wide ? Cpe : 0) * kWidth, kWidth, kWidth, true };
+            o_wT[l] = pack_layer(blob, st, kall, kWidth, operands, nullptr);
+            if (wide) a.skip_layer = l;
+        }
+        // narrow transposes: column n of the engine's encoding layout is reference row pe[n] (or padding)
+        auto pack_pe_T = [&](const float *Wl) {
+            std::vector<float> tmp((size_t)kWidth * 64, 0.f);       // [k][n] row-major, n < 64
+            for (int n = 0; n < (int)pe.size() && n < 64; ++n)
+                if (pe[n] >= 0)
+                    for (int k = 0; k < kWidth; ++k) tmp[(size_t)k * 64 + n] = Wl[(size_t)pe[n] * kWidth + k];
+            Src sn{ tmp.data(), kWidth, 64, false };
+            return pack_layer(blob, sn, kall, 64, operands, nullptr);
+        };
+        o_wT_pe0 = pack_pe_T(W[0]);
+        if (a.skip_layer >= 0) o_wT_pes = pack_pe_T(W[a.skip_layer]);
+    }
     // colour trunk
     std::vector<int> ka;
     enc_map(ka, E, KH, 0);
@@ -206,6 +234,9 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     for (int l = 0; l < n_trunk; ++l) { a.layer[l].wp = base + o_wp[l]; a.layer[l].bias = base + o_b[l]; }
     for (int s = 0; s < a.n_stash; ++s) a.stash[s].wp = base + o_st[s];
     a.w_ddf_out = base + o_wddf; a.w_aux_out = base + o_waux;
+    for (int l = 1; l < n_trunk; ++l) a.wT[l] = base + o_wT[l];
+    a.wT_pe0 = base + o_wT_pe0;
+    a.wT_pe_skip = a.skip_layer >= 0 ? base + o_wT_pes : nullptr;
     c.wp_a = base + o_wa;
     for (int l = 0; l < n_col; ++l) { c.layer[l].wp = base + c_wp[l]; c.layer[l].bias = base + c_b[l]; }
     c.w_out = base + o_cout;
@@ -399,6 +430,11 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     }
     const bool full = (out_mode == NEDDF_OUT_FULL) && penalty && f.d.kind == NEDDF_FIELD_NEDDF;
     const int fr = full ? 4 : 1;
+    // Eval-minimal NeDDF needs the gradient of one scalar (the distance) only: reverse mode halves the matrix work
+    // (NEDDF_DDF_REVERSE=0 keeps the forward-mode Jacobian rows, which the penalties of the full mode need anyway)
+    static const bool rev_enabled = [] { const char *e = getenv("NEDDF_DDF_REVERSE"); return !e || atoi(e) != 0; }();
+    const bool reverse = rev_enabled && !full && f.d.kind == NEDDF_FIELD_NEDDF && dt == NEDDF_DTYPE_F32 && f.ddf.n_stash <= 1 &&
+                         field_wgs_per_cu(dt) == 2;
     const int64_t chunk_cap = full ? (1 << 19) : (1 << 21);
     const int64_t chunk = N < chunk_cap ? N : chunk_cap;
     // activations' element type and planes: fp32 1024 B, bf16 512 B, split bf16 (two planes) 1024 B per row
@@ -419,11 +455,19 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         a.distance = distance ? distance + off : nullptr;
         a.density = density ? density + off : nullptr;
         a.aux_grad = aux ? aux + off : nullptr;
-        int64_t tiles = (n + ddf_points_per_tile(dt) - 1) / ddf_points_per_tile(dt);
         a.sched = (int *)ctx->sched.p;
         a.sched_flags = sched_flags();
         HIPCHK(hipMemsetAsync(a.sched, 0, kSchedInts * sizeof(int), s));
-        STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf(a, (int)(tiles < grid_cap_ddf ? tiles : grid_cap_ddf), s));
+        if (reverse) {          // one scalar's gradient: reverse mode, 64 points per tile (field_kernels.hip ddf_rev_kernel)
+            const int64_t tiles = (n + kRevPoints - 1) / kRevPoints;
+            const int grid = (int)(tiles < 2 * ctx->cus ? tiles : 2 * ctx->cus);
+            if (int rc = ensure(ctx, ctx->rev_scratch, (size_t)2 * ctx->cus * ddf_rev_scratch_floats_per_wg(a.n_layers) * sizeof(float))) return rc;
+            a.rev_scratch = (float *)ctx->rev_scratch.p;
+            STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf_rev(a, grid, s));
+        } else {
+            const int64_t tiles = (n + ddf_points_per_tile(dt) - 1) / ddf_points_per_tile(dt);
+            STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf(a, (int)(tiles < grid_cap_ddf ? tiles : grid_cap_ddf), s));
+        }
         if (color || full) {
             ColArgs c = f.col;
             fill_enc(c.enc, f);
@@ -490,7 +534,7 @@ void neddf_destroy(neddf_ctx *ctx)
     (void)hipDeviceSynchronize();
     neddf_comm_release(ctx);
     for (auto &f : ctx->field) if (f.blob.p) (void)hipFree(f.blob.p);
-    for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags, &ctx->rflags, &ctx->sched, &ctx->tpack, &ctx->ttmp, &ctx->tamax })
+    for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags, &ctx->rflags, &ctx->rev_scratch, &ctx->sched, &ctx->tpack, &ctx->ttmp, &ctx->tamax })
         if (b->p) (void)hipFree(b->p);
     for (auto &e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : ctx->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

@@ -332,7 +332,6 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
     typedef typename Ops::act_t act_t;
     typedef typename Ops::bfrag frag;
     constexpr int MT = 2, NT = 2, ROWS = MT * 32, LD = Ops::kLd;
-    constexpr float unscale = 1.0f / Ops::kWScale;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     act_t *act = (act_t *)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -238,9 +238,20 @@ def test_neddf_bunny_field(dev, orc, bunny_weights, bunny_stages):
     net.output_mode = "minimal"
     o2 = net(smp(g, dev, "f"))
     assert "fields_penalty" not in o2
-    for k in ("distance", "density", "aux_grad"):
-        assert torch.equal(o2[k], o[k]), k
-    assert_close(N(o2["color"]), N(o["color"]), 1e-5, 1e-6, "minimal vs full colour")
+    # minimal mode takes the distance gradient in reverse mode (one scalar: half the matrix work), full mode carries the Jacobian
+    # rows forward like the reference: same function, different rounding -- and both must hold the gates against the reference
+    ref = {k: g["f_" + k] for k in ("distance", "density", "aux_grad", "color")}
+    assert_close(N(o2["distance"]), ref["distance"], 1e-4, 1e-6, "minimal distance vs golden")
+    assert_close(N(o2["aux_grad"]), ref["aux_grad"], 1e-4, 1e-6, "minimal aux vs golden")
+    assert_close(N(o2["density"]), ref["density"], 1e-4, 3e-4, "minimal density vs golden")
+    assert_close(N(o2["color"]), ref["color"], 1e-4, 2e-5, "minimal colour vs golden")
+    # the two modes agree far inside the gates (value rows: only the skip layer's partial is summed in a different order)
+    assert_close(N(o2["distance"]), N(o["distance"]), 1e-5, 1e-6, "minimal vs full distance")
+    assert_close(N(o2["density"]), N(o["density"]), 1e-4, 3e-4, "minimal vs full density")
+    g64 = golden("bunny_field_fp64.npz")
+    e_ref = float(np.abs(g["f_density"].astype(np.float64) - g64["f_density"]).max())
+    e_min = float(np.abs(N(o2["density"]).astype(np.float64) - g64["f_density"]).max())
+    assert e_min <= 2.5 * e_ref, (e_min, e_ref)
 
 
 @pytest.mark.parametrize("name", ["neddf_relu", "neddf_tanhexp", "neddf_leaky"])
