@@ -34,8 +34,14 @@ WIDTH = HEIGHT = 800
 SAMPLES = 128
 CAMERA_ANGLE_X = 0.6911112070083618
 # algorithmic work per field evaluation, shipped NeDDF architecture, eval-minimal:
-#   distance trunk: 4 rows x (60*256 + 4*256*256 + 316*256 + 256*256 + 256 [ddf head]) + 256 [aux head] MACs
-DDF_FLOP_PER_POINT = 2 * (4 * (423936 + 256) + 256)
+#   distance trunk with the Jacobian carried FORWARD (the reference's formulation; the 16-bit operand policies and the
+#   training-mode outputs): 4 rows x (60*256 + 4*256*256 + 316*256 + 256*256 + 256 [ddf head]) + 256 [aux head] MACs
+DDF_FLOP_PER_POINT_FORWARD = 2 * (4 * (423936 + 256) + 256)
+#   distance trunk with the distance gradient in REVERSE mode (fp32 eval-minimal since round 2, ddf_rev_kernel): value rows
+#   forward (423 936 + both heads 512) + one gradient row backward (6 hidden transposes 393 216 + the encoding rows of W_0 and
+#   of the skip layer 2 x 15 360) MACs -- the same function with half the matrix work
+DDF_FLOP_PER_POINT_REVERSE = 2 * (423936 + 512 + 393216 + 2 * 15360)
+DDF_FLOP_PER_POINT = DDF_FLOP_PER_POINT_FORWARD
 #   colour trunk (value row only): 343*256 + 2*256*256 + 256*3 MACs
 COL_FLOP_PER_POINT = 2 * (219648 + 768)
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
@@ -400,6 +406,9 @@ def main():
     if rank == 0:
         pts = n_rays * samples_per_ray * args.steps               # field evaluations on this rank
         ddf_s = tm["ddf_ms"] / 1e3
+        # the library's rule (neddf_capi.hip field_forward): fp32 eval-minimal takes the reverse-mode kernel unless switched off
+        reverse = args.dtype == "f32" and os.environ.get("NEDDF_DDF_REVERSE", "1") != "0" and os.environ.get("NEDDF_TILE_MT", "2") != "4"
+        DDF_FLOP_PER_POINT = DDF_FLOP_PER_POINT_REVERSE if reverse else DDF_FLOP_PER_POINT_FORWARD
         achieved = pts * DDF_FLOP_PER_POINT / ddf_s / 1e12 if ddf_s > 0 else 0.0
         peak = PEAK_FP32_MFMA_TFLOPS
         if args.dtype == "bf16":
@@ -432,9 +441,14 @@ def main():
                        "parallelism": "ray-parallel x%d" % world, "comm": comm},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,
-                         "kernel": "neddf::ddf_trunk_kernel", "launches": tm["ddf_launches"],
+                         "kernel": "neddf::ddf_rev_kernel" if reverse else "neddf::ddf_trunk_kernel", "launches": tm["ddf_launches"],
                          "avg_launch_ms": tm["ddf_ms"] / max(tm["ddf_launches"], 1),
                          "flop_per_point": DDF_FLOP_PER_POINT,
+                         "algorithm": ("distance gradient in reverse mode: value rows forward + one gradient row backward = 2 rows of matrix "
+                                       "work per point and layer; `achieved` / `frac` count THESE flops" if reverse else
+                                       "Jacobian rows carried forward (value + 3 rows per point), the reference's formulation"),
+                         "forward_mode_flop_per_point": DDF_FLOP_PER_POINT_FORWARD,
+                         "forward_mode_equivalent_tflops": (pts * DDF_FLOP_PER_POINT_FORWARD / ddf_s / 1e12) if ddf_s > 0 else 0.0,
                          "colour_kernel": {"avg_launch_ms": tm["col_ms"] / max(tm["col_launches"], 1),
                                            "achieved": (pts * COL_FLOP_PER_POINT / (tm["col_ms"] / 1e3) / 1e12) if tm["col_ms"] > 0 else 0.0}},
             # every stage kernel of the timed region (HIP events on its stream): summed ms per step and launches per step
@@ -445,7 +459,8 @@ def main():
                 raise KeyError("no PMC pass for this workload")
             # HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            ent = next(v for k, v in pmc.items() if "ddf_trunk_kernel" in k and ("OpsBF16" in k) == (args.dtype == "bf16"))
+            want = "ddf_rev_kernel" if reverse else "ddf_trunk_kernel"
+            ent = next(v for k, v in pmc.items() if want in k and ("OpsBF16" in k) == (args.dtype == "bf16"))
             line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
             line["roofline"]["traffic_source"] = ent["source"]
             line["roofline"]["algorithmic_hbm_bytes_per_launch"] = ent["algorithmic_bytes_per_launch"]

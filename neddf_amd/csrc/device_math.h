@@ -17,8 +17,9 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 
 __device__ __forceinline__ float tanh_nonneg(float u)
 {
-    float e2u = __builtin_amdgcn_exp2f((u + u) * 1.4426950408889634f);
-    float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e2u + 1.0f);
+    // u * (2 log2 e) and fma(-2, r, 1) are bitwise what (u + u) * log2 e and 1 - 2 r give (doubling is exact), one instruction less each
+    float e2u = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);
+    float big = fmaf(-2.0f, __builtin_amdgcn_rcpf(e2u + 1.0f), 1.0f);
     float p = u * u;
     float poly = fmaf(p, fmaf(p, fmaf(p, fmaf(p, 62.0f / 2835.0f, -17.0f / 315.0f), 2.0f / 15.0f), -1.0f / 3.0f), 1.0f) * u;
     return u < 0.3f ? poly : big;
@@ -58,13 +59,14 @@ __device__ __forceinline__ void act_grad(float x, float &y, float &dy)
         float s = (x < 0.f) ? 0.01f : 1.f;
         y = x * s; dy = s;
     } else {                    // tanh_exp.py:38-46
-        float ex = fast_exp(x);
+        // The reference returns (x, 1) for x > 20.  Clamping the exponent's argument at 80 gives exactly that without the
+        // comparison and two selects: for e^x >= ~10 the tanh below is exactly 1, so y = x * 1 and y' = 1 - x e^x * (1 - 1) = 1
+        // (x e^x stays finite up to the clamp); below 20 nothing changes.  v_med3_f32 is one instruction.
+        const float xc = __builtin_amdgcn_fmed3f(x, -3.0e38f, 80.0f);
+        float ex = fast_exp(xc);
         float tx = tanh_nonneg(ex);
-        float yy = x * tx;
-        float dd = fmaf(-(x * ex), fmaf(tx, tx, -1.0f), tx);      // tx - x*ex*(tx^2 - 1)
-        bool big = x > 20.0f;
-        y = big ? x : yy;
-        dy = big ? 1.0f : dd;
+        y = x * tx;
+        dy = fmaf(-(xc * ex), fmaf(tx, tx, -1.0f), tx);     // tx - x*ex*(tx^2 - 1); xc keeps the product finite for any x
     }
 }
 
@@ -78,8 +80,7 @@ __device__ __forceinline__ float act_val(float x)
     }
     if (KIND == 0) return x > 0.f ? x : 0.f;            // F.relu
     if (KIND == 1) return x > 0.f ? x : 0.01f * x;       // F.leaky_relu
-    float t = x * tanh_nonneg(fast_exp(x));              // nn_module/tanh_exp.py:28-31
-    return x > 20.0f ? x : t;
+    return x * tanh_nonneg(fast_exp(__builtin_amdgcn_fmed3f(x, -3.0e38f, 80.0f)));      // nn_module/tanh_exp.py:28-31; x > 20 -> x exactly, see act_grad
 }
 
 __device__ __forceinline__ float act_val_rt(int kind, float x)

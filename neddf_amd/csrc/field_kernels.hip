@@ -496,6 +496,7 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
         f32x16 gpe[1][1];               // this wave's 32 x 32 block of the encoding gradient: M-tile wave >> 1, N-tile wave & 1
         acc_init<1, 1, false>(gpe, nullptr, wave, lane);
         const act_t *pe_lane = act_lane + (wave >> 1) * 32 * LD;
+        if (a.n_layers > 1) layer_prefetch<NT, Ops>(pre, a.wT[a.n_layers - 1], nullptr, KS, wave, lane);
         for (int l = a.n_layers - 1; l >= 1; --l) {
             if (l == a.skip_layer)      // cat([encoding, h]): the encoding rows of W_l take their share of g_l
                 dense<1, 1, Ops>(gpe, pe_lane, (const frag *)a.wT_pe_skip + (size_t)(wave & 1) * KS * 64 + lane, KS);
@@ -515,7 +516,8 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
             }
             __builtin_amdgcn_sched_barrier(0);
             acc_init<MT, NT, false>(acc, nullptr, wave, lane);
-            dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
+            dense_pre<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS, pre);
+            if (l > 1) layer_prefetch<NT, Ops>(pre, a.wT[l - 1], nullptr, KS, wave, lane);      // next product's first fragments fly during the epilogue
             __syncthreads();            // every wave finished reading g_l
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)

@@ -22,6 +22,9 @@ def main(argv=None) -> None:
     parser = ArgumentParser()
     parser.add_argument("output_dir", type=Path, help="directory path where models and render are located")
     parser.add_argument("--epoch", type=int, default=2000, help="epoch number of model")
+    parser.add_argument("--seed", type=int, default=None,
+                        help="torch seed for the sample uniforms (not a reference option: the reference's run_eval never seeds, and "
+                             "torch seeds its default generator randomly per process)")
     args = parser.parse_args(argv)
     output_dir = args.output_dir.resolve()
     conf = output_dir / ".hydra" / "config.yaml"
@@ -47,6 +50,14 @@ def main(argv=None) -> None:
     save_dir = args.output_dir / "eval"
     if rank == 0:
         save_dir.mkdir(exist_ok=True)
+    # ray sharding replays ONE stream of uniforms (each rank jumps the CPU generator to its slab): every rank needs rank 0's seed
+    seed = args.seed
+    if world > 1:
+        box = [torch.initial_seed() if seed is None else seed]
+        torch.distributed.broadcast_object_list(box, src=0)
+        seed = int(box[0]) % (1 << 63)
+    if seed is not None:
+        torch.manual_seed(seed)
     trainer.render_all(save_dir)
     if world > 1:
         torch.distributed.barrier()
