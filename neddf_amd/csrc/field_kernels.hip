@@ -1081,7 +1081,9 @@ static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s)
 
 void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s)
 {
-    launch_ddf_rev_t<OpsF32>(a, grid, s);
+    if (a.operands == 2) launch_ddf_rev_t<OpsF16Split>(a, grid, s);
+    else if (a.operands == 1) launch_ddf_rev_t<OpsBF16>(a, grid, s);
+    else launch_ddf_rev_t<OpsF32>(a, grid, s);
 }
 
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)

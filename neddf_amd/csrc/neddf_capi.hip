@@ -433,8 +433,11 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     // Eval-minimal NeDDF needs the gradient of one scalar (the distance) only: reverse mode halves the matrix work
     // (NEDDF_DDF_REVERSE=0 keeps the forward-mode Jacobian rows, which the penalties of the full mode need anyway)
     static const bool rev_enabled = [] { const char *e = getenv("NEDDF_DDF_REVERSE"); return !e || atoi(e) != 0; }();
-    const bool reverse = rev_enabled && !full && f.d.kind == NEDDF_FIELD_NEDDF && dt == NEDDF_DTYPE_F32 && f.ddf.n_stash <= 1 &&
-                         field_wgs_per_cu(dt) == 2;
+    // bit per operand policy: fp32 (28.5 vs 52.0 ms per 2^21 points) and split fp16 (16.3 vs 19.9 ms) gain; bf16, whose epilogue per
+    // element dominates either way, does not (8.4 vs 7.8 ms) and keeps the forward-mode kernel
+    static const int rev_mask = [] { const char *e = getenv("NEDDF_DDF_REVERSE_DTYPES"); return e ? atoi(e) : 5; }();
+    const bool reverse = rev_enabled && ((rev_mask >> dt) & 1) && !full && f.d.kind == NEDDF_FIELD_NEDDF && f.ddf.n_stash <= 1 &&
+                         field_wgs_per_cu(NEDDF_DTYPE_F32) == 2;
     const int64_t chunk_cap = full ? (1 << 19) : (1 << 21);
     const int64_t chunk = N < chunk_cap ? N : chunk_cap;
     // activations' element type and planes: fp32 1024 B, bf16 512 B, split bf16 (two planes) 1024 B per row
