@@ -493,31 +493,38 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
                 for (int q = 0; q < 16; ++q) Ops::put(o + (8 * (q >> 2) + (q & 3)) * LD, acc[mt][t][q]);
             }
         __syncthreads();
-        f32x16 gpe[1][1];               // this wave's 32 x 32 block of the encoding gradient: M-tile wave >> 1, N-tile wave & 1
-        acc_init<1, 1, false>(gpe, nullptr, wave, lane);
+        // this wave's 32 x 32 block of the encoding gradient (M-tile wave >> 1, N-tile wave & 1).  The skip layer's share waits in the
+        // scratch, not in 16 registers, while the remaining layers run (the product loop below needs them)
         const act_t *pe_lane = act_lane + (wave >> 1) * 32 * LD;
-        if (a.n_layers > 1) layer_prefetch<NT, Ops>(pre, a.wT[a.n_layers - 1], nullptr, KS, wave, lane);
+        f32x4v *gpe_park = (f32x4v *)pv + (size_t)wave * 4 * 64 + lane;        // the encoding copy in pv is no longer needed here
         for (int l = a.n_layers - 1; l >= 1; --l) {
-            if (l == a.skip_layer)      // cat([encoding, h]): the encoding rows of W_l take their share of g_l
-                dense<1, 1, Ops>(gpe, pe_lane, (const frag *)a.wT_pe_skip + (size_t)(wave & 1) * KS * 64 + lane, KS);
-            // y'_{l-1} of this lane's accumulator positions, requested before the product so that it lands under the MFMAs
-            f32x16 ypre[MT][NT];
-            {
-                const f32x4v *src = (const f32x4v *)(yp + (size_t)(l - 1) * ROWS * kWidth) + (size_t)wave * (MT * NT * 4) * 64 + lane;
+            if (l == a.skip_layer) {    // cat([encoding, h]): the encoding rows of W_l take their share of g_l
+                f32x16 gs[1][1];
+                acc_init<1, 1, false>(gs, nullptr, wave, lane);
+                dense<1, 1, Ops>(gs, pe_lane, (const frag *)a.wT_pe_skip + (size_t)(wave & 1) * KS * 64 + lane, KS);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            f32x4v v = src[((mt * NT + t) * 4 + g) * 64];
-                            ypre[mt][t][4 * g] = v[0]; ypre[mt][t][4 * g + 1] = v[1]; ypre[mt][t][4 * g + 2] = v[2]; ypre[mt][t][4 * g + 3] = v[3];
-                        }
+                for (int g = 0; g < 4; ++g) {
+                    f32x4v v = { gs[0][0][4 * g], gs[0][0][4 * g + 1], gs[0][0][4 * g + 2], gs[0][0][4 * g + 3] };
+                    gpe_park[g * 64] = v;
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            // y'_{l-1} of this lane's accumulator positions, fetched after the product: requesting it before (64 more live
+            // registers) measured no faster -- the other workgroup of the CU covers the latency
+            f32x16 ypre[MT][NT];
+            const f32x4v *ysrc = (const f32x4v *)(yp + (size_t)(l - 1) * ROWS * kWidth) + (size_t)wave * (MT * NT * 4) * 64 + lane;
+            auto load_ypre = [&](int mt) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4v v = ysrc[((mt * NT + t) * 4 + g) * 64];
+                        ypre[mt][t][4 * g] = v[0]; ypre[mt][t][4 * g + 1] = v[1]; ypre[mt][t][4 * g + 2] = v[2]; ypre[mt][t][4 * g + 3] = v[3];
+                    }
+            };
             acc_init<MT, NT, false>(acc, nullptr, wave, lane);
-            dense_pre<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS, pre);
-            if (l > 1) layer_prefetch<NT, Ops>(pre, a.wT[l - 1], nullptr, KS, wave, lane);      // next product's first fragments fly during the epilogue
+            dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
+            load_ypre(0);
+            load_ypre(1);
             __syncthreads();            // every wave finished reading g_l
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -533,6 +540,14 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
                 }
             __syncthreads();
         }
+        f32x16 gpe[1][1];
+        if (a.skip_layer >= 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4v v = gpe_park[g * 64];
+                gpe[0][0][4 * g] = v[0]; gpe[0][0][4 * g + 1] = v[1]; gpe[0][0][4 * g + 2] = v[2]; gpe[0][0][4 * g + 3] = v[3];
+            }
+        } else acc_init<1, 1, false>(gpe, nullptr, wave, lane);
         dense<1, 1, Ops>(gpe, pe_lane, (const frag *)a.wT_pe0 + (size_t)(wave & 1) * KS * 64 + lane, KS);       // g_0 W_0^T
         __syncthreads();                // every wave finished reading g_0
         {

@@ -13,12 +13,14 @@ python bench.py --dtype bf16 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c
 python bench.py --workload train --steps 5 --warmup 2 > $O/bench_train_f32.json 2>/dev/null
 NEDDF_BENCH_FORCE_DIST=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c2_forced_collective.json 2>/dev/null
 python tools/host_rng_probe.py > $O/host_rng_probe.json 2>/dev/null
+NEDDF_DDF_REVERSE=0 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c2_f32_forward_mode.json 2>/dev/null
+python tools/parity_report.py > $O/parity_report.json 2>/dev/null
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o b -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_bench.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$c -- python $ROOT/tools/pmc_probe.py 1 > $O/pmc_$c.log 2>&1
 done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc/sq -- python $ROOT/tools/pmc_probe.py 1 > $O/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc/sq -- python $ROOT/tools/pmc_probe.py 1 > $O/pmc_sq.log 2>&1
 cd $ROOT
 python tools/pmc_summary.py $O/pmc > $O/pmc_summary.csv
 find $O/prof -name "*stats*" | head; find $O/prof -name "*.csv" | head
