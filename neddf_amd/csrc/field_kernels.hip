@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
             constexpr int CE = 16 / sizeof(act_t), CPP = kWidth / CE, CPR = Ops::kPlanes * CPP;
             act_t *features = (act_t *)a.features;
             const int fr = a.feat_rows;
-            for (int idx = tid; idx < P * fr * CPR; idx += THREADS) {
+            for (int idx = tid; features && idx < P * fr * CPR; idx += THREADS) {
                 int r = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
                 int p = r / fr, rr = r - p * fr;
                 if (p0 + p < a.n_points) {
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
         {
             constexpr int CE = 16 / sizeof(act_t), CPP = kWidth / CE, CPR = Ops::kPlanes * CPP;
             act_t *features = (act_t *)a.features;
-            for (int idx = tid; idx < P * CPR; idx += kThreads) {
+            for (int idx = tid; features && idx < P * CPR; idx += kThreads) {
                 const int p = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
                 if (p0 + p < a.n_points) {
                     f32x4v v = *(const f32x4v *)(act + p * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));

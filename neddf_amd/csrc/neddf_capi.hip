@@ -453,7 +453,8 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         a.pos = pos + off * 3; a.dir = dir + off * 3; a.var = var + off * 3; a.n_points = n;
         a.aux_grad_scale = f.aux_grad_scale;
         a.scratch = (float *)ctx->scratch.p;
-        a.features = (float *)ctx->features.p; a.feat_rows = fr;
+        a.features = (color || full) ? (float *)ctx->features.p : nullptr;      // no colour trunk follows: no hand-off
+        a.feat_rows = fr;
         a.ptaux = (float *)ctx->ptaux.p;
         a.distance = distance ? distance + off : nullptr;
         a.density = density ? density + off : nullptr;
@@ -705,10 +706,13 @@ static int render_pass(neddf_ctx *ctx, int slot, const float *rd, const float *r
 {
     STAGE(ctx, s, NEDDF_STAGE_SAMPLING, launch_sampling(rd, ro, view, dists, B, S, rp->cone_sampling ? rp->ray_radius : -1.0, pos, dir, var, s));
     const bool want_pen = pen_out && ctx->field[slot].d.kind == NEDDF_FIELD_NEDDF;
-    int rc = field_forward(ctx, slot, pos, dir, var, B * S, want_pen ? NEDDF_OUT_FULL : NEDDF_OUT_MINIMAL, nullptr, dens, col,
+    // a pass whose pixels nobody asked for (the coarse pass of render_image: only its resampling weights are consumed) needs the
+    // densities only -- the colour trunk is skipped (the reference evaluates and discards it)
+    const bool want_col = depth || color || trans || want_pen;
+    int rc = field_forward(ctx, slot, pos, dir, var, B * S, want_pen ? NEDDF_OUT_FULL : NEDDF_OUT_MINIMAL, nullptr, dens, want_col ? col : nullptr,
                            want_pen ? pen : nullptr, nullptr, s);
     if (rc) return rc;
-    STAGE(ctx, s, NEDDF_STAGE_COMPOSITE, launch_composite(dists, dens, col, B, S, rp->max_dist, w_out, depth, color, trans, nan_flag, s));
+    STAGE(ctx, s, NEDDF_STAGE_COMPOSITE, launch_composite(dists, dens, want_col ? col : nullptr, B, S, rp->max_dist, w_out, depth, color, trans, nan_flag, s));
     if (want_pen) STAGE(ctx, s, NEDDF_STAGE_PENALTY, launch_integrate_penalty(dists, pen, B, S, pen_out, s));
     return 0;
 }
@@ -735,9 +739,11 @@ int neddf_render_rays(neddf_ctx *ctx, const void *uv, int uv_type, int64_t B, co
     float *pos = cv.take(B * S2 * 3), *dir = cv.take(B * S2 * 3), *var = cv.take(B * S2 * 3);
     float *dens = cv.take(B * S2), *pen = cv.take(B * S2), *col = cv.take(B * S2 * 3);
     float *wc = out->weight_coarse ? out->weight_coarse : cv.take(B * (Sc1 - 1));
-    float *depth_c = out->depth_coarse ? out->depth_coarse : cv.take(B);
-    float *color_c = out->color_coarse ? out->color_coarse : cv.take(B * 3);
-    float *trans_c = out->transmittance_coarse ? out->transmittance_coarse : cv.take(B);
+    // coarse pixels only when the caller asked for one of them (render_rays); render_image does not
+    const bool coarse_px = out->depth_coarse || out->color_coarse || out->transmittance_coarse || out->fields_penalty_coarse;
+    float *depth_c = out->depth_coarse ? out->depth_coarse : (coarse_px ? cv.take(B) : nullptr);
+    float *color_c = out->color_coarse ? out->color_coarse : (coarse_px ? cv.take(B * 3) : nullptr);
+    float *trans_c = out->transmittance_coarse ? out->transmittance_coarse : (coarse_px ? cv.take(B) : nullptr);
     float *depth = out->depth ? out->depth : cv.take(B);
     float *color = out->color ? out->color : cv.take(B * 3);
     float *trans = out->transmittance ? out->transmittance : cv.take(B);

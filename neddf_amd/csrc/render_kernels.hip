@@ -169,6 +169,8 @@ __device__ __forceinline__ float wave_sum(float v)
 // integrate_volume_render base_neural_render.py:117-172.  One wavefront per
 // ray; T_j = prod_{k<j}(1 - o_k + 1e-7) is a wave multiplicative scan carried in
 // fp64 (torch-CPU cumprod accumulates in double and rounds each output, N2).
+// col == NULL: weights only (the coarse pass of render_rays when nobody asked for
+// its pixels: only the resampling weights are consumed); depth / color / trans may then be NULL too.
 __global__ __launch_bounds__(256) void composite_kernel(const float *dists, const float *dens, const float *col, int64_t n,
                                                         int S, float max_dist, float *weight, float *depth, float *color,
                                                         float *trans, int *nan_flag)
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const float *dists, cons
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= n) return;
-    const float *d = dists + b * S, *r = dens + b * S, *c = col + b * S * 3;
+    const float *d = dists + b * S, *r = dens + b * S, *c = col ? col + b * S * 3 : nullptr;
     double carry = 1.0;               // T entering this 64-sample chunk
     float sd = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
     bool bad = false;
@@ -196,18 +198,20 @@ __global__ __launch_bounds__(256) void composite_kernel(const float *dists, cons
             if (w != w) bad = true;
             if (weight) weight[b * (S - 1) + j] = w;
             sd += w * dj;
-            s0 += w * c[3 * j + 0];
-            s1 += w * c[3 * j + 1];
-            s2 += w * c[3 * j + 2];
+            if (c) {
+                s0 += w * c[3 * j + 0];
+                s1 += w * c[3 * j + 1];
+                s2 += w * c[3 * j + 2];
+            }
         }
         carry = __shfl(incl, 63, 64);
     }
     sd = wave_sum(sd); s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
     float tend = (float)carry;
     if (lane == 0) {
-        depth[b] = sd + tend * max_dist;                        // black background, :163
-        color[3 * b + 0] = s0; color[3 * b + 1] = s1; color[3 * b + 2] = s2;
-        trans[b] = tend;
+        if (depth) depth[b] = sd + tend * max_dist;             // black background, :163
+        if (color) { color[3 * b + 0] = s0; color[3 * b + 1] = s1; color[3 * b + 2] = s2; }
+        if (trans) trans[b] = tend;
     }
     if (nan_flag && __any(bad) && lane == 0) atomicOr(nan_flag, 1);
 }
