@@ -395,10 +395,10 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
     const int kin = Ops::kStep * a.layer[0].ksteps;
     const int K3 = 3 * a.enc.E, KH = a.enc.KH;
     const int64_t ntiles = (a.n_points + P - 1) / P;
-    // super-steps of a 256-wide product, as a RUN-TIME value (the argument block carries it): with the compile-time constant hipcc
+    // super-steps of a 256-wide product, as a RUN-TIME value (the argument block carries it, DdfArgs::ks_hidden): with the compile-time constant hipcc
     // unrolls the reverse products completely, materialises one 64-bit address per weight fragment, spills them and reloads each
     // behind an s_waitcnt vmcnt(0) -- which serialises the operand prefetch of half of the kernel's matrix work
-    const int KS = a.layer[a.n_layers - 1].ksteps;
+    const int KS = a.ks_hidden;
     const int j = lane & 31, h = lane >> 5;
 
     int *ctl = (int *)(lp + 12);

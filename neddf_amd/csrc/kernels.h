@@ -66,6 +66,7 @@ struct DdfArgs {
     const float *wT[kMaxLayers];          // [l >= 1] packed (hidden rows of W_l)^T, 256 x 256
     const float *wT_pe0, *wT_pe_skip;     // packed [256 x 64]: W_0^T and the skip layer's encoding rows^T (engine column order)
     int skip_layer;                       // trunk layer whose input is cat([encoding, h]), or -1
+    int ks_hidden;                        // super-steps of a 256-wide product under this operand policy
     float *rev_scratch;                   // per workgroup: y' of every layer [n_layers][64][256] + encoding Jacobian [64][64]
     int *sched;                           // [0] tile queue head (zeroed before each launch)
     int sched_flags;                      // bit 1: dynamic tile queue; higher bits: timing ablations, -DNEDDF_ABLATE builds only

@@ -237,6 +237,7 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     for (int l = 1; l < n_trunk; ++l) a.wT[l] = base + o_wT[l];
     a.wT_pe0 = base + o_wT_pe0;
     a.wT_pe_skip = a.skip_layer >= 0 ? base + o_wT_pes : nullptr;
+    a.ks_hidden = kWidth / (operands ? 16 : 8);
     c.wp_a = base + o_wa;
     for (int l = 0; l < n_col; ++l) { c.layer[l].wp = base + c_wp[l]; c.layer[l].bias = base + c_b[l]; }
     c.w_out = base + o_cout;

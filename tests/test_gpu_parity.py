@@ -270,6 +270,13 @@ def test_neddf_synth(dev, orc, name):
         for k in ("distance", "aux_grad", "color", "density", "fields_penalty"):
             assert_close(N(o[k]), g["%s_%s" % (tag, k)], 2e-4, 2e-5, "%s %s %s vs golden" % (name, tag, k))
             assert_close(N(o[k]), ref[k], 2e-4, 2e-5, "%s %s %s vs oracle" % (name, tag, k))
+        # the eval-minimal path (reverse-mode distance gradient, ddf_rev_kernel) on the same architecture / iteration state
+        net.output_mode = "minimal"
+        o2 = net(smp(g, dev))
+        net.output_mode = "full"
+        assert "fields_penalty" not in o2
+        for k in ("distance", "aux_grad", "color", "density"):
+            assert_close(N(o2[k]), g["%s_%s" % (tag, k)], 2e-4, 2e-5, "%s %s %s minimal vs golden" % (name, tag, k))
 
 
 @pytest.mark.parametrize("name", ["nerf_relu", "nerf_tanhexp"])
