@@ -422,8 +422,8 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
             Ops::put(act + p * LD + KH + q, vc);
             pj[p * 64 + q] = js;
             pj[p * 64 + 32 + q] = jc;
-            pv[p * 64 + q] = vs;
-            pv[p * 64 + 32 + q] = vc;
+            pv[p * 64 + q] = vs;               // same column order as the LDS tile: [sine half (KH) | cosine half (KH)]
+            pv[p * 64 + KH + q] = vc;
         }
         __syncthreads();
 
