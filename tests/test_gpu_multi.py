@@ -222,3 +222,70 @@ def test_run_eval_under_a_launcher_matches_single_process(tmp_path):
         for suffix in ("rgb", "rgb_gt", "depth"):
             name = "%03d_%s.png" % (i, suffix)
             assert (outs["one"] / name).read_bytes() == (outs["two"] / name).read_bytes(), name
+
+
+def test_c_client_of_the_abi(tmp_path):
+    """INTEGRATION.md mode B: a plain-C program (tests/capi/c_smoke.c, built with gcc against include/neddf_hip.h -- no Python, no
+    torch) sets up the shipped NeDDF architecture, renders 96 rays through neddf_render_rays in both output modes and gathers the
+    pixels over a one-rank communicator.  Its outputs must equal what the Python binding renders from the same numbers (weights,
+    rays, uniforms from the same linear congruential generator): the C calling convention, struct layouts and pointer ownership
+    of the header are what a reference-side binding would rely on."""
+    import ctypes
+    from conftest import BUNNY_CFG
+    import neddf_amd
+    exe = str(tmp_path / "c_smoke")
+    out = str(tmp_path / "out.bin")
+    csrc = os.path.join(ROOT, "neddf_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "capi", "c_smoke.c"), "-L", csrc, "-lneddf_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+                           "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    p = subprocess.run([exe, out], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "c_smoke ok" in p.stdout, p.stdout + p.stderr
+    RAYS = 96
+    got = np.fromfile(out, np.float32)
+    assert got.size == RAYS * 21
+    full, mini, packed, gathered = got[:RAYS * 6], got[RAYS * 6:RAYS * 11], got[RAYS * 11:RAYS * 16], got[RAYS * 16:]
+    assert np.array_equal(packed, gathered)                                   # the library's own all-gather, one rank
+    assert np.array_equal(packed.reshape(RAYS, 5)[:, :3].ravel(), mini[:RAYS * 3])
+
+    # the same numbers on the Python side
+    state = 12345
+    def lcg(n):
+        nonlocal state
+        vals = np.empty(n, np.float64)
+        for i in range(n):
+            state = (state * 1664525 + 1013904223) & 0xFFFFFFFF
+            vals[i] = (state >> 8) / 8388608.0 - 1.0
+        return vals.astype(np.float32)
+    dims = [(60 if l == 0 else (316 if l == 5 else 256), 256) for l in range(7)] + [(343 if l == 0 else 256, 256) for l in range(3)] + \
+           [(256, 1), (256, 1), (256, 3)]
+    names = ["layers_ddf.%d" % l for l in range(7)] + ["layers_col.%d" % l for l in range(3)] + ["layer_ddf_out", "layer_aux_out", "layer_col_out"]
+    sd = {}
+    for name, (i, o) in zip(names, dims):
+        s_ = np.float32(np.sqrt(np.float32(2.0) / np.float32(i + o)))
+        sd[name + ".weight"] = torch.from_numpy((np.float32(1.7) * s_ * lcg(i * o)).astype(np.float32).reshape(i, o))
+        sd[name + ".bias"] = torch.from_numpy((np.float32(0.05) * lcg(o)).astype(np.float32))
+    uc = (np.float32(0.5) * (lcg(RAYS * 65) + np.float32(1.0))).reshape(RAYS, 65)
+    uf = (np.float32(0.5) * (lcg(RAYS * 129) + np.float32(1.0))).reshape(RAYS, 129)
+    dev = torch.device("cuda:0")
+    r = neddf_amd.NeRFRender(dict(BUNNY_CFG, _target_="neddf.network.NeDDF"), sample_coarse=64, sample_fine=128, dist_near=2.0, dist_far=6.0,
+                             max_dist=6.0, use_coarse_network=False, sampling_type="cone")
+    r.network_fine.load_state_dict(sd)
+    r.to(dev)
+    r.set_iter(-1)
+    cam = neddf_amd.Camera(neddf_amd.PinholeCalib(np.array([555.6, 555.6, 200.0, 200.0])), None).to(dev)
+    cam.R = torch.eye(3, device=dev)
+    cam.T = torch.tensor([0.1, -0.05, 4.0], device=dev)
+    uv = torch.tensor([[140 + (k * 7) % 120, 150 + (k * 11) % 100] for k in range(RAYS)], dtype=torch.int64, device=dev)
+    with torch.no_grad():
+        ctx = r._ctx(dev)
+        of = r._render(ctx, uv, cam, torch.from_numpy(uc).to(dev), torch.from_numpy(uf).to(dev), full=True)
+        om = r._render(ctx, uv, cam, torch.from_numpy(uc).to(dev), torch.from_numpy(uf).to(dev), full=False)
+    want_full = np.concatenate([of["color"].cpu().numpy().ravel(), of["depth"].cpu().numpy(), of["transmittance"].cpu().numpy(),
+                                of["fields_penalty"].cpu().numpy()])
+    want_mini = np.concatenate([om["color"].cpu().numpy().ravel(), om["depth"].cpu().numpy(), om["transmittance"].cpu().numpy()])
+    assert np.isfinite(got).all()
+    # same library, same inputs: the full-mode pass differs from the Python call only in which optional outputs were requested
+    # (the C program asks for no coarse outputs), which selects no different arithmetic -- bit-identical
+    assert np.array_equal(mini, want_mini), float(np.abs(mini - want_mini).max())
+    assert np.array_equal(full, want_full), float(np.abs(full - want_full).max())
