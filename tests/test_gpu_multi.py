@@ -285,7 +285,8 @@ def test_c_client_of_the_abi(tmp_path):
                                 of["fields_penalty"].cpu().numpy()])
     want_mini = np.concatenate([om["color"].cpu().numpy().ravel(), om["depth"].cpu().numpy(), om["transmittance"].cpu().numpy()])
     assert np.isfinite(got).all()
-    # same library, same inputs: the full-mode pass differs from the Python call only in which optional outputs were requested
-    # (the C program asks for no coarse outputs), which selects no different arithmetic -- bit-identical
+    # same library, same inputs, same outputs requested: bit-identical
     assert np.array_equal(mini, want_mini), float(np.abs(mini - want_mini).max())
-    assert np.array_equal(full, want_full), float(np.abs(full - want_full).max())
+    # the C program's first call asks for fields_penalty but for no coarse outputs, so its coarse pass runs eval-minimal (reverse-mode
+    # distance gradient) where the Python render_rays-style call (every key) carries Jacobian rows: same function, different rounding
+    assert_close(full, want_full, 1e-4, 1e-5, "C full-mode outputs vs Python binding")
