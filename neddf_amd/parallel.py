@@ -58,13 +58,35 @@ def native_comm(ctx, group=None):
         return info
     if info["nranks"]:
         ctx.comm_destroy()
-    # the id travels as a byte tensor: on the device for an RCCL process group, on the host for gloo
+    # the id travels as a byte tensor: on the device for an RCCL process group, on the host for gloo.  Byte 128 says whether
+    # rank 0 could make one, and the join ends with a vote, so that a failure raises on EVERY rank (a caller with a second
+    # route -- bench.py falls back to torch.distributed's all-gather -- must take it on all ranks or on none)
     on_device = "nccl" in str(dist.get_backend(group))
-    box = torch.zeros(128, dtype=torch.uint8, device=ctx.device if on_device else "cpu")
+    side = ctx.device if on_device else "cpu"
+    box = torch.zeros(129, dtype=torch.uint8, device=side)
+    err = None
     if rank == 0:
-        box.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
+        try:
+            staged = torch.zeros(129, dtype=torch.uint8)
+            staged[:128] = torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8)
+            staged[128] = 1
+            box.copy_(staged)
+        except Exception as e:              # no RCCL to load, ...: tell the others instead of leaving them in the broadcast
+            err = e
     dist.broadcast(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    ctx.comm_init(rank, world, bytes(box.cpu().numpy().tobytes()))
+    host = box.cpu()
+    if int(host[128]) != 1:
+        raise RuntimeError("rank 0 could not create an RCCL unique id%s" % (": %s" % err if err is not None else ""))
+    try:
+        ctx.comm_init(rank, world, bytes(host[:128].numpy().tobytes()))
+    except Exception as e:
+        err = e
+    vote = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=side)
+    dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=group)
+    if int(vote.item()) != 1:
+        if err is None:
+            ctx.comm_destroy()
+        raise RuntimeError("neddf_comm_init failed on %s" % ("this rank: %s" % err if err is not None else "another rank"))
     return ctx.comm_info()
 
 

@@ -246,6 +246,34 @@ if rank == 0:
 average_gradients(ps)
 assert torch.allclose(ps[0].grad, torch.full((3, 4), (world + 1) / 2)) and torch.allclose(ps[1].grad, torch.zeros(5), atol=1e-6)
 assert torch.allclose(ps[2].grad, torch.full((2, 2), 1.0 / world))
+# communicator bootstrap (native_comm): a failure anywhere must raise on EVERY rank, never strand the others in a collective
+from neddf_amd.parallel import native_comm
+class FakeCtx:
+    device = torch.device("cpu")
+    def __init__(self, fail_id=False, fail_init_on=None):
+        self.fail_id, self.fail_init_on, self.info, self.destroyed = fail_id, fail_init_on, dict(rank=0, nranks=0), False
+    def comm_info(self):
+        return self.info
+    def comm_unique_id(self):
+        if self.fail_id:
+            raise OSError("librccl.so.1 not found")
+        return bytes(range(128))
+    def comm_init(self, r, n, uid):
+        assert uid == bytes(range(128)), "unique id did not arrive intact"
+        if self.fail_init_on == r:
+            raise RuntimeError("ncclCommInitRank: unhandled system error")
+        self.info = dict(rank=r, nranks=n, rccl_version=0)
+    def comm_destroy(self):
+        self.destroyed, self.info = True, dict(rank=0, nranks=0)
+good = FakeCtx()
+assert native_comm(good) == dict(rank=rank, nranks=world, rccl_version=0)
+for bad in (FakeCtx(fail_id=True), FakeCtx(fail_init_on=world - 1)):
+    try:
+        native_comm(bad)
+        raise AssertionError("native_comm must raise on every rank")
+    except RuntimeError as e:
+        pass
+    assert bad.comm_info()["nranks"] == 0, "a rank that joined must leave again when another rank failed"
 dist.barrier()
 print("rank", rank, "ok")
 '''
