@@ -326,9 +326,9 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
 // i.e. two rows of matrix work per point and layer instead of four, on tiles of 64 POINTS (all M-tile rows useful) instead of
 // 16 points x 4 rows: 13 layer-equivalents of MFMA work per 64 points against 29.6.  Same function, same weights; the
 // result differs from the forward-mode Jacobian only in rounding (checked against the oracle and the reference goldens by the
-// same gates).  What it costs: y'_l of the tile (7 x 64 KB) does not fit in LDS next to the activations, so it makes a round trip
-// through a per-workgroup scratch in global memory (written by the forward epilogue, read back -- prefetched a layer ahead --
-// by the backward one); and the activation is evaluated per element instead of once per four accumulator rows.
+// same gates).  What it costs: y'_l of the tile (64 KB per layer) does not fit in LDS next to the activations, so it makes a round
+// trip through a per-workgroup scratch in global memory (written by the forward epilogue, read back by the backward one right
+// after its product); and the activation is evaluated per element instead of once per four accumulator rows.
 // Used when the caller wants no penalties / Jacobian outputs (render_image, render_rays without fields_penalty); the
 // forward-mode kernel above serves the training-mode outputs.
 size_t ddf_rev_scratch_floats_per_wg(int n_layers) { return (size_t)n_layers * kRevPoints * kWidth + (size_t)kRevPoints * 128; }
