@@ -182,14 +182,50 @@ __device__ __forceinline__ const typename Ops::act_t *act_lane_ptr(const typenam
 
 // ----------------------------------------------------------------------------
 // dense: acc[mt][t] += act[rows, k0 .. k0+kStep*ksteps) x Wpacked
+//
+// Operand addresses cost no vector instructions inside the product loop (on gfx950 a VALU instruction between two MFMAs of
+// a wave costs ~16 cycles of matrix time, profiles/r02_shadow_ubench.txt): the weight pointer of a wave is wave-uniform
+// apart from the lane's slot, so the fragments are fetched as buffer loads -- a scalar resource (the wave's base), the
+// constant lane offset in a VGPR and the super-step's offset in an SGPR (`buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen`)
+// -- instead of one 64-bit v_lshl_add_u64 per global load.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct WeightStream {
+    __amdgpu_buffer_rsrc_t rsrc;    // base = the wave's first fragment, raw buffer without range clamp
+    unsigned lane_off;              // lane * sizeof(fragment)
+};
+
+template <class F>
+__device__ __forceinline__ WeightStream weight_stream(const F *wl)
+{
+    // wl = (wave-uniform fragment pointer) + lane: recover the uniform part and hand it to the scalar unit
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const unsigned long long u = (unsigned long long)(wl - lane);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    void *base = (void *)(((unsigned long long)hi << 32) | lo);
+    return { __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)0xffffffffu, 0x00020000), lane * (unsigned)sizeof(F) };
+}
+
+template <class F>
+__device__ __forceinline__ F stream_load(const WeightStream &w, unsigned frag_index)
+{
+    static_assert(sizeof(F) % 16 == 0, "fragments are fetched 16 bytes at a time");
+    struct Raw { u32x4 v[sizeof(F) / 16]; } raw;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(F) / 16; ++i)
+        raw.v[i] = __builtin_amdgcn_raw_buffer_load_b128(w.rsrc, w.lane_off + 16 * i, frag_index * (64 * (unsigned)sizeof(F)), 0);
+    return __builtin_bit_cast(F, raw);
+}
+
+// B fragments of super-step S (scalar index, clamped by the caller) and A fragments at `ap` (the lane's pointer for that
+// super-step: the caller advances it, so the LDS reads carry immediate offsets and cost no address arithmetic either)
 template <int MT, int NT, class Ops = OpsF32>
-__device__ __forceinline__ void dense_load(typename Ops::afrag (&a)[MT], typename Ops::bfrag (&b)[NT], const typename Ops::act_t *act_lane,
-                                           const typename Ops::bfrag *wl, int ksteps, int S)
+__device__ __forceinline__ void dense_load(typename Ops::afrag (&a)[MT], typename Ops::bfrag (&b)[NT], const typename Ops::act_t *ap,
+                                           const WeightStream &w, int ksteps, int S)
 {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) b[t] = wl[((size_t)t * ksteps + S) * 64];
+    for (int t = 0; t < NT; ++t) b[t] = stream_load<typename Ops::bfrag>(w, (unsigned)(t * ksteps + S));
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = Ops::load_a(act_lane + mt * 32 * Ops::kLd + Ops::kStep * S);
+    for (int mt = 0; mt < MT; ++mt) a[mt] = Ops::load_a(ap + mt * 32 * Ops::kLd);
 }
 
 template <int MT, int NT, class Ops = OpsF32>
@@ -240,22 +276,26 @@ __device__ __forceinline__ void acc_init_pre(f32x16 (&acc)[MT][NT], const LayerP
 
 template <int MT, int NT, class Ops = OpsF32>
 __device__ __forceinline__ void dense_pipeline(f32x16 (&acc)[MT][NT], typename Ops::afrag (&a0)[MT], typename Ops::bfrag (&b0)[NT],
-                                               const typename Ops::act_t *act_lane, const typename Ops::bfrag *wl, int ksteps)
+                                               const typename Ops::act_t *act_lane, const WeightStream &wl, int ksteps)
 {
     typename Ops::afrag a1[MT];
     typename Ops::bfrag b1[NT];
+    // A fragments past the last super-step are fetched like the others and never used (the reads stay inside the workgroup's
+    // LDS: at most two super-steps beyond a row's columns); the weight index is clamped instead, it could leave the allocation
+    const typename Ops::act_t *ap = act_lane;
     for (int S = 0; S < ksteps; S += 2) {
         const bool more = S + 1 < ksteps;
-        dense_load<MT, NT, Ops>(a1, b1, act_lane, wl, ksteps, more ? S + 1 : S);
+        dense_load<MT, NT, Ops>(a1, b1, ap + Ops::kStep, wl, ksteps, more ? S + 1 : S);
         __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
         dense_mfma<MT, NT, Ops>(acc, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            dense_load<MT, NT, Ops>(a0, b0, act_lane, wl, ksteps, S + 2 < ksteps ? S + 2 : S);
+            dense_load<MT, NT, Ops>(a0, b0, ap + 2 * Ops::kStep, wl, ksteps, S + 2 < ksteps ? S + 2 : S);
             __builtin_amdgcn_sched_barrier(0);
             dense_mfma<MT, NT, Ops>(acc, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        ap += 2 * Ops::kStep;
     }
 }
 
@@ -269,7 +309,7 @@ __device__ __forceinline__ void dense_pre(f32x16 (&acc)[MT][NT], const typename 
     for (int t = 0; t < NT; ++t) b0[t] = p.b[t];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) a0[mt] = Ops::load_a(act_lane + mt * 32 * Ops::kLd);
-    dense_pipeline<MT, NT, Ops>(acc, a0, b0, act_lane, wl, ksteps);
+    dense_pipeline<MT, NT, Ops>(acc, a0, b0, act_lane, weight_stream(wl), ksteps);
 }
 
 template <int MT, int NT, class Ops = OpsF32>
@@ -277,8 +317,9 @@ __device__ __forceinline__ void dense(f32x16 (&acc)[MT][NT], const typename Ops:
 {
     typename Ops::afrag a0[MT];
     typename Ops::bfrag b0[NT];
-    dense_load<MT, NT, Ops>(a0, b0, act_lane, wl, ksteps, 0);
-    dense_pipeline<MT, NT, Ops>(acc, a0, b0, act_lane, wl, ksteps);
+    const WeightStream w = weight_stream(wl);
+    dense_load<MT, NT, Ops>(a0, b0, act_lane, w, ksteps, 0);
+    dense_pipeline<MT, NT, Ops>(acc, a0, b0, act_lane, w, ksteps);
 }
 
 template <int MT, int NT, bool ROWS4>
