@@ -348,14 +348,20 @@ __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], type
             typename Ops::act_t *o = act + (mt * 32 + 4 * h) * LD + col;
             const float ws = LAST ? wseed[col] : 1.0f;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < 16; q += 2) {       // accumulator registers q, q + 1 = rows r, r + 1 of this lane's column
                 const int r = 8 * (q >> 2) + (q & 3);
-                float z = acc[mt][t][q];
-                if constexpr (Ops::kWScale != 1.0f) z *= (1.0f / Ops::kWScale);
-                float y, dy;
-                act_grad<KIND, Ops::kFastAct>(z, y, dy);
-                Ops::put(o + r * LD, y);
-                acc[mt][t][q] = LAST ? ws * dy : dy;     // y' replaces the accumulator (LAST: the seed of the reverse pass, dz_D / dz_L)
+                float y[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float z = acc[mt][t][q + u];
+                    if constexpr (Ops::kWScale != 1.0f) z *= (1.0f / Ops::kWScale);
+                    float dy;
+                    act_grad<KIND, Ops::kFastAct>(z, y[u], dy);
+                    // y' replaces the accumulator (LAST: the seed of the reverse pass, dz_D / dz_L).  The stashed copy carries the
+                    // weight scale's inverse (a power of two: exact), so the reverse epilogue is one multiply per element
+                    acc[mt][t][q + u] = LAST ? ws * dy : dy * (1.0f / Ops::kWScale);
+                }
+                Ops::put2(o + r * LD, o + (r + 1) * LD, y[0], y[1]);
             }
         }
     // y' leaves in the accumulators' own fragment order (16 bytes per lane, 1 KiB per wave and store): only this workgroup's
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
             for (int t = 0; t < NT; ++t) {
                 act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) Ops::put(o + (8 * (q >> 2) + (q & 3)) * LD, acc[mt][t][q]);
+                for (int q = 0; q < 16; q += 2) Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, acc[mt][t][q], acc[mt][t][q + 1]);
             }
         __syncthreads();
         // this wave's 32 x 32 block of the encoding gradient (M-tile wave >> 1, N-tile wave & 1).  The skip layer's share waits in the
@@ -535,11 +541,9 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
                 for (int t = 0; t < NT; ++t) {
                     act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        float g = acc[mt][t][q] * ypre[mt][t][q];
-                        if constexpr (Ops::kWScale != 1.0f) g *= (1.0f / Ops::kWScale);
-                        Ops::put(o + (8 * (q >> 2) + (q & 3)) * LD, g);
-                    }
+                    for (int q = 0; q < 16; q += 2)
+                        Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, acc[mt][t][q] * ypre[mt][t][q],
+                                  acc[mt][t][q + 1] * ypre[mt][t][q + 1]);
                 }
             __syncthreads();
         }

@@ -42,6 +42,7 @@ struct OpsF32 {
     static __device__ __forceinline__ void zero(act_t *p) { *p = 0.f; }
     static __device__ __forceinline__ void put4(act_t *p, const f32x4v &v) { *(f32x4v *)p = v; }     // 4 consecutive columns
     static __device__ __forceinline__ void put(act_t *p, float v) { *p = v; }
+    static __device__ __forceinline__ void put2(act_t *pa, act_t *pb, float va, float vb) { *pa = va; *pb = vb; }   // two values, two places
     static __device__ __forceinline__ float get(const act_t *p) { return *p; }
     static __device__ __forceinline__ void load4(const act_t *p, float (&x)[4])
     {
@@ -78,6 +79,13 @@ struct OpsBF16 {
         return __builtin_bit_cast(unsigned int, o) & 0xffffu;
     }
     static __device__ __forceinline__ void put(act_t *p, float v) { *p = cvt(v); }
+    static __device__ __forceinline__ void put2(act_t *pa, act_t *pb, float va, float vb)      // one packed conversion for both
+    {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const unsigned int w = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){ va, vb }, bf16x2));
+        *pa = (unsigned short)w; *pb = (unsigned short)(w >> 16);
+    }
     // four values of one column to four consecutive rows: two packed conversions, the upper halves stored with d16_hi
     static constexpr bool kPackedRows = true;
     static __device__ __forceinline__ void put_rows4(act_t *p, int ld, float v0, float v1, float v2, float v3)
@@ -135,6 +143,9 @@ struct OpsF16Split {
         p[0] = __builtin_bit_cast(unsigned short, h);
         p[kPlane] = __builtin_bit_cast(unsigned short, m);
     }
+    // (a packed variant -- both first terms from one v_cvt_pkrtz, both remainders from a second one, rounded toward zero -- was
+    // measured: 1 % faster, 20 dB of PSNR lost to the truncated remainders; not kept)
+    static __device__ __forceinline__ void put2(act_t *pa, act_t *pb, float va, float vb) { put(pa, va); put(pb, vb); }
     static __device__ __forceinline__ void zero(act_t *p) { p[0] = 0; p[kPlane] = 0; }
     static __device__ __forceinline__ void put4(act_t *p, const f32x4v &v)                               // 4 consecutive columns
     {
@@ -386,21 +397,21 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[MT][NT], typename O
                     if constexpr (Ops::kWScale != 1.0f) z[r] *= (1.0f / Ops::kWScale);      // exact: a power of two
                 }
                 if constexpr (Ops::kPackedRows) {
-                    // 16-bit policies are VALU-bound (profiles/r02_geometry_sweep.md): packed multiplies (x, z1) * (t, y') and
-                    // (z2, z3) * (y', y'), two packed conversions, four 2-byte stores
+                    // 16-bit policies are VALU-bound (profiles/r02_geometry_sweep.md): four scalar multiplies (measured faster than
+                    // two v_pk_mul_f32 + the move that pairs their operands), two packed conversions, four 2-byte stores
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
                     if (ROWS4) {
                         f32x2 lo, hi;
                         if constexpr (KIND == 2 && Ops::kFastAct) {
                             float tx, dy;
                             tanhexp_parts_fast(z[0], tx, dy);
-                            lo = (f32x2){ z[0], z[1] } * (f32x2){ tx, dy };
-                            hi = (f32x2){ z[2], z[3] } * (f32x2){ dy, dy };
+                            lo = (f32x2){ z[0] * tx, z[1] * dy };
+                            hi = (f32x2){ z[2] * dy, z[3] * dy };
                         } else {
                             float y, dy;
                             act_grad<KIND, Ops::kFastAct>(z[0], y, dy);
                             lo = (f32x2){ y, dy * z[1] };
-                            hi = (f32x2){ z[2], z[3] } * (f32x2){ dy, dy };
+                            hi = (f32x2){ z[2] * dy, z[3] * dy };
                         }
                         Ops::put_rows4(o + (8 * g) * LD, LD, lo[0], lo[1], hi[0], hi[1]);
                     } else {
@@ -410,13 +421,12 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[MT][NT], typename O
                 } else if (ROWS4) {
                     float y, dy;
                     act_grad<KIND, Ops::kFastAct>(z[0], y, dy);
-                    Ops::put(o + (8 * g + 0) * LD, y);
-                    Ops::put(o + (8 * g + 1) * LD, dy * z[1]);
-                    Ops::put(o + (8 * g + 2) * LD, dy * z[2]);
-                    Ops::put(o + (8 * g + 3) * LD, dy * z[3]);
+                    Ops::put2(o + (8 * g + 0) * LD, o + (8 * g + 1) * LD, y, dy * z[1]);
+                    Ops::put2(o + (8 * g + 2) * LD, o + (8 * g + 3) * LD, dy * z[2], dy * z[3]);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Ops::put(o + (8 * g + r) * LD, act_val<KIND, Ops::kFastAct>(z[r]));
+                    for (int r = 0; r < 4; r += 2)
+                        Ops::put2(o + (8 * g + r) * LD, o + (8 * g + r + 1) * LD, act_val<KIND, Ops::kFastAct>(z[r]), act_val<KIND, Ops::kFastAct>(z[r + 1]));
                 }
             }
         }

@@ -1,15 +1,17 @@
-# quick regression pass on the GPU box: the -m gpu suite + one bench line per operand policy / workload
-set -x
+# A/B on the GPU box: bench lines of library variants (tools/bin/libneddf_hip_<X>.so, built by hand) against the tree's build
 O=gpurun_out/quick; mkdir -p $O
-timeout 900 python -m pytest tests -x -q -m gpu > $O/tests_full.log 2>&1; grep -E "passed|failed|error" $O/tests_full.log | tail -3 > $O/tests.log
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/c2_f32.json 2>$O/c2_f32.err
-python bench.py --dtype bf16 --steps 3 --warmup 1 --no-cpu-baseline > $O/c2_bf16.json 2>/dev/null
-python bench.py --workload train --steps 5 --warmup 2 > $O/train.json 2>/dev/null
-python bench.py --workload c5 --steps 2 --warmup 1 > $O/c5.json 2>/dev/null
-cat $O/tests.log
-for f in c2_f32 c2_bf16 train c5; do python - <<PY
+run() { # name, lib, args
+  if [ -n "$2" ]; then export NEDDF_LIB_PATH=$PWD/tools/bin/libneddf_hip_$2.so; else unset NEDDF_LIB_PATH; fi
+  python bench.py $3 --steps 3 --warmup 1 --no-cpu-baseline > $O/$1.json 2>/dev/null
+  python - <<PY
 import json
-d=json.loads(open("$O/$f.json").read().strip().split("\n")[-1])
-print("$f", round(d["value"]), round(d["ms_per_step"],1), d["roofline"].get("avg_launch_ms"), d["roofline"].get("frac"), d["roofline"].get("colour_kernel"), d.get("alt_operand_policy",{}).get("value"))
+d=json.loads(open("$O/$1.json").read().strip().split("\n")[-1])
+print("$1", round(d["value"]), round(d["ms_per_step"],1), round(d["roofline"]["avg_launch_ms"],3), round(d["roofline"]["colour_kernel"]["avg_launch_ms"],3), d.get("psnr_vs_oracle_db"))
 PY
+}
+for rep in 1 2; do
+run f32_tree_$rep "" ""
+run f32_R_$rep R ""
 done
+run c3_tree "" "--workload c3"
+run c3_R R "--workload c3"
