@@ -331,8 +331,12 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
 // after its product); and the activation is evaluated per element instead of once per four accumulator rows.
 // Used when the caller wants no penalties / Jacobian outputs (render_image, render_rays without fields_penalty); the
 // forward-mode kernel above serves the training-mode outputs.
-size_t ddf_rev_scratch_floats_per_wg(int n_layers) { return (size_t)n_layers * kRevPoints * kWidth + (size_t)kRevPoints * 128; }
-__device__ __forceinline__ size_t ddf_rev_scratch_floats_per_wg_dev(int n_layers) { return (size_t)n_layers * kRevPoints * kWidth + (size_t)kRevPoints * 128; }
+// Tile shape (MT M-tiles = 32 MT points per tile, NW waves, WPS workgroups per CU): 64 points, 4 waves, two workgroups per CU
+// under every operand policy.  The kernel is written over the shape because the obvious alternative was measured: 128-point
+// tiles on one 8-wave workgroup per CU (half the L2 -> VGPR weight stream per point) are SLOWER for the 16-bit policies (split
+// fp16 14.5 vs 12.4 ms, bf16 8.4 vs 8.4 ms per launch): with one workgroup per CU nothing covers its barriers and the y'
+// round trip, and two 128-point workgroups do not fit (bf16: 403 spilled registers at 128 accumulators + the y' sets).
+size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points) { return (size_t)n_layers * points * kWidth + (size_t)points * 128; }
 
 template <int KIND, bool LAST, int MT, int NT, class Ops>
 __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *yp, const float *wseed, int wave,
@@ -365,8 +369,12 @@ __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], type
             }
         }
     // y' leaves in the accumulators' own fragment order (16 bytes per lane, 1 KiB per wave and store): only this workgroup's
-    // same lanes read it back, so nothing needs it row-major
-    if (!LAST) stash_store<MT, NT>(acc, yp, wave, lane);
+    // same lanes read it back, so nothing needs it row-major.  Under the bf16 policy it travels as bf16 (the product it enters
+    // is rounded to bf16 anyway): at that policy's speed the fp32 round trip (26 GB per launch) would be the kernel's bound
+    if (!LAST) {
+        if constexpr (Ops::kStash16) stash_store16<MT, NT>(acc, yp, wave, lane);
+        else stash_store<MT, NT>(acc, yp, wave, lane);
+    }
 }
 
 template <bool LAST, int MT, int NT, class Ops>
@@ -378,20 +386,21 @@ __device__ __forceinline__ void rev_forward_epilogue_rt(f32x16 (&acc)[MT][NT], t
     else rev_forward_epilogue<2, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane);
 }
 
-template <int WPS, class Ops>
-__global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
+template <int MT, int NW, int WPS, class Ops>
+__global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const DdfArgs a)
 {
     typedef typename Ops::act_t act_t;
     typedef typename Ops::bfrag frag;
-    constexpr int MT = 2, NT = 2, ROWS = MT * 32, P = ROWS, LD = Ops::kLd;
-    static_assert(P == kRevPoints, "tile size");
+    constexpr int NT = 8 / NW, THREADS = 64 * NW, ROWS = MT * 32, P = ROWS, LD = Ops::kLd;
+    constexpr int BPW = 2 * MT / NW;             // 32 x 32 blocks of the [P, 64] encoding gradient per wave
+    static_assert(BPW >= 1 && BPW * NW == 2 * MT, "the encoding gradient's blocks must divide over the waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     act_t *act = (act_t *)smem;
-    float *hd = (float *)(act + ROWS * LD);  // [2 parts][2 heads][ROWS] head dot products
+    float *hd = (float *)(act + ROWS * LD);  // [2 k-halves][2 heads][ROWS] head dot products
     float *lp = hd + 6 * ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
-    float *yp = a.rev_scratch + (size_t)blockIdx.x * ddf_rev_scratch_floats_per_wg_dev(a.n_layers);
+    float *yp = a.rev_scratch + (size_t)blockIdx.x * ((size_t)a.n_layers * P * kWidth + (size_t)P * 128);
     float *pj = yp + (size_t)a.n_layers * ROWS * kWidth;        // [ROWS][64] dPE/dx factors: [q] sine half, [32 + q] cosine half
     float *pv = pj + ROWS * 64;                                  // [ROWS][64] the encoding itself, for the skip layer
     if (tid == 0) {
@@ -413,12 +422,12 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
         const int64_t p0 = tile * P;
         LayerPre<NT, Ops> pre;
         layer_prefetch<NT, Ops>(pre, a.layer[0].wp, a.layer[0].bias, a.layer[0].ksteps, wave, lane);
-        zero_cols<Ops>(act, ROWS, kin, tid);
+        zero_cols<Ops, THREADS>(act, ROWS, kin, tid);
         __syncthreads();
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
         // scaled integrated encoding (neddf.py:193-204), value rows; the factors of its Jacobian go to the scratch
-        for (int item = tid; item < P * K3; item += kThreads) {
+        for (int item = tid; item < P * K3; item += THREADS) {
             const int p = item / K3, q = item - p * K3;
             const int e = q / 3, d = q - 3 * e;
             const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
             if (L.stash >= 0) {         // cat([encoding, h]) (neddf.py:217-219): the encoding comes back from the scratch into the tile's first columns
                 const StashW &sw = a.stash[L.stash];
                 __syncthreads();                        // every wave finished reading the hidden state
-                for (int i = tid; i < ROWS * (kin / 4); i += kThreads) {
+                for (int i = tid; i < ROWS * (kin / 4); i += THREADS) {
                     const int r = i / (kin / 4), c = i - r * (kin / 4);
                     f32x4v v = { 0.f, 0.f, 0.f, 0.f };
                     if (4 * c < 64) v = *(const f32x4v *)(pv + r * 64 + 4 * c);
@@ -465,8 +474,8 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
         }
         // ---- heads on the features (value only: the distance gradient comes from the reverse pass, the aux gradient's own
         // Jacobian is not an eval output), and the feature hand-off to the colour kernel
-        {
-            const int part = tid >> 7, pr = tid & 127, head = pr >> 6, row = pr & 63;      // 2 k-halves x 2 heads x 64 rows = 256 threads
+        for (int item = tid; item < 4 * ROWS; item += THREADS) {       // 2 k-halves x 2 heads x ROWS rows
+            const int part = item / (2 * ROWS), head = (item / ROWS) & 1, row = item % ROWS;
             const f32x4v *w = (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out) + part * 32;
             const act_t *ar = act + row * LD + part * 128;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -478,12 +487,12 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
                 s0 = fmaf(x[0], ww[0], s0); s1 = fmaf(x[1], ww[1], s1);
                 s2 = fmaf(x[2], ww[2], s2); s3 = fmaf(x[3], ww[3], s3);
             }
-            hd[tid] = (s0 + s1) + (s2 + s3);
+            hd[item] = (s0 + s1) + (s2 + s3);
         }
         {
             constexpr int CE = 16 / sizeof(act_t), CPP = kWidth / CE, CPR = Ops::kPlanes * CPP;
             act_t *features = (act_t *)a.features;
-            for (int idx = tid; features && idx < P * CPR; idx += kThreads) {
+            for (int idx = tid; features && idx < P * CPR; idx += THREADS) {
                 const int p = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
                 if (p0 + p < a.n_points) {
                     f32x4v v = *(const f32x4v *)(act + p * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));
@@ -502,66 +511,83 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
                 for (int q = 0; q < 16; q += 2) Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, acc[mt][t][q], acc[mt][t][q + 1]);
             }
         __syncthreads();
-        // this wave's 32 x 32 block of the encoding gradient (M-tile wave >> 1, N-tile wave & 1).  The skip layer's share waits in the
-        // scratch, not in 16 registers, while the remaining layers run (the product loop below needs them)
-        const act_t *pe_lane = act_lane + (wave >> 1) * 32 * LD;
-        f32x4v *gpe_park = (f32x4v *)pv + (size_t)wave * 4 * 64 + lane;        // the encoding copy in pv is no longer needed here
+        // the [P, 64] encoding gradient in 32 x 32 blocks, BPW per wave: block b = wave * BPW + i is M-tile b >> 1, N-tile b & 1.  The
+        // skip layer's share waits in the scratch, not in registers, while the remaining layers run (the product loop needs them)
+        f32x4v *gpe_park = (f32x4v *)pv + (size_t)wave * BPW * 4 * 64 + lane;        // the encoding copy in pv is no longer needed here
         for (int l = a.n_layers - 1; l >= 1; --l) {
             if (l == a.skip_layer) {    // cat([encoding, h]): the encoding rows of W_l take their share of g_l
-                f32x16 gs[1][1];
-                acc_init<1, 1, false>(gs, nullptr, wave, lane);
-                dense<1, 1, Ops>(gs, pe_lane, (const frag *)a.wT_pe_skip + (size_t)(wave & 1) * KS * 64 + lane, KS);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4v v = { gs[0][0][4 * g], gs[0][0][4 * g + 1], gs[0][0][4 * g + 2], gs[0][0][4 * g + 3] };
-                    gpe_park[g * 64] = v;
-                }
-            }
-            // y'_{l-1} of this lane's accumulator positions, fetched after the product: requesting it before (64 more live
-            // registers) measured no faster -- the other workgroup of the CU covers the latency
-            f32x16 ypre[MT][NT];
-            const f32x4v *ysrc = (const f32x4v *)(yp + (size_t)(l - 1) * ROWS * kWidth) + (size_t)wave * (MT * NT * 4) * 64 + lane;
-            auto load_ypre = [&](int mt) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int i = 0; i < BPW; ++i) {
+                    const int b = wave * BPW + i;
+                    f32x16 gs[1][1];
+                    acc_init<1, 1, false>(gs, nullptr, wave, lane);
+                    dense<1, 1, Ops>(gs, act_lane + (b >> 1) * 32 * LD, (const frag *)a.wT_pe_skip + (size_t)(b & 1) * KS * 64 + lane, KS);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        f32x4v v = ysrc[((mt * NT + t) * 4 + g) * 64];
-                        ypre[mt][t][4 * g] = v[0]; ypre[mt][t][4 * g + 1] = v[1]; ypre[mt][t][4 * g + 2] = v[2]; ypre[mt][t][4 * g + 3] = v[3];
+                        f32x4v v = { gs[0][0][4 * g], gs[0][0][4 * g + 1], gs[0][0][4 * g + 2], gs[0][0][4 * g + 3] };
+                        gpe_park[(i * 4 + g) * 64] = v;
                     }
+                }
+            }
+            // y'_{l-1} of this lane's accumulator positions comes back M-tile by M-tile through two register sets: the first two
+            // are requested after the product (requesting them before it -- 64 more live registers -- measured no faster: the
+            // CU's other waves cover the latency), the others while the previous M-tile is multiplied and stored
+            f32x16 yb[2][NT];
+            const f32x4v *ysrc = (const f32x4v *)(yp + (size_t)(l - 1) * ROWS * kWidth) + (size_t)wave * (MT * NT * (Ops::kStash16 ? 2 : 4)) * 64 + lane;
+            auto load_y = [&](f32x16 (&dst)[NT], int mt) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if constexpr (Ops::kStash16) stash_load16(dst[t], (const u32x4 *)ysrc + ((mt * NT + t) * 2) * 64);
+                    else
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4v v = ysrc[((mt * NT + t) * 4 + g) * 64];
+                            dst[t][4 * g] = v[0]; dst[t][4 * g + 1] = v[1]; dst[t][4 * g + 2] = v[2]; dst[t][4 * g + 3] = v[3];
+                        }
+                }
             };
             acc_init<MT, NT, false>(acc, nullptr, wave, lane);
             dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
-            load_ypre(0);
-            load_ypre(1);
+            load_y(yb[0], 0);
+            if (MT > 1) load_y(yb[1], 1);
             __syncthreads();            // every wave finished reading g_l
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
 #pragma unroll
                     for (int q = 0; q < 16; q += 2)
-                        Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, acc[mt][t][q] * ypre[mt][t][q],
-                                  acc[mt][t][q + 1] * ypre[mt][t][q + 1]);
+                        Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, acc[mt][t][q] * yb[mt & 1][t][q],
+                                  acc[mt][t][q + 1] * yb[mt & 1][t][q + 1]);
                 }
+                if (mt + 2 < MT) load_y(yb[mt & 1], mt + 2);
+            }
             __syncthreads();
         }
-        f32x16 gpe[1][1];
-        if (a.skip_layer >= 1) {
+        f32x16 gpe[BPW][1];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4v v = gpe_park[g * 64];
-                gpe[0][0][4 * g] = v[0]; gpe[0][0][4 * g + 1] = v[1]; gpe[0][0][4 * g + 2] = v[2]; gpe[0][0][4 * g + 3] = v[3];
-            }
-        } else acc_init<1, 1, false>(gpe, nullptr, wave, lane);
-        dense<1, 1, Ops>(gpe, pe_lane, (const frag *)a.wT_pe0 + (size_t)(wave & 1) * KS * 64 + lane, KS);       // g_0 W_0^T
+        for (int i = 0; i < BPW; ++i) {
+            const int b = wave * BPW + i;
+            f32x16 one[1][1];
+            if (a.skip_layer >= 1) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4v v = gpe_park[(i * 4 + g) * 64];
+                    one[0][0][4 * g] = v[0]; one[0][0][4 * g + 1] = v[1]; one[0][0][4 * g + 2] = v[2]; one[0][0][4 * g + 3] = v[3];
+                }
+            } else acc_init<1, 1, false>(one, nullptr, wave, lane);
+            dense<1, 1, Ops>(one, act_lane + (b >> 1) * 32 * LD, (const frag *)a.wT_pe0 + (size_t)(b & 1) * KS * 64 + lane, KS);       // g_0 W_0^T
+            gpe[i][0] = one[0][0];
+        }
         __syncthreads();                // every wave finished reading g_0
-        {
-            act_t *o = act + ((wave >> 1) * 32 + 4 * h) * LD + (wave & 1) * 32 + j;
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int b = wave * BPW + i;
+            act_t *o = act + ((b >> 1) * 32 + 4 * h) * LD + (b & 1) * 32 + j;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                float g = gpe[0][0][q];
+                float g = gpe[i][0][q];
                 if constexpr (Ops::kWScale != 1.0f) g *= (1.0f / Ops::kWScale);
                 Ops::put(o + (8 * (q >> 2) + (q & 3)) * LD, g);
             }
@@ -580,8 +606,8 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
                     gz[d] = fmaf(Ops::get(gr + q), pjr[q], gz[d]);
                     gz[d] = fmaf(Ops::get(gr + KH + q), pjr[32 + q], gz[d]);
                 }
-            const float z = (hd[tid] + hd[128 + tid]) + a.b_ddf_out;
-            const float az = (hd[64 + tid] + hd[192 + tid]) + a.b_aux_out;
+            const float z = (hd[tid] + hd[2 * ROWS + tid]) + a.b_ddf_out;
+            const float az = (hd[ROWS + tid] + hd[3 * ROWS + tid]) + a.b_aux_out;
             float sp, dsp, t, dsg;
             softplus_grad(z, sp, dsp);               // softplus.py:38-49
             const float D = sp + a.d_near;
@@ -1093,19 +1119,23 @@ void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
     return launch_ddf_g<4, 1, 4, OpsF32>(a, grid, s);
 }
 
-template <class Ops>
+// reverse-mode kernel: its tile shape per operand policy (see ddf_rev_kernel)
+template <int MT, int NW, int WPS, class Ops>
 static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s)
 {
-    static bool once = (set_lds((const void *)ddf_rev_kernel<2, Ops>, lds_bytes<Ops>(2)), true);
+    static bool once = (set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops>, lds_bytes<Ops>(MT)), true);
     (void)once;
-    hipLaunchKernelGGL((ddf_rev_kernel<2, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a);
+    hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a);
 }
+
+int ddf_rev_points(int) { return 64; }
+int ddf_rev_wgs_per_cu(int) { return 2; }
 
 void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s)
 {
-    if (a.operands == 2) launch_ddf_rev_t<OpsF16Split>(a, grid, s);
-    else if (a.operands == 1) launch_ddf_rev_t<OpsBF16>(a, grid, s);
-    else launch_ddf_rev_t<OpsF32>(a, grid, s);
+    if (a.operands == 2) launch_ddf_rev_t<2, 4, 2, OpsF16Split>(a, grid, s);
+    else if (a.operands == 1) launch_ddf_rev_t<2, 4, 2, OpsBF16>(a, grid, s);
+    else launch_ddf_rev_t<2, 4, 2, OpsF32>(a, grid, s);
 }
 
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)

@@ -67,7 +67,7 @@ struct DdfArgs {
     const float *wT_pe0, *wT_pe_skip;     // packed [256 x 64]: W_0^T and the skip layer's encoding rows^T (engine column order)
     int skip_layer;                       // trunk layer whose input is cat([encoding, h]), or -1
     int ks_hidden;                        // super-steps of a 256-wide product under this operand policy
-    float *rev_scratch;                   // per workgroup: y' of every layer [n_layers][64][256] + encoding Jacobian [64][64]
+    float *rev_scratch;                   // per workgroup: y' of every layer [n_layers][P][256] + encoding Jacobian and copy [P][128]
     int *sched;                           // [0] tile queue head (zeroed before each launch)
     int sched_flags;                      // bit 1: dynamic tile queue; higher bits: timing ablations, -DNEDDF_ABLATE builds only
     float *features;                      // [n_points][feat_rows][256]
@@ -131,8 +131,9 @@ struct CameraArg {
 size_t field_lds_bytes(int mt);
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s);
 void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s);
-size_t ddf_rev_scratch_floats_per_wg(int n_layers);
-constexpr int kRevPoints = 64;         // sample points per tile of ddf_rev_kernel
+size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points);
+int ddf_rev_points(int operands);        // sample points per tile of ddf_rev_kernel under an operand policy
+int ddf_rev_wgs_per_cu(int operands);
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s);
 void launch_nerf(const NerfArgs &a, int grid, hipStream_t s);
 int ddf_points_per_tile(int operands = 0);

@@ -434,9 +434,9 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     // Eval-minimal NeDDF needs the gradient of one scalar (the distance) only: reverse mode halves the matrix work
     // (NEDDF_DDF_REVERSE=0 keeps the forward-mode Jacobian rows, which the penalties of the full mode need anyway)
     static const bool rev_enabled = [] { const char *e = getenv("NEDDF_DDF_REVERSE"); return !e || atoi(e) != 0; }();
-    // bit per operand policy: fp32 (28.5 vs 52.0 ms per 2^21 points) and split fp16 (16.3 vs 19.9 ms) gain; bf16, whose epilogue per
-    // element dominates either way, does not (8.4 vs 7.8 ms) and keeps the forward-mode kernel
-    static const int rev_mask = [] { const char *e = getenv("NEDDF_DDF_REVERSE_DTYPES"); return e ? atoi(e) : 5; }();
+    // bit per operand policy (1 fp32, 2 bf16, 4 split fp16); all three gain: fp32 27.5 vs 51.8 ms per 2^21 points, split fp16 12.4 vs
+    // 19.9 ms, bf16 6.4 vs 7.4 ms (once its y' round trip went to bf16: with fp32 y' the kernel was HBM-bound at 8.4 ms)
+    static const int rev_mask = [] { const char *e = getenv("NEDDF_DDF_REVERSE_DTYPES"); return e ? atoi(e) : 7; }();
     const bool reverse = rev_enabled && ((rev_mask >> dt) & 1) && !full && f.d.kind == NEDDF_FIELD_NEDDF && f.ddf.n_stash <= 1 &&
                          field_wgs_per_cu(NEDDF_DTYPE_F32) == 2;
     const int64_t chunk_cap = full ? (1 << 19) : (1 << 21);
@@ -463,10 +463,11 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         a.sched = (int *)ctx->sched.p;
         a.sched_flags = sched_flags();
         HIPCHK(hipMemsetAsync(a.sched, 0, kSchedInts * sizeof(int), s));
-        if (reverse) {          // one scalar's gradient: reverse mode, 64 points per tile (field_kernels.hip ddf_rev_kernel)
-            const int64_t tiles = (n + kRevPoints - 1) / kRevPoints;
-            const int grid = (int)(tiles < 2 * ctx->cus ? tiles : 2 * ctx->cus);
-            if (int rc = ensure(ctx, ctx->rev_scratch, (size_t)2 * ctx->cus * ddf_rev_scratch_floats_per_wg(a.n_layers) * sizeof(float))) return rc;
+        if (reverse) {          // one scalar's gradient: reverse mode, 64 or 128 points per tile (field_kernels.hip ddf_rev_kernel)
+            const int pts = ddf_rev_points(dt), wgs = ddf_rev_wgs_per_cu(dt) * ctx->cus;
+            const int64_t tiles = (n + pts - 1) / pts;
+            const int grid = (int)(tiles < wgs ? tiles : wgs);
+            if (int rc = ensure(ctx, ctx->rev_scratch, (size_t)wgs * ddf_rev_scratch_floats_per_wg(a.n_layers, pts) * sizeof(float))) return rc;
             a.rev_scratch = (float *)ctx->rev_scratch.p;
             STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf_rev(a, grid, s));
         } else {

@@ -38,6 +38,7 @@ struct OpsF32 {
     static constexpr bool kLean = false;     // room for register-resident extras (skip partial, feature prefetch)
     static constexpr bool kPackedRows = false;
     static constexpr float kWScale = 1.0f;   // packed weights = kWScale * w
+    static constexpr bool kStash16 = false;  // y' of the reverse-mode kernel travels in fp32
     static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
     static __device__ __forceinline__ void zero(act_t *p) { *p = 0.f; }
     static __device__ __forceinline__ void put4(act_t *p, const f32x4v &v) { *(f32x4v *)p = v; }     // 4 consecutive columns
@@ -68,6 +69,7 @@ struct OpsBF16 {
     static constexpr int kPlanes = 1, kPlane = 0;
     static constexpr bool kLean = false;
     static constexpr float kWScale = 1.0f;
+    static constexpr bool kStash16 = true;   // ... as bf16 here
     static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
     static __device__ __forceinline__ void zero(act_t *p) { *p = 0; }
     static __device__ __forceinline__ unsigned short cvt(float v)       // round to nearest even (v_cvt_pk_bf16_f32)
@@ -133,6 +135,7 @@ struct OpsF16Split {
     static constexpr bool kLean = false;                 // measured: register-resident skip partial / feature prefetch pay off here too
     static constexpr bool kPackedRows = false;
     static constexpr float kWScale = 1024.0f;            // weights are packed as 2^10 w
+    static constexpr bool kStash16 = false;
     static __device__ __forceinline__ float f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
     static __device__ __forceinline__ void put(act_t *p, float v)
     {
@@ -239,6 +242,23 @@ __device__ __forceinline__ void dense_load(typename Ops::afrag (&a)[MT], typenam
     for (int mt = 0; mt < MT; ++mt) a[mt] = Ops::load_a(ap + mt * 32 * Ops::kLd);
 }
 
+// ds_read offsets are 16 bits: when the tile's upper M-tiles lie beyond them (128 rows of two-plane fp16), a second advancing
+// pointer serves the upper half
+template <int MT, class Ops>
+constexpr bool kFarTiles = ((MT - 1) * 32 * Ops::kLd + Ops::kPlane + 4 * Ops::kStep) * (int)sizeof(typename Ops::act_t) > 65000;
+
+template <int MT, int NT, class Ops = OpsF32>
+__device__ __forceinline__ void dense_load2(typename Ops::afrag (&a)[MT], typename Ops::bfrag (&b)[NT], const typename Ops::act_t *ap,
+                                            const typename Ops::act_t *aq, const WeightStream &w, int ksteps, int S)
+{
+    if constexpr (kFarTiles<MT, Ops>) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = stream_load<typename Ops::bfrag>(w, (unsigned)(t * ksteps + S));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = Ops::load_a((mt < MT / 2 ? ap + mt * 32 * Ops::kLd : aq + (mt - MT / 2) * 32 * Ops::kLd));
+    } else dense_load<MT, NT, Ops>(a, b, ap, w, ksteps, S);
+}
+
 template <int MT, int NT, class Ops = OpsF32>
 __device__ __forceinline__ void dense_mfma(f32x16 (&acc)[MT][NT], const typename Ops::afrag (&a)[MT], const typename Ops::bfrag (&b)[NT])
 {
@@ -293,20 +313,25 @@ __device__ __forceinline__ void dense_pipeline(f32x16 (&acc)[MT][NT], typename O
     typename Ops::bfrag b1[NT];
     // A fragments past the last super-step are fetched like the others and never used (the reads stay inside the workgroup's
     // LDS: at most two super-steps beyond a row's columns); the weight index is clamped instead, it could leave the allocation
-    const typename Ops::act_t *ap = act_lane;
+    // (the distance between the two pointers is hidden from the compiler, which otherwise folds them back into one induction
+    // variable + one vector add per far read)
+    int far = (MT / 2) * 32 * Ops::kLd;
+    if constexpr (kFarTiles<MT, Ops>) asm volatile("" : "+v"(far));
+    const typename Ops::act_t *ap = act_lane, *aq = act_lane + far;
     for (int S = 0; S < ksteps; S += 2) {
         const bool more = S + 1 < ksteps;
-        dense_load<MT, NT, Ops>(a1, b1, ap + Ops::kStep, wl, ksteps, more ? S + 1 : S);
+        dense_load2<MT, NT, Ops>(a1, b1, ap + Ops::kStep, aq + Ops::kStep, wl, ksteps, more ? S + 1 : S);
         __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
         dense_mfma<MT, NT, Ops>(acc, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            dense_load<MT, NT, Ops>(a0, b0, ap + 2 * Ops::kStep, wl, ksteps, S + 2 < ksteps ? S + 2 : S);
+            dense_load2<MT, NT, Ops>(a0, b0, ap + 2 * Ops::kStep, aq + 2 * Ops::kStep, wl, ksteps, S + 2 < ksteps ? S + 2 : S);
             __builtin_amdgcn_sched_barrier(0);
             dense_mfma<MT, NT, Ops>(acc, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
         ap += 2 * Ops::kStep;
+        if constexpr (kFarTiles<MT, Ops>) aq += 2 * Ops::kStep;
     }
 }
 
@@ -359,6 +384,40 @@ __device__ __forceinline__ void stash_store(const f32x16 (&acc)[MT][NT], float *
                 f32x4v v = { acc[mt][t][4 * g], acc[mt][t][4 * g + 1], acc[mt][t][4 * g + 2], acc[mt][t][4 * g + 3] };
                 dst[((mt * NT + t) * 4 + g) * 64] = v;
             }
+}
+
+// the same in bf16: 16 accumulators = two 16-byte chunks per lane
+template <int MT, int NT>
+__device__ __forceinline__ void stash_store16(const f32x16 (&acc)[MT][NT], float *slot, int wave, int lane)
+{
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    u32x4 *dst = (u32x4 *)slot + (size_t)wave * (MT * NT * 2) * 64 + lane;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                u32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    v[i] = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){ acc[mt][t][8 * c + 2 * i], acc[mt][t][8 * c + 2 * i + 1] }, bf16x2));
+                dst[((mt * NT + t) * 2 + c) * 64] = v;
+            }
+}
+
+__device__ __forceinline__ void stash_load16(f32x16 &dst, const u32x4 *src)     // src: this lane's first chunk of the accumulator tile
+{
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const u32x4 v = src[c * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dst[8 * c + 2 * i] = __builtin_bit_cast(float, v[i] << 16);
+            dst[8 * c + 2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+        }
+    }
 }
 
 template <int MT, int NT>
