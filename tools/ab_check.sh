@@ -1,18 +1,13 @@
-O=gpurun_out/quick; mkdir -p $O
-run() { # name, lib, args
-  if [ -n "$2" ]; then export NEDDF_LIB_PATH=$PWD/tools/bin/libneddf_hip_$2.so; else unset NEDDF_LIB_PATH; fi
-  python bench.py $3 --steps 3 --warmup 1 --no-cpu-baseline > $O/$1.json 2>$O/$1.err
-  python - <<PY
-import json
-try:
-    d=json.loads(open("$O/$1.json").read().strip().split("\n")[-1])
-    r=d["roofline"]
-    print("$1", round(d["value"]), round(d["ms_per_step"],1), r.get("avg_launch_ms"), (r.get("colour_kernel") or {}).get("avg_launch_ms"), d.get("psnr_vs_oracle_db"))
-except Exception as e:
-    print("$1 FAILED", e, open("$O/$1.err").read()[-600:])
+# A/B inside one gpurun call (boxes differ by +-2.5 %): kernel stats of the training step under two settings
+O=$PWD/gpurun_out/quick; mkdir -p $O; export TMPDIR=/tmp; ROOT=$PWD
+cd /tmp
+for w in 4 8; do
+NEDDF_DW_WAVES=$w timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_w$w -o t -- python $ROOT/bench.py --workload train --steps 5 --warmup 2 > $O/prof_w$w.log 2>&1
+python - <<PY
+import csv
+rows=list(csv.DictReader(open("$O/prof_w$w/t_kernel_stats.csv")))
+tot=sum(float(r["TotalDurationNs"]) for r in rows)
+print("dw_waves=$w total kernel ms per step", round(tot/7e6,2))
+for r in rows[:6]: print("   %-60s %5s %9.3f %8.4f"%(r["Name"][:60], r["Calls"], float(r["TotalDurationNs"])/1e6, float(r["AverageNs"])/1e6))
 PY
-}
-for rep in 1 2; do
-run split_tree_$rep "" "--dtype f16_split"
-run split_S_$rep S "--dtype f16_split"
 done
