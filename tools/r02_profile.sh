@@ -21,7 +21,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$c -- python $ROOT/tools/pmc_probe.py 1 > $O/pmc_$c.log 2>&1
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc/sq -- python $ROOT/tools/pmc_probe.py 1 > $O/pmc_sq.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  NEDDF_PROBE_DTYPE=bf16 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_bf16/$c -- python $ROOT/tools/pmc_probe.py 1 > $O/pmc_bf16_$c.log 2>&1
+done
+NEDDF_PROBE_DTYPE=bf16 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_bf16/sq -- python $ROOT/tools/pmc_probe.py 1 > $O/pmc_bf16_sq.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -o t -- python $ROOT/bench.py --workload train --steps 5 --warmup 2 > $O/prof_train.log 2>&1
 cd $ROOT
 python tools/pmc_summary.py $O/pmc > $O/pmc_summary.csv
+python tools/pmc_summary.py $O/pmc_bf16 > $O/pmc_bf16_summary.csv
 find $O/prof -name "*stats*" | head; find $O/prof -name "*.csv" | head
 tail -c 600 $O/bench_c2_f32.json
