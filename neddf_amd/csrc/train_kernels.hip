@@ -125,19 +125,22 @@ __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, 
     const act_t *act_lane = act_lane_ptr<Ops>(opd, lane);
     const typename Ops::bfrag *wl = (const typename Ops::bfrag *)wp + (size_t)wave * NT * ksteps * 64 + lane;
     const int64_t ntiles = (R + ROWS - 1) / ROWS;
-    const int c4n = kload >> 2, total = ROWS * c4n, kpack = Ops::kStep * ksteps;
+    const int c4n = kload >> 2, kpack = Ops::kStep * ksteps;
     f32x4v pf[NPF];
+    // 16-byte chunk idx = tid + i * kThreads of the tile is (row idx / c4n, column idx % c4n): one division per thread, then
+    // steps of kThreads chunks (as 2 x 16 runtime divisions per tile they were 800 of the tile's vector instructions)
+    const int step_r = kThreads / c4n, step_c = kThreads - step_r * c4n;
+    const int row0 = tid / c4n, col0 = tid - row0 * c4n;
     auto fetch = [&](int64_t tile) {
         const int64_t r0 = tile * ROWS;
+        int r = row0, c = col0;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            int idx = tid + i * kThreads;
             f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-            if (idx < total) {
-                int r = idx / c4n, c = idx - r * c4n;
-                if (r0 + r < R) v = *(const f32x4v *)(X + (r0 + r) * ldx + 4 * c);
-            }
+            if (r < ROWS && r0 + r < R) v = *(const f32x4v *)(X + (r0 + r) * ldx + 4 * c);
             pf[i] = v;
+            r += step_r; c += step_c;
+            if (c >= c4n) { c -= c4n; ++r; }
         }
     };
     int64_t tile = blockIdx.x;
@@ -145,12 +148,13 @@ __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, 
     for (; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * ROWS;
         __syncthreads();                // the previous tile's epilogue is done with the LDS tile
+        {
+            int r = row0, c = col0;
 #pragma unroll
-        for (int i = 0; i < NPF; ++i) {
-            int idx = tid + i * kThreads;
-            if (idx < total) {
-                int r = idx / c4n, c = idx - r * c4n;
-                Ops::put4(opd + r * LD + 4 * c, SCALED ? pf[i] * xs : pf[i]);
+            for (int i = 0; i < NPF; ++i) {
+                if (r < ROWS) Ops::put4(opd + r * LD + 4 * c, SCALED ? pf[i] * xs : pf[i]);
+                r += step_r; c += step_c;
+                if (c >= c4n) { c -= c4n; ++r; }
             }
         }
         for (int i = tid; i < ROWS * (kpack - kload); i += kThreads) {      // packed width beyond the loaded width
