@@ -461,7 +461,7 @@ __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, in
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[kt][t][q] = 0.f;
-    float bs0 = 0.f, bs1 = 0.f;
+    f32x4v bsum = { 0.f, 0.f, 0.f, 0.f };       // this thread's share of db: columns 4 (tid & 63) .. +3
     f32x4v xp[XPF], gp[GPF];
     auto fetch = [&](int64_t c0) {
 #pragma unroll
@@ -491,6 +491,11 @@ __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, in
         for (int i = 0; i < GPF; ++i) {
             int idx = tid + i * kThreads;
             *(f32x4v *)(Gs + (idx >> 6) * LDG + 4 * (idx & 63)) = gp[i];
+            // db: column sums over the value rows, taken here from the staged registers (row idx >> 6 = wave + 4 i; chunks start at
+            // multiples of 32 and bias_period is 1 or 4, so the row's phase is its phase in the chunk; rows past `re` are zero).
+            // Inside the MFMA loop -- first as a 64-bit vector modulo per row pair, 280 of that loop's 314 vector instructions per
+            // 64 MFMAs, then as a masked add -- every one of these instructions broke the MFMA issue chain
+            if (db && (((idx >> 6) & (bias_period - 1)) == 0)) bsum += gp[i];
         }
         __syncthreads();
         if (c0 + RC < re) fetch(c0 + RC);
@@ -507,9 +512,6 @@ __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, in
                 acc[kt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], b0, acc[kt][0], 0, 0, 0);
                 acc[kt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], b1, acc[kt][1], 0, 0, 0);
             }
-            // value rows: bias_period is 1 or 4 and chunks start at multiples of 32, so the row's phase is r's (as a 64-bit
-            // vector modulo this test was 280 of the loop's 314 vector instructions per 64 MFMAs: dW 0.716 -> 0.658 ms per launch)
-            if (db && (r & (bias_period - 1)) == 0) { bs0 += b0; bs1 += b1; }      // rows past `re` are zero in LDS
         }
     }
 #pragma unroll
@@ -521,13 +523,10 @@ __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, in
                 int k = 32 * kt + 8 * (q >> 2) + 4 * h + (q & 3), n = n0 + 32 * t + j;
                 if (k < K && n < nvalid) atomicAdd(&dW[k * sk + n * sn], acc[kt][t][q]);
             }
-    if (db) {
-        bs0 += __shfl_xor(bs0, 32, 64);
-        bs1 += __shfl_xor(bs1, 32, 64);
-        if (h == 0) {
-            if (n0 + j < nvalid) atomicAdd(&db[n0 + j], bs0);
-            if (n0 + 32 + j < nvalid) atomicAdd(&db[n0 + 32 + j], bs1);
-        }
+    if (db && (wave & (bias_period - 1)) == 0) {        // staged rows are wave + 4 i: with bias_period 4 only wave 0 holds value rows
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (4 * lane + q < nvalid) atomicAdd(&db[4 * lane + q], bsum[q]);
     }
 }
 
