@@ -372,6 +372,8 @@ def main():
 
     def sync():
         if state["pending"] is not None:
+            if native:      # host-side wait with a deadline: a peer that died or a stuck collective ends the bench with
+                ctx.comm_wait_host(300000)      # NEDDF_ETIMEOUT / the asynchronous RCCL error instead of hanging it
             state["pending"].wait()
             state["pending"] = None
         if use_dist:

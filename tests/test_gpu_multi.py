@@ -160,6 +160,22 @@ def test_bench_self_launch_two_ranks_shared_gpu():
         assert line["config"]["comm"]["rccl_comm_ranks"] == 2
 
 
+def test_bench_collective_path_on_one_rank():
+    """The N > 1 code path of bench.py on ONE rank (NEDDF_BENCH_FORCE_DIST=1): RCCL process group, the library's own communicator
+    bootstrapped through it, pixel all-gather on the communication stream with the host-side deadline wait, max-over-ranks."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NEDDF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29600 + os.getpid() % 300))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    comm = line["config"]["comm"]
+    assert comm["rccl_comm_ranks"] == 1 and comm["torch_distributed_world_size"] == 1 and "neddf_gather_pixels" in comm["gather"], comm
+    assert line["stage_ms_per_step"]["gather"] > 0 and line["value"] > 0
+
+
 def test_smoke_under_asan():
     """smoke() -- weight packing, workspace carving, the fused render_rays orchestration, 64 rays against the oracle -- with the
     host side of the library under AddressSanitizer + UBSan (the device code is the shipped one)."""
