@@ -2,8 +2,8 @@
 """Headline benchmark: rendered rays/s on BASELINE.json configs[1]
 (800x800 view, 128 stratified cone samples per ray, NeDDF fp32, one MI355X per
 rank).  A "step" renders one full view per GPU: raygen -> stratified sampling
--> cone moments -> NeDDF field (distance trunk with forward-mode Jacobian +
-colour trunk) -> wave-scan compositing, plus -- for N > 1 -- the RCCL gather of
+-> cone moments -> NeDDF field (distance trunk with the distance gradient in
+reverse mode + colour trunk) -> wave-scan compositing, plus -- for N > 1 -- the RCCL gather of
 the rendered pixels (20 B/ray) so that every rank ends the step with all N
 views.  Weak scaling: N GPUs render N views.
 
@@ -11,8 +11,8 @@ views.  Weak scaling: N GPUs render N views.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement), extended with
-  roofline      the distance-trunk kernel (88 % of the algorithmic flops) against
-                the fp32 MFMA peak, timed live with HIP events on its stream
+  roofline      the distance-trunk kernel (78 % of the step) against the fp32 MFMA
+                peak, timed live with HIP events on its stream
   cpu_baseline  the CPU oracle (oracle/, a C port of the reference) on the host
                 cores, on a bounded sample of the same workload (rank 0, N=1)
 """
@@ -34,10 +34,10 @@ WIDTH = HEIGHT = 800
 SAMPLES = 128
 CAMERA_ANGLE_X = 0.6911112070083618
 # algorithmic work per field evaluation, shipped NeDDF architecture, eval-minimal:
-#   distance trunk with the Jacobian carried FORWARD (the reference's formulation; the 16-bit operand policies and the
-#   training-mode outputs): 4 rows x (60*256 + 4*256*256 + 316*256 + 256*256 + 256 [ddf head]) + 256 [aux head] MACs
+#   distance trunk with the Jacobian carried FORWARD (the reference's formulation; NEDDF_DDF_REVERSE=0 and the training-mode
+#   outputs): 4 rows x (60*256 + 4*256*256 + 316*256 + 256*256 + 256 [ddf head]) + 256 [aux head] MACs
 DDF_FLOP_PER_POINT_FORWARD = 2 * (4 * (423936 + 256) + 256)
-#   distance trunk with the distance gradient in REVERSE mode (fp32 eval-minimal since round 2, ddf_rev_kernel): value rows
+#   distance trunk with the distance gradient in REVERSE mode (eval-minimal under every operand policy, ddf_rev_kernel): value rows
 #   forward (423 936 + both heads 512) + one gradient row backward (6 hidden transposes 393 216 + the encoding rows of W_0 and
 #   of the skip layer 2 x 15 360) MACs -- the same function with half the matrix work
 DDF_FLOP_PER_POINT_REVERSE = 2 * (423936 + 512 + 393216 + 2 * 15360)
