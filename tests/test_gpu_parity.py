@@ -594,6 +594,23 @@ def test_128_row_tile_variant_in_subprocess():
     assert p.returncode == 0 and "smoke ok" in p.stdout, p.stdout + p.stderr
 
 
+def test_forward_mode_kernels_in_subprocess():
+    """NEDDF_DDF_REVERSE=0: the eval-minimal path on the forward-mode Jacobian kernels (the round-1 formulation, which still
+    serves the training-mode outputs) must hold the same gates under every operand policy: the fp32 field and end-to-end
+    goldens, the bf16 emulation and the split-fp16 gates."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, NEDDF_DDF_REVERSE="0")
+    sel = ["tests/test_gpu_parity.py::test_neddf_bunny_field", "tests/test_gpu_parity.py::test_render_rays_end_to_end",
+           "tests/test_gpu_c5.py::test_bf16_field_against_bf16_emulation", "tests/test_gpu_c5.py::test_render_rays_ndc_bf16_end_to_end",
+           "tests/test_gpu_c5.py::test_split_operand_fields_meet_the_fp32_gate"]
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu"] + sel, env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+
+
 def test_full_frame_invariants(dev, bunny_weights):
     """One full BASELINE configs[1] frame (640 000 rays x 128 samples) and a 64k-ray hierarchical batch: invariants
     that hold at any size -- sorted fine distances containing every coarse knot, compositing linear in colour,
