@@ -468,6 +468,11 @@ def main():
             line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
             line["roofline"]["traffic_source"] = ent["source"]
             line["roofline"]["algorithmic_hbm_bytes_per_launch"] = ent["algorithmic_bytes_per_launch"]
+            # the same launch against the HBM roofline (the 16-bit policies are partly bound by the y' round trip)
+            ms = line["roofline"]["avg_launch_ms"]
+            if ms > 0:
+                line["roofline"]["hbm"] = {"achieved": ent["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                           "frac": ent["hbm_bytes_per_launch"] / (ms * 1e-3) / 8e12}
         except Exception:
             pass
         if args.workload == "c2":
