@@ -1,12 +1,10 @@
-# training step: tests + kernel stats (GPU box)
+# A/B inside ONE gpurun call (boxes differ by +-2.5 %): bench lines or kernel stats of a library variant against the tree's build.
+# Build the variant by hand (e.g. hipcc -c the edited file to /tmp/x.o, link it with the tree's other objects into
+# tools/bin/libneddf_hip_<X>.so -- git-ignored, travels with gpurun) and select it with NEDDF_LIB_PATH.
 O=$PWD/gpurun_out/quick; mkdir -p $O; export TMPDIR=/tmp; ROOT=$PWD
-timeout 600 python -m pytest tests/test_gpu_train.py -x -q -m gpu > $O/tests_train.log 2>&1; grep -E "passed|failed|error" $O/tests_train.log | tail -3
-cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_t -o t -- python $ROOT/bench.py --workload train --steps 5 --warmup 2 > $O/prof_t.log 2>&1
-python - <<PY
-import csv
-rows=list(csv.DictReader(open("$O/prof_t/t_kernel_stats.csv")))
-tot=sum(float(r["TotalDurationNs"]) for r in rows)
-print("total kernel ms per step", round(tot/7e6,2))
-for r in rows[:8]: print("   %-60s %5s %9.3f %8.4f"%(r["Name"][:60], r["Calls"], float(r["TotalDurationNs"])/1e6, float(r["AverageNs"])/1e6))
-PY
+VARIANT=${1:-X}; ARGS=${2:---dtype f16_split}
+for rep in 1 2; do
+for v in tree $VARIANT; do
+if [ $v = tree ]; then unset NEDDF_LIB_PATH; else export NEDDF_LIB_PATH=$ROOT/tools/bin/libneddf_hip_$v.so; fi
+python bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$v', round(d['value']), round(d['ms_per_step'],1), r.get('avg_launch_ms'), (r.get('colour_kernel') or {}).get('avg_launch_ms'), d.get('psnr_vs_oracle_db'))"
+done; done
