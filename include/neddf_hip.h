@@ -155,7 +155,7 @@ int neddf_rays_to_ndc(neddf_ctx *ctx, const float *d_ray_dir, const float *d_ray
 /* NeDDF.forward (neddf.py:162-309) / NeRF.forward (nerf.py:107-165) on N
  * sample points (pos/dir/var [N,3]).  Any output pointer may be NULL.
  * NeRF fields produce density and color only; NeuS fields (neus.py:101-162) return the sdf in d_distance.
- * NeDDF without a penalty output (NEDDF_OUT_MINIMAL, or d_penalty == NULL): the position gradient of the distance is taken
+ * NeDDF without a penalty output (NEDDF_OUT_MINIMAL, or d_penalty == NULL) and NeuS: the position gradient of the distance / sdf is taken
  * in reverse mode (one gradient row per point instead of the reference's three forward-mode Jacobian rows, neddf.py:206-230);
  * with a penalty output the Jacobian rows are carried forward as in the reference.  The two agree within rounding (the
  * parity gates of tests/test_gpu_parity.py hold for both). */

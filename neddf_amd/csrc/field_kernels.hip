@@ -432,7 +432,8 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             const int e = q / 3, d = q - 3 * e;
             const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
             float vs, vc, js, jc;
-            pe_pair<true, Ops::kFast>(e, a.pos[gp * 3 + d], a.var[gp * 3 + d], lp[e], vs, vc, js, jc);
+            if (a.neus) pe_pair<false, Ops::kFast>(e, a.pos[gp * 3 + d], 0.0f, lp[e], vs, vc, js, jc);      // plain PE (neus.py:118)
+            else pe_pair<true, Ops::kFast>(e, a.pos[gp * 3 + d], a.var[gp * 3 + d], lp[e], vs, vc, js, jc);
             Ops::put(act + p * LD + q, vs);
             Ops::put(act + p * LD + KH + q, vc);
             pj[p * 64 + q] = js;
@@ -608,6 +609,16 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
                 }
             const float z = (hd[tid] + hd[2 * ROWS + tid]) + a.b_ddf_out;
             const float az = (hd[ROWS + tid] + hd[3 * ROWS + tid]) + a.b_aux_out;
+            if (a.neus) {       // NeuS: the "distance head" is e_0, so z is the sdf and gz its position gradient (neus.py:132-156)
+                const float ex = expf(-a.neus_v10 * z), den = 1 + ex;
+                const float rho = a.neus_v10 * ex * (1.0f / (den * den));
+                float *pa = a.ptaux + gp * kPtAux;
+                f32x4v v0 = { z, rho, 0.f, gz[0] };
+                f32x4v v1 = { gz[1], gz[2], 0.f, 0.f };
+                ((f32x4v *)pa)[0] = v0; ((f32x4v *)pa)[1] = v1;
+                if (a.distance) a.distance[gp] = z;
+                if (a.density) a.density[gp] = rho;
+            } else {
             float sp, dsp, t, dsg;
             softplus_grad(z, sp, dsp);               // softplus.py:38-49
             const float D = sp + a.d_near;
@@ -629,6 +640,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             if (a.distance) a.distance[gp] = D;
             if (a.density) a.density[gp] = rho;
             if (a.aux_grad) a.aux_grad[gp] = aux;
+            }
         }
         if (tid == 0) ctl[0] = next_tile;
         __syncthreads();

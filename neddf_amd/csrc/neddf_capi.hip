@@ -291,6 +291,39 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
         }
         o_b[l] = put(blob, B[l], kWidth);
     }
+    // Reverse-mode normal (ddf_rev_kernel): the sdf is feature 0 of the last activated layer, so the seed of the reverse pass is
+    // e_0 * y'_L -- the "distance head" of the kernel becomes the unit vector e_0 with zero bias, the aux head is zero -- and the
+    // transposes are read straight off nn.Linear's [out][in] storage: B[k][n] = W_l[k][n] for the hidden inputs n < 256 (hidden
+    // state first in NeuS's concatenation), the encoding inputs through the engine's column map
+    std::vector<size_t> o_wT(n_sdf, 0);
+    size_t o_wT_pe0 = 0, o_wT_pes = 0, o_e0 = 0, o_zero = 0;
+    a.skip_layer = -1;
+    {
+        std::vector<int> kall;
+        for (int k = 0; k < kWidth; ++k) kall.push_back(k);
+        for (int l = 1; l < n_sdf; ++l) {
+            const bool wide = in_skips(d, l - 1);
+            Src st{ W[l], kWidth, wide ? kWidth + Cpe : kWidth, false };
+            o_wT[l] = pack_layer(blob, st, kall, kWidth, operands, nullptr);
+            if (wide) a.skip_layer = l;
+        }
+        auto pack_pe_T = [&](const float *Wl, int cin, int base) {
+            std::vector<int> cols;
+            enc_map(cols, E, KH, base);
+            std::vector<float> tmp((size_t)kWidth * 64, 0.f);       // [k][n] row-major, n < 64
+            for (int n = 0; n < (int)cols.size() && n < 64; ++n)
+                if (cols[n] >= 0)
+                    for (int k = 0; k < kWidth; ++k) tmp[(size_t)k * 64 + n] = Wl[(size_t)k * cin + cols[n]];
+            Src sn{ tmp.data(), kWidth, 64, false };
+            return pack_layer(blob, sn, kall, 64, operands, nullptr);
+        };
+        o_wT_pe0 = pack_pe_T(W[0], Cpe, 0);
+        if (a.skip_layer >= 0) o_wT_pes = pack_pe_T(W[a.skip_layer], kWidth + Cpe, kWidth);
+        std::vector<float> e0(kWidth, 0.f), zero(kWidth, 0.f);
+        e0[0] = 1.0f;
+        o_e0 = put(blob, e0.data(), kWidth);
+        o_zero = put(blob, zero.data(), kWidth);
+    }
     // colour trunk: engine columns [pos 3 | gradient 3 | pad 2 | dir sin KD | dir cos KD]
     std::vector<int> ka;
     for (int k = 0; k < 3; ++k) ka.push_back(k);
@@ -323,6 +356,12 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     c.wp_a = base + o_wa;
     for (int l = 0; l < n_col; ++l) { c.layer[l].wp = base + c_wp[l]; c.layer[l].bias = base + c_b[l]; }
     c.w_out = base + o_cout;
+    for (int l = 1; l < n_sdf; ++l) a.wT[l] = base + o_wT[l];
+    a.wT_pe0 = base + o_wT_pe0;
+    a.wT_pe_skip = a.skip_layer >= 0 ? base + o_wT_pes : nullptr;
+    a.ks_hidden = kWidth / (operands ? 16 : 8);
+    a.w_ddf_out = base + o_e0; a.w_aux_out = base + o_zero;
+    a.b_ddf_out = 0.f; a.b_aux_out = 0.f;
     a.activation = c.activation = d.activation;
     a.neus = 1;
     a.operands = c.operands = operands;
@@ -437,7 +476,8 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     // bit per operand policy (1 fp32, 2 bf16, 4 split fp16); all three gain: fp32 27.5 vs 51.8 ms per 2^21 points, split fp16 12.4 vs
     // 19.9 ms, bf16 6.4 vs 7.4 ms (once its y' round trip went to bf16: with fp32 y' the kernel was HBM-bound at 8.4 ms)
     static const int rev_mask = [] { const char *e = getenv("NEDDF_DDF_REVERSE_DTYPES"); return e ? atoi(e) : 7; }();
-    const bool reverse = rev_enabled && ((rev_mask >> dt) & 1) && !full && f.d.kind == NEDDF_FIELD_NEDDF && f.ddf.n_stash <= 1 &&
+    const bool reverse = rev_enabled && ((rev_mask >> dt) & 1) && !full && (f.d.kind == NEDDF_FIELD_NEDDF || f.d.kind == NEDDF_FIELD_NEUS) &&
+                         f.ddf.n_stash <= 1 &&
                          field_wgs_per_cu(NEDDF_DTYPE_F32) == 2;
     const int64_t chunk_cap = full ? (1 << 19) : (1 << 21);
     const int64_t chunk = N < chunk_cap ? N : chunk_cap;

@@ -304,8 +304,9 @@ class NeRF(BaseNeuralField):
 
 class NeuS(BaseNeuralField):
     """NeuS SDF field (neus.py:30-99 constructor keywords).  The reference takes the
-    surface normal with torch.autograd.grad; here it is the forward-mode Jacobian
-    carried through the sdf trunk by the same tile engine as NeDDF's distance trunk."""
+    surface normal with torch.autograd.grad; here rendering takes it in reverse mode
+    through the sdf trunk (the kernel of NeDDF's distance gradient, seeded with the
+    unit vector of the sdf feature), training carries forward-mode Jacobian rows."""
 
     def __init__(self, embed_pos_rank: int = 6, embed_dir_rank: int = 4, sdf_layer_count: int = 8,
                  sdf_layer_width: int = 256, col_layer_count: int = 8, col_layer_width: int = 256,

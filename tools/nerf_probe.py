@@ -38,3 +38,7 @@ for dtype in ("fp32", "f16_split", "bf16"):
         run(net, "NeDDF eval-minimal " + dtype, 2 * (4 * (423936 + 256) + 256 + 219648 + 768))
         net.output_mode = "full"
         run(net, "NeDDF full (penalties) " + dtype, 2 * 4 * (423936 + 512 + 219648 + 768))
+        neus = neddf_amd.NeuS()
+        neus.to(dev)
+        neus.weight_dtype = dtype
+        run(neus, "NeuS (random init) " + dtype, 0)
