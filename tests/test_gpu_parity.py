@@ -604,6 +604,7 @@ def test_forward_mode_kernels_in_subprocess():
     from conftest import ROOT
     env = dict(os.environ, NEDDF_DDF_REVERSE="0")
     sel = ["tests/test_gpu_parity.py::test_neddf_bunny_field", "tests/test_gpu_parity.py::test_render_rays_end_to_end",
+           "tests/test_gpu_parity.py::test_neus_synth", "tests/test_gpu_parity.py::test_neus_render_rays",
            "tests/test_gpu_c5.py::test_bf16_field_against_bf16_emulation", "tests/test_gpu_c5.py::test_render_rays_ndc_bf16_end_to_end",
            "tests/test_gpu_c5.py::test_split_operand_fields_meet_the_fp32_gate"]
     p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu"] + sel, env=env, cwd=ROOT, capture_output=True, text=True,
