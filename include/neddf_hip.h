@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NEDDF_ABI_VERSION 3
+#define NEDDF_ABI_VERSION 4
 
 enum { NEDDF_OK = 0, NEDDF_EINVAL = -1, NEDDF_EHIP = -2, NEDDF_EUNSUPPORTED = -3, NEDDF_ENOFIELD = -4,
        NEDDF_ECOMM = -5,      /* RCCL reported an error (message in neddf_last_error) or is not loadable */
@@ -263,16 +263,26 @@ int neddf_comm_info(neddf_ctx *ctx, int *rank, int *nranks, int *rccl_version);
 int neddf_comm_destroy(neddf_ctx *ctx);
 /* Slab [lo, hi) of range(n_total) that `rank` of `nranks` owns: contiguous, sizes differ by at most one. */
 void neddf_shard_range(int64_t n_total, int rank, int nranks, int64_t *lo, int64_t *hi);
+/* The same with slab boundaries on multiples of `granule` rows (the last granule of the range may be short): granule counts per
+ * rank differ by at most one.  render_image's chunk is the granule of a sharded frame, so that no chunk -- the unit the reference
+ * decides sample_pdf's NaN fallback on, base_neural_render.py:105-114 -- is split between two ranks.  granule = 1 is
+ * neddf_shard_range. */
+void neddf_shard_range_granular(int64_t n_total, int64_t granule, int rank, int nranks, int64_t *lo, int64_t *hi);
 /* All-gather of the per-rank slabs d_local [hi-lo, channels] (fp32, neddf_shard_range order) into d_all
  * [n_total, channels] on every rank.  The collective runs on the ctx's own communication stream, ordered after the
  * work already enqueued on `stream` (the renderer's stream), and returns immediately: the caller keeps rendering the
  * next view on `stream` while the pixels travel.  d_local and d_all must stay untouched until neddf_comm_wait.
  * With equal slabs the gather lands directly in d_all; ragged slabs go through a ctx-owned padded staging buffer. */
 int neddf_gather_pixels(neddf_ctx *ctx, const float *d_local, int64_t n_total, int channels, float *d_all, void *stream);
-/* Make `stream` wait (device-side, no host block) for the last neddf_gather_pixels of this ctx. */
+/* ... of slabs cut by neddf_shard_range_granular(n_total, granule, ...). */
+int neddf_gather_pixels_granular(neddf_ctx *ctx, const float *d_local, int64_t n_total, int64_t granule, int channels, float *d_all,
+                                 void *stream);
+/* Make `stream` wait (device-side, no host block) for the last neddf_gather_pixels of this ctx.  NEDDF_ECOMM (once) if the
+ * communicator was aborted while that gather was in flight: d_all is incomplete. */
 int neddf_comm_wait(neddf_ctx *ctx, void *stream);
 /* Host-side wait with a deadline: 0 when the last gather has completed; on an asynchronous RCCL error NEDDF_ECOMM; after
- * timeout_ms without completion the communicator is aborted (ncclCommAbort) and NEDDF_ETIMEOUT returned -- a peer died. */
+ * timeout_ms without completion the communicator is aborted (ncclCommAbort), the ctx returns to "no communicator"
+ * (neddf_comm_info: 0 ranks; neddf_comm_init may be called again) and NEDDF_ETIMEOUT is returned -- a peer died. */
 int neddf_comm_wait_host(neddf_ctx *ctx, int timeout_ms);
 
 /* ---- training step -------------------------------------------

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NEDDF_LIB_PATH selects another build of the same library (the sanitizer build, `make -C neddf_amd/csrc asan`)
 LIB_PATH = os.environ.get("NEDDF_LIB_PATH") or os.path.join(_HERE, "csrc", "libneddf_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 FIELD_NEDDF, FIELD_NERF, FIELD_NEUS = 0, 1, 2
 ACT = {"ReLU": 0, "LeakyReLU": 1, "tanhExp": 2}
@@ -93,7 +93,9 @@ SYMBOLS = [
     ("neddf_comm_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("neddf_comm_destroy", C.c_int, [_vp]),
     ("neddf_shard_range", None, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
+    ("neddf_shard_range_granular", None, [_i64, _i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     ("neddf_gather_pixels", C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
+    ("neddf_gather_pixels_granular", C.c_int, [_vp, _vp, _i64, _i64, C.c_int, _vp, _vp]),
     ("neddf_comm_wait", C.c_int, [_vp, _vp]),
     ("neddf_comm_wait_host", C.c_int, [_vp, C.c_int]),
     ("neddf_train_workspace_floats", _i64, [_vp, C.c_int, _i64]),
@@ -431,14 +433,15 @@ class Context:
         self.check(self.lib.neddf_comm_destroy(self.h))
         self._gather_refs = None
 
-    def gather_pixels(self, local, n_total, out=None):
+    def gather_pixels(self, local, n_total, out=None, granule=1):
         """Start the all-gather of this rank's slab [n_rank, C] into out [n_total, C] on the library's communication stream,
-        ordered after the current stream's work; returns `out`.  Nothing may touch local / out until comm_wait()."""
+        ordered after the current stream's work; returns `out`.  Nothing may touch local / out until comm_wait().
+        Slabs are cut on multiples of `granule` rows (neddf_shard_range_granular)."""
         require_device(local, "local pixels")
         local = f32c(local)
         if out is None:
             out = torch.empty(n_total, local.shape[1], device=local.device, dtype=torch.float32)
-        self.check(self.lib.neddf_gather_pixels(self.h, _ptr(local), n_total, local.shape[1], _ptr(out), self.stream()))
+        self.check(self.lib.neddf_gather_pixels_granular(self.h, _ptr(local), n_total, int(granule), local.shape[1], _ptr(out), self.stream()))
         self._gather_refs = (local, out)       # keep both alive (and out of the caching allocator) until the wait
         return out
 

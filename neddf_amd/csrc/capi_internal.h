@@ -39,6 +39,7 @@ struct CommState {
     hipEvent_t ready = nullptr;  // recorded on the compute stream: the local slab is complete
     hipEvent_t done = nullptr;   // recorded on the communication stream: the gathered pixels are complete
     bool pending = false;
+    bool lost = false;           // the communicator was aborted with a gather in flight: the next wait reports it
     DevBuf pad;                  // [nranks * pad_rows * channels] staging for ragged slabs
 };
 

@@ -13,7 +13,20 @@
 
 #include <dlfcn.h>
 #include <string.h>
+// RCCL is bound at run time (dlopen below); its development headers are used when the build host has them and otherwise
+// replaced by the handful of declarations this file needs (RCCL keeps NCCL's public ABI: opaque communicator, 128-byte id)
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4,
+               ncclInvalidUsage = 5, ncclRemoteError = 6, ncclInProgress = 7 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6,
+               ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8 } ncclDataType_t;
+}
+#endif
 
 #include <chrono>
 #include <string>
@@ -76,6 +89,20 @@ int need_rccl(neddf_ctx *ctx, Rccl *&r)
 
 }  // namespace
 
+// everything of the communicator state except the communicator itself: stream, events, staging, rank bookkeeping.
+// `lost` marks a gather that was in flight when the communicator went away (neddf_comm_wait then reports it instead of
+// letting a consumer read a partially gathered buffer)
+static void comm_reset(CommState &c, bool lost)
+{
+    if (c.ready) { (void)hipEventDestroy(c.ready); c.ready = nullptr; }
+    if (c.done) { (void)hipEventDestroy(c.done); c.done = nullptr; }
+    if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
+    if (c.pad.p) { (void)hipFree(c.pad.p); c.pad = DevBuf{}; }
+    c.rank = c.nranks = 0;
+    c.pending = false;
+    c.lost = lost;
+}
+
 // called by neddf_destroy (neddf_capi.hip)
 void neddf_comm_release(neddf_ctx *ctx)
 {
@@ -86,23 +113,28 @@ void neddf_comm_release(neddf_ctx *ctx)
         if (r->handle) (void)r->CommDestroy((ncclComm_t)c.comm);
         c.comm = nullptr;
     }
-    if (c.ready) { (void)hipEventDestroy(c.ready); c.ready = nullptr; }
-    if (c.done) { (void)hipEventDestroy(c.done); c.done = nullptr; }
-    if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
-    if (c.pad.p) { (void)hipFree(c.pad.p); c.pad = DevBuf{}; }
-    c.rank = c.nranks = 0;
-    c.pending = false;
+    comm_reset(c, false);
 }
 
 extern "C" {
 
 void neddf_shard_range(int64_t n_total, int rank, int nranks, int64_t *lo, int64_t *hi)
 {
+    neddf_shard_range_granular(n_total, 1, rank, nranks, lo, hi);
+}
+
+void neddf_shard_range_granular(int64_t n_total, int64_t granule, int rank, int nranks, int64_t *lo, int64_t *hi)
+{
     if (nranks < 1) nranks = 1;
-    const int64_t base = n_total / nranks, rem = n_total % nranks;
-    const int64_t l = rank * base + (rank < rem ? rank : rem);
+    if (granule < 1) granule = 1;
+    if (n_total < 0) n_total = 0;
+    // the units are the granules (the last one may be short); unit counts per rank differ by at most one
+    const int64_t units = (n_total + granule - 1) / granule;
+    const int64_t base = units / nranks, rem = units % nranks;
+    const int64_t ul = rank * base + (rank < rem ? rank : rem), uh = ul + base + (rank < rem ? 1 : 0);
+    const int64_t l = ul * granule < n_total ? ul * granule : n_total, h = uh * granule < n_total ? uh * granule : n_total;
     if (lo) *lo = l;
-    if (hi) *hi = l + base + (rank < rem ? 1 : 0);
+    if (hi) *hi = h;
 }
 
 int neddf_comm_unique_id(neddf_ctx *ctx, void *h_id)
@@ -131,10 +163,15 @@ int neddf_comm_init(neddf_ctx *ctx, int rank, int nranks, const void *h_id)
     memcpy(&id, h_id, sizeof(id));
     ncclComm_t comm = nullptr;
     RCCLCHK(r->CommInitRank(&comm, nranks, id, rank));
-    c.comm = comm; c.rank = rank; c.nranks = nranks;
-    HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+    c.comm = comm; c.rank = rank; c.nranks = nranks; c.lost = false;
+    hipError_t e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c.ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c.done, hipEventDisableTiming);
+    if (e != hipSuccess) {          // no half-built communicator state: unwind to "no communicator"
+        const std::string why = std::string("comm_init: ") + hipGetErrorString(e);
+        neddf_comm_release(ctx);
+        return fail(ctx, NEDDF_EHIP, why);
+    }
     return 0;
 }
 
@@ -161,7 +198,13 @@ int neddf_comm_destroy(neddf_ctx *ctx)
 
 int neddf_gather_pixels(neddf_ctx *ctx, const float *d_local, int64_t n_total, int channels, float *d_all, void *stream)
 {
-    if (!ctx || !d_all || n_total < 0 || channels < 1) return NEDDF_EINVAL;
+    return neddf_gather_pixels_granular(ctx, d_local, n_total, 1, channels, d_all, stream);
+}
+
+int neddf_gather_pixels_granular(neddf_ctx *ctx, const float *d_local, int64_t n_total, int64_t granule, int channels, float *d_all,
+                                 void *stream)
+{
+    if (!ctx || !d_all || n_total < 0 || channels < 1 || granule < 1) return NEDDF_EINVAL;
     CommState &c = ctx->comm;
     if (!c.comm) return fail(ctx, NEDDF_ECOMM, "gather_pixels: no communicator (neddf_comm_init)");
     if (n_total == 0) return 0;
@@ -169,10 +212,16 @@ int neddf_gather_pixels(neddf_ctx *ctx, const float *d_local, int64_t n_total, i
     if (int rc = need_rccl(ctx, r)) return rc;
     DeviceGuard guard_(ctx->device);
     int64_t lo, hi;
-    neddf_shard_range(n_total, c.rank, c.nranks, &lo, &hi);
+    neddf_shard_range_granular(n_total, granule, c.rank, c.nranks, &lo, &hi);
     if (hi > lo && !d_local) return NEDDF_EINVAL;
-    const int64_t pad = (n_total + c.nranks - 1) / c.nranks;         // rows of the largest slab
-    const bool ragged = n_total % c.nranks != 0;
+    int64_t pad = 0;                                                 // rows of the largest slab
+    bool ragged = false;
+    for (int q = 0; q < c.nranks; ++q) {
+        int64_t l, h;
+        neddf_shard_range_granular(n_total, granule, q, c.nranks, &l, &h);
+        if (q && h - l != pad) ragged = true;
+        if (h - l > pad) pad = h - l;
+    }
     const size_t row = (size_t)channels * sizeof(float);
     if (ragged)
         if (int rc = ensure(ctx, c.pad, (size_t)(c.nranks + 1) * pad * row)) return rc;
@@ -190,7 +239,7 @@ int neddf_gather_pixels(neddf_ctx *ctx, const float *d_local, int64_t n_total, i
         RCCLCHK(r->AllGather(send, recv, (size_t)pad * channels, ncclFloat, (ncclComm_t)c.comm, c.stream));
         for (int q = 0; q < c.nranks; ++q) {
             int64_t l, h;
-            neddf_shard_range(n_total, q, c.nranks, &l, &h);
+            neddf_shard_range_granular(n_total, granule, q, c.nranks, &l, &h);
             if (h > l)
                 HIPCHK(hipMemcpyAsync((char *)d_all + l * row, recv + (size_t)q * pad * row, (size_t)(h - l) * row,
                                       hipMemcpyDeviceToDevice, c.stream));
@@ -206,6 +255,7 @@ int neddf_comm_wait(neddf_ctx *ctx, void *stream)
 {
     if (!ctx) return NEDDF_EINVAL;
     CommState &c = ctx->comm;
+    if (c.lost) { c.lost = false; return fail(ctx, NEDDF_ECOMM, "comm_wait: the communicator was aborted while a pixel gather was in flight; its output is incomplete"); }
     if (!c.comm || !c.pending) return 0;
     DeviceGuard guard_(ctx->device);
     HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c.done, 0));
@@ -216,6 +266,7 @@ int neddf_comm_wait_host(neddf_ctx *ctx, int timeout_ms)
 {
     if (!ctx) return NEDDF_EINVAL;
     CommState &c = ctx->comm;
+    if (c.lost) { c.lost = false; return fail(ctx, NEDDF_ECOMM, "comm_wait_host: the communicator was aborted while a pixel gather was in flight; its output is incomplete"); }
     if (!c.comm || !c.pending) return 0;
     Rccl *r;
     if (int rc = need_rccl(ctx, r)) return rc;
@@ -232,7 +283,10 @@ int neddf_comm_wait_host(neddf_ctx *ctx, int timeout_ms)
         const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
         if (timeout_ms >= 0 && ms > timeout_ms) {
             (void)r->CommAbort((ncclComm_t)c.comm);      // frees the communicator; a peer is gone or stuck
-            c.comm = nullptr; c.pending = false;
+            c.comm = nullptr;
+            // back to "no communicator" (neddf_comm_info reports 0 ranks, so a caller re-initialises instead of finding every
+            // later gather refused), remembering that the gather in flight never completed
+            comm_reset(c, true);
             return fail(ctx, NEDDF_ETIMEOUT, "comm_wait_host: pixel gather did not complete in " + std::to_string(timeout_ms) + " ms; communicator aborted");
         }
         std::this_thread::sleep_for(std::chrono::microseconds(200));

@@ -95,8 +95,10 @@ __device__ __forceinline__ void encode_dir(typename Ops::act_t *act, int col0, c
 // ctl[0] = next tile index, written by thread 0.
 #ifdef NEDDF_ABLATE
 #define NEDDF_ABL(flags, bit) ((flags) & (bit))
+constexpr bool kAblate = true;
 #else
 #define NEDDF_ABL(flags, bit) 0
+constexpr bool kAblate = false;
 #endif
 __device__ __forceinline__ int64_t sched_begin(int *sched, int flags, int *ctl, int tid)
 {
@@ -340,7 +342,7 @@ size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points) { return (size_t)
 
 template <int KIND, bool LAST, int MT, int NT, class Ops>
 __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *yp, const float *wseed, int wave,
-                                                     int lane)
+                                                     int lane, int ymask)
 {
     constexpr int LD = Ops::kLd;
     const int j = lane & 31, h = lane >> 5;
@@ -371,19 +373,19 @@ __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], type
     // y' leaves in the accumulators' own fragment order (16 bytes per lane, 1 KiB per wave and store): only this workgroup's
     // same lanes read it back, so nothing needs it row-major.  Under the bf16 policy it travels as bf16 (the product it enters
     // is rounded to bf16 anyway): at that policy's speed the fp32 round trip (26 GB per launch) would be the kernel's bound
-    if (!LAST) {
-        if constexpr (Ops::kStash16) stash_store16<MT, NT>(acc, yp, wave, lane);
-        else stash_store<MT, NT>(acc, yp, wave, lane);
+    if (!LAST && (!kAblate || yp)) {
+        if constexpr (Ops::kStash16) stash_store16<MT, NT>(acc, yp, wave, lane, ymask);
+        else stash_store<MT, NT>(acc, yp, wave, lane, ymask);
     }
 }
 
 template <bool LAST, int MT, int NT, class Ops>
 __device__ __forceinline__ void rev_forward_epilogue_rt(f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *yp, const float *wseed, int kind,
-                                                        int wave, int lane)
+                                                        int wave, int lane, int ymask = -1)
 {
-    if (kind == 0) rev_forward_epilogue<0, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane);
-    else if (kind == 1) rev_forward_epilogue<1, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane);
-    else rev_forward_epilogue<2, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane);
+    if (kind == 0) rev_forward_epilogue<0, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane, ymask);
+    else if (kind == 1) rev_forward_epilogue<1, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane, ymask);
+    else rev_forward_epilogue<2, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane, ymask);
 }
 
 template <int MT, int NW, int WPS, class Ops>
@@ -415,6 +417,10 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
     // behind an s_waitcnt vmcnt(0) -- which serialises the operand prefetch of half of the kernel's matrix work
     const int KS = a.ks_hidden;
     const int j = lane & 31, h = lane >> 5;
+    // timing probes of the y' round trip (-DNEDDF_ABLATE builds only, results invalid): 128 = every layer shares one slot
+    // (footprint / 6), 512 = and every M-tile folds onto the first (footprint / 12: L2-resident), 256 = no y' traffic at all
+    const int ylstep = NEDDF_ABL(a.sched_flags, 128) ? 0 : 1, ymask = NEDDF_ABL(a.sched_flags, 512) ? 0 : -1;
+    const bool ynone = NEDDF_ABL(a.sched_flags, 256);
 
     int *ctl = (int *)(lp + 12);
     int64_t tile = sched_begin(a.sched, a.sched_flags, ctl, tid);
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             }
             if (l + 1 < a.n_layers) layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
             __syncthreads();
-            if (l + 1 < a.n_layers) rev_forward_epilogue_rt<false, MT, NT, Ops>(acc, act, yp + (size_t)l * ROWS * kWidth, nullptr, a.activation, wave, lane);
+            if (l + 1 < a.n_layers) rev_forward_epilogue_rt<false, MT, NT, Ops>(acc, act, ynone ? nullptr : yp + (size_t)(l * ylstep) * ROWS * kWidth, nullptr, a.activation, wave, lane, ymask);
             else rev_forward_epilogue_rt<true, MT, NT, Ops>(acc, act, nullptr, a.w_ddf_out, a.activation, wave, lane);
             __syncthreads();
         }
@@ -534,8 +540,16 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             // are requested after the product (requesting them before it -- 64 more live registers -- measured no faster: the
             // CU's other waves cover the latency), the others while the previous M-tile is multiplied and stored
             f32x16 yb[2][NT];
-            const f32x4v *ysrc = (const f32x4v *)(yp + (size_t)(l - 1) * ROWS * kWidth) + (size_t)wave * (MT * NT * (Ops::kStash16 ? 2 : 4)) * 64 + lane;
+            const f32x4v *ysrc = (const f32x4v *)(yp + (size_t)((l - 1) * ylstep) * ROWS * kWidth) + (size_t)wave * (MT * NT * (Ops::kStash16 ? 2 : 4)) * 64 + lane;
             auto load_y = [&](f32x16 (&dst)[NT], int mt) {
+                mt &= ymask;
+                if (ynone) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) dst[t][q] = 1.0f;
+                    return;
+                }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     if constexpr (Ops::kStash16) stash_load16(dst[t], (const u32x4 *)ysrc + ((mt * NT + t) * 2) * 64);

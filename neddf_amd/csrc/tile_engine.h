@@ -371,8 +371,9 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[MT][NT], const float *bia
     }
 }
 
+// (mtmask: -1; the timing probes of -DNEDDF_ABLATE builds pass 0 to fold every M-tile onto the first one's slot)
 template <int MT, int NT>
-__device__ __forceinline__ void stash_store(const f32x16 (&acc)[MT][NT], float *slot, int wave, int lane)
+__device__ __forceinline__ void stash_store(const f32x16 (&acc)[MT][NT], float *slot, int wave, int lane, int mtmask = -1)
 {
     f32x4v *dst = (f32x4v *)slot + (size_t)wave * (MT * NT * 4) * 64 + lane;
 #pragma unroll
@@ -382,13 +383,13 @@ __device__ __forceinline__ void stash_store(const f32x16 (&acc)[MT][NT], float *
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4v v = { acc[mt][t][4 * g], acc[mt][t][4 * g + 1], acc[mt][t][4 * g + 2], acc[mt][t][4 * g + 3] };
-                dst[((mt * NT + t) * 4 + g) * 64] = v;
+                dst[(((mt & mtmask) * NT + t) * 4 + g) * 64] = v;
             }
 }
 
 // the same in bf16: 16 accumulators = two 16-byte chunks per lane
 template <int MT, int NT>
-__device__ __forceinline__ void stash_store16(const f32x16 (&acc)[MT][NT], float *slot, int wave, int lane)
+__device__ __forceinline__ void stash_store16(const f32x16 (&acc)[MT][NT], float *slot, int wave, int lane, int mtmask = -1)
 {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -403,7 +404,7 @@ __device__ __forceinline__ void stash_store16(const f32x16 (&acc)[MT][NT], float
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     v[i] = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){ acc[mt][t][8 * c + 2 * i], acc[mt][t][8 * c + 2 * i + 1] }, bf16x2));
-                dst[((mt * NT + t) * 2 + c) * 64] = v;
+                dst[(((mt & mtmask) * NT + t) * 2 + c) * 64] = v;
             }
 }
 

@@ -29,15 +29,22 @@ from torch import Tensor
 CHANNELS = {"color": 3, "depth": 1, "transmittance": 1}
 
 
-def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous slab [lo, hi) of range(n) owned by `rank`; sizes differ by at most one."""
-    base, rem = divmod(n, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+def shard_range(n: int, rank: int, world: int, granule: int = 1) -> Tuple[int, int]:
+    """Contiguous slab [lo, hi) of range(n) owned by `rank`, cut on multiples of `granule` (the last granule of the range may
+    be short): granule counts differ by at most one (neddf_shard_range_granular of the C ABI).  A sharded frame uses
+    render_image's `chunk` as the granule, so that no chunk is split between two ranks: the reference decides sample_pdf's
+    NaN fallback per chunk (base_neural_render.py:105-114), and a rank that held only part of one would decide it on
+    different rays."""
+    units = -(-n // granule)
+    base, rem = divmod(units, world)
+    ul = rank * base + min(rank, rem)
+    uh = ul + base + (1 if rank < rem else 0)
+    return min(n, ul * granule), min(n, uh * granule)
 
 
 def pack_pixels(parts: Dict[str, Tensor], keys: Iterable[str]) -> Tensor:
-    return torch.cat([parts[k].reshape(parts[k].shape[0], -1) for k in keys], dim=1).contiguous()
+    # (explicit channel counts: a rank's slab may be empty -- more ranks than chunks -- and reshape(0, -1) is ambiguous)
+    return torch.cat([parts[k].reshape(parts[k].shape[0], CHANNELS[k]) for k in keys], dim=1).contiguous()
 
 
 def unpack_pixels(packed: Tensor, keys: Iterable[str]) -> Dict[str, Tensor]:
@@ -104,8 +111,9 @@ class PixelGather:
         return self.out
 
 
-def gather_pixels(local: Tensor, n_total: int, group=None, force_collective: bool = False, wait: bool = True, out: Tensor = None):
-    """All-gather per-rank slabs [n_rank, C] (shard_range order) into [n_total, C] on every rank.
+def gather_pixels(local: Tensor, n_total: int, group=None, force_collective: bool = False, wait: bool = True, out: Tensor = None,
+                  granule: int = 1):
+    """All-gather per-rank slabs [n_rank, C] (shard_range(..., granule) order) into [n_total, C] on every rank.
 
     Device tensors go through the HIP library's own RCCL communicator (neddf_gather_pixels): the collective runs on a
     communication stream ordered after the current stream, so with wait=False the caller can keep rendering the next
@@ -117,7 +125,7 @@ def gather_pixels(local: Tensor, n_total: int, group=None, force_collective: boo
     if local.is_cuda and "nccl" not in str(dist.get_backend(group)):
         # a process group without a device backend (gloo: several test ranks sharing one GPU, where RCCL cannot form a
         # communicator): stage the slab through the host
-        full = gather_pixels(local.cpu(), n_total, group, force_collective).to(local.device)
+        full = gather_pixels(local.cpu(), n_total, group, force_collective, granule=granule).to(local.device)
         if out is not None:
             out.copy_(full)
             full = out
@@ -128,10 +136,10 @@ def gather_pixels(local: Tensor, n_total: int, group=None, force_collective: boo
         native_comm(ctx, group)
         if ctx._gather_refs is not None:       # one gather in flight per context: its buffers are released by the wait
             ctx.comm_wait()
-        res = ctx.gather_pixels(local, n_total, out)
+        res = ctx.gather_pixels(local, n_total, out, granule)
         handle = PixelGather(ctx, res)
         return handle.wait() if wait else handle
-    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    sizes = [shard_range(n_total, r, world, granule) for r in range(world)]
     pad = max(hi - lo for lo, hi in sizes)
     buf = local
     if local.shape[0] < pad:
@@ -155,9 +163,9 @@ def render_image_sharded(render, width: int, height: int, camera, target_types: 
     w, h = width // downsampling, height // downsampling
     n = w * h
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    lo, hi = shard_range(n, rank, world)
-    parts = render.render_image(width, height, camera, keys, downsampling, chunk, pixel_range=(lo, hi))
-    full = gather_pixels(pack_pixels(parts, keys), n, group)
+    lo, hi = shard_range(n, rank, world, chunk)          # whole chunks per rank: the image is the single-GPU one bit for bit,
+    parts = render.render_image(width, height, camera, keys, downsampling, chunk, pixel_range=(lo, hi))    # NaN fallback included
+    full = gather_pixels(pack_pixels(parts, keys), n, group, granule=chunk)
     return {k: v.reshape(h, w, -1) for k, v in unpack_pixels(full, keys).items()}
 
 
@@ -184,3 +192,40 @@ def average_gradients(params: Iterable[Tensor], group=None, force_collective: bo
         else:
             p.grad.copy_(g)
         off += n
+
+
+def sync_parameters(tensors: Iterable[Tensor], group=None, src: int = 0) -> None:
+    """Data-parallel start: every rank takes rank `src`'s values (one broadcast of the flattened parameters and buffers),
+    so that the replicas the averaged gradients are applied to are the SAME point in parameter space."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    tensors = list(tensors)
+    if not tensors:
+        return
+    with torch.no_grad():
+        flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
+        dist.broadcast(flat, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t).to(t.dtype))
+            off += n
+
+
+def assert_replicas_identical(tensors: Iterable[Tensor], group=None, what: str = "parameters") -> None:
+    """Raise on every rank unless all ranks hold bit-identical values: a (sum, sum of squares, xor of the bit patterns)
+    signature per rank, compared by min / max all-reduces."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    tensors = list(tensors)
+    if not tensors:
+        return
+    with torch.no_grad():
+        flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
+        bits = flat.view(torch.int32).to(torch.int64)
+        sig = torch.stack([flat.double().sum(), flat.double().square().sum(), (bits * (torch.arange(bits.numel(), device=bits.device) % 8191 + 1)).sum().double()])
+        lo, hi = sig.clone(), sig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not torch.equal(lo, hi):
+        raise RuntimeError("data-parallel replicas hold different %s (signature spread %s)" % (what, (hi - lo).tolist()))

@@ -278,13 +278,17 @@ class NeRFRender(BaseNeuralRender):
                         uc, uf, start, count = [], [], start + count, 0
                 skip_uniforms((n - below) * per_ray)
             else:
-                for below in range(lo, hi, self.rays_per_call):
-                    above = min(hi, below + self.rays_per_call)
+                # batches of whole chunks (sample_pdf's NaN fallback is decided per chunk, never on part of one)
+                step = max(chunk, self.rays_per_call // chunk * chunk)
+                for below in range(lo, hi, step):
+                    above = min(hi, below + step)
                     launch(below, above, self._rand(above - below, self.sample_coarse + 1, dev),
                            self._rand(above - below, self.sample_fine + 1, dev))
-            assert int(torch.stack(flags).sum().item()) == 0, "NaN weight in integrate_volume_render"
+            assert not flags or int(torch.stack(flags).sum().item()) == 0, "NaN weight in integrate_volume_render"
             if pixel_range is None:
                 images = {k: torch.cat(parts[k], 0).reshape(h, w, -1) for k in target_types}
+            elif hi <= lo:          # an empty slab (more ranks than chunks)
+                images = {k: torch.empty(0, 3 if k == "color" else 1, device=dev) for k in target_types}
             else:
                 images = {k: torch.cat(parts[k], 0).reshape(hi - lo, -1) for k in target_types}
             self.network_coarse.train(True)

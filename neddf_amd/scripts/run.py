@@ -52,8 +52,12 @@ def compose(overrides: List[str], config_dir: Path = CONFIG_DIR) -> Dict[str, An
 def main(argv=None) -> None:
     """Single process: the reference's behaviour.  Under a launcher (`python -m torch.distributed.run --nproc-per-node N
     neddf/scripts/run.py ...`; not in the reference, which trains on one device) training is data-parallel over rays: rank r
-    takes device cuda:r and seed 3408 + r (its own cameras / pixels), the gradients are averaged with one all-reduce per
-    step (parallel.average_gradients), and only rank 0 creates the run directory and writes checkpoints, renders and logs."""
+    takes device cuda:r; the trainer (and with it the networks' initial weights) is built under the COMMON seed, the
+    parameters are then broadcast from rank 0 and checked to be identical on every rank, and only after that each rank
+    switches to seed 3408 + r (its own cameras / pixels); the gradients are averaged with one all-reduce per step
+    (parallel.average_gradients), and only rank 0 creates the run directory and writes checkpoints, renders and logs
+    (the periodic test render included: it is rank 0's own, not a sharded collective).  NEDDF_DIST_BACKEND=gloo selects
+    the host backend (tests on one shared GPU)."""
     argv = sys.argv[1:] if argv is None else argv
     cfg = compose(argv)
     cwd = Path.cwd()
@@ -62,10 +66,14 @@ def main(argv=None) -> None:
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("NEDDF_DIST_BACKEND", "nccl")
+        local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
         cfg["trainer"]["device"] = "cuda:%d" % local
-        seed_everything(3408 + rank)
     now = datetime.datetime.now()
     run_dir = [str(cwd / "outputs" / now.strftime("%Y-%m-%d") / now.strftime("%H-%M-%S"))]
     if world > 1:
@@ -78,8 +86,16 @@ def main(argv=None) -> None:
     if world > 1:
         torch.distributed.barrier()
     os.chdir(run_dir)
-    trainer = instantiate(cfg["trainer"], global_config=cfg, _recursive_=False)
+    trainer = instantiate(cfg["trainer"], global_config=cfg, _recursive_=False)      # under the common seed (3408)
     trainer.writes_outputs = rank == 0
+    if world > 1:
+        from neddf_amd.parallel import assert_replicas_identical, sync_parameters
+        state = [t for t in trainer.neural_render.state_dict().values() if torch.is_tensor(t) and t.is_floating_point()]
+        sync_parameters(state)
+        assert_replicas_identical(state)
+        if os.environ.get("NEDDF_RUN_PRINT_SIGNATURE"):
+            print("replica_signature[%d]=%.17g" % (rank, float(sum(t.double().sum() for t in state))), flush=True)
+        seed_everything(3408 + rank)          # from here on every rank draws its own cameras and pixels
     trainer.run_train()
     if world > 1:
         torch.distributed.destroy_process_group()

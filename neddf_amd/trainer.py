@@ -52,14 +52,19 @@ class BaseTrainer:
         """base_trainer.py:115-121"""
         self.neural_render.load_state_dict(torch.load(str(model_path), map_location="cpu"))
 
-    def render_test(self, output_dir: Path, camera_id: int, downsampling: int = 1) -> None:
+    def render_test(self, output_dir: Path, camera_id: int, downsampling: int = 1, sharded: Any = None) -> None:
         """base_trainer.py:123-174: colour -> clamp(c*255) uint8, depth -> clamp((d-2)/4*50000/256) uint8,
-        PNGs {id:03}_rgb / _rgb_gt / _depth, PSNR + SSIM vs the ground truth at full resolution."""
+        PNGs {id:03}_rgb / _rgb_gt / _depth, PSNR + SSIM vs the ground truth at full resolution.
+        sharded (not a reference keyword): None = ray-shard the frame over the ranks whenever a process group is up (a
+        COLLECTIVE: every rank must call, with the same torch seed -- run_eval.py / render_all); False = render on this rank
+        alone (the periodic test render of a data-parallel training run, which only rank 0 makes)."""
         rgb_gt = self.dataset[camera_id]["rgb_images"].astype(np.uint8)
         camera = self.cameras[camera_id]
         camera.update_transform()
         h, w = rgb_gt.shape[0], rgb_gt.shape[1]
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        if sharded is None:
+            sharded = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        if sharded:
             # under a launcher (scripts/run_eval.py, BASELINE.json configs[3]): every rank renders a slab of the frame's pixel
             # index, one all-gather of the pixels, rank 0 writes the files.  Same seed on every rank => the single-GPU image
             images = render_image_sharded(self.neural_render, w, h, camera, ["color", "depth"], downsampling, self.chunk)
@@ -154,7 +159,9 @@ class NeRFTrainer(BaseTrainer):
                 print("test rendering...")
                 output_dir = render_dir / "{:04}".format(epoch)
                 output_dir.mkdir(parents=True)
-                self.render_test(output_dir, int(camera_ids[0]), downsampling=3)
+                # rank 0 alone: the other ranks are already in the next epoch's gradient all-reduce, and their generators
+                # hold other seeds -- a sharded (collective) render here would mismatch collectives and deadlock
+                self.render_test(output_dir, int(camera_ids[0]), downsampling=3, sharded=False)
             if epoch % self.epoch_save_model == 0:
                 torch.save(self.neural_render.state_dict(), "models/model_{:0=5}.pth".format(epoch))
 

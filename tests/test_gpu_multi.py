@@ -240,6 +240,35 @@ def test_run_eval_under_a_launcher_matches_single_process(tmp_path):
             assert (outs["one"] / name).read_bytes() == (outs["two"] / name).read_bytes(), name
 
 
+def test_run_script_two_ranks_data_parallel(tmp_path):
+    """scripts/run.py under a launcher with two ranks (data-parallel training, one gradient all-reduce per step): the run must
+    FINISH -- rank 0's periodic test render is its own, not a sharded collective the other rank never joins --, both ranks must
+    start from identical parameters (run.py asserts the signature across ranks before step 1), and rank 0 alone writes the
+    checkpoints / renders.  One-GPU boxes: the ranks share the device, gradients travel through gloo."""
+    from test_host import _make_dataset
+    ds = tmp_path / "data" / "tiny"
+    _make_dataset(str(ds), n=2, w=20, h=16, split="train")
+    script = os.path.join(ROOT, "neddf", "scripts", "run.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NEDDF_RUN_PRINT_SIGNATURE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["NEDDF_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29700 + os.getpid() % 90), script, "trainer=test", "dataset.dataset_dir=data/tiny/",
+                        "trainer.batch_size=16", "trainer.epoch_max=1", "trainer.epoch_save_model=1", "trainer.epoch_test_rendering=1",
+                        "trainer.epoch_save_fields=1"], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    sigs = [l.split("=", 1)[1] for l in p.stdout.splitlines() if l.startswith("replica_signature")]
+    assert len(sigs) == 2 and sigs[0] == sigs[1], p.stdout[-2000:]
+    rds = list((tmp_path / "outputs").glob("*/*"))
+    assert len(rds) == 1, rds                                         # one run directory: rank 0's
+    for e in (0, 1):
+        sd = torch.load(rds[0] / "models" / ("model_%05d.pth" % e), map_location="cpu")
+        assert len(sd) == 52 and all(torch.isfinite(v).all() for v in sd.values())
+        assert len(list((rds[0] / "render" / ("%04d" % e)).glob("*_rgb.png"))) == 1
+
+
 def test_c_client_of_the_abi(tmp_path):
     """INTEGRATION.md mode B: a plain-C program (tests/capi/c_smoke.c, built with gcc against include/neddf_hip.h -- no Python, no
     torch) sets up the shipped NeDDF architecture, renders 96 rays through neddf_render_rays in both output modes and gathers the

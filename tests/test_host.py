@@ -172,6 +172,13 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+            for granule in (1, 50, 1024):          # chunk-granular slabs (a sharded frame never splits a chunk)
+                spans = [shard_range(n, r, world, granule) for r in range(world)]
+                assert spans[0][0] == 0 and spans[-1][1] == n
+                assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+                assert all((l % granule == 0 or l == n) and (h % granule == 0 or h == n) for l, h in spans)
+                units = [-(-(h - l) // granule) for l, h in spans]
+                assert max(units) - min(units) <= 1
 
 
 _WORKER = r'''
@@ -222,7 +229,8 @@ img = render_image_sharded(stub, W, H, Cam(), ["color", "depth"], 1, CHUNK)
 assert torch.equal(img["color"].reshape(-1, 3), torch.stack([uc[:, 0], uc[:, -1], uf[:, 7]], 1)), "slab uniforms differ from the reference order"
 assert torch.equal(img["depth"].reshape(-1), uf[:, -1])
 assert torch.equal(torch.get_rng_state(), end_state), "generator must end where the whole-frame draw ends"
-lo, hi = shard_range(W * H, rank, world)
+lo, hi = shard_range(W * H, rank, world, CHUNK)     # whole chunks per rank
+assert lo % CHUNK == 0
 first = (lo // CHUNK) * CHUNK
 chunks_touched = range(first, min(W * H, ((hi + CHUNK - 1) // CHUNK) * CHUNK), CHUNK)
 assert stub.drawn == (hi - lo) * 194, (stub.drawn, hi - lo)     # only the slab's rows reach the device
@@ -246,6 +254,21 @@ if rank == 0:
 average_gradients(ps)
 assert torch.allclose(ps[0].grad, torch.full((3, 4), (world + 1) / 2)) and torch.allclose(ps[1].grad, torch.zeros(5), atol=1e-6)
 assert torch.allclose(ps[2].grad, torch.full((2, 2), 1.0 / world))
+# data-parallel start: replicas built under different seeds are made identical by one broadcast, and the check that guards
+# the first step tells identical from diverged replicas on EVERY rank
+from neddf_amd.parallel import assert_replicas_identical, sync_parameters
+torch.manual_seed(100 + rank)
+reps = [torch.randn(7, 3), torch.randn(5)]
+if world > 1:
+    try:
+        assert_replicas_identical(reps)
+        raise SystemExit("diverged replicas went unnoticed")
+    except RuntimeError as e:
+        assert "different parameters" in str(e)
+sync_parameters(reps)
+assert_replicas_identical(reps)
+torch.manual_seed(100)
+assert torch.equal(reps[0], torch.randn(7, 3)) and torch.equal(reps[1], torch.randn(5))      # rank 0's values
 # communicator bootstrap (native_comm): a failure anywhere must raise on EVERY rank, never strand the others in a collective
 from neddf_amd.parallel import native_comm
 class FakeCtx:
@@ -625,7 +648,7 @@ def test_capi_rejects_null_context_without_touching_a_device():
     from neddf_amd import _lib
     lib = _lib.load()
     skip = {"neddf_abi_version", "neddf_create", "neddf_destroy", "neddf_last_error", "neddf_device_cus",
-            "neddf_shard_range"}       # pure arithmetic, no context
+            "neddf_shard_range", "neddf_shard_range_granular"}       # pure arithmetic, no context
     lo, hi = C.c_int64(), C.c_int64()
     spans = []
     for r in range(3):
@@ -633,6 +656,12 @@ def test_capi_rejects_null_context_without_touching_a_device():
         spans.append((lo.value, hi.value))
     from neddf_amd.parallel import shard_range
     assert spans == [(0, 4), (4, 7), (7, 10)] == [shard_range(10, r, 3) for r in range(3)]      # library and host agree
+    for n, g, world in ((120, 50, 2), (120, 50, 3), (640000, 1024, 8), (5, 7, 3), (0, 4, 2)):
+        got = []
+        for r in range(world):
+            lib.neddf_shard_range_granular(n, g, r, world, C.byref(lo), C.byref(hi))
+            got.append((lo.value, hi.value))
+        assert got == [shard_range(n, r, world, g) for r in range(world)], (n, g, world, got)
     for name, res, args in _lib.SYMBOLS:
         if name in skip:
             continue
@@ -695,7 +724,7 @@ lib = _lib.load()
 assert lib.neddf_abi_version() == _lib.ABI_VERSION
 # every entry point with a NULL context and NULL pointers: must return NEDDF_EINVAL without touching memory
 for name, res, args in _lib.SYMBOLS:
-    if name in ("neddf_abi_version", "neddf_create", "neddf_destroy", "neddf_last_error", "neddf_device_cus", "neddf_shard_range"):
+    if name in ("neddf_abi_version", "neddf_create", "neddf_destroy", "neddf_last_error", "neddf_device_cus", "neddf_shard_range", "neddf_shard_range_granular"):
         continue
     call = [a(0) if a in (C.c_int, C.c_int64) else a(0.0) if a in (C.c_float, C.c_double) else None for a in args]
     assert getattr(lib, name)(*call) == -1, name
