@@ -20,6 +20,7 @@ struct Field {
     float aux_grad_scale = 1.1f, distance_range_max = 2.0f;
     float lowpass[10];
     DevBuf blob;
+    hipEvent_t last_use = nullptr;       // recorded after the last launch that reads `blob` (neddf_set_field waits on it)
     DdfArgs ddf{};
     ColArgs col{};
     NerfArgs nerf{};

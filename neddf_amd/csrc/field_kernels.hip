@@ -125,7 +125,8 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
 {
     typedef typename Ops::act_t act_t;
     typedef typename Ops::bfrag frag;            // weight fragments
-    constexpr int NT = 8 / NW, THREADS = 64 * NW, ROWS = MT * 32, P = MT * 8, LD = Ops::kLd;
+    constexpr int WID = Ops::kWid, NT = WID / 32 / NW, THREADS = 64 * NW, ROWS = MT * 32, P = MT * 8, LD = Ops::kLd;
+    static_assert(NT >= 1 && NT * 32 * NW == WID && MT * NT <= 8, "engine width = NW waves x NT column tiles of 32; a stash slot holds MT x NT <= 8 tiles per wave");
     constexpr int REG_BUDGET = 512 / (WPS * NW / 4);        // registers per lane at this occupancy
     // ping-pong operand registers of the dense pipeline
     constexpr int OPREGS = 2 * (MT * (int)sizeof(typename Ops::afrag) / 4 + NT * (int)sizeof(typename Ops::bfrag) / 4);
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
     float *lp = hd + 6 * ROWS;              // [16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
-    float *scratch = a.scratch + (size_t)blockIdx.x * kStashFloatsPerWg * kMaxStash;
+    float *scratch = a.scratch + (size_t)blockIdx.x * kStashFloatsPerWg * (a.n_stash > 1 ? a.n_stash : 1);
     if (tid == 0) {
 #pragma unroll
         for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
         } else {
         // heads (neddf.py:220-230): ddf_out on all four rows, aux_out likewise (rows 1..3 feed aux_gg);
         // HSPLIT threads share one (row, head) dot product so that all 256 threads work on a 64-row tile
-        constexpr int HSPLIT = (4 * ROWS <= THREADS) ? 2 : 1, KQ = kWidth / 4 / HSPLIT;
+        constexpr int HSPLIT = (4 * ROWS <= THREADS) ? 2 : 1, KQ = WID / 4 / HSPLIT;
         for (int idx = tid; idx < HSPLIT * 2 * ROWS; idx += THREADS) {
             int part = idx / (2 * ROWS), pr = idx - part * 2 * ROWS;
             int head = pr / ROWS, row = pr - head * ROWS;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
         // hand the trunk features to the colour kernel (value row, or all four rows in full mode)
         {
             // 16-byte chunks; the feature matrix has the element type (and the planes) of the activations, planes packed densely
-            constexpr int CE = 16 / sizeof(act_t), CPP = kWidth / CE, CPR = Ops::kPlanes * CPP;
+            constexpr int CE = 16 / sizeof(act_t), CPP = WID / CE, CPR = Ops::kPlanes * CPP;
             act_t *features = (act_t *)a.features;
             const int fr = a.feat_rows;
             for (int idx = tid; features && idx < P * fr * CPR; idx += THREADS) {
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
                 int p = r / fr, rr = r - p * fr;
                 if (p0 + p < a.n_points) {
                     f32x4v v = *(const f32x4v *)(act + (4 * p + rr) * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));
-                    *(f32x4v *)(features + ((size_t)(p0 + p) * fr + rr) * (Ops::kPlanes * kWidth) + CE * c4) = v;
+                    *(f32x4v *)(features + ((size_t)(p0 + p) * fr + rr) * (Ops::kPlanes * WID) + CE * c4) = v;
                 }
             }
         }
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
 // tiles on one 8-wave workgroup per CU (half the L2 -> VGPR weight stream per point) are SLOWER for the 16-bit policies (split
 // fp16 14.5 vs 12.4 ms, bf16 8.4 vs 8.4 ms per launch): with one workgroup per CU nothing covers its barriers and the y'
 // round trip, and two 128-point workgroups do not fit (bf16: 403 spilled registers at 128 accumulators + the y' sets).
-size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points) { return (size_t)n_layers * points * kWidth + (size_t)points * 128; }
+size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points, int width) { return (size_t)n_layers * points * width + (size_t)points * 128; }
 
 template <int KIND, bool LAST, int MT, int NT, class Ops>
 __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *yp, const float *wseed, int wave,
@@ -393,17 +394,19 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
 {
     typedef typename Ops::act_t act_t;
     typedef typename Ops::bfrag frag;
-    constexpr int NT = 8 / NW, THREADS = 64 * NW, ROWS = MT * 32, P = ROWS, LD = Ops::kLd;
-    constexpr int BPW = 2 * MT / NW;             // 32 x 32 blocks of the [P, 64] encoding gradient per wave
-    static_assert(BPW >= 1 && BPW * NW == 2 * MT, "the encoding gradient's blocks must divide over the waves");
+    constexpr int WID = Ops::kWid, NT = WID / 32 / NW, THREADS = 64 * NW, ROWS = MT * 32, P = ROWS, LD = Ops::kLd;
+    static_assert(NT >= 1 && NT * 32 * NW == WID, "engine width = NW waves x NT column tiles of 32");
+    // 32 x 32 blocks of the [P, 64] encoding gradient per wave; a 32-point tile has two blocks for four waves: the upper waves idle there
+    constexpr int NBLK = 2 * MT, BPW = NBLK >= NW ? NBLK / NW : 1;
+    static_assert(BPW * NW == NBLK || NBLK < NW, "the encoding gradient's blocks must divide over the waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     act_t *act = (act_t *)smem;
     float *hd = (float *)(act + ROWS * LD);  // [2 k-halves][2 heads][ROWS] head dot products
     float *lp = hd + 6 * ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
-    float *yp = a.rev_scratch + (size_t)blockIdx.x * ((size_t)a.n_layers * P * kWidth + (size_t)P * 128);
-    float *pj = yp + (size_t)a.n_layers * ROWS * kWidth;        // [ROWS][64] dPE/dx factors: [q] sine half, [32 + q] cosine half
+    float *yp = a.rev_scratch + (size_t)blockIdx.x * ((size_t)a.n_layers * P * WID + (size_t)P * 128);
+    float *pj = yp + (size_t)a.n_layers * ROWS * WID;           // [ROWS][64] dPE/dx factors: [q] sine half, [32 + q] cosine half
     float *pv = pj + ROWS * 64;                                  // [ROWS][64] the encoding itself, for the skip layer
     if (tid == 0) {
 #pragma unroll
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             }
             if (l + 1 < a.n_layers) layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
             __syncthreads();
-            if (l + 1 < a.n_layers) rev_forward_epilogue_rt<false, MT, NT, Ops>(acc, act, ynone ? nullptr : yp + (size_t)(l * ylstep) * ROWS * kWidth, nullptr, a.activation, wave, lane, ymask);
+            if (l + 1 < a.n_layers) rev_forward_epilogue_rt<false, MT, NT, Ops>(acc, act, ynone ? nullptr : yp + (size_t)(l * ylstep) * ROWS * WID, nullptr, a.activation, wave, lane, ymask);
             else rev_forward_epilogue_rt<true, MT, NT, Ops>(acc, act, nullptr, a.w_ddf_out, a.activation, wave, lane);
             __syncthreads();
         }
@@ -483,11 +486,11 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
         // Jacobian is not an eval output), and the feature hand-off to the colour kernel
         for (int item = tid; item < 4 * ROWS; item += THREADS) {       // 2 k-halves x 2 heads x ROWS rows
             const int part = item / (2 * ROWS), head = (item / ROWS) & 1, row = item % ROWS;
-            const f32x4v *w = (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out) + part * 32;
-            const act_t *ar = act + row * LD + part * 128;
+            const f32x4v *w = (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out) + part * (WID / 8);
+            const act_t *ar = act + row * LD + part * (WID / 2);
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
-            for (int k = 0; k < 32; ++k) {
+            for (int k = 0; k < WID / 8; ++k) {
                 float x[4];
                 Ops::load4(ar + 4 * k, x);
                 f32x4v ww = w[k];
@@ -497,13 +500,13 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             hd[item] = (s0 + s1) + (s2 + s3);
         }
         {
-            constexpr int CE = 16 / sizeof(act_t), CPP = kWidth / CE, CPR = Ops::kPlanes * CPP;
+            constexpr int CE = 16 / sizeof(act_t), CPP = WID / CE, CPR = Ops::kPlanes * CPP;
             act_t *features = (act_t *)a.features;
             for (int idx = tid; features && idx < P * CPR; idx += THREADS) {
                 const int p = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
                 if (p0 + p < a.n_points) {
                     f32x4v v = *(const f32x4v *)(act + p * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));
-                    *(f32x4v *)(features + (size_t)(p0 + p) * (Ops::kPlanes * kWidth) + CE * c4) = v;
+                    *(f32x4v *)(features + (size_t)(p0 + p) * (Ops::kPlanes * WID) + CE * c4) = v;
                 }
             }
         }
@@ -521,26 +524,35 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
         // the [P, 64] encoding gradient in 32 x 32 blocks, BPW per wave: block b = wave * BPW + i is M-tile b >> 1, N-tile b & 1.  The
         // skip layer's share waits in the scratch, not in registers, while the remaining layers run (the product loop needs them)
         f32x4v *gpe_park = (f32x4v *)pv + (size_t)wave * BPW * 4 * 64 + lane;        // the encoding copy in pv is no longer needed here
+        bool parked = false;
         for (int l = a.n_layers - 1; l >= 1; --l) {
-            if (l == a.skip_layer) {    // cat([encoding, h]): the encoding rows of W_l take their share of g_l
+            if (a.layer[l].stash >= 0) {    // cat([encoding, h]): the encoding rows of W_l take their share of g_l (every skip layer adds its own)
 #pragma unroll
                 for (int i = 0; i < BPW; ++i) {
                     const int b = wave * BPW + i;
+                    if (NBLK < NW && b >= NBLK) break;
                     f32x16 gs[1][1];
-                    acc_init<1, 1, false>(gs, nullptr, wave, lane);
-                    dense<1, 1, Ops>(gs, act_lane + (b >> 1) * 32 * LD, (const frag *)a.wT_pe_skip + (size_t)(b & 1) * KS * 64 + lane, KS);
+                    if (parked) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4v v = gpe_park[(i * 4 + g) * 64];
+                            gs[0][0][4 * g] = v[0]; gs[0][0][4 * g + 1] = v[1]; gs[0][0][4 * g + 2] = v[2]; gs[0][0][4 * g + 3] = v[3];
+                        }
+                    } else acc_init<1, 1, false>(gs, nullptr, wave, lane);
+                    dense<1, 1, Ops>(gs, act_lane + (b >> 1) * 32 * LD, (const frag *)a.wT_pe_skip[a.layer[l].stash] + (size_t)(b & 1) * KS * 64 + lane, KS);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4v v = { gs[0][0][4 * g], gs[0][0][4 * g + 1], gs[0][0][4 * g + 2], gs[0][0][4 * g + 3] };
                         gpe_park[(i * 4 + g) * 64] = v;
                     }
                 }
+                parked = true;
             }
             // y'_{l-1} of this lane's accumulator positions comes back M-tile by M-tile through two register sets: the first two
             // are requested after the product (requesting them before it -- 64 more live registers -- measured no faster: the
             // CU's other waves cover the latency), the others while the previous M-tile is multiplied and stored
             f32x16 yb[2][NT];
-            const f32x4v *ysrc = (const f32x4v *)(yp + (size_t)((l - 1) * ylstep) * ROWS * kWidth) + (size_t)wave * (MT * NT * (Ops::kStash16 ? 2 : 4)) * 64 + lane;
+            const f32x4v *ysrc = (const f32x4v *)(yp + (size_t)((l - 1) * ylstep) * ROWS * WID) + (size_t)wave * (MT * NT * (Ops::kStash16 ? 2 : 4)) * 64 + lane;
             auto load_y = [&](f32x16 (&dst)[NT], int mt) {
                 mt &= ymask;
                 if (ynone) {
@@ -584,8 +596,9 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
             const int b = wave * BPW + i;
+            if (NBLK < NW && b >= NBLK) break;
             f32x16 one[1][1];
-            if (a.skip_layer >= 1) {
+            if (parked) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4v v = gpe_park[(i * 4 + g) * 64];
@@ -599,6 +612,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
             const int b = wave * BPW + i;
+            if (NBLK < NW && b >= NBLK) break;
             act_t *o = act + ((b >> 1) * 32 + 4 * h) * LD + (b & 1) * 32 + j;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -671,7 +685,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
 {
     typedef typename Ops::act_t act_t;
     typedef typename Ops::bfrag frag;            // weight fragments
-    constexpr int NT = 8 / NW, THREADS = 64 * NW;        // geometry: see ddf_trunk_kernel
+    constexpr int WID = Ops::kWid, NT = WID / 32 / NW, THREADS = 64 * NW;        // geometry: see ddf_trunk_kernel
     constexpr int ROWS = MT * 32, P = ROWS4 ? MT * 8 : ROWS, RPP = ROWS4 ? 4 : 1, LD = Ops::kLd;
     constexpr int REG_BUDGET = 512 / (WPS * NW / 4);
     constexpr int OPREGS = 2 * (MT * (int)sizeof(typename Ops::afrag) / 4 + NT * (int)sizeof(typename Ops::bfrag) / 4);
@@ -719,7 +733,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
         f32x16 acc[MT][NT];
         // layer 0, feature segment: in the eval-minimal 64-row tile the trunk features are requested now
         // (global -> VGPR) and land in LDS after the small-input dense; the other variants lack the registers
-        constexpr int CE = 16 / sizeof(act_t), CPP = kWidth / CE, CPR = Ops::kPlanes * CPP;     // 16-byte chunks per feature row
+        constexpr int CE = 16 / sizeof(act_t), CPP = WID / CE, CPR = Ops::kPlanes * CPP;     // 16-byte chunks per feature row
         constexpr int NF = ROWS * CPR / THREADS;
         auto lds_chunk = [&](int idx) {     // chunk idx of the tile -> its place in LDS (planes are kPlane elements apart)
             const int r = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
@@ -734,7 +748,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
             int64_t last = a.n_points * RPP - 1;
             if (grow > last) grow = last;
             int64_t src = ROWS4 ? grow : grow * a.feat_rows;      // value row of [n][feat_rows][256]
-            return (const f32x4v *)((const act_t *)a.features + (size_t)src * (Ops::kPlanes * kWidth) + CE * c4);
+            return (const f32x4v *)((const act_t *)a.features + (size_t)src * (Ops::kPlanes * WID) + CE * c4);
         };
         if constexpr (FPRE) {
 #pragma unroll
@@ -770,11 +784,11 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
         // layer_col_out 256 -> 3 (neddf.py:257), no output activation; two k-halves per row
         for (int idx = tid; idx < 2 * ROWS; idx += THREADS) {
             int half = idx / ROWS, row = idx - half * ROWS;
-            const act_t *ar = act + row * LD + half * 128;
-            const float *w = a.w_out + half * 128 * 3;
+            const act_t *ar = act + row * LD + half * (WID / 2);
+            const float *w = a.w_out + half * (WID / 2) * 3;
             float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll 4
-            for (int k = 0; k < 32; ++k) {
+            for (int k = 0; k < WID / 8; ++k) {
                 float x[4];
                 Ops::load4(ar + 4 * k, x);
 #pragma unroll
@@ -842,14 +856,15 @@ __global__ __launch_bounds__(kThreads, WPS) void nerf_kernel(const NerfArgs a)
 {
     typedef typename Ops::act_t act_t;
     typedef typename Ops::bfrag frag;            // weight fragments
-    constexpr int NT = 2, ROWS = MT * 32, P = ROWS, LD = Ops::kLd;
+    // NTC: column tiles per wave of the colour head's hidden layer (layer_width / 2 outputs, padded to a multiple of 128)
+    constexpr int WID = Ops::kWid, NT = WID / 128, NTC = (WID / 2 + 127) / 128, HC = NTC * 128, ROWS = MT * 32, P = ROWS, LD = Ops::kLd;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     act_t *act = (act_t *)smem;
     float *hd = (float *)(act + ROWS * LD);  // [2][ROWS][3]
     float *lp = hd + 2 * ROWS * 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
-    float *scratch = a.scratch + (size_t)blockIdx.x * kStashFloatsPerWg * kMaxStash;
+    float *scratch = a.scratch + (size_t)blockIdx.x * kStashFloatsPerWg * (a.n_stash > 1 ? a.n_stash : 1);
     if (tid == 0) {
 #pragma unroll
         for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
@@ -871,22 +886,22 @@ __global__ __launch_bounds__(kThreads, WPS) void nerf_kernel(const NerfArgs a)
         // otherwise they are parked in the per-workgroup global scratch (3 KB of HBM traffic per point).
         constexpr bool REG_STASH = (MT == 2) && (WPS <= 2);
         const bool in_regs = REG_STASH && a.n_stash == 2;
-        f32x16 held[REG_STASH ? MT : 1][REG_STASH ? NT : 1], held1[REG_STASH ? MT : 1][1];
+        f32x16 held[REG_STASH ? MT : 1][REG_STASH ? NT : 1], held1[REG_STASH ? MT : 1][REG_STASH ? NTC : 1];
         for (int s = 0; s < a.n_stash; ++s) {
             const frag *wl = (const frag *)a.stash[s].wp;
             float *slot = scratch + (size_t)s * kStashFloatsPerWg;
-            if (s == a.col_stash) {         // colour head's view-direction segment: 128 outputs, NT = 1
+            if (s == a.col_stash) {         // colour head's view-direction segment: layer_width / 2 outputs (NTC tiles per wave)
                 if constexpr (REG_STASH) {
                     if (in_regs) {
-                        acc_init<MT, 1, false>(held1, nullptr, wave, lane);
-                        dense<MT, 1, Ops>(held1, act_lane + a.stash[s].col0, wl + (size_t)wave * a.stash[s].ksteps * 64 + lane, a.stash[s].ksteps);
+                        acc_init<MT, NTC, false>(held1, nullptr, wave, lane);
+                        dense<MT, NTC, Ops>(held1, act_lane + a.stash[s].col0, wl + (size_t)wave * NTC * a.stash[s].ksteps * 64 + lane, a.stash[s].ksteps);
                         continue;
                     }
                 }
-                f32x16 acc1[MT][1];
-                acc_init<MT, 1, false>(acc1, nullptr, wave, lane);
-                dense<MT, 1, Ops>(acc1, act_lane + a.stash[s].col0, wl + (size_t)wave * a.stash[s].ksteps * 64 + lane, a.stash[s].ksteps);
-                stash_store<MT, 1>(acc1, slot, wave, lane);
+                f32x16 acc1[MT][NTC];
+                acc_init<MT, NTC, false>(acc1, nullptr, wave, lane);
+                dense<MT, NTC, Ops>(acc1, act_lane + a.stash[s].col0, wl + (size_t)wave * NTC * a.stash[s].ksteps * 64 + lane, a.stash[s].ksteps);
+                stash_store<MT, NTC>(acc1, slot, wave, lane);
             } else {                        // skip layers: cat([hx, embed_pos]) (nerf.py:154-155)
                 if constexpr (REG_STASH) {
                     if (in_regs) {
@@ -927,7 +942,7 @@ __global__ __launch_bounds__(kThreads, WPS) void nerf_kernel(const NerfArgs a)
             const f32x4v *w = (const f32x4v *)a.w_density;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
-            for (int k = 0; k < kWidth / 4; ++k) {
+            for (int k = 0; k < WID / 4; ++k) {
                 float x[4];
                 Ops::load4(ar + 4 * k, x);
                 f32x4v ww = w[k];
@@ -939,34 +954,36 @@ __global__ __launch_bounds__(kThreads, WPS) void nerf_kernel(const NerfArgs a)
         }
         // colour head: Linear(256+dir, 128) -> ReLU -> Linear(128, 3) (nerf.py:99-103,158-159)
         {
-            f32x16 acc1[MT][1];
-            acc_init<MT, 1, false>(acc1, a.col0.bias, wave, lane, Ops::kWScale);
+            f32x16 acc1[MT][NTC];
+            acc_init<MT, NTC, false>(acc1, a.col0.bias, wave, lane, Ops::kWScale);
             bool done = false;
             if constexpr (REG_STASH) {
                 if (in_regs) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc1[mt][0] += held1[mt][0];
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int t = 0; t < NTC; ++t) acc1[mt][t] += held1[mt][t];
                     done = true;
                 }
             }
-            if (!done) stash_add<MT, 1>(acc1, scratch + (size_t)a.col_stash * kStashFloatsPerWg, wave, lane);
-            dense<MT, 1, Ops>(acc1, act_lane, (const frag *)a.col0.wp + (size_t)wave * a.col0.ksteps * 64 + lane, a.col0.ksteps);
+            if (!done) stash_add<MT, NTC>(acc1, scratch + (size_t)a.col_stash * kStashFloatsPerWg, wave, lane);
+            dense<MT, NTC, Ops>(acc1, act_lane, (const frag *)a.col0.wp + (size_t)wave * NTC * a.col0.ksteps * 64 + lane, a.col0.ksteps);
             __syncthreads();
-            epilogue<MT, 1, false, 0, Ops>(acc1, act, wave, lane);
+            epilogue<MT, NTC, false, 0, Ops>(acc1, act, wave, lane);
             __syncthreads();
         }
         for (int idx = tid; idx < 2 * ROWS; idx += kThreads) {
             int half = idx / ROWS, row = idx - half * ROWS;
-            const act_t *ar = act + row * LD + half * 64;
+            const act_t *ar = act + row * LD + half * (HC / 2);       // w_col1: [3][HC], zero beyond layer_width / 2
             float c[3] = { 0.f, 0.f, 0.f };
 #pragma unroll 4
-            for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < HC / 8; ++k) {
                 float x[4];
                 Ops::load4(ar + 4 * k, x);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int o = 0; o < 3; ++o) c[o] = fmaf(x[u], a.w_col1[o * 128 + half * 64 + 4 * k + u], c[o]);
+                    for (int o = 0; o < 3; ++o) c[o] = fmaf(x[u], a.w_col1[o * HC + half * (HC / 2) + 4 * k + u], c[o]);
             }
             hd[idx * 3 + 0] = c[0]; hd[idx * 3 + 1] = c[1]; hd[idx * 3 + 2] = c[2];
         }
@@ -1085,6 +1102,13 @@ static Geo geo(int operands)
     }
     return g[operands < 0 || operands > 2 ? 0 : operands];
 }
+// Engine widths other than 256 (hidden width padded to 128 / 384 / 512; the reference's constructors take any width,
+// neddf.py:52-66, nerf.py:34-44) have ONE shape per width under every operand policy: 64-row tiles at 128 columns, 32-row tiles
+// at 384 / 512 (the LDS tile and the accumulators grow with the width: 32 x 516 floats and 4 column tiles per wave at 512 are
+// the footprint of the 64 x 260 tile with 2 column tiles at 256) -- always two workgroups per CU, so that one workgroup's
+// barriers and epilogues are covered by the other's matrix work, as at width 256.
+static Geo geo_w(int width) { return width == 128 ? Geo{ 2, 2, 4 } : Geo{ 1, 2, 4 }; }
+static Geo geo(int operands, int width) { return width == 256 ? geo(operands) : geo_w(width); }
 // The colour trunk follows the distance trunk's shape except under bf16, where its value-row-only epilogue is light enough for
 // the eight-wave shape to pay (1.71 ms against 1.82 ms per 2^21-point launch; NEDDF_BF16_COL_GEO).
 static Geo geo_col(int operands)
@@ -1094,12 +1118,15 @@ static Geo geo_col(int operands)
     if (!g.mt) g = parse_geo("NEDDF_BF16_COL_GEO", Geo{ 4, 2, 8 }, { { 4, 2, 8 }, { 4, 1, 8 }, { 4, 2, 4 }, { 2, 2, 4 }, { 4, 1, 4 } });
     return g;
 }
-int field_wgs_per_cu(int operands) { return geo(operands).wps; }
-int col_wgs_per_cu(int operands) { return geo_col(operands).wps; }
-int ddf_points_per_tile(int operands) { return geo(operands).mt * 8; }
-int col_points_per_tile(bool rows4, int operands) { return rows4 ? geo_col(operands).mt * 8 : geo_col(operands).mt * 32; }
-int nerf_points_per_tile() { return tile_mt() * 32; }
-int nerf_wgs_per_cu() { return tile_mt() == 2 ? 2 : 1; }
+static Geo geo_col(int operands, int width) { return width == 256 ? geo_col(operands) : geo_w(width); }
+static Geo geo_nerf(int width) { return width == 256 ? (tile_mt() == 2 ? Geo{ 2, 2, 4 } : Geo{ 4, 1, 4 }) : geo_w(width); }
+int field_wgs_per_cu(int operands, int width) { return geo(operands, width).wps; }
+int col_wgs_per_cu(int operands, int width) { return geo_col(operands, width).wps; }
+int ddf_points_per_tile(int operands, int width) { return geo(operands, width).mt * 8; }
+int col_points_per_tile(bool rows4, int operands, int width) { return rows4 ? geo_col(operands, width).mt * 8 : geo_col(operands, width).mt * 32; }
+int nerf_points_per_tile(int width) { return geo_nerf(width).mt * 32; }
+int nerf_wgs_per_cu(int width) { return geo_nerf(width).wps; }
+bool ddf_rev_available() { return tile_mt() == 2; }      // NEDDF_TILE_MT=4 (one 128-row workgroup per CU) keeps the forward-mode kernels
 
 static void set_lds(const void *fn, size_t bytes)
 {
@@ -1126,8 +1153,21 @@ static void launch_col_g(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 
 #define NEDDF_GEO_CASE(MT_, WPS_, NW_) if (g.mt == MT_ && g.wps == WPS_ && g.nw == NW_)
 
+// one shape per non-256 engine width (geo_w), every operand policy
+template <int WID>
+static void launch_ddf_w(const DdfArgs &a, int grid, hipStream_t s)
+{
+    constexpr int MT = WID == 128 ? 2 : 1;
+    if (a.operands == 2) launch_ddf_g<MT, 2, 4, OpsF16SplitT<WID>>(a, grid, s);
+    else if (a.operands == 1) launch_ddf_g<MT, 2, 4, OpsBF16T<WID>>(a, grid, s);
+    else launch_ddf_g<MT, 2, 4, OpsF32T<WID>>(a, grid, s);
+}
+
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
 {
+    if (a.width == 128) return launch_ddf_w<128>(a, grid, s);
+    if (a.width == 384) return launch_ddf_w<384>(a, grid, s);
+    if (a.width == 512) return launch_ddf_w<512>(a, grid, s);
     const Geo g = geo(a.operands);
     if (a.operands == 2) {
         NEDDF_GEO_CASE(4, 1, 8) return launch_ddf_g<4, 1, 8, OpsF16Split>(a, grid, s);
@@ -1154,18 +1194,42 @@ static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s)
     hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a);
 }
 
-int ddf_rev_points(int) { return 64; }
-int ddf_rev_wgs_per_cu(int) { return 2; }
+int ddf_rev_points(int, int width) { return width == 256 ? 64 : geo_w(width).mt * 32; }
+int ddf_rev_wgs_per_cu(int, int) { return 2; }
+
+template <int WID>
+static void launch_ddf_rev_w(const DdfArgs &a, int grid, hipStream_t s)
+{
+    constexpr int MT = WID == 128 ? 2 : 1;
+    if (a.operands == 2) launch_ddf_rev_t<MT, 4, 2, OpsF16SplitT<WID>>(a, grid, s);
+    else if (a.operands == 1) launch_ddf_rev_t<MT, 4, 2, OpsBF16T<WID>>(a, grid, s);
+    else launch_ddf_rev_t<MT, 4, 2, OpsF32T<WID>>(a, grid, s);
+}
 
 void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s)
 {
+    if (a.width == 128) return launch_ddf_rev_w<128>(a, grid, s);
+    if (a.width == 384) return launch_ddf_rev_w<384>(a, grid, s);
+    if (a.width == 512) return launch_ddf_rev_w<512>(a, grid, s);
     if (a.operands == 2) launch_ddf_rev_t<2, 4, 2, OpsF16Split>(a, grid, s);
     else if (a.operands == 1) launch_ddf_rev_t<2, 4, 2, OpsBF16>(a, grid, s);
     else launch_ddf_rev_t<2, 4, 2, OpsF32>(a, grid, s);
 }
 
+template <int WID>
+static void launch_col_w(const ColArgs &a, int grid, bool rows4, hipStream_t s)
+{
+    constexpr int MT = WID == 128 ? 2 : 1;
+    if (a.operands == 2) launch_col_g<MT, 2, 4, OpsF16SplitT<WID>>(a, grid, rows4, s);
+    else if (a.operands == 1) launch_col_g<MT, 2, 4, OpsBF16T<WID>>(a, grid, rows4, s);
+    else launch_col_g<MT, 2, 4, OpsF32T<WID>>(a, grid, rows4, s);
+}
+
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 {
+    if (a.width == 128) return launch_col_w<128>(a, grid, rows4, s);
+    if (a.width == 384) return launch_col_w<384>(a, grid, rows4, s);
+    if (a.width == 512) return launch_col_w<512>(a, grid, rows4, s);
     const Geo g = geo_col(a.operands);
     if (a.operands == 2) {
         NEDDF_GEO_CASE(4, 1, 8) return launch_col_g<4, 1, 8, OpsF16Split>(a, grid, rows4, s);
@@ -1183,18 +1247,35 @@ void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)
     return launch_col_g<4, 1, 4, OpsF32>(a, grid, rows4, s);
 }
 
+template <int MT, int WPS, class Ops>
+static void launch_nerf_g(const NerfArgs &a, int grid, hipStream_t s)
+{
+    static bool once = (set_lds((const void *)nerf_kernel<MT, WPS, Ops>, lds_bytes<Ops>(MT)), true);
+    (void)once;
+    hipLaunchKernelGGL((nerf_kernel<MT, WPS, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(MT), s, a);
+}
+
 template <class Ops>
 static void launch_nerf_t(const NerfArgs &a, int grid, hipStream_t s)
 {
-    static bool once = (set_lds((const void *)nerf_kernel<4, 1, Ops>, lds_bytes<Ops>(4)),
-                        set_lds((const void *)nerf_kernel<2, 2, Ops>, lds_bytes<Ops>(2)), true);
-    (void)once;
-    if (tile_mt() == 2) hipLaunchKernelGGL((nerf_kernel<2, 2, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(2), s, a);
-    else hipLaunchKernelGGL((nerf_kernel<4, 1, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(4), s, a);
+    if (tile_mt() == 2) launch_nerf_g<2, 2, Ops>(a, grid, s);
+    else launch_nerf_g<4, 1, Ops>(a, grid, s);
+}
+
+template <int WID>
+static void launch_nerf_w(const NerfArgs &a, int grid, hipStream_t s)
+{
+    constexpr int MT = WID == 128 ? 2 : 1;
+    if (a.operands == 2) launch_nerf_g<MT, 2, OpsF16SplitT<WID>>(a, grid, s);
+    else if (a.operands == 1) launch_nerf_g<MT, 2, OpsBF16T<WID>>(a, grid, s);
+    else launch_nerf_g<MT, 2, OpsF32T<WID>>(a, grid, s);
 }
 
 void launch_nerf(const NerfArgs &a, int grid, hipStream_t s)
 {
+    if (a.width == 128) return launch_nerf_w<128>(a, grid, s);
+    if (a.width == 384) return launch_nerf_w<384>(a, grid, s);
+    if (a.width == 512) return launch_nerf_w<512>(a, grid, s);
     if (a.operands == 2) launch_nerf_t<OpsF16Split>(a, grid, s);
     else if (a.operands) launch_nerf_t<OpsBF16>(a, grid, s);
     else launch_nerf_t<OpsF32>(a, grid, s);

@@ -9,9 +9,10 @@ namespace neddf {
 constexpr int kWaves = 4;            // waves per workgroup (one per SIMD)
 constexpr int kThreads = 64 * kWaves;
 constexpr int kActLd = 260;          // LDS row stride (floats): 256 + 4 -> conflict-free ds_read_b128 of MFMA A fragments
-constexpr int kWidth = 256;          // hidden width handled by the tile engine
+constexpr int kWidth = 256;          // engine width of the shipped configurations (and of the training kernels); other hidden widths run on 128 / 384 / 512
+constexpr int kMaxWidth = 512;
 constexpr int kMaxLayers = 12;
-constexpr int kMaxStash = 2;
+constexpr int kMaxStash = 4;         // early partials per field: skip connections (+ the NeRF colour head's direction segment)
 constexpr int kSchedInts = 16;          // tile-queue head (+ padding)
 constexpr int kPtAux = 16;           // floats per point handed from the distance kernel to the colour kernel
 // floats of one stash slot of one workgroup: 4 waves x (MT=4 x NT=2 x 4 float4) x 64 lanes x 4
@@ -55,7 +56,8 @@ struct DdfArgs {
     LayerW layer[kMaxLayers];
     int n_stash;
     StashW stash[kMaxStash];
-    const float *w_ddf_out, *w_aux_out;   // [256] each
+    int width;                            // engine width: hidden width padded to 128 / 256 / 384 / 512 (padding = zero weights: exact)
+    const float *w_ddf_out, *w_aux_out;   // [width] each
     float b_ddf_out, b_aux_out;
     float d_near, aux_grad_scale;
     int operands;                         // 0 fp32 (32x32x2 f32 MFMA), 1 bf16, 2 split fp16 (three fp16 products per multiply-add), see tile_engine.h
@@ -63,14 +65,15 @@ struct DdfArgs {
     float neus_v10;                       // variance * 10
     float *scratch;                       // per-workgroup stash area
     // reverse-mode distance gradient (ddf_rev_kernel, eval-minimal): transposed weights and a per-workgroup scratch
-    const float *wT[kMaxLayers];          // [l >= 1] packed (hidden rows of W_l)^T, 256 x 256
-    const float *wT_pe0, *wT_pe_skip;     // packed [256 x 64]: W_0^T and the skip layer's encoding rows^T (engine column order)
-    int skip_layer;                       // trunk layer whose input is cat([encoding, h]), or -1
-    int ks_hidden;                        // super-steps of a 256-wide product under this operand policy
+    const float *wT[kMaxLayers];          // [l >= 1] packed (hidden rows of W_l)^T, width x width
+    const float *wT_pe0;                  // packed [width x 64]: W_0^T (engine column order of the encoding)
+    const float *wT_pe_skip[kMaxStash];   // ... and the encoding rows^T of the skip layer that owns stash[s]
+    int skip_layer;                       // a trunk layer whose input is cat([encoding, h]) (the last one), or -1
+    int ks_hidden;                        // super-steps of a width-wide product under this operand policy
     float *rev_scratch;                   // per workgroup: y' of every layer [n_layers][P][256] + encoding Jacobian and copy [P][128]
     int *sched;                           // [0] tile queue head (zeroed before each launch)
     int sched_flags;                      // bit 1: dynamic tile queue; higher bits: timing ablations, -DNEDDF_ABLATE builds only
-    float *features;                      // [n_points][feat_rows][256]
+    float *features;                      // [n_points][feat_rows][width]
     int feat_rows;                        // 1 (value row) or 4 (value + Jacobian rows)
     float *ptaux;                         // [n_points][kPtAux]
     float *distance, *density, *aux_grad; // optional outputs [n_points]
@@ -86,10 +89,11 @@ struct ColArgs {
     int mode;                             // 0 NeDDF inputs [embed_pos | embed_dir | normal], 1 NeuS inputs [pos | gradient | embed_dir]
     int final_act;                        // activation id applied to the 3 outputs (NeuS, neus.py:150-152) or -1
     int operands;                         // as DdfArgs::operands
+    int width;                            // as DdfArgs::width
     int ksteps_a;                         // super-steps of layer 0's small-input segment [pe_pos | pe_dir | normal]
     const float *wp_a;                    // its packed weights
     LayerW layer[kMaxLayers];             // layer[0] = feature segment of layer 0
-    const float *w_out;                   // [256][3] row-major (layer_col_out.weight)
+    const float *w_out;                   // [width][3] row-major (layer_col_out.weight)
     float b_out[3];
     const float *features;                // from DdfArgs
     int feat_rows;
@@ -114,12 +118,13 @@ struct NerfArgs {
     int n_stash;
     StashW stash[kMaxStash];              // [0..] skip partials, last = colour-head dir partial
     int col_stash;                        // stash index of the colour head's dir segment
-    const float *w_density;               // [256]
+    const float *w_density;               // [width]
     float b_density;
-    LayerW col0;                          // outL_color.0: 256(+dir) -> 128
-    const float *w_col1;                  // [3][128] (nn.Linear layout)
+    LayerW col0;                          // outL_color.0: layer_width (+dir) -> layer_width / 2, padded to HC = a multiple of 128 columns
+    const float *w_col1;                  // [3][HC] (nn.Linear layout, zero-padded)
     float b_col1[3];
     int operands;                         // as DdfArgs::operands
+    int width;                            // as DdfArgs::width
     float *scratch;
     float *density, *color;
 };
@@ -131,17 +136,18 @@ struct CameraArg {
 size_t field_lds_bytes(int mt);
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s);
 void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s);
-size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points);
-int ddf_rev_points(int operands);        // sample points per tile of ddf_rev_kernel under an operand policy
-int ddf_rev_wgs_per_cu(int operands);
+size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points, int width);
+int ddf_rev_points(int operands, int width);        // sample points per tile of ddf_rev_kernel under an operand policy / engine width
+int ddf_rev_wgs_per_cu(int operands, int width);
+bool ddf_rev_available();
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s);
 void launch_nerf(const NerfArgs &a, int grid, hipStream_t s);
-int ddf_points_per_tile(int operands = 0);
-int col_points_per_tile(bool rows4, int operands = 0);
-int nerf_points_per_tile();
-int nerf_wgs_per_cu();
-int field_wgs_per_cu(int operands = 0);
-int col_wgs_per_cu(int operands = 0);
+int ddf_points_per_tile(int operands, int width);
+int col_points_per_tile(bool rows4, int operands, int width);
+int nerf_points_per_tile(int width);
+int nerf_wgs_per_cu(int width);
+int field_wgs_per_cu(int operands, int width);
+int col_wgs_per_cu(int operands, int width);
 
 void launch_raygen(const void *uv, int uv_type, int64_t n, const CameraArg &cam, float *dir, float *orig, hipStream_t s);
 void launch_sample_coarse(const float *U, int64_t n, int S1, float near_, float far_, float *dists, hipStream_t s);

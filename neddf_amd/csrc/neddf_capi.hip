@@ -123,13 +123,25 @@ static size_t pack_layer(std::vector<float> &blob, const Src &src, std::vector<i
     return off;
 }
 
-static size_t put(std::vector<float> &blob, const float *p, size_t n)
+static size_t put(std::vector<float> &blob, const float *p, size_t n, size_t n_padded = 0)      // zero-padded to n_padded elements
 {
     size_t off = roundup((int)blob.size(), 64);
-    blob.resize(off + n);
+    blob.resize(off + (n_padded > n ? n_padded : n), 0.f);
     memcpy(blob.data() + off, p, n * sizeof(float));
     return off;
 }
+
+// engine columns of a hidden state of `width` features (zero-padded to the engine width wp) -> reference weight row base + k
+static std::vector<int> hidden_map(int width, int wp, int base)
+{
+    std::vector<int> m;
+    for (int k = 0; k < wp; ++k) m.push_back(k < width ? base + k : -1);
+    return m;
+}
+
+// engine width of a hidden width: the next multiple of 128 (four waves x 32-column MFMA tiles).  The padding columns carry zero
+// weights and biases, so they hold a(0) = 0 under every activation of the reference and feed zero rows downstream: exact
+static int engine_width(int width) { return roundup(width, 128); }
 
 // engine columns of the [sin half | cos half] encoding -> reference feature index base+...
 static void enc_map(std::vector<int> &m, int rank, int K, int base)
@@ -146,6 +158,10 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n_trunk = d.layer_count - 1, n_col = d.col_layer_count - 1;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
     const int operands = d.weight_dtype;      // 0 fp32, 1 bf16, 2 split fp16
+    const int Wd = d.layer_width, WP = engine_width(Wd);      // hidden width of the reference network / of the tile engine
+    if (d.col_layer_width != Wd)
+        return fail(ctx, NEDDF_EUNSUPPORTED, "NeDDF: col_layer_width must equal ddf_layer_width (the reference's layer_col_out takes ddf_layer_width inputs, "
+                                             "neddf.py:145: its own forward fails otherwise)");
     if (n_tensors != n_trunk + n_col + 3) return fail(ctx, NEDDF_EINVAL, "NeDDF: wrong tensor count");
     if (n_trunk < 1 || n_trunk > kMaxLayers || n_col < 1 || n_col > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeDDF: layer count out of range");
     for (int i = 0; i < d.n_skips; ++i)
@@ -161,52 +177,49 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     a.n_layers = n_trunk; a.n_stash = 0;
     for (int l = 0; l < n_trunk; ++l) {
         bool wide = l > 0 && in_skips(d, l - 1);
-        int cin = l == 0 ? Cpe : (wide ? kWidth + Cpe : kWidth);
-        Src src{ W[l], cin, kWidth, false };
+        int cin = l == 0 ? Cpe : (wide ? Wd + Cpe : Wd);
+        Src src{ W[l], cin, Wd, false };
         std::vector<int> km;
         a.layer[l].stash = -1;
         if (l == 0) km = pe;
-        else for (int k = 0; k < kWidth; ++k) km.push_back(wide ? Cpe + k : k);
-        o_wp[l] = pack_layer(blob, src, km, kWidth, operands, &a.layer[l].ksteps);
+        else km = hidden_map(Wd, WP, wide ? Cpe : 0);
+        o_wp[l] = pack_layer(blob, src, km, WP, operands, &a.layer[l].ksteps);
         if (wide) {
-            if (a.n_stash >= kMaxStash) return fail(ctx, NEDDF_EUNSUPPORTED, "NeDDF: too many skip connections");
-            o_st.push_back(pack_layer(blob, src, pe, kWidth, operands, &a.stash[a.n_stash].ksteps));
+            if (a.n_stash >= kMaxStash) return fail(ctx, NEDDF_EUNSUPPORTED, "NeDDF: more than 4 skip connections");
+            o_st.push_back(pack_layer(blob, src, pe, WP, operands, &a.stash[a.n_stash].ksteps));
             a.stash[a.n_stash].col0 = 0;
             a.layer[l].stash = a.n_stash++;
         }
-        o_b[l] = put(blob, B[l], kWidth);
+        o_b[l] = put(blob, B[l], Wd, WP);
     }
     const int i_ddf = n_trunk + n_col, i_aux = i_ddf + 1, i_cout = i_ddf + 2;
-    size_t o_wddf = put(blob, W[i_ddf], kWidth), o_waux = put(blob, W[i_aux], kWidth);
+    size_t o_wddf = put(blob, W[i_ddf], Wd, WP), o_waux = put(blob, W[i_aux], Wd, WP);
     a.b_ddf_out = B[i_ddf][0]; a.b_aux_out = B[i_aux][0];
     // Reverse-mode distance gradient (ddf_rev_kernel): the transposes.  dL/dH_{l-1} = g_l x (hidden rows of W_l)^T is a dense
     // product with B[k][n] = W_l[row0 + n][k]; the gradient of the encoding collects g_0 x W_0^T and g_skip x (encoding rows of
     // W_skip)^T, 64 engine columns wide (same [sin half | cos half] order as the forward encoding in LDS)
     std::vector<size_t> o_wT(n_trunk, 0);
-    size_t o_wT_pe0 = 0, o_wT_pes = 0;
+    size_t o_wT_pe0 = 0, o_wT_pes[kMaxStash] = { 0 };
     a.skip_layer = -1;
     {
-        std::vector<int> kall;
-        for (int k = 0; k < kWidth; ++k) kall.push_back(k);
-        struct TSrc { const float *w; int row0; };
-        for (int l = 1; l < n_trunk; ++l) {
-            const bool wide = in_skips(d, l - 1);
-            // logical B[k][n] = W_l[(wide ? Cpe : 0) + n][k], W_l row-major [in][256]  ==  Src "transposed" with rows = 256
-            Src st{ W[l] + (size_t)(wide ? Cpe : 0) * kWidth, kWidth, kWidth, true };
-            o_wT[l] = pack_layer(blob, st, kall, kWidth, operands, nullptr);
-            if (wide) a.skip_layer = l;
-        }
+        const std::vector<int> kall = hidden_map(Wd, WP, 0);
         // narrow transposes: column n of the engine's encoding layout is reference row pe[n] (or padding)
         auto pack_pe_T = [&](const float *Wl) {
-            std::vector<float> tmp((size_t)kWidth * 64, 0.f);       // [k][n] row-major, n < 64
+            std::vector<float> tmp((size_t)Wd * 64, 0.f);           // [k][n] row-major, n < 64
             for (int n = 0; n < (int)pe.size() && n < 64; ++n)
                 if (pe[n] >= 0)
-                    for (int k = 0; k < kWidth; ++k) tmp[(size_t)k * 64 + n] = Wl[(size_t)pe[n] * kWidth + k];
-            Src sn{ tmp.data(), kWidth, 64, false };
+                    for (int k = 0; k < Wd; ++k) tmp[(size_t)k * 64 + n] = Wl[(size_t)pe[n] * Wd + k];
+            Src sn{ tmp.data(), Wd, 64, false };
             return pack_layer(blob, sn, kall, 64, operands, nullptr);
         };
+        for (int l = 1; l < n_trunk; ++l) {
+            const bool wide = in_skips(d, l - 1);
+            // logical B[k][n] = W_l[(wide ? Cpe : 0) + n][k], W_l row-major [in][Wd]  ==  Src "transposed" with rows = Wd
+            Src st{ W[l] + (size_t)(wide ? Cpe : 0) * Wd, Wd, Wd, true };
+            o_wT[l] = pack_layer(blob, st, kall, WP, operands, nullptr);
+            if (wide) { a.skip_layer = l; o_wT_pes[a.layer[l].stash] = pack_pe_T(W[l]); }
+        }
         o_wT_pe0 = pack_pe_T(W[0]);
-        if (a.skip_layer >= 0) o_wT_pes = pack_pe_T(W[a.skip_layer]);
     }
     // colour trunk
     std::vector<int> ka;
@@ -214,18 +227,17 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     enc_map(ka, Ed, KD, Cpe);
     for (int k = 0; k < 3; ++k) ka.push_back(Cpe + Cdir + k);
     std::vector<size_t> c_wp(n_col), c_b(n_col);
-    Src s0{ W[n_trunk], Cpe + Cdir + 3 + kWidth, kWidth, false };
-    size_t o_wa = pack_layer(blob, s0, ka, kWidth, operands, &c.ksteps_a);
+    Src s0{ W[n_trunk], Cpe + Cdir + 3 + Wd, Wd, false };
+    size_t o_wa = pack_layer(blob, s0, ka, WP, operands, &c.ksteps_a);
     c.n_layers = n_col;
     for (int l = 0; l < n_col; ++l) {
-        std::vector<int> km;
-        for (int k = 0; k < kWidth; ++k) km.push_back(l == 0 ? Cpe + Cdir + 3 + k : k);
-        Src src{ W[n_trunk + l], l == 0 ? Cpe + Cdir + 3 + kWidth : kWidth, kWidth, false };
-        c_wp[l] = pack_layer(blob, src, km, kWidth, operands, &c.layer[l].ksteps);
+        const std::vector<int> km = hidden_map(Wd, WP, l == 0 ? Cpe + Cdir + 3 : 0);
+        Src src{ W[n_trunk + l], l == 0 ? Cpe + Cdir + 3 + Wd : Wd, Wd, false };
+        c_wp[l] = pack_layer(blob, src, km, WP, operands, &c.layer[l].ksteps);
         c.layer[l].stash = -1;
-        c_b[l] = put(blob, B[n_trunk + l], kWidth);
+        c_b[l] = put(blob, B[n_trunk + l], Wd, WP);
     }
-    size_t o_cout = put(blob, W[i_cout], kWidth * 3);
+    size_t o_cout = put(blob, W[i_cout], (size_t)Wd * 3, (size_t)WP * 3);
     for (int k = 0; k < 3; ++k) c.b_out[k] = B[i_cout][k];
 
     if (int rc = ensure(ctx, f.blob, blob.size() * sizeof(float))) return rc;
@@ -236,8 +248,9 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     a.w_ddf_out = base + o_wddf; a.w_aux_out = base + o_waux;
     for (int l = 1; l < n_trunk; ++l) a.wT[l] = base + o_wT[l];
     a.wT_pe0 = base + o_wT_pe0;
-    a.wT_pe_skip = a.skip_layer >= 0 ? base + o_wT_pes : nullptr;
-    a.ks_hidden = kWidth / (operands ? 16 : 8);
+    for (int st = 0; st < a.n_stash; ++st) a.wT_pe_skip[st] = base + o_wT_pes[st];
+    a.ks_hidden = WP / (operands ? 16 : 8);
+    a.width = c.width = WP;
     c.wp_a = base + o_wa;
     for (int l = 0; l < n_col; ++l) { c.layer[l].wp = base + c_wp[l]; c.layer[l].bias = base + c_b[l]; }
     c.w_out = base + o_cout;
@@ -258,6 +271,8 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n_sdf = d.layer_count, n_col = d.col_layer_count;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
     const int operands = d.weight_dtype;
+    // sdf and colour trunks may have different widths (neus.py:80-99); both run on one engine width, zero-padded
+    const int Ws = d.layer_width, Wc = d.col_layer_width, WP = engine_width(Ws > Wc ? Ws : Wc);
     if (n_tensors != n_sdf + n_col + 2) return fail(ctx, NEDDF_EINVAL, "NeuS: wrong tensor count");
     if (n_sdf < 1 || n_sdf > kMaxLayers || n_col < 1 || n_col > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: layer count out of range");
     if (d.activation == NEDDF_ACT_LEAKY) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: activation must be ReLU or tanhExp");
@@ -274,55 +289,60 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     a.n_layers = n_sdf; a.n_stash = 0;
     for (int l = 0; l < n_sdf; ++l) {
         bool wide = l > 0 && in_skips(d, l - 1);
-        int cin = l == 0 ? Cpe : (wide ? kWidth + Cpe : kWidth);
-        Src src{ W[l], cin, kWidth, true };
+        int cin = l == 0 ? Cpe : (wide ? Ws + Cpe : Ws);
+        Src src{ W[l], cin, Ws, true };
         std::vector<int> km;
         a.layer[l].stash = -1;
         if (l == 0) km = pe;
-        else for (int k = 0; k < kWidth; ++k) km.push_back(k);       // cat([hx, embed_pos]): hidden state first
-        o_wp[l] = pack_layer(blob, src, km, kWidth, operands, &a.layer[l].ksteps);
+        else km = hidden_map(Ws, WP, 0);                            // cat([hx, embed_pos]): hidden state first
+        o_wp[l] = pack_layer(blob, src, km, WP, operands, &a.layer[l].ksteps);
         if (wide) {
-            if (a.n_stash >= kMaxStash) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: too many skip connections");
+            if (a.n_stash >= kMaxStash) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: more than 4 skip connections");
             std::vector<int> ps;
-            enc_map(ps, E, KH, kWidth);
-            o_st.push_back(pack_layer(blob, src, ps, kWidth, operands, &a.stash[a.n_stash].ksteps));
+            enc_map(ps, E, KH, Ws);
+            o_st.push_back(pack_layer(blob, src, ps, WP, operands, &a.stash[a.n_stash].ksteps));
             a.stash[a.n_stash].col0 = 0;
             a.layer[l].stash = a.n_stash++;
         }
-        o_b[l] = put(blob, B[l], kWidth);
+        o_b[l] = put(blob, B[l], Ws, WP);
     }
     // Reverse-mode normal (ddf_rev_kernel): the sdf is feature 0 of the last activated layer, so the seed of the reverse pass is
     // e_0 * y'_L -- the "distance head" of the kernel becomes the unit vector e_0 with zero bias, the aux head is zero -- and the
     // transposes are read straight off nn.Linear's [out][in] storage: B[k][n] = W_l[k][n] for the hidden inputs n < 256 (hidden
     // state first in NeuS's concatenation), the encoding inputs through the engine's column map
     std::vector<size_t> o_wT(n_sdf, 0);
-    size_t o_wT_pe0 = 0, o_wT_pes = 0, o_e0 = 0, o_zero = 0;
+    size_t o_wT_pe0 = 0, o_wT_pes[kMaxStash] = { 0 }, o_e0 = 0, o_zero = 0;
     a.skip_layer = -1;
     {
-        std::vector<int> kall;
-        for (int k = 0; k < kWidth; ++k) kall.push_back(k);
-        for (int l = 1; l < n_sdf; ++l) {
-            const bool wide = in_skips(d, l - 1);
-            Src st{ W[l], kWidth, wide ? kWidth + Cpe : kWidth, false };
-            o_wT[l] = pack_layer(blob, st, kall, kWidth, operands, nullptr);
-            if (wide) a.skip_layer = l;
-        }
+        const std::vector<int> kall = hidden_map(Ws, WP, 0);
         auto pack_pe_T = [&](const float *Wl, int cin, int base) {
             std::vector<int> cols;
             enc_map(cols, E, KH, base);
-            std::vector<float> tmp((size_t)kWidth * 64, 0.f);       // [k][n] row-major, n < 64
+            std::vector<float> tmp((size_t)Ws * 64, 0.f);           // [k][n] row-major, n < 64
             for (int n = 0; n < (int)cols.size() && n < 64; ++n)
                 if (cols[n] >= 0)
-                    for (int k = 0; k < kWidth; ++k) tmp[(size_t)k * 64 + n] = Wl[(size_t)k * cin + cols[n]];
-            Src sn{ tmp.data(), kWidth, 64, false };
+                    for (int k = 0; k < Ws; ++k) tmp[(size_t)k * 64 + n] = Wl[(size_t)k * cin + cols[n]];
+            Src sn{ tmp.data(), Ws, 64, false };
             return pack_layer(blob, sn, kall, 64, operands, nullptr);
         };
+        for (int l = 1; l < n_sdf; ++l) {
+            const bool wide = in_skips(d, l - 1);
+            // logical B[k][n] = W_l[k][n] over nn.Linear's [out][in] storage, hidden inputs n < Ws only
+            Src st{ W[l], Ws, wide ? Ws + Cpe : Ws, false };
+            std::vector<float> sq;                                   // pack_layer reads n < src.cols: cut the encoding inputs off
+            if (wide) {
+                sq.assign((size_t)Ws * Ws, 0.f);
+                for (int k = 0; k < Ws; ++k) memcpy(&sq[(size_t)k * Ws], W[l] + (size_t)k * (Ws + Cpe), (size_t)Ws * sizeof(float));
+                st = Src{ sq.data(), Ws, Ws, false };
+            }
+            o_wT[l] = pack_layer(blob, st, kall, WP, operands, nullptr);
+            if (wide) { a.skip_layer = l; o_wT_pes[a.layer[l].stash] = pack_pe_T(W[l], Ws + Cpe, Ws); }
+        }
         o_wT_pe0 = pack_pe_T(W[0], Cpe, 0);
-        if (a.skip_layer >= 0) o_wT_pes = pack_pe_T(W[a.skip_layer], kWidth + Cpe, kWidth);
-        std::vector<float> e0(kWidth, 0.f), zero(kWidth, 0.f);
+        std::vector<float> e0(WP, 0.f), zero(WP, 0.f);
         e0[0] = 1.0f;
-        o_e0 = put(blob, e0.data(), kWidth);
-        o_zero = put(blob, zero.data(), kWidth);
+        o_e0 = put(blob, e0.data(), WP);
+        o_zero = put(blob, zero.data(), WP);
     }
     // colour trunk: engine columns [pos 3 | gradient 3 | pad 2 | dir sin KD | dir cos KD]
     std::vector<int> ka;
@@ -330,22 +350,21 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     for (int k = 0; k < 3; ++k) ka.push_back(3 + Cdir + k);
     ka.push_back(-1); ka.push_back(-1);
     enc_map(ka, Ed, KD, 3);
-    const int in_col = 6 + Cdir + kWidth;
-    Src s0{ W[n_sdf], in_col, kWidth, true };
-    size_t o_wa = pack_layer(blob, s0, ka, kWidth, operands, &c.ksteps_a);
+    const int in_col = 6 + Cdir + Ws;
+    Src s0{ W[n_sdf], in_col, Wc, true };
+    size_t o_wa = pack_layer(blob, s0, ka, WP, operands, &c.ksteps_a);
     c.n_layers = n_col;
     std::vector<size_t> c_wp(n_col), c_b(n_col);
     for (int l = 0; l < n_col; ++l) {
-        std::vector<int> km;
-        for (int k = 0; k < kWidth; ++k) km.push_back(l == 0 ? 6 + Cdir + k : k);
-        Src src{ W[n_sdf + l], l == 0 ? in_col : kWidth, kWidth, true };
-        c_wp[l] = pack_layer(blob, src, km, kWidth, operands, &c.layer[l].ksteps);
+        const std::vector<int> km = l == 0 ? hidden_map(Ws, WP, 6 + Cdir) : hidden_map(Wc, WP, 0);
+        Src src{ W[n_sdf + l], l == 0 ? in_col : Wc, Wc, true };
+        c_wp[l] = pack_layer(blob, src, km, WP, operands, &c.layer[l].ksteps);
         c.layer[l].stash = -1;
-        c_b[l] = put(blob, B[n_sdf + l], kWidth);
+        c_b[l] = put(blob, B[n_sdf + l], Wc, WP);
     }
-    std::vector<float> wout(kWidth * 3);                  // [3][256] -> [256][3]
-    for (int k = 0; k < kWidth; ++k)
-        for (int o = 0; o < 3; ++o) wout[k * 3 + o] = W[n_sdf + n_col][(size_t)o * kWidth + k];
+    std::vector<float> wout((size_t)WP * 3, 0.f);         // [3][Wc] -> [WP][3]
+    for (int k = 0; k < Wc; ++k)
+        for (int o = 0; o < 3; ++o) wout[k * 3 + o] = W[n_sdf + n_col][(size_t)o * Wc + k];
     size_t o_cout = put(blob, wout.data(), wout.size());
     for (int k = 0; k < 3; ++k) c.b_out[k] = B[n_sdf + n_col][k];
     if (int rc = ensure(ctx, f.blob, blob.size() * sizeof(float))) return rc;
@@ -358,8 +377,9 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     c.w_out = base + o_cout;
     for (int l = 1; l < n_sdf; ++l) a.wT[l] = base + o_wT[l];
     a.wT_pe0 = base + o_wT_pe0;
-    a.wT_pe_skip = a.skip_layer >= 0 ? base + o_wT_pes : nullptr;
-    a.ks_hidden = kWidth / (operands ? 16 : 8);
+    for (int st = 0; st < a.n_stash; ++st) a.wT_pe_skip[st] = base + o_wT_pes[st];
+    a.ks_hidden = WP / (operands ? 16 : 8);
+    a.width = c.width = WP;
     a.w_ddf_out = base + o_e0; a.w_aux_out = base + o_zero;
     a.b_ddf_out = 0.f; a.b_aux_out = 0.f;
     a.activation = c.activation = d.activation;
@@ -377,6 +397,8 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n = d.layer_count;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
     const int operands = d.weight_dtype, step = operands ? 16 : 8;
+    const int Wn = d.layer_width, WP = engine_width(Wn);
+    const int Wh = Wn / 2, HC = roundup(Wh > 0 ? Wh : 1, 128);      // colour head's hidden layer (nerf.py:99-103: layer_width // 2) and its engine width
     if (n_tensors != n + 3) return fail(ctx, NEDDF_EINVAL, "NeRF: wrong tensor count");
     if (n < 1 || n > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: layer count out of range");
     for (int i = 0; i < d.n_skips; ++i)
@@ -391,37 +413,39 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     a.n_layers = n; a.n_stash = 0;
     for (int l = 0; l < n; ++l) {
         bool wide = l > 0 && in_skips(d, l - 1);
-        int cin = l == 0 ? Cpe : (wide ? kWidth + Cpe : kWidth);
-        Src src{ W[l], cin, kWidth, true };
+        int cin = l == 0 ? Cpe : (wide ? Wn + Cpe : Wn);
+        Src src{ W[l], cin, Wn, true };
         std::vector<int> km;
         a.layer[l].stash = -1;
         if (l == 0) km = pe;
-        else for (int k = 0; k < kWidth; ++k) km.push_back(k);       // cat([hx, embed_pos]): hidden state first
-        o_wp[l] = pack_layer(blob, src, km, kWidth, operands, &a.layer[l].ksteps);
+        else km = hidden_map(Wn, WP, 0);                            // cat([hx, embed_pos]): hidden state first
+        o_wp[l] = pack_layer(blob, src, km, WP, operands, &a.layer[l].ksteps);
         if (wide) {
-            if (a.n_stash >= kMaxStash - 1) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: too many skip connections");
+            if (a.n_stash >= kMaxStash - 1) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: more than 3 skip connections");
             std::vector<int> ps;
-            enc_map(ps, E, KH, kWidth);
-            o_st.push_back(pack_layer(blob, src, ps, kWidth, operands, &a.stash[a.n_stash].ksteps));
+            enc_map(ps, E, KH, Wn);
+            o_st.push_back(pack_layer(blob, src, ps, WP, operands, &a.stash[a.n_stash].ksteps));
             a.stash[a.n_stash].col0 = 0;
             a.layer[l].stash = a.n_stash++;
         }
-        o_b[l] = put(blob, B[l], kWidth);
+        o_b[l] = put(blob, B[l], Wn, WP);
     }
-    size_t o_wd = put(blob, W[n], kWidth);
+    size_t o_wd = put(blob, W[n], Wn, WP);
     a.b_density = B[n][0];
-    // colour head: Linear(256 + dir, 128)
-    Src sc{ W[n + 1], kWidth + Cdir, kWidth / 2, true };
-    std::vector<int> km, kd;
-    for (int k = 0; k < kWidth; ++k) km.push_back(k);
-    enc_map(kd, Ed, KD, kWidth);
-    size_t o_c0 = pack_layer(blob, sc, km, kWidth / 2, operands, &a.col0.ksteps);
+    // colour head: Linear(layer_width + dir, layer_width // 2)
+    Src sc{ W[n + 1], Wn + Cdir, Wh, true };
+    const std::vector<int> km = hidden_map(Wn, WP, 0);
+    std::vector<int> kd;
+    enc_map(kd, Ed, KD, Wn);
+    size_t o_c0 = pack_layer(blob, sc, km, HC, operands, &a.col0.ksteps);
     a.col_stash = a.n_stash;
-    size_t o_c0s = pack_layer(blob, sc, kd, kWidth / 2, operands, &a.stash[a.n_stash].ksteps);
+    size_t o_c0s = pack_layer(blob, sc, kd, HC, operands, &a.stash[a.n_stash].ksteps);
     a.stash[a.n_stash].col0 = roundup(2 * KH, step);          // direction encoding: first super-step boundary after the position encoding
     a.n_stash++;
-    size_t o_c0b = put(blob, B[n + 1], kWidth / 2);
-    size_t o_c1 = put(blob, W[n + 2], 3 * (kWidth / 2));
+    size_t o_c0b = put(blob, B[n + 1], Wh, HC);
+    std::vector<float> w1((size_t)3 * HC, 0.f);               // [3][Wh] -> [3][HC]
+    for (int o = 0; o < 3; ++o) memcpy(&w1[(size_t)o * HC], W[n + 2] + (size_t)o * Wh, (size_t)Wh * sizeof(float));
+    size_t o_c1 = put(blob, w1.data(), w1.size());
     for (int k = 0; k < 3; ++k) a.b_col1[k] = B[n + 2][k];
 
     if (int rc = ensure(ctx, f.blob, blob.size() * sizeof(float))) return rc;
@@ -436,10 +460,19 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     a.activation = d.activation;
     a.density_activation = d.density_activation;
     a.operands = operands;
+    a.width = WP;
     return 0;
 }
 
 // ---------------------------------------------------------------------------
+// the slot's packed weights were just read by work enqueued on `s`: neddf_set_field waits for exactly this before it repacks
+static int mark_use(neddf_ctx *ctx, Field &f, hipStream_t s)
+{
+    if (!f.last_use) HIPCHK(hipEventCreateWithFlags(&f.last_use, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(f.last_use, s));
+    return 0;
+}
+
 static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float *dir, const float *var, int64_t N,
                          int out_mode, float *distance, float *density, float *color, float *penalty, float *aux,
                          hipStream_t s)
@@ -447,11 +480,13 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");
     if (N <= 0) return 0;
     Field &f = ctx->field[slot];
-    const int grid_cap = ctx->cus * nerf_wgs_per_cu();
     const int dt = f.d.weight_dtype;
-    const int grid_cap_ddf = ctx->cus * field_wgs_per_cu(dt);
-    const int grid_cap_col = ctx->cus * col_wgs_per_cu(dt);
-    if (int rc = ensure(ctx, ctx->scratch, (size_t)(grid_cap > grid_cap_ddf ? grid_cap : grid_cap_ddf) * kMaxStash * kStashFloatsPerWg * sizeof(float))) return rc;
+    const int wid = f.d.kind == NEDDF_FIELD_NERF ? f.nerf.width : f.ddf.width;        // engine width
+    const int grid_cap = ctx->cus * nerf_wgs_per_cu(wid);
+    const int grid_cap_ddf = ctx->cus * field_wgs_per_cu(dt, wid);
+    const int grid_cap_col = ctx->cus * col_wgs_per_cu(dt, wid);
+    const int n_parked = f.d.kind == NEDDF_FIELD_NERF ? f.nerf.n_stash : f.ddf.n_stash;      // early partials a kernel may park per workgroup
+    if (int rc = ensure(ctx, ctx->scratch, (size_t)(grid_cap > grid_cap_ddf ? grid_cap : grid_cap_ddf) * (n_parked > 1 ? n_parked : 1) * kStashFloatsPerWg * sizeof(float))) return rc;
     if (f.d.kind == NEDDF_FIELD_NERF) {
         NerfArgs a = f.nerf;
         fill_enc(a.enc, f);
@@ -463,10 +498,10 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         }
         a.density = density ? density : (float *)tmp.p;
         a.color = color ? color : (float *)tmp.p + N;
-        int64_t tiles = (N + nerf_points_per_tile() - 1) / nerf_points_per_tile();
+        int64_t tiles = (N + nerf_points_per_tile(wid) - 1) / nerf_points_per_tile(wid);
         STAGE(ctx, s, NEDDF_STAGE_NERF, launch_nerf(a, (int)(tiles < grid_cap ? tiles : grid_cap), s));
         HIPCHK(hipGetLastError());
-        return 0;
+        return mark_use(ctx, f, s);
     }
     const bool full = (out_mode == NEDDF_OUT_FULL) && penalty && f.d.kind == NEDDF_FIELD_NEDDF;
     const int fr = full ? 4 : 1;
@@ -477,12 +512,11 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     // 19.9 ms, bf16 6.4 vs 7.4 ms (once its y' round trip went to bf16: with fp32 y' the kernel was HBM-bound at 8.4 ms)
     static const int rev_mask = [] { const char *e = getenv("NEDDF_DDF_REVERSE_DTYPES"); return e ? atoi(e) : 7; }();
     const bool reverse = rev_enabled && ((rev_mask >> dt) & 1) && !full && (f.d.kind == NEDDF_FIELD_NEDDF || f.d.kind == NEDDF_FIELD_NEUS) &&
-                         f.ddf.n_stash <= 1 &&
-                         field_wgs_per_cu(NEDDF_DTYPE_F32) == 2;
+                         ddf_rev_available();
     const int64_t chunk_cap = full ? (1 << 19) : (1 << 21);
     const int64_t chunk = N < chunk_cap ? N : chunk_cap;
     // activations' element type and planes: fp32 1024 B, bf16 512 B, split bf16 (two planes) 1024 B per row
-    if (int rc = ensure(ctx, ctx->features, (size_t)chunk * fr * kWidth * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->features, (size_t)chunk * fr * wid * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ptaux, (size_t)chunk * kPtAux * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->sched, 2 * kSchedInts * sizeof(int))) return rc;
     DevBuf &sink = ctx->flags;      // [>= 64 B] flags live in front; colour sink handled below
@@ -504,14 +538,14 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         a.sched_flags = sched_flags();
         HIPCHK(hipMemsetAsync(a.sched, 0, kSchedInts * sizeof(int), s));
         if (reverse) {          // one scalar's gradient: reverse mode, 64 or 128 points per tile (field_kernels.hip ddf_rev_kernel)
-            const int pts = ddf_rev_points(dt), wgs = ddf_rev_wgs_per_cu(dt) * ctx->cus;
+            const int pts = ddf_rev_points(dt, wid), wgs = ddf_rev_wgs_per_cu(dt, wid) * ctx->cus;
             const int64_t tiles = (n + pts - 1) / pts;
             const int grid = (int)(tiles < wgs ? tiles : wgs);
-            if (int rc = ensure(ctx, ctx->rev_scratch, (size_t)wgs * ddf_rev_scratch_floats_per_wg(a.n_layers, pts) * sizeof(float))) return rc;
+            if (int rc = ensure(ctx, ctx->rev_scratch, (size_t)wgs * ddf_rev_scratch_floats_per_wg(a.n_layers, pts, wid) * sizeof(float))) return rc;
             a.rev_scratch = (float *)ctx->rev_scratch.p;
             STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf_rev(a, grid, s));
         } else {
-            const int64_t tiles = (n + ddf_points_per_tile(dt) - 1) / ddf_points_per_tile(dt);
+            const int64_t tiles = (n + ddf_points_per_tile(dt, wid) - 1) / ddf_points_per_tile(dt, wid);
             STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf(a, (int)(tiles < grid_cap_ddf ? tiles : grid_cap_ddf), s));
         }
         if (color || full) {
@@ -526,7 +560,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
                 if (int rc = ensure(ctx, ctx->arena, (size_t)chunk * 3 * sizeof(float))) return rc;
                 c.color = (float *)ctx->arena.p;
             }
-            int ppt = col_points_per_tile(full, dt);
+            int ppt = col_points_per_tile(full, dt, wid);
             int64_t ctiles = (n + ppt - 1) / ppt;
             c.sched = (int *)ctx->sched.p + kSchedInts;
             c.sched_flags = sched_flags();
@@ -535,7 +569,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         }
     }
     HIPCHK(hipGetLastError());
-    return 0;
+    return mark_use(ctx, f, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -579,7 +613,10 @@ void neddf_destroy(neddf_ctx *ctx)
     DeviceGuard guard_(ctx->device);
     (void)hipDeviceSynchronize();
     neddf_comm_release(ctx);
-    for (auto &f : ctx->field) if (f.blob.p) (void)hipFree(f.blob.p);
+    for (auto &f : ctx->field) {
+        if (f.blob.p) (void)hipFree(f.blob.p);
+        if (f.last_use) (void)hipEventDestroy(f.last_use);
+    }
     for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags, &ctx->rflags, &ctx->rev_scratch, &ctx->sched, &ctx->tpack, &ctx->ttmp, &ctx->tamax })
         if (b->p) (void)hipFree(b->p);
     for (auto &e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -594,16 +631,28 @@ int neddf_set_field(neddf_ctx *ctx, int slot, const neddf_field_desc *desc, cons
     if (!ctx || !desc || !W || !B) return NEDDF_EINVAL;
     if (slot < 0 || slot >= NEDDF_NUM_SLOTS) return fail(ctx, NEDDF_EINVAL, "bad slot");
     DeviceGuard guard_(ctx->device);
-    if (desc->embed_pos_rank < 1 || desc->embed_pos_rank > 10 || desc->embed_dir_rank < 1 || desc->embed_dir_rank > 4)
-        return fail(ctx, NEDDF_EUNSUPPORTED, "embed_pos_rank must be in [1,10] and embed_dir_rank in [1,4]");
-    if (desc->layer_width != kWidth || (desc->kind != NEDDF_FIELD_NERF && desc->col_layer_width != kWidth))
-        return fail(ctx, NEDDF_EUNSUPPORTED, "the tile engine is built for hidden width 256");
+    // Hidden widths: any (neddf.py:52-66, nerf.py:34-44, neus.py:80-99 take any); the engine runs them zero-padded to the next
+    // multiple of 128, up to 512 (beyond that one 32-row tile no longer fits two workgroups into a CU's LDS).
+    // Encoding ranks: the position encoding owns one 64-column block of the tile (2 x roundup(3 E, 4) <= 64, and ten low-pass
+    // factors in the argument block) -> E <= 10, the reference's default and the largest frequency (2^9) that still resolves fp32
+    // scene coordinates; the direction encoding only has to fit the tile row next to it.
+    const int wmax = desc->kind == NEDDF_FIELD_NERF ? desc->layer_width
+                                                    : (desc->layer_width > desc->col_layer_width ? desc->layer_width : desc->col_layer_width);
+    if (desc->layer_width < 1 || (desc->kind != NEDDF_FIELD_NERF && desc->col_layer_width < 1) || wmax > kMaxWidth)
+        return fail(ctx, NEDDF_EUNSUPPORTED, "hidden widths must be in [1, 512]");
+    if (desc->kind == NEDDF_FIELD_NERF && desc->layer_width < 2) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: layer_width must be at least 2 (the colour head is layer_width // 2 wide)");
+    if (desc->embed_pos_rank < 1 || desc->embed_pos_rank > 10 || desc->embed_dir_rank < 1)
+        return fail(ctx, NEDDF_EUNSUPPORTED, "embed_pos_rank must be in [1,10] and embed_dir_rank >= 1");
+    if (2 * roundup(3 * desc->embed_pos_rank, 4) + 2 * roundup(3 * desc->embed_dir_rank, 4) + 32 > roundup(wmax, 128))
+        return fail(ctx, NEDDF_EUNSUPPORTED, "embed_dir_rank: the encodings do not fit one tile row of this hidden width");
     if (desc->n_skips < 0 || desc->n_skips > 8) return fail(ctx, NEDDF_EINVAL, "bad n_skips");
     if (desc->activation < 0 || desc->activation > 2 || desc->density_activation < 0 || desc->density_activation > 2)
         return fail(ctx, NEDDF_EINVAL, "bad activation id");
     if (desc->weight_dtype < NEDDF_DTYPE_F32 || desc->weight_dtype > NEDDF_DTYPE_F16_SPLIT) return fail(ctx, NEDDF_EINVAL, "bad weight_dtype");
     Field &f = ctx->field[slot];
-    HIPCHK(hipDeviceSynchronize());
+    // the packed weights of this slot are about to be overwritten: wait for the LAST launch that reads them (an event recorded
+    // on its stream by field_forward), not for the whole device -- other streams and other slots keep running
+    if (f.last_use) HIPCHK(hipEventSynchronize(f.last_use));
     f.valid = false;
     f.d = *desc;
     f.aux_grad_scale = 1.1f; f.distance_range_max = 2.0f;

@@ -24,12 +24,16 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
-struct OpsF32 {
+// Every policy is written over the engine width WID (hidden width padded to a multiple of 128: four waves x 32-column MFMA
+// tiles); the 256-wide aliases below are what the shipped configurations and the training kernels use.
+template <int WID>
+struct OpsF32T {
+    static constexpr int kWid = WID;
     typedef float act_t;
     typedef f32x4v frag;
     typedef frag afrag;                      // activation (A) and weight (B) fragments have the same type
     typedef frag bfrag;
-    static constexpr int kLd = kActLd;       // LDS row stride in elements (260 floats: conflict-free ds_read_b128)
+    static constexpr int kLd = WID + 4;      // LDS row stride in elements (260 floats at width 256): stride = 4 dwords mod 64 -> conflict-free ds_read_b128
     static constexpr int kStep = 8;          // k values per super-step
     static constexpr int kSub = 4;           // MFMA instructions per fragment
     static constexpr bool kFast = false;     // reference-exact elementwise math
@@ -56,12 +60,16 @@ struct OpsF32 {
     }
 };
 
-struct OpsBF16 {
+typedef OpsF32T<256> OpsF32;
+
+template <int WID>
+struct OpsBF16T {
+    static constexpr int kWid = WID;
     typedef unsigned short act_t;            // bf16 bit pattern
     typedef bf16x8 frag;
     typedef frag afrag;
     typedef frag bfrag;
-    static constexpr int kLd = 264;          // 528 B rows: same bank pattern as the fp32 tile (row stride = 4 dwords mod 64)
+    static constexpr int kLd = WID + 8;      // 528 B rows at width 256: same bank pattern as the fp32 tile (row stride = 4 dwords mod 64)
     static constexpr int kStep = 16;
     static constexpr int kSub = 1;
     static constexpr bool kFast = true;      // reduced-cost elementwise math (device_math.h), invisible after bf16 rounding
@@ -111,6 +119,7 @@ struct OpsBF16 {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
 };
+typedef OpsBF16T<256> OpsBF16;
 
 // Split-fp16 operands: fp16 carries 11 mantissa bits, so TWO terms per operand (a = h + m, h rounded toward zero -- which
 // also saturates instead of overflowing --, m the remainder rounded to nearest) hold 21-22 bits, and a.w needs only the
@@ -122,12 +131,14 @@ struct hfrag2 {
     f16x8 h, m;
 };
 
-struct OpsF16Split {
+template <int WID>
+struct OpsF16SplitT {
+    static constexpr int kWid = WID;
     typedef unsigned short act_t;
     typedef hfrag2 afrag;
     typedef hfrag2 bfrag;
-    static constexpr int kPlanes = 2, kPlane = 264;
-    static constexpr int kLd = 2 * 264;
+    static constexpr int kPlanes = 2, kPlane = WID + 8;
+    static constexpr int kLd = 2 * (WID + 8);
     static constexpr int kStep = 16;
     static constexpr int kSub = 3;
     static constexpr bool kFast = false;
@@ -186,6 +197,7 @@ struct OpsF16Split {
         }
     }
 };
+typedef OpsF16SplitT<256> OpsF16Split;
 
 // per-lane base of the A fragments of M-tile 0
 template <class Ops>

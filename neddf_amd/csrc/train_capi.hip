@@ -22,11 +22,22 @@ struct Plan {
 
 constexpr int kLdPe = 64, kLdDir = 32, kLdNarrow = 4;
 
+// The training kernels (train_kernels.hip) are built for the hidden width of every shipped configuration; rendering takes any
+// width up to 512 (neddf_set_field), training the others is refused loudly rather than computed wrongly.
+int train_supported(neddf_ctx *ctx, const Field &f)
+{
+    if (f.d.layer_width != kWidth || (f.d.kind != NEDDF_FIELD_NERF && f.d.col_layer_width != kWidth))
+        return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels are built for hidden width 256 (rendering supports 1..512)");
+    if (f.d.embed_dir_rank > 4) return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels take embed_dir_rank <= 4");
+    return 0;
+}
+
 int make_plan(neddf_ctx *ctx, int slot, int64_t N, int n_tensors, Plan &p)
 {
     if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");
     const Field &f = ctx->field[slot];
     if (f.d.kind != NEDDF_FIELD_NEDDF) return fail(ctx, NEDDF_EUNSUPPORTED, "unknown field kind");
+    if (int rc = train_supported(ctx, f)) return rc;
     p.E = f.d.embed_pos_rank; p.Ed = f.d.embed_dir_rank;
     p.Cpe = 6 * p.E; p.Cdir = 6 * p.Ed; p.Ca = p.Cpe + p.Cdir + 3; p.ldxa = roundup(p.Ca, 8);
     p.n_trunk = f.d.layer_count - 1; p.n_col = f.d.col_layer_count - 1;
@@ -91,6 +102,7 @@ struct NerfPlan {
 int make_nerf_plan(neddf_ctx *ctx, int slot, int64_t N, int n_tensors, NerfPlan &p)
 {
     const Field &f = ctx->field[slot];
+    if (int rc = train_supported(ctx, f)) return rc;
     p.E = f.d.embed_pos_rank; p.Ed = f.d.embed_dir_rank;
     p.Cpe = 6 * p.E; p.Cdir = 6 * p.Ed; p.n = f.d.layer_count;
     p.i_dens = p.n; p.i_c0 = p.n + 1; p.i_c1 = p.n + 2; p.in_c0 = kWidth + p.Cdir;
@@ -242,6 +254,7 @@ struct NeusPlan {
 int make_neus_plan(neddf_ctx *ctx, int slot, int64_t N, int n_tensors, NeusPlan &p)
 {
     const Field &f = ctx->field[slot];
+    if (int rc = train_supported(ctx, f)) return rc;
     p.E = f.d.embed_pos_rank; p.Ed = f.d.embed_dir_rank;
     p.Cpe = 6 * p.E; p.Cdir = 6 * p.Ed; p.Ca = 6 + p.Cdir; p.ldxa = roundup(p.Ca, 8);
     p.n_sdf = f.d.layer_count; p.n_col = f.d.col_layer_count;

@@ -740,7 +740,8 @@ void orc_nerf_forward(const orc_nerf_t *net, const float *pos, const float *dir,
 typedef struct {
     int embed_pos_rank, embed_dir_rank;
     int n_sdf;              /* sdf_layer_count */
-    int width;
+    int width;              /* sdf_layer_width */
+    int col_width;          /* col_layer_width (neus.py:80-99: the two trunks may differ) */
     int n_col;              /* col_layer_count hidden layers; layers_col has n_col + 1 entries */
     int n_skips;
     int skips[8];
@@ -765,7 +766,7 @@ static inline void orc_act_plain_grad(int kind, float x, float *y, float *dy)
 void orc_neus_forward(const orc_neus_t *net, const float *pos, const float *dir, int N, float *sdf_out, float *density,
                       float *color)
 {
-    const int E = net->embed_pos_rank, Ed = net->embed_dir_rank, Cpe = 6 * E, Cdir = 6 * Ed, W = net->width;
+    const int E = net->embed_pos_rank, Ed = net->embed_dir_rank, Cpe = 6 * E, Cdir = 6 * Ed, W = net->width, Wc = net->col_width;
 #pragma omp parallel
     {
         const int LD = ORC_MAX_IN;
@@ -823,7 +824,7 @@ void orc_neus_forward(const orc_neus_t *net, const float *pos, const float *dir,
             int ccin = 6 + Cdir + cin;
             float *co = h;
             for (int l = 0; l <= net->n_col; ++l) {                         /* :150-152, activation on every layer */
-                int cout = l < net->n_col ? W : 3;
+                int cout = l < net->n_col ? Wc : 3;
                 orc_linear_t(ci, net->col_w[l], net->col_b[l], ccin, cout, co);
                 for (int j = 0; j < cout; ++j) co[j] = orc_act(net->activation, co[j]);
                 ccin = cout;

@@ -60,7 +60,7 @@ class _NeRF(C.Structure):
 
 class _NeuS(C.Structure):
     _fields_ = [("embed_pos_rank", C.c_int), ("embed_dir_rank", C.c_int), ("n_sdf", C.c_int), ("width", C.c_int),
-                ("n_col", C.c_int), ("n_skips", C.c_int), ("skips", C.c_int * 8), ("activation", C.c_int),
+                ("col_width", C.c_int), ("n_col", C.c_int), ("n_skips", C.c_int), ("skips", C.c_int * 8), ("activation", C.c_int),
                 ("variance", C.c_float), ("sdf_w", _fp * MAXL), ("sdf_b", _fp * MAXL), ("col_w", _fp * MAXL),
                 ("col_b", _fp * MAXL)]
 
@@ -321,10 +321,10 @@ class NeuSOracle:
                  col_layer_count=8, col_layer_width=256, activation_type="ReLU", init_variance=0.3, skips=None):
         if skips is None:
             skips = [4]
-        assert sdf_layer_width == col_layer_width
         self._keep = {k: _f32(v) for k, v in state.items()}
         s = _NeuS()
         s.embed_pos_rank, s.embed_dir_rank, s.n_sdf, s.width, s.n_col = embed_pos_rank, embed_dir_rank, sdf_layer_count, sdf_layer_width, col_layer_count
+        s.col_width = col_layer_width
         s.n_skips = len(skips)
         for i, k in enumerate(skips):
             s.skips[i] = k

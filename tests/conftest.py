@@ -16,6 +16,9 @@ def pytest_configure(config):
 
 
 def golden(name):
+    if name == "bunny_weights.npz":         # ships with the product (bench.py / smoke() measure on it): neddf_amd/fixtures
+        from neddf_amd.fixtures import BUNNY_SMOKE_WEIGHTS
+        return np.load(BUNNY_SMOKE_WEIGHTS)
     return np.load(os.path.join(GOLDEN, name))
 
 
@@ -31,12 +34,7 @@ def bunny_stages():
     return {k: d[k] for k in d.files}
 
 
-BUNNY_CFG = dict(embed_pos_rank=10, embed_dir_rank=4, ddf_layer_count=8, ddf_layer_width=256,
-                 col_layer_count=4, col_layer_width=256, d_near=0.001, activation_type="tanhExp",
-                 density_activation_type="LeakyReLU", lowpass_alpha_offset=10, skips=[4],
-                 penalty_weight={"constraints_aux_grad": 0.05, "constraints_dDdt": 0.5,
-                                 "constraints_color": 0.0001, "range_distance": 1.0,
-                                 "range_aux_grad": 1.0, "range_color": 0.1})
+from neddf_amd.fixtures import BUNNY_SMOKE_CFG as BUNNY_CFG  # noqa: E402  (the shipped network's configuration)
 
 
 def close(a, b, rtol, atol):

@@ -24,6 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
 sys.path.insert(0, REF)
 sys.path.insert(0, HERE)
+sys.path.append(os.path.join(HERE, "..", ".."))      # neddf_amd.fixtures.synth (behind the reference on the path: `neddf` must resolve to it)
 sys.dont_write_bytecode = True
 
 import synth  # noqa: E402
@@ -123,7 +124,7 @@ def gen_bunny():
     render.set_iter(-1)
     render.network_fine.eval()
     net_sd = {k: npy(v) for k, v in render.network_fine.state_dict().items()}
-    save("bunny_weights.npz", **net_sd)
+    np.savez(os.path.join(HERE, "..", "..", "neddf_amd", "fixtures", "bunny_smoke_weights.npz"), **net_sd)     # ships with the product
 
     tf = json.load(open(os.path.join(REF, "data/bunny_smoke/transforms_test.json")))
     W = H = 400
@@ -277,19 +278,40 @@ def gen_fields():
                             col_layer_count=3, col_layer_width=256, d_near=0.01, activation_type="LeakyReLU",
                             density_activation_type="tanhExp", skips=[2], lowpass_alpha_offset=3),
     }
+    # other hidden widths and more than one skip connection: the constructors take any (neddf.py:52-66, nerf.py:34-44)
+    cases.update({
+        "neddf_w128": dict(embed_pos_rank=6, embed_dir_rank=4, ddf_layer_count=6, ddf_layer_width=128,
+                           col_layer_count=4, col_layer_width=128, d_near=0.01, activation_type="tanhExp",
+                           density_activation_type="ReLU", skips=[2], lowpass_alpha_offset=10),
+        "neddf_w384": dict(embed_pos_rank=10, embed_dir_rank=4, ddf_layer_count=8, ddf_layer_width=384,
+                           col_layer_count=4, col_layer_width=384, d_near=0.01, activation_type="ReLU",
+                           density_activation_type="ReLU", skips=[4], lowpass_alpha_offset=10),
+        "neddf_w192": dict(embed_pos_rank=8, embed_dir_rank=4, ddf_layer_count=7, ddf_layer_width=192,
+                           col_layer_count=3, col_layer_width=192, d_near=0.01, activation_type="tanhExp",
+                           density_activation_type="LeakyReLU", skips=[3], lowpass_alpha_offset=5),
+        "neddf_skips2": dict(embed_pos_rank=8, embed_dir_rank=4, ddf_layer_count=8, ddf_layer_width=256,
+                             col_layer_count=4, col_layer_width=256, d_near=0.01, activation_type="tanhExp",
+                             density_activation_type="ReLU", skips=[1, 4], lowpass_alpha_offset=10),
+    })
     for name, kw in cases.items():
-        net = NeDDF(**kw)
         sd = synth.neddf_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["ddf_layer_count"],
                                kw["ddf_layer_width"], kw["col_layer_count"], kw["col_layer_width"],
                                tuple(kw["skips"]), seed=7)
-        print(name, net.load_state_dict(to_torch_sd(sd)))
         arrs = dict(pos=pos, dir=d, var=var, config=np.array(json.dumps(kw)))
-        for it in (-1, 2500):   # eval, and a warm-up iteration (lowpass + aux_grad_scale live)
-            net.set_iter(it)
-            out = net(smp)
-            tag = "eval" if it == -1 else "it%d" % it
-            for k, v in out.items():
-                arrs["%s_%s" % (tag, k)] = npy(v)
+        # fp32 = the golden; fp64 (torch default dtype float64: same code, same weights) = the yardstick for fp32 noise --
+        # density = (1 - |grad D, aux|) / D amplifies rounding, so its gate is stated relative to the reference's OWN fp32 error
+        for dtype, suffix in ((torch.float32, ""), (torch.float64, "_fp64")):
+            torch.set_default_dtype(dtype)
+            net = NeDDF(**kw)
+            print(name, dtype, net.load_state_dict({k: v.to(dtype) for k, v in to_torch_sd(sd).items()}))
+            smp_t = Sampling(*(torch.from_numpy(x).to(dtype) for x in (pos, d, var)))
+            for it in (-1, 2500):   # eval, and a warm-up iteration (lowpass + aux_grad_scale live)
+                net.set_iter(it)
+                out = net(smp_t)
+                tag = "eval" if it == -1 else "it%d" % it
+                for k, v in out.items():
+                    arrs["%s_%s%s" % (tag, k, suffix)] = npy(v)
+            torch.set_default_dtype(torch.float32)
         save(name + ".npz", **arrs)
 
     kw = dict(embed_pos_rank=10, embed_dir_rank=4, layer_count=8, layer_width=256, activation_type="ReLU",
@@ -297,7 +319,11 @@ def gen_fields():
     for name, kw2 in (("nerf_relu", kw),
                       ("nerf_tanhexp", dict(kw, activation_type="tanhExp", density_activation_type="LeakyReLU",
                                             embed_pos_rank=6, layer_count=6, skips=[2],
-                                            lowpass_alpha_offset=2))):
+                                            lowpass_alpha_offset=2)),
+                      ("nerf_w128", dict(kw, layer_width=128)),
+                      ("nerf_w384", dict(kw, layer_width=384, activation_type="tanhExp", embed_pos_rank=8, layer_count=6,
+                                         skips=[2])),
+                      ("nerf_skips2", dict(kw, skips=[1, 4]))):
         net = NeRF(**kw2)
         sd = synth.nerf_state(kw2["embed_pos_rank"], kw2["embed_dir_rank"], kw2["layer_count"],
                               kw2["layer_width"], tuple(kw2["skips"]), seed=11)
@@ -389,6 +415,11 @@ def gen_neus():
                           col_layer_width=256, init_variance=0.3, activation_type="ReLU", skips=[4]),     # tests/conftest.py:61-74
         "neus_tanhexp": dict(embed_pos_rank=10, embed_dir_rank=3, sdf_layer_count=6, sdf_layer_width=256, col_layer_count=3,
                              col_layer_width=256, init_variance=0.7, activation_type="tanhExp", skips=[2]),
+        # the two trunks of a NeuS may have different widths (neus.py:80-99)
+        "neus_w128_384": dict(embed_pos_rank=6, embed_dir_rank=4, sdf_layer_count=6, sdf_layer_width=128, col_layer_count=3,
+                              col_layer_width=384, init_variance=0.5, activation_type="tanhExp", skips=[2]),
+        "neus_w320_64": dict(embed_pos_rank=8, embed_dir_rank=4, sdf_layer_count=7, sdf_layer_width=320, col_layer_count=4,
+                             col_layer_width=64, init_variance=0.4, activation_type="ReLU", skips=[1, 4]),
     }
     for name, kw in cases.items():
         net = NeuS(**kw)
@@ -829,6 +860,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "fp64":
         gen_fp64()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fields":
+        from neddf.ray import Sampling  # noqa: F401  (gen_bunny normally imports the reference first)
+        gen_fields()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "configs":
         gen_config_digests()

@@ -1,115 +1,5 @@
-"""Deterministic synthetic weights shared by the golden generator and the tests.
-
-The golden generator (gen_goldens.py, runs only where /root/reference exists)
-loads these arrays into the *reference* networks and records their outputs;
-the tests regenerate the very same arrays with the same numpy bit-generator
-and load them into the HIP path / the C oracle.  Only inputs and expected
-outputs are stored in the fixtures, never the weights.
-
-numpy's PCG64 + `standard_normal` stream is stable across numpy versions.
-"""
-from collections import OrderedDict
-
-import numpy as np
-
-
-def _layer(rng, fan_in, fan_out, transposed):
-    """xavier-normal weight, small non-zero bias (exercises the bias path)."""
-    std = np.sqrt(2.0 / (fan_in + fan_out))
-    w = (rng.standard_normal((fan_in, fan_out)) * std).astype(np.float32)
-    b = (rng.standard_normal((fan_out,)) * 0.05).astype(np.float32)
-    if transposed:  # nn.Linear layout [out, in]
-        w = np.ascontiguousarray(w.T)
-    return w, b
-
-
-def neddf_state(embed_pos_rank=10, embed_dir_rank=4, ddf_layer_count=8,
-                ddf_layer_width=256, col_layer_count=4, col_layer_width=256,
-                skips=(4,), seed=7):
-    """State dict (numpy) with the key names/shapes of the reference NeDDF
-    (neddf/network/neddf.py:129-145): LinearGradLayer weights are [in, out]."""
-    rng = np.random.default_rng(seed)
-    in_ddf = embed_pos_rank * 6
-    in_col = (embed_pos_rank + embed_dir_rank) * 6 + 3 + ddf_layer_width
-    sd = OrderedDict()
-    dims = [(in_ddf, ddf_layer_width)]
-    for layer_id in range(ddf_layer_count - 2):
-        if layer_id in skips:
-            dims.append((ddf_layer_width + in_ddf, ddf_layer_width))
-        else:
-            dims.append((ddf_layer_width, ddf_layer_width))
-    for i, (a, b) in enumerate(dims):
-        w, bias = _layer(rng, a, b, False)
-        sd["layers_ddf.%d.weight" % i] = w
-        sd["layers_ddf.%d.bias" % i] = bias
-    dims = [(in_col, col_layer_width)] + [(col_layer_width, col_layer_width)] * (col_layer_count - 2)
-    for i, (a, b) in enumerate(dims):
-        w, bias = _layer(rng, a, b, False)
-        sd["layers_col.%d.weight" % i] = w
-        sd["layers_col.%d.bias" % i] = bias
-    for name, n in (("layer_ddf_out", 1), ("layer_aux_out", 1), ("layer_col_out", 3)):
-        w, bias = _layer(rng, ddf_layer_width, n, False)
-        sd[name + ".weight"] = w
-        sd[name + ".bias"] = bias
-    return sd
-
-
-def nerf_state(embed_pos_rank=10, embed_dir_rank=4, layer_count=8, layer_width=256,
-               skips=(4,), seed=11):
-    """State dict (numpy) with the key names/shapes of the reference NeRF
-    (neddf/network/nerf.py:88-103): nn.Linear weights are [out, in]."""
-    rng = np.random.default_rng(seed)
-    in_pos = embed_pos_rank * 6
-    in_dir = embed_dir_rank * 6
-    sd = OrderedDict()
-    dims = [(in_pos, layer_width)]
-    for layer_id in range(layer_count - 1):
-        if layer_id in skips:
-            dims.append((layer_width + in_pos, layer_width))
-        else:
-            dims.append((layer_width, layer_width))
-    for i, (a, b) in enumerate(dims):
-        w, bias = _layer(rng, a, b, True)
-        sd["layers.%d.weight" % i] = w
-        sd["layers.%d.bias" % i] = bias
-    w, bias = _layer(rng, layer_width, 1, True)
-    sd["outL_density.weight"], sd["outL_density.bias"] = w, bias
-    w, bias = _layer(rng, layer_width + in_dir, layer_width // 2, True)
-    sd["outL_color.0.weight"], sd["outL_color.0.bias"] = w, bias
-    w, bias = _layer(rng, layer_width // 2, 3, True)
-    sd["outL_color.2.weight"], sd["outL_color.2.bias"] = w, bias
-    return sd
-
-
-def random_sampling(n_rays, n_samples, seed, cone=True):
-    """Seeded Sampling-like inputs (pos, unit dir, diag variance)."""
-    rng = np.random.default_rng(seed)
-    pos = rng.uniform(-1.2, 1.2, (n_rays, n_samples, 3)).astype(np.float32)
-    d = rng.standard_normal((n_rays, 1, 3))
-    d = d / np.linalg.norm(d, axis=-1, keepdims=True)
-    d = np.broadcast_to(d, (n_rays, n_samples, 3)).astype(np.float32).copy()
-    if cone:
-        var = (rng.uniform(0.0, 1.0, (n_rays, n_samples, 3)) ** 4 * 2e-3).astype(np.float32)
-    else:
-        var = np.zeros((n_rays, n_samples, 3), np.float32)
-    return pos, d, var
-
-
-def neus_state(embed_pos_rank=6, embed_dir_rank=4, sdf_layer_count=8, sdf_layer_width=256, col_layer_count=8,
-               col_layer_width=256, skips=(4,), init_variance=0.3, seed=13):
-    """State dict (numpy) with the key names/shapes of the reference NeuS
-    (neddf/network/neus.py:80-99): nn.Linear weights [out, in] + scalar `variance`."""
-    rng = np.random.default_rng(seed)
-    in_sdf = embed_pos_rank * 6
-    in_col = 6 + embed_dir_rank * 6 + sdf_layer_width
-    sd = OrderedDict()
-    dims = [(in_sdf, sdf_layer_width)]
-    for layer_id in range(sdf_layer_count - 1):
-        dims.append((sdf_layer_width + (in_sdf if layer_id in skips else 0), sdf_layer_width))
-    for i, (a, b) in enumerate(dims):
-        sd["layers_sdf.%d.weight" % i], sd["layers_sdf.%d.bias" % i] = _layer(rng, a, b, True)
-    dims = [(in_col, col_layer_width)] + [(col_layer_width, col_layer_width)] * (col_layer_count - 1) + [(col_layer_width, 3)]
-    for i, (a, b) in enumerate(dims):
-        sd["layers_col.%d.weight" % i], sd["layers_col.%d.bias" % i] = _layer(rng, a, b, True)
-    sd["variance"] = np.float32(init_variance)
-    return sd
+"""Deterministic synthetic weights shared by the golden generator and the tests: the generator itself lives with the product's
+fixtures (neddf_amd/fixtures/synth.py -- bench.py uses it for its non-default hidden widths); this name keeps `import synth`
+working for the generator script and the test modules."""
+from neddf_amd.fixtures.synth import *  # noqa: F401,F403
+from neddf_amd.fixtures.synth import neddf_state, nerf_state, neus_state, random_sampling  # noqa: F401

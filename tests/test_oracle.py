@@ -125,7 +125,7 @@ def test_neddf_bunny_field(bunny_weights, bunny_stages):
         assert_close(o["fields_penalty"], g[tag + "_fields_penalty"], 2e-3, 1e-5, tag + " penalty")
 
 
-@pytest.mark.parametrize("name", ["neddf_relu", "neddf_tanhexp", "neddf_leaky"])
+@pytest.mark.parametrize("name", ["neddf_relu", "neddf_tanhexp", "neddf_leaky", "neddf_w128", "neddf_w384", "neddf_w192", "neddf_skips2"])
 def test_neddf_synth(name):
     g = golden(name + ".npz")
     kw = json.loads(str(g["config"]))
@@ -136,10 +136,10 @@ def test_neddf_synth(name):
         net.set_iter(it)
         o = net.forward(g["pos"], g["dir"], g["var"])
         for k in ("distance", "aux_grad", "color", "density", "fields_penalty"):
-            assert_close(o[k], g["%s_%s" % (tag, k)], 2e-4, 2e-5, "%s %s %s" % (name, tag, k))
+            assert_close(o[k], g["%s_%s" % (tag, k)], 1e-4, 1e-5, "%s %s %s" % (name, tag, k))
 
 
-@pytest.mark.parametrize("name", ["nerf_relu", "nerf_tanhexp"])
+@pytest.mark.parametrize("name", ["nerf_relu", "nerf_tanhexp", "nerf_w128", "nerf_w384", "nerf_skips2"])
 def test_nerf_synth(name):
     g = golden(name + ".npz")
     kw = json.loads(str(g["config"]))
@@ -181,7 +181,7 @@ def test_nerf_render_rays():
         assert_close(out[k], g["out_" + k], 1e-4, 1e-5, k)
 
 
-@pytest.mark.parametrize("name", ["neus_relu", "neus_tanhexp"])
+@pytest.mark.parametrize("name", ["neus_relu", "neus_tanhexp", "neus_w128_384", "neus_w320_64"])
 def test_neus_synth(name):
     """NeuS (neus.py:101-162): forward-mode normals of the oracle vs the reference's autograd normals."""
     g = golden(name + ".npz")
