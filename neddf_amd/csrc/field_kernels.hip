@@ -712,7 +712,10 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
         __syncthreads();
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
-        if (a.mode == 1) {      // NeuS: [pos | gradient | pad | embed_dir] (neus.py:146-149)
+        // timing ablations of the colour kernel (-DNEDDF_ABLATE builds only, results invalid): 1024 no input encodings, 2048 no
+        // feature load, 4096 no small-input product, 8192 no 256 -> 3 head, 16384 ReLU in place of the configured activation
+        if (NEDDF_ABL(a.sched_flags, 1024)) {
+        } else if (a.mode == 1) {      // NeuS: [pos | gradient | pad | embed_dir] (neus.py:146-149)
             for (int i = tid; i < P * 3; i += THREADS) {
                 int p = i / 3, d = i - 3 * p;
                 int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
@@ -750,13 +753,19 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
             int64_t src = ROWS4 ? grow : grow * a.feat_rows;      // value row of [n][feat_rows][256]
             return (const f32x4v *)((const act_t *)a.features + (size_t)src * (Ops::kPlanes * WID) + CE * c4);
         };
+        const bool abl_nofeat = NEDDF_ABL(a.sched_flags, 2048);
         if constexpr (FPRE) {
+            if (!abl_nofeat) {
 #pragma unroll
-            for (int i = 0; i < NF; ++i) fpre[i] = *feature_src(tid + i * THREADS);
+                for (int i = 0; i < NF; ++i) fpre[i] = *feature_src(tid + i * THREADS);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NF; ++i) fpre[i] = f32x4v{ 0.f, 0.f, 0.f, 0.f };
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         acc_init<MT, NT, ROWS4>(acc, a.layer[0].bias, wave, lane, Ops::kWScale);
-        dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wp_a + (size_t)wave * NT * a.ksteps_a * 64 + lane, a.ksteps_a);
+        if (!NEDDF_ABL(a.sched_flags, 4096)) dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wp_a + (size_t)wave * NT * a.ksteps_a * 64 + lane, a.ksteps_a);
         LayerPre<NT, Ops> pre;
         layer_prefetch<NT, Ops>(pre, a.layer[0].wp, nullptr, a.layer[0].ksteps, wave, lane);
         __syncthreads();
@@ -766,7 +775,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
                 int idx = tid + i * THREADS;
                 *lds_chunk(idx) = fpre[i];
             }
-        } else {
+        } else if (!abl_nofeat) {
             for (int idx = tid; idx < ROWS * CPR; idx += THREADS)
                 *lds_chunk(idx) = *feature_src(idx);
         }
@@ -778,11 +787,11 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
             if (l + 1 < a.n_layers)
                 layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
             __syncthreads();
-            epilogue_rt<MT, NT, ROWS4, Ops>(acc, act, a.activation, wave, lane);
+            epilogue_rt<MT, NT, ROWS4, Ops>(acc, act, NEDDF_ABL(a.sched_flags, 16384) ? 0 : a.activation, wave, lane);
             __syncthreads();
         }
         // layer_col_out 256 -> 3 (neddf.py:257), no output activation; two k-halves per row
-        for (int idx = tid; idx < 2 * ROWS; idx += THREADS) {
+        for (int idx = tid; idx < (NEDDF_ABL(a.sched_flags, 8192) ? 0 : 2 * ROWS); idx += THREADS) {
             int half = idx / ROWS, row = idx - half * ROWS;
             const act_t *ar = act + row * LD + half * (WID / 2);
             const float *w = a.w_out + half * (WID / 2) * 3;

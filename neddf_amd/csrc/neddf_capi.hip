@@ -33,7 +33,7 @@ static int sched_flags()
     if (v < 0) {
         const char *e = getenv("NEDDF_SCHED");
 #ifdef NEDDF_ABLATE
-        v = e ? atoi(e) & 1022 : 2;
+        v = e ? atoi(e) & 32766 : 2;
 #else
         v = e ? atoi(e) & 2 : 2;
 #endif

@@ -689,6 +689,70 @@ def test_c1_bunny_400x400_vs_oracle(dev, orc, bunny_weights):
     assert 10 * np.log10(1.0 / max(mse, 1e-30)) > 120.0
 
 
+def test_c2_single_pass_vs_oracle(dev, orc, bunny_weights):
+    """BASELINE.json configs[1] through the entry point bench.py times: render_image_single_pass (neddf_render_rays_single --
+    stratified distances, cone moments, the reverse-mode distance kernel, the colour trunk, compositing) on 4 096 random pixels
+    of the 800x800 benchmark pose with 128 samples per ray, against the CPU oracle on identical uniforms at the north-star
+    tolerance (1e-4 rel + the 1e-5 abs floor of SURVEY.md N7), PSNR > 120 dB.  The slab is rendered through `pixel_range` and a
+    permutation so that the sampled rays are arbitrary pixels of the frame, not one contiguous run."""
+    import math
+    import bench
+    import neddf_amd
+    r = bunny_render(dev, bunny_weights)
+    fx = 0.5 * 800 / math.tan(0.5 * bench.CAMERA_ANGLE_X)
+    R, T_ = bench.view_pose(0)
+    calib = np.array([fx, fx, 400.0, 400.0], np.float32)
+    cam = neddf_amd.Camera(neddf_amd.PinholeCalib(calib.astype(np.float64)), None).to(dev)
+    cam.R, cam.T = T(R, dev), T(T_, dev)
+    rng = np.random.default_rng(11)
+    n, S = 4096, 128
+    # four slabs of 1 024 consecutive pixels at random rows + columns of the frame (render_image_single_pass takes pixel ranges)
+    starts = rng.integers(0, 800 * 800 - 1024, 4)
+    U = rng.uniform(0, 1, (n, S)).astype(np.float32)
+    got = {k: [] for k in ("color", "depth", "transmittance")}
+    uv = []
+    for i, lo in enumerate(starts):
+        o = r.render_image_single_pass(800, 800, cam, S, U=T(U[1024 * i:1024 * (i + 1)], dev), pixel_range=(int(lo), int(lo) + 1024))
+        assert int(o["_nan"].item()) == 0
+        for k in got:
+            got[k].append(N(o[k]))
+        idx = np.arange(lo, lo + 1024)
+        uv.append(np.stack([idx % 800, idx // 800], 1))
+    uv = np.concatenate(uv).astype(np.float32)
+    onet = orc.NeDDFOracle(bunny_weights, **BUNNY_CFG)
+    rd, ro = orc.create_rays(uv, R, T_, calib)
+    d = orc.sample_coarse(U, 2.0, 6.0)
+    v = onet.forward(*orc.sampling(rd, ro, d, 1.0 / 1111 / math.sqrt(12)))
+    ref = orc.integrate(d, v["density"], v["color"], 6.0)
+    for k in got:
+        assert_close(np.concatenate(got[k]), ref[k], 1e-4, 1e-5, "C2 single pass " + k)
+    mse = float(np.mean((np.concatenate(got["color"]).astype(np.float64) - ref["color"]) ** 2))
+    assert 10 * np.log10(1.0 / max(mse, 1e-30)) > 120.0
+
+
+def test_width_and_rank_limits_fail_loudly(dev):
+    """The engine takes hidden widths 1..512 (zero-padded to a multiple of 128); beyond that -- and for the training kernels, which
+    are built for width 256 -- the C ABI refuses with NEDDF_EUNSUPPORTED instead of computing something else.  A NeDDF whose two
+    widths differ is refused like the reference's own forward would fail (neddf.py:145)."""
+    import neddf_amd
+    from neddf_amd import NeddfError, Sampling
+    pos, d, var = synth.random_sampling(2, 8, seed=1)
+    s = Sampling(T(pos, dev), T(d, dev), T(var, dev))
+    kw = dict(embed_pos_rank=4, embed_dir_rank=2, ddf_layer_count=4, col_layer_count=3, activation_type="ReLU", density_activation_type="ReLU", skips=[1])
+    for wd, wc in ((640, 640), (128, 256)):
+        net = neddf_amd.NeDDF(ddf_layer_width=wd, col_layer_width=wc, **kw).to(dev)
+        net.set_iter(-1)
+        with pytest.raises(NeddfError):
+            net(s)
+    net = neddf_amd.NeDDF(ddf_layer_width=72, col_layer_width=72, **kw).to(dev)      # any width below: runs (zero-padded to 128)
+    net.set_iter(-1)
+    o = net(s)
+    assert bool(torch.isfinite(o["color"]).all()) and o["density"].shape == (2, 8)
+    with torch.enable_grad():                                                        # training at that width: refused loudly
+        with pytest.raises(NeddfError):
+            net(s)
+
+
 def test_c3_full_frame_hierarchical_properties(dev, bunny_weights):
     """BASELINE.json configs[2] at full size: all 640 000 rays of an 800x800 view through render_rays' hierarchical path
     (65 coarse + 129 importance samples).  Size-independent properties of the importance-resample kernel and the compositor:
@@ -853,4 +917,4 @@ def test_neus_render_rays(dev):
     assert "fields_penalty" not in o
     for k in ("color", "depth", "transmittance", "color_coarse", "depth_coarse", "transmittance_coarse"):
         assert_close(N(o[k]), g["out_" + k], 1e-4, 1e-5, k)
-    assert_close(N(o["weight"]), g["out_weight"], 1e-3, 1e-5, "weight")
+    assert_close(N(o["weight"]), g["out_weight"], 1e-4, 1e-5, "weight")
