@@ -275,6 +275,20 @@ class NeDDFOracle:
             lib().orc_set_bf16(0)
         return {k: v.reshape(shp + ((3,) if k == "color" else ())) for k, v in o.items()}
 
+    def forward_fast(self, pos, dir, var):
+        """The same field values (no fields_penalty) by bench.py's CPU BASELINE implementation (oracle/neddf_cpu_fast.c):
+        eval-minimal like the HIP path -- value rows forward, reverse-mode distance gradient, colour trunk on value rows -- on
+        blocked GEMM micro-kernels.  Not the parity checker (summation order differs); held to the 1e-4 gates against forward()."""
+        assert not self.bf16
+        pos = _f32(pos); dir = _f32(dir); var = _f32(var)
+        shp = pos.shape[:-1]
+        N = int(np.prod(shp))
+        o = dict(distance=np.empty(N, np.float32), density=np.empty(N, np.float32), color=np.empty((N, 3), np.float32),
+                 aux_grad=np.empty(N, np.float32))
+        lib().fast_neddf_forward(C.byref(self.s), _p(pos), _p(dir), _p(var), N, _p(o["distance"]), _p(o["density"]), _p(o["color"]),
+                                 _p(o["aux_grad"]))
+        return {k: v.reshape(shp + ((3,) if k == "color" else ())) for k, v in o.items()}
+
 
 class NeRFOracle:
     """Mirrors NeRF(...) ctor keywords (nerf.py:34-44) + a numpy state dict."""

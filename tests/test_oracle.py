@@ -153,6 +153,32 @@ def test_nerf_synth(name):
             assert_close(o[k], g["%s_%s" % (tag, k)], 1e-4, 1e-5, "%s %s %s" % (name, tag, k))
 
 
+def test_cpu_baseline_implementation_matches_the_oracle(bunny_weights, bunny_stages):
+    """bench.py's CPU baseline (oracle/neddf_cpu_fast.c: eval-minimal, reverse-mode distance gradient, blocked GEMM micro-kernels,
+    vectorised activations) computes the same field values as the operation-order-exact oracle: the 1e-4 gates of the HIP
+    path (density with the 3e-4 abs term of its fp32 noise), on the shipped network and on a synthetic one with
+    another width and two skip connections."""
+    g = bunny_stages
+    net = orc.NeDDFOracle(bunny_weights, **BUNNY_CFG)
+    for tag in ("c", "f"):
+        a = net.forward(g[tag + "_pos"], g[tag + "_dir"], g[tag + "_var"])
+        b = net.forward_fast(g[tag + "_pos"], g[tag + "_dir"], g[tag + "_var"])
+        assert "fields_penalty" not in b
+        for k in ("distance", "aux_grad", "color"):
+            assert_close(b[k], a[k], 1e-4, 1e-5, "%s %s" % (tag, k))
+        assert_close(b["density"], a["density"], 1e-4, 3e-4, tag + " density")
+    for name in ("neddf_w192", "neddf_skips2", "neddf_relu"):
+        gg = golden(name + ".npz")
+        kw = json.loads(str(gg["config"]))
+        sd = synth.neddf_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["ddf_layer_count"], kw["ddf_layer_width"],
+                               kw["col_layer_count"], kw["col_layer_width"], tuple(kw["skips"]), seed=7)
+        n2 = orc.NeDDFOracle(sd, **kw)
+        n2.set_iter(2500)
+        b = n2.forward_fast(gg["pos"], gg["dir"], gg["var"])
+        for k in ("distance", "aux_grad", "color", "density"):
+            assert_close(b[k], gg["it2500_" + k], 1e-4, 1e-5, "%s %s vs reference golden" % (name, k))
+
+
 def test_render_rays_end_to_end(bunny_weights, bunny_stages):
     g = bunny_stages
     net = orc.NeDDFOracle(bunny_weights, **BUNNY_CFG)
