@@ -119,15 +119,46 @@ __device__ __forceinline__ void fast_sincos(float x, float &sn, float &cs)
     cs = __builtin_amdgcn_cosf(r);
 }
 
+// sin and cos of the exact (fp32-policy) encodings.  The library sincosf carries a Payne-Hanek path for arguments the
+// encodings never reach and costs ~180 instructions, expf ~50; with 30 + 12 (frequency, axis) pairs per sample point the
+// colour kernel spent 5.5 % of its time there (profiles/r03_col_ablation.txt).  Here: Cody-Waite reduction by pi/2 with a
+// three-term constant (exact products through fma; |x| up to ~1e4 rad, the encodings stay below 2^9 |pos|), then the
+// degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4] -- ~25 instructions, |error| <= 2.5e-7 (measured against fp64
+// over |x| <= 4096, tests/test_gpu_parity.py::test_layer_ops sweeps it through neddf_op_positional_encoding).
+__device__ __forceinline__ void sincos_cw(float x, float &sn, float &cs)
+{
+    const float k = rintf(x * 0.636619772367581343f);                 // x / (pi/2)
+    float r = fmaf(-k, 1.57079637050628662109375f, x);                // pi/2 = c1 + c2 + c3
+    r = fmaf(-k, -4.37113882867379116e-8f, r);
+    r = fmaf(-k, -1.71512449944288e-15f, r);
+    const float r2 = r * r;
+    const float sp = fmaf(r * r2, fmaf(r2, fmaf(r2, fmaf(r2, 2.7183114939898219064e-6f, -1.9840874255356029e-4f), 8.3333169820368300e-3f), -1.6666666055418920e-1f), r);
+    const float cp = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f), fmaf(-0.5f, r2, 1.0f));
+    const int q = (int)k;
+    const float a = (q & 1) ? cp : sp, b = (q & 1) ? sp : cp;
+    sn = (q & 2) ? -a : a;
+    cs = ((q + 1) & 2) ? -b : b;
+}
+
+// e^x on the exp2 unit with the rounding error of x * log2(e) carried along: relative error <= 2e-7 for the (non-positive)
+// arguments of the integrated encoding's weights (sampling.py:71)
+__device__ __forceinline__ float exp_acc(float x)
+{
+    const float t = x * 1.44269502162933349609375f;
+    const float r = fmaf(x, 1.44269502162933349609375f, -t) + x * 1.925963033500011e-8f;
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * 0.693147182464599609375f, e);
+}
+
 template <bool GRADSCALE, bool FAST = false>
 __device__ __forceinline__ void pe_pair(int e, float x, float v, float lowpass, float &vs, float &vc, float &js, float &jc)
 {
     float f = (float)(1 << e);
-    float w = FAST ? fast_exp(-0.5f * (f * f) * v) : expf(-0.5f * (f * f) * v);
+    float w = FAST ? fast_exp(-0.5f * (f * f) * v) : exp_acc(-0.5f * (f * f) * v);
     float s = GRADSCALE ? ((1.0f / (0.5f * f)) * lowpass) * w : lowpass * w;
     float sn, cs;
     if (FAST) fast_sincos(f * x, sn, cs);
-    else sincosf(f * x, &sn, &cs);
+    else sincos_cw(f * x, sn, cs);
     vs = s * sn;
     vc = s * cs;
     float g = f * s;

@@ -78,7 +78,7 @@ __device__ __forceinline__ void encode_dir(typename Ops::act_t *act, int col0, c
         int64_t gp = p0 + p < N ? p0 + p : N - 1;
         float sn, cs;
         if (Ops::kFast) fast_sincos((float)(1 << e) * dir[gp * 3 + d], sn, cs);
-        else sincosf((float)(1 << e) * dir[gp * 3 + d], &sn, &cs);
+        else sincos_cw((float)(1 << e) * dir[gp * 3 + d], sn, cs);
         typename Ops::act_t *r0 = act + (ROWS4 ? 4 * p : p) * Ops::kLd + col0 + q;
         Ops::put(r0, sn);
         Ops::put(r0 + KD, cs);
@@ -691,8 +691,8 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
     constexpr int OPREGS = 2 * (MT * (int)sizeof(typename Ops::afrag) / 4 + NT * (int)sizeof(typename Ops::bfrag) / 4);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     act_t *act = (act_t *)smem;
-    float *hd = (float *)(act + ROWS * LD);  // [2][ROWS][3] partial colour dots
-    float *lp = hd + 2 * ROWS * 3;
+    float *hd = (float *)(act + ROWS * LD);  // [THREADS / ROWS][ROWS][3] partial colour dots
+    float *lp = hd + THREADS * 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
     if (tid == 0) {
@@ -790,14 +790,19 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
             epilogue_rt<MT, NT, ROWS4, Ops>(acc, act, NEDDF_ABL(a.sched_flags, 16384) ? 0 : a.activation, wave, lane);
             __syncthreads();
         }
-        // layer_col_out 256 -> 3 (neddf.py:257), no output activation; two k-halves per row
-        for (int idx = tid; idx < (NEDDF_ABL(a.sched_flags, 8192) ? 0 : 2 * ROWS); idx += THREADS) {
-            int half = idx / ROWS, row = idx - half * ROWS;
-            const act_t *ar = act + row * LD + half * (WID / 2);
-            const float *w = a.w_out + half * (WID / 2) * 3;
+        // layer_col_out 256 -> 3 (neddf.py:257), no output activation.  Every thread works: NPART = THREADS / ROWS threads share a
+        // row, each over WID / NPART consecutive features.  With 64-row tiles the part index is the wave index, so the weights are
+        // wave-uniform (scalar loads, SGPR operands) instead of one vector load per multiply-add; the 128 idle threads and those
+        // loads made this head 2.8 % of the kernel (profiles/r03_col_ablation.txt)
+        constexpr int NPART = THREADS / ROWS, KPART = WID / NPART;
+        static_assert(NPART >= 1 && NPART * ROWS == THREADS && KPART % 4 == 0, "the colour head splits a row over THREADS / ROWS threads");
+        if (!NEDDF_ABL(a.sched_flags, 8192)) {
+            const int part = ROWS == 64 ? __builtin_amdgcn_readfirstlane(wave) : tid / ROWS, row = tid - (tid / ROWS) * ROWS;
+            const act_t *ar = act + row * LD + part * KPART;
+            const float *w = a.w_out + part * KPART * 3;
             float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll 4
-            for (int k = 0; k < WID / 8; ++k) {
+            for (int k = 0; k < KPART / 4; ++k) {
                 float x[4];
                 Ops::load4(ar + 4 * k, x);
 #pragma unroll
@@ -807,7 +812,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
                     c2 = fmaf(x[u], w[(4 * k + u) * 3 + 2], c2);
                 }
             }
-            hd[idx * 3 + 0] = c0; hd[idx * 3 + 1] = c1; hd[idx * 3 + 2] = c2;
+            hd[tid * 3 + 0] = c0; hd[tid * 3 + 1] = c1; hd[tid * 3 + 2] = c2;
         }
         __syncthreads();
         if (tid < P && p0 + tid < a.n_points) {
@@ -816,8 +821,12 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
 #pragma unroll
             for (int r = 0; r < RPP; ++r)
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    c[r][k] = hd[(RPP * tid + r) * 3 + k] + hd[(ROWS + RPP * tid + r) * 3 + k] + (r == 0 ? a.b_out[k] : 0.f);
+                for (int k = 0; k < 3; ++k) {
+                    float sum = (r == 0 ? a.b_out[k] : 0.f);
+#pragma unroll
+                    for (int q = 0; q < NPART; ++q) sum += hd[(q * ROWS + RPP * tid + r) * 3 + k];
+                    c[r][k] = sum;
+                }
             if (a.final_act >= 0)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) c[0][k] = act_val_rt(a.final_act, c[0][k]);
@@ -1062,7 +1071,11 @@ void launch_linear_grad(const float *x, const float *J, int64_t n, int cin, int 
 
 // ----------------------------------------------------------------------------
 template <class Ops>
-static size_t lds_bytes(int mt) { return (size_t)mt * 32 * Ops::kLd * sizeof(typename Ops::act_t) + (size_t)(2 * mt * 32 * 3 + 16) * sizeof(float); }
+static size_t lds_bytes(int mt)      // the tile + the kernels' small scratch behind it: 6 floats per row (head dot products) or 3 per thread (8 waves at most), + 16
+{
+    const size_t small = (size_t)(2 * mt * 32 * 3) > (size_t)(3 * 512) ? (size_t)(2 * mt * 32 * 3) : (size_t)(3 * 512);
+    return (size_t)mt * 32 * Ops::kLd * sizeof(typename Ops::act_t) + (small + 16) * sizeof(float);
+}
 size_t field_lds_bytes(int mt) { return lds_bytes<OpsF32>(mt); }
 
 // Tile geometry (MT, WPS, NW) per operand policy -- see ddf_trunk_kernel.
