@@ -346,6 +346,9 @@ __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], type
                                                      int lane, int ymask)
 {
     constexpr int LD = Ops::kLd;
+    constexpr bool MASK = KIND != 2 && !LAST;       // ReLU / LeakyReLU: y' leaves as one bit per element, built on the fly
+    constexpr int NMW = (MT * NT + 1) / 2;
+    unsigned mbits[MASK ? NMW : 1] = { 0 };
     const int j = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -366,7 +369,8 @@ __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], type
                     act_grad<KIND, Ops::kFastAct>(z, y[u], dy);
                     // y' replaces the accumulator (LAST: the seed of the reverse pass, dz_D / dz_L).  The stashed copy carries the
                     // weight scale's inverse (a power of two: exact), so the reverse epilogue is one multiply per element
-                    acc[mt][t][q + u] = LAST ? ws * dy : dy * (1.0f / Ops::kWScale);
+                    if constexpr (MASK) mbits[(mt * NT + t) / 2] |= (dy == 1.0f ? 1u : 0u) << (16 * ((mt * NT + t) & 1) + q + u);
+                    else acc[mt][t][q + u] = LAST ? ws * dy : dy * (1.0f / Ops::kWScale);
                 }
                 Ops::put2(o + r * LD, o + (r + 1) * LD, y[0], y[1]);
             }
@@ -375,21 +379,40 @@ __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], type
     // same lanes read it back, so nothing needs it row-major.  Under the bf16 policy it travels as bf16 (the product it enters
     // is rounded to bf16 anyway): at that policy's speed the fp32 round trip (26 GB per launch) would be the kernel's bound
     if (!LAST && (!kAblate || yp)) {
-        if constexpr (Ops::kStash16) stash_store16<MT, NT>(acc, yp, wave, lane, ymask);
-        else stash_store<MT, NT>(acc, yp, wave, lane, ymask);
+        if constexpr (KIND == 2) {
+            if constexpr (Ops::kStash16) stash_store16<MT, NT>(acc, yp, wave, lane, ymask);
+            else stash_store<MT, NT>(acc, yp, wave, lane, ymask);
+        } else {
+            // ReLU / LeakyReLU: y' takes two values, so ONE BIT per element travels (16 per accumulator tile, two tiles per
+            // dword: 8 bytes per lane and layer instead of 256) -- 12 KB per workgroup for six layers, 6 MB per launch grid: it
+            // never leaves the L2, where the value-carrying round trip of tanhExp is 26 GB of HBM traffic per 2^21-point launch
+            unsigned *dst = (unsigned *)yp + (size_t)wave * NMW * 64 + lane;
+#pragma unroll
+            for (int w = 0; w < NMW; ++w) dst[w * 64] = mbits[w];
+        }
     }
 }
 
-template <bool LAST, int MT, int NT, class Ops>
+// y' of a ReLU (slope 0) / LeakyReLU (slope 0.01) layer from its mask bit, with the weight scale's inverse folded in like the stashed values
+template <class Ops>
+__device__ __forceinline__ float mask_factor(unsigned bit, int kind)
+{
+    constexpr float inv = 1.0f / Ops::kWScale;
+    return bit ? inv : (kind == 1 ? 0.01f * inv : 0.0f);
+}
+
+// MASKY kernels serve ReLU / LeakyReLU (y' as mask bits), the others tanhExp (y' as values): each carries only its own epilogues
+template <bool LAST, bool MASKY, int MT, int NT, class Ops>
 __device__ __forceinline__ void rev_forward_epilogue_rt(f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *yp, const float *wseed, int kind,
                                                         int wave, int lane, int ymask = -1)
 {
-    if (kind == 0) rev_forward_epilogue<0, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane, ymask);
-    else if (kind == 1) rev_forward_epilogue<1, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane, ymask);
-    else rev_forward_epilogue<2, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane, ymask);
+    if constexpr (MASKY) {
+        if (kind == 0) rev_forward_epilogue<0, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane, ymask);
+        else rev_forward_epilogue<1, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane, ymask);
+    } else rev_forward_epilogue<2, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane, ymask);
 }
 
-template <int MT, int NW, int WPS, class Ops>
+template <int MT, int NW, int WPS, class Ops, bool MASKY>
 __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const DdfArgs a)
 {
     typedef typename Ops::act_t act_t;
@@ -424,6 +447,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
     // (footprint / 6), 512 = and every M-tile folds onto the first (footprint / 12: L2-resident), 256 = no y' traffic at all
     const int ylstep = NEDDF_ABL(a.sched_flags, 128) ? 0 : 1, ymask = NEDDF_ABL(a.sched_flags, 512) ? 0 : -1;
     const bool ynone = NEDDF_ABL(a.sched_flags, 256);
+    constexpr bool masked = MASKY;                  // ReLU / LeakyReLU: y' is one bit per element (rev_forward_epilogue)
 
     int *ctl = (int *)(lp + 12);
     int64_t tile = sched_begin(a.sched, a.sched_flags, ctl, tid);
@@ -478,8 +502,8 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             }
             if (l + 1 < a.n_layers) layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
             __syncthreads();
-            if (l + 1 < a.n_layers) rev_forward_epilogue_rt<false, MT, NT, Ops>(acc, act, ynone ? nullptr : yp + (size_t)(l * ylstep) * ROWS * WID, nullptr, a.activation, wave, lane, ymask);
-            else rev_forward_epilogue_rt<true, MT, NT, Ops>(acc, act, nullptr, a.w_ddf_out, a.activation, wave, lane);
+            if (l + 1 < a.n_layers) rev_forward_epilogue_rt<false, MASKY, MT, NT, Ops>(acc, act, ynone ? nullptr : yp + (size_t)(l * ylstep) * ROWS * WID, nullptr, a.activation, wave, lane, ymask);
+            else rev_forward_epilogue_rt<true, MASKY, MT, NT, Ops>(acc, act, nullptr, a.w_ddf_out, a.activation, wave, lane);
             __syncthreads();
         }
         // ---- heads on the features (value only: the distance gradient comes from the reverse pass, the aux gradient's own
@@ -574,7 +598,30 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
                 }
             };
             acc_init<MT, NT, false>(acc, nullptr, wave, lane);
+            constexpr int NMW = (MT * NT + 1) / 2;
+            unsigned mw[NMW];
+            if constexpr (masked) {     // ReLU / LeakyReLU: the layer's mask bits (rev_forward_epilogue), requested ahead of the product
+                const unsigned *msrc = (const unsigned *)(yp + (size_t)((l - 1) * ylstep) * ROWS * WID) + (size_t)wave * NMW * 64 + lane;
+#pragma unroll
+                for (int w = 0; w < NMW; ++w) mw[w] = msrc[w * 64];
+            }
             dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
+            if constexpr (masked) {
+                __syncthreads();        // every wave finished reading g_l
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
+                        const unsigned bits = mw[(mt * NT + t) / 2] >> (16 * ((mt * NT + t) & 1));
+#pragma unroll
+                        for (int q = 0; q < 16; q += 2)
+                            Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD,
+                                      acc[mt][t][q] * mask_factor<Ops>((bits >> q) & 1u, a.activation),
+                                      acc[mt][t][q + 1] * mask_factor<Ops>((bits >> (q + 1)) & 1u, a.activation));
+                    }
+                __syncthreads();
+            } else {
             load_y(yb[0], 0);
             if (MT > 1) load_y(yb[1], 1);
             __syncthreads();            // every wave finished reading g_l
@@ -591,6 +638,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
                 if (mt + 2 < MT) load_y(yb[mt & 1], mt + 2);
             }
             __syncthreads();
+            }
         }
         f32x16 gpe[BPW][1];
 #pragma unroll
@@ -1211,9 +1259,12 @@ void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
 template <int MT, int NW, int WPS, class Ops>
 static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s)
 {
-    static bool once = (set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops>, lds_bytes<Ops>(MT)), true);
+    static bool once = (set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, false>, lds_bytes<Ops>(MT)),
+                        set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, true>, lds_bytes<Ops>(MT)), true);
     (void)once;
-    hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a);
+    // tanhExp: y' round trip as values; ReLU / LeakyReLU: as mask bits (the kernel's header)
+    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, false>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a);
+    else hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, true>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a);
 }
 
 int ddf_rev_points(int, int width) { return width == 256 ? 64 : geo_w(width).mt * 32; }
