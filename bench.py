@@ -87,10 +87,13 @@ def network_config(width=256):
                                        cfg["col_layer_count"], width, tuple(cfg["skips"]), seed=7))
 
 
-def build_render(dev, width=256):
+def build_render(dev, width=256, activation=None):
+    """activation (probes only): another hidden activation on the same weights, e.g. "ReLU" to measure the mask-bit y' path."""
     import neddf_amd
     from neddf_amd.fixtures import BUNNY_SMOKE_RENDER
     net_cfg, wts = network_config(width)
+    if activation:
+        net_cfg = dict(net_cfg, activation_type=activation)
     render = neddf_amd.NeRFRender(dict(net_cfg, _target_="neddf.network.NeDDF"), **BUNNY_SMOKE_RENDER)
     render.network_fine.load_state_dict({k: torch.from_numpy(v) for k, v in wts.items()})
     render.to(dev)
@@ -524,7 +527,9 @@ def main():
             # HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             want = "ddf_rev_kernel" if reverse else "ddf_trunk_kernel"
-            ent = next(v for k, v in pmc.items() if want in k and ("OpsBF16" in k) == (args.dtype == "bf16"))
+            masked = render.bench_network_config["activation_type"] != "tanhExp"      # ReLU / LeakyReLU: the mask-bit kernel
+            ent = next(v for k, v in pmc.items() if want in k and ("OpsBF16" in k) == (args.dtype == "bf16")
+                       and (want != "ddf_rev_kernel" or k.rstrip(">").endswith("true") == masked))
             line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
             line["roofline"]["traffic_source"] = "static: %s (a committed rocprofv3 --pmc pass of this kernel and launch size, not measured in this run)" % ent["source"]
             line["roofline"]["algorithmic_hbm_bytes_per_launch"] = ent["algorithmic_bytes_per_launch"]

@@ -621,6 +621,84 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     const Field &f = ctx->field[slot];
     const int act = f.d.activation;
     const int sp = f.d.weight_dtype == NEDDF_DTYPE_F16_SPLIT;      // GEMM operands as two fp16 terms (tile_engine.h)
+    // fp32 MFMA policy: the input-gradient chain of each layer stack is ONE kernel (train_kernels.h MlpBackwardArgs); every dZ_l keeps
+    // its own matrix for the weight-gradient products.  NEDDF_TRAIN_UNFUSED=1 and the split-fp16 policy take the per-layer route below.
+    static const bool unfused = [] { const char *e = getenv("NEDDF_TRAIN_UNFUSED"); return e && atoi(e) != 0; }();
+    if (!sp && !unfused) {
+        const int nT = p.n_trunk, nC = p.n_col;
+        const size_t slot = (size_t)p.R * kWidth;
+        if (int rc = ensure(ctx, ctx->tpack, (size_t)(nT + nC) * kPackFloats * sizeof(float))) return rc;
+        if (int rc = ensure(ctx, ctx->ttmp, ((size_t)(nT + nC + 1) * slot + (size_t)p.R * 2 * kLdNarrow) * sizeof(float))) return rc;
+        float *tb = (float *)ctx->ttmp.p, *pack_at = (float *)ctx->tpack.p;
+        auto dZc = [&](int l) { return tb + (size_t)l * slot; };
+        auto dZt = [&](int l) { return tb + (size_t)(nC + l) * slot; };
+        float *dFeat = tb + (size_t)(nC + nT) * slot, *GZH = dFeat + slot, *GCR = GZH + (size_t)p.R * kLdNarrow;
+        auto next_pack = [&]() { float *r = pack_at; pack_at += kPackFloats; return r; };
+        const float *PEs = ws + p.o_pes;
+        TrainPointArgs a;
+        point_args(a, f, p, ws);
+        a.g_distance = g_distance; a.g_density = g_density; a.g_color = g_color; a.g_penalty = g_penalty; a.g_aux = g_aux_grad;
+        a.GZH = GZH; a.GCR = GCR;
+        launch_point_backward(a, s);
+        // colour head: LinearGradFunction.backward (linear.py:62-88) on [HC | JC] rows, then the last colour activation
+        NarrowW cout{};
+        cout.nc = 3; cout.wstride = 3; cout.kcount = kWidth;
+        for (int c = 0; c < 3; ++c) cout.w[c] = W[p.i_cout] + c;
+        const float *HClast = ws + p.o_hc[nC - 1], *Hlast = ws + p.o_h[nT - 1];
+        launch_narrow_backward_act(GCR, kLdNarrow, p.R, cout, nullptr, 0, act, 4, ws + p.o_zc[nC - 1], dZc(nC - 1), kWidth, s, nullptr);
+        {
+            float *wc[3] = { gW[p.i_cout], gW[p.i_cout] + 1, gW[p.i_cout] + 2 }, *bc[3] = { gB[p.i_cout], gB[p.i_cout] + 1, gB[p.i_cout] + 2 };
+            launch_narrow_dw(HClast, kWidth, GCR, kLdNarrow, p.R, 3, wc, 3, bc, 4, kWidth, s);
+        }
+        {   // colour trunk: dZ of every layer in one kernel
+            MlpBackwardArgs m{};
+            m.R = p.R; m.dZtop = dZc(nC - 1); m.n_layers = nC; m.act_kind = act;
+            for (int l = 1; l < nC; ++l) {
+                float *wl = next_pack();
+                launch_pack(0, W[nT + l], 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wl, s);             // W_l^T
+                m.wT[l] = wl; m.Z[l - 1] = ws + p.o_zc[l - 1]; m.dZ[l - 1] = dZc(l - 1);
+            }
+            launch_mlp_backward(m, ctx->cus, s);
+        }
+        for (int l = nC - 1; l >= 1; --l)
+            launch_dw(0, ws + p.o_hc[l - 1], kWidth, kWidth, dZc(l), kWidth, p.R, gW[nT + l], kWidth, 1, kWidth, gB[nT + l], 4, ctx->cus, s);
+        launch_dw(0, ws + p.o_xa, p.ldxa, p.Ca, dZc(0), kWidth, p.R, gW[nT], kWidth, 1, kWidth, gB[nT], 4, ctx->cus, s);
+        launch_dw(0, Hlast, kWidth, kWidth, dZc(0), kWidth, p.R, gW[nT] + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s);
+        {   // the small colour inputs (encodings, detached normal) carry no parameters: only the feature segment propagates
+            float *wl = next_pack();
+            launch_pack(0, W[nT], 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wl, s);                  // (feature rows of W)^T
+            launch_rows_gemm(0, dZc(0), p.R, kWidth, kWidth, wl, gemm_ksteps(kWidth, 0), nullptr, 4, dFeat, kWidth, 0, -1, nullptr, ctx->cus, s);
+        }
+        // dFeat = gradient of the trunk features from the colour trunk; add the distance / aux heads, then the last trunk activation
+        NarrowW heads{};
+        heads.nc = 2; heads.wstride = 1; heads.kcount = kWidth;
+        heads.w[0] = W[p.i_ddf]; heads.w[1] = W[p.i_aux];
+        launch_narrow_backward_act(GZH, kLdNarrow, p.R, heads, dFeat, 1, act, 4, ws + p.o_z[nT - 1], dZt(nT - 1), kWidth, s, nullptr);
+        {
+            float *wh[2] = { gW[p.i_ddf], gW[p.i_aux] }, *bh[2] = { gB[p.i_ddf], gB[p.i_aux] };
+            launch_narrow_dw(Hlast, kWidth, GZH, kLdNarrow, p.R, 2, wh, 1, bh, 4, kWidth, s);
+        }
+        {   // distance trunk
+            MlpBackwardArgs m{};
+            m.R = p.R; m.dZtop = dZt(nT - 1); m.n_layers = nT; m.act_kind = act;
+            for (int l = 1; l < nT; ++l) {
+                const bool wide = in_skips(f.d, l - 1);
+                float *wl = next_pack();
+                launch_pack(0, W[l], 1, kWidth, 0, wide ? p.Cpe : 0, kWidth, kWidth, kWidth, wl, s);   // (hidden rows of W_l)^T
+                m.wT[l] = wl; m.Z[l - 1] = ws + p.o_z[l - 1]; m.dZ[l - 1] = dZt(l - 1);
+            }
+            launch_mlp_backward(m, ctx->cus, s);
+        }
+        for (int l = nT - 1; l >= 0; --l) {
+            const bool wide = l > 0 && in_skips(f.d, l - 1);
+            if (l == 0 || wide) launch_dw(0, PEs, kLdPe, p.Cpe, dZt(l), kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s);
+            if (l > 0)
+                launch_dw(0, ws + p.o_h[l - 1], kWidth, kWidth, dZt(l), kWidth, p.R, gW[l] + (size_t)(wide ? p.Cpe : 0) * kWidth, kWidth, 1, kWidth,
+                          wide ? nullptr : gB[l], 4, ctx->cus, s);
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ttmp, (size_t)p.R * (2 * kWidth + 2 * kLdNarrow) * sizeof(float))) return rc;
     float *wp = (float *)ctx->tpack.p;

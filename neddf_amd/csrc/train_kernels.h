@@ -71,6 +71,26 @@ struct MlpForwardArgs {
 };
 void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t s);
 
+// Input-gradient chain of a whole stack of (value, Jacobian)-row layers in ONE kernel (round 3), the mirror image of
+// launch_mlp_forward: the 64-row tile of gradients stays in LDS from the top layer down,
+//   dZ_{l-1} = act_backward(Z_{l-1}; dZ_l x (hidden rows of W_l)^T)          l = n_layers-1 .. 1
+// (LinearGradFunction.backward linear.py:62-74 followed by the activation's backward, e.g. tanh_exp.py:57-88), and every dZ_l
+// is left in its own [R, 256] matrix for the weight-gradient products that follow.  Per row and layer the chain reads Z_{l-1}
+// and writes dZ_{l-1} (2 KB) where one GEMM kernel per layer also re-read dZ_l (3 KB), and there is no per-layer launch, fill and
+// drain.  The activation backward runs on the accumulators themselves: in the 32x32 layout a lane holds the four rows of a point
+// for one feature, and Z_{l-1} is requested in that layout before the product.  fp32 MFMA operands (the split-fp16 policy
+// keeps the per-layer route: its gradient operands are range-scaled per matrix).
+struct MlpBackwardArgs {
+    int64_t R;
+    const float *dZtop;                   // [R, 256]: gradient of the top layer's pre-activations
+    int n_layers;
+    const float *wT[kMaxLayers];          // [l >= 1] packed (hidden rows of W_l)^T, 256 x 256
+    const float *Z[kMaxLayers];           // pre-activations [R, 256]; l = 0 .. n_layers-2 are read
+    float *dZ[kMaxLayers];                // outputs [R, 256], l = 0 .. n_layers-2
+    int act_kind;                         // backward kind of act_grad2 (0 ReLU, 1 LeakyReLU, 2 tanhExp, 3 tanhExp as NeuS differentiates it)
+};
+void launch_mlp_backward(const MlpBackwardArgs &a, int cus, hipStream_t s);
+
 // dW[k * sk + n * sn] += sum_r X[r, k] G[r, n], k < K <= 256, n < nvalid <= 256; db[n] += sum over rows r % bias_period == 0 of G[r, n]
 // dZ[R,256] = activation backward (pre-activations Zprev, row period, kind) of X[R, 0:kload) x Wpacked: the input-gradient GEMM of
 // a layer fused with the backward of the previous layer's activation

@@ -433,6 +433,102 @@ void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t
 }
 
 // ----------------------------------------------------------------------------
+// Fused input-gradient chain of a layer stack (train_kernels.h MlpBackwardArgs): see the header.  64-row tiles, two workgroups
+// per CU, fp32 MFMA.
+template <int KIND>
+__device__ __forceinline__ void mlp_backward_epilogue(const f32x16 (&acc)[2][2], const f32x16 (&zp)[2][2], float *act, float *dZl, int64_t r0,
+                                                      int64_t R, int wave, int lane)
+{
+    constexpr int MT = 2, NT = 2, LD = OpsF32::kLd;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t base = (r0 + 4 * h) * kWidth + wave * NT * 32 + j;
+    float *gb = dZl + base;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // rows 8 g + 4 h + {0, 1, 2, 3} of the tile = (value, d/dx, d/dy, d/dz) of one point, one feature
+                float dy, d2;
+                act_grad2<KIND>(zp[mt][t][4 * g], dy, d2);
+                const float g0 = acc[mt][t][4 * g], g1 = acc[mt][t][4 * g + 1], g2 = acc[mt][t][4 * g + 2], g3 = acc[mt][t][4 * g + 3];
+                float sj = g1 * zp[mt][t][4 * g + 1];
+                sj += g2 * zp[mt][t][4 * g + 2];
+                sj += g3 * zp[mt][t][4 * g + 3];
+                const float ov[4] = { g0 * dy + sj * d2, g1 * dy, g2 * dy, g3 * dy };
+                const int off = (mt * 32 + 8 * g) * kWidth + t * 32;
+                if (r0 + mt * 32 + 8 * g + 4 * h < R) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gb[off + r * kWidth] = ov[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[(8 * g + r) * LD] = ov[r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBackwardArgs a)
+{
+    typedef OpsF32 Ops;
+    typedef typename Ops::bfrag frag;
+    constexpr int MT = 2, NT = 2, ROWS = MT * 32, LD = Ops::kLd, KS = kWidth / Ops::kStep;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *act = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *act_lane = act_lane_ptr<Ops>(act, lane);
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t ntiles = (a.R + ROWS - 1) / ROWS;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * ROWS;
+        __syncthreads();                // the previous tile is done with the LDS tile
+        for (int idx = tid; idx < ROWS * (kWidth / 4); idx += kThreads) {
+            const int r = idx >> 6, c = idx & 63;
+            f32x4v v = { 0.f, 0.f, 0.f, 0.f };
+            if (r0 + r < a.R) v = *(const f32x4v *)(a.dZtop + (r0 + r) * kWidth + 4 * c);
+            *(f32x4v *)(act + r * LD + 4 * c) = v;
+        }
+        __syncthreads();
+        for (int l = a.n_layers - 1; l >= 1; --l) {
+            // Z_{l-1} of this lane's accumulator positions, requested before the product (rows past R: zero; R is a multiple of 4)
+            f32x16 zp[MT][NT];
+            const float *zb = a.Z[l - 1] + (r0 + 4 * h) * kWidth + wave * NT * 32 + j;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const bool in = r0 + mt * 32 + 8 * g + 4 * h < a.R;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zp[mt][t][4 * g + r] = in ? zb[(mt * 32 + 8 * g + r) * kWidth + t * 32] : 0.f;
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc[MT][NT];
+            acc_init<MT, NT, false>(acc, nullptr, wave, lane);
+            dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
+            __syncthreads();            // every wave finished reading dZ_l
+            if (a.act_kind == 0) mlp_backward_epilogue<0>(acc, zp, act, a.dZ[l - 1], r0, a.R, wave, lane);
+            else if (a.act_kind == 1) mlp_backward_epilogue<1>(acc, zp, act, a.dZ[l - 1], r0, a.R, wave, lane);
+            else if (a.act_kind == 2) mlp_backward_epilogue<2>(acc, zp, act, a.dZ[l - 1], r0, a.R, wave, lane);
+            else mlp_backward_epilogue<3>(acc, zp, act, a.dZ[l - 1], r0, a.R, wave, lane);
+            if (l > 1) __syncthreads(); // the next layer reads what this epilogue wrote
+        }
+    }
+}
+
+void launch_mlp_backward(const MlpBackwardArgs &a, int cus, hipStream_t s)
+{
+    if (a.R <= 0 || a.n_layers < 2) return;
+    constexpr size_t lds = (size_t)64 * OpsF32::kLd * sizeof(float);
+    static bool once = ((void)hipFuncSetAttribute((const void *)mlp_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    const int64_t tiles = (a.R + 63) / 64;
+    hipLaunchKernelGGL(mlp_backward_kernel, dim3((unsigned)(tiles < 2 * cus ? tiles : 2 * cus)), dim3(kThreads), lds, s, a);
+}
+
+// ----------------------------------------------------------------------------
 // dW[K, 256] += X[R, 0:K]^T x G[R, 0:256], db[n] += sum over rows r % bias_period == 0 of G[r, n]
 // (LinearGradFunction.backward, linear.py:75-82: x^T dLdy + J^T dLdG is one product over the stacked value + Jacobian rows).
 // Each workgroup owns a contiguous range of rows and the WHOLE K x 256 output in accumulators (wave w: all K-tiles x output

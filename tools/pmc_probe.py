@@ -15,7 +15,7 @@ import numpy as np  # noqa: E402
 import math  # noqa: E402
 
 dev = torch.device("cuda:0")
-render, _ = bench.build_render(dev)
+render, _ = bench.build_render(dev, activation=os.environ.get("NEDDF_PROBE_ACT"))      # NEDDF_PROBE_ACT=ReLU: y' travels as mask bits
 render.network_fine.weight_dtype = os.environ.get("NEDDF_PROBE_DTYPE", "fp32")      # "bf16": the configs[4] kernels
 fx = 0.5 * 800 / math.tan(0.5 * bench.CAMERA_ANGLE_X)
 R, T = bench.view_pose(0)
