@@ -103,6 +103,28 @@ def build_render(dev, width=256, activation=None):
     return render, wts
 
 
+def host_cpu_limits():
+    """What the process may actually use of the host: scheduler affinity and the cgroup CPU quota (a container often sees every
+    logical CPU of the box in os.cpu_count() while its quota is a fraction of them -- which is where an OpenMP sweep stops scaling)."""
+    info = {"logical_cpus": os.cpu_count()}
+    try:
+        info["sched_affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                info["cgroup_cpu_quota"] = "unlimited" if txt[0] == "max" else round(int(txt[0]) / int(txt[1]), 2)
+            else:
+                q = int(txt[0])
+                info["cgroup_cpu_quota"] = "unlimited" if q < 0 else round(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()), 2)
+            break
+        except Exception:
+            continue
+    return info
+
+
 def cpu_baseline(weights, net_cfg, R, T, calib, budget_s=20.0):
     """The path on the host cores, on a bounded sample of the same workload (rank 0, N = 1).  Two CPU implementations are timed:
     `value` = oracle/neddf_cpu_fast.c, the SAME algorithm as the HIP path (eval-minimal: value rows forward, reverse-mode
@@ -133,7 +155,7 @@ def cpu_baseline(weights, net_cfg, R, T, calib, budget_s=20.0):
     for th in sorted({avail, max(avail // 2, 1), max(avail // 4, 1), min(avail, 64), min(avail, 32), min(avail, 16), min(avail, 8)}, reverse=True):
         lib.orc_set_num_threads(th)
         one_pass(2 * th, True)                        # warm the thread pool
-        sweep[th] = one_pass(max(512, 16 * th), True)
+        sweep[th] = one_pass(max(2048, 48 * th), True)      # large enough that the per-call weight packing and page faults do not decide the sweep
     best = max(sweep, key=sweep.get)
     lib.orc_set_num_threads(best)
     remaining = max(3.0, 0.6 * budget_s - (time.perf_counter() - t_start))
@@ -151,7 +173,8 @@ def cpu_baseline(weights, net_cfg, R, T, calib, budget_s=20.0):
     aw_rate = one_pass(aw_rays, False)
     lib.orc_set_num_threads(avail)
     _, flop_rev, flop_col = field_flops(net_cfg)
-    return {"value": rate, "unit": "rays/s", "cores": best, "host_logical_cpus": os.cpu_count(), "openmp_max_threads": avail, "kind": "port",
+    return {"value": rate, "unit": "rays/s", "cores": best, "host_logical_cpus": os.cpu_count(), "host": host_cpu_limits(), "openmp_max_threads": avail,
+            "kind": "port",
             "simd": "avx512" if int(lib.fast_uses_avx512()) else "avx2",
             "flop_per_point": flop_rev + flop_col,
             "achieved_gflops": rate * SAMPLES * (flop_rev + flop_col) / 1e9,
