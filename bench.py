@@ -540,7 +540,10 @@ def main():
                          "forward_mode_equivalent_tflops": (pts * flop_fwd / ddf_s / 1e12) if ddf_s > 0 else 0.0,
                          "colour_kernel": {"avg_launch_ms": tm["col_ms"] / max(tm["col_launches"], 1),
                                            "flop_per_point": flop_col,
-                                           "achieved": (pts * flop_col / (tm["col_ms"] / 1e3) / 1e12) if tm["col_ms"] > 0 else 0.0}},
+                                           # the hierarchical workloads skip the colour trunk on the coarse pass (its colours are not an output)
+                                           "points_per_ray": SAMPLES if args.workload == "c2" else 194,
+                                           "achieved": ((pts if args.workload == "c2" else n_rays * 194 * args.steps) * flop_col / (tm["col_ms"] / 1e3) / 1e12)
+                                                       if tm["col_ms"] > 0 else 0.0}},
             # every stage kernel of the timed region (HIP events on its stream): summed ms per step and launches per step
             "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stage.items() if v[1]},
         }
