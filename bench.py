@@ -326,6 +326,9 @@ def main():
                     help="operand type of the 256-wide layers (default f32 = fp32 MFMA; c5 defaults to bf16; f16_split = fp32 data, "
                          "operands split into two fp16 terms, three fp16 MFMAs per multiply-add)")
     args = ap.parse_args()
+    # dmabuf IPC for RCCL / cross-process device memory (the host driver supports nothing else): must be in the environment before
+    # the HIP runtime initialises, i.e. before the first torch.cuda call below
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.dtype is None:
         args.dtype = "bf16" if args.workload == "c5" else "f32"
     global WIDTH, HEIGHT

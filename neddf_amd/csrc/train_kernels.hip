@@ -559,19 +559,46 @@ __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, in
             for (int q = 0; q < 16; ++q) acc[kt][t][q] = 0.f;
     f32x4v bsum = { 0.f, 0.f, 0.f, 0.f };       // this thread's share of db: columns 4 (tid & 63) .. +3
     f32x4v xp[XPF], gp[GPF];
+    // Which 16-byte pieces of a 32-row chunk this thread stages never changes: its element offsets from the chunk's first row are
+    // computed once (-1: a padding column of X), and a FULL chunk is fetched with one 64-bit base per matrix and those offsets.
+    // Per chunk the index arithmetic, three bounds tests and the 64-bit address of every piece had been ~370 vector
+    // instructions per wave in front of 256 MFMAs, with nothing to overlap them at one wave per SIMD (PMC: 1.45 per MFMA).
+    int xoff[XPF], goff[GPF];
+#pragma unroll
+    for (int i = 0; i < XPF; ++i) {
+        const int idx = tid + i * kThreads, r = idx / (KP / 4), c = idx - r * (KP / 4);
+        xoff[i] = (r < RC && c < k4) ? r * ldx + 4 * c : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < GPF; ++i) {
+        const int idx = tid + i * kThreads;
+        goff[i] = (idx >> 6) * ldg + 4 * (idx & 63);
+    }
     auto fetch = [&](int64_t c0) {
+        const float *xb = X + c0 * ldx, *gb = G + c0 * ldg;
+        if (c0 + RC <= re) {            // a full chunk: no row tests
+#pragma unroll
+            for (int i = 0; i < XPF; ++i) {
+                f32x4v v = { 0.f, 0.f, 0.f, 0.f };
+                if (xoff[i] >= 0) v = *(const f32x4v *)(xb + xoff[i]);
+                xp[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < GPF; ++i) gp[i] = *(const f32x4v *)(gb + goff[i]);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < XPF; ++i) {
-            int idx = tid + i * kThreads, r = idx / (KP / 4), c = idx - r * (KP / 4);
+            int idx = tid + i * kThreads, r = idx / (KP / 4);
             f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-            if (r < RC && c < k4 && c0 + r < re) v = *(const f32x4v *)(X + (c0 + r) * ldx + 4 * c);
+            if (xoff[i] >= 0 && c0 + r < re) v = *(const f32x4v *)(xb + xoff[i]);
             xp[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < GPF; ++i) {
-            int idx = tid + i * kThreads, r = idx >> 6, c = idx & 63;
+            int idx = tid + i * kThreads, r = idx >> 6;
             f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-            if (c0 + r < re) v = *(const f32x4v *)(G + (c0 + r) * ldg + 4 * c);
+            if (c0 + r < re) v = *(const f32x4v *)(gb + goff[i]);
             gp[i] = v;
         }
     };
@@ -596,18 +623,36 @@ __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, in
         __syncthreads();
         if (c0 + RC < re) fetch(c0 + RC);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 4
-        for (int rp = 0; rp < RC / 2; ++rp) {
-            const int r = 2 * rp + h;
-            float b0 = Gs[r * LDG + n0 + j], b1 = Gs[r * LDG + n0 + 32 + j];
-            float a[KT];
+        // Software pipeline over the row pairs of the chunk: the operands of pair rp + 1 (KT + 2 LDS reads) are requested before the
+        // 2 KT MFMAs of pair rp issue.  Left to itself hipcc reads each pair of k-tiles right in front of its four MFMAs and waits
+        // (`ds_read2_b32; s_waitcnt lgkmcnt(0)` every 4 MFMAs: the LDS latency of 16 loads per chunk row pair, un-overlapped with
+        // one wave per SIMD) -- the kernel streamed at 68 % of the matrix peak (PMC: 1.45 vector instructions per MFMA, matrix pipe
+        // busy 68 %)
+        const float *xr = Xs + h * LDX + j, *gr = Gs + h * LDG + n0 + j;
+        float a0[KT], a1[KT], b00, b01, b10, b11;
+        auto load_pair = [&](float (&a)[KT], float &b0, float &b1, int rp) {
+            b0 = gr[2 * rp * LDG]; b1 = gr[2 * rp * LDG + 32];
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) a[kt] = Xs[r * LDX + 32 * kt + j];
+            for (int kt = 0; kt < KT; ++kt) a[kt] = xr[2 * rp * LDX + 32 * kt];
+        };
+        auto mfma_pair = [&](const float (&a)[KT], float b0, float b1) {
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
                 acc[kt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], b0, acc[kt][0], 0, 0, 0);
                 acc[kt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], b1, acc[kt][1], 0, 0, 0);
             }
+        };
+        load_pair(a0, b00, b01, 0);
+#pragma unroll
+        for (int rp = 0; rp < RC / 2; rp += 2) {
+            load_pair(a1, b10, b11, rp + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_pair(a0, b00, b01);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rp + 2 < RC / 2) load_pair(a0, b00, b01, rp + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_pair(a1, b10, b11);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
