@@ -753,6 +753,41 @@ def test_width_and_rank_limits_fail_loudly(dev):
             net(s)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "f16_split"])
+def test_widest_engine_vs_oracle(dev, orc, dtype):
+    """Hidden width 512 (the widest engine: 32-row tiles, four column tiles per wave) and 448 (zero-padded to it) against the oracle --
+    no reference golden at these widths, the oracle is pinned at 128 .. 384 by the same code path.  NeDDF in both differentiation
+    modes and NeRF."""
+    import neddf_amd
+    pos, d, var = synth.random_sampling(5, 37, seed=9)
+    s = smp(dict(pos=pos, dir=d, var=var), dev)
+    for width in (512, 448):
+        kw = dict(embed_pos_rank=10, embed_dir_rank=4, ddf_layer_count=5, ddf_layer_width=width, col_layer_count=3, col_layer_width=width,
+                  d_near=0.01, activation_type="tanhExp", density_activation_type="ReLU", skips=[2], lowpass_alpha_offset=10)
+        sd = synth.neddf_state(10, 4, 5, width, 3, width, (2,), seed=3)
+        net = neddf_module(kw, sd, dev)
+        net.set_iter(-1)
+        net.weight_dtype = dtype
+        ref = orc.NeDDFOracle(sd, **kw).forward(pos, d, var)
+        for mode in ("full", "minimal"):
+            net.output_mode = mode
+            o = net(s)
+            for k in o:
+                assert_close(N(o[k]), ref[k], 1e-4, 2e-5 if k == "color" else 1e-5, "NeDDF %d %s %s %s" % (width, dtype, mode, k))
+        kn = dict(embed_pos_rank=10, embed_dir_rank=4, layer_count=5, layer_width=width, activation_type="ReLU", density_activation_type="ReLU",
+                  skips=[2], lowpass_alpha_offset=10)
+        sn = synth.nerf_state(10, 4, 5, width, (2,), seed=4)
+        nerf = neddf_amd.NeRF(**kn)
+        nerf.load_state_dict({k: torch.from_numpy(v) for k, v in sn.items()})
+        nerf.to(dev)
+        nerf.set_iter(-1)
+        nerf.weight_dtype = dtype
+        rn = orc.NeRFOracle(sn, **kn).forward(pos, d, var)
+        on = nerf(s)
+        for k in ("density", "color"):
+            assert_close(N(on[k]), rn[k], 1e-4, 2e-5, "NeRF %d %s %s" % (width, dtype, k))
+
+
 def test_c3_full_frame_hierarchical_properties(dev, bunny_weights):
     """BASELINE.json configs[2] at full size: all 640 000 rays of an 800x800 view through render_rays' hierarchical path
     (65 coarse + 129 importance samples).  Size-independent properties of the importance-resample kernel and the compositor:
