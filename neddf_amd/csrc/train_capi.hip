@@ -22,12 +22,13 @@ struct Plan {
 
 constexpr int kLdPe = 64, kLdDir = 32, kLdNarrow = 4;
 
-// The training kernels (train_kernels.hip) are built for the hidden width of every shipped configuration; rendering takes any
-// width up to 512 (neddf_set_field), training the others is refused loudly rather than computed wrongly.
+// The training kernels (train_kernels.hip) are built for the hidden width of every shipped configuration, 256.  Narrower networks
+// reach these entry points zero-padded to that width (neddf_amd/network.py _train_tensors: exact); wider ones (rendering takes up
+// to 512, neddf_set_field) are refused loudly rather than computed wrongly.
 int train_supported(neddf_ctx *ctx, const Field &f)
 {
     if (f.d.layer_width != kWidth || (f.d.kind != NEDDF_FIELD_NERF && f.d.col_layer_width != kWidth))
-        return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels are built for hidden width 256 (rendering supports 1..512)");
+        return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels are built for hidden width 256: pass narrower networks zero-padded to it (neddf_amd does), wider ones cannot train (rendering supports 1..512)");
     if (f.d.embed_dir_rank > 4) return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels take embed_dir_rank <= 4");
     return 0;
 }

@@ -62,6 +62,27 @@ class LinearGradLayer(nn.Module):
 
 _module_ids = itertools.count(1)
 
+TRAIN_ENGINE_WIDTH = 256        # hidden width of the training kernels (csrc/train_*.hip)
+
+
+def _pad_axis(t: Tensor, dim: int, segments) -> Tensor:
+    """Zero-pad consecutive segments of `t` along `dim`: segments = [(length, padded_length), ...] covering the axis.  Built
+    from narrow / cat, so the result carries the autograd graph back to `t` (the padding receives no gradient that matters:
+    it is sliced off on the way back)."""
+    if all(a == b for a, b in segments):
+        return t
+    parts, off = [], 0
+    for length, padded in segments:
+        piece = t.narrow(dim, off, length)
+        if padded > length:
+            shape = list(t.shape)
+            shape[dim] = padded - length
+            piece = torch.cat([piece, t.new_zeros(shape)], dim)
+        parts.append(piece)
+        off += length
+    assert off == t.shape[dim], (off, tuple(t.shape), dim)
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim)
+
 
 class BaseNeuralField(ABC, nn.Module):
     def __init__(self) -> None:
@@ -116,11 +137,38 @@ class BaseNeuralField(ABC, nn.Module):
             val = self.forward(Sampling(pos, d, torch.zeros_like(pos)))     # one call: no need to chunk on 288 GB
             return val[field_name].reshape(cube_resolution, cube_resolution, cube_resolution).cpu().numpy()
 
-    def upload(self, ctx: Context, slot: int, weights: bool = True) -> None:
-        """Pack + upload the parameters into `slot` if they changed since the last upload.  weights=False (training
-        step: the kernels read the live parameter tensors) only makes sure the slot describes this architecture."""
-        ws, bs = self._tensors()
+    # ---- training at hidden widths below 256 ------------------------------------------------------------------------
+    # The training kernels are built for hidden width 256.  A narrower network trains through them ZERO-PADDED: every
+    # parameter tensor is padded to the 256-wide architecture with differentiable torch ops (narrow / cat), the kernels see a
+    # 256-wide network, and autograd slices the parameter gradients back.  Exact: a padded unit has zero weights and bias, so
+    # it outputs a(0) = 0 under every activation of the reference, feeds zero weight rows downstream and receives a zero
+    # gradient; the real parameters' gradients are what the reference computes (tests/golden/train_widths.npz).  Widths above
+    # 256 are refused by the library (train_supported).
+    def _train_layout(self):
+        """None, or (weight layouts, bias layouts): per tensor, per axis, the [(length, padded_length)] segments."""
+        return None
+
+    def _train_tensors(self, ws, bs):
+        """(descriptor, weights, biases) the training kernels are called with."""
         desc = self._descriptor()
+        layout = self._train_layout()
+        if layout is None:
+            return desc, ws, bs
+        wl, bl = layout
+        pw = [w if lay is None else _pad_axis(_pad_axis(w, 0, lay[0]), 1, lay[1]) if w.dim() == 2 else _pad_axis(w, 0, lay[0])
+              for w, lay in zip(ws, wl)]
+        pb = [b if lay is None else _pad_axis(b, 0, lay[0]) for b, lay in zip(bs, bl)]
+        desc.layer_width = TRAIN_ENGINE_WIDTH
+        if desc.kind != FIELD_NERF:
+            desc.col_layer_width = TRAIN_ENGINE_WIDTH
+        return desc, pw, pb
+
+    def upload(self, ctx: Context, slot: int, weights: bool = True, train=None) -> None:
+        """Pack + upload the parameters into `slot` if they changed since the last upload.  weights=False (training
+        step: the kernels read the live parameter tensors) only makes sure the slot describes this architecture;
+        train = (descriptor, weights, biases) of _train_tensors when that is a zero-padded one."""
+        ws, bs = self._tensors() if train is None else (train[1], train[2])
+        desc = self._descriptor() if train is None else train[0]
         desc.weight_dtype = DTYPE[self.weight_dtype]
         sig = (self._uid, slot, bytes(desc), tuple((t.data_ptr(), t._version) for t in ws + bs), self._epoch)
         have = ctx.slot_owner.get(slot)
@@ -206,13 +254,33 @@ class NeDDF(BaseNeuralField):
     def _iter_state(self):
         return self.aux_grad_scale, self.distance_range_max, lowpass_scale(self.lowpass_alpha, self.pe_pos.embed_dim)
 
+    def _train_layout(self):
+        W, E = self.ddf_layer_width, TRAIN_ENGINE_WIDTH
+        if W >= E or self.col_layer_width != W:
+            return None
+        cpe, small = 6 * self.pe_pos.embed_dim, 6 * (self.pe_pos.embed_dim + self.pe_dir.embed_dim) + 3
+        hid, same = [(W, E)], lambda n: [(n, n)]
+        wl, bl = [], []
+        for l in range(len(self.layers_ddf)):               # [in, out]; cat([embed_pos_scaled, h]) puts the encoding first
+            wide = l > 0 and (l - 1) in self.skips
+            wl.append((same(cpe) if l == 0 else (same(cpe) + hid if wide else hid), hid))
+            bl.append((hid,))
+        for l in range(len(self.layers_col)):
+            wl.append((same(small) + hid if l == 0 else hid, hid))
+            bl.append((hid,))
+        for n in (1, 1, 3):                                  # heads: [W, n]
+            wl.append((hid, same(n)))
+            bl.append(None)
+        return wl, bl
+
     def _forward_with_grad(self, sampling: Sampling) -> Dict[str, Tensor]:
         """Training-mode forward: one autograd node over the layer-by-layer HIP kernels (csrc/train_*.hip)."""
         from .autograd import FieldFunction
         pos = sampling.sample_pos
         ctx = Context.get(pos.device)
-        self.upload(ctx, self._slot, weights=False)
         ws, bs = self._tensors()
+        desc, ws, bs = self._train_tensors(ws, bs)
+        self.upload(ctx, self._slot, weights=False, train=(desc, ws, bs) if self._train_layout() is not None else None)
         B, S = pos.shape[0], pos.shape[1]
         distance, density, color, penalty, aux = FieldFunction.apply(
             ctx, self._slot, self._iter_state(), len(ws), pos.detach(), sampling.sample_dir.detach(),
@@ -283,6 +351,21 @@ class NeRF(BaseNeuralField):
     def _iter_state(self):
         return 1.1, 2.0, lowpass_scale(self.lowpass_alpha, self.pe_pos.embed_dim)
 
+    def _train_layout(self):
+        W, E = self.layer_width, TRAIN_ENGINE_WIDTH
+        if W >= E or W % 2:
+            return None
+        cpe, cdir = 6 * self.pe_pos.embed_dim, 6 * self.pe_dir.embed_dim
+        hid, half, same = [(W, E)], [(W // 2, E // 2)], lambda n: [(n, n)]
+        wl, bl = [], []
+        for l in range(len(self.layers)):                   # nn.Linear [out, in]; cat([hx, embed_pos]) puts the hidden state first
+            wide = l > 0 and (l - 1) in self.skips
+            wl.append((hid, same(cpe) if l == 0 else (hid + same(cpe) if wide else hid)))
+            bl.append((hid,))
+        wl += [(same(1), hid), (half, hid + same(cdir)), (same(3), half)]
+        bl += [None, (half,), None]
+        return wl, bl
+
     def forward(self, sampling: Sampling) -> Dict[str, Tensor]:
         """density [B,S], color [B,S,3] (nerf.py:161-164); with autograd enabled and trainable parameters the outputs
         carry the graph (one node over the HIP forward / backward kernels), under torch.no_grad() the fused kernel runs."""
@@ -290,8 +373,9 @@ class NeRF(BaseNeuralField):
             from .autograd import RadianceFieldFunction
             pos = sampling.sample_pos
             ctx = Context.get(pos.device)
-            self.upload(ctx, self._slot, weights=False)
             ws, bs = self._tensors()
+            desc, ws, bs = self._train_tensors(ws, bs)
+            self.upload(ctx, self._slot, weights=False, train=(desc, ws, bs) if self._train_layout() is not None else None)
             B, S = pos.shape[0], pos.shape[1]
             density, color = RadianceFieldFunction.apply(ctx, self._slot, self._iter_state(), len(ws), pos.detach(),
                                                          sampling.sample_dir.detach(), sampling.diag_variance.detach(), *ws, *bs)
@@ -348,10 +432,30 @@ class NeuS(BaseNeuralField):
         dummy = torch.zeros(1)
         return [m.weight for m in mods] + [self.variance.reshape(1)], [m.bias for m in mods] + [dummy]
 
-    def upload(self, ctx: Context, slot: int, weights: bool = True) -> None:
+    def _train_layout(self):
+        Ws, Wc, E = self.sdf_layer_width, self.col_layer_width, TRAIN_ENGINE_WIDTH
+        if (Ws >= E and Wc >= E) or Ws > E or Wc > E:
+            return None
+        cpe, small = 6 * self.pe_pos.embed_dim, 6 + 6 * self.pe_dir.embed_dim
+        hs, hc, same = [(Ws, E)], [(Wc, E)], lambda n: [(n, n)]
+        wl, bl = [], []
+        for l in range(len(self.layers_sdf)):               # nn.Linear [out, in]; cat([hx, embed_pos]): hidden state first
+            wide = l > 0 and (l - 1) in self.skips
+            wl.append((hs, same(cpe) if l == 0 else (hs + same(cpe) if wide else hs)))
+            bl.append((hs,))
+        n_col = len(self.layers_col)
+        for l in range(n_col):                               # colour input [pos, embed_dir, gradients | sdf features] (neus.py:146-149)
+            last = l == n_col - 1
+            wl.append((same(3) if last else hc, same(small) + hs if l == 0 else hc))
+            bl.append(None if last else (hc,))
+        wl.append(None)                                      # variance
+        bl.append(None)
+        return wl, bl
+
+    def upload(self, ctx: Context, slot: int, weights: bool = True, train=None) -> None:
         # `variance.reshape(1)` is a fresh view each call: key the upload on the parameter itself
-        ws, bs = self._tensors()
-        desc = self._descriptor()
+        ws, bs = self._tensors() if train is None else (train[1], train[2])
+        desc = self._descriptor() if train is None else train[0]
         desc.weight_dtype = DTYPE[self.weight_dtype]
         sig = (self._uid, slot, bytes(desc), tuple((t.data_ptr(), t._version) for t in ws[:-1] + bs[:-1]), self.variance.data_ptr(),
                self.variance._version)
@@ -373,10 +477,11 @@ class NeuS(BaseNeuralField):
             from .autograd import SdfFieldFunction
             pos = sampling.sample_pos
             ctx = Context.get(pos.device)
-            self.upload(ctx, self._slot, weights=False)
             mods = list(self.layers_sdf) + list(self.layers_col)
             ws = [m.weight for m in mods] + [self.variance.reshape(1)]
             bs = [m.bias for m in mods] + [torch.zeros(1, device=pos.device)]
+            desc, ws, bs = self._train_tensors(ws, bs)
+            self.upload(ctx, self._slot, weights=False, train=(desc, ws, bs) if self._train_layout() is not None else None)
             B, S = pos.shape[0], pos.shape[1]
             sdf, density, color = SdfFieldFunction.apply(ctx, self._slot, len(ws), pos.detach(), sampling.sample_dir.detach(), *ws, *bs)
             return {"sdf": sdf.view(B, S), "density": density.view(B, S), "color": color.view(B, S, 3)}

@@ -747,6 +747,79 @@ def gen_train_neus():
     save("train_neus.npz", **arrs)
 
 
+def gen_train_widths():
+    """Field-level backward goldens at hidden widths other than 256 (the constructors take any: neddf.py:52-66, nerf.py:34-44,
+    neus.py:30-41): NeDDF 128 (tanhExp) and 192 (ReLU) under the reference's hand-written (value, Jacobian) backward passes, NeRF
+    128 under plain autograd, NeuS with a 128-wide sdf trunk and a 64-wide colour trunk under its double backward; random upstream
+    gradients on every output, 33 sample points each."""
+    arrs = {}
+    rng = np.random.default_rng(2026)
+    shape = (3, 11)
+    pos, dd, var = synth.random_sampling(shape[0], shape[1], seed=47, cone=True)
+    arrs.update(pos=pos, dir=dd, var=var)
+    smp = lambda: Sampling(torch.from_numpy(pos.copy()), torch.from_numpy(dd), torch.from_numpy(var))
+    for tag, kw in (("neddf128", dict(embed_pos_rank=6, embed_dir_rank=4, ddf_layer_count=6, ddf_layer_width=128, col_layer_count=4,
+                                      col_layer_width=128, d_near=0.01, activation_type="tanhExp", density_activation_type="ReLU", skips=[2],
+                                      lowpass_alpha_offset=10, penalty_weight={"constraints_aux_grad": 0.05, "constraints_dDdt": 0.5, "range_color": 0.1})),
+                    ("neddf192", dict(embed_pos_rank=8, embed_dir_rank=3, ddf_layer_count=7, ddf_layer_width=192, col_layer_count=3,
+                                      col_layer_width=192, d_near=0.01, activation_type="ReLU", density_activation_type="LeakyReLU", skips=[1, 4],
+                                      lowpass_alpha_offset=10))):
+        net = NeDDF(**kw)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.neddf_state(
+            kw["embed_pos_rank"], kw["embed_dir_rank"], kw["ddf_layer_count"], kw["ddf_layer_width"], kw["col_layer_count"],
+            kw["col_layer_width"], tuple(kw["skips"]), seed=29).items()})
+        net.set_iter(2500)
+        ups = {k: torch.from_numpy(rng.standard_normal(shape + ((3,) if k == "color" else ())).astype(np.float32))
+               for k in ("distance", "density", "color", "fields_penalty", "aux_grad")}
+        with torch.enable_grad():
+            net.zero_grad()
+            o = net(smp())
+            sum((o[k] * ups[k]).sum() for k in ups).backward()
+        pre = tag + "_"
+        arrs[pre + "config"] = np.array(json.dumps(kw))
+        for k in ups:
+            arrs[pre + "g_" + k] = npy(ups[k])
+            arrs[pre + "out_" + k] = npy(o[k])
+        _grad_records(arrs, pre, net, 790, ("layers_ddf.0.weight", "layers_ddf.1.weight", "layers_ddf.0.bias", "layers_col.0.weight",
+                                           "layer_aux_out.weight", "layer_ddf_out.weight", "layer_col_out.weight", "layer_col_out.bias"))
+    kn = dict(embed_pos_rank=6, embed_dir_rank=4, layer_count=6, layer_width=128, activation_type="tanhExp", density_activation_type="ReLU",
+              skips=[2], lowpass_alpha_offset=10)
+    net = NeRF(**kn)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_state(6, 4, 6, 128, (2,), seed=31).items()})
+    net.set_iter(1500)
+    ups = {"density": torch.from_numpy(rng.standard_normal(shape).astype(np.float32)),
+           "color": torch.from_numpy(rng.standard_normal(shape + (3,)).astype(np.float32))}
+    with torch.enable_grad():
+        net.zero_grad()
+        o = net(smp())
+        sum((o[k] * ups[k]).sum() for k in ups).backward()
+    arrs["nerf128_config"] = np.array(json.dumps(kn))
+    for k in ups:
+        arrs["nerf128_g_" + k] = npy(ups[k])
+        arrs["nerf128_out_" + k] = npy(o[k])
+    _grad_records(arrs, "nerf128_", net, 791, ("layers.0.weight", "layers.3.weight", "layers.5.bias", "outL_density.weight", "outL_color.0.weight",
+                                              "outL_color.0.bias", "outL_color.2.weight", "outL_color.2.bias"))
+    ks = dict(embed_pos_rank=6, embed_dir_rank=4, sdf_layer_count=5, sdf_layer_width=128, col_layer_count=3, col_layer_width=64,
+              init_variance=0.4, activation_type="tanhExp", skips=[2])
+    net = NeuS(**ks)
+    sd = synth.neus_state(6, 4, 5, 128, 3, 64, (2,), 0.4, seed=33)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    ups = {"sdf": torch.from_numpy(rng.standard_normal(shape).astype(np.float32)),
+           "density": torch.from_numpy(rng.standard_normal(shape).astype(np.float32)),
+           "color": torch.from_numpy(rng.standard_normal(shape + (3,)).astype(np.float32))}
+    with torch.enable_grad():
+        net.zero_grad()
+        o = net(Sampling(torch.from_numpy(pos.copy()), torch.from_numpy(dd), torch.from_numpy(np.zeros_like(var))))
+        sum((o[k] * ups[k]).sum() for k in ups).backward()
+    arrs["neus128_config"] = np.array(json.dumps(ks))
+    for k in ups:
+        arrs["neus128_g_" + k] = npy(ups[k])
+        arrs["neus128_out_" + k] = npy(o[k])
+    _grad_records(arrs, "neus128_", net, 792, ("variance", "layers_sdf.0.weight", "layers_sdf.3.weight", "layers_sdf.4.bias", "layers_col.0.weight",
+                                              "layers_col.0.bias", "layers_col.3.weight", "layers_col.3.bias"))
+    save("train_widths.npz", **arrs)
+
+
 # --------------------------------------------------------------------------
 def gen_dataset():
     """the reference's own NeRFSyntheticDataset (nerf_synthetic_dataset.py:25-84, with cv2.imread backed
@@ -858,6 +931,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train_neus":
         gen_train_neus()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "train_widths":
+        gen_train_widths()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "fp64":
         gen_fp64()
         sys.exit(0)
@@ -885,4 +961,5 @@ if __name__ == "__main__":
     gen_train()
     gen_train_nerf()
     gen_train_neus()
+    gen_train_widths()
     gen_fp64()          # last: switches torch's default dtype while it runs

@@ -731,8 +731,9 @@ def test_c2_single_pass_vs_oracle(dev, orc, bunny_weights):
 
 
 def test_width_and_rank_limits_fail_loudly(dev):
-    """The engine takes hidden widths 1..512 (zero-padded to a multiple of 128); beyond that -- and for the training kernels, which
-    are built for width 256 -- the C ABI refuses with NEDDF_EUNSUPPORTED instead of computing something else.  A NeDDF whose two
+    """The engine takes hidden widths 1..512 (zero-padded to a multiple of 128); beyond that -- and for training above width 256, the
+    width the training kernels are built for (narrower networks train zero-padded) -- the C ABI refuses with NEDDF_EUNSUPPORTED
+    instead of computing something else.  A NeDDF whose two
     widths differ is refused like the reference's own forward would fail (neddf.py:145)."""
     import neddf_amd
     from neddf_amd import NeddfError, Sampling
@@ -748,9 +749,16 @@ def test_width_and_rank_limits_fail_loudly(dev):
     net.set_iter(-1)
     o = net(s)
     assert bool(torch.isfinite(o["color"]).all()) and o["density"].shape == (2, 8)
-    with torch.enable_grad():                                                        # training at that width: refused loudly
+    with torch.enable_grad():                                                        # ... and trains (zero-padded onto the 256-wide training kernels)
+        og = net(s)
+        og["color"].sum().backward()
+        assert all(p.grad is not None and tuple(p.grad.shape) == tuple(p.shape) for p in net.parameters())
+    wide = neddf_amd.NeDDF(ddf_layer_width=384, col_layer_width=384, **kw).to(dev)   # above 256: rendering yes, training refused loudly
+    wide.set_iter(-1)
+    assert bool(torch.isfinite(wide(s)["density"]).all())
+    with torch.enable_grad():
         with pytest.raises(NeddfError):
-            net(s)
+            wide(s)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "f16_split"])
