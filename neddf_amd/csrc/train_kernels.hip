@@ -16,6 +16,8 @@
 #include "tile_engine.h"
 #include "train_kernels.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 namespace neddf {
@@ -535,6 +537,15 @@ void launch_mlp_backward(const MlpBackwardArgs &a, int cus, hipStream_t s)
 // columns [64w, 64w+64)), so X and G are read from HBM exactly once; 32-row chunks are staged through LDS with the next
 // chunk in flight (global -> VGPR) during the MFMAs.  The contraction index of v_mfma_f32_32x32x2_f32 is the row:
 // A[i = k][kk = row parity], B[kk][j = n]; LDS row strides are 32 mod 64 floats so the two row parities hit disjoint banks.
+// timing ablations of the weight-gradient kernel (-DNEDDF_ABLATE builds only, NEDDF_DW_ABLATE bits; results invalid):
+// 1 no global fetch, 2 no LDS staging / barriers, 4 no MFMA loop, 8 no atomic epilogue
+#ifdef NEDDF_ABLATE
+__device__ int g_dw_ablate = 0;
+#define DW_ABL(bit) (g_dw_ablate & (bit))
+#else
+#define DW_ABL(bit) 0
+#endif
+
 template <int KT>
 __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, int ldx, int K, const float *G, int ldg, int64_t R,
                                                               int64_t rows_per_wg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
@@ -576,6 +587,13 @@ __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, in
     }
     auto fetch = [&](int64_t c0) {
         const float *xb = X + c0 * ldx, *gb = G + c0 * ldg;
+        if (DW_ABL(1)) {
+#pragma unroll
+            for (int i = 0; i < XPF; ++i) xp[i] = f32x4v{ 1.f, 1.f, 1.f, 1.f };
+#pragma unroll
+            for (int i = 0; i < GPF; ++i) gp[i] = f32x4v{ 1.f, 1.f, 1.f, 1.f };
+            return;
+        }
         if (c0 + RC <= re) {            // a full chunk: no row tests
 #pragma unroll
             for (int i = 0; i < XPF; ++i) {
@@ -604,25 +622,26 @@ __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, in
     };
     fetch(rb);
     for (int64_t c0 = rb; c0 < re; c0 += RC) {
-        __syncthreads();
+        if (!DW_ABL(2)) __syncthreads();
 #pragma unroll
         for (int i = 0; i < XPF; ++i) {
             int idx = tid + i * kThreads, r = idx / (KP / 4), c = idx - r * (KP / 4);
-            if (r < RC) *(f32x4v *)(Xs + r * LDX + 4 * c) = xp[i];
+            if (r < RC && !DW_ABL(2)) *(f32x4v *)(Xs + r * LDX + 4 * c) = xp[i];
         }
 #pragma unroll
         for (int i = 0; i < GPF; ++i) {
             int idx = tid + i * kThreads;
-            *(f32x4v *)(Gs + (idx >> 6) * LDG + 4 * (idx & 63)) = gp[i];
+            if (!DW_ABL(2)) *(f32x4v *)(Gs + (idx >> 6) * LDG + 4 * (idx & 63)) = gp[i];
             // db: column sums over the value rows, taken here from the staged registers (row idx >> 6 = wave + 4 i; chunks start at
             // multiples of 32 and bias_period is 1 or 4, so the row's phase is its phase in the chunk; rows past `re` are zero).
             // Inside the MFMA loop -- first as a 64-bit vector modulo per row pair, 280 of that loop's 314 vector instructions per
             // 64 MFMAs, then as a masked add -- every one of these instructions broke the MFMA issue chain
             if (db && (((idx >> 6) & (bias_period - 1)) == 0)) bsum += gp[i];
         }
-        __syncthreads();
+        if (!DW_ABL(2)) __syncthreads();
         if (c0 + RC < re) fetch(c0 + RC);
         __builtin_amdgcn_sched_barrier(0);
+        if (DW_ABL(4)) continue;
         // Software pipeline over the row pairs of the chunk: the operands of pair rp + 1 (KT + 2 LDS reads) are requested before the
         // 2 KT MFMAs of pair rp issue.  Left to itself hipcc reads each pair of k-tiles right in front of its four MFMAs and waits
         // (`ds_read2_b32; s_waitcnt lgkmcnt(0)` every 4 MFMAs: the LDS latency of 16 loads per chunk row pair, un-overlapped with
@@ -662,7 +681,7 @@ __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, in
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 int k = 32 * kt + 8 * (q >> 2) + 4 * h + (q & 3), n = n0 + 32 * t + j;
-                if (k < K && n < nvalid) atomicAdd(&dW[k * sk + n * sn], acc[kt][t][q]);
+                if (k < K && n < nvalid && !DW_ABL(8)) atomicAdd(&dW[k * sk + n * sn], acc[kt][t][q]);
             }
     if (db && (wave & (bias_period - 1)) == 0) {        // staged rows are wave + 4 i: with bias_period 4 only wave 0 holds value rows
 #pragma unroll
@@ -682,6 +701,10 @@ static void launch_dw_tile(const float *X, int ldx, int K, const float *G, int l
     int64_t chunks = (R + 31) / 32;
     int grid = (int)(chunks < cus ? chunks : cus);
     int64_t rows_per_wg = ((chunks + grid - 1) / grid) * 32;
+#ifdef NEDDF_ABLATE
+    static bool abl_once = [] { const char *e = getenv("NEDDF_DW_ABLATE"); int v = e ? atoi(e) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dw_ablate), &v, sizeof(v)); return true; }();
+    (void)abl_once;
+#endif
     hipLaunchKernelGGL((dw_tile_kernel<KT>), dim3(grid), dim3(kThreads), lds, s, X, ldx, K, G, ldg, R, rows_per_wg, dW, sk, sn, nvalid, db, bias_period);
 }
 
