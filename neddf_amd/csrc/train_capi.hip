@@ -641,6 +641,8 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         a.g_distance = g_distance; a.g_density = g_density; a.g_color = g_color; a.g_penalty = g_penalty; a.g_aux = g_aux_grad;
         a.GZH = GZH; a.GCR = GCR;
         launch_point_backward(a, s);
+        DwJobs dwj{};          // every weight-gradient product of this pass: one job-parallel launch at the end (launch_dw_jobs)
+        dwj.R = p.R;
         // colour head: LinearGradFunction.backward (linear.py:62-88) on [HC | JC] rows, then the last colour activation
         NarrowW cout{};
         cout.nc = 3; cout.wstride = 3; cout.kcount = kWidth;
@@ -662,9 +664,9 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
             launch_mlp_backward(m, ctx->cus, s);
         }
         for (int l = nC - 1; l >= 1; --l)
-            launch_dw(0, ws + p.o_hc[l - 1], kWidth, kWidth, dZc(l), kWidth, p.R, gW[nT + l], kWidth, 1, kWidth, gB[nT + l], 4, ctx->cus, s);
-        launch_dw(0, ws + p.o_xa, p.ldxa, p.Ca, dZc(0), kWidth, p.R, gW[nT], kWidth, 1, kWidth, gB[nT], 4, ctx->cus, s);
-        launch_dw(0, Hlast, kWidth, kWidth, dZc(0), kWidth, p.R, gW[nT] + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s);
+            dwj.add(ws + p.o_hc[l - 1], kWidth, kWidth, dZc(l), kWidth, gW[nT + l], kWidth, 1, kWidth, gB[nT + l], 4);
+        dwj.add(ws + p.o_xa, p.ldxa, p.Ca, dZc(0), kWidth, gW[nT], kWidth, 1, kWidth, gB[nT], 4);
+        dwj.add(Hlast, kWidth, kWidth, dZc(0), kWidth, gW[nT] + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4);
         {   // the small colour inputs (encodings, detached normal) carry no parameters: only the feature segment propagates
             float *wl = next_pack();
             launch_pack(0, W[nT], 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wl, s);                  // (feature rows of W)^T
@@ -692,11 +694,12 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         }
         for (int l = nT - 1; l >= 0; --l) {
             const bool wide = l > 0 && in_skips(f.d, l - 1);
-            if (l == 0 || wide) launch_dw(0, PEs, kLdPe, p.Cpe, dZt(l), kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s);
+            if (l == 0 || wide) dwj.add(PEs, kLdPe, p.Cpe, dZt(l), kWidth, gW[l], kWidth, 1, kWidth, gB[l], 4);
             if (l > 0)
-                launch_dw(0, ws + p.o_h[l - 1], kWidth, kWidth, dZt(l), kWidth, p.R, gW[l] + (size_t)(wide ? p.Cpe : 0) * kWidth, kWidth, 1, kWidth,
-                          wide ? nullptr : gB[l], 4, ctx->cus, s);
+                dwj.add(ws + p.o_h[l - 1], kWidth, kWidth, dZt(l), kWidth, gW[l] + (size_t)(wide ? p.Cpe : 0) * kWidth, kWidth, 1, kWidth,
+                          wide ? nullptr : gB[l], 4);
         }
+        launch_dw_jobs(dwj, ctx->cus, s);
         HIPCHK(hipGetLastError());
         return 0;
     }

@@ -97,6 +97,26 @@ void launch_mlp_backward(const MlpBackwardArgs &a, int cus, hipStream_t s);
 void launch_rows_gemm_actback(int split, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, int period, int act_kind,
                               const float *Zprev, float *dZ, int ldy, int cus, hipStream_t s, const float *amax_in = nullptr,
                               float *amax_out = nullptr);
+// All weight-gradient products of a backward pass in one launch (fp32 MFMA policy): the workgroups are divided among the products in
+// proportion to their cost, each accumulates ITS product over its share of the rows and adds it to dW once.
+struct DwJob {
+    const float *X; int ldx, K;           // dW[k * sk + n * sn] += sum_r X[r, k] G[r, n], k < K <= 256, n < nvalid <= 256
+    const float *G; int ldg;
+    float *dW; int64_t sk, sn; int nvalid;
+    float *db; int bias_period;           // db[n] += sum over rows r % bias_period == 0 of G[r, n] (or NULL)
+    int wg0;                              // first workgroup of the product (set by launch_dw_jobs)
+};
+constexpr int kMaxDwJobs = 32;
+struct DwJobs {
+    int n;
+    int64_t R;                            // rows of every X / G
+    DwJob job[kMaxDwJobs];
+    void add(const float *X, int ldx, int K, const float *G, int ldg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db, int bias_period)
+    {
+        if (n < kMaxDwJobs) job[n++] = DwJob{ X, ldx, K, G, ldg, dW, sk, sn, nvalid, db, bias_period, 0 };
+    }
+};
+void launch_dw_jobs(DwJobs &jobs, int cus, hipStream_t s);
 void launch_dw(int split, const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
                int bias_period, int cus, hipStream_t s, const float *amax_g = nullptr, float *scaled_tmp = nullptr);
 // scaled_tmp: [256, 256] floats of scratch, required with amax_g (the scaled product is formed there, then added to dW unscaled)

@@ -546,10 +546,12 @@ __device__ int g_dw_ablate = 0;
 #define DW_ABL(bit) 0
 #endif
 
-template <int KT>
-__global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, int ldx, int K, const float *G, int ldg, int64_t R,
-                                                              int64_t rows_per_wg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
-                                                              int bias_period)
+// rows [rb, re) of one weight-gradient product; the LDS layout and the accumulator file are those of KT k-tiles, KTN <= KT of them
+// carry data (K <= 32 KTN) and are multiplied -- a compile-time count, so that the job-parallel kernel below can serve products of
+// different K from one accumulator allocation without run-time tests between its MFMAs
+template <int KT, int KTN = KT>
+__device__ __forceinline__ void dw_tile_rows(const float *X, int ldx, int K, const float *G, int ldg, int64_t rb, int64_t re, float *dW,
+                                             int64_t sk, int64_t sn, int nvalid, float *db, int bias_period)
 {
     constexpr int RC = 32, KP = 32 * KT, LDX = ((KP + 32) % 64 == 32) ? KP + 32 : KP + 64, LDG = kWidth + 32;
     constexpr int XPF = (RC * (KP / 4) + kThreads - 1) / kThreads, GPF = RC * (kWidth / 4) / kThreads;
@@ -557,8 +559,6 @@ __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, in
     float *Xs = smem, *Gs = smem + RC * LDX;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int n0 = wave * 64;
-    const int64_t rb = (int64_t)blockIdx.x * rows_per_wg;
-    const int64_t re = rb + rows_per_wg < R ? rb + rows_per_wg : R;
     if (rb >= re) return;
     const int k4 = (K + 3) >> 2;                 // float4 columns actually present (ldx >= 4 * k4)
     f32x16 acc[KT][2];
@@ -652,11 +652,11 @@ __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, in
         auto load_pair = [&](float (&a)[KT], float &b0, float &b1, int rp) {
             b0 = gr[2 * rp * LDG]; b1 = gr[2 * rp * LDG + 32];
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) a[kt] = xr[2 * rp * LDX + 32 * kt];
+            for (int kt = 0; kt < KTN; ++kt) a[kt] = xr[2 * rp * LDX + 32 * kt];
         };
         auto mfma_pair = [&](const float (&a)[KT], float b0, float b1) {
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
+            for (int kt = 0; kt < KTN; ++kt) {
                 acc[kt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], b0, acc[kt][0], 0, 0, 0);
                 acc[kt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], b1, acc[kt][1], 0, 0, 0);
             }
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, in
         }
     }
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int kt = 0; kt < KTN; ++kt) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -683,11 +683,63 @@ __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, in
                 int k = 32 * kt + 8 * (q >> 2) + 4 * h + (q & 3), n = n0 + 32 * t + j;
                 if (k < K && n < nvalid && !DW_ABL(8)) atomicAdd(&dW[k * sk + n * sn], acc[kt][t][q]);
             }
+    }
     if (db && (wave & (bias_period - 1)) == 0) {        // staged rows are wave + 4 i: with bias_period 4 only wave 0 holds value rows
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (4 * lane + q < nvalid) atomicAdd(&db[4 * lane + q], bsum[q]);
     }
+}
+
+template <int KT>
+__global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, int ldx, int K, const float *G, int ldg, int64_t R,
+                                                              int64_t rows_per_wg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
+                                                              int bias_period)
+{
+    const int64_t rb = (int64_t)blockIdx.x * rows_per_wg;
+    dw_tile_rows<KT>(X, ldx, K, G, ldg, rb, rb + rows_per_wg < R ? rb + rows_per_wg : R, dW, sk, sn, nvalid, db, bias_period);
+}
+
+// Job-parallel weight gradients (train_kernels.h DwJobs): every product of a backward pass in ONE launch, each workgroup working on ONE
+// of them.  A workgroup's epilogue is 65 536 device-scope atomic adds whatever its share of rows (profiles/r03_dw_ablation.txt: 1.8 ms
+// of a step when every product is its own launch over all CUs); with the workgroups divided among the products instead of every
+// workgroup visiting every product, a pass issues one such epilogue per workgroup, not one per workgroup and product.
+__global__ __launch_bounds__(kThreads, 1) void dw_jobs_kernel(const DwJobs jobs)
+{
+    int jb = 0;
+    while (jb + 1 < jobs.n && (int)blockIdx.x >= jobs.job[jb + 1].wg0) ++jb;
+    const DwJob &J = jobs.job[jb];
+    const int w = (int)blockIdx.x - J.wg0, nw = (jb + 1 < jobs.n ? jobs.job[jb + 1].wg0 : (int)gridDim.x) - J.wg0;
+    const int64_t chunks = (jobs.R + 31) / 32, per = (chunks + nw - 1) / nw;
+    const int64_t rb = (int64_t)w * per * 32, re_ = rb + per * 32;
+    const int64_t re = re_ < jobs.R ? re_ : jobs.R;
+    if (J.K <= 64) dw_tile_rows<8, 2>(J.X, J.ldx, J.K, J.G, J.ldg, rb, re, J.dW, J.sk, J.sn, J.nvalid, J.db, J.bias_period);
+    else if (J.K <= 96) dw_tile_rows<8, 3>(J.X, J.ldx, J.K, J.G, J.ldg, rb, re, J.dW, J.sk, J.sn, J.nvalid, J.db, J.bias_period);
+    else dw_tile_rows<8, 8>(J.X, J.ldx, J.K, J.G, J.ldg, rb, re, J.dW, J.sk, J.sn, J.nvalid, J.db, J.bias_period);
+}
+
+void launch_dw_jobs(DwJobs &jobs, int cus, hipStream_t s)
+{
+    if (jobs.n <= 0 || jobs.R <= 0) return;
+    // workgroups in proportion to the products' cost: matrix work ~ K, plus the streaming of G that every product pays
+    float cost[kMaxDwJobs], total = 0.f;
+    // (the constant = the staging / streaming share of a chunk, ~a quarter of a 256-wide product's time; measured flat between 32 and 192)
+    for (int i = 0; i < jobs.n; ++i) { const int K = jobs.job[i].K; cost[i] = 64.0f + (float)(K <= 64 ? 64 : K <= 96 ? 96 : 256); total += cost[i]; }
+    int grid = cus > jobs.n ? cus : jobs.n, at = 0;
+    for (int i = 0; i < jobs.n; ++i) {
+        jobs.job[i].wg0 = at;
+        int share = (int)(cost[i] / total * grid + 0.5f);
+        if (share < 1) share = 1;
+        const int left = jobs.n - 1 - i;
+        if (at + share > grid - left) share = grid - left - at;
+        at += share;
+    }
+    grid = at;
+    constexpr int KP = 256, LDX = KP + 32, LDG = kWidth + 32;
+    const size_t lds = (size_t)32 * (LDX + LDG) * sizeof(float);
+    static bool once = ((void)hipFuncSetAttribute((const void *)dw_jobs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32 * (LDX + LDG) * sizeof(float))), true);
+    (void)once;
+    hipLaunchKernelGGL(dw_jobs_kernel, dim3(grid), dim3(kThreads), lds, s, jobs);
 }
 
 template <int KT>
