@@ -628,7 +628,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     if (!sp && !unfused) {
         const int nT = p.n_trunk, nC = p.n_col;
         const size_t slot = (size_t)p.R * kWidth;
-        if (int rc = ensure(ctx, ctx->tpack, (size_t)(nT + nC) * kPackFloats * sizeof(float))) return rc;
+        if (int rc = ensure(ctx, ctx->tpack, (size_t)(nT + nC + 1) * kPackFloats * sizeof(float))) return rc;
         if (int rc = ensure(ctx, ctx->ttmp, ((size_t)(nT + nC + 1) * slot + (size_t)p.R * 2 * kLdNarrow) * sizeof(float))) return rc;
         float *tb = (float *)ctx->ttmp.p, *pack_at = (float *)ctx->tpack.p;
         auto dZc = [&](int l) { return tb + (size_t)l * slot; };
@@ -648,14 +648,17 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         cout.nc = 3; cout.wstride = 3; cout.kcount = kWidth;
         for (int c = 0; c < 3; ++c) cout.w[c] = W[p.i_cout] + c;
         const float *HClast = ws + p.o_hc[nC - 1], *Hlast = ws + p.o_h[nT - 1];
-        launch_narrow_backward_act(GCR, kLdNarrow, p.R, cout, nullptr, 0, act, 4, ws + p.o_zc[nC - 1], dZc(nC - 1), kWidth, s, nullptr);
         {
             float *wc[3] = { gW[p.i_cout], gW[p.i_cout] + 1, gW[p.i_cout] + 2 }, *bc[3] = { gB[p.i_cout], gB[p.i_cout] + 1, gB[p.i_cout] + 2 };
             launch_narrow_dw(HClast, kWidth, GCR, kLdNarrow, p.R, 3, wc, 3, bc, 4, kWidth, s);
         }
         {   // colour trunk: dZ of every layer in one kernel
             MlpBackwardArgs m{};
-            m.R = p.R; m.dZtop = dZc(nC - 1); m.n_layers = nC; m.act_kind = act;
+            m.R = p.R; m.n_layers = nC; m.act_kind = act;
+            // prologue: dZ of the last colour layer = activation backward of the head's upstream gradient (3 raw colour columns)
+            m.top_G = GCR; m.top_ldg = kLdNarrow; m.top_nc = 3; m.top_wstride = 3;
+            for (int c = 0; c < 3; ++c) m.top_w[c] = cout.w[c];
+            m.top_Z = ws + p.o_zc[nC - 1]; m.top_out = dZc(nC - 1);
             for (int l = 1; l < nC; ++l) {
                 float *wl = next_pack();
                 launch_pack(0, W[nT + l], 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wl, s);             // W_l^T
@@ -667,23 +670,21 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
             dwj.add(ws + p.o_hc[l - 1], kWidth, kWidth, dZc(l), kWidth, gW[nT + l], kWidth, 1, kWidth, gB[nT + l], 4);
         dwj.add(ws + p.o_xa, p.ldxa, p.Ca, dZc(0), kWidth, gW[nT], kWidth, 1, kWidth, gB[nT], 4);
         dwj.add(Hlast, kWidth, kWidth, dZc(0), kWidth, gW[nT] + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4);
-        {   // the small colour inputs (encodings, detached normal) carry no parameters: only the feature segment propagates
-            float *wl = next_pack();
-            launch_pack(0, W[nT], 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wl, s);                  // (feature rows of W)^T
-            launch_rows_gemm(0, dZc(0), p.R, kWidth, kWidth, wl, gemm_ksteps(kWidth, 0), nullptr, 4, dFeat, kWidth, 0, -1, nullptr, ctx->cus, s);
-        }
-        // dFeat = gradient of the trunk features from the colour trunk; add the distance / aux heads, then the last trunk activation
-        NarrowW heads{};
-        heads.nc = 2; heads.wstride = 1; heads.kcount = kWidth;
-        heads.w[0] = W[p.i_ddf]; heads.w[1] = W[p.i_aux];
-        launch_narrow_backward_act(GZH, kLdNarrow, p.R, heads, dFeat, 1, act, 4, ws + p.o_z[nT - 1], dZt(nT - 1), kWidth, s, nullptr);
         {
             float *wh[2] = { gW[p.i_ddf], gW[p.i_aux] }, *bh[2] = { gB[p.i_ddf], gB[p.i_aux] };
             launch_narrow_dw(Hlast, kWidth, GZH, kLdNarrow, p.R, 2, wh, 1, bh, 4, kWidth, s);
         }
         {   // distance trunk
             MlpBackwardArgs m{};
-            m.R = p.R; m.dZtop = dZt(nT - 1); m.n_layers = nT; m.act_kind = act;
+            m.R = p.R; m.n_layers = nT; m.act_kind = act;
+            // prologue: dZ of the last trunk layer = activation backward of (gradient of the features from the colour trunk -- only the
+            // feature segment of its first layer propagates: the small colour inputs carry no parameters -- + the distance / aux heads)
+            float *wf = next_pack();
+            launch_pack(0, W[nT], 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wf, s);                  // (feature rows of W_c0)^T
+            m.top_src = dZc(0); m.top_wT = wf;
+            m.top_G = GZH; m.top_ldg = kLdNarrow; m.top_nc = 2; m.top_wstride = 1;
+            m.top_w[0] = W[p.i_ddf]; m.top_w[1] = W[p.i_aux];
+            m.top_Z = ws + p.o_z[nT - 1]; m.top_out = dZt(nT - 1);
             for (int l = 1; l < nT; ++l) {
                 const bool wide = in_skips(f.d, l - 1);
                 float *wl = next_pack();

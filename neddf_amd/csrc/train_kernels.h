@@ -82,7 +82,13 @@ void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t
 // keeps the per-layer route: its gradient operands are range-scaled per matrix).
 struct MlpBackwardArgs {
     int64_t R;
-    const float *dZtop;                   // [R, 256]: gradient of the top layer's pre-activations
+    const float *dZtop;                   // [R, 256]: gradient of the top layer's pre-activations -- or NULL: formed in the kernel's prologue,
+    //   dZ_top = act_backward(Z_top; top_src x top_wT + sum_c top_G[:, c] top_w[c][:])     and left in top_out for its weight gradient:
+    const float *top_src, *top_wT;        // optional [R, 256] matrix and packed 256 x 256 weights (the colour trunk's gradient of the features)
+    const float *top_G; int top_ldg, top_nc;              // narrow upstream gradient [R, top_ldg], top_nc <= 3 columns (the heads' raw outputs)
+    const float *top_w[3]; int top_wstride;               // column c of the heads' weights: top_w[c][feature * top_wstride]
+    const float *top_Z;                   // pre-activations of the top layer [R, 256]
+    float *top_out;                       // [R, 256]
     int n_layers;
     const float *wT[kMaxLayers];          // [l >= 1] packed (hidden rows of W_l)^T, 256 x 256
     const float *Z[kMaxLayers];           // pre-activations [R, 256]; l = 0 .. n_layers-2 are read

@@ -285,6 +285,23 @@ void launch_rows_gemm_actback(int split, const float *X, int64_t R, int ldx, int
                           amax_in, amax_out);
 }
 
+// timing ablations (-DNEDDF_ABLATE builds only, NEDDF_DW_ABLATE bits; results invalid).  Weight-gradient kernel: 1 no global fetch,
+// 2 no LDS staging / barriers, 4 no MFMA loop, 8 no atomic epilogue.  Fused forward: 16 no Z store, 32 no H store, 64 activation
+// replaced by a move, 128 no LDS write.  Fused backward: 256 no dZ store, 512 no Z load, 1024 activation derivatives replaced by
+// constants, 2048 no LDS write.  4096: no MFMA loops in the two.
+#ifdef NEDDF_ABLATE
+__device__ int g_dw_ablate = 0;
+#define DW_ABL(bit) (g_dw_ablate & (bit))
+static void ablate_init()
+{
+    static bool once = [] { const char *e = getenv("NEDDF_DW_ABLATE"); int v = e ? atoi(e) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dw_ablate), &v, sizeof(v)); return true; }();
+    (void)once;
+}
+#else
+#define DW_ABL(bit) 0
+static void ablate_init() {}
+#endif
+
 // ----------------------------------------------------------------------------
 // Fused forward of a layer stack (train_kernels.h MlpForwardArgs): the inference tile engine with side stores.
 // 64-row tiles, two workgroups per CU.  The skip layer's X0 product is taken at tile start, while X0 sits in LDS, and held in
@@ -312,17 +329,23 @@ __device__ __forceinline__ void mlp_epilogue(const f32x16 (&acc)[MT][NT], typena
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z[r] = acc[mt][t][4 * g + r] * unscale;
                 float y, dy;
+                if (DW_ABL(64)) { y = z[0]; dy = 1.f; } else
                 act_grad<KIND>(z[0], y, dy);
                 const float hv[4] = { y, dy * z[1], dy * z[2], dy * z[3] };
                 const int off = (mt * 32 + 8 * g) * kWidth + t * 32;
                 if (FULL || r0 + mt * 32 + 8 * g + 4 * h < R) {     // R is a multiple of 4: a point's rows are all inside or all outside
+                    if (DW_ABL(8192)) {      // timing probe: 16 bytes per lane, [row / 4][column][row % 4]
+                        const int64_t ib = ((r0 + mt * 32 + 8 * g + 4 * h) >> 2) * (4 * kWidth) + (wave * NT * 32 + t * 32 + j) * 4;
+                        *(f32x4v *)(Zl + ib) = f32x4v{ z[0], z[1], z[2], z[3] };
+                        *(f32x4v *)(Hl + ib) = f32x4v{ hv[0], hv[1], hv[2], hv[3] };
+                    } else
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        zb[off + r * kWidth] = z[r];
-                        hb[off + r * kWidth] = hv[r];
+                        if (!DW_ABL(16)) zb[off + r * kWidth] = z[r];
+                        if (!DW_ABL(32)) hb[off + r * kWidth] = hv[r];
                     }
                 }
-                if (!LAST) {
+                if (!LAST && !DW_ABL(128)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Ops::put(o + (8 * g + r) * LD, hv[r]);
                 }
@@ -389,6 +412,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
                             for (int t = 0; t < NT; ++t) acc[mt][t] += held[mt][t];
                     }
                 }
+                if (!DW_ABL(4096))
                 dense<MT, NT, Ops>(acc, act_lane, frags(a.wp[l], kWidth / Ops::kStep), kWidth / Ops::kStep);
                 if constexpr (!HOLD) {
                     if (l == a.skip_layer) {
@@ -430,6 +454,7 @@ static void launch_mlp_forward_ops(const MlpForwardArgs &a, int cus, hipStream_t
 void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t s)
 {
     if (a.R <= 0) return;
+    ablate_init();
     if (split) launch_mlp_forward_ops<OpsF16Split, false>(a, cus, s);
     else launch_mlp_forward_ops<OpsF32, true>(a, cus, s);
 }
@@ -454,6 +479,7 @@ __device__ __forceinline__ void mlp_backward_epilogue(const f32x16 (&acc)[2][2],
             for (int g = 0; g < 4; ++g) {
                 // rows 8 g + 4 h + {0, 1, 2, 3} of the tile = (value, d/dx, d/dy, d/dz) of one point, one feature
                 float dy, d2;
+                if (DW_ABL(1024)) { dy = 1.f; d2 = 0.5f; } else
                 act_grad2<KIND>(zp[mt][t][4 * g], dy, d2);
                 const float g0 = acc[mt][t][4 * g], g1 = acc[mt][t][4 * g + 1], g2 = acc[mt][t][4 * g + 2], g3 = acc[mt][t][4 * g + 3];
                 float sj = g1 * zp[mt][t][4 * g + 1];
@@ -462,15 +488,20 @@ __device__ __forceinline__ void mlp_backward_epilogue(const f32x16 (&acc)[2][2],
                 const float ov[4] = { g0 * dy + sj * d2, g1 * dy, g2 * dy, g3 * dy };
                 const int off = (mt * 32 + 8 * g) * kWidth + t * 32;
                 if (r0 + mt * 32 + 8 * g + 4 * h < R) {
+                    if (DW_ABL(16384)) {
+                        const int64_t ib = ((r0 + mt * 32 + 8 * g + 4 * h) >> 2) * (4 * kWidth) + (wave * NT * 32 + t * 32 + j) * 4;
+                        *(f32x4v *)(dZl + ib) = f32x4v{ ov[0], ov[1], ov[2], ov[3] };
+                    } else
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) gb[off + r * kWidth] = ov[r];
+                    for (int r = 0; r < 4; ++r) if (!DW_ABL(256)) gb[off + r * kWidth] = ov[r];
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[(8 * g + r) * LD] = ov[r];
+                for (int r = 0; r < 4; ++r) if (!DW_ABL(2048)) o[(8 * g + r) * LD] = ov[r];
             }
         }
 }
 
+template <int KIND>      // backward kind of the stack's activation: one straight-line epilogue per kernel, not four behind run-time branches
 __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBackwardArgs a)
 {
     typedef OpsF32 Ops;
@@ -485,13 +516,64 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * ROWS;
         __syncthreads();                // the previous tile is done with the LDS tile
-        for (int idx = tid; idx < ROWS * (kWidth / 4); idx += kThreads) {
-            const int r = idx >> 6, c = idx & 63;
-            f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-            if (r0 + r < a.R) v = *(const f32x4v *)(a.dZtop + (r0 + r) * kWidth + 4 * c);
-            *(f32x4v *)(act + r * LD + 4 * c) = v;
+        auto stage = [&](const float *src) {
+            for (int idx = tid; idx < ROWS * (kWidth / 4); idx += kThreads) {
+                const int r = idx >> 6, c = idx & 63;
+                f32x4v v = { 0.f, 0.f, 0.f, 0.f };
+                if (r0 + r < a.R) v = *(const f32x4v *)(src + (r0 + r) * kWidth + 4 * c);
+                *(f32x4v *)(act + r * LD + 4 * c) = v;
+            }
+        };
+        if (a.dZtop) {
+            stage(a.dZtop);
+            __syncthreads();
+        } else {
+            // prologue: the top layer's gradient is formed here instead of by two more passes over HBM (a plain GEMM kernel for the
+            // colour trunk's feature gradient + a kernel that adds the heads and applies the top activation's backward)
+            f32x16 zp[MT][NT], acc[MT][NT];
+            const float *zb = a.top_Z + (r0 + 4 * h) * kWidth + wave * NT * 32 + j;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const bool in = r0 + mt * 32 + 8 * g + 4 * h < a.R;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zp[mt][t][4 * g + r] = in ? zb[(mt * 32 + 8 * g + r) * kWidth + t * 32] : 0.f;
+                    }
+            acc_init<MT, NT, false>(acc, nullptr, wave, lane);
+            if (a.top_src) {
+                stage(a.top_src);
+                __syncthreads();
+                dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.top_wT + (size_t)wave * NT * KS * 64 + lane, KS);
+                __syncthreads();        // every wave finished reading the staged matrix
+            }
+            float hw[3][NT];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) hw[c][t] = c < a.top_nc ? a.top_w[c][(size_t)(wave * NT * 32 + t * 32 + j) * a.top_wstride] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = r0 + mt * 32 + 8 * g + 4 * h + r;
+                        float gv[3] = { 0.f, 0.f, 0.f };
+                        if (row < a.R)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                if (c < a.top_nc) gv[c] = a.top_G[row * a.top_ldg + c];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) acc[mt][t][4 * g + r] = fmaf(gv[c], hw[c][t], acc[mt][t][4 * g + r]);
+                    }
+            mlp_backward_epilogue<KIND>(acc, zp, act, a.top_out, r0, a.R, wave, lane);
+            __syncthreads();
         }
-        __syncthreads();
         for (int l = a.n_layers - 1; l >= 1; --l) {
             // Z_{l-1} of this lane's accumulator positions, requested before the product (rows past R: zero; R is a multiple of 4)
             f32x16 zp[MT][NT];
@@ -503,18 +585,22 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const bool in = r0 + mt * 32 + 8 * g + 4 * h < a.R;
+                        if (DW_ABL(16384)) {
+                            f32x4v v = { 0.f, 0.f, 0.f, 0.f };
+                            if (in) v = *(const f32x4v *)(a.Z[l - 1] + ((r0 + mt * 32 + 8 * g + 4 * h) >> 2) * (4 * kWidth) + (wave * NT * 32 + t * 32 + j) * 4);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) zp[mt][t][4 * g + r] = in ? zb[(mt * 32 + 8 * g + r) * kWidth + t * 32] : 0.f;
+                            for (int r = 0; r < 4; ++r) zp[mt][t][4 * g + r] = v[r];
+                        } else
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zp[mt][t][4 * g + r] = (in && !DW_ABL(512)) ? zb[(mt * 32 + 8 * g + r) * kWidth + t * 32] : 0.f;
                     }
             __builtin_amdgcn_sched_barrier(0);
             f32x16 acc[MT][NT];
             acc_init<MT, NT, false>(acc, nullptr, wave, lane);
+            if (!DW_ABL(4096))
             dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
             __syncthreads();            // every wave finished reading dZ_l
-            if (a.act_kind == 0) mlp_backward_epilogue<0>(acc, zp, act, a.dZ[l - 1], r0, a.R, wave, lane);
-            else if (a.act_kind == 1) mlp_backward_epilogue<1>(acc, zp, act, a.dZ[l - 1], r0, a.R, wave, lane);
-            else if (a.act_kind == 2) mlp_backward_epilogue<2>(acc, zp, act, a.dZ[l - 1], r0, a.R, wave, lane);
-            else mlp_backward_epilogue<3>(acc, zp, act, a.dZ[l - 1], r0, a.R, wave, lane);
+            mlp_backward_epilogue<KIND>(acc, zp, act, a.dZ[l - 1], r0, a.R, wave, lane);
             if (l > 1) __syncthreads(); // the next layer reads what this epilogue wrote
         }
     }
@@ -522,12 +608,20 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
 
 void launch_mlp_backward(const MlpBackwardArgs &a, int cus, hipStream_t s)
 {
-    if (a.R <= 0 || a.n_layers < 2) return;
+    if (a.R <= 0 || (a.n_layers < 2 && a.dZtop)) return;         // a one-layer stack still has a prologue to run
+    ablate_init();
     constexpr size_t lds = (size_t)64 * OpsF32::kLd * sizeof(float);
-    static bool once = ((void)hipFuncSetAttribute((const void *)mlp_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    static bool once = ((void)hipFuncSetAttribute((const void *)mlp_backward_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                        (void)hipFuncSetAttribute((const void *)mlp_backward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                        (void)hipFuncSetAttribute((const void *)mlp_backward_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                        (void)hipFuncSetAttribute((const void *)mlp_backward_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     const int64_t tiles = (a.R + 63) / 64;
-    hipLaunchKernelGGL(mlp_backward_kernel, dim3((unsigned)(tiles < 2 * cus ? tiles : 2 * cus)), dim3(kThreads), lds, s, a);
+    const dim3 grid((unsigned)(tiles < 2 * cus ? tiles : 2 * cus));
+    if (a.act_kind == 0) hipLaunchKernelGGL(mlp_backward_kernel<0>, grid, dim3(kThreads), lds, s, a);
+    else if (a.act_kind == 1) hipLaunchKernelGGL(mlp_backward_kernel<1>, grid, dim3(kThreads), lds, s, a);
+    else if (a.act_kind == 2) hipLaunchKernelGGL(mlp_backward_kernel<2>, grid, dim3(kThreads), lds, s, a);
+    else hipLaunchKernelGGL(mlp_backward_kernel<3>, grid, dim3(kThreads), lds, s, a);
 }
 
 // ----------------------------------------------------------------------------
@@ -537,14 +631,6 @@ void launch_mlp_backward(const MlpBackwardArgs &a, int cus, hipStream_t s)
 // columns [64w, 64w+64)), so X and G are read from HBM exactly once; 32-row chunks are staged through LDS with the next
 // chunk in flight (global -> VGPR) during the MFMAs.  The contraction index of v_mfma_f32_32x32x2_f32 is the row:
 // A[i = k][kk = row parity], B[kk][j = n]; LDS row strides are 32 mod 64 floats so the two row parities hit disjoint banks.
-// timing ablations of the weight-gradient kernel (-DNEDDF_ABLATE builds only, NEDDF_DW_ABLATE bits; results invalid):
-// 1 no global fetch, 2 no LDS staging / barriers, 4 no MFMA loop, 8 no atomic epilogue
-#ifdef NEDDF_ABLATE
-__device__ int g_dw_ablate = 0;
-#define DW_ABL(bit) (g_dw_ablate & (bit))
-#else
-#define DW_ABL(bit) 0
-#endif
 
 // rows [rb, re) of one weight-gradient product; the LDS layout and the accumulator file are those of KT k-tiles, KTN <= KT of them
 // carry data (K <= 32 KTN) and are multiplied -- a compile-time count, so that the job-parallel kernel below can serve products of
@@ -739,6 +825,7 @@ void launch_dw_jobs(DwJobs &jobs, int cus, hipStream_t s)
     const size_t lds = (size_t)32 * (LDX + LDG) * sizeof(float);
     static bool once = ((void)hipFuncSetAttribute((const void *)dw_jobs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32 * (LDX + LDG) * sizeof(float))), true);
     (void)once;
+    ablate_init();
     hipLaunchKernelGGL(dw_jobs_kernel, dim3(grid), dim3(kThreads), lds, s, jobs);
 }
 
@@ -753,10 +840,7 @@ static void launch_dw_tile(const float *X, int ldx, int K, const float *G, int l
     int64_t chunks = (R + 31) / 32;
     int grid = (int)(chunks < cus ? chunks : cus);
     int64_t rows_per_wg = ((chunks + grid - 1) / grid) * 32;
-#ifdef NEDDF_ABLATE
-    static bool abl_once = [] { const char *e = getenv("NEDDF_DW_ABLATE"); int v = e ? atoi(e) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dw_ablate), &v, sizeof(v)); return true; }();
-    (void)abl_once;
-#endif
+    ablate_init();
     hipLaunchKernelGGL((dw_tile_kernel<KT>), dim3(grid), dim3(kThreads), lds, s, X, ldx, K, G, ldg, R, rows_per_wg, dW, sk, sn, nvalid, db, bias_period);
 }
 
