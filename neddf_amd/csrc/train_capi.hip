@@ -512,10 +512,13 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     // distance trunk (neddf.py:206-218); the fused kernel holds one skip partial, architectures with more take the per-layer route
     int n_wide = 0;
     for (int l = 1; l < p.n_trunk; ++l) n_wide += in_skips(f.d, l - 1) ? 1 : 0;
+    // fp32 policy, both stacks fused: the hidden states are kept point-major (train_kernels.h MlpForwardArgs.point_major), the layout of
+    // the fused backward (neddf_train_field_backward takes that route under the same condition)
+    const int pm = (!sp && !unfused && n_wide <= 1) ? 1 : 0;
     if (!unfused && n_wide <= 1) {
         MlpForwardArgs m{};
         m.R = p.R; m.X0 = PEs; m.ld0 = kLdPe; m.kload0 = kpe; m.ksteps0 = gemm_ksteps(p.Cpe, sp);
-        m.n_layers = p.n_trunk; m.skip_layer = -1; m.act_kind = act;
+        m.n_layers = p.n_trunk; m.skip_layer = -1; m.act_kind = act; m.point_major = pm;
         float *w0 = next_pack();
         launch_pack(sp, W[0], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, w0, s);
         m.wp0 = w0;
@@ -556,7 +559,7 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     heads.nc = 2; heads.wstride = 1; heads.kcount = kWidth;
     heads.w[0] = W[p.i_ddf]; heads.w[1] = W[p.i_aux];
     heads.b[0] = B[p.i_ddf]; heads.b[1] = B[p.i_aux];
-    launch_narrow_forward(Hlast, kWidth, p.R, heads, 4, ZH, kLdNarrow, s);
+    launch_narrow_forward(Hlast, kWidth, p.R, heads, 4, ZH, kLdNarrow, s, pm);
     a.ZH = ZH; a.PEu = PEu; a.Ed = Ed;
     a.distance = distance; a.density = density; a.aux_grad = aux_grad;
     launch_point_forward(a, s);
@@ -564,7 +567,7 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     if (!unfused) {
         MlpForwardArgs m{};
         m.R = p.R; m.X0 = ws + p.o_xa; m.ld0 = p.ldxa; m.kload0 = p.ldxa; m.ksteps0 = gemm_ksteps(p.Ca, sp);
-        m.X1 = Hlast; m.n_layers = p.n_col; m.skip_layer = -1; m.act_kind = act;
+        m.X1 = Hlast; m.n_layers = p.n_col; m.skip_layer = -1; m.act_kind = act; m.point_major = pm;
         pack_at = wp;           // same stream: the trunk kernel is done with the buffer when these packs run
         float *w0 = next_pack(), *w1 = next_pack();
         launch_pack(sp, W[p.n_trunk], kWidth, 1, 0, 0, p.Ca, kWidth, kWidth, w0, s);
@@ -596,7 +599,7 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     NarrowW cout{};
     cout.nc = 3; cout.wstride = 3; cout.kcount = kWidth;
     for (int c = 0; c < 3; ++c) { cout.w[c] = W[p.i_cout] + c; cout.b[c] = B[p.i_cout] + c; }
-    launch_narrow_forward(ws + p.o_hc[p.n_col - 1], kWidth, p.R, cout, 4, ws + p.o_cr, kLdNarrow, s);
+    launch_narrow_forward(ws + p.o_hc[p.n_col - 1], kWidth, p.R, cout, 4, ws + p.o_cr, kLdNarrow, s, pm);
     a.color = color; a.penalty = penalty;
     launch_penalty_forward(a, s);
     HIPCHK(hipGetLastError());
@@ -625,7 +628,9 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     // fp32 MFMA policy: the input-gradient chain of each layer stack is ONE kernel (train_kernels.h MlpBackwardArgs); every dZ_l keeps
     // its own matrix for the weight-gradient products.  NEDDF_TRAIN_UNFUSED=1 and the split-fp16 policy take the per-layer route below.
     static const bool unfused = [] { const char *e = getenv("NEDDF_TRAIN_UNFUSED"); return e && atoi(e) != 0; }();
-    if (!sp && !unfused) {
+    int n_wide = 0;
+    for (int l = 1; l < p.n_trunk; ++l) n_wide += in_skips(f.d, l - 1) ? 1 : 0;
+    if (!sp && !unfused && n_wide <= 1) {      // (= the forward's condition for point-major hidden states)
         const int nT = p.n_trunk, nC = p.n_col;
         const size_t slot = (size_t)p.R * kWidth;
         if (int rc = ensure(ctx, ctx->tpack, (size_t)(nT + nC + 1) * kPackFloats * sizeof(float))) return rc;
@@ -650,7 +655,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         const float *HClast = ws + p.o_hc[nC - 1], *Hlast = ws + p.o_h[nT - 1];
         {
             float *wc[3] = { gW[p.i_cout], gW[p.i_cout] + 1, gW[p.i_cout] + 2 }, *bc[3] = { gB[p.i_cout], gB[p.i_cout] + 1, gB[p.i_cout] + 2 };
-            launch_narrow_dw(HClast, kWidth, GCR, kLdNarrow, p.R, 3, wc, 3, bc, 4, kWidth, s);
+            launch_narrow_dw(HClast, kWidth, GCR, kLdNarrow, p.R, 3, wc, 3, bc, 4, kWidth, s, 1);
         }
         {   // colour trunk: dZ of every layer in one kernel
             MlpBackwardArgs m{};
@@ -667,12 +672,12 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
             launch_mlp_backward(m, ctx->cus, s);
         }
         for (int l = nC - 1; l >= 1; --l)
-            dwj.add(ws + p.o_hc[l - 1], kWidth, kWidth, dZc(l), kWidth, gW[nT + l], kWidth, 1, kWidth, gB[nT + l], 4);
-        dwj.add(ws + p.o_xa, p.ldxa, p.Ca, dZc(0), kWidth, gW[nT], kWidth, 1, kWidth, gB[nT], 4);
-        dwj.add(Hlast, kWidth, kWidth, dZc(0), kWidth, gW[nT] + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4);
+            dwj.add(ws + p.o_hc[l - 1], kWidth, kWidth, 1, dZc(l), kWidth, gW[nT + l], kWidth, 1, kWidth, gB[nT + l], 4);
+        dwj.add(ws + p.o_xa, p.ldxa, p.Ca, 0, dZc(0), kWidth, gW[nT], kWidth, 1, kWidth, gB[nT], 4);
+        dwj.add(Hlast, kWidth, kWidth, 1, dZc(0), kWidth, gW[nT] + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4);
         {
             float *wh[2] = { gW[p.i_ddf], gW[p.i_aux] }, *bh[2] = { gB[p.i_ddf], gB[p.i_aux] };
-            launch_narrow_dw(Hlast, kWidth, GZH, kLdNarrow, p.R, 2, wh, 1, bh, 4, kWidth, s);
+            launch_narrow_dw(Hlast, kWidth, GZH, kLdNarrow, p.R, 2, wh, 1, bh, 4, kWidth, s, 1);
         }
         {   // distance trunk
             MlpBackwardArgs m{};
@@ -695,9 +700,9 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         }
         for (int l = nT - 1; l >= 0; --l) {
             const bool wide = l > 0 && in_skips(f.d, l - 1);
-            if (l == 0 || wide) dwj.add(PEs, kLdPe, p.Cpe, dZt(l), kWidth, gW[l], kWidth, 1, kWidth, gB[l], 4);
+            if (l == 0 || wide) dwj.add(PEs, kLdPe, p.Cpe, 0, dZt(l), kWidth, gW[l], kWidth, 1, kWidth, gB[l], 4);
             if (l > 0)
-                dwj.add(ws + p.o_h[l - 1], kWidth, kWidth, dZt(l), kWidth, gW[l] + (size_t)(wide ? p.Cpe : 0) * kWidth, kWidth, 1, kWidth,
+                dwj.add(ws + p.o_h[l - 1], kWidth, kWidth, 1, dZt(l), kWidth, gW[l] + (size_t)(wide ? p.Cpe : 0) * kWidth, kWidth, 1, kWidth,
                           wide ? nullptr : gB[l], 4);
         }
         launch_dw_jobs(dwj, ctx->cus, s);

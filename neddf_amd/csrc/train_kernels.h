@@ -68,6 +68,14 @@ struct MlpForwardArgs {
     const float *wp_skip;                 // its X0 segment (ksteps0 super-steps)
     float *Z[kMaxLayers], *H[kMaxLayers]; // [R, 256] each
     int act_kind;
+    // Point-major layout of the [R, 256] matrices (X1, Z, H; fp32 policy, R a multiple of 4): element (row, c) sits at
+    //   (row >> 2) * 1024 + 4 c + (row & 3)
+    // i.e. the four rows of a point -- (value, d/dx, d/dy, d/dz) -- of one feature are 16 contiguous bytes.  That is exactly what a lane
+    // of the 32x32 accumulator layout holds, so the epilogues store (and the backward chain loads) 16 bytes per lane and instruction
+    // instead of 4: the row-major side stores of a layer were 128 + 64 scalar memory instructions per wave behind 512 MFMAs, 3.8 of the
+    // forward's 13 ms per training step (profiles/r03_train_ablation.txt).  The NeDDF fp32 training route uses it end to end
+    // (forward, backward chain, weight gradients, heads); every other route keeps row-major matrices.
+    int point_major;
 };
 void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t s);
 
@@ -75,7 +83,8 @@ void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t
 // launch_mlp_forward: the 64-row tile of gradients stays in LDS from the top layer down,
 //   dZ_{l-1} = act_backward(Z_{l-1}; dZ_l x (hidden rows of W_l)^T)          l = n_layers-1 .. 1
 // (LinearGradFunction.backward linear.py:62-74 followed by the activation's backward, e.g. tanh_exp.py:57-88), and every dZ_l
-// is left in its own [R, 256] matrix for the weight-gradient products that follow.  Per row and layer the chain reads Z_{l-1}
+// is left in its own [R, 256] matrix for the weight-gradient products that follow.  EVERY [R, 256] matrix of this kernel (dZtop, top_src,
+// top_Z, top_out, Z, dZ) is in the POINT-MAJOR layout (MlpForwardArgs.point_major).  Per row and layer the chain reads Z_{l-1}
 // and writes dZ_{l-1} (2 KB) where one GEMM kernel per layer also re-read dZ_l (3 KB), and there is no per-layer launch, fill and
 // drain.  The activation backward runs on the accumulators themselves: in the 32x32 layout a lane holds the four rows of a point
 // for one feature, and Z_{l-1} is requested in that layout before the product.  fp32 MFMA operands (the split-fp16 policy
@@ -110,6 +119,7 @@ struct DwJob {
     const float *G; int ldg;
     float *dW; int64_t sk, sn; int nvalid;
     float *db; int bias_period;           // db[n] += sum over rows r % bias_period == 0 of G[r, n] (or NULL)
+    int x_point_major;                    // X is a point-major [R, 256] matrix (MlpForwardArgs.point_major); G always is, R % 4 == 0
     int wg0;                              // first workgroup of the product (set by launch_dw_jobs)
 };
 constexpr int kMaxDwJobs = 32;
@@ -117,9 +127,10 @@ struct DwJobs {
     int n;
     int64_t R;                            // rows of every X / G
     DwJob job[kMaxDwJobs];
-    void add(const float *X, int ldx, int K, const float *G, int ldg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db, int bias_period)
+    void add(const float *X, int ldx, int K, int x_point_major, const float *G, int ldg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
+             int bias_period)
     {
-        if (n < kMaxDwJobs) job[n++] = DwJob{ X, ldx, K, G, ldg, dW, sk, sn, nvalid, db, bias_period, 0 };
+        if (n < kMaxDwJobs) job[n++] = DwJob{ X, ldx, K, G, ldg, dW, sk, sn, nvalid, db, bias_period, x_point_major, 0 };
     }
 };
 void launch_dw_jobs(DwJobs &jobs, int cus, hipStream_t s);
@@ -128,7 +139,7 @@ void launch_dw(int split, const float *X, int ldx, int K, const float *G, int ld
 // scaled_tmp: [256, 256] floats of scratch, required with amax_g (the scaled product is formed there, then added to dW unscaled)
 // heads (1..4 output columns, input width 256): column c of the weight gradient is w[c][k * wstride], b[c] its bias gradient
 void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t R, int nc, float *const *w, int wstride, float *const *b,
-                      int bias_period, int kcount, hipStream_t s);
+                      int bias_period, int kcount, hipStream_t s, int x_point_major = 0);
 void launch_pe_values(const float *pos, const float *dir, const float *var, int64_t N, const EncodeDesc &enc, float *PE, int ld, float *Ed, int ldd,
                       hipStream_t s);
 void launch_density_head(int kind, const float *z, int ldz, int64_t N, const float *g, float *out, int ldo, hipStream_t s);
@@ -143,7 +154,8 @@ struct NarrowW {
     const float *b[4];        // device pointers to the scalar biases (or NULL)
     int kcount;               // input features present (<= 256; columns beyond are not read)
 };
-void launch_narrow_forward(const float *X, int ldx, int64_t R, const NarrowW &w, int bias_period, float *Y, int ldy, hipStream_t s);
+void launch_narrow_forward(const float *X, int ldx, int64_t R, const NarrowW &w, int bias_period, float *Y, int ldy, hipStream_t s,
+                           int x_point_major = 0);
 // dX[R, ldx] (+)= sum_c G[r, c] * w_c[k]
 void launch_narrow_backward(const float *G, int ldg, int64_t R, const NarrowW &w, float *dX, int ldx, int accumulate, hipStream_t s);
 

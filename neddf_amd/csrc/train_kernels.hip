@@ -288,7 +288,7 @@ void launch_rows_gemm_actback(int split, const float *X, int64_t R, int ldx, int
 // timing ablations (-DNEDDF_ABLATE builds only, NEDDF_DW_ABLATE bits; results invalid).  Weight-gradient kernel: 1 no global fetch,
 // 2 no LDS staging / barriers, 4 no MFMA loop, 8 no atomic epilogue.  Fused forward: 16 no Z store, 32 no H store, 64 activation
 // replaced by a move, 128 no LDS write.  Fused backward: 256 no dZ store, 512 no Z load, 1024 activation derivatives replaced by
-// constants, 2048 no LDS write.  4096: no MFMA loops in the two.
+// constants, 2048 no LDS write.  4096: no MFMA loops in the two.  32768: cycle counters of the fused forward (where a wave's time goes).
 #ifdef NEDDF_ABLATE
 __device__ int g_dw_ablate = 0;
 #define DW_ABL(bit) (g_dw_ablate & (bit))
@@ -308,7 +308,8 @@ static void ablate_init() {}
 // registers until its layer (as in ddf_trunk_kernel).  Z_l / H_l leave from the accumulator registers: a store instruction
 // covers 2 rows x 32 consecutive columns = two full 128-byte lines.
 // accumulators -> Z_l (global), H_l = a(Z_l) (global + LDS tile for the next layer)
-template <int KIND, bool FULL, bool LAST, int MT, int NT, class Ops>
+// PM: Z_l / H_l leave in the POINT-MAJOR layout (train_kernels.h): the lane's four rows of a point are one 16-byte store
+template <int KIND, bool FULL, bool LAST, int MT, int NT, class Ops, bool PM>
 __device__ __forceinline__ void mlp_epilogue(const f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *Zl, float *Hl, int64_t r0,
                                              int64_t R, int wave, int lane)
 {
@@ -318,6 +319,8 @@ __device__ __forceinline__ void mlp_epilogue(const f32x16 (&acc)[MT][NT], typena
     // one 64-bit base per lane; everything else is a compile-time offset from it
     const int64_t base = (r0 + 4 * h) * kWidth + wave * NT * 32 + j;
     float *zb = Zl + base, *hb = Hl + base;
+    const int64_t pbase = ((r0 >> 2) + h) * (4 * kWidth) + (wave * NT * 32 + j) * 4;      // point r0 / 4 + h, this lane's first column
+    float *zpm = Zl + pbase, *hpm = Hl + pbase;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -334,10 +337,10 @@ __device__ __forceinline__ void mlp_epilogue(const f32x16 (&acc)[MT][NT], typena
                 const float hv[4] = { y, dy * z[1], dy * z[2], dy * z[3] };
                 const int off = (mt * 32 + 8 * g) * kWidth + t * 32;
                 if (FULL || r0 + mt * 32 + 8 * g + 4 * h < R) {     // R is a multiple of 4: a point's rows are all inside or all outside
-                    if (DW_ABL(8192)) {      // timing probe: 16 bytes per lane, [row / 4][column][row % 4]
-                        const int64_t ib = ((r0 + mt * 32 + 8 * g + 4 * h) >> 2) * (4 * kWidth) + (wave * NT * 32 + t * 32 + j) * 4;
-                        *(f32x4v *)(Zl + ib) = f32x4v{ z[0], z[1], z[2], z[3] };
-                        *(f32x4v *)(Hl + ib) = f32x4v{ hv[0], hv[1], hv[2], hv[3] };
+                    if constexpr (PM) {
+                        const int poff = (mt * 8 + 2 * g) * (4 * kWidth) + t * 128;
+                        if (!DW_ABL(16)) __builtin_nontemporal_store(f32x4v{ z[0], z[1], z[2], z[3] }, (f32x4v *)(zpm + poff));
+                        if (!DW_ABL(32)) __builtin_nontemporal_store(f32x4v{ hv[0], hv[1], hv[2], hv[3] }, (f32x4v *)(hpm + poff));
                     } else
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -355,7 +358,7 @@ __device__ __forceinline__ void mlp_epilogue(const f32x16 (&acc)[MT][NT], typena
 
 // HOLD: the skip partial waits in 64 registers (fp32); otherwise X0 is staged a second time at the skip layer (split fp16: its
 // conversion-heavy epilogue has no registers to spare -- 136 spilled with the partial held)
-template <class Ops, bool HOLD>
+template <class Ops, bool HOLD, bool PM>
 __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwardArgs a)
 {
     typedef typename Ops::act_t act_t;
@@ -381,6 +384,26 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
             Ops::zero(act + r * LD + 4 * c4cols + c);
         }
     };
+    auto stage_pm = [&](const float *X, int64_t r0) {        // 64 rows of a point-major [R, 256] matrix -> the row-major LDS tile
+        for (int idx = tid; idx < (ROWS / 4) * kWidth; idx += kThreads) {
+            const int p = idx >> 8, c = idx & 255;
+            f32x4v v = { 0.f, 0.f, 0.f, 0.f };
+            if (r0 + 4 * p < a.R) v = *(const f32x4v *)(X + ((r0 >> 2) + p) * (4 * kWidth) + 4 * c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Ops::put(act + (4 * p + q) * LD + c, v[q]);
+        }
+    };
+#ifdef NEDDF_ABLATE
+    // NEDDF_DW_ABLATE bit 32768: where a wave's time goes (shader clocks), printed by two workgroups at the end of the launch
+    const bool timed = DW_ABL(32768) != 0;
+    long long tk[6] = { 0, 0, 0, 0, 0, 0 }, tlast = 0, tstart = 0;
+    auto tick = [&](int k) { if (timed) { const long long t = clock64(); tk[k] += t - tlast; tlast = t; } };
+    long long treal = 0;
+    if (timed) { tlast = tstart = clock64(); treal = wall_clock64(); }
+#define FWD_TICK(k) tick(k)
+#else
+#define FWD_TICK(k)
+#endif
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * ROWS;
         __syncthreads();                // the previous tile is done with the LDS tile
@@ -397,7 +420,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
         dense<MT, NT, Ops>(acc, act_lane, frags(a.wp0, a.ksteps0), a.ksteps0);
         if (a.X1) {
             __syncthreads();
-            stage(a.X1, kWidth, kWidth / 4, kWidth, r0);
+            if constexpr (PM) stage_pm(a.X1, r0); else stage(a.X1, kWidth, kWidth / 4, kWidth, r0);
             __syncthreads();
             dense<MT, NT, Ops>(acc, act_lane, frags(a.wp1, kWidth / Ops::kStep), kWidth / Ops::kStep);
         }
@@ -423,11 +446,13 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
                     }
                 }
             }
+            FWD_TICK(0);                // staging + products (with their waits for weights -- and for the previous epilogue's stores)
             __syncthreads();            // every wave finished reading the previous activations
+            FWD_TICK(1);
             // one straight-line epilogue per (activation, interior / ragged tile, last layer or not): no per-group branches
             const bool full = r0 + ROWS <= a.R, last = l + 1 == a.n_layers;
             auto run = [&](auto kind, auto is_full, auto is_last) {
-                mlp_epilogue<decltype(kind)::value, decltype(is_full)::value, decltype(is_last)::value, MT, NT, Ops>(acc, act, a.Z[l], a.H[l], r0, a.R, wave, lane);
+                mlp_epilogue<decltype(kind)::value, decltype(is_full)::value, decltype(is_last)::value, MT, NT, Ops, PM>(acc, act, a.Z[l], a.H[l], r0, a.R, wave, lane);
             };
             auto by_shape = [&](auto kind) {
                 if (full) { if (last) run(kind, std::true_type{}, std::true_type{}); else run(kind, std::true_type{}, std::false_type{}); }
@@ -436,27 +461,39 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
             if (a.act_kind == 0) by_shape(std::integral_constant<int, 0>{});
             else if (a.act_kind == 1) by_shape(std::integral_constant<int, 1>{});
             else by_shape(std::integral_constant<int, 2>{});
+            FWD_TICK(2);
+#ifdef NEDDF_ABLATE
+            if (timed) { __builtin_amdgcn_s_waitcnt(0x0F70); tick(3); }        // vmcnt(0): the side stores have completed
+#endif
             if (l + 1 < a.n_layers) __syncthreads();        // the next layer reads what this epilogue wrote
+            FWD_TICK(4);
         }
     }
+#ifdef NEDDF_ABLATE
+    if (timed && (blockIdx.x == 0 || blockIdx.x == 301) && (threadIdx.x & 63) == 0)
+        printf("fwd wg %d wave %d R %lld layers %d: products %lld bar1 %lld epilogue %lld drain %lld bar2 %lld total %lld (%lld ticks of the 100 MHz clock)\n",
+               (int)blockIdx.x, (int)(threadIdx.x >> 6), (long long)a.R, a.n_layers, tk[0], tk[1], tk[2], tk[3], tk[4], (long long)clock64() - tstart,
+               (long long)wall_clock64() - treal);
+#endif
 }
 
-template <class Ops, bool HOLD>
+template <class Ops, bool HOLD, bool PM>
 static void launch_mlp_forward_ops(const MlpForwardArgs &a, int cus, hipStream_t s)
 {
     constexpr size_t lds = (size_t)64 * Ops::kLd * sizeof(typename Ops::act_t);
-    static bool once = ((void)hipFuncSetAttribute((const void *)mlp_forward_kernel<Ops, HOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    static bool once = ((void)hipFuncSetAttribute((const void *)mlp_forward_kernel<Ops, HOLD, PM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     const int64_t tiles = (a.R + 63) / 64;
-    hipLaunchKernelGGL((mlp_forward_kernel<Ops, HOLD>), dim3((unsigned)(tiles < 2 * cus ? tiles : 2 * cus)), dim3(kThreads), lds, s, a);
+    hipLaunchKernelGGL((mlp_forward_kernel<Ops, HOLD, PM>), dim3((unsigned)(tiles < 2 * cus ? tiles : 2 * cus)), dim3(kThreads), lds, s, a);
 }
 
 void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t s)
 {
     if (a.R <= 0) return;
     ablate_init();
-    if (split) launch_mlp_forward_ops<OpsF16Split, false>(a, cus, s);
-    else launch_mlp_forward_ops<OpsF32, true>(a, cus, s);
+    if (split) launch_mlp_forward_ops<OpsF16Split, false, false>(a, cus, s);      // (the split policy's per-layer backward reads row-major matrices)
+    else if (a.point_major) launch_mlp_forward_ops<OpsF32, true, true>(a, cus, s);
+    else launch_mlp_forward_ops<OpsF32, true, false>(a, cus, s);
 }
 
 // ----------------------------------------------------------------------------
@@ -468,8 +505,7 @@ __device__ __forceinline__ void mlp_backward_epilogue(const f32x16 (&acc)[2][2],
 {
     constexpr int MT = 2, NT = 2, LD = OpsF32::kLd;
     const int j = lane & 31, h = lane >> 5;
-    const int64_t base = (r0 + 4 * h) * kWidth + wave * NT * 32 + j;
-    float *gb = dZl + base;
+    float *gb = dZl + ((r0 >> 2) + h) * (4 * kWidth) + (wave * NT * 32 + j) * 4;      // point-major: point r0 / 4 + h, this lane's first column
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -486,15 +522,8 @@ __device__ __forceinline__ void mlp_backward_epilogue(const f32x16 (&acc)[2][2],
                 sj += g2 * zp[mt][t][4 * g + 2];
                 sj += g3 * zp[mt][t][4 * g + 3];
                 const float ov[4] = { g0 * dy + sj * d2, g1 * dy, g2 * dy, g3 * dy };
-                const int off = (mt * 32 + 8 * g) * kWidth + t * 32;
-                if (r0 + mt * 32 + 8 * g + 4 * h < R) {
-                    if (DW_ABL(16384)) {
-                        const int64_t ib = ((r0 + mt * 32 + 8 * g + 4 * h) >> 2) * (4 * kWidth) + (wave * NT * 32 + t * 32 + j) * 4;
-                        *(f32x4v *)(dZl + ib) = f32x4v{ ov[0], ov[1], ov[2], ov[3] };
-                    } else
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (!DW_ABL(256)) gb[off + r * kWidth] = ov[r];
-                }
+                if (r0 + mt * 32 + 8 * g + 4 * h < R && !DW_ABL(256))
+                    __builtin_nontemporal_store(f32x4v{ ov[0], ov[1], ov[2], ov[3] }, (f32x4v *)(gb + (mt * 8 + 2 * g) * (4 * kWidth) + t * 128));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (!DW_ABL(2048)) o[(8 * g + r) * LD] = ov[r];
             }
@@ -516,13 +545,29 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * ROWS;
         __syncthreads();                // the previous tile is done with the LDS tile
-        auto stage = [&](const float *src) {
-            for (int idx = tid; idx < ROWS * (kWidth / 4); idx += kThreads) {
-                const int r = idx >> 6, c = idx & 63;
+        auto stage = [&](const float *src) {            // 64 rows of a point-major matrix -> the row-major LDS tile
+            for (int idx = tid; idx < (ROWS / 4) * kWidth; idx += kThreads) {
+                const int p = idx >> 8, c = idx & 255;
                 f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-                if (r0 + r < a.R) v = *(const f32x4v *)(src + (r0 + r) * kWidth + 4 * c);
-                *(f32x4v *)(act + r * LD + 4 * c) = v;
+                if (r0 + 4 * p < a.R) v = *(const f32x4v *)(src + ((r0 >> 2) + p) * (4 * kWidth) + 4 * c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) act[(4 * p + q) * LD + c] = v[q];
             }
+        };
+        // Z of this lane's accumulator positions: the four rows of a point for one feature = one 16-byte load in the point-major layout
+        auto load_z = [&](const float *Z, f32x16 (&zp)[MT][NT]) {
+            const float *zb = Z + ((r0 >> 2) + h) * (4 * kWidth) + (wave * NT * 32 + j) * 4;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4v v = { 0.f, 0.f, 0.f, 0.f };
+                        if (r0 + mt * 32 + 8 * g + 4 * h < a.R && !DW_ABL(512)) v = __builtin_nontemporal_load((const f32x4v *)(zb + (mt * 8 + 2 * g) * (4 * kWidth) + t * 128));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zp[mt][t][4 * g + r] = v[r];
+                    }
         };
         if (a.dZtop) {
             stage(a.dZtop);
@@ -531,17 +576,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
             // prologue: the top layer's gradient is formed here instead of by two more passes over HBM (a plain GEMM kernel for the
             // colour trunk's feature gradient + a kernel that adds the heads and applies the top activation's backward)
             f32x16 zp[MT][NT], acc[MT][NT];
-            const float *zb = a.top_Z + (r0 + 4 * h) * kWidth + wave * NT * 32 + j;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const bool in = r0 + mt * 32 + 8 * g + 4 * h < a.R;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) zp[mt][t][4 * g + r] = in ? zb[(mt * 32 + 8 * g + r) * kWidth + t * 32] : 0.f;
-                    }
+            load_z(a.top_Z, zp);
             acc_init<MT, NT, false>(acc, nullptr, wave, lane);
             if (a.top_src) {
                 stage(a.top_src);
@@ -577,23 +612,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
         for (int l = a.n_layers - 1; l >= 1; --l) {
             // Z_{l-1} of this lane's accumulator positions, requested before the product (rows past R: zero; R is a multiple of 4)
             f32x16 zp[MT][NT];
-            const float *zb = a.Z[l - 1] + (r0 + 4 * h) * kWidth + wave * NT * 32 + j;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const bool in = r0 + mt * 32 + 8 * g + 4 * h < a.R;
-                        if (DW_ABL(16384)) {
-                            f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-                            if (in) v = *(const f32x4v *)(a.Z[l - 1] + ((r0 + mt * 32 + 8 * g + 4 * h) >> 2) * (4 * kWidth) + (wave * NT * 32 + t * 32 + j) * 4);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) zp[mt][t][4 * g + r] = v[r];
-                        } else
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) zp[mt][t][4 * g + r] = (in && !DW_ABL(512)) ? zb[(mt * 32 + 8 * g + r) * kWidth + t * 32] : 0.f;
-                    }
+            load_z(a.Z[l - 1], zp);
             __builtin_amdgcn_sched_barrier(0);
             f32x16 acc[MT][NT];
             acc_init<MT, NT, false>(acc, nullptr, wave, lane);
@@ -635,14 +654,21 @@ void launch_mlp_backward(const MlpBackwardArgs &a, int cus, hipStream_t s)
 // rows [rb, re) of one weight-gradient product; the LDS layout and the accumulator file are those of KT k-tiles, KTN <= KT of them
 // carry data (K <= 32 KTN) and are multiplied -- a compile-time count, so that the job-parallel kernel below can serve products of
 // different K from one accumulator allocation without run-time tests between its MFMAs
-template <int KT, int KTN = KT>
+// XPM / GPM: X / G arrive in the POINT-MAJOR layout (train_kernels.h; 256 columns, ld 256) and are staged as they are: a 32-row chunk
+// is 8 points x 256 columns x 4 rows, and a lane's operands of TWO row pairs are one 8-byte LDS read.  The contraction pairs rows
+// (4p + e, 4p + 2 + e), e = 0, 1, of a point in either layout (any pairing is the same sum; the two matrices only have to agree).
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+template <int KT, int KTN = KT, bool XPM = false, bool GPM = false>
 __device__ __forceinline__ void dw_tile_rows(const float *X, int ldx, int K, const float *G, int ldg, int64_t rb, int64_t re, float *dW,
                                              int64_t sk, int64_t sn, int nvalid, float *db, int bias_period)
 {
     constexpr int RC = 32, KP = 32 * KT, LDX = ((KP + 32) % 64 == 32) ? KP + 32 : KP + 64, LDG = kWidth + 32;
     constexpr int XPF = (RC * (KP / 4) + kThreads - 1) / kThreads, GPF = RC * (kWidth / 4) / kThreads;
+    constexpr int PS = 4 * kWidth;              // floats per point in the point-major layout
+    static_assert(!XPM || KT == 8, "a point-major X has 256 columns");
+    static_assert(kThreads == kWidth, "point-major staging: thread = column");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Xs = smem, *Gs = smem + RC * LDX;
+    float *Xs = smem, *Gs = smem + RC * LDX;    // (a point-major chunk is 8 PS floats <= RC LDX)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int n0 = wave * 64;
     if (rb >= re) return;
@@ -654,23 +680,27 @@ __device__ __forceinline__ void dw_tile_rows(const float *X, int ldx, int K, con
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[kt][t][q] = 0.f;
-    f32x4v bsum = { 0.f, 0.f, 0.f, 0.f };       // this thread's share of db: columns 4 (tid & 63) .. +3
+    // this thread's share of db.  Row-major G: columns 4 (tid & 63) .. +3 of rows wave + 4 i; point-major: column tid (component 0)
+    f32x4v bsum = { 0.f, 0.f, 0.f, 0.f };
     f32x4v xp[XPF], gp[GPF];
     // Which 16-byte pieces of a 32-row chunk this thread stages never changes: its element offsets from the chunk's first row are
     // computed once (-1: a padding column of X), and a FULL chunk is fetched with one 64-bit base per matrix and those offsets.
     // Per chunk the index arithmetic, three bounds tests and the 64-bit address of every piece had been ~370 vector
     // instructions per wave in front of 256 MFMAs, with nothing to overlap them at one wave per SIMD (PMC: 1.45 per MFMA).
+    // (point-major: piece i = point i of the chunk, column tid; the chunk's first element is at c0 * 256 either way)
     int xoff[XPF], goff[GPF];
 #pragma unroll
     for (int i = 0; i < XPF; ++i) {
         const int idx = tid + i * kThreads, r = idx / (KP / 4), c = idx - r * (KP / 4);
-        xoff[i] = (r < RC && c < k4) ? r * ldx + 4 * c : -1;
+        xoff[i] = XPM ? i * PS + 4 * tid : ((r < RC && c < k4) ? r * ldx + 4 * c : -1);
     }
 #pragma unroll
     for (int i = 0; i < GPF; ++i) {
         const int idx = tid + i * kThreads;
-        goff[i] = (idx >> 6) * ldg + 4 * (idx & 63);
+        goff[i] = GPM ? i * PS + 4 * tid : (idx >> 6) * ldg + 4 * (idx & 63);
     }
+    auto xrow = [&](int i) { return XPM ? 4 * i : (tid + i * kThreads) / (KP / 4); };       // first chunk row of piece i
+    auto grow = [&](int i) { return GPM ? 4 * i : (tid + i * kThreads) >> 6; };
     auto fetch = [&](int64_t c0) {
         const float *xb = X + c0 * ldx, *gb = G + c0 * ldg;
         if (DW_ABL(1)) {
@@ -693,16 +723,14 @@ __device__ __forceinline__ void dw_tile_rows(const float *X, int ldx, int K, con
         }
 #pragma unroll
         for (int i = 0; i < XPF; ++i) {
-            int idx = tid + i * kThreads, r = idx / (KP / 4);
             f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-            if (xoff[i] >= 0 && c0 + r < re) v = *(const f32x4v *)(xb + xoff[i]);
+            if (xoff[i] >= 0 && c0 + xrow(i) < re) v = *(const f32x4v *)(xb + xoff[i]);
             xp[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < GPF; ++i) {
-            int idx = tid + i * kThreads, r = idx >> 6;
             f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-            if (c0 + r < re) v = *(const f32x4v *)(gb + goff[i]);
+            if (c0 + grow(i) < re) v = *(const f32x4v *)(gb + goff[i]);
             gp[i] = v;
         }
     };
@@ -712,51 +740,67 @@ __device__ __forceinline__ void dw_tile_rows(const float *X, int ldx, int K, con
 #pragma unroll
         for (int i = 0; i < XPF; ++i) {
             int idx = tid + i * kThreads, r = idx / (KP / 4), c = idx - r * (KP / 4);
-            if (r < RC && !DW_ABL(2)) *(f32x4v *)(Xs + r * LDX + 4 * c) = xp[i];
+            if (XPM) { if (!DW_ABL(2)) *(f32x4v *)(Xs + i * PS + 4 * tid) = xp[i]; }
+            else if (r < RC && !DW_ABL(2)) *(f32x4v *)(Xs + r * LDX + 4 * c) = xp[i];
         }
 #pragma unroll
         for (int i = 0; i < GPF; ++i) {
             int idx = tid + i * kThreads;
-            if (!DW_ABL(2)) *(f32x4v *)(Gs + (idx >> 6) * LDG + 4 * (idx & 63)) = gp[i];
-            // db: column sums over the value rows, taken here from the staged registers (row idx >> 6 = wave + 4 i; chunks start at
-            // multiples of 32 and bias_period is 1 or 4, so the row's phase is its phase in the chunk; rows past `re` are zero).
+            // db: column sums over the value rows, taken here from the staged registers (row-major: row idx >> 6 = wave + 4 i; chunks
+            // start at multiples of 32 and bias_period is 1 or 4, so the row's phase is its phase in the chunk; rows past `re` are zero).
             // Inside the MFMA loop -- first as a 64-bit vector modulo per row pair, 280 of that loop's 314 vector instructions per
             // 64 MFMAs, then as a masked add -- every one of these instructions broke the MFMA issue chain
-            if (db && (((idx >> 6) & (bias_period - 1)) == 0)) bsum += gp[i];
+            if (GPM) {
+                if (!DW_ABL(2)) *(f32x4v *)(Gs + i * PS + 4 * tid) = gp[i];
+                if (db) bsum[0] += bias_period == 4 ? gp[i][0] : (gp[i][0] + gp[i][1]) + (gp[i][2] + gp[i][3]);
+            } else {
+                if (!DW_ABL(2)) *(f32x4v *)(Gs + (idx >> 6) * LDG + 4 * (idx & 63)) = gp[i];
+                if (db && (((idx >> 6) & (bias_period - 1)) == 0)) bsum += gp[i];
+            }
         }
         if (!DW_ABL(2)) __syncthreads();
         if (c0 + RC < re) fetch(c0 + RC);
         __builtin_amdgcn_sched_barrier(0);
         if (DW_ABL(4)) continue;
-        // Software pipeline over the row pairs of the chunk: the operands of pair rp + 1 (KT + 2 LDS reads) are requested before the
-        // 2 KT MFMAs of pair rp issue.  Left to itself hipcc reads each pair of k-tiles right in front of its four MFMAs and waits
+        // Software pipeline over the points of the chunk (2 row pairs each): the operands of point p + 1 are requested before the
+        // 4 KT MFMAs of point p issue.  Left to itself hipcc reads each pair of k-tiles right in front of its four MFMAs and waits
         // (`ds_read2_b32; s_waitcnt lgkmcnt(0)` every 4 MFMAs: the LDS latency of 16 loads per chunk row pair, un-overlapped with
         // one wave per SIMD) -- the kernel streamed at 68 % of the matrix peak (PMC: 1.45 vector instructions per MFMA, matrix pipe
         // busy 68 %)
-        const float *xr = Xs + h * LDX + j, *gr = Gs + h * LDG + n0 + j;
-        float a0[KT], a1[KT], b00, b01, b10, b11;
-        auto load_pair = [&](float (&a)[KT], float &b0, float &b1, int rp) {
-            b0 = gr[2 * rp * LDG]; b1 = gr[2 * rp * LDG + 32];
+        const float *xr = XPM ? Xs + 4 * j + 2 * h : Xs + 2 * h * LDX + j;
+        const float *gr = GPM ? Gs + 4 * (n0 + j) + 2 * h : Gs + 2 * h * LDG + n0 + j;
+        float a0[KT][2], a1[KT][2], b0[2][2], b1[2][2];
+        auto load_point = [&](float (&a)[KT][2], float (&b)[2][2], int p) {
 #pragma unroll
-            for (int kt = 0; kt < KTN; ++kt) a[kt] = xr[2 * rp * LDX + 32 * kt];
-        };
-        auto mfma_pair = [&](const float (&a)[KT], float b0, float b1) {
+            for (int t = 0; t < 2; ++t) {
+                if (GPM) { const f32x2v v = *(const f32x2v *)(gr + p * PS + t * 128); b[t][0] = v[0]; b[t][1] = v[1]; }
+                else { b[t][0] = gr[(4 * p) * LDG + 32 * t]; b[t][1] = gr[(4 * p + 1) * LDG + 32 * t]; }
+            }
 #pragma unroll
             for (int kt = 0; kt < KTN; ++kt) {
-                acc[kt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], b0, acc[kt][0], 0, 0, 0);
-                acc[kt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], b1, acc[kt][1], 0, 0, 0);
+                if (XPM) { const f32x2v v = *(const f32x2v *)(xr + p * PS + kt * 128); a[kt][0] = v[0]; a[kt][1] = v[1]; }
+                else { a[kt][0] = xr[(4 * p) * LDX + 32 * kt]; a[kt][1] = xr[(4 * p + 1) * LDX + 32 * kt]; }
             }
         };
-        load_pair(a0, b00, b01, 0);
+        auto mfma_point = [&](const float (&a)[KT][2], const float (&b)[2][2]) {
 #pragma unroll
-        for (int rp = 0; rp < RC / 2; rp += 2) {
-            load_pair(a1, b10, b11, rp + 1);
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int kt = 0; kt < KTN; ++kt) {
+                    acc[kt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt][e], b[0][e], acc[kt][0], 0, 0, 0);
+                    acc[kt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt][e], b[1][e], acc[kt][1], 0, 0, 0);
+                }
+        };
+        load_point(a0, b0, 0);
+#pragma unroll
+        for (int p = 0; p < RC / 4; p += 2) {
+            load_point(a1, b1, p + 1);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_pair(a0, b00, b01);
+            mfma_point(a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            if (rp + 2 < RC / 2) load_pair(a0, b00, b01, rp + 2);
+            if (p + 2 < RC / 4) load_point(a0, b0, p + 2);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_pair(a1, b10, b11);
+            mfma_point(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -770,7 +814,9 @@ __device__ __forceinline__ void dw_tile_rows(const float *X, int ldx, int K, con
                 if (k < K && n < nvalid && !DW_ABL(8)) atomicAdd(&dW[k * sk + n * sn], acc[kt][t][q]);
             }
     }
-    if (db && (wave & (bias_period - 1)) == 0) {        // staged rows are wave + 4 i: with bias_period 4 only wave 0 holds value rows
+    if (GPM) {
+        if (db && tid < nvalid) atomicAdd(&db[tid], bsum[0]);
+    } else if (db && (wave & (bias_period - 1)) == 0) {        // staged rows are wave + 4 i: with bias_period 4 only wave 0 holds value rows
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (4 * lane + q < nvalid) atomicAdd(&db[4 * lane + q], bsum[q]);
@@ -799,9 +845,12 @@ __global__ __launch_bounds__(kThreads, 1) void dw_jobs_kernel(const DwJobs jobs)
     const int64_t chunks = (jobs.R + 31) / 32, per = (chunks + nw - 1) / nw;
     const int64_t rb = (int64_t)w * per * 32, re_ = rb + per * 32;
     const int64_t re = re_ < jobs.R ? re_ : jobs.R;
-    if (J.K <= 64) dw_tile_rows<8, 2>(J.X, J.ldx, J.K, J.G, J.ldg, rb, re, J.dW, J.sk, J.sn, J.nvalid, J.db, J.bias_period);
-    else if (J.K <= 96) dw_tile_rows<8, 3>(J.X, J.ldx, J.K, J.G, J.ldg, rb, re, J.dW, J.sk, J.sn, J.nvalid, J.db, J.bias_period);
-    else dw_tile_rows<8, 8>(J.X, J.ldx, J.K, J.G, J.ldg, rb, re, J.dW, J.sk, J.sn, J.nvalid, J.db, J.bias_period);
+    // G (a dZ of the fused backward chain) is point-major in every job; X is point-major when it is a hidden state (K = 256), row-major
+    // when it is one of the narrow first-layer inputs
+    if (J.x_point_major) dw_tile_rows<8, 8, true, true>(J.X, J.ldx, J.K, J.G, J.ldg, rb, re, J.dW, J.sk, J.sn, J.nvalid, J.db, J.bias_period);
+    else if (J.K <= 64) dw_tile_rows<8, 2, false, true>(J.X, J.ldx, J.K, J.G, J.ldg, rb, re, J.dW, J.sk, J.sn, J.nvalid, J.db, J.bias_period);
+    else if (J.K <= 96) dw_tile_rows<8, 3, false, true>(J.X, J.ldx, J.K, J.G, J.ldg, rb, re, J.dW, J.sk, J.sn, J.nvalid, J.db, J.bias_period);
+    else dw_tile_rows<8, 8, false, true>(J.X, J.ldx, J.K, J.G, J.ldg, rb, re, J.dW, J.sk, J.sn, J.nvalid, J.db, J.bias_period);
 }
 
 void launch_dw_jobs(DwJobs &jobs, int cus, hipStream_t s)
@@ -853,6 +902,7 @@ struct NarrowGrad {
     float *b[4];          // scalar bias gradients (or NULL)
     int kcount;           // input features present (<= 256)
 };
+template <bool PM>      // PM: X point-major (ld 256); rows_per_wg is a multiple of 4
 __global__ __launch_bounds__(kThreads) void narrow_dw_kernel(const float *X, int ldx, const float *G, int ldg, int64_t R, int64_t rows_per_wg,
                                                              NarrowGrad o, int bias_period)
 {
@@ -861,8 +911,14 @@ __global__ __launch_bounds__(kThreads) void narrow_dw_kernel(const float *X, int
     float acc[4] = { 0.f, 0.f, 0.f, 0.f }, bs[4] = { 0.f, 0.f, 0.f, 0.f };
     for (int64_t r0 = rb; r0 < re; r0 += 4) {           // four independent row loads in flight
         float x[4];
+        if (PM) {
+            const f32x4v v = *(const f32x4v *)(X + (r0 >> 2) * (4 * kWidth) + 4 * k);      // R is a multiple of 4: the point is whole
 #pragma unroll
-        for (int u = 0; u < 4; ++u) x[u] = r0 + u < re ? X[(r0 + u) * ldx + k] : 0.f;
+            for (int u = 0; u < 4; ++u) x[u] = v[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = r0 + u < re ? X[(r0 + u) * ldx + k] : 0.f;
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t r = r0 + u;
@@ -883,7 +939,7 @@ __global__ __launch_bounds__(kThreads) void narrow_dw_kernel(const float *X, int
     }
 }
 void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t R, int nc, float *const *w, int wstride, float *const *b,
-                      int bias_period, int kcount, hipStream_t s)
+                      int bias_period, int kcount, hipStream_t s, int x_point_major)
 {
     if (R <= 0) return;
     NarrowGrad o{};
@@ -891,8 +947,9 @@ void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t 
     for (int c = 0; c < nc; ++c) { o.w[c] = w[c]; o.b[c] = b ? b[c] : nullptr; }
     int grid = (int)((R + 255) / 256);
     if (grid > 4096) grid = 4096;
-    int64_t rows_per_wg = (R + grid - 1) / grid;
-    hipLaunchKernelGGL(narrow_dw_kernel, dim3(grid), dim3(kThreads), 0, s, X, ldx, G, ldg, R, rows_per_wg, o, bias_period);
+    int64_t rows_per_wg = ((R + grid - 1) / grid + 3) & ~(int64_t)3;
+    if (x_point_major) hipLaunchKernelGGL(narrow_dw_kernel<true>, dim3(grid), dim3(kThreads), 0, s, X, ldx, G, ldg, R, rows_per_wg, o, bias_period);
+    else hipLaunchKernelGGL(narrow_dw_kernel<false>, dim3(grid), dim3(kThreads), 0, s, X, ldx, G, ldg, R, rows_per_wg, o, bias_period);
 }
 
 // The same product with split-fp16 operands (tile_engine.h OpsF16Split; three fp16 MFMAs per multiply-add).  The contraction
@@ -1524,6 +1581,7 @@ void launch_pack(int split, const float *src, int64_t sk, int64_t sn, int k_off,
 }
 
 // narrow heads (1..4 output columns from a 256-wide input): one wavefront per row
+template <bool PM>      // PM: X point-major (ld 256, R a multiple of 4): the wave's four rows are one point
 __global__ __launch_bounds__(256) void narrow_forward_kernel(const float *X, int ldx, int64_t R, NarrowW w, int bias_period, float *Y, int ldy)
 {
     const int lane = threadIdx.x & 63;
@@ -1535,10 +1593,19 @@ __global__ __launch_bounds__(256) void narrow_forward_kernel(const float *X, int
     const int64_t nw = (int64_t)gridDim.x * 4, w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     for (int64_t base = w0 * 4; base < R; base += nw * 4) {         // four rows per wave per pass
         f32x4v x[4];
+        if (PM) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
-            x[u] = base + u < R ? *(const f32x4v *)(X + (base + u) * ldx + 4 * lane) : zero;
+            for (int q = 0; q < 4; ++q) {       // feature 4 lane + q: its four rows
+                const f32x4v v = *(const f32x4v *)(X + (base >> 2) * (4 * kWidth) + 4 * (4 * lane + q));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u][q] = v[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
+                x[u] = base + u < R ? *(const f32x4v *)(X + (base + u) * ldx + 4 * lane) : zero;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1554,12 +1621,13 @@ __global__ __launch_bounds__(256) void narrow_forward_kernel(const float *X, int
         }
     }
 }
-void launch_narrow_forward(const float *X, int ldx, int64_t R, const NarrowW &w, int bias_period, float *Y, int ldy, hipStream_t s)
+void launch_narrow_forward(const float *X, int ldx, int64_t R, const NarrowW &w, int bias_period, float *Y, int ldy, hipStream_t s, int x_point_major)
 {
     if (R <= 0) return;
     int64_t wgs = (R + 15) / 16;
     if (wgs > 8192) wgs = 8192;
-    hipLaunchKernelGGL(narrow_forward_kernel, dim3((unsigned)wgs), dim3(256), 0, s, X, ldx, R, w, bias_period, Y, ldy);
+    if (x_point_major) hipLaunchKernelGGL(narrow_forward_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, s, X, ldx, R, w, bias_period, Y, ldy);
+    else hipLaunchKernelGGL(narrow_forward_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, s, X, ldx, R, w, bias_period, Y, ldy);
 }
 __global__ void narrow_backward_kernel(const float *G, int ldg, int64_t R, NarrowW w, float *dX, int ldx, int accumulate)
 {
