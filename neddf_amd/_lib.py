@@ -388,8 +388,14 @@ class Context:
     def train_field_backward(self, slot, weights, biases, N, ws, g_distance, g_density, g_color, g_penalty, g_aux):
         """Returns (grad_weights, grad_biases) in the layout of `weights` / `biases`."""
         gs = [None if g is None else f32c(g) for g in (g_distance, g_density, g_color, g_penalty, g_aux)]
-        gw = [torch.zeros_like(w) for w in weights]
-        gb = [torch.zeros_like(b) for b in biases]
+        # one zero fill for all gradients (the kernels accumulate into them): views into a flat buffer, 16-byte aligned pieces
+        offs, at = [], 0
+        for t in list(weights) + list(biases):
+            offs.append(at)
+            at += (t.numel() + 3) & ~3
+        flat = torch.zeros(at, device=weights[0].device, dtype=torch.float32)
+        views = [flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, list(weights) + list(biases))]
+        gw, gb = views[:len(weights)], views[len(weights):]
         wa, ba = self._dev_ptrs(weights, "weights"), self._dev_ptrs(biases, "biases")
         gwa, gba = self._dev_ptrs(gw, "weight gradients"), self._dev_ptrs(gb, "bias gradients")
         self.check(self.lib.neddf_train_field_backward(self.h, slot, wa, ba, len(weights), N, _ptr(ws), _ptr(gs[0]), _ptr(gs[1]),
