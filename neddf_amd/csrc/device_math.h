@@ -25,9 +25,11 @@ __device__ __forceinline__ float tanh_nonneg(float u)
     return u < 0.3f ? poly : big;
 }
 
-// Reduced-cost tanhExp for the bf16-operand kernels (results are rounded to 8 mantissa bits anyway): no small-argument
+// Reduced-cost tanhExp of the fused kernels (every operand policy since round 3, tile_engine.h kFastAct): no small-argument
 // polynomial, no x > 20 branch (tanh saturates to exactly 1 there; the clamp keeps x e^x finite).  11 VALU instructions
-// instead of 23 -- in those kernels the matrix pipe and the VALU hardly overlap, so every instruction is wall time.
+// instead of 23 -- the matrix pipe and the VALU do not overlap, so every instruction is wall time.  Where e^x < 0.3 the
+// difference 1 - 2 r loses relative accuracy (absolute error of tanh ~1e-7, of y ~1e-7 |x|): rounding noise next to O(1)
+// activations, see the measurements cited at kFastAct.
 __device__ __forceinline__ void tanhexp_grad_fast(float x, float &y, float &dy)
 {
     // v_med3_f32 clamps in ONE instruction (fminf costs a NaN-quieting v_max in front of its v_min)
