@@ -158,7 +158,10 @@ int neddf_rays_to_ndc(neddf_ctx *ctx, const float *d_ray_dir, const float *d_ray
  * NeDDF without a penalty output (NEDDF_OUT_MINIMAL, or d_penalty == NULL) and NeuS: the position gradient of the distance / sdf is taken
  * in reverse mode (one gradient row per point instead of the reference's three forward-mode Jacobian rows, neddf.py:206-230);
  * with a penalty output the Jacobian rows are carried forward as in the reference.  The two agree within rounding (the
- * parity gates of tests/test_gpu_parity.py hold for both). */
+ * parity gates of tests/test_gpu_parity.py hold for both).
+ * Hidden tanhExp activations (nn_module/with_grad/tanh_exp.py:15-54) are evaluated as x (1 - 2 / (e^(2 e^x) + 1)) for every x: absolute
+ * error ~1e-7 |x| where the reference's tanh keeps relative accuracy; network outputs stay as close to an fp64 evaluation as the
+ * reference's own fp32 ones.  The stand-alone neddf_op_activation below keeps the reference's form. */
 int neddf_field_forward(neddf_ctx *ctx, int slot, const float *d_pos, const float *d_dir, const float *d_var,
                         int64_t n_points, int out_mode, float *d_distance, float *d_density, float *d_color,
                         float *d_fields_penalty, float *d_aux_grad, void *stream);
