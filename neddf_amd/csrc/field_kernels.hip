@@ -366,7 +366,7 @@ __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], type
                     float z = acc[mt][t][q + u];
                     if constexpr (Ops::kWScale != 1.0f) z *= (1.0f / Ops::kWScale);
                     float dy;
-                    act_grad<KIND, Ops::kFastAct>(z, y[u], dy);
+                    act_grad<KIND, Ops::kActMode>(z, y[u], dy);
                     // y' replaces the accumulator (LAST: the seed of the reverse pass, dz_D / dz_L).  The stashed copy carries the
                     // weight scale's inverse (a power of two: exact), so the reverse epilogue is one multiply per element
                     if constexpr (MASK) mbits[(mt * NT + t) / 2] |= (dy == 1.0f ? 1u : 0u) << (16 * ((mt * NT + t) & 1) + q + u);

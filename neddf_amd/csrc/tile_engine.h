@@ -24,6 +24,21 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
+// `make exactact` (-DNEDDF_EXACT_ACT -> libneddf_hip_exactact.so) builds the fp32 and split-fp16 policies with the reference's
+// branch-exact tanhExp in the fused kernels too, so that the reduced-cost form stays A/B-testable on any network
+// (tests/test_gpu_parity.py::test_fast_activation_against_the_branch_exact_build)
+// (-DNEDDF_ACT_F32=<mode> / -DNEDDF_ACT_SPLIT=<mode> build any other pairing for A/B timing: tools/act_variants.sh)
+#ifdef NEDDF_EXACT_ACT
+#define NEDDF_ACT_F32 0
+#define NEDDF_ACT_SPLIT 0
+#endif
+#ifndef NEDDF_ACT_F32
+#define NEDDF_ACT_F32 1
+#endif
+#ifndef NEDDF_ACT_SPLIT
+#define NEDDF_ACT_SPLIT 2
+#endif
+
 // Every policy is written over the engine width WID (hidden width padded to a multiple of 128: four waves x 32-column MFMA
 // tiles); the 256-wide aliases below are what the shipped configurations and the training kernels use.
 template <int WID>
@@ -42,7 +57,7 @@ struct OpsF32T {
     // is fp32 rounding noise at the scale of the activations: on the shipped network density / distance / colour sit as close to the
     // fp64 evaluation as with the branch-exact form (profiles/r03_fast_tanhexp.txt; tests/test_gpu_parity.py holds density to 2.5x the
     // reference's own fp32 error either way).  The stand-alone ops (nn_module) and the training kernels keep the branch-exact form.
-    static constexpr bool kFastAct = true;
+    static constexpr int kActMode = NEDDF_ACT_F32;
     static constexpr int kPlanes = 1, kPlane = 0;
     static constexpr bool kLean = false;     // room for register-resident extras (skip partial, feature prefetch)
     static constexpr bool kPackedRows = false;
@@ -78,7 +93,7 @@ struct OpsBF16T {
     static constexpr int kStep = 16;
     static constexpr int kSub = 1;
     static constexpr bool kFast = true;      // reduced-cost elementwise math (device_math.h), invisible after bf16 rounding
-    static constexpr bool kFastAct = true;
+    static constexpr int kActMode = 1;
     static constexpr int kPlanes = 1, kPlane = 0;
     static constexpr bool kLean = false;
     static constexpr float kWScale = 1.0f;
@@ -147,7 +162,8 @@ struct OpsF16SplitT {
     static constexpr int kStep = 16;
     static constexpr int kSub = 3;
     static constexpr bool kFast = false;
-    static constexpr bool kFastAct = true;      // as OpsF32T
+    static constexpr int kActMode = NEDDF_ACT_SPLIT;      // the middle form: this policy is sold on the fp32 gates, and the closed form alone
+                                                          // triples its density error where most pre-activations are very negative (profiles/r04_act_modes.txt)
     static constexpr bool kLean = false;                 // measured: register-resident skip partial / feature prefetch pay off here too
     static constexpr bool kPackedRows = false;
     static constexpr float kWScale = 1024.0f;            // weights are packed as 2^10 w
@@ -479,31 +495,31 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[MT][NT], typename O
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
                     if (ROWS4) {
                         f32x2 lo, hi;
-                        if constexpr (KIND == 2 && Ops::kFastAct) {
+                        if constexpr (KIND == 2 && Ops::kActMode == 1) {
                             float tx, dy;
                             tanhexp_parts_fast(z[0], tx, dy);
                             lo = (f32x2){ z[0] * tx, z[1] * dy };
                             hi = (f32x2){ z[2] * dy, z[3] * dy };
                         } else {
                             float y, dy;
-                            act_grad<KIND, Ops::kFastAct>(z[0], y, dy);
+                            act_grad<KIND, Ops::kActMode>(z[0], y, dy);
                             lo = (f32x2){ y, dy * z[1] };
                             hi = (f32x2){ z[2] * dy, z[3] * dy };
                         }
                         Ops::put_rows4(o + (8 * g) * LD, LD, lo[0], lo[1], hi[0], hi[1]);
                     } else {
-                        Ops::put_rows4(o + (8 * g) * LD, LD, act_val<KIND, Ops::kFastAct>(z[0]), act_val<KIND, Ops::kFastAct>(z[1]),
-                                       act_val<KIND, Ops::kFastAct>(z[2]), act_val<KIND, Ops::kFastAct>(z[3]));
+                        Ops::put_rows4(o + (8 * g) * LD, LD, act_val<KIND, Ops::kActMode>(z[0]), act_val<KIND, Ops::kActMode>(z[1]),
+                                       act_val<KIND, Ops::kActMode>(z[2]), act_val<KIND, Ops::kActMode>(z[3]));
                     }
                 } else if (ROWS4) {
                     float y, dy;
-                    act_grad<KIND, Ops::kFastAct>(z[0], y, dy);
+                    act_grad<KIND, Ops::kActMode>(z[0], y, dy);
                     Ops::put2(o + (8 * g + 0) * LD, o + (8 * g + 1) * LD, y, dy * z[1]);
                     Ops::put2(o + (8 * g + 2) * LD, o + (8 * g + 3) * LD, dy * z[2], dy * z[3]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; r += 2)
-                        Ops::put2(o + (8 * g + r) * LD, o + (8 * g + r + 1) * LD, act_val<KIND, Ops::kFastAct>(z[r]), act_val<KIND, Ops::kFastAct>(z[r + 1]));
+                        Ops::put2(o + (8 * g + r) * LD, o + (8 * g + r + 1) * LD, act_val<KIND, Ops::kActMode>(z[r]), act_val<KIND, Ops::kActMode>(z[r + 1]));
                 }
             }
         }

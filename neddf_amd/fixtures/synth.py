@@ -113,3 +113,36 @@ def neus_state(embed_pos_rank=6, embed_dir_rank=4, sdf_layer_count=8, sdf_layer_
         sd["layers_col.%d.weight" % i], sd["layers_col.%d.bias" % i] = _layer(rng, a, b, True)
     sd["variance"] = np.float32(init_variance)
     return sd
+
+
+def neddf_state_negbias(embed_pos_rank=10, embed_dir_rank=4, ddf_layer_count=8, ddf_layer_width=256, col_layer_count=4,
+                        col_layer_width=256, skips=(4,), seed=7, frac=0.8, lo=-15.0, hi=-1.0, wscale=3.0, head_bias=-3.0):
+    """`neddf_state` pushed into the regime where a tanhExp evaluated as 1 - 2 / (e^(2 e^x) + 1) loses RELATIVE accuracy:
+    a fraction `frac` of the hidden units of both trunks get a bias drawn from [lo, hi], so their pre-activations sit at
+    e^x << 0.3; the hidden weights are scaled by `wscale` so that the remaining units still carry a position-dependent
+    signal, and the distance head's bias makes D = softplus(z) + d_near small (the 1/D of the density, neddf.py:239)."""
+    sd = neddf_state(embed_pos_rank, embed_dir_rank, ddf_layer_count, ddf_layer_width, col_layer_count, col_layer_width, skips, seed)
+    rng = np.random.default_rng(seed + 1000)
+    for k in list(sd):
+        if not k.startswith(("layers_ddf.", "layers_col.")):
+            continue
+        if k.endswith(".weight"):
+            sd[k] = (sd[k] * np.float32(wscale)).astype(np.float32)
+        else:
+            b = sd[k].copy()
+            m = rng.uniform(size=b.shape) < frac
+            b[m] = rng.uniform(lo, hi, size=int(m.sum())).astype(np.float32)
+            sd[k] = b
+    sd["layer_ddf_out.bias"] = np.full_like(sd["layer_ddf_out.bias"], head_bias)
+    return sd
+
+
+def wide_sampling(n_rays, n_samples, seed, reach=6.0):
+    """`random_sampling` with half of the rays reaching out to |pos| <= reach (2^9 * 6 rad at the highest frequency of a
+    rank-10 encoding) and half of the rays at zero variance (point sampling: the high frequencies keep their weight)."""
+    pos, d, var = random_sampling(n_rays, n_samples, seed, cone=True)
+    rng = np.random.default_rng(seed + 77)
+    far = rng.uniform(-reach, reach, pos.shape).astype(np.float32)
+    pos[n_rays // 2:] = far[n_rays // 2:]
+    var[::2] = 0.0
+    return pos, d, var

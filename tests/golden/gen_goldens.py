@@ -918,6 +918,80 @@ def gen_fp64():
     torch.set_default_dtype(torch.float32)
 
 
+NEGBIAS_KW = dict(embed_pos_rank=10, embed_dir_rank=4, ddf_layer_count=8, ddf_layer_width=256, col_layer_count=4,
+                  col_layer_width=256, d_near=0.001, activation_type="tanhExp", density_activation_type="LeakyReLU",
+                  skips=[4], lowpass_alpha_offset=10,
+                  penalty_weight={"constraints_aux_grad": 0.05, "constraints_dDdt": 1.0, "constraints_color": 0.0001,
+                                  "range_distance": 1.0, "range_aux_grad": 1.0, "range_color": 0.1})
+
+
+def gen_negbias():
+    """The regime in which the fused kernels' reduced-cost arithmetic differs from the reference's:
+    tanhExp networks whose pre-activations sit at e^x << 0.3 on most units (`synth.neddf_state_negbias`: 80 % of the hidden
+    biases in [-15, -1]) -- where 1 - 2 / (e^(2 e^x) + 1) has lost its relative accuracy --, a small D (d_near = 1e-3, distance
+    head biased to softplus ~ 0.05: the 1/D of neddf.py:239 amplifies), sample positions out to |pos| = 6 under a rank-10
+    encoding (sincos arguments to 2^9 * 6 rad) and zero-variance points (the high frequencies keep their weight).  fp32
+    outputs of the reference AND its evaluation in double; the pre-activation quantiles the reference saw are stored so that the
+    fixture documents its own regime.  Plus one 64-ray render_rays through NeRFRender on the same network."""
+    kw = NEGBIAS_KW
+    pos, d, var = synth.wide_sampling(8, 48, seed=5)
+    sd = synth.neddf_state_negbias(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["ddf_layer_count"], kw["ddf_layer_width"],
+                                   kw["col_layer_count"], kw["col_layer_width"], tuple(kw["skips"]), seed=7)
+    arrs = dict(pos=pos, dir=d, var=var, config=np.array(json.dumps(kw)))
+    for dtype, suffix in ((torch.float32, ""), (torch.float64, "_fp64")):
+        torch.set_default_dtype(dtype)
+        net = NeDDF(**kw)
+        print("negbias", dtype, net.load_state_dict({k: v.to(dtype) for k, v in to_torch_sd(sd).items()}))
+        seen = []
+        inner = net.activation
+
+        def spy(x, J, inner=inner, seen=seen):
+            seen.append(npy(x).reshape(-1))
+            return inner(x, J)
+        net.activation = spy
+        smp_t = Sampling(*(torch.from_numpy(x).to(dtype) for x in (pos, d, var)))
+        for it in (-1, 2500):
+            net.set_iter(it)
+            del seen[:]
+            out = net(smp_t)
+            tag = "eval" if it == -1 else "it%d" % it
+            for k, v in out.items():
+                arrs["%s_%s%s" % (tag, k, suffix)] = npy(v)
+            if dtype == torch.float32 and it == -1:
+                z = np.concatenate(seen)
+                arrs["preact_quantiles"] = np.quantile(z, [0.0, 0.05, 0.25, 0.5, 0.75, 0.95, 1.0]).astype(np.float32)
+                arrs["preact_frac_below_m1"] = np.float32((z < -1.0).mean())
+                print("pre-activations: quantiles", arrs["preact_quantiles"], "fraction below -1:", arrs["preact_frac_below_m1"])
+        torch.set_default_dtype(torch.float32)
+    for k in ("distance", "density", "aux_grad", "color", "fields_penalty"):
+        a, b = arrs["eval_" + k], arrs["eval_" + k + "_fp64"]
+        print("  %-15s range [%.4g, %.4g]  reference fp32-vs-fp64 max abs %.3g" % (k, a.min(), a.max(), np.abs(a - b).max()))
+    save("neddf_negbias.npz", **arrs)
+
+    # 64 rays through the whole renderer on that network (cone sampling, 32 + 64 samples, camera at radius ~4: |pos| up to ~6)
+    ncfg = dict(kw, _target_="neddf.network.NeDDF")
+    render = NeRFRender(network_config=ncfg, sample_coarse=32, sample_fine=64, dist_near=2.0, dist_far=6.0, max_dist=6.0,
+                        use_coarse_network=False, sampling_type="cone")
+    render.network_fine.load_state_dict(to_torch_sd(sd))
+    render.set_iter(-1)
+    calib = np.array([1111.1, 1111.1, 400.0, 400.0])
+    cam = Camera(PinholeCalib(calib), np.array([0.9, -0.5, 0.3, 1.2, -2.9, 2.4], dtype=np.float32))
+    cam.update_transform()
+    rs = np.random.RandomState(4)
+    uv = torch.from_numpy(rs.randint(0, 800, (64, 2)).astype(np.int64))
+    torch.manual_seed(11)
+    state = torch.get_rng_state()
+    u_c = torch.rand(64, 33)
+    u_f = torch.rand(64, 65)
+    torch.set_rng_state(state)
+    out = render.render_rays(uv, cam)
+    r = dict(uv=npy(uv), R=npy(cam.R), T=npy(cam.T), calib=calib.astype(np.float32), u_coarse=npy(u_c), u_fine=npy(u_f))
+    for k, v in out.items():
+        r["out_" + k] = npy(v)
+        print("  render_rays %-22s range [%.4g, %.4g]" % (k, float(v.min()), float(v.max())))
+    save("neddf_negbias_render_rays.npz", **r)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train_nerf":
         gen_train_nerf()
@@ -941,6 +1015,10 @@ if __name__ == "__main__":
         from neddf.ray import Sampling  # noqa: F401  (gen_bunny normally imports the reference first)
         gen_fields()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "negbias":
+        from neddf.ray import Sampling  # noqa: F401
+        gen_negbias()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "configs":
         gen_config_digests()
         sys.exit(0)
@@ -962,4 +1040,5 @@ if __name__ == "__main__":
     gen_train_nerf()
     gen_train_neus()
     gen_train_widths()
+    gen_negbias()
     gen_fp64()          # last: switches torch's default dtype while it runs

@@ -255,3 +255,40 @@ def test_bf16_rounding_and_emulation(bunny_weights):
     assert np.abs(a["distance"] - b["distance"]).max() > 1e-5          # the mode is actually on
     c = orc.NeDDFOracle(bunny_weights, **BUNNY_CFG).forward(pos, d, var)
     assert all(np.array_equal(a[k], c[k]) for k in a)                  # ... and off again afterwards
+
+
+def _negbias():
+    g = golden("neddf_negbias.npz")
+    kw = json.loads(str(g["config"]))
+    sd = synth.neddf_state_negbias(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["ddf_layer_count"], kw["ddf_layer_width"],
+                                   kw["col_layer_count"], kw["col_layer_width"], tuple(kw["skips"]), seed=7)
+    return g, kw, sd
+
+
+def test_neddf_negative_bias_regime():
+    """The fixture that enters the regime where the fused kernels' reduced-cost tanhExp / sincos / exp differ from the
+    reference's arithmetic (tests/golden/gen_goldens.py::gen_negbias): 80 % of the pre-activations below -1 (median -6),
+    D down to 0.014, |pos| up to 6 under a rank-10 encoding.  The oracle -- branch-exact -- must hold the reference's fp32
+    outputs at the north-star gate here too, and the fixture must really be in that regime."""
+    g, kw, sd = _negbias()
+    assert float(g["preact_frac_below_m1"]) > 0.75 and float(g["preact_quantiles"][3]) < -5.0
+    assert float(np.abs(g["pos"]).max()) > 5.9 and float(g["eval_distance"].min()) < 0.02
+    net = orc.NeDDFOracle(sd, **kw)
+    for it, tag in ((-1, "eval"), (2500, "it2500")):
+        net.set_iter(it)
+        o = net.forward(g["pos"], g["dir"], g["var"])
+        exact = g["%s_density_fp64" % tag]
+        e_ref = float(np.abs(g["%s_density" % tag].astype(np.float64) - exact).max())
+        for k in ("distance", "aux_grad", "color", "density", "fields_penalty"):
+            assert_close(o[k], g["%s_%s" % (tag, k)], 1e-4, 1e-5, "negbias %s %s" % (tag, k))
+        assert float(np.abs(o["density"].astype(np.float64) - exact).max()) <= 2.5 * e_ref + 1e-7
+
+
+def test_neddf_negative_bias_render_rays():
+    g, kw, sd = _negbias()
+    r = golden("neddf_negbias_render_rays.npz")
+    net = orc.NeDDFOracle(sd, **kw)
+    net.set_iter(-1)
+    o = orc.render_rays(net, net, r["uv"], r["R"], r["T"], r["calib"], r["u_coarse"], r["u_fine"], 2.0, 6.0, 6.0, "cone")
+    for k in ("color", "depth", "transmittance", "color_coarse", "depth_coarse", "weight_coarse", "fields_penalty"):
+        assert_close(o[k], r["out_" + k], 1e-4, 1e-5, "negbias render_rays " + k)
