@@ -265,30 +265,96 @@ def train_workload(args, dev, world=1, rank=0, use_dist=False):
             "final_loss": float(loss.item())}
 
 
+def preflight(world, share=False):
+    """Fail in seconds, with a readable message, when this box cannot run `world` ranks (instead of a rendezvous timeout or an
+    RCCL "Duplicate GPU" abort minutes later)."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no HIP device visible (torch.cuda.is_available() is False); the benchmark has no CPU path")
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and not share:
+        raise SystemExit("bench.py: --gpus %d but this process sees %d HIP device(s) (HIP_VISIBLE_DEVICES=%s, ROCR_VISIBLE_DEVICES=%s); "
+                         "RCCL needs one device per rank.  NEDDF_BENCH_SHARE_GPU=1 runs the ranks on shared devices through gloo -- a "
+                         "functional test mode, never a measurement" % (world, n_dev, os.environ.get("HIP_VISIBLE_DEVICES"),
+                                                                        os.environ.get("ROCR_VISIBLE_DEVICES")))
+    return n_dev
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU, and pass
-    the ranks' stdout through (rank 0 prints the JSON line)."""
+    the ranks' stdout through (rank 0 prints the JSON line).  Every rank's stderr goes to its own file; when the run fails, the
+    tail of each is printed, so that the rank that died first can be told from the ranks that died of it."""
+    import glob
     import socket
     import subprocess
+    import tempfile
+    preflight(args.gpus, os.environ.get("NEDDF_BENCH_SHARE_GPU") == "1")
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    logs = tempfile.mkdtemp(prefix="neddf_bench_ranks_")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), "--log-dir", logs, "--redirects", "2", os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
-    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    rc = subprocess.run(cmd, env=env).returncode
+    if rc != 0:
+        for path in sorted(glob.glob(os.path.join(logs, "**", "stderr.log"), recursive=True)):
+            try:
+                tail = open(path, errors="replace").read()[-1500:]
+            except OSError:
+                continue
+            sys.stderr.write("---- %s (tail) ----\n%s\n" % (os.path.relpath(path, logs), tail))
+        sys.stderr.write("bench.py: the %d-rank run failed with exit code %d (per-rank stderr under %s)\n" % (args.gpus, rc, logs))
+    raise SystemExit(rc)
 
 
-def psnr_vs_oracle(render, ctx, cam, weights, R, T, calib, U, n_sample=256):
+def measured_traffic(kernel_substr, dtype, masked):
+    """NEDDF_BENCH_PMC=1: HBM bytes per launch of the dominant kernel measured NOW -- two rocprofv3 --pmc passes (FETCH_SIZE, then
+    WRITE_SIZE: the TCC has four counter slots, FETCH_SIZE takes three) over tools/pmc_probe.py, which renders one 65 536-ray
+    slab of the same workload (4 launches of 2^21 points).  bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: both counters are in
+    KB, and on gfx950 FETCH_SIZE reports half of a wide coalesced read stream (MI355X_MICROARCH.md, HBM / rocprofv3 section).
+    Counter passes run with --kernel-trace only (no hip / hsa / memory-copy tracing)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        raise RuntimeError("rocprofv3 not on PATH")
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="neddf_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp", NEDDF_PROBE_DTYPE={"f32": "fp32"}.get(dtype, dtype))
+        env.pop("NEDDF_BENCH_PMC", None)
+        subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", out, "--output-format", "csv", "--", sys.executable,
+                        os.path.join(ROOT, "tools", "pmc_probe.py"), "1"], cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=600)
+        per = []
+        for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(path)):
+                k = r["Kernel_Name"]
+                if kernel_substr in k and r["Counter_Name"] == counter and ("OpsBF16" in k) == (dtype == "bf16") and \
+                        ("OpsF16Split" in k) == (dtype == "f16_split") and (kernel_substr != "ddf_rev_kernel" or k.split("(")[0].rstrip("> ").endswith("true") == masked):
+                    per.append(float(r["Counter_Value"]))
+        shutil.rmtree(out, ignore_errors=True)
+        if not per:
+            raise RuntimeError("no %s rows for %s" % (counter, kernel_substr))
+        vals[counter] = sum(per) / len(per)
+        vals[counter + "_dispatches"] = len(per)
+    vals["hbm_bytes_per_launch"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return vals
+
+
+def psnr_vs_oracle(render, ctx, cam, weights, R, T, calib, U, n_sample=256, lo=0):
     """PSNR (data range 1.0) of the HIP path's pixel colours against the CPU oracle on a sample of the benchmarked view's
     rays with the same uniforms (outside the timed region; BASELINE.json's metric reads "...; PSNR vs ref")."""
     from neddf_amd._lib import SLOT_FINE
     from oracle import oracle as orc
     dev = U.device
     gen = torch.Generator(device="cpu").manual_seed(99)
-    idx = torch.randint(0, WIDTH * HEIGHT, (n_sample,), generator=gen)
-    uv = torch.stack([idx % WIDTH, idx // WIDTH], 1).to(dev)
+    idx = torch.randint(0, U.shape[0], (n_sample,), generator=gen)       # U holds this rank's slab [lo, lo + len(U)) of the pixel index
+    pix = idx + lo
+    uv = torch.stack([pix % WIDTH, pix // WIDTH], 1).to(dev)
     Us = U[idx.to(dev)].contiguous()
     out = dict(color=torch.empty(n_sample, 3, device=dev), depth=torch.empty(n_sample, device=dev),
                transmittance=torch.empty(n_sample, device=dev))
@@ -325,7 +391,14 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16", "f16_split"], default=None,
                     help="operand type of the 256-wide layers (default f32 = fp32 MFMA; c5 defaults to bf16; f16_split = fp32 data, "
                          "operands split into two fp16 terms, three fp16 MFMAs per multiply-add)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every GPU renders its own 800x800 view, N views per step (BASELINE configs[3]); strong: ONE "
+                         "800x800 view per step, its rays cut into N contiguous chunk-granular slabs (render_image's pixel_range, "
+                         "neddf_shard_range_granular), pixels all-gathered by neddf_gather_pixels_granular -- north_star's 'rays shard "
+                         "across the GPUs' read literally.  c2 only")
     args = ap.parse_args()
+    if args.scaling == "strong" and args.workload != "c2":
+        raise SystemExit("bench.py: --scaling strong exists for the c2 workload")
     # dmabuf IPC for RCCL / cross-process device memory (the host driver supports nothing else): must be in the environment before
     # the HIP runtime initialises, i.e. before the first torch.cuda call below
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -341,12 +414,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    n_dev = torch.cuda.device_count()
+    n_dev = preflight(world, os.environ.get("NEDDF_BENCH_SHARE_GPU") == "1")
     # NEDDF_BENCH_SHARE_GPU=1 (test mode for boxes with fewer GPUs than ranks): ranks share devices and the pixel gather is
     # staged through gloo, because RCCL refuses two ranks on one device.  Never a measurement; the line says so.
     share = os.environ.get("NEDDF_BENCH_SHARE_GPU") == "1" and world > n_dev
-    assert share or world <= n_dev, "%d ranks but %d HIP devices" % (world, n_dev)
     local = local % n_dev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -377,7 +448,8 @@ def main():
     render.network_fine.weight_dtype = {"f32": "fp32", "bf16": "bf16", "f16_split": "f16_split"}[args.dtype]
     fx = 0.5 * WIDTH / math.tan(0.5 * CAMERA_ANGLE_X)
     calib = np.array([fx, fx, WIDTH / 2.0, HEIGHT / 2.0])
-    R, T = view_pose(rank)
+    strong = args.scaling == "strong"
+    R, T = view_pose(0 if strong else rank)      # strong scaling: every rank renders its slab of the SAME view
     if args.workload == "c5":       # forward-facing: camera near the origin looking down -z, NDC depths 0..1, point samples
         calib = np.array([C5_FOCAL, C5_FOCAL, WIDTH / 2.0, HEIGHT / 2.0])
         R, T = np.eye(3, dtype=np.float32), np.array([0.05 * rank, -0.02, 0.1], np.float32)
@@ -386,8 +458,15 @@ def main():
     cam = neddf_amd.Camera(neddf_amd.PinholeCalib(calib), None).to(dev)
     cam.R, cam.T = torch.from_numpy(R).to(dev), torch.from_numpy(T).to(dev)
     n_rays = WIDTH * HEIGHT
+    # strong scaling: this rank's contiguous slab of the flat pixel index, cut on render_image's chunk (512 rays) like
+    # parallel.render_image_sharded / neddf_shard_range_granular do -- no chunk is split between two ranks
+    from neddf_amd.parallel import shard_range
+    GRANULE = 512
+    lo, hi = shard_range(n_rays, rank, world, GRANULE) if strong else (0, n_rays)
+    n_local = hi - lo
+    n_total = n_rays if strong else n_rays * world            # pixels every rank ends a step with
     # synthetic inputs resident in HBM before the timed region
-    U = torch.rand(n_rays, SAMPLES, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
+    U = torch.rand(n_local, SAMPLES, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
     ctx = render._ctx(dev)
     keys = ("color", "depth", "transmittance")
     idx = torch.arange(n_rays, device=dev)
@@ -410,15 +489,17 @@ def main():
         else:
             try:
                 info = native_comm(ctx)
-                comm.update(gather="neddf_gather_pixels: library-owned RCCL communicator, all-gather on its own stream, "
-                                   "overlapped with the next view's render", rccl_comm_ranks=info["nranks"],
+                comm.update(gather="neddf_gather_pixels%s: library-owned RCCL communicator, all-gather on its own stream, "
+                                   "overlapped with the next view's render" % ("_granular" if strong else ""), rccl_comm_ranks=info["nranks"],
                             rccl_version=info["rccl_version"])
+                if info["nranks"] != world:
+                    raise SystemExit("bench.py: the library's RCCL communicator came up with %d ranks, %d were launched" % (info["nranks"], world))
             except Exception as e:      # a second RCCL route, never a CPU path: torch.distributed's all_gather_into_tensor
                 comm.update(gather="torch.distributed all_gather_into_tensor (RCCL); library communicator failed: %s" % e)
     native = use_dist and "rccl_comm_ranks" in comm
-    gathered = [torch.empty(n_rays * world, 5, device=dev) for _ in range(2)] if use_dist else None
+    gathered = [torch.empty(n_total, 5, device=dev) for _ in range(2)] if use_dist else None
     nan_flags = []
-    state = {"i": 0, "pending": None}
+    state = {"i": 0, "pending": None, "last_packed": None}
 
     def render_view():
         if args.workload in ("c3", "c5"):
@@ -430,7 +511,7 @@ def main():
                 for k in keys:
                     parts[k].append(o[k])
             return {k: torch.cat(v) for k, v in parts.items()}
-        out = render.render_image_single_pass(WIDTH, HEIGHT, cam, SAMPLES, U=U)
+        out = render.render_image_single_pass(WIDTH, HEIGHT, cam, SAMPLES, U=U, pixel_range=(lo, hi) if strong else None)
         nan_flags.append(out["_nan"])
         return out
 
@@ -439,16 +520,20 @@ def main():
         if not use_dist:
             return out
         packed = pack_pixels(out, keys)
+        state["last_packed"] = packed
         if native:          # every rank ends with all N views [N * n_rays, 5]; view i's pixels travel while view i+1 renders
             if state["pending"] is not None:
                 state["pending"].wait()
-            state["pending"] = gather_pixels(packed, n_rays * world, force_collective=True, wait=False, out=gathered[state["i"] & 1])
+            state["pending"] = gather_pixels(packed, n_total, force_collective=True, wait=False, out=gathered[state["i"] & 1],
+                                             granule=GRANULE if strong else 1)
             state["i"] += 1
             return state["pending"]
         if share:
-            full = gather_pixels(packed.cpu(), n_rays * world, force_collective=True)
+            full = gather_pixels(packed.cpu(), n_total, force_collective=True, granule=GRANULE if strong else 1)
             gathered[0].copy_(full)
             return gathered[0]
+        if strong:          # ragged slabs: only the library's granular gather (or the gloo test route) assembles them
+            raise SystemExit("bench.py: --scaling strong needs the library's RCCL communicator (neddf_gather_pixels_granular): %s" % comm["gather"])
         full = packed.new_empty(world * n_rays, 5)
         torch.distributed.all_gather_into_tensor(full, packed)
         return full
@@ -485,11 +570,13 @@ def main():
     nan = int(torch.stack(nan_flags).sum().item()) if nan_flags else 0          # every batch of every step
     assert nan == 0, "NaN weight in integrate_volume_render"
     if use_dist and native:       # the gathered frame must hold this rank's own view at its slab
-        mine = res.out[rank * n_rays:(rank + 1) * n_rays] if hasattr(res, "out") else res[rank * n_rays:(rank + 1) * n_rays]
-        assert torch.isfinite(mine).all()
+        full = res.out if hasattr(res, "out") else res
+        assert full.shape[0] == n_total and torch.isfinite(full).all(), "gathered frame incomplete"
+        off = lo if strong else rank * n_rays
+        assert torch.equal(full[off:off + n_local], state["last_packed"]), "the gathered frame does not hold this rank's pixels at its slab"
 
     if rank == 0:
-        pts = n_rays * samples_per_ray * args.steps               # field evaluations on this rank
+        pts = n_local * samples_per_ray * args.steps              # field evaluations on this rank
         ddf_s = tm["ddf_ms"] / 1e3
         # the library's rule (neddf_capi.hip field_forward): fp32 eval-minimal takes the reverse-mode kernel unless switched off
         rev_mask = int(os.environ.get("NEDDF_DDF_REVERSE_DTYPES", "7"))
@@ -509,7 +596,12 @@ def main():
                    " + 4x%d colour trunk on value rows) %s, 1 view per GPU per step, synthetic poses, %s"
                    % (args.width, "in reverse mode (value rows forward, one gradient row backward)" if reverse else
                       "as forward-mode Jacobian rows (the reference's formulation)", args.width, args.dtype, net_name))
-        if world > 1:
+        if strong:
+            c2_name = ("STRONG scaling of BASELINE.json configs[1]: ONE 800x800 view per step, its 640 000 rays cut into %d contiguous "
+                       "chunk-granular slabs (512-ray chunks, neddf_shard_range_granular), one slab per MI355X, RCCL all-gather of the "
+                       "rendered pixels (20 B/ray) so that every rank ends with the whole view; 128 stratified cone samples/ray, NeDDF %s, "
+                       "distance gradient %s" % (world, args.dtype, "in reverse mode" if reverse else "as forward-mode Jacobian rows"))
+        elif world > 1:
             c2_name = ("BASELINE.json configs[3]: %d-view batch 800x800 (8 azimuths), rays sharded one view per GPU over %d x MI355X "
                        "(contiguous slabs of the flat pixel index), RCCL all-gather of the rendered pixels (20 B/ray) so that every "
                        "rank ends with all %d views; per-GPU work = configs[1] (128 stratified cone samples/ray, NeDDF %s)"
@@ -518,19 +610,19 @@ def main():
             "metric": {"c2": "rendered rays/sec (800x800, 128 samples/ray)",
                        "c3": "rendered rays/sec (800x800, 65 coarse + 194 fine hierarchical samples/ray)",
                        "c5": "rendered rays/sec (1008x756 forward-facing NDC view, 65 coarse + 194 fine samples/ray)"}[args.workload],
-            "value": n_rays * world * args.steps / elapsed,
+            "value": n_total * args.steps / elapsed,
             "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": {"c2": c2_name,
                                     "c3": "BASELINE.json configs[2]: as configs[1] with render_rays' hierarchical sampling "
                                           "(65 coarse + 129 importance samples merged to 194), %s" % args.dtype,
                                     "c5": "BASELINE.json configs[4]: 1008x756 forward-facing view (fern at 1/4 scale), NDC rays, "
                                           "point samples, hierarchical 65 + 194, NeDDF with %s operands" % args.dtype}[args.workload],
-                       "rays_per_step_per_gpu": n_rays, "samples_per_ray": samples_per_ray, "workload_id": args.workload,
-                       "parallelism": "ray-parallel x%d" % world, "comm": comm},
+                       "rays_per_step_per_gpu": n_local, "rays_per_step": n_total, "samples_per_ray": samples_per_ray, "workload_id": args.workload,
+                       "parallelism": "ray-parallel x%d%s" % (world, " (one view, chunk-granular pixel slabs)" if strong else ""), "comm": comm},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,
                          "kernel": "neddf::ddf_rev_kernel" if reverse else "neddf::ddf_trunk_kernel", "launches": tm["ddf_launches"],
@@ -545,7 +637,7 @@ def main():
                                            "flop_per_point": flop_col,
                                            # the hierarchical workloads skip the colour trunk on the coarse pass (its colours are not an output)
                                            "points_per_ray": SAMPLES if args.workload == "c2" else 194,
-                                           "achieved": ((pts if args.workload == "c2" else n_rays * 194 * args.steps) * flop_col / (tm["col_ms"] / 1e3) / 1e12)
+                                           "achieved": ((pts if args.workload == "c2" else n_local * 194 * args.steps) * flop_col / (tm["col_ms"] / 1e3) / 1e12)
                                                        if tm["col_ms"] > 0 else 0.0}},
             # every stage kernel of the timed region (HIP events on its stream): summed ms per step and launches per step
             "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stage.items() if v[1]},
@@ -560,7 +652,20 @@ def main():
             ent = next(v for k, v in pmc.items() if want in k and ("OpsBF16" in k) == (args.dtype == "bf16")
                        and (want != "ddf_rev_kernel" or k.rstrip(">").endswith("true") == masked))
             line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
-            line["roofline"]["traffic_source"] = "static: %s (a committed rocprofv3 --pmc pass of this kernel and launch size, not measured in this run)" % ent["source"]
+            line["roofline"]["traffic_source"] = ("static: %s (a committed rocprofv3 --pmc pass of this kernel and launch size, not measured in "
+                                                  "this run; NEDDF_BENCH_PMC=1 measures it in the run)" % ent["source"])
+            if os.environ.get("NEDDF_BENCH_PMC") == "1":
+                try:
+                    m = measured_traffic(want, args.dtype, masked)
+                    line["roofline"]["traffic"] = m["hbm_bytes_per_launch"]
+                    line["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, "
+                                                          "--kernel-trace only) over tools/pmc_probe.py, %d dispatches of 2^21 points; bytes = "
+                                                          "(2 x FETCH_SIZE + WRITE_SIZE) x 1024" % m["FETCH_SIZE_dispatches"])
+                    line["roofline"]["traffic_counters_kb"] = {"FETCH_SIZE": m["FETCH_SIZE"], "WRITE_SIZE": m["WRITE_SIZE"]}
+                    line["roofline"]["traffic_static"] = ent["hbm_bytes_per_launch"]
+                    ent = dict(ent, hbm_bytes_per_launch=m["hbm_bytes_per_launch"])
+                except Exception as e:
+                    line["roofline"]["traffic_source"] += "; NEDDF_BENCH_PMC=1 failed: %r" % (e,)
             line["roofline"]["algorithmic_hbm_bytes_per_launch"] = ent["algorithmic_bytes_per_launch"]
             # the same launch against the HBM roofline (the 16-bit policies are partly bound by the y' round trip)
             ms = line["roofline"]["avg_launch_ms"]
@@ -570,7 +675,7 @@ def main():
         except Exception:
             pass
         if args.workload == "c2":
-            psnr, worst, ns, margin = psnr_vs_oracle(render, ctx, cam, weights, R, T, calib, U)
+            psnr, worst, ns, margin = psnr_vs_oracle(render, ctx, cam, weights, R, T, calib, U, lo=lo)
             line["psnr_vs_oracle_db"] = psnr
             line["parity_sample"] = {"rays": ns, "max_abs_err": worst, "gate_margin": margin,
                                      "oracle": "oracle/neddf_oracle.c (pinned on the reference's goldens)",

@@ -335,3 +335,44 @@ def test_c_client_of_the_abi(tmp_path):
     # the C program's first call asks for fields_penalty but for no coarse outputs, so its coarse pass runs eval-minimal (reverse-mode
     # distance gradient) where the Python render_rays-style call (every key) carries Jacobian rows: same function, different rounding
     assert_close(full, want_full, 1e-4, 1e-5, "C full-mode outputs vs Python binding")
+
+
+def _bench_line(extra_args, extra_env):
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29300 + os.getpid() % 300))
+    env.update(extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra_args,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_scaling_modes_agree_at_one_rank():
+    """bench.py --scaling weak / strong through the FORCED collective path on one rank against the plain line: at N = 1 both modes
+    render the same 640 000 rays (the strong mode through pixel_range + the chunk-granular gather), so their rays/s must agree with
+    the plain line within 1 % -- the day an 8-GPU node runs it, N = 1 of either curve is the headline number."""
+    plain = _bench_line([], {})
+    weak = _bench_line([], {"NEDDF_BENCH_FORCE_DIST": "1"})
+    strong = _bench_line(["--scaling", "strong"], {"NEDDF_BENCH_FORCE_DIST": "1"})
+    assert plain["scaling"] == "weak" and weak["scaling"] == "weak" and strong["scaling"] == "strong"
+    assert strong["config"]["comm"]["rccl_comm_ranks"] == 1 and "granular" in strong["config"]["comm"]["gather"]
+    assert strong["config"]["rays_per_step"] == 640000 and strong["n_gpus"] == 1
+    for name, line in (("weak", weak), ("strong", strong)):
+        assert abs(line["value"] / plain["value"] - 1.0) < 0.01, (name, line["value"], plain["value"])
+
+
+def test_bench_preflight_fails_fast_and_readably():
+    """--gpus N on a box with fewer devices: a message and a non-zero exit within seconds, not a rendezvous timeout."""
+    import time
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NEDDF_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "HIP device" in p.stderr and "--gpus %d" % n in p.stderr, p.stderr[-2000:]
+    assert time.time() - t0 < 60.0      # (the first `import torch` of a fresh box is most of this)
