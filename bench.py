@@ -462,8 +462,8 @@ def main():
     # parallel.render_image_sharded / neddf_shard_range_granular do -- no chunk is split between two ranks
     from neddf_amd.parallel import shard_range
     GRANULE = 512
-    lo, hi = shard_range(n_rays, rank, world, GRANULE) if strong else (0, n_rays)
-    n_local = hi - lo
+    slab_lo, slab_hi = shard_range(n_rays, rank, world, GRANULE) if strong else (0, n_rays)
+    n_local = slab_hi - slab_lo
     n_total = n_rays if strong else n_rays * world            # pixels every rank ends a step with
     # synthetic inputs resident in HBM before the timed region
     U = torch.rand(n_local, SAMPLES, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
@@ -511,7 +511,7 @@ def main():
                 for k in keys:
                     parts[k].append(o[k])
             return {k: torch.cat(v) for k, v in parts.items()}
-        out = render.render_image_single_pass(WIDTH, HEIGHT, cam, SAMPLES, U=U, pixel_range=(lo, hi) if strong else None)
+        out = render.render_image_single_pass(WIDTH, HEIGHT, cam, SAMPLES, U=U, pixel_range=(slab_lo, slab_hi) if strong else None)
         nan_flags.append(out["_nan"])
         return out
 
@@ -572,7 +572,7 @@ def main():
     if use_dist and native:       # the gathered frame must hold this rank's own view at its slab
         full = res.out if hasattr(res, "out") else res
         assert full.shape[0] == n_total and torch.isfinite(full).all(), "gathered frame incomplete"
-        off = lo if strong else rank * n_rays
+        off = slab_lo if strong else rank * n_rays
         assert torch.equal(full[off:off + n_local], state["last_packed"]), "the gathered frame does not hold this rank's pixels at its slab"
 
     if rank == 0:
@@ -675,7 +675,7 @@ def main():
         except Exception:
             pass
         if args.workload == "c2":
-            psnr, worst, ns, margin = psnr_vs_oracle(render, ctx, cam, weights, R, T, calib, U, lo=lo)
+            psnr, worst, ns, margin = psnr_vs_oracle(render, ctx, cam, weights, R, T, calib, U, lo=slab_lo)
             line["psnr_vs_oracle_db"] = psnr
             line["parity_sample"] = {"rays": ns, "max_abs_err": worst, "gate_margin": margin,
                                      "oracle": "oracle/neddf_oracle.c (pinned on the reference's goldens)",
