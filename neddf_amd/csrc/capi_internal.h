@@ -21,6 +21,8 @@ struct Field {
     float lowpass[10];
     DevBuf blob;
     hipEvent_t last_use = nullptr;       // recorded after the last launch that reads `blob` (neddf_set_field waits on it)
+    bool last_use_recorded = false;      // ... and the stream that recorded it last: another stream waits for it before re-recording
+    hipStream_t last_use_stream = nullptr;
     DdfArgs ddf{};
     ColArgs col{};
     NerfArgs nerf{};

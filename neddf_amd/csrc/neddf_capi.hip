@@ -469,9 +469,20 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
 static int mark_use(neddf_ctx *ctx, Field &f, hipStream_t s)
 {
     if (!f.last_use) HIPCHK(hipEventCreateWithFlags(&f.last_use, hipEventDisableTiming));
+    // one event per slot, shared by every stream that reads it: a stream that takes the event over first waits for the previous
+    // holder's mark, so the waits chain and the event always lies behind EVERY earlier reader (two streams reading one slot)
+    if (f.last_use_recorded && f.last_use_stream != s) HIPCHK(hipStreamWaitEvent(s, f.last_use, 0));
     HIPCHK(hipEventRecord(f.last_use, s));
+    f.last_use_recorded = true;
+    f.last_use_stream = s;
     return 0;
 }
+
+// marks the slot on every way out of a function that may have launched readers of it (error returns after a chunk included)
+struct UseMark {
+    neddf_ctx *ctx; Field &f; hipStream_t s;
+    ~UseMark() { (void)mark_use(ctx, f, s); }
+};
 
 static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float *dir, const float *var, int64_t N,
                          int out_mode, float *distance, float *density, float *color, float *penalty, float *aux,
@@ -480,6 +491,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");
     if (N <= 0) return 0;
     Field &f = ctx->field[slot];
+    UseMark mark{ ctx, f, s };
     const int dt = f.d.weight_dtype;
     const int wid = f.d.kind == NEDDF_FIELD_NERF ? f.nerf.width : f.ddf.width;        // engine width
     const int grid_cap = ctx->cus * nerf_wgs_per_cu(wid);
@@ -501,7 +513,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         int64_t tiles = (N + nerf_points_per_tile(wid) - 1) / nerf_points_per_tile(wid);
         STAGE(ctx, s, NEDDF_STAGE_NERF, launch_nerf(a, (int)(tiles < grid_cap ? tiles : grid_cap), s));
         HIPCHK(hipGetLastError());
-        return mark_use(ctx, f, s);
+        return 0;
     }
     const bool full = (out_mode == NEDDF_OUT_FULL) && penalty && f.d.kind == NEDDF_FIELD_NEDDF;
     const int fr = full ? 4 : 1;
@@ -569,7 +581,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         }
     }
     HIPCHK(hipGetLastError());
-    return mark_use(ctx, f, s);
+    return 0;           // (the slot is marked by `mark` on every way out)
 }
 
 // ---------------------------------------------------------------------------

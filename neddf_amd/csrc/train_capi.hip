@@ -705,6 +705,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
                 dwj.add(ws + p.o_h[l - 1], kWidth, kWidth, 1, dZt(l), kWidth, gW[l] + (size_t)(wide ? p.Cpe : 0) * kWidth, kWidth, 1, kWidth,
                           wide ? nullptr : gB[l], 4);
         }
+        if (dwj.overflow) return fail(ctx, NEDDF_EUNSUPPORTED, "more weight-gradient products than DwJobs holds (train_kernels.h kMaxDwJobs)");
         launch_dw_jobs(dwj, ctx->cus, s);
         HIPCHK(hipGetLastError());
         return 0;

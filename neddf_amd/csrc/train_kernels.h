@@ -123,14 +123,19 @@ struct DwJob {
     int wg0;                              // first workgroup of the product (set by launch_dw_jobs)
 };
 constexpr int kMaxDwJobs = 32;
+// the fused NeDDF backward registers one job per trunk layer (distance + colour trunks: <= 2 * kMaxLayers), the wide halves of
+// skip layers and the first layers' encoding segments; a job that did not fit would leave a weight gradient silently at zero
+static_assert(kMaxDwJobs >= 2 * kMaxLayers + 4, "DwJobs must hold every weight-gradient product of a pass");
 struct DwJobs {
     int n;
+    bool overflow = false;               // add() past kMaxDwJobs: launch_dw_jobs' caller returns NEDDF_EUNSUPPORTED
     int64_t R;                            // rows of every X / G
     DwJob job[kMaxDwJobs];
     void add(const float *X, int ldx, int K, int x_point_major, const float *G, int ldg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
              int bias_period)
     {
         if (n < kMaxDwJobs) job[n++] = DwJob{ X, ldx, K, G, ldg, dW, sk, sn, nvalid, db, bias_period, x_point_major, 0 };
+        else overflow = true;
     }
 };
 void launch_dw_jobs(DwJobs &jobs, int cus, hipStream_t s);

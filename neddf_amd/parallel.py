@@ -223,9 +223,14 @@ def assert_replicas_identical(tensors: Iterable[Tensor], group=None, what: str =
     with torch.no_grad():
         flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
         bits = flat.view(torch.int32).to(torch.int64)
-        sig = torch.stack([flat.double().sum(), flat.double().square().sum(), (bits * (torch.arange(bits.numel(), device=bits.device) % 8191 + 1)).sum().double()])
-        lo, hi = sig.clone(), sig.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-    if not torch.equal(lo, hi):
-        raise RuntimeError("data-parallel replicas hold different %s (signature spread %s)" % (what, (hi - lo).tolist()))
+        # the bit-pattern checksums stay int64 through the collective (a double resolves only ~2^7 at their magnitude of 2^60: a
+        # one-ulp divergence of one parameter would be rounded away); two independent weightings so that no single swap cancels
+        idx = torch.arange(bits.numel(), device=bits.device)
+        isig = torch.stack([(bits * (idx % 8191 + 1)).sum(), (bits * ((idx * 2654435761) % 65521 + 1)).sum(), bits.sum()])
+        sig = torch.stack([flat.double().sum(), flat.double().square().sum()])        # for the error message only
+        ilo, ihi, lo, hi = isig.clone(), isig.clone(), sig.clone(), sig.clone()
+        for t, op in ((ilo, dist.ReduceOp.MIN), (ihi, dist.ReduceOp.MAX), (lo, dist.ReduceOp.MIN), (hi, dist.ReduceOp.MAX)):
+            dist.all_reduce(t, op=op, group=group)
+    if not torch.equal(ilo, ihi):
+        raise RuntimeError("data-parallel replicas hold different %s (bit-pattern checksums differ; spread of sum / sum of squares %s)" % (what, (hi - lo).tolist()))
+    return

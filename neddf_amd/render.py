@@ -355,9 +355,14 @@ class NeRFRender(BaseNeuralRender):
 
 
 def jet_bgr(gray):
-    """uint8 [h,w] -> uint8 [h,w,3] (B,G,R) with the classic jet ramp (r = 1.5-|4v-3|, g = 1.5-|4v-2|, b = 1.5-|4v-1|)."""
+    """uint8 [h,w] -> uint8 [h,w,3] (B,G,R): cv2.applyColorMap(gray, cv2.COLORMAP_JET) restated (nerf_render.py:330; cv2 is in neither
+    container, so this is pinned on the published algorithm, not on cv2's output).  OpenCV builds the table from three float arrays
+    r, g, b of 256 entries -- the piecewise-linear ramps clamp(1.5 - |4 i/255 - c|, 0, 1) with c = 3, 2, 1, written out as literals --
+    and converts them with `convertTo(CV_8U, 255.)`: a float product and cvRound (round half to EVEN).  Every ramp entry times 255 is
+    an exact half-integer (382.5 - |4 i - 255 c|), so the rounding mode decides each of them: the ramps step by 4 (blue: 128, 132,
+    136, ... at i = 0, 1, 2, ...; entries 0 / 255 are (128, 0, 0) / (0, 0, 128) in B, G, R).  Round 3's `+ 0.5` truncation in double
+    differed from this on 149 of the 768 entries by one count."""
     import numpy as np
-    v = np.arange(256, dtype=np.float64) / 255.0
-    lut = np.stack([np.clip(1.5 - np.abs(4 * v - 1), 0, 1), np.clip(1.5 - np.abs(4 * v - 2), 0, 1),
-                    np.clip(1.5 - np.abs(4 * v - 3), 0, 1)], 1)
-    return (lut * 255 + 0.5).astype(np.uint8)[gray]
+    x = np.arange(256, dtype=np.float64) / 255.0
+    lut = np.stack([np.rint(np.clip(1.5 - np.abs(4 * x - c), 0, 1).astype(np.float32) * np.float32(255.0)) for c in (1, 2, 3)], 1)
+    return lut.astype(np.uint8)[gray]

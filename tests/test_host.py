@@ -267,6 +267,17 @@ if world > 1:
         assert "different parameters" in str(e)
 sync_parameters(reps)
 assert_replicas_identical(reps)
+# ... down to ONE ulp of ONE element of a large parameter set (the checksums travel as int64, not as doubles)
+big = [torch.randn(700, 1000, generator=torch.Generator().manual_seed(5)), torch.randn(300, generator=torch.Generator().manual_seed(6))]
+assert_replicas_identical(big)
+if world > 1:
+    if rank == world - 1:
+        big[0].view(-1)[3] = torch.nextafter(big[0].view(-1)[3], torch.tensor(10.0))
+    try:
+        assert_replicas_identical(big)
+        raise SystemExit("a one-ulp divergence went unnoticed")
+    except RuntimeError as e:
+        assert "bit-pattern" in str(e)
 torch.manual_seed(100)
 assert torch.equal(reps[0], torch.randn(7, 3)) and torch.equal(reps[1], torch.randn(5))      # rank 0's values
 # communicator bootstrap (native_comm): a failure anywhere must raise on EVERY rank, never strand the others in a collective
@@ -759,3 +770,16 @@ def test_capi_error_paths_under_asan(tmp_path):
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "asan ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
     assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]
+
+
+def test_jet_colour_map_follows_opencv_rounding():
+    """render_field_slice's colour map (nerf_render.py:330, cv2.COLORMAP_JET): ramps of OpenCV's table, converted with round half to
+    even -- every ramp entry x 255 is an exact half-integer, so the ramps step by exactly 4."""
+    from neddf_amd.render import jet_bgr
+    t = jet_bgr(np.arange(256, dtype=np.uint8)).astype(int)
+    assert t[0].tolist() == [128, 0, 0] and t[255].tolist() == [0, 0, 128] and t[128].tolist() == [126, 255, 130]
+    assert t[:32, 0].tolist() == [128 + 4 * i for i in range(32)] and (t[:32, 1:] == 0).all()
+    assert t[96, 2] == 2 and t[97, 2] == 6 and t[159, 2] == 254 and (t[160:224, 2] == 255).all()
+    assert (t[32:96, 0] == 255).all() and t[32, 1] == 0 and t[33, 1] == 4
+    g = np.array([[0, 255], [64, 191]], np.uint8)
+    assert jet_bgr(g).shape == (2, 2, 3) and jet_bgr(g).dtype == np.uint8
