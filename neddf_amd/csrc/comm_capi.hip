@@ -12,6 +12,7 @@
 #include "kernels.h"
 
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 // RCCL is bound at run time (dlopen below); its development headers are used when the build host has them and otherwise
 // replaced by the handful of declarations this file needs (RCCL keeps NCCL's public ABI: opaque communicator, 128-byte id)
@@ -45,6 +46,10 @@ struct Rccl {
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    // optional (ragged slabs gathered in place): absent symbols select the padded staging route
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
@@ -70,7 +75,10 @@ Rccl *rccl()
     r.CommGetAsyncError = (decltype(r.CommGetAsyncError))sym("ncclCommGetAsyncError");
     r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
-    if (!ok) { dlclose(r.handle); r.handle = nullptr; }
+    if (!ok) { dlclose(r.handle); r.handle = nullptr; return &r; }
+    r.Broadcast = (decltype(r.Broadcast))dlsym(r.handle, "ncclBroadcast");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(r.handle, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.handle, "ncclGroupEnd");
     return &r;
 }
 
@@ -223,7 +231,13 @@ int neddf_gather_pixels_granular(neddf_ctx *ctx, const float *d_local, int64_t n
         if (h - l > pad) pad = h - l;
     }
     const size_t row = (size_t)channels * sizeof(float);
-    if (ragged)
+    // Ragged slabs (chunk-granular shards: 1 250 chunks of an 800 x 800 frame over 8 ranks are 157 or 156 each) are gathered IN
+    // PLACE: one grouped set of broadcasts, rank q's slab from its own buffer straight to its offset of every rank's d_all -- the
+    // all-gather-v idiom; no staging copy, no padding, no compaction.  NEDDF_GATHER_STAGED=1 (or an RCCL without the group
+    // calls) keeps round 3's route: equal-count all-gather through a padded staging buffer + one compaction copy per rank.
+    static const bool staged_env = [] { const char *e = getenv("NEDDF_GATHER_STAGED"); return e && atoi(e) != 0; }();
+    const bool in_place = ragged && !staged_env && r->Broadcast && r->GroupStart && r->GroupEnd;
+    if (ragged && !in_place)
         if (int rc = ensure(ctx, c.pad, (size_t)(c.nranks + 1) * pad * row)) return rc;
     // the communication stream picks up after what `stream` has enqueued so far (the render of this slab) ...
     HIPCHK(hipEventRecord(c.ready, (hipStream_t)stream));
@@ -232,6 +246,21 @@ int neddf_gather_pixels_granular(neddf_ctx *ctx, const float *d_local, int64_t n
     tick(ctx, c.stream, NEDDF_STAGE_GATHER, true);
     if (!ragged) {
         RCCLCHK(r->AllGather(d_local, d_all, (size_t)pad * channels, ncclFloat, (ncclComm_t)c.comm, c.stream));
+    } else if (in_place) {
+        RCCLCHK(r->GroupStart());
+        ncclResult_t first = ncclSuccess;
+        for (int q = 0; q < c.nranks; ++q) {
+            int64_t l, h;
+            neddf_shard_range_granular(n_total, granule, q, c.nranks, &l, &h);
+            if (h <= l) continue;               // more ranks than chunks: that rank contributes nothing
+            char *dst = (char *)d_all + l * row;
+            const ncclResult_t e = r->Broadcast(q == c.rank ? (const void *)d_local : (const void *)dst, dst, (size_t)(h - l) * channels, ncclFloat, q,
+                                                (ncclComm_t)c.comm, c.stream);
+            if (e != ncclSuccess && first == ncclSuccess) first = e;
+        }
+        const ncclResult_t ge = r->GroupEnd();          // always closed, also after a failed member
+        if (first != ncclSuccess) return fail(ctx, NEDDF_ECOMM, std::string("ncclBroadcast (grouped gather): ") + r->GetErrorString(first));
+        if (ge != ncclSuccess) return fail(ctx, NEDDF_ECOMM, std::string("ncclGroupEnd: ") + r->GetErrorString(ge));
     } else {
         // equal-count all-gather through [send: pad rows | recv: nranks * pad rows], then one compaction copy per rank
         char *send = (char *)c.pad.p, *recv = send + pad * row;
