@@ -100,6 +100,18 @@ constexpr bool kAblate = true;
 #define NEDDF_ABL(flags, bit) 0
 constexpr bool kAblate = false;
 #endif
+// Phase time stamps (-DNEDDF_STAMP, `make stamp`): lane 0 of every wave of the first kStampBlocks workgroups records s_memtime at
+// the phase boundaries of its kStampTile-th tile; neddf_capi.hip dumps them after the launch, tools/stamp_timeline.py prints them.
+#ifdef NEDDF_STAMP
+#define NEDDF_STAMP_DECL int sidx_ = 0, stile_ = 0; unsigned long long *sbuf_ = (a.stamps && blockIdx.x < kStampBlocks && lane == 0) ? a.stamps + ((size_t)blockIdx.x * 8 + wave) * kStampSlots : nullptr
+#define NEDDF_STAMP_TILE() do { sidx_ = 0; ++stile_; } while (0)
+#define STAMP() do { if (sbuf_ && stile_ == kStampTile && sidx_ < kStampSlots) sbuf_[sidx_++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NEDDF_STAMP_DECL
+#define NEDDF_STAMP_TILE() do { } while (0)
+#define STAMP() do { } while (0)
+#endif
+
 __device__ __forceinline__ int64_t sched_begin(int *sched, int flags, int *ctl, int tid)
 {
     if (tid == 0) ctl[0] = (flags & 2) ? atomicAdd(&sched[0], 1) : (int)blockIdx.x;
@@ -450,8 +462,11 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
     constexpr bool masked = MASKY;                  // ReLU / LeakyReLU: y' is one bit per element (rev_forward_epilogue)
 
     int *ctl = (int *)(lp + 12);
+    NEDDF_STAMP_DECL;
     int64_t tile = sched_begin(a.sched, a.sched_flags, ctl, tid);
     while (tile < ntiles) {
+        NEDDF_STAMP_TILE();
+        STAMP();                                    // 0: tile start
         const int64_t p0 = tile * P;
         LayerPre<NT, Ops> pre;
         layer_prefetch<NT, Ops>(pre, a.layer[0].wp, a.layer[0].bias, a.layer[0].ksteps, wave, lane);
@@ -474,7 +489,9 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             pv[p * 64 + q] = vs;               // same column order as the LDS tile: [sine half (KH) | cosine half (KH)]
             pv[p * 64 + KH + q] = vc;
         }
+        STAMP();                                    // 1: encoding done
         __syncthreads();
+        STAMP();                                    // 2: encoding barrier passed
 
         f32x16 acc[MT][NT];
         // ---- forward, value rows
@@ -501,10 +518,14 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
                 dense<MT, NT, Ops>(acc, act_lane + sw.col0, (const frag *)sw.wp + (size_t)wave * NT * sw.ksteps * 64 + lane, sw.ksteps);
             }
             if (l + 1 < a.n_layers) layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
+            STAMP();                                // forward layer l: 3 + 4l product done
             __syncthreads();
+            STAMP();                                //                  4 + 4l barrier passed
             if (l + 1 < a.n_layers) rev_forward_epilogue_rt<false, MASKY, MT, NT, Ops>(acc, act, ynone ? nullptr : yp + (size_t)(l * ylstep) * ROWS * WID, nullptr, a.activation, wave, lane, ymask);
             else rev_forward_epilogue_rt<true, MASKY, MT, NT, Ops>(acc, act, nullptr, a.w_ddf_out, a.activation, wave, lane);
+            STAMP();                                //                  5 + 4l epilogue done
             __syncthreads();
+            STAMP();                                //                  6 + 4l barrier passed
         }
         // ---- heads on the features (value only: the distance gradient comes from the reverse pass, the aux gradient's own
         // Jacobian is not an eval output), and the feature hand-off to the colour kernel
@@ -534,7 +555,9 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
                 }
             }
         }
+        STAMP();                        // F: heads + feature hand-off done
         __syncthreads();                // the features are consumed: the tile now carries gradients
+        STAMP();                        // F + 1
         // ---- reverse pass: g_L (held in the accumulators since the last epilogue) -> LDS
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -544,7 +567,9 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
 #pragma unroll
                 for (int q = 0; q < 16; q += 2) Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, acc[mt][t][q], acc[mt][t][q + 1]);
             }
+        STAMP();                        // F + 2: g_L stored
         __syncthreads();
+        STAMP();                        // F + 3
         // the [P, 64] encoding gradient in 32 x 32 blocks, BPW per wave: block b = wave * BPW + i is M-tile b >> 1, N-tile b & 1.  The
         // skip layer's share waits in the scratch, not in registers, while the remaining layers run (the product loop needs them)
         f32x4v *gpe_park = (f32x4v *)pv + (size_t)wave * BPW * 4 * 64 + lane;        // the encoding copy in pv is no longer needed here
@@ -605,7 +630,9 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
 #pragma unroll
                 for (int w = 0; w < NMW; ++w) mw[w] = msrc[w * 64];
             }
+            STAMP();                    // reverse layer: +0 skip share / setup done
             dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
+            STAMP();                    //                +1 product done
             if constexpr (masked) {
                 __syncthreads();        // every wave finished reading g_l
 #pragma unroll
@@ -625,6 +652,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             load_y(yb[0], 0);
             if (MT > 1) load_y(yb[1], 1);
             __syncthreads();            // every wave finished reading g_l
+            STAMP();                    //                +2 barrier passed
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -637,7 +665,9 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
                 }
                 if (mt + 2 < MT) load_y(yb[mt & 1], mt + 2);
             }
+            STAMP();                    //                +3 y' multiply + store done
             __syncthreads();
+            STAMP();                    //                +4 barrier passed
             }
         }
         f32x16 gpe[BPW][1];
@@ -718,9 +748,11 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             if (a.aux_grad) a.aux_grad[gp] = aux;
             }
         }
+        STAMP();                        // tail: encoding gradient, head arithmetic, outputs done
         if (tid == 0) ctl[0] = next_tile;
         __syncthreads();
         tile = ctl[0];
+        STAMP();                        // tile end
     }
 }
 
@@ -1267,8 +1299,20 @@ static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s)
     else hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, true>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a);
 }
 
+// Tile shape of the reverse-mode kernel at width 256 per operand policy: (MT, NW, WPS) = (2, 4, 2) under fp32; the 16-bit policies
+// take NEDDF_REV_GEO="MTxNWxWPS" (probes: eight waves per workgroup = 32 columns per wave, three workgroups per CU)
+static Geo geo_rev(int operands)
+{
+    static Geo g[3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+    if (!g[0].mt) {
+        g[0] = Geo{ 2, 2, 4 };
+        g[1] = parse_geo("NEDDF_REV_GEO_BF16", Geo{ 2, 2, 4 }, { { 2, 2, 4 }, { 2, 2, 8 }, { 2, 3, 4 }, { 2, 3, 8 }, { 2, 4, 8 } });
+        g[2] = parse_geo("NEDDF_REV_GEO_SPLIT", Geo{ 2, 2, 4 }, { { 2, 2, 4 }, { 2, 2, 8 }, { 2, 3, 8 } });
+    }
+    return g[operands < 0 || operands > 2 ? 0 : operands];
+}
 int ddf_rev_points(int, int width) { return width == 256 ? 64 : geo_w(width).mt * 32; }
-int ddf_rev_wgs_per_cu(int, int) { return 2; }
+int ddf_rev_wgs_per_cu(int operands, int width) { return width == 256 ? geo_rev(operands).wps : 2; }
 
 template <int WID>
 static void launch_ddf_rev_w(const DdfArgs &a, int grid, hipStream_t s)
@@ -1284,9 +1328,20 @@ void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s)
     if (a.width == 128) return launch_ddf_rev_w<128>(a, grid, s);
     if (a.width == 384) return launch_ddf_rev_w<384>(a, grid, s);
     if (a.width == 512) return launch_ddf_rev_w<512>(a, grid, s);
-    if (a.operands == 2) launch_ddf_rev_t<2, 4, 2, OpsF16Split>(a, grid, s);
-    else if (a.operands == 1) launch_ddf_rev_t<2, 4, 2, OpsBF16>(a, grid, s);
-    else launch_ddf_rev_t<2, 4, 2, OpsF32>(a, grid, s);
+    const Geo g = geo_rev(a.operands);          // (mt, wps, nw)
+    if (a.operands == 2) {
+        NEDDF_GEO_CASE(2, 2, 8) return launch_ddf_rev_t<2, 8, 2, OpsF16Split>(a, grid, s);
+        NEDDF_GEO_CASE(2, 3, 8) return launch_ddf_rev_t<2, 8, 3, OpsF16Split>(a, grid, s);
+        return launch_ddf_rev_t<2, 4, 2, OpsF16Split>(a, grid, s);
+    }
+    if (a.operands == 1) {
+        NEDDF_GEO_CASE(2, 2, 8) return launch_ddf_rev_t<2, 8, 2, OpsBF16>(a, grid, s);
+        NEDDF_GEO_CASE(2, 3, 4) return launch_ddf_rev_t<2, 4, 3, OpsBF16>(a, grid, s);
+        NEDDF_GEO_CASE(2, 3, 8) return launch_ddf_rev_t<2, 8, 3, OpsBF16>(a, grid, s);
+        NEDDF_GEO_CASE(2, 4, 8) return launch_ddf_rev_t<2, 8, 4, OpsBF16>(a, grid, s);
+        return launch_ddf_rev_t<2, 4, 2, OpsBF16>(a, grid, s);
+    }
+    launch_ddf_rev_t<2, 4, 2, OpsF32>(a, grid, s);
 }
 
 template <int WID>

@@ -77,7 +77,9 @@ struct DdfArgs {
     int feat_rows;                        // 1 (value row) or 4 (value + Jacobian rows)
     float *ptaux;                         // [n_points][kPtAux]
     float *distance, *density, *aux_grad; // optional outputs [n_points]
+    unsigned long long *stamps = nullptr; // -DNEDDF_STAMP builds only (`make stamp`, tools/stamp_timeline.py): phase time stamps of a few workgroups
 };
+constexpr int kStampBlocks = 8, kStampSlots = 160, kStampTile = 6;      // workgroups stamped, stamps per wave, which tile of the workgroup
 
 // Colour trunk of NeDDF (neddf.py:243-300).
 struct ColArgs {

@@ -555,7 +555,22 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
             const int grid = (int)(tiles < wgs ? tiles : wgs);
             if (int rc = ensure(ctx, ctx->rev_scratch, (size_t)wgs * ddf_rev_scratch_floats_per_wg(a.n_layers, pts, wid) * sizeof(float))) return rc;
             a.rev_scratch = (float *)ctx->rev_scratch.p;
+#ifdef NEDDF_STAMP
+            static unsigned long long *d_stamps = nullptr;
+            const size_t stamp_bytes = (size_t)kStampBlocks * 8 * kStampSlots * sizeof(unsigned long long);
+            if (!d_stamps) HIPCHK(hipMalloc((void **)&d_stamps, stamp_bytes));
+            HIPCHK(hipMemsetAsync(d_stamps, 0, stamp_bytes, s));
+            a.stamps = d_stamps;
+#endif
             STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf_rev(a, grid, s));
+#ifdef NEDDF_STAMP
+            if (const char *path = getenv("NEDDF_STAMP_FILE")) {        // the LAST launch's stamps (a diagnostic build: synchronising here is fine)
+                HIPCHK(hipStreamSynchronize(s));
+                std::vector<unsigned long long> h((size_t)kStampBlocks * 8 * kStampSlots);
+                HIPCHK(hipMemcpy(h.data(), d_stamps, stamp_bytes, hipMemcpyDeviceToHost));
+                if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), 1, stamp_bytes, fp); fclose(fp); }
+            }
+#endif
         } else {
             const int64_t tiles = (n + ddf_points_per_tile(dt, wid) - 1) / ddf_points_per_tile(dt, wid);
             STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf(a, (int)(tiles < grid_cap_ddf ? tiles : grid_cap_ddf), s));

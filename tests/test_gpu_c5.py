@@ -227,6 +227,66 @@ def test_render_rays_ndc_bf16_end_to_end(dev, orc, bunny_weights):
             assert_close(N(o[k]), ref[k], tol, tol * 0.1 + 1e-5, "%s %s" % (dtype, k))
 
 
+def test_c5_full_frame_properties(dev, bunny_weights):
+    """BASELINE.json configs[4] at full size: all 762 048 rays of a 1008x756 forward-facing view, NDC rays, point samples,
+    hierarchical 65 + 194, bf16 operands (what `bench.py --workload c5` times).  Size-independent properties: fine distances sorted
+    inside [0, 1] with every coarse knot present, no NaN flag, finite pixels; the frame is bit-identical under another batch split
+    (tile tails and the 128-row bf16 shapes included); rendering is deterministic; and the bf16 frame stays within the policy's
+    error of the fp32 frame of the same rays and uniforms (PSNR, median and 99th-percentile colour error)."""
+    import neddf_amd
+    W, H, near = 1008, 756, 1.0
+    cfg = dict(BUNNY_CFG, _target_="neddf.network.NeDDF")
+    r = neddf_amd.NeRFRender(cfg, sample_coarse=64, sample_fine=128, dist_near=0.0, dist_far=1.0, max_dist=1.0,
+                             use_coarse_network=False, sampling_type="point")
+    r.network_fine.load_state_dict({k: torch.from_numpy(v) for k, v in bunny_weights.items()})
+    r.to(dev)
+    r.set_iter(-1)
+    r.ray_space, r.ndc_width, r.ndc_height, r.ndc_near = "ndc", W, H, near
+    cam = neddf_amd.Camera(neddf_amd.PinholeCalib(np.array([815.13, 815.13, W / 2.0, H / 2.0])), None).to(dev)
+    cam.R, cam.T = T(np.eye(3, dtype=np.float32), dev), T(np.array([0.05, -0.02, 0.1], np.float32), dev)
+    desc = cam.descriptor()
+    n = W * H
+    gen = torch.Generator(device=dev).manual_seed(7)
+    U_c = torch.rand(n, 65, device=dev, generator=gen)
+    U_f = torch.rand(n, 129, device=dev, generator=gen)
+    idx = torch.arange(n, device=dev)
+    uv = torch.stack([idx % W, idx // W], 1)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def frame(dtype, batch, check=False):
+        r.network_fine.weight_dtype = dtype
+        ctx = r._ctx(dev)          # (re-packs the slot's weights under the operand policy just selected)
+        color, depth, trans = torch.empty(n, 3, device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev)
+        dc, df = torch.empty(batch, 65, device=dev), torch.empty(batch, 194, device=dev)
+        for lo in range(0, n, batch):
+            hi = min(n, lo + batch)
+            b = hi - lo
+            ctx.render_rays(uv[lo:hi], desc, r._params(), U_c[lo:hi], U_f[lo:hi],
+                            dict(color=color[lo:hi], depth=depth[lo:hi], transmittance=trans[lo:hi], dists_coarse=dc[:b], dists_fine=df[:b], nan_flag=flag))
+            if check:
+                assert bool((df[:b, 1:] >= df[:b, :-1]).all()), lo
+                merged = torch.sort(torch.cat([df[:b], dc[:b]], 1), dim=1)[0]
+                assert bool((merged[:, 1:] == merged[:, :-1]).sum(1).ge(65).all()), lo
+                assert float(df[:b].min()) >= 0.0 and bool((df[:b].max(1)[0] <= dc[:b].max(1)[0] + 1e-6).all())
+        return color, depth, trans
+
+    c16, d16, t16 = frame("bf16", 1 << 16, check=True)
+    assert int(flag.item()) == 0
+    for v in (c16, d16, t16):
+        assert bool(torch.isfinite(v).all())
+    c16b, d16b, t16b = frame("bf16", 50001)           # another batch split (odd size: every tile tail)
+    assert torch.equal(c16, c16b) and torch.equal(d16, d16b) and torch.equal(t16, t16b)
+    c32, d32, t32 = frame("fp32", 1 << 16)
+    assert int(flag.item()) == 0
+    err = (c16 - c32).abs()
+    assert float(err.max()) > 0.0, "the bf16 frame is bit-identical to the fp32 one: the operand policy was not applied"
+    mse = float(((c16 - c32).double() ** 2).mean())
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
+    print("\nc5 full frame: bf16 vs fp32 colour PSNR %.1f dB, median |err| %.2e, 99th percentile %.2e, max %.2e; depth max |err| %.2e"
+          % (psnr, float(err.median()), float(torch.quantile(err.flatten()[::7], 0.99)), float(err.max()), float((d16 - d32).abs().max())))
+    assert psnr > 45.0 and float(err.median()) < 2e-3 and float(torch.quantile(err.flatten()[::7], 0.99)) < 3e-2
+
+
 def test_llff_ndc_training_and_eval_flow(dev, tmp_path, monkeypatch, capsys):
     """configs[4] as a workflow: LLFF-layout dataset -> scripts/run.py with NDC rays and a NeRF network pair (one epoch) ->
     scripts/run_eval.py on the result."""

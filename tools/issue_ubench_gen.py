@@ -64,6 +64,11 @@ class Fill:
             if k == "dsw32":
                 return f"ds_write_b32 %[la], %[z{e}] offset:{off}"
             return f"ds_write_b64 %[la8], %[zz] offset:{off}"
+        if k == "mixplain":          # the mix with its three transcendentals replaced by plain multiplies: same dependences, no quarter-rate unit
+            seq = ["v_mul_f32 %[u{e}], %[z{e}], %[kl]", "v_mul_f32 %[u{e}], %[u{e}], %[k1]", "v_mul_f32 %[t{e}], %[u{e}], %[k2l]", "v_mul_f32 %[t{e}], %[t{e}], %[k1]",
+                   "v_add_f32 %[t{e}], 1.0, %[t{e}]", "v_mul_f32 %[t{e}], %[t{e}], %[k1]", "v_fma_f32 %[t{e}], %[t{e}], -2.0, 1.0", "v_mul_f32 %[w{e}], %[z{e}], %[u{e}]",
+                   "v_fma_f32 %[u{e}], %[t{e}], %[t{e}], -1.0", "v_fma_f32 %[w{e}], -%[w{e}], %[u{e}], %[t{e}]", "v_mul_f32 %[u{e}], %[z{e}], %[t{e}]"]
+            return seq[(j // NMIX) % 11].format(e=j % NMIX)
         if k in ("mix", "mixdep", "eplg"):
             seq = [
                 "v_mul_f32 %[u{e}], %[z{e}], %[kl]",
@@ -94,7 +99,7 @@ class Fill:
 
 def nb_of(kind):
     """MFMAs per loop body: a multiple of NACC that makes NB * K fillers a whole number of the filler pattern's periods"""
-    if kind in ("mix", "mixdep"):
+    if kind in ("mix", "mixdep", "mixplain"):
         return NACC * 11
     if kind == "eplg":
         return NACC * 13
@@ -279,6 +284,16 @@ def main():
                         continue
                     add(f"k_{mf}_{kind}_p{K}_{pm}{pv}", 512, [("wave >= 4", body(mf, kind, K, "fill", nb), pv), ("true", body(mf, None, 0, "mfma", nb), pm)],
                         mf, K, kind, "partner", nb, f"prio(matrix,filler)=({pm},{pv})")
+        # two FILLER waves per SIMD, no matrix work: does the vector pipe take instructions from both at the single-wave rate?
+        if mf == "bf16":
+            add("k_valu_fma_beside_exp", 512, [("wave >= 4", body(mf, "exp", 8, "fill", 32), 0), ("true", body(mf, "fma", 8, "fill", 32), 0)], mf, 8, "fma|exp",
+                "partner", 32, "waves 0..3 v_fma only (cyc/MFMA column), waves 4..7 v_exp only (fill_cyc column); alone: 33.2 / 67.9")
+            add("k_valu_fma_beside_exp4", 512, [("wave >= 4", body(mf, "exp", 4, "fill", 32), 0), ("true", body(mf, "fma", 8, "fill", 32), 0)], mf, 8, "fma|exp4",
+                "partner", 32, "as above with 4 v_exp per 8 v_fma")
+            for kind in ("fma", "exp", "mix", "mixplain", "eplg", "dsw16"):
+                nb = nb_of(kind)
+                add(f"k_valu2_{kind}", 512, [("true", body(mf, kind, 8, "fill", nb), 0)], mf, 8, kind, "two-filler-waves", nb)
+                add(f"k_valu1_{kind}", 256, [("true", body(mf, kind, 8, "fill", nb), 0)], mf, 8, kind, "one-filler-wave", nb)
         add(f"k_{mf}_base2", 512, [("true", body(mf, None, 0, "mfma", 32), 0)], mf, 0, None, "two-matrix-waves", 32)
 
     src = PRE + "".join(kernels)

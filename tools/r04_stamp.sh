@@ -1,0 +1,6 @@
+# phase timelines of the reverse-mode distance kernel under the three operand policies (make stamp; tools/stamp_timeline.py)
+O=gpurun_out/r04/stamp; mkdir -p $O
+for dt in fp32 f16_split bf16; do
+  NEDDF_LIB_PATH=neddf_amd/csrc/libneddf_hip_stamp.so NEDDF_STAMP_FILE=$O/$dt.bin NEDDF_PROBE_DTYPE=$dt python tools/pmc_probe.py 1 > $O/$dt.log 2>&1
+  echo "=== $dt"; python tools/stamp_timeline.py $O/$dt.bin 7 | tee $O/$dt.txt
+done
