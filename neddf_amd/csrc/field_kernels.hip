@@ -351,7 +351,9 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
 // tiles on one 8-wave workgroup per CU (half the L2 -> VGPR weight stream per point) are SLOWER for the 16-bit policies (split
 // fp16 14.5 vs 12.4 ms, bf16 8.4 vs 8.4 ms per launch): with one workgroup per CU nothing covers its barriers and the y'
 // round trip, and two 128-point workgroups do not fit (bf16: 403 spilled registers at 128 accumulators + the y' sets).
-size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points, int width) { return (size_t)n_layers * points * width + (size_t)points * 128; }
+// y' of every layer + [encoding Jacobian factors | encoding copy | parked encoding gradient] (64 columns each) + the fused colour trunk's parked
+// first-layer product (one accumulator set)
+size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points, int width) { return (size_t)n_layers * points * width + (size_t)points * 192 + (size_t)points * width; }
 
 template <int KIND, bool LAST, int MT, int NT, class Ops>
 __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *yp, const float *wseed, int wave,
@@ -424,8 +426,14 @@ __device__ __forceinline__ void rev_forward_epilogue_rt(f32x16 (&acc)[MT][NT], t
     } else rev_forward_epilogue<2, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane, ymask);
 }
 
-template <int MT, int NW, int WPS, class Ops, bool MASKY>
-__global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const DdfArgs a)
+// FUSED (round 4: one field kernel per slab): the colour trunk (neddf.py:243-257, value rows) runs on the SAME 64-point tile right after
+// the reverse pass -- its first layer's product with the trunk features is taken while the features still sit in LDS (before the
+// gradients overwrite them) and parked in the workgroup's scratch in accumulator layout; after the tail has produced the normal, the
+// tile's first columns receive [embed_pos | embed_dir | normal] (the unscaled encoding is the saved scaled one times 2^(e-1): exact,
+// no second sincos), the small-input product joins the parked one, and the remaining colour layers and the 256 -> 3 head follow.
+// No [N, 256] feature matrix, no per-point record, no second launch: the hand-off of 1 088 B per point never reaches HBM.
+template <int MT, int NW, int WPS, class Ops, bool MASKY, bool FUSED = false>
+__global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const DdfArgs a, const ColArgs c)
 {
     typedef typename Ops::act_t act_t;
     typedef typename Ops::bfrag frag;
@@ -440,9 +448,13 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
     float *lp = hd + 6 * ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
-    float *yp = a.rev_scratch + (size_t)blockIdx.x * ((size_t)a.n_layers * P * WID + (size_t)P * 128);
+    float *yp = a.rev_scratch + (size_t)blockIdx.x * ((size_t)a.n_layers * P * WID + (size_t)P * 192 + (size_t)P * WID);
     float *pj = yp + (size_t)a.n_layers * ROWS * WID;           // [ROWS][64] dPE/dx factors: [q] sine half, [32 + q] cosine half
-    float *pv = pj + ROWS * 64;                                  // [ROWS][64] the encoding itself, for the skip layer
+    float *pv = pj + ROWS * 64;                                  // [ROWS][64] the encoding itself, for the skip layer (and the colour trunk's inputs)
+    float *pg = pv + ROWS * 64;                                  // [ROWS][64] the skip layers' share of the encoding gradient, parked
+    float *cpark = pg + ROWS * 64;                               // [ROWS][WID] FUSED: the colour trunk's first-layer product with the features
+    float *chd = lp + 16;                                        // FUSED: [THREADS][3] partial colour dots (behind lp / ctl)
+    static_assert(!FUSED || NW == 4, "the fused colour phases are laid out for four waves");
     if (tid == 0) {
 #pragma unroll
         for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
@@ -544,7 +556,14 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             }
             hd[item] = (s0 + s1) + (s2 + s3);
         }
-        {
+        if constexpr (FUSED) {
+            // colour layer 0, feature segment (neddf.py:243: cat[..., features]): the features are this tile right now; the seed of the
+            // reverse pass stays in `acc` (parking it in the last layer's y' slot instead measured 3 % slower: r04_fused_field_kernel.txt)
+            f32x16 cacc[MT][NT];
+            acc_init<MT, NT, false>(cacc, c.layer[0].bias, wave, lane, Ops::kWScale);
+            dense<MT, NT, Ops>(cacc, act_lane, (const frag *)c.layer[0].wp + (size_t)wave * NT * c.layer[0].ksteps * 64 + lane, c.layer[0].ksteps);
+            stash_store<MT, NT>(cacc, cpark, wave, lane);
+        } else {
             constexpr int CE = 16 / sizeof(act_t), CPP = WID / CE, CPR = Ops::kPlanes * CPP;
             act_t *features = (act_t *)a.features;
             for (int idx = tid; features && idx < P * CPR; idx += THREADS) {
@@ -572,7 +591,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
         STAMP();                        // F + 3
         // the [P, 64] encoding gradient in 32 x 32 blocks, BPW per wave: block b = wave * BPW + i is M-tile b >> 1, N-tile b & 1.  The
         // skip layer's share waits in the scratch, not in registers, while the remaining layers run (the product loop needs them)
-        f32x4v *gpe_park = (f32x4v *)pv + (size_t)wave * BPW * 4 * 64 + lane;        // the encoding copy in pv is no longer needed here
+        f32x4v *gpe_park = (f32x4v *)pg + (size_t)wave * BPW * 4 * 64 + lane;
         bool parked = false;
         for (int l = a.n_layers - 1; l >= 1; --l) {
             if (a.layer[l].stash >= 0) {    // cat([encoding, h]): the encoding rows of W_l take their share of g_l (every skip layer adds its own)
@@ -701,6 +720,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
         }
         __syncthreads();
         // ---- per point: grad_x z_D = sum over the encoding channels of g_pe * dPE/dx, then the head arithmetic (neddf.py:220-241)
+        float nrm[3] = { 0.f, 0.f, 0.f };          // FUSED: the normal of this thread's point, input of the colour trunk
         if (tid < P && p0 + tid < a.n_points) {
             const int64_t gp = p0 + tid;
             const act_t *gr = act + tid * LD;
@@ -737,18 +757,110 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             const float Dinv = 1.0f / D;
             const float rho = act_val_rt(a.density_activation, Dinv * (1 - dDdt));   // :239-240
             const float ninv = 1.0f / (dgn + 1e-7f);               // :241
+            if constexpr (FUSED) {
+                nrm[0] = ninv * dg0; nrm[1] = ninv * dg1; nrm[2] = ninv * dg2;
+            } else {
             float *pa = a.ptaux + gp * kPtAux;
             f32x4v v0 = { D, rho, aux, ninv * dg0 };
             f32x4v v1 = { ninv * dg1, ninv * dg2, z, az };
             f32x4v v2 = { dg0, dg1, dg2, 0.f };
             f32x4v v3 = { 0.f, 0.f, dgn, dDdt };
             ((f32x4v *)pa)[0] = v0; ((f32x4v *)pa)[1] = v1; ((f32x4v *)pa)[2] = v2; ((f32x4v *)pa)[3] = v3;
+            }
             if (a.distance) a.distance[gp] = D;
             if (a.density) a.density[gp] = rho;
             if (a.aux_grad) a.aux_grad[gp] = aux;
             }
         }
         STAMP();                        // tail: encoding gradient, head arithmetic, outputs done
+        if constexpr (FUSED) {
+            // ---- colour trunk on this tile (neddf.py:243-257, value rows; col_trunk_kernel<false> is the stand-alone form)
+            __syncthreads();            // every thread finished reading the encoding gradient rows
+            const int c_dir = 2 * KH, KD = a.enc.KD, c_n = c_dir + 2 * KD, K3d = 3 * a.enc.Ed;
+            const int ka = Ops::kStep * c.ksteps_a;
+            // layer 0, small-input segment [embed_pos | embed_dir | normal]; every column below ka is written exactly once (values or zero padding)
+            for (int i = tid; i < P * 2 * KH; i += THREADS) {       // embed_pos = the saved embed_pos_scaled x (0.5 * 2^e): exact (neddf.py:193-204)
+                const int p = (unsigned)i / (unsigned)(2 * KH), cc = i - p * 2 * KH;
+                const int q = cc < KH ? cc : cc - KH;
+                float v = 0.f;
+                if (q < K3) v = pv[p * 64 + cc] * (0.5f * (float)(1 << (q / 3)));
+                Ops::put(act + p * LD + cc, v);
+            }
+            for (int i = tid; i < P * KD; i += THREADS) {           // embed_dir (positional_encoding.py:51-65)
+                const int p = (unsigned)i / (unsigned)KD, q = i - p * KD;
+                float sn = 0.f, cs = 0.f;
+                if (q < K3d) {
+                    const int e = q / 3, d = q - 3 * e;
+                    const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
+                    if (Ops::kFast) fast_sincos((float)(1 << e) * a.dir[gp * 3 + d], sn, cs);
+                    else sincos_cw((float)(1 << e) * a.dir[gp * 3 + d], sn, cs);
+                }
+                Ops::put(act + p * LD + c_dir + q, sn);
+                Ops::put(act + p * LD + c_dir + KD + q, cs);
+            }
+            for (int i = tid; i < P * (ka - c_n); i += THREADS) {   // normal (written by the thread that derived it) + zero padding
+                const int p = (unsigned)i / (unsigned)(ka - c_n), cc = i - p * (ka - c_n);
+                if (cc >= 3) Ops::zero(act + p * LD + c_n + cc);
+            }
+            if (tid < P) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) Ops::put(act + tid * LD + c_n + d, nrm[d]);
+            }
+            // the parked feature product comes back while the inputs settle
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4v v = ((const f32x4v *)cpark + (size_t)wave * (MT * NT * 4) * 64 + lane)[((mt * NT + t) * 4 + g) * 64];
+                        acc[mt][t][4 * g] = v[0]; acc[mt][t][4 * g + 1] = v[1]; acc[mt][t][4 * g + 2] = v[2]; acc[mt][t][4 * g + 3] = v[3];
+                    }
+            __syncthreads();
+            dense<MT, NT, Ops>(acc, act_lane, (const frag *)c.wp_a + (size_t)wave * NT * c.ksteps_a * 64 + lane, c.ksteps_a);
+            for (int l = 0; l < c.n_layers; ++l) {                  // neddf.py:254-256 (prefetching the next layer's first fragments as
+                if (l > 0) {                                        // col_trunk_kernel does measured slower here: register pressure)
+                    acc_init<MT, NT, false>(acc, c.layer[l].bias, wave, lane, Ops::kWScale);
+                    dense<MT, NT, Ops>(acc, act_lane, (const frag *)c.layer[l].wp + (size_t)wave * NT * c.layer[l].ksteps * 64 + lane, c.layer[l].ksteps);
+                }
+                __syncthreads();
+                epilogue_rt<MT, NT, false, Ops>(acc, act, c.activation, wave, lane);
+                __syncthreads();
+            }
+            // layer_col_out 256 -> 3 (neddf.py:257): NPART threads share a row (col_trunk_kernel)
+            constexpr int NPART = THREADS / ROWS, KPART = WID / NPART;
+            static_assert(NPART >= 1 && NPART * ROWS == THREADS && KPART % 4 == 0, "the colour head splits a row over THREADS / ROWS threads");
+            {
+                const int part = ROWS == 64 ? __builtin_amdgcn_readfirstlane(wave) : tid / ROWS, row = tid - (tid / ROWS) * ROWS;
+                const act_t *ar = act + row * LD + part * KPART;
+                const float *w = c.w_out + part * KPART * 3;
+                float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll 4
+                for (int k = 0; k < KPART / 4; ++k) {
+                    float x[4];
+                    Ops::load4(ar + 4 * k, x);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        c0 = fmaf(x[u], w[(4 * k + u) * 3 + 0], c0);
+                        c1 = fmaf(x[u], w[(4 * k + u) * 3 + 1], c1);
+                        c2 = fmaf(x[u], w[(4 * k + u) * 3 + 2], c2);
+                    }
+                }
+                chd[tid * 3 + 0] = c0; chd[tid * 3 + 1] = c1; chd[tid * 3 + 2] = c2;
+            }
+            __syncthreads();
+            if (tid < P && p0 + tid < a.n_points) {
+                const int64_t gp = p0 + tid;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float sum = c.b_out[k];
+#pragma unroll
+                    for (int q = 0; q < NPART; ++q) sum += chd[(q * ROWS + tid) * 3 + k];
+                    c.color[gp * 3 + k] = sum;
+                }
+            }
+            STAMP();                    // colour trunk done
+        }
         if (tid == 0) ctl[0] = next_tile;
         __syncthreads();
         tile = ctl[0];
@@ -1289,14 +1401,25 @@ void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
 
 // reverse-mode kernel: its tile shape per operand policy (see ddf_rev_kernel)
 template <int MT, int NW, int WPS, class Ops>
-static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s)
+static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *col = nullptr)
 {
+    // tanhExp: y' round trip as values; ReLU / LeakyReLU: as mask bits (the kernel's header).  col: the colour trunk runs on the same tile (FUSED)
+    if constexpr (NW == 4) {
+        if (col) {
+            static bool oncef = (set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, false, true>, lds_bytes<Ops>(MT)),
+                                 set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, true, true>, lds_bytes<Ops>(MT)), true);
+            (void)oncef;
+            if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, false, true>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a, *col);
+            else hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, true, true>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a, *col);
+            return;
+        }
+    }
     static bool once = (set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, false>, lds_bytes<Ops>(MT)),
                         set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, true>, lds_bytes<Ops>(MT)), true);
     (void)once;
-    // tanhExp: y' round trip as values; ReLU / LeakyReLU: as mask bits (the kernel's header)
-    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, false>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a);
-    else hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, true>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a);
+    const ColArgs none{};
+    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, false>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a, none);
+    else hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, true>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a, none);
 }
 
 // Tile shape of the reverse-mode kernel at width 256 per operand policy: (MT, NW, WPS) = (2, 4, 2) under fp32; the 16-bit policies
@@ -1315,33 +1438,36 @@ int ddf_rev_points(int, int width) { return width == 256 ? 64 : geo_w(width).mt 
 int ddf_rev_wgs_per_cu(int operands, int width) { return width == 256 ? geo_rev(operands).wps : 2; }
 
 template <int WID>
-static void launch_ddf_rev_w(const DdfArgs &a, int grid, hipStream_t s)
+static void launch_ddf_rev_w(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *col)
 {
     constexpr int MT = WID == 128 ? 2 : 1;
-    if (a.operands == 2) launch_ddf_rev_t<MT, 4, 2, OpsF16SplitT<WID>>(a, grid, s);
-    else if (a.operands == 1) launch_ddf_rev_t<MT, 4, 2, OpsBF16T<WID>>(a, grid, s);
-    else launch_ddf_rev_t<MT, 4, 2, OpsF32T<WID>>(a, grid, s);
+    if (a.operands == 2) launch_ddf_rev_t<MT, 4, 2, OpsF16SplitT<WID>>(a, grid, s, col);
+    else if (a.operands == 1) launch_ddf_rev_t<MT, 4, 2, OpsBF16T<WID>>(a, grid, s, col);
+    else launch_ddf_rev_t<MT, 4, 2, OpsF32T<WID>>(a, grid, s, col);
 }
 
-void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s)
+// the shapes that can take the colour trunk on their tile (four waves per workgroup: every shipped shape; the eight-wave probes cannot)
+bool ddf_rev_can_fuse(int operands, int width) { return width != 256 || (geo_rev(operands).nw == 4 && geo_rev(operands).wps == 2); }
+
+void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *col)
 {
-    if (a.width == 128) return launch_ddf_rev_w<128>(a, grid, s);
-    if (a.width == 384) return launch_ddf_rev_w<384>(a, grid, s);
-    if (a.width == 512) return launch_ddf_rev_w<512>(a, grid, s);
+    if (a.width == 128) return launch_ddf_rev_w<128>(a, grid, s, col);
+    if (a.width == 384) return launch_ddf_rev_w<384>(a, grid, s, col);
+    if (a.width == 512) return launch_ddf_rev_w<512>(a, grid, s, col);
     const Geo g = geo_rev(a.operands);          // (mt, wps, nw)
     if (a.operands == 2) {
         NEDDF_GEO_CASE(2, 2, 8) return launch_ddf_rev_t<2, 8, 2, OpsF16Split>(a, grid, s);
         NEDDF_GEO_CASE(2, 3, 8) return launch_ddf_rev_t<2, 8, 3, OpsF16Split>(a, grid, s);
-        return launch_ddf_rev_t<2, 4, 2, OpsF16Split>(a, grid, s);
+        return launch_ddf_rev_t<2, 4, 2, OpsF16Split>(a, grid, s, col);
     }
     if (a.operands == 1) {
         NEDDF_GEO_CASE(2, 2, 8) return launch_ddf_rev_t<2, 8, 2, OpsBF16>(a, grid, s);
         NEDDF_GEO_CASE(2, 3, 4) return launch_ddf_rev_t<2, 4, 3, OpsBF16>(a, grid, s);
         NEDDF_GEO_CASE(2, 3, 8) return launch_ddf_rev_t<2, 8, 3, OpsBF16>(a, grid, s);
         NEDDF_GEO_CASE(2, 4, 8) return launch_ddf_rev_t<2, 8, 4, OpsBF16>(a, grid, s);
-        return launch_ddf_rev_t<2, 4, 2, OpsBF16>(a, grid, s);
+        return launch_ddf_rev_t<2, 4, 2, OpsBF16>(a, grid, s, col);
     }
-    launch_ddf_rev_t<2, 4, 2, OpsF32>(a, grid, s);
+    launch_ddf_rev_t<2, 4, 2, OpsF32>(a, grid, s, col);
 }
 
 template <int WID>

@@ -137,7 +137,8 @@ struct CameraArg {
 
 size_t field_lds_bytes(int mt);
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s);
-void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s);
+void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *col = nullptr);   // col: the colour trunk on the same tile (one field kernel)
+bool ddf_rev_can_fuse(int operands, int width);
 size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points, int width);
 int ddf_rev_points(int operands, int width);        // sample points per tile of ddf_rev_kernel under an operand policy / engine width
 int ddf_rev_wgs_per_cu(int operands, int width);

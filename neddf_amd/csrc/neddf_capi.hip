@@ -525,11 +525,21 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     static const int rev_mask = [] { const char *e = getenv("NEDDF_DDF_REVERSE_DTYPES"); return e ? atoi(e) : 7; }();
     const bool reverse = rev_enabled && ((rev_mask >> dt) & 1) && !full && (f.d.kind == NEDDF_FIELD_NEDDF || f.d.kind == NEDDF_FIELD_NEUS) &&
                          ddf_rev_available();
+    // One field kernel per slab (round 4): with the distance gradient in reverse mode the colour trunk can run on
+    // the distance kernel's own tile (ddf_rev_kernel<..., FUSED>): no [N, width] feature matrix, no per-point record, no second launch.
+    // Built, parity-green and MEASURED SLOWER than the two-kernel route (fp32 34.60 vs 34.42 ms per 2^21 points, split fp16 16.46 vs
+    // 16.10, bf16 8.29 vs 8.10; profiles/r04_fused_field_kernel.txt): the fp32 matrix pipe is saturated either way (the hand-off it
+    // saves was free), and under the 16-bit policies the stand-alone colour kernel's own tile shape beats the distance kernel's.  So it
+    // is opt-in: NEDDF_FUSED=1 (tests/test_gpu_parity.py::test_fused_field_kernel_in_subprocess holds it to the same gates).
+    static const bool fuse_enabled = [] { const char *e = getenv("NEDDF_FUSED"); return e && atoi(e) != 0; }();
+    const bool fused = fuse_enabled && reverse && color && f.d.kind == NEDDF_FIELD_NEDDF && ddf_rev_can_fuse(dt, wid);
     const int64_t chunk_cap = full ? (1 << 19) : (1 << 21);
     const int64_t chunk = N < chunk_cap ? N : chunk_cap;
     // activations' element type and planes: fp32 1024 B, bf16 512 B, split bf16 (two planes) 1024 B per row
-    if (int rc = ensure(ctx, ctx->features, (size_t)chunk * fr * wid * sizeof(float))) return rc;
-    if (int rc = ensure(ctx, ctx->ptaux, (size_t)chunk * kPtAux * sizeof(float))) return rc;
+    if (!fused) {
+        if (int rc = ensure(ctx, ctx->features, (size_t)chunk * fr * wid * sizeof(float))) return rc;
+        if (int rc = ensure(ctx, ctx->ptaux, (size_t)chunk * kPtAux * sizeof(float))) return rc;
+    }
     if (int rc = ensure(ctx, ctx->sched, 2 * kSchedInts * sizeof(int))) return rc;
     DevBuf &sink = ctx->flags;      // [>= 64 B] flags live in front; colour sink handled below
     (void)sink;
@@ -540,9 +550,9 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         a.pos = pos + off * 3; a.dir = dir + off * 3; a.var = var + off * 3; a.n_points = n;
         a.aux_grad_scale = f.aux_grad_scale;
         a.scratch = (float *)ctx->scratch.p;
-        a.features = (color || full) ? (float *)ctx->features.p : nullptr;      // no colour trunk follows: no hand-off
+        a.features = ((color || full) && !fused) ? (float *)ctx->features.p : nullptr;      // no colour kernel follows: no hand-off
         a.feat_rows = fr;
-        a.ptaux = (float *)ctx->ptaux.p;
+        a.ptaux = fused ? nullptr : (float *)ctx->ptaux.p;
         a.distance = distance ? distance + off : nullptr;
         a.density = density ? density + off : nullptr;
         a.aux_grad = aux ? aux + off : nullptr;
@@ -562,6 +572,13 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
             HIPCHK(hipMemsetAsync(d_stamps, 0, stamp_bytes, s));
             a.stamps = d_stamps;
 #endif
+            if (fused) {
+                ColArgs c = f.col;
+                fill_enc(c.enc, f);
+                c.pos = a.pos; c.dir = a.dir; c.var = a.var; c.n_points = n;
+                c.color = color + off * 3;
+                STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf_rev(a, grid, s, &c));
+            } else
             STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf_rev(a, grid, s));
 #ifdef NEDDF_STAMP
             if (const char *path = getenv("NEDDF_STAMP_FILE")) {        // the LAST launch's stamps (a diagnostic build: synchronising here is fine)
@@ -575,7 +592,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
             const int64_t tiles = (n + ddf_points_per_tile(dt, wid) - 1) / ddf_points_per_tile(dt, wid);
             STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf(a, (int)(tiles < grid_cap_ddf ? tiles : grid_cap_ddf), s));
         }
-        if (color || full) {
+        if ((color || full) && !fused) {
             ColArgs c = f.col;
             fill_enc(c.enc, f);
             c.pos = a.pos; c.dir = a.dir; c.var = a.var; c.n_points = n;

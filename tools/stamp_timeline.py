@@ -21,7 +21,12 @@ for l in range(L):
 names += ["heads+handoff", "bar", "gL store", "bar"]
 for l in range(L - 1, 0, -1):
     names += ["R%d setup/skip" % l, "R%d product" % l, "R%d bar(+y' req)" % l, "R%d y' mul+store" % l, "R%d bar" % l]
-names += ["tail", "next-tile bar"]
+names += ["tail"]
+# NEDDF_FUSED=1: one more stamp after the colour trunk that runs on the same tile
+fused = bool((raw[:, :, len(names) + 2] != 0).all())
+if fused:
+    names += ["colour trunk (fused)"]
+names += ["next-tile bar"]
 n = len(names) + 1
 ok = raw[:, :, :n]
 if (ok[:, :, 1:] == 0).any():
