@@ -619,7 +619,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             // y'_{l-1} of this lane's accumulator positions comes back M-tile by M-tile through two register sets: the first two
             // are requested after the product (requesting them before it -- 64 more live registers -- measured no faster: the
             // CU's other waves cover the latency), the others while the previous M-tile is multiplied and stored
-            f32x16 yb[2][NT];
+            f32x16 yb[MT >= 4 ? 1 : 2][MT >= 4 ? 1 : NT];
             const f32x4v *ysrc = (const f32x4v *)(yp + (size_t)((l - 1) * ylstep) * ROWS * WID) + (size_t)wave * (MT * NT * (Ops::kStash16 ? 2 : 4)) * 64 + lane;
             auto load_y = [&](f32x16 (&dst)[NT], int mt) {
                 mt &= ymask;
@@ -668,6 +668,35 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
                     }
                 __syncthreads();
             } else {
+            if constexpr (MT >= 4) {
+                // 128-point tiles: 128 accumulator registers leave no room for two M-tiles of y' -- one 32 x 32 block at a time through two
+                // 16-register sets, block i + 2 requested while block i is multiplied and stored
+                constexpr int NB = MT * NT;
+                f32x16 y1[2];
+                auto load_blk = [&](f32x16 &dst, int i) {
+                    if constexpr (Ops::kStash16) stash_load16(dst, (const u32x4 *)ysrc + (i * 2) * 64);
+                    else
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4v v = ysrc[(i * 4 + g) * 64];
+                            dst[4 * g] = v[0]; dst[4 * g + 1] = v[1]; dst[4 * g + 2] = v[2]; dst[4 * g + 3] = v[3];
+                        }
+                };
+                load_blk(y1[0], 0);
+                load_blk(y1[1], 1);
+                __syncthreads();            // every wave finished reading g_l
+                STAMP();
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int mt = i / NT, t = i % NT;
+                    act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2)
+                        Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, acc[mt][t][q] * y1[i & 1][q],
+                                  acc[mt][t][q + 1] * y1[i & 1][q + 1]);
+                    if (i + 2 < NB) load_blk(y1[i & 1], i + 2);
+                }
+            } else {
             load_y(yb[0], 0);
             if (MT > 1) load_y(yb[1], 1);
             __syncthreads();            // every wave finished reading g_l
@@ -683,6 +712,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
                                   acc[mt][t][q + 1] * yb[mt & 1][t][q + 1]);
                 }
                 if (mt + 2 < MT) load_y(yb[mt & 1], mt + 2);
+            }
             }
             STAMP();                    //                +3 y' multiply + store done
             __syncthreads();
@@ -1429,12 +1459,12 @@ static Geo geo_rev(int operands)
     static Geo g[3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
     if (!g[0].mt) {
         g[0] = Geo{ 2, 2, 4 };
-        g[1] = parse_geo("NEDDF_REV_GEO_BF16", Geo{ 2, 2, 4 }, { { 2, 2, 4 }, { 2, 2, 8 }, { 2, 3, 4 }, { 2, 3, 8 }, { 2, 4, 8 } });
-        g[2] = parse_geo("NEDDF_REV_GEO_SPLIT", Geo{ 2, 2, 4 }, { { 2, 2, 4 }, { 2, 2, 8 }, { 2, 3, 8 } });
+        g[1] = parse_geo("NEDDF_REV_GEO_BF16", Geo{ 2, 2, 4 }, { { 2, 2, 4 }, { 4, 2, 4 }, { 2, 2, 8 }, { 2, 3, 4 } });
+        g[2] = parse_geo("NEDDF_REV_GEO_SPLIT", Geo{ 2, 2, 4 }, { { 2, 2, 4 }, { 2, 2, 8 } });
     }
     return g[operands < 0 || operands > 2 ? 0 : operands];
 }
-int ddf_rev_points(int, int width) { return width == 256 ? 64 : geo_w(width).mt * 32; }
+int ddf_rev_points(int operands, int width) { return width == 256 ? geo_rev(operands).mt * 32 : geo_w(width).mt * 32; }
 int ddf_rev_wgs_per_cu(int operands, int width) { return width == 256 ? geo_rev(operands).wps : 2; }
 
 template <int WID>
@@ -1457,14 +1487,12 @@ void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *co
     const Geo g = geo_rev(a.operands);          // (mt, wps, nw)
     if (a.operands == 2) {
         NEDDF_GEO_CASE(2, 2, 8) return launch_ddf_rev_t<2, 8, 2, OpsF16Split>(a, grid, s);
-        NEDDF_GEO_CASE(2, 3, 8) return launch_ddf_rev_t<2, 8, 3, OpsF16Split>(a, grid, s);
         return launch_ddf_rev_t<2, 4, 2, OpsF16Split>(a, grid, s, col);
     }
     if (a.operands == 1) {
         NEDDF_GEO_CASE(2, 2, 8) return launch_ddf_rev_t<2, 8, 2, OpsBF16>(a, grid, s);
         NEDDF_GEO_CASE(2, 3, 4) return launch_ddf_rev_t<2, 4, 3, OpsBF16>(a, grid, s);
-        NEDDF_GEO_CASE(2, 3, 8) return launch_ddf_rev_t<2, 8, 3, OpsBF16>(a, grid, s);
-        NEDDF_GEO_CASE(2, 4, 8) return launch_ddf_rev_t<2, 8, 4, OpsBF16>(a, grid, s);
+        NEDDF_GEO_CASE(4, 2, 4) return launch_ddf_rev_t<4, 4, 2, OpsBF16>(a, grid, s);
         return launch_ddf_rev_t<2, 4, 2, OpsBF16>(a, grid, s, col);
     }
     launch_ddf_rev_t<2, 4, 2, OpsF32>(a, grid, s, col);

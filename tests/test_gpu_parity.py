@@ -622,6 +622,35 @@ def test_forward_mode_kernels_in_subprocess():
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
 
 
+def test_reduced_cost_activation_against_the_branch_exact_build(dev):
+    """`make exactact` (built by __graft_entry__.build()): the fused kernels of the fp32 / split-fp16 policies with the reference's
+    branch-exact tanhExp.  (1) The exact build holds every gate of the stress fixture and of the shipped network -- the exact path
+    stays tested; (2) on the negative-bias fixture the shipped forms stay within the stated factors of it: the fp32 policy's closed
+    form at most 2.5x the exact build's density error against fp64, the split-fp16 policy's polynomial form at most 1.3x."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import ROOT
+    lib = os.path.join(ROOT, "neddf_amd", "csrc", "libneddf_hip_exactact.so")
+    if not os.path.exists(lib):
+        pytest.skip("libneddf_hip_exactact.so not built (python -c 'import __graft_entry__ as g; g.build()' makes it)")
+    sel = ["tests/test_gpu_parity.py::test_neddf_negative_bias_regime", "tests/test_gpu_parity.py::test_neddf_bunny_field",
+           "tests/test_gpu_parity.py::test_neddf_synth", "tests/test_gpu_parity.py::test_render_rays_end_to_end"]
+    errs = {}
+    for name, env in (("exact", dict(os.environ, NEDDF_LIB_PATH=lib)), ("shipped", dict(os.environ))):
+        env.pop("NEDDF_LIB_PATH", None) if name == "shipped" else None
+        p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu"] + sel, env=env, cwd=ROOT, capture_output=True, text=True,
+                           timeout=900)
+        assert p.returncode == 0, name + p.stdout[-3000:] + p.stderr[-2000:]
+        for m in re.finditer(r"negbias (\w+) (\w+): density error vs fp64 -- reference fp32 ([0-9.e+-]+), full ([0-9.e+-]+), minimal ([0-9.e+-]+)", p.stdout):
+            errs[(name, m.group(1), m.group(2))] = max(float(m.group(4)), float(m.group(5)))
+    assert len(errs) == 8, errs
+    for dtype, factor in (("fp32", 2.5), ("f16_split", 1.3)):
+        for tag in ("eval", "it2500"):
+            assert errs[("shipped", dtype, tag)] <= factor * errs[("exact", dtype, tag)] + 1e-7, (dtype, tag, errs)
+
+
 def test_fused_field_kernel_in_subprocess():
     """NEDDF_FUSED=1: ONE field kernel per slab -- the colour trunk on the reverse-mode distance kernel's own tile (SURVEY section 7
     step 6; ddf_rev_kernel<..., FUSED>; opt-in because it measured 0.5-2 % slower than two kernels, profiles/r04_fused_field_kernel.txt).
