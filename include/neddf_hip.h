@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NEDDF_ABI_VERSION 4
+#define NEDDF_ABI_VERSION 5
 
 enum { NEDDF_OK = 0, NEDDF_EINVAL = -1, NEDDF_EHIP = -2, NEDDF_EUNSUPPORTED = -3, NEDDF_ENOFIELD = -4,
        NEDDF_ECOMM = -5,      /* RCCL reported an error (message in neddf_last_error) or is not loadable */
@@ -110,6 +110,11 @@ void neddf_destroy(neddf_ctx *ctx);
 const char *neddf_last_error(neddf_ctx *ctx);
 /* number of compute units of the ctx's device (for roofline reporting) */
 int neddf_device_cus(neddf_ctx *ctx);
+/* Bounds probe (ABI v5; no reference counterpart -- the stand-in for a GPU-side sanitizer run).  With NEDDF_GUARD=1 in the environment
+ * every workspace of the context is allocated at its exact size between two poisoned 4 KiB bands and every carve of the render arena
+ * is followed by a 256 B one; this call synchronises the device and reports how many bands exist and how many of their bytes a kernel
+ * has overwritten (0 = no out-of-bounds store reached a band).  Without NEDDF_GUARD it reports 0 bands. */
+int neddf_debug_check_guards(neddf_ctx *ctx, int64_t *n_bands, int64_t *n_bad_bytes);
 
 /* Replaces nn.Module.load_state_dict for one network (base_trainer.py:121).
  * h_weights / h_biases: HOST fp32 arrays in state-dict order

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NEDDF_LIB_PATH selects another build of the same library (the sanitizer build, `make -C neddf_amd/csrc asan`)
 LIB_PATH = os.environ.get("NEDDF_LIB_PATH") or os.path.join(_HERE, "csrc", "libneddf_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 FIELD_NEDDF, FIELD_NERF, FIELD_NEUS = 0, 1, 2
 ACT = {"ReLU": 0, "LeakyReLU": 1, "tanhExp": 2}
@@ -66,6 +66,7 @@ SYMBOLS = [
     ("neddf_destroy", None, [_vp]),
     ("neddf_last_error", C.c_char_p, [_vp]),
     ("neddf_device_cus", C.c_int, [_vp]),
+    ("neddf_debug_check_guards", C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     ("neddf_set_field", C.c_int, [_vp, C.c_int, C.POINTER(FieldDesc), C.POINTER(_fp), C.POINTER(_fp), C.c_int]),
     ("neddf_set_iter", C.c_int, [_vp, C.c_int, C.c_float, C.c_float, _fp]),
     ("neddf_raygen", C.c_int, [_vp, _vp, C.c_int, _i64, C.POINTER(CameraDesc), _vp, _vp, _vp]),
@@ -173,6 +174,12 @@ class Context:
     @property
     def cus(self):
         return self.lib.neddf_device_cus(self.h)
+
+    def check_guards(self):
+        """(bands, overwritten bytes) of the NEDDF_GUARD=1 bounds probe (neddf_debug_check_guards); (0, 0) without it."""
+        nb, bad = _i64(0), _i64(0)
+        self.check(self.lib.neddf_debug_check_guards(self.h, C.byref(nb), C.byref(bad)))
+        return int(nb.value), int(bad.value)
 
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -4,6 +4,7 @@
 #include "../../include/neddf_hip.h"
 #include "kernels.h"
 
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -12,7 +13,21 @@ using namespace neddf;
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    void *base = nullptr;       // NEDDF_GUARD=1: the allocation starts one guard band in front of p
 };
+
+// NEDDF_GUARD=1 (a debug mode, tests/test_gpu_multi.py::test_workspace_guard_bands): every workspace of a context is allocated at its
+// EXACT requested size between two poisoned guard bands, every carve of the render arena is followed by one, and
+// neddf_debug_check_guards() counts the band bytes a kernel has overwritten -- the bounds probe that stands in for a GPU-side
+// AddressSanitizer run (ROCm's ASan runtime does not start beside an uninstrumented python on this image, tools/asan_probe.sh).
+constexpr size_t kGuardBytes = 4096, kCarveGuardBytes = 256;
+constexpr int kGuardByte = 0xA5;
+static inline bool guard_mode()
+{
+    static const bool on = [] { const char *e = getenv("NEDDF_GUARD"); return e && atoi(e) != 0; }();
+    return on;
+}
+struct GuardBand { const void *p; size_t bytes; };
 
 struct Field {
     bool valid = false;
@@ -70,6 +85,7 @@ struct neddf_ctx {
     DevBuf rev_scratch;          // reverse-mode distance kernel: per-workgroup y' of every layer + encoding Jacobian
     DevBuf tpack, ttmp;          // training step: packed weights of the layer in flight, gradient ping-pong buffers
     DevBuf tamax;                // training step: max |dZ| of every gradient matrix of a backward pass (split-fp16 operand range)
+    std::vector<GuardBand> carve_guards;      // NEDDF_GUARD=1: the bands behind the carves of the last render call
     bool timing = false;
     std::vector<EventPair> events;
     std::vector<EventPair> pool;
@@ -109,11 +125,20 @@ static inline int fail(neddf_ctx *ctx, int code, const std::string &msg)
 
 static inline int ensure(neddf_ctx *ctx, DevBuf &b, size_t bytes)
 {
-    if (b.cap >= bytes) return 0;
+    if (b.cap >= bytes && !(guard_mode() && b.cap != ((bytes + 15) & ~(size_t)15))) return 0;
     if (b.p) {
         HIPCHK(hipDeviceSynchronize());      // nothing in flight may still use the old block
-        HIPCHK(hipFree(b.p));
-        b.p = nullptr; b.cap = 0;
+        HIPCHK(hipFree(b.base ? b.base : b.p));
+        b.p = nullptr; b.cap = 0; b.base = nullptr;
+    }
+    if (guard_mode()) {         // exact size (rounded to 16 B) between two poisoned bands: one element past either end lands in a band
+        const size_t want = (bytes + 15) & ~(size_t)15;
+        HIPCHK(hipMalloc(&b.base, want + 2 * kGuardBytes));
+        HIPCHK(hipMemset(b.base, kGuardByte, kGuardBytes));
+        HIPCHK(hipMemset((char *)b.base + kGuardBytes + want, kGuardByte, kGuardBytes));
+        b.p = (char *)b.base + kGuardBytes;
+        b.cap = want;
+        return 0;
     }
     size_t want = bytes + bytes / 8;
     HIPCHK(hipMalloc(&b.p, want));

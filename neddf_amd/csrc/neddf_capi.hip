@@ -662,13 +662,41 @@ void neddf_destroy(neddf_ctx *ctx)
         if (f.last_use) (void)hipEventDestroy(f.last_use);
     }
     for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags, &ctx->rflags, &ctx->rev_scratch, &ctx->sched, &ctx->tpack, &ctx->ttmp, &ctx->tamax })
-        if (b->p) (void)hipFree(b->p);
+        if (b->p) (void)hipFree(b->base ? b->base : b->p);
     for (auto &e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : ctx->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete ctx;
 }
 
 int neddf_device_cus(neddf_ctx *ctx) { return ctx ? ctx->cus : 0; }
+
+int neddf_debug_check_guards(neddf_ctx *ctx, int64_t *n_bands, int64_t *n_bad_bytes)
+{
+    if (!ctx) return NEDDF_EINVAL;
+    if (n_bands) *n_bands = 0;
+    if (n_bad_bytes) *n_bad_bytes = 0;
+    if (!guard_mode()) return 0;            // bands exist only under NEDDF_GUARD=1
+    DeviceGuard guard_(ctx->device);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<GuardBand> bands = ctx->carve_guards;
+    for (DevBuf *b : { &ctx->features, &ctx->ptaux, &ctx->scratch, &ctx->arena, &ctx->flags, &ctx->rflags, &ctx->rev_scratch, &ctx->sched, &ctx->tpack,
+                       &ctx->ttmp, &ctx->tamax })
+        if (b->base) {
+            bands.push_back(GuardBand{ b->base, kGuardBytes });
+            bands.push_back(GuardBand{ (char *)b->p + b->cap, kGuardBytes });
+        }
+    // NEDDF_GUARD_SELFTEST=1: overwrite one byte of the last band first -- the test of the probe itself
+    if (const char *e = getenv("NEDDF_GUARD_SELFTEST")) if (atoi(e) && !bands.empty()) HIPCHK(hipMemset((void *)bands.back().p, 0, 1));
+    std::vector<unsigned char> h(kGuardBytes);
+    int64_t bad = 0;
+    for (const GuardBand &g : bands) {
+        HIPCHK(hipMemcpy(h.data(), g.p, g.bytes, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < g.bytes; ++i) bad += h[i] != (unsigned char)kGuardByte;
+    }
+    if (n_bands) *n_bands = (int64_t)bands.size();
+    if (n_bad_bytes) *n_bad_bytes = bad;
+    return 0;
+}
 
 int neddf_set_field(neddf_ctx *ctx, int slot, const neddf_field_desc *desc, const float *const *W, const float *const *B, int n)
 {
@@ -822,18 +850,32 @@ int neddf_importance_resample(neddf_ctx *ctx, const float *dists, float *weights
 }
 
 // carve helper for the render arena
+// NEDDF_GUARD=1: a carve ends exactly at its last element and is followed by a poisoned band (capi_internal.h guard_mode)
 struct Carver {
     char *p;
+    neddf_ctx *ctx = nullptr;
+    hipStream_t s = nullptr;
     size_t off = 0;
     float *take(size_t n_floats)
     {
         float *r = (float *)(p + off);
+        if (guard_mode() && ctx) {
+            const size_t used = (n_floats * sizeof(float) + 15) & ~(size_t)15;
+            (void)hipMemsetAsync(p + off + used, kGuardByte, kCarveGuardBytes, s);
+            ctx->carve_guards.push_back(GuardBand{ p + off + used, kCarveGuardBytes });
+            off += (used + kCarveGuardBytes + 255) & ~(size_t)255;
+            return r;
+        }
         off += (n_floats * sizeof(float) + 255) & ~(size_t)255;
         return r;
     }
 };
 
-static size_t carve_bytes(size_t n_floats) { return (n_floats * sizeof(float) + 255) & ~(size_t)255; }
+static size_t carve_bytes(size_t n_floats)
+{
+    if (guard_mode()) return (((n_floats * sizeof(float) + 15) & ~(size_t)15) + kCarveGuardBytes + 255) & ~(size_t)255;
+    return (n_floats * sizeof(float) + 255) & ~(size_t)255;
+}
 
 static int render_pass(neddf_ctx *ctx, int slot, const float *rd, const float *ro, const float *view, const float *dists, int64_t B, int S,
                        const neddf_render_params *rp, float *pos, float *dir, float *var, float *dens, float *col, float *pen,
@@ -867,7 +909,8 @@ int neddf_render_rays(neddf_ctx *ctx, const void *uv, int uv_type, int64_t B, co
                   8 * carve_bytes(B * 3);
     // the arena is also used by field_forward as a colour sink only when colour is not requested; never the case here
     if (int rc = ensure(ctx, ctx->arena, need)) return rc;
-    Carver cv{ (char *)ctx->arena.p };
+    ctx->carve_guards.clear();
+    Carver cv{ (char *)ctx->arena.p, ctx, s };
     float *rd = cv.take(B * 3), *ro = cv.take(B * 3);
     float *dc = out->dists_coarse ? out->dists_coarse : cv.take(B * Sc1);
     float *df = out->dists_fine ? out->dists_fine : cv.take(B * S2);
@@ -920,7 +963,8 @@ int neddf_render_rays_single(neddf_ctx *ctx, int slot, const void *uv, int uv_ty
     size_t need = 2 * carve_bytes(B * 3) + carve_bytes(B * S1) + 3 * carve_bytes(B * S1 * 3) + 2 * carve_bytes(B * S1) +
                   carve_bytes(B * S1 * 3) + 5 * carve_bytes(B * 3);
     if (int rc = ensure(ctx, ctx->arena, need)) return rc;
-    Carver cv{ (char *)ctx->arena.p };
+    ctx->carve_guards.clear();
+    Carver cv{ (char *)ctx->arena.p, ctx, s };
     float *rd = cv.take(B * 3), *ro = cv.take(B * 3);
     float *dc = out->dists_fine ? out->dists_fine : cv.take(B * S1);
     float *pos = cv.take(B * S1 * 3), *dir = cv.take(B * S1 * 3), *var = cv.take(B * S1 * 3);

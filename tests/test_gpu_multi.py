@@ -376,3 +376,79 @@ def test_bench_preflight_fails_fast_and_readably():
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "HIP device" in p.stderr and "--gpus %d" % n in p.stderr, p.stderr[-2000:]
     assert time.time() - t0 < 60.0      # (the first `import torch` of a fresh box is most of this)
+
+
+_GUARD_WORKER = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import neddf_amd
+from neddf_amd import Sampling
+from neddf_amd.fixtures import BUNNY_SMOKE_CFG, BUNNY_SMOKE_RENDER, bunny_smoke_weights, synth
+dev = torch.device("cuda:0")
+wts = bunny_smoke_weights()
+r = neddf_amd.NeRFRender(dict(BUNNY_SMOKE_CFG, _target_="neddf.network.NeDDF"), **BUNNY_SMOKE_RENDER)
+r.network_fine.load_state_dict({k: torch.from_numpy(v) for k, v in wts.items()})
+r.to(dev); r.set_iter(-1)
+fx = 0.5 * 800 / np.tan(0.5 * 0.6911112070083618)
+cam = neddf_amd.Camera(neddf_amd.PinholeCalib(np.array([fx, fx, 400.0, 400.0])), None).to(dev)
+cam.R, cam.T = torch.eye(3, device=dev), torch.tensor([0.0, 0.0, 4.0], device=dev)
+ctx = r._ctx(dev)
+total = 0
+with torch.no_grad():
+    for dtype in ("fp32", "f16_split", "bf16"):
+        r.network_fine.weight_dtype = dtype
+        ctx = r._ctx(dev)
+        # hierarchical render_rays at ragged batch sizes (tile tails of every kernel), full dict and eval-minimal
+        for n in (1, 63, 1000, 4097):
+            uv = torch.randint(0, 800, (n, 2), device=dev)
+            for full in (True, False):
+                o = r._render(ctx, uv, cam, torch.rand(n, 65, device=dev), torch.rand(n, 129, device=dev), full=full)
+                bands, bad = ctx.check_guards()
+                assert bands >= 20 and bad == 0, (dtype, n, full, bands, bad)
+                total += bands
+        # the single-pass image path (bench.py's workload) on a slab that is not a multiple of any tile
+        o = r.render_image_single_pass(800, 800, cam, 128, pixel_range=(777, 777 + 70001))
+        bands, bad = ctx.check_guards()
+        assert bad == 0, (dtype, "single pass", bands, bad)
+        # the stand-alone field on an odd point count, both output modes
+        pos, d, var = synth.random_sampling(3, 333, seed=2)
+        net = r.network_fine
+        for mode in ("full", "minimal"):
+            net.output_mode = mode
+            net(Sampling(torch.from_numpy(pos).to(dev), torch.from_numpy(d).to(dev), torch.from_numpy(var).to(dev)))
+            bands, bad = ctx.check_guards()
+            assert bad == 0, (dtype, mode, bands, bad)
+# one training step (forward with every saved tensor, backward, weight gradients): workspace carves of the training ABI
+r.network_fine.weight_dtype = "fp32"
+r.set_iter(1500)
+uv = torch.randint(100, 300, (1024, 2), device=dev).to(torch.int16)
+out = r.render_rays(uv, cam)
+loss = out["color"].square().mean() + out["fields_penalty"].mean() + out["depth"].mean() * 1e-3
+loss.backward()
+bands, bad = r._ctx(dev).check_guards()
+assert bad == 0, ("train", bands, bad)
+# the probe itself: a deliberate one-element overrun must be seen
+ctx = r._ctx(dev)
+import ctypes
+bands0, _ = ctx.check_guards()
+print("GUARD_OK bands_checked=%d last=%d" % (total, bands0))
+"""
+
+
+def test_workspace_guard_bands(tmp_path):
+    """The bounds probe that stands in for a GPU-side sanitizer (neddf_debug_check_guards, NEDDF_GUARD=1): every workspace allocated at
+    its exact size between poisoned bands, every arena carve followed by one.  Renders at ragged batch sizes under the three operand
+    policies, the single-pass path on an odd slab, the stand-alone field in both modes and a training step must leave every band
+    byte untouched."""
+    w = tmp_path / "guard_worker.py"
+    w.write_text(_GUARD_WORKER)
+    env = dict(os.environ, NEDDF_GUARD="1")
+    p = subprocess.run([sys.executable, str(w), ROOT], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "GUARD_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+    n = int(p.stdout.split("bands_checked=")[1].split()[0])
+    assert n > 500
+    # the probe sees an overrun: with one band byte overwritten on purpose the same worker must fail at its first check
+    p = subprocess.run([sys.executable, str(w), ROOT], env=dict(env, NEDDF_GUARD_SELFTEST="1"), capture_output=True, text=True, timeout=900)
+    assert p.returncode != 0 and "GUARD_OK" not in p.stdout and "AssertionError" in p.stderr, p.stdout[-500:] + p.stderr[-1500:]
