@@ -342,6 +342,7 @@ def measured_traffic(kernel_substr, dtype, masked):
         vals[counter] = sum(per) / len(per)
         vals[counter + "_dispatches"] = len(per)
     vals["hbm_bytes_per_launch"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    vals["points_per_dispatch"] = 65536.0 * 128 / (vals["FETCH_SIZE_dispatches"] / 1.0)     # tools/pmc_probe.py renders ONE 65 536-ray x 128-sample slab
     return vals
 
 
@@ -651,15 +652,23 @@ def main():
             masked = render.bench_network_config["activation_type"] != "tanhExp"      # ReLU / LeakyReLU: the mask-bit kernel
             ent = next(v for k, v in pmc.items() if want in k and ("OpsBF16" in k) == (args.dtype == "bf16")
                        and (want != "ddf_rev_kernel" or k.rstrip(">").endswith("true") == masked))
+            # the committed pass measured launches of ent["points_per_launch"] points; this run's launches may be larger (the per-point
+            # traffic of these kernels does not depend on the launch size: per-workgroup scratch, per-point hand-off)
+            per_launch = pts / max(tm["ddf_launches"], 1)
+            scale = per_launch / float(ent.get("points_per_launch", per_launch))
+            ent = dict(ent, hbm_bytes_per_launch=ent["hbm_bytes_per_launch"] * scale,
+                       algorithmic_bytes_per_launch=ent["algorithmic_bytes_per_launch"] * scale)
+            line["roofline"]["points_per_launch"] = per_launch
             line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
             line["roofline"]["traffic_source"] = ("static: %s (a committed rocprofv3 --pmc pass of this kernel and launch size, not measured in "
                                                   "this run; NEDDF_BENCH_PMC=1 measures it in the run)" % ent["source"])
             if os.environ.get("NEDDF_BENCH_PMC") == "1":
                 try:
                     m = measured_traffic(want, args.dtype, masked)
+                    m["hbm_bytes_per_launch"] *= per_launch / m["points_per_dispatch"]
                     line["roofline"]["traffic"] = m["hbm_bytes_per_launch"]
                     line["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, "
-                                                          "--kernel-trace only) over tools/pmc_probe.py, %d dispatches of 2^21 points; bytes = "
+                                                          "--kernel-trace only) over tools/pmc_probe.py, %d dispatch(es) of one 65 536-ray slab, scaled to this run's launch size; bytes = "
                                                           "(2 x FETCH_SIZE + WRITE_SIZE) x 1024" % m["FETCH_SIZE_dispatches"])
                     line["roofline"]["traffic_counters_kb"] = {"FETCH_SIZE": m["FETCH_SIZE"], "WRITE_SIZE": m["WRITE_SIZE"]}
                     line["roofline"]["traffic_static"] = ent["hbm_bytes_per_launch"]

@@ -533,7 +533,12 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     // is opt-in: NEDDF_FUSED=1 (tests/test_gpu_parity.py::test_fused_field_kernel_in_subprocess holds it to the same gates).
     static const bool fuse_enabled = [] { const char *e = getenv("NEDDF_FUSED"); return e && atoi(e) != 0; }();
     const bool fused = fuse_enabled && reverse && color && f.d.kind == NEDDF_FIELD_NEDDF && ddf_rev_can_fuse(dt, wid);
-    const int64_t chunk_cap = full ? (1 << 19) : (1 << 21);
+    // Points per launch of the field kernels.  Every launch boundary drains the persistent grid (workgroups finish up to one tile
+    // apart) and refills it: at 2^21 points a 65 536-ray x 128-sample call was four launch pairs, at 2^23 it is one -- fp32 +0.8 %,
+    // split fp16 +0.7 %, bf16 +2.8 % (profiles/r04_launch_size.txt).  The hand-off buffers grow with it (1 088 B per point
+    // eval-minimal: 9.1 GB at 2^23 of the 288 GB); NEDDF_FIELD_CHUNK_LOG2 overrides.
+    static const int chunk_log2 = [] { const char *e = getenv("NEDDF_FIELD_CHUNK_LOG2"); int v = e ? atoi(e) : 23; return v < 16 ? 16 : (v > 25 ? 25 : v); }();
+    const int64_t chunk_cap = full ? (1 << 19) : ((int64_t)1 << chunk_log2);
     const int64_t chunk = N < chunk_cap ? N : chunk_cap;
     // activations' element type and planes: fp32 1024 B, bf16 512 B, split bf16 (two planes) 1024 B per row
     if (!fused) {

@@ -8,6 +8,8 @@ inverse-CDF resampling -> field -> compositing) on the current HIP stream.
 import math
 from typing import Any, Dict, Iterable, List, Optional
 
+import os
+
 import torch
 from torch import Tensor, nn
 
@@ -63,7 +65,7 @@ class NeRFRender(BaseNeuralRender):
         self.dist_near, self.dist_far, self.max_dist = dist_near, dist_far, max_dist
         self.sampling_type = sampling_type
         self.rng = "torch_cpu"
-        self.rays_per_call = 1 << 16
+        self.rays_per_call = int(os.environ.get("NEDDF_RAYS_PER_CALL", 1 << 16))
         self.ray_space = ray_space          # the two keywords after sampling_type are not reference keywords
         self.ndc_width, self.ndc_height, self.ndc_near = 0, 0, ndc_near
 
