@@ -15,6 +15,7 @@ namespace {
 
 struct Plan {
     int E, Ed, Cpe, Cdir, Ca, ldxa, n_trunk, n_col, i_ddf, i_aux, i_cout;
+    int WH;                     // hidden width the kernels see: 256, or 512 (NeDDF, per-layer route in 256 x 256 blocks)
     int64_t N, R;
     // workspace offsets (floats)
     size_t o_pes, o_xa, o_pt, o_cr, o_z[kMaxLayers], o_h[kMaxLayers], o_zc[kMaxLayers], o_hc[kMaxLayers], total;
@@ -22,13 +23,18 @@ struct Plan {
 
 constexpr int kLdPe = 64, kLdDir = 32, kLdNarrow = 4;
 
-// The training kernels (train_kernels.hip) are built for the hidden width of every shipped configuration, 256.  Narrower networks
-// reach these entry points zero-padded to that width (neddf_amd/network.py _train_tensors: exact); wider ones (rendering takes up
-// to 512, neddf_set_field) are refused loudly rather than computed wrongly.
+// The training kernels (train_kernels.hip) are built for the hidden width of every shipped configuration, 256: tiles, fused layer
+// chains and weight-gradient products are 256 columns wide.  Narrower networks reach these entry points zero-padded to 256
+// (neddf_amd/network.py _train_tensors: exact).  Round 4: a NeDDF up to hidden width 512 (the reference trains whatever it
+// constructs, neddf.py:52-66) arrives padded to 512 and takes the PER-LAYER route with every product cut into 256 x 256 blocks
+// (K blocks accumulate in the output, the activation / its backward runs on the last one): the same kernels, correct at any
+// multiple of 256, without the fused chains' speed.  NeRF / NeuS and anything wider are refused loudly rather than computed wrongly.
 int train_supported(neddf_ctx *ctx, const Field &f)
 {
-    if (f.d.layer_width != kWidth || (f.d.kind != NEDDF_FIELD_NERF && f.d.col_layer_width != kWidth))
-        return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels are built for hidden width 256: pass narrower networks zero-padded to it (neddf_amd does), wider ones cannot train (rendering supports 1..512)");
+    const int wmax = f.d.kind == NEDDF_FIELD_NEDDF ? 2 * kWidth : kWidth;
+    if (f.d.layer_width % kWidth != 0 || f.d.layer_width < kWidth || f.d.layer_width > wmax ||
+        (f.d.kind != NEDDF_FIELD_NERF && f.d.col_layer_width != f.d.layer_width))
+        return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels take hidden widths 256 (every field kind) and 512 (NeDDF): pass narrower networks zero-padded (neddf_amd does); NeRF / NeuS above 256 and anything above 512 cannot train (rendering supports 1..512)");
     if (f.d.embed_dir_rank > 4) return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels take embed_dir_rank <= 4");
     return 0;
 }
@@ -45,14 +51,15 @@ int make_plan(neddf_ctx *ctx, int slot, int64_t N, int n_tensors, Plan &p)
     p.i_ddf = p.n_trunk + p.n_col; p.i_aux = p.i_ddf + 1; p.i_cout = p.i_ddf + 2;
     if (n_tensors >= 0 && n_tensors != p.n_trunk + p.n_col + 3) return fail(ctx, NEDDF_EINVAL, "NeDDF: wrong tensor count");
     p.N = N; p.R = 4 * N;
+    p.WH = f.d.layer_width;
     size_t o = 0;
     auto take = [&](size_t n) { size_t at = o; o += (n + 63) & ~(size_t)63; return at; };
     p.o_pes = take((size_t)p.R * kLdPe);
     p.o_xa = take((size_t)p.R * p.ldxa);
     p.o_pt = take((size_t)N * kTrainPt);
     p.o_cr = take((size_t)p.R * kLdNarrow);
-    for (int l = 0; l < p.n_trunk; ++l) { p.o_z[l] = take((size_t)p.R * kWidth); p.o_h[l] = take((size_t)p.R * kWidth); }
-    for (int l = 0; l < p.n_col; ++l) { p.o_zc[l] = take((size_t)p.R * kWidth); p.o_hc[l] = take((size_t)p.R * kWidth); }
+    for (int l = 0; l < p.n_trunk; ++l) { p.o_z[l] = take((size_t)p.R * p.WH); p.o_h[l] = take((size_t)p.R * p.WH); }
+    for (int l = 0; l < p.n_col; ++l) { p.o_zc[l] = take((size_t)p.R * p.WH); p.o_hc[l] = take((size_t)p.R * p.WH); }
     p.total = o;
     return 0;
 }
@@ -498,7 +505,7 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     // packed weights of a whole layer stack: [layer][256 x 256] + the narrow first-layer / skip segments
     if (int rc = ensure(ctx, ctx->tpack, (size_t)(kMaxLayers + 2) * kPackFloats * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ttmp, ((size_t)p.R * (kLdPe + kLdNarrow) + (size_t)N * kLdDir) * sizeof(float))) return rc;
-    float *wp = (float *)ctx->tpack.p, *wp2 = wp + kPackFloats;
+    float *wp = (float *)ctx->tpack.p;
     float *PEu = (float *)ctx->ttmp.p, *Ed = PEu + (size_t)p.R * kLdPe, *ZH = Ed + (size_t)N * kLdDir;
     float *PEs = ws + p.o_pes;
     TrainPointArgs a;
@@ -514,8 +521,32 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     for (int l = 1; l < p.n_trunk; ++l) n_wide += in_skips(f.d, l - 1) ? 1 : 0;
     // fp32 policy, both stacks fused: the hidden states are kept point-major (train_kernels.h MlpForwardArgs.point_major), the layout of
     // the fused backward (neddf_train_field_backward takes that route under the same condition)
-    const int pm = (!sp && !unfused && n_wide <= 1) ? 1 : 0;
-    if (!unfused && n_wide <= 1) {
+    const int WH = p.WH, NBK = WH / kWidth;      // hidden width the kernels see, in 256-column blocks
+    const bool fused = !unfused && n_wide <= 1 && WH == kWidth;       // (the fused chains are 256 wide)
+    const int pm = (!sp && fused) ? 1 : 0;
+    // Z[R, WH] (+)= X[R, Kin] x (rows k_off .. k_off + Kin of the [in, WH] weight) (+ bias on value rows); H = a(Z) when act_kind >= 0.
+    // Kin <= 256: one K block of `kload` loaded columns; otherwise Kin = WH in 256-row blocks.  Every block is one rows_gemm launch:
+    // K blocks accumulate in Z, the activation runs with the last one
+    auto gemm_fw = [&](const float *X, int ldx, int kload, int Kin, const float *Wsrc, int k_off, const float *bias, float *Z, int acc0,
+                       int act_kind, float *H) {
+        const int KB = Kin <= kWidth ? 1 : Kin / kWidth, kc = Kin <= kWidth ? Kin : kWidth, kl = Kin <= kWidth ? kload : kWidth;
+        for (int nb = 0; nb < NBK; ++nb)
+            for (int kb = 0; kb < KB; ++kb) {
+                const bool last = kb == KB - 1;
+                launch_pack(sp, Wsrc, WH, 1, k_off + kb * kWidth, nb * kWidth, kc, kWidth, kWidth, wp, s);
+                launch_rows_gemm(sp, X + kb * kWidth, p.R, ldx, kl, wp, gemm_ksteps(kc, sp), (kb == 0 && bias) ? bias + nb * kWidth : nullptr, 4,
+                                 Z + nb * kWidth, WH, (acc0 || kb > 0) ? 1 : 0, last ? act_kind : -1, (last && H) ? H + nb * kWidth : nullptr, ctx->cus, s);
+            }
+    };
+    // Y[R, kLdNarrow] = X[R, WH] . (nc narrow columns) + bias: one narrow_forward launch per 256-column block of X
+    auto narrow_fw = [&](const float *X, NarrowW w, float *Y, int x_pm) {
+        const float *w0[4] = { w.w[0], w.w[1], w.w[2], w.w[3] }, *b0[4] = { w.b[0], w.b[1], w.b[2], w.b[3] };
+        for (int kb = 0; kb < NBK; ++kb) {
+            for (int c = 0; c < w.nc; ++c) { w.w[c] = w0[c] + (size_t)kb * kWidth * w.wstride; w.b[c] = kb == 0 ? b0[c] : nullptr; }
+            launch_narrow_forward(X + kb * kWidth, WH, p.R, w, 4, Y, kLdNarrow, s, x_pm, kb > 0);
+        }
+    };
+    if (fused) {
         MlpForwardArgs m{};
         m.R = p.R; m.X0 = PEs; m.ld0 = kLdPe; m.kload0 = kpe; m.ksteps0 = gemm_ksteps(p.Cpe, sp);
         m.n_layers = p.n_trunk; m.skip_layer = -1; m.act_kind = act; m.point_major = pm;
@@ -540,17 +571,11 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
         for (int l = 0; l < p.n_trunk; ++l) {
             float *Z = ws + p.o_z[l], *H = ws + p.o_h[l];
             const bool wide = l > 0 && in_skips(f.d, l - 1);
-            if (l == 0) {
-                launch_pack(sp, W[0], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp, s);
-                launch_rows_gemm(sp, PEs, p.R, kLdPe, kpe, wp, gemm_ksteps(p.Cpe, sp), B[0], 4, Z, kWidth, 0, act, H, ctx->cus, s);
-            } else if (!wide) {
-                launch_pack(sp, W[l], kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
-                launch_rows_gemm(sp, ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 4, Z, kWidth, 0, act, H, ctx->cus, s);
-            } else {
-                launch_pack(sp, W[l], kWidth, 1, p.Cpe, 0, kWidth, kWidth, kWidth, wp, s);
-                launch_rows_gemm(sp, ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 4, Z, kWidth, 0, -1, nullptr, ctx->cus, s);
-                launch_pack(sp, W[l], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wp2, s);
-                launch_rows_gemm(sp, PEs, p.R, kLdPe, kpe, wp2, gemm_ksteps(p.Cpe, sp), nullptr, 4, Z, kWidth, 1, act, H, ctx->cus, s);
+            if (l == 0) gemm_fw(PEs, kLdPe, kpe, p.Cpe, W[0], 0, B[0], Z, 0, act, H);
+            else if (!wide) gemm_fw(ws + p.o_h[l - 1], WH, WH, WH, W[l], 0, B[l], Z, 0, act, H);
+            else {              // hx = cat([embed_pos_scaled, hx]): the encoding feeds rows 0 .. Cpe-1 of the weight
+                gemm_fw(ws + p.o_h[l - 1], WH, WH, WH, W[l], p.Cpe, B[l], Z, 0, -1, nullptr);
+                gemm_fw(PEs, kLdPe, kpe, p.Cpe, W[l], 0, nullptr, Z, 1, act, H);
             }
         }
     }
@@ -559,12 +584,12 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     heads.nc = 2; heads.wstride = 1; heads.kcount = kWidth;
     heads.w[0] = W[p.i_ddf]; heads.w[1] = W[p.i_aux];
     heads.b[0] = B[p.i_ddf]; heads.b[1] = B[p.i_aux];
-    launch_narrow_forward(Hlast, kWidth, p.R, heads, 4, ZH, kLdNarrow, s, pm);
+    narrow_fw(Hlast, heads, ZH, pm);
     a.ZH = ZH; a.PEu = PEu; a.Ed = Ed;
     a.distance = distance; a.density = density; a.aux_grad = aux_grad;
     launch_point_forward(a, s);
     // colour trunk (neddf.py:243-258)
-    if (!unfused) {
+    if (fused) {
         MlpForwardArgs m{};
         m.R = p.R; m.X0 = ws + p.o_xa; m.ld0 = p.ldxa; m.kload0 = p.ldxa; m.ksteps0 = gemm_ksteps(p.Ca, sp);
         m.X1 = Hlast; m.n_layers = p.n_col; m.skip_layer = -1; m.act_kind = act; m.point_major = pm;
@@ -585,21 +610,16 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
         for (int l = 0; l < p.n_col; ++l) {
             float *Z = ws + p.o_zc[l], *H = ws + p.o_hc[l];
             const float *Wl = W[p.n_trunk + l], *Bl = B[p.n_trunk + l];
-            if (l == 0) {
-                launch_pack(sp, Wl, kWidth, 1, 0, 0, p.Ca, kWidth, kWidth, wp, s);
-                launch_rows_gemm(sp, ws + p.o_xa, p.R, p.ldxa, p.ldxa, wp, gemm_ksteps(p.Ca, sp), Bl, 4, Z, kWidth, 0, -1, nullptr, ctx->cus, s);
-                launch_pack(sp, Wl, kWidth, 1, p.Ca, 0, kWidth, kWidth, kWidth, wp2, s);
-                launch_rows_gemm(sp, Hlast, p.R, kWidth, kWidth, wp2, gemm_ksteps(kWidth, sp), nullptr, 4, Z, kWidth, 1, act, H, ctx->cus, s);
-            } else {
-                launch_pack(sp, Wl, kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
-                launch_rows_gemm(sp, ws + p.o_hc[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), Bl, 4, Z, kWidth, 0, act, H, ctx->cus, s);
-            }
+            if (l == 0) {       // [embed_pos | embed_dir | normal | features] (neddf.py:243)
+                gemm_fw(ws + p.o_xa, p.ldxa, p.ldxa, p.Ca, Wl, 0, Bl, Z, 0, -1, nullptr);
+                gemm_fw(Hlast, WH, WH, WH, Wl, p.Ca, nullptr, Z, 1, act, H);
+            } else gemm_fw(ws + p.o_hc[l - 1], WH, WH, WH, Wl, 0, Bl, Z, 0, act, H);
         }
     }
     NarrowW cout{};
     cout.nc = 3; cout.wstride = 3; cout.kcount = kWidth;
     for (int c = 0; c < 3; ++c) { cout.w[c] = W[p.i_cout] + c; cout.b[c] = B[p.i_cout] + c; }
-    launch_narrow_forward(ws + p.o_hc[p.n_col - 1], kWidth, p.R, cout, 4, ws + p.o_cr, kLdNarrow, s, pm);
+    narrow_fw(ws + p.o_hc[p.n_col - 1], cout, ws + p.o_cr, pm);
     a.color = color; a.penalty = penalty;
     launch_penalty_forward(a, s);
     HIPCHK(hipGetLastError());
@@ -630,7 +650,8 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     static const bool unfused = [] { const char *e = getenv("NEDDF_TRAIN_UNFUSED"); return e && atoi(e) != 0; }();
     int n_wide = 0;
     for (int l = 1; l < p.n_trunk; ++l) n_wide += in_skips(f.d, l - 1) ? 1 : 0;
-    if (!sp && !unfused && n_wide <= 1) {      // (= the forward's condition for point-major hidden states)
+    const int WH = p.WH, NBK = WH / kWidth;
+    if (!sp && !unfused && n_wide <= 1 && WH == kWidth) {      // (= the forward's condition for point-major hidden states)
         const int nT = p.n_trunk, nC = p.n_col;
         const size_t slot = (size_t)p.R * kWidth;
         if (int rc = ensure(ctx, ctx->tpack, (size_t)(nT + nC + 1) * kPackFloats * sizeof(float))) return rc;
@@ -711,47 +732,81 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         return 0;
     }
     if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
-    if (int rc = ensure(ctx, ctx->ttmp, (size_t)p.R * (2 * kWidth + 2 * kLdNarrow) * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->ttmp, (size_t)p.R * (2 * WH + 2 * kLdNarrow) * sizeof(float))) return rc;
     float *wp = (float *)ctx->tpack.p;
-    float *dA = (float *)ctx->ttmp.p, *dB = dA + (size_t)p.R * kWidth, *GZH = dB + (size_t)p.R * kWidth, *GCR = GZH + (size_t)p.R * kLdNarrow;
+    float *dA = (float *)ctx->ttmp.p, *dB = dA + (size_t)p.R * WH, *GZH = dB + (size_t)p.R * WH, *GCR = GZH + (size_t)p.R * kLdNarrow;
     const float *PEs = ws + p.o_pes;
     TrainPointArgs a;
     point_args(a, f, p, ws);
     a.g_distance = g_distance; a.g_density = g_density; a.g_color = g_color; a.g_penalty = g_penalty; a.g_aux = g_aux_grad;
     a.GZH = GZH; a.GCR = GCR;
     launch_point_backward(a, s);
-    // Every activation backward is fused into the kernel that produces its upstream gradient: dA always holds dZ of the layer
-    // in flight, the input-gradient GEMM of layer l writes dZ of layer l-1 straight away (no dH round trip through HBM).
+    AmaxSlots am;
+    if (int rc = amax_begin(ctx, sp, am, s)) return rc;
+    // Every product of this route is cut into 256 x 256 blocks (NBK = 1 at hidden width 256, 2 at 512).  dA always holds dZ of the layer
+    // in flight ([R, WH]); every activation backward is fused into the kernel that produces its upstream gradient.
+    // dW[row_off + k, n] += X[R, Kin]^T dA (+ db): Kin <= 256 (an encoding segment) or Kin = WH
+    auto dw_blocks = [&](const float *X, int ldx, int Kin, float *gWl, int row_off, float *gBl, const float *mA) {
+        const int KB = Kin <= kWidth ? 1 : Kin / kWidth, kc = Kin <= kWidth ? Kin : kWidth;
+        for (int nb = 0; nb < NBK; ++nb)
+            for (int kb = 0; kb < KB; ++kb)
+                launch_dw(sp, X + kb * kWidth, ldx, kc, dA + nb * kWidth, WH, p.R, gWl + (size_t)(row_off + kb * kWidth) * WH + nb * kWidth, WH, 1, kWidth,
+                          (kb == 0 && gBl) ? gBl + nb * kWidth : nullptr, 4, ctx->cus, s, mA, am.dw_tmp);
+    };
+    // dB[R, WH] = [activation backward with Zprev of] dA x (rows row_off .. row_off + WH of the [in, WH] weight)^T: K blocks accumulate
+    // in dB, the activation backward runs with the last one
+    auto gemm_bw = [&](const float *Wsrc, int row_off, int act_kind, const float *Zprev, const float *mIn, float *mOut) {
+        for (int nb = 0; nb < NBK; ++nb)
+            for (int kb = 0; kb < NBK; ++kb) {
+                launch_pack(sp, Wsrc, 1, WH, kb * kWidth, row_off + nb * kWidth, kWidth, kWidth, kWidth, wp, s);        // W^T block
+                if (Zprev && kb == NBK - 1)
+                    launch_rows_gemm_actback(sp, dA + kb * kWidth, p.R, WH, kWidth, wp, gemm_ksteps(kWidth, sp), 4, act_kind, Zprev + nb * kWidth,
+                                             dB + nb * kWidth, WH, ctx->cus, s, mIn, mOut, kb > 0);
+                else
+                    launch_rows_gemm(sp, dA + kb * kWidth, p.R, WH, kWidth, wp, gemm_ksteps(kWidth, sp), nullptr, 4, dB + nb * kWidth, WH, kb > 0, -1, nullptr,
+                                     ctx->cus, s, mIn);
+            }
+    };
+    // dZ[R, WH] = activation backward with Zprev of ((accumulate ? dH : 0) + sum_c G[., c] w_c), and the narrow columns' weight gradients
+    auto narrow_bw_act = [&](const float *G, NarrowW w, const float *dH, int accumulate, const float *Zprev, float *dZ, float *mOut) {
+        const float *w0[4] = { w.w[0], w.w[1], w.w[2], w.w[3] };
+        for (int kb = 0; kb < NBK; ++kb) {
+            for (int c = 0; c < w.nc; ++c) w.w[c] = w0[c] + (size_t)kb * kWidth * w.wstride;
+            launch_narrow_backward_act(G, kLdNarrow, p.R, w, dH ? dH + kb * kWidth : nullptr, accumulate, act, 4, Zprev + kb * kWidth, dZ + kb * kWidth, WH, s, mOut);
+        }
+    };
+    auto narrow_dw = [&](const float *X, const float *G, int nc, float *const *w, int wstride, float *const *b) {
+        for (int kb = 0; kb < NBK; ++kb) {
+            float *wk[4] = { nullptr, nullptr, nullptr, nullptr };
+            for (int c = 0; c < nc; ++c) wk[c] = w[c] + (size_t)kb * kWidth * wstride;
+            launch_narrow_dw(X + kb * kWidth, WH, G, kLdNarrow, p.R, nc, wk, wstride, kb == 0 ? b : nullptr, 4, kWidth, s);
+        }
+    };
     // colour head: LinearGradFunction.backward (linear.py:62-88) on [HC | JC] rows
     NarrowW cout{};
     cout.nc = 3; cout.wstride = 3; cout.kcount = kWidth;
     for (int c = 0; c < 3; ++c) cout.w[c] = W[p.i_cout] + c;
     const float *HClast = ws + p.o_hc[p.n_col - 1];
-    AmaxSlots am;
-    if (int rc = amax_begin(ctx, sp, am, s)) return rc;
     float *mA = am.take();          // max |dA| of the gradient matrix currently in dA
-    launch_narrow_backward_act(GCR, kLdNarrow, p.R, cout, nullptr, 0, act, 4, ws + p.o_zc[p.n_col - 1], dA, kWidth, s, mA);
+    narrow_bw_act(GCR, cout, nullptr, 0, ws + p.o_zc[p.n_col - 1], dA, mA);
     {
         float *wc[3] = { gW[p.i_cout], gW[p.i_cout] + 1, gW[p.i_cout] + 2 }, *bc[3] = { gB[p.i_cout], gB[p.i_cout] + 1, gB[p.i_cout] + 2 };
-        launch_narrow_dw(HClast, kWidth, GCR, kLdNarrow, p.R, 3, wc, 3, bc, 4, kWidth, s);
+        narrow_dw(HClast, GCR, 3, wc, 3, bc);
     }
     const float *Hlast = ws + p.o_h[p.n_trunk - 1];
     for (int l = p.n_col - 1; l >= 0; --l) {
         const float *Wl = W[p.n_trunk + l];
         float *gWl = gW[p.n_trunk + l], *gBl = gB[p.n_trunk + l];
         if (l > 0) {
-            launch_dw(sp, ws + p.o_hc[l - 1], kWidth, kWidth, dA, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s, mA, am.dw_tmp);
-            launch_pack(sp, Wl, 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wp, s);                 // W^T
+            dw_blocks(ws + p.o_hc[l - 1], WH, WH, gWl, 0, gBl, mA);
             float *mB = am.take();
-            launch_rows_gemm_actback(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 4, act, ws + p.o_zc[l - 1], dB, kWidth, ctx->cus, s,
-                                     mA, mB);
+            gemm_bw(Wl, 0, act, ws + p.o_zc[l - 1], mA, mB);
             mA = mB;
         } else {
-            launch_dw(sp, ws + p.o_xa, p.ldxa, p.Ca, dA, kWidth, p.R, gWl, kWidth, 1, kWidth, gBl, 4, ctx->cus, s, mA, am.dw_tmp);
-            launch_dw(sp, Hlast, kWidth, kWidth, dA, kWidth, p.R, gWl + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s, mA, am.dw_tmp);
-            launch_pack(sp, Wl, 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wp, s);              // (feature rows of W)^T
+            dw_blocks(ws + p.o_xa, p.ldxa, p.Ca, gWl, 0, gBl, mA);
+            dw_blocks(Hlast, WH, WH, gWl, p.Ca, nullptr, mA);
             // the small colour inputs (encodings, detached normal) carry no parameters: only the feature segment propagates
-            launch_rows_gemm(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), nullptr, 4, dB, kWidth, 0, -1, nullptr, ctx->cus, s, mA);
+            gemm_bw(Wl, p.Ca, -1, nullptr, mA, nullptr);
         }
         float *t = dA; dA = dB; dB = t;
     }
@@ -760,27 +815,24 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     heads.nc = 2; heads.wstride = 1; heads.kcount = kWidth;
     heads.w[0] = W[p.i_ddf]; heads.w[1] = W[p.i_aux];
     mA = am.take();
-    launch_narrow_backward_act(GZH, kLdNarrow, p.R, heads, dA, 1, act, 4, ws + p.o_z[p.n_trunk - 1], dA, kWidth, s, mA);
+    narrow_bw_act(GZH, heads, dA, 1, ws + p.o_z[p.n_trunk - 1], dA, mA);
     {
         float *wh[2] = { gW[p.i_ddf], gW[p.i_aux] }, *bh[2] = { gB[p.i_ddf], gB[p.i_aux] };
-        launch_narrow_dw(Hlast, kWidth, GZH, kLdNarrow, p.R, 2, wh, 1, bh, 4, kWidth, s);
+        narrow_dw(Hlast, GZH, 2, wh, 1, bh);
     }
     // distance trunk
     for (int l = p.n_trunk - 1; l >= 0; --l) {
         const bool wide = l > 0 && in_skips(f.d, l - 1);
         if (l == 0) {
-            launch_dw(sp, PEs, kLdPe, p.Cpe, dA, kWidth, p.R, gW[0], kWidth, 1, kWidth, gB[0], 4, ctx->cus, s, mA, am.dw_tmp);
+            dw_blocks(PEs, kLdPe, p.Cpe, gW[0], 0, gB[0], mA);
             break;
         }
         if (wide) {
-            launch_dw(sp, PEs, kLdPe, p.Cpe, dA, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s, mA, am.dw_tmp);
-            launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l] + (size_t)p.Cpe * kWidth, kWidth, 1, kWidth, nullptr, 4, ctx->cus, s, mA, am.dw_tmp);
-        } else {
-            launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l], kWidth, 1, kWidth, gB[l], 4, ctx->cus, s, mA, am.dw_tmp);
-        }
-        launch_pack(sp, W[l], 1, kWidth, 0, wide ? p.Cpe : 0, kWidth, kWidth, kWidth, wp, s);
+            dw_blocks(PEs, kLdPe, p.Cpe, gW[l], 0, gB[l], mA);
+            dw_blocks(ws + p.o_h[l - 1], WH, WH, gW[l], p.Cpe, nullptr, mA);
+        } else dw_blocks(ws + p.o_h[l - 1], WH, WH, gW[l], 0, gB[l], mA);
         float *mB = am.take();
-        launch_rows_gemm_actback(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 4, act, ws + p.o_z[l - 1], dB, kWidth, ctx->cus, s, mA, mB);
+        gemm_bw(W[l], wide ? p.Cpe : 0, act, ws + p.o_z[l - 1], mA, mB);
         float *t = dA; dA = dB; dB = t;
         mA = mB;
     }

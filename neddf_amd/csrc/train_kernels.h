@@ -111,7 +111,7 @@ void launch_mlp_backward(const MlpBackwardArgs &a, int cus, hipStream_t s);
 // a layer fused with the backward of the previous layer's activation
 void launch_rows_gemm_actback(int split, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, int period, int act_kind,
                               const float *Zprev, float *dZ, int ldy, int cus, hipStream_t s, const float *amax_in = nullptr,
-                              float *amax_out = nullptr);
+                              float *amax_out = nullptr, int accumulate = 0);      // accumulate: dZ holds earlier K blocks' partial products
 // All weight-gradient products of a backward pass in one launch (fp32 MFMA policy): the workgroups are divided among the products in
 // proportion to their cost, each accumulates ITS product over its share of the rows and adds it to dW once.
 struct DwJob {
@@ -160,7 +160,7 @@ struct NarrowW {
     int kcount;               // input features present (<= 256; columns beyond are not read)
 };
 void launch_narrow_forward(const float *X, int ldx, int64_t R, const NarrowW &w, int bias_period, float *Y, int ldy, hipStream_t s,
-                           int x_point_major = 0);
+                           int x_point_major = 0, int accumulate = 0);       // accumulate: Y += (one more 256-column block of a wider input)
 // dX[R, ldx] (+)= sum_c G[r, c] * w_c[k]
 void launch_narrow_backward(const float *G, int ldg, int64_t R, const NarrowW &w, float *dX, int ldx, int accumulate, hipStream_t s);
 

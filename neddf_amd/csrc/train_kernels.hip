@@ -194,6 +194,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_gemm_kernel(const float *X, 
                     z[r] = *(const f32x4v *)(act + (4 * grp + r) * kActLd + 4 * c4);
                     const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
                     zp[r] = row + r < R ? *(const f32x4v *)(H + (row + r) * ldy + 4 * c4) : zero;
+                    // K-blocked products (hidden widths above 256): the earlier blocks' partial sums wait in Y
+                    if (accumulate && row + r < R) z[r] += *(const f32x4v *)(Y + (row + r) * ldy + 4 * c4);
                 }
                 act_backward_group(act_kind, bias_period, zp, z);
 #pragma unroll
@@ -257,7 +259,7 @@ static void launch_rows_gemm_ops(int mode, const float *X, int64_t R, int ldx, i
     if (mode == 1)
         hipLaunchKernelGGL((rows_gemm_kernel<1, Ops>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, act_kind, H, amax_in, amax_out);
     else if (mode == 2)
-        hipLaunchKernelGGL((rows_gemm_kernel<2, Ops>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, 0, act_kind, H, amax_in, amax_out);
+        hipLaunchKernelGGL((rows_gemm_kernel<2, Ops>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, act_kind, H, amax_in, amax_out);
     else
         hipLaunchKernelGGL((rows_gemm_kernel<0, Ops>), dim3(grid), dim3(kThreads), lds, s, X, R, ldx, kload, wp, ksteps, bias, period, Y, ldy, accumulate, -1, nullptr, amax_in, amax_out);
 }
@@ -279,9 +281,9 @@ void launch_rows_gemm(int split, const float *X, int64_t R, int ldx, int kload, 
 }
 
 void launch_rows_gemm_actback(int split, const float *X, int64_t R, int ldx, int kload, const float *wp, int ksteps, int period, int act_kind,
-                              const float *Zprev, float *dZ, int ldy, int cus, hipStream_t s, const float *amax_in, float *amax_out)
+                              const float *Zprev, float *dZ, int ldy, int cus, hipStream_t s, const float *amax_in, float *amax_out, int accumulate)
 {
-    launch_rows_gemm_mode(2, split, X, R, ldx, kload, wp, ksteps, nullptr, period, dZ, ldy, 0, act_kind, const_cast<float *>(Zprev), cus, s,
+    launch_rows_gemm_mode(2, split, X, R, ldx, kload, wp, ksteps, nullptr, period, dZ, ldy, accumulate, act_kind, const_cast<float *>(Zprev), cus, s,
                           amax_in, amax_out);
 }
 
@@ -1582,7 +1584,7 @@ void launch_pack(int split, const float *src, int64_t sk, int64_t sn, int k_off,
 
 // narrow heads (1..4 output columns from a 256-wide input): one wavefront per row
 template <bool PM>      // PM: X point-major (ld 256, R a multiple of 4): the wave's four rows are one point
-__global__ __launch_bounds__(256) void narrow_forward_kernel(const float *X, int ldx, int64_t R, NarrowW w, int bias_period, float *Y, int ldy)
+__global__ __launch_bounds__(256) void narrow_forward_kernel(const float *X, int ldx, int64_t R, NarrowW w, int bias_period, float *Y, int ldy, int accumulate)
 {
     const int lane = threadIdx.x & 63;
     float wv[4][4];                 // this lane's four input features of every output column
@@ -1616,18 +1618,23 @@ __global__ __launch_bounds__(256) void narrow_forward_kernel(const float *X, int
                 for (int q = 0; q < 4; ++q) s = fmaf(x[u][q], wv[c][q], s);
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-                if (lane == 0) Y[(base + u) * ldy + c] = s + ((w.b[c] && ((int)(base + u) & (bias_period - 1)) == 0) ? w.b[c][0] : 0.f);
+                if (lane == 0) {         // accumulate: the input is wider than 256 columns and this call adds one more 256-column block
+                    float *y = Y + (base + u) * ldy + c;
+                    const float v = s + ((w.b[c] && ((int)(base + u) & (bias_period - 1)) == 0) ? w.b[c][0] : 0.f);
+                    *y = accumulate ? *y + v : v;
+                }
             }
         }
     }
 }
-void launch_narrow_forward(const float *X, int ldx, int64_t R, const NarrowW &w, int bias_period, float *Y, int ldy, hipStream_t s, int x_point_major)
+void launch_narrow_forward(const float *X, int ldx, int64_t R, const NarrowW &w, int bias_period, float *Y, int ldy, hipStream_t s, int x_point_major,
+                           int accumulate)
 {
     if (R <= 0) return;
     int64_t wgs = (R + 15) / 16;
     if (wgs > 8192) wgs = 8192;
-    if (x_point_major) hipLaunchKernelGGL(narrow_forward_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, s, X, ldx, R, w, bias_period, Y, ldy);
-    else hipLaunchKernelGGL(narrow_forward_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, s, X, ldx, R, w, bias_period, Y, ldy);
+    if (x_point_major) hipLaunchKernelGGL(narrow_forward_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, s, X, ldx, R, w, bias_period, Y, ldy, accumulate);
+    else hipLaunchKernelGGL(narrow_forward_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, s, X, ldx, R, w, bias_period, Y, ldy, accumulate);
 }
 __global__ void narrow_backward_kernel(const float *G, int ldg, int64_t R, NarrowW w, float *dX, int ldx, int accumulate)
 {

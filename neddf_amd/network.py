@@ -137,13 +137,14 @@ class BaseNeuralField(ABC, nn.Module):
             val = self.forward(Sampling(pos, d, torch.zeros_like(pos)))     # one call: no need to chunk on 288 GB
             return val[field_name].reshape(cube_resolution, cube_resolution, cube_resolution).cpu().numpy()
 
-    # ---- training at hidden widths below 256 ------------------------------------------------------------------------
-    # The training kernels are built for hidden width 256.  A narrower network trains through them ZERO-PADDED: every
-    # parameter tensor is padded to the 256-wide architecture with differentiable torch ops (narrow / cat), the kernels see a
-    # 256-wide network, and autograd slices the parameter gradients back.  Exact: a padded unit has zero weights and bias, so
-    # it outputs a(0) = 0 under every activation of the reference, feeds zero weight rows downstream and receives a zero
-    # gradient; the real parameters' gradients are what the reference computes (tests/golden/train_widths.npz).  Widths above
-    # 256 are refused by the library (train_supported).
+    # ---- training at hidden widths other than 256 ---------------------------------------------------------------------
+    # The training kernels are built for hidden width 256 (every field kind) and, on their per-layer route in 256 x 256 blocks,
+    # 512 (NeDDF; csrc/train_capi.hip train_supported).  Any other width trains ZERO-PADDED to the next of the two: every parameter
+    # tensor is padded with differentiable torch ops (narrow / cat), the kernels see the padded network, and autograd slices the
+    # parameter gradients back.  Exact: a padded unit has zero weights and bias, so it outputs a(0) = 0 under every activation of
+    # the reference, feeds zero weight rows downstream and receives a zero gradient; the real parameters' gradients are what the
+    # reference computes (tests/golden/train_widths.npz: 128 / 192 / 384 / 512).  NeRF / NeuS above 256 and anything above 512 are
+    # refused by the library.
     def _train_layout(self):
         """None, or (weight layouts, bias layouts): per tensor, per axis, the [(length, padded_length)] segments."""
         return None
@@ -158,10 +159,14 @@ class BaseNeuralField(ABC, nn.Module):
         pw = [w if lay is None else _pad_axis(_pad_axis(w, 0, lay[0]), 1, lay[1]) if w.dim() == 2 else _pad_axis(w, 0, lay[0])
               for w, lay in zip(ws, wl)]
         pb = [b if lay is None else _pad_axis(b, 0, lay[0]) for b, lay in zip(bs, bl)]
-        desc.layer_width = TRAIN_ENGINE_WIDTH
+        desc.layer_width = self._train_engine_width()
         if desc.kind != FIELD_NERF:
-            desc.col_layer_width = TRAIN_ENGINE_WIDTH
+            desc.col_layer_width = desc.layer_width
         return desc, pw, pb
+
+    def _train_engine_width(self) -> int:
+        """Hidden width the training kernels see for this module (the padded one)."""
+        return TRAIN_ENGINE_WIDTH
 
     def upload(self, ctx: Context, slot: int, weights: bool = True, train=None) -> None:
         """Pack + upload the parameters into `slot` if they changed since the last upload.  weights=False (training
@@ -254,9 +259,12 @@ class NeDDF(BaseNeuralField):
     def _iter_state(self):
         return self.aux_grad_scale, self.distance_range_max, lowpass_scale(self.lowpass_alpha, self.pe_pos.embed_dim)
 
+    def _train_engine_width(self) -> int:
+        return TRAIN_ENGINE_WIDTH if self.ddf_layer_width <= TRAIN_ENGINE_WIDTH else 2 * TRAIN_ENGINE_WIDTH
+
     def _train_layout(self):
-        W, E = self.ddf_layer_width, TRAIN_ENGINE_WIDTH
-        if W >= E or self.col_layer_width != W:
+        W, E = self.ddf_layer_width, self._train_engine_width()
+        if W >= E or self.col_layer_width != W:       # E itself needs no padding; wider than 512: the library refuses
             return None
         cpe, small = 6 * self.pe_pos.embed_dim, 6 * (self.pe_pos.embed_dim + self.pe_dir.embed_dim) + 3
         hid, same = [(W, E)], lambda n: [(n, n)]

@@ -820,6 +820,43 @@ def gen_train_widths():
     save("train_widths.npz", **arrs)
 
 
+def gen_train_wide():
+    """Field-level backward goldens ABOVE hidden width 256 (the reference trains whatever it constructs, neddf.py:52-66): NeDDF 384
+    (tanhExp, one skip: trains zero-padded to 512) and NeDDF 512 (ReLU, two skips) under the reference's hand-written (value,
+    Jacobian) backward passes; random upstream gradients on every output, 33 sample points."""
+    arrs = {}
+    rng = np.random.default_rng(2027)
+    shape = (3, 11)
+    pos, dd, var = synth.random_sampling(shape[0], shape[1], seed=53, cone=True)
+    arrs.update(pos=pos, dir=dd, var=var)
+    for tag, kw in (("neddf384", dict(embed_pos_rank=6, embed_dir_rank=4, ddf_layer_count=5, ddf_layer_width=384, col_layer_count=3,
+                                      col_layer_width=384, d_near=0.01, activation_type="tanhExp", density_activation_type="ReLU", skips=[1],
+                                      lowpass_alpha_offset=10, penalty_weight={"constraints_aux_grad": 0.05, "constraints_dDdt": 0.5, "range_color": 0.1})),
+                    ("neddf512", dict(embed_pos_rank=8, embed_dir_rank=3, ddf_layer_count=6, ddf_layer_width=512, col_layer_count=4,
+                                      col_layer_width=512, d_near=0.01, activation_type="ReLU", density_activation_type="LeakyReLU", skips=[1, 3],
+                                      lowpass_alpha_offset=10))):
+        net = NeDDF(**kw)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.neddf_state(
+            kw["embed_pos_rank"], kw["embed_dir_rank"], kw["ddf_layer_count"], kw["ddf_layer_width"], kw["col_layer_count"],
+            kw["col_layer_width"], tuple(kw["skips"]), seed=37).items()})
+        net.set_iter(2500)
+        ups = {k: torch.from_numpy(rng.standard_normal(shape + ((3,) if k == "color" else ())).astype(np.float32))
+               for k in ("distance", "density", "color", "fields_penalty", "aux_grad")}
+        with torch.enable_grad():
+            net.zero_grad()
+            o = net(Sampling(torch.from_numpy(pos.copy()), torch.from_numpy(dd), torch.from_numpy(var)))
+            sum((o[k] * ups[k]).sum() for k in ups).backward()
+        pre = tag + "_"
+        arrs[pre + "config"] = np.array(json.dumps(kw))
+        for k in ups:
+            arrs[pre + "g_" + k] = npy(ups[k])
+            arrs[pre + "out_" + k] = npy(o[k])
+        # (full gradients only of the small tensors -- the wide ones are pinned by their norm and a random projection)
+        _grad_records(arrs, pre, net, 793, ("layers_ddf.0.weight", "layers_ddf.0.bias", "layers_ddf.2.bias", "layers_col.1.bias",
+                                           "layer_aux_out.weight", "layer_ddf_out.weight", "layer_col_out.weight", "layer_col_out.bias"))
+    save("train_wide.npz", **arrs)
+
+
 # --------------------------------------------------------------------------
 def gen_dataset():
     """the reference's own NeRFSyntheticDataset (nerf_synthetic_dataset.py:25-84, with cv2.imread backed
@@ -1005,6 +1042,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train_neus":
         gen_train_neus()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "train_wide":
+        from neddf.ray import Sampling  # noqa: F401
+        gen_train_wide()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "train_widths":
         gen_train_widths()
         sys.exit(0)
@@ -1040,5 +1081,6 @@ if __name__ == "__main__":
     gen_train_nerf()
     gen_train_neus()
     gen_train_widths()
+    gen_train_wide()
     gen_negbias()
     gen_fp64()          # last: switches torch's default dtype while it runs

@@ -784,8 +784,8 @@ def test_c2_single_pass_vs_oracle(dev, orc, bunny_weights):
 
 
 def test_width_and_rank_limits_fail_loudly(dev):
-    """The engine takes hidden widths 1..512 (zero-padded to a multiple of 128); beyond that -- and for training above width 256, the
-    width the training kernels are built for (narrower networks train zero-padded) -- the C ABI refuses with NEDDF_EUNSUPPORTED
+    """The engine takes hidden widths 1..512 (zero-padded to a multiple of 128); beyond that -- and for training NeRF / NeuS above width
+    256 (NeDDF trains up to 512 since round 4; narrower networks train zero-padded) -- the C ABI refuses with NEDDF_EUNSUPPORTED
     instead of computing something else.  A NeDDF whose two
     widths differ is refused like the reference's own forward would fail (neddf.py:145)."""
     import neddf_amd
@@ -806,12 +806,19 @@ def test_width_and_rank_limits_fail_loudly(dev):
         og = net(s)
         og["color"].sum().backward()
         assert all(p.grad is not None and tuple(p.grad.shape) == tuple(p.shape) for p in net.parameters())
-    wide = neddf_amd.NeDDF(ddf_layer_width=384, col_layer_width=384, **kw).to(dev)   # above 256: rendering yes, training refused loudly
-    wide.set_iter(-1)
+    wide = neddf_amd.NeDDF(ddf_layer_width=384, col_layer_width=384, **kw).to(dev)   # NeDDF above 256: renders AND trains (round 4: padded to 512,
+    wide.set_iter(-1)                                                                # per-layer route in 256 x 256 blocks; test_gpu_train.py pins it)
     assert bool(torch.isfinite(wide(s)["density"]).all())
     with torch.enable_grad():
+        wide(s)["color"].sum().backward()
+        assert all(p.grad is not None and tuple(p.grad.shape) == tuple(p.shape) for p in wide.parameters())
+    nerf = neddf_amd.NeRF(embed_pos_rank=4, embed_dir_rank=2, layer_count=4, layer_width=384, activation_type="ReLU", density_activation_type="ReLU",
+                          skips=[1]).to(dev)                                         # NeRF / NeuS above 256: rendering yes, training refused loudly
+    nerf.set_iter(-1)
+    assert bool(torch.isfinite(nerf(s)["density"]).all())
+    with torch.enable_grad():
         with pytest.raises(NeddfError):
-            wide(s)
+            nerf(s)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "f16_split"])
