@@ -21,7 +21,7 @@ struct Plan {
     size_t o_pes, o_xa, o_pt, o_cr, o_z[kMaxLayers], o_h[kMaxLayers], o_zc[kMaxLayers], o_hc[kMaxLayers], total;
 };
 
-constexpr int kLdPe = 64, kLdDir = 32, kLdNarrow = 4;
+constexpr int kLdPe = 64, kLdDir = 64, kLdNarrow = 4;      // row strides of the encoding matrices: 6 x rank columns each (rank <= 10)
 
 // The training kernels (train_kernels.hip) are built for the hidden width of every shipped configuration, 256: tiles, fused layer
 // chains and weight-gradient products are 256 columns wide.  Narrower networks reach these entry points zero-padded to 256
@@ -35,7 +35,7 @@ int train_supported(neddf_ctx *ctx, const Field &f)
     if (f.d.layer_width % kWidth != 0 || f.d.layer_width < kWidth || f.d.layer_width > wmax ||
         (f.d.kind != NEDDF_FIELD_NERF && f.d.col_layer_width != f.d.layer_width))
         return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels take hidden widths 256 (every field kind) and 512 (NeDDF): pass narrower networks zero-padded (neddf_amd does); NeRF / NeuS above 256 and anything above 512 cannot train (rendering supports 1..512)");
-    if (f.d.embed_dir_rank > 4) return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels take embed_dir_rank <= 4");
+    if (6 * f.d.embed_dir_rank > kLdDir) return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels take embed_dir_rank <= 10");
     return 0;
 }
 
