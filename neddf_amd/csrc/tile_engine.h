@@ -63,6 +63,7 @@ struct OpsF32T {
     static constexpr bool kPackedRows = false;
     static constexpr float kWScale = 1.0f;   // packed weights = kWScale * w
     static constexpr bool kStash16 = false;  // y' of the reverse-mode kernel travels in fp32
+    static constexpr bool kDeepPrefetch = false;
     static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
     static __device__ __forceinline__ void zero(act_t *p) { *p = 0.f; }
     static __device__ __forceinline__ void put4(act_t *p, const f32x4v &v) { *(f32x4v *)p = v; }     // 4 consecutive columns
@@ -98,6 +99,7 @@ struct OpsBF16T {
     static constexpr bool kLean = false;
     static constexpr float kWScale = 1.0f;
     static constexpr bool kStash16 = true;   // ... as bf16 here
+    static constexpr bool kDeepPrefetch = true;      // weight fragments two super-steps ahead (dense_pipeline3)
     static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
     static __device__ __forceinline__ void zero(act_t *p) { *p = 0; }
     static __device__ __forceinline__ unsigned short cvt(float v)       // round to nearest even (v_cvt_pk_bf16_f32)
@@ -168,6 +170,7 @@ struct OpsF16SplitT {
     static constexpr bool kPackedRows = false;
     static constexpr float kWScale = 1024.0f;            // weights are packed as 2^10 w
     static constexpr bool kStash16 = false;
+    static constexpr bool kDeepPrefetch = false;         // measured: the colour kernel spills with a third operand set (dense_pipeline3)
     static __device__ __forceinline__ float f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
     static __device__ __forceinline__ void put(act_t *p, float v)
     {
@@ -338,10 +341,51 @@ __device__ __forceinline__ void acc_init_pre(f32x16 (&acc)[MT][NT], const LayerP
             for (int q = 0; q < 16; ++q) acc[mt][t][q] = (ROWS4 && (q & 3)) ? 0.f : p.bias[t];
 }
 
+// bf16 policy (Ops::kDeepPrefetch): the weight fragments travel TWO super-steps ahead (ring of three B sets), the LDS fragments one.
+// A bf16 super-step is 4 MFMAs = 128 matrix cycles, a fraction of one L2 round trip (300-500 cycles under load): with one super-step
+// of distance a wave had 2 KB of weights in flight where latency x the CU's 64 B/clk asks for ~4 KB.  Measured in one call
+// (tools/r04_prefetch.sh): bf16 distance kernel 24.69 -> 23.96 ms per launch (C2 2.024 -> 2.072 M rays/s, C5 1.056 -> 1.080 M); split fp16
+// (384 matrix cycles per super-step) distance kernel 50.06 -> 49.88 ms but its colour kernel 13.40 -> 13.86 ms (the third set spills
+// there): not taken for that policy.
+template <int MT, int NT, class Ops>
+__device__ __forceinline__ void dense_pipeline3(f32x16 (&acc)[MT][NT], typename Ops::afrag (&a0)[MT], typename Ops::bfrag (&b0)[NT],
+                                                const typename Ops::act_t *act_lane, const WeightStream &wl, int ksteps)
+{
+    typename Ops::afrag a[2][MT];
+    typename Ops::bfrag b[3][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[0][mt] = a0[mt];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        b[0][t] = b0[t];
+        b[1][t] = stream_load<typename Ops::bfrag>(wl, (unsigned)(t * ksteps + (ksteps > 1 ? 1 : 0)));
+    }
+    const typename Ops::act_t *ap = act_lane;
+    for (int S = 0; S < ksteps; S += 6) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            if (S + u >= ksteps) break;                 // wave-uniform
+            const int s2 = S + u + 2 < ksteps ? S + u + 2 : ksteps - 1;     // (clamped: the index could leave the allocation)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[(u + 2) % 3][t] = stream_load<typename Ops::bfrag>(wl, (unsigned)(t * ksteps + s2));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[(u + 1) & 1][mt] = Ops::load_a(ap + (u + 1) * Ops::kStep + mt * 32 * Ops::kLd);
+            __builtin_amdgcn_sched_barrier(0);
+            dense_mfma<MT, NT, Ops>(acc, a[u & 1], b[u % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ap += 6 * Ops::kStep;
+    }
+}
+
 template <int MT, int NT, class Ops = OpsF32>
 __device__ __forceinline__ void dense_pipeline(f32x16 (&acc)[MT][NT], typename Ops::afrag (&a0)[MT], typename Ops::bfrag (&b0)[NT],
                                                const typename Ops::act_t *act_lane, const WeightStream &wl, int ksteps)
 {
+    if constexpr (Ops::kDeepPrefetch && !kFarTiles<MT, Ops>) {
+        dense_pipeline3<MT, NT, Ops>(acc, a0, b0, act_lane, wl, ksteps);
+        return;
+    }
     typename Ops::afrag a1[MT];
     typename Ops::bfrag b1[NT];
     // A fragments past the last super-step are fetched like the others and never used (the reads stay inside the workgroup's
