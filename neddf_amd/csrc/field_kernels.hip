@@ -355,6 +355,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
 // first-layer product (one accumulator set)
 size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points, int width) { return (size_t)n_layers * points * width + (size_t)points * 192 + (size_t)points * width; }
 
+constexpr int kRevSmallFloats = 3 * 512 + 16;      // head dots / lp / ctl / colour dots behind the tile (lds_bytes: small + 16; MT <= 8)
 template <int KIND, bool LAST, int MT, int NT, class Ops>
 __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *yp, const float *wseed, int wave,
                                                      int lane, int ymask)
@@ -454,6 +455,10 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
     float *pg = pv + ROWS * 64;                                  // [ROWS][64] the skip layers' share of the encoding gradient, parked
     float *cpark = pg + ROWS * 64;                               // [ROWS][WID] FUSED: the colour trunk's first-layer product with the features
     float *chd = lp + 16;                                        // FUSED: [THREADS][3] partial colour dots (behind lp / ctl)
+    // Ops::kEncInLds (bf16: the tile is half the bytes): the encoding also lives in a narrow LDS tile of its own for the whole tile, so a
+    // skip layer multiplies it from there -- no reload from the scratch, no extra barriers (14.1 k -> 6.5 k cycles for that layer)
+    act_t *enc_tile = (act_t *)(hd + kRevSmallFloats);
+    const act_t *enc_lane = act_lane_ptr<EncView<Ops>>(enc_tile, lane);
     static_assert(!FUSED || NW == 4, "the fused colour phases are laid out for four waves");
     if (tid == 0) {
 #pragma unroll
@@ -483,6 +488,9 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
         LayerPre<NT, Ops> pre;
         layer_prefetch<NT, Ops>(pre, a.layer[0].wp, a.layer[0].bias, a.layer[0].ksteps, wave, lane);
         zero_cols<Ops, THREADS>(act, ROWS, kin, tid);
+        if constexpr (Ops::kEncInLds) {
+            for (int i = tid; i < ROWS * 64; i += THREADS) Ops::zero(enc_tile + (i >> 6) * kEncLd + (i & 63));
+        }
         __syncthreads();
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
@@ -496,6 +504,10 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             else pe_pair<true, Ops::kFast>(e, a.pos[gp * 3 + d], a.var[gp * 3 + d], lp[e], vs, vc, js, jc);
             Ops::put(act + p * LD + q, vs);
             Ops::put(act + p * LD + KH + q, vc);
+            if constexpr (Ops::kEncInLds) {
+                Ops::put(enc_tile + p * kEncLd + q, vs);
+                Ops::put(enc_tile + p * kEncLd + KH + q, vc);
+            }
             pj[p * 64 + q] = js;
             pj[p * 64 + 32 + q] = jc;
             pv[p * 64 + q] = vs;               // same column order as the LDS tile: [sine half (KH) | cosine half (KH)]
@@ -511,7 +523,10 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             const LayerW &L = a.layer[l];
             acc_init_pre<MT, NT, false, Ops>(acc, pre);
             dense_pre<MT, NT, Ops>(acc, act_lane, (const frag *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane, L.ksteps, pre);
-            if (L.stash >= 0) {         // cat([encoding, h]) (neddf.py:217-219): the encoding comes back from the scratch into the tile's first columns
+            if (L.stash >= 0 && Ops::kEncInLds) {       // cat([encoding, h]) (neddf.py:217-219): the encoding's own LDS tile
+                const StashW &sw = a.stash[L.stash];
+                dense<MT, NT, EncView<Ops>>(acc, enc_lane + sw.col0, (const frag *)sw.wp + (size_t)wave * NT * sw.ksteps * 64 + lane, sw.ksteps);
+            } else if (L.stash >= 0) {  // ... or the encoding comes back from the scratch into the tile's first columns
                 const StashW &sw = a.stash[L.stash];
                 __syncthreads();                        // every wave finished reading the hidden state
                 for (int i = tid; i < ROWS * (kin / 4); i += THREADS) {
@@ -1430,26 +1445,29 @@ void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
 }
 
 // reverse-mode kernel: its tile shape per operand policy (see ddf_rev_kernel)
+template <class Ops>
+static size_t rev_lds_bytes(int mt) { return lds_bytes<Ops>(mt) + (Ops::kEncInLds ? (size_t)mt * 32 * kEncLd * sizeof(typename Ops::act_t) : 0); }
+
 template <int MT, int NW, int WPS, class Ops>
 static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *col = nullptr)
 {
     // tanhExp: y' round trip as values; ReLU / LeakyReLU: as mask bits (the kernel's header).  col: the colour trunk runs on the same tile (FUSED)
     if constexpr (NW == 4) {
         if (col) {
-            static bool oncef = (set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, false, true>, lds_bytes<Ops>(MT)),
-                                 set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, true, true>, lds_bytes<Ops>(MT)), true);
+            static bool oncef = (set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, false, true>, rev_lds_bytes<Ops>(MT)),
+                                 set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, true, true>, rev_lds_bytes<Ops>(MT)), true);
             (void)oncef;
-            if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, false, true>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a, *col);
-            else hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, true, true>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a, *col);
+            if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, false, true>), dim3(grid), dim3(64 * NW), rev_lds_bytes<Ops>(MT), s, a, *col);
+            else hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, true, true>), dim3(grid), dim3(64 * NW), rev_lds_bytes<Ops>(MT), s, a, *col);
             return;
         }
     }
-    static bool once = (set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, false>, lds_bytes<Ops>(MT)),
-                        set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, true>, lds_bytes<Ops>(MT)), true);
+    static bool once = (set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, false>, rev_lds_bytes<Ops>(MT)),
+                        set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, true>, rev_lds_bytes<Ops>(MT)), true);
     (void)once;
     const ColArgs none{};
-    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, false>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a, none);
-    else hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, true>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a, none);
+    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, false>), dim3(grid), dim3(64 * NW), rev_lds_bytes<Ops>(MT), s, a, none);
+    else hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, true>), dim3(grid), dim3(64 * NW), rev_lds_bytes<Ops>(MT), s, a, none);
 }
 
 // Tile shape of the reverse-mode kernel at width 256 per operand policy: (MT, NW, WPS) = (2, 4, 2) under fp32; the 16-bit policies

@@ -64,6 +64,7 @@ struct OpsF32T {
     static constexpr float kWScale = 1.0f;   // packed weights = kWScale * w
     static constexpr bool kStash16 = false;  // y' of the reverse-mode kernel travels in fp32
     static constexpr bool kDeepPrefetch = false;
+    static constexpr bool kEncInLds = false; // no LDS to spare next to two 67 KB tiles
     static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
     static __device__ __forceinline__ void zero(act_t *p) { *p = 0.f; }
     static __device__ __forceinline__ void put4(act_t *p, const f32x4v &v) { *(f32x4v *)p = v; }     // 4 consecutive columns
@@ -100,6 +101,7 @@ struct OpsBF16T {
     static constexpr float kWScale = 1.0f;
     static constexpr bool kStash16 = true;   // ... as bf16 here
     static constexpr bool kDeepPrefetch = true;      // weight fragments two super-steps ahead (dense_pipeline3)
+    static constexpr bool kEncInLds = true;          // the reverse-mode kernel keeps the encoding in a second LDS tile for its skip layers (a bf16 tile is 33 KB)
     static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
     static __device__ __forceinline__ void zero(act_t *p) { *p = 0; }
     static __device__ __forceinline__ unsigned short cvt(float v)       // round to nearest even (v_cvt_pk_bf16_f32)
@@ -171,6 +173,7 @@ struct OpsF16SplitT {
     static constexpr float kWScale = 1024.0f;            // weights are packed as 2^10 w
     static constexpr bool kStash16 = false;
     static constexpr bool kDeepPrefetch = false;         // measured: the colour kernel spills with a third operand set (dense_pipeline3)
+    static constexpr bool kEncInLds = false;
     static __device__ __forceinline__ float f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
     static __device__ __forceinline__ void put(act_t *p, float v)
     {
@@ -222,6 +225,14 @@ struct OpsF16SplitT {
     }
 };
 typedef OpsF16SplitT<256> OpsF16Split;
+
+// the same policy over a narrow side tile (the encoding kept in LDS for the skip layers): 64 columns + 8 of padding per row, i.e. a row
+// stride of 36 dwords -- 16 rows x 16-byte fragments tile the 64 banks exactly
+constexpr int kEncLd = 72;
+template <class Ops>
+struct EncView : Ops {
+    static constexpr int kLd = kEncLd;
+};
 
 // per-lane base of the A fragments of M-tile 0
 template <class Ops>
