@@ -207,7 +207,7 @@ int neddf_op_pe_weights(neddf_ctx *ctx, const float *d_var, int64_t N, int embed
 /* LinearGradFunction.forward (with_grad/linear.py:15-46) on the MFMA tile engine:
  * y = xW + b, G = JW.  h_W [Cin,Cout] / h_b [Cout] are HOST arrays (packed + uploaded
  * per call: this op is a test/compat entry point, the renderer keeps weights resident).
- * Supported: Cin <= 256, Cout in {128, 256}. */
+ * Any Cin, Cout (round 4): K blocks of 256 input columns accumulate in the outputs, N blocks of 256 / 128 output columns. */
 int neddf_op_linear_grad(neddf_ctx *ctx, const float *d_x, const float *d_J, const float *h_W, const float *h_b,
                          int64_t N, int Cin, int Cout, float *d_y, float *d_G, void *stream);
 

@@ -1254,10 +1254,13 @@ __global__ __launch_bounds__(kThreads, WPS) void nerf_kernel(const NerfArgs a)
 // LinearGradFunction.forward (linear.py:40-46) as a stand-alone op on the same tile
 // engine: y = xW + b, G = JW for N points; Cin <= 256 (zero-padded to 8), Cout = 128*NT.
 template <int NT>
-__global__ __launch_bounds__(kThreads, 1) void linear_grad_kernel(const float *x, const float *J, int64_t n_points, int cin,
-                                                                  int ksteps, const float *wp, const float *bias, float *y, float *G)
+__global__ __launch_bounds__(kThreads, 1) void linear_grad_kernel(const float *x, const float *J, int64_t n_points, int cin, int ldx,
+                                                                  int ksteps, const float *wp, const float *bias, float *y, float *G,
+                                                                  int ldo, int nvalid, int accumulate)
 {
-    constexpr int MT = 4, ROWS = MT * 32, P = MT * 8, COUT = NT * 128;
+    // one (K block, N block) of the layer: input columns [0, cin) of rows with stride ldx, output columns [0, nvalid) of rows with stride
+    // ldo (the caller offsets the pointers); accumulate adds to what an earlier K block left
+    constexpr int MT = 4, ROWS = MT * 32, P = MT * 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *act = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1270,7 +1273,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_grad_kernel(const float *x
         for (int i = tid; i < ROWS * cin; i += kThreads) {
             int r = i / cin, c = i - r * cin;
             int64_t gp = p0 + (r >> 2);
-            if (gp < n_points) act[r * kActLd + c] = (r & 3) == 0 ? x[gp * cin + c] : J[(gp * 3 + (r & 3) - 1) * cin + c];
+            if (gp < n_points) act[r * kActLd + c] = (r & 3) == 0 ? x[gp * ldx + c] : J[(gp * 3 + (r & 3) - 1) * ldx + c];
         }
         __syncthreads();
         f32x16 acc[MT][NT];
@@ -1285,25 +1288,29 @@ __global__ __launch_bounds__(kThreads, 1) void linear_grad_kernel(const float *x
                 for (int g = 0; g < 4; ++g) {
                     int64_t gp = p0 + mt * 8 + 2 * g + h;
                     int col = (wave * NT + t) * 32 + j;
-                    if (gp < n_points) {
-                        y[gp * COUT + col] = acc[mt][t][4 * g];
+                    if (gp < n_points && col < nvalid) {
+                        float *yo = y + gp * ldo + col;
+                        *yo = accumulate ? *yo + acc[mt][t][4 * g] : acc[mt][t][4 * g];
 #pragma unroll
-                        for (int r = 1; r < 4; ++r) G[(gp * 3 + r - 1) * COUT + col] = acc[mt][t][4 * g + r];
+                        for (int r = 1; r < 4; ++r) {
+                            float *go = G + (gp * 3 + r - 1) * ldo + col;
+                            *go = accumulate ? *go + acc[mt][t][4 * g + r] : acc[mt][t][4 * g + r];
+                        }
                     }
                 }
         __syncthreads();
     }
 }
 
-void launch_linear_grad(const float *x, const float *J, int64_t n, int cin, int cout, int ksteps, const float *wp,
-                        const float *bias, float *y, float *G, int grid, hipStream_t s)
+void launch_linear_grad(const float *x, const float *J, int64_t n, int cin, int ldx, int cout_block, int ksteps, const float *wp,
+                        const float *bias, float *y, float *G, int ldo, int nvalid, int accumulate, int grid, hipStream_t s)
 {
     size_t lds = field_lds_bytes(4);
     static bool once = ((void)hipFuncSetAttribute((const void *)linear_grad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)field_lds_bytes(4)),
                         (void)hipFuncSetAttribute((const void *)linear_grad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)field_lds_bytes(4)), true);
     (void)once;
-    if (cout == 256) hipLaunchKernelGGL((linear_grad_kernel<2>), dim3(grid), dim3(kThreads), lds, s, x, J, n, cin, ksteps, wp, bias, y, G);
-    else hipLaunchKernelGGL((linear_grad_kernel<1>), dim3(grid), dim3(kThreads), lds, s, x, J, n, cin, ksteps, wp, bias, y, G);
+    if (cout_block == 256) hipLaunchKernelGGL((linear_grad_kernel<2>), dim3(grid), dim3(kThreads), lds, s, x, J, n, cin, ldx, ksteps, wp, bias, y, G, ldo, nvalid, accumulate);
+    else hipLaunchKernelGGL((linear_grad_kernel<1>), dim3(grid), dim3(kThreads), lds, s, x, J, n, cin, ldx, ksteps, wp, bias, y, G, ldo, nvalid, accumulate);
 }
 
 // ----------------------------------------------------------------------------

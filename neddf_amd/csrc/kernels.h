@@ -164,8 +164,8 @@ void launch_integrate_penalty(const float *dists, const float *pen, int64_t n, i
 void launch_resample(const float *dists, float *weights, const float *U, int64_t n_rays, int n, int nf, int cat,
                      float *out, int64_t *ids, int *flag, int64_t group, int64_t offset, hipStream_t s);
 
-void launch_linear_grad(const float *x, const float *J, int64_t n, int cin, int cout, int ksteps, const float *wp,
-                        const float *bias, float *y, float *G, int grid, hipStream_t s);
+void launch_linear_grad(const float *x, const float *J, int64_t n, int cin, int ldx, int cout_block, int ksteps, const float *wp,
+                        const float *bias, float *y, float *G, int ldo, int nvalid, int accumulate, int grid, hipStream_t s);
 void launch_op_activation(int kind, const float *x, const float *J, int64_t N, int C, float *y, float *G, hipStream_t s);
 void launch_op_pe(const float *x, const float *J, const float *scale, int64_t N, int E, float *y, float *G, hipStream_t s);
 void launch_op_pe_weights(const float *var, int64_t N, int E, float *w, hipStream_t s);

@@ -1024,23 +1024,38 @@ int neddf_op_linear_grad(neddf_ctx *ctx, const float *x, const float *J, const f
                          int Cout, float *y, float *G, void *stream)
 {
     if (!ctx || !x || !J || !W || !y || !G) return NEDDF_EINVAL;
-    if (Cin < 1 || Cin > 256 || (Cout != 128 && Cout != 256)) return fail(ctx, NEDDF_EUNSUPPORTED, "op_linear_grad: Cin <= 256, Cout in {128, 256}");
+    if (Cin < 1 || Cout < 1 || Cin > 65536 || Cout > 65536) return fail(ctx, NEDDF_EINVAL, "op_linear_grad: bad Cin / Cout");
     if (N <= 0) return 0;
     DeviceGuard guard_(ctx->device);
-    std::vector<float> blob;
-    std::vector<int> km;
-    for (int k = 0; k < roundup(Cin, 8); ++k) km.push_back(k < Cin ? k : -1);
-    Src src{ W, Cin, Cout, false };
-    size_t o_w = pack_layer(blob, src, km, Cout, 0, nullptr);
-    std::vector<float> zeros(Cout, 0.f);
-    size_t o_b = put(blob, b ? b : zeros.data(), Cout);
-    if (int rc = ensure(ctx, ctx->features, blob.size() * sizeof(float))) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->features.p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));       // blob is a host temporary
-    const float *base = (const float *)ctx->features.p;
-    int64_t tiles = (N + 31) / 32;
-    launch_linear_grad(x, J, N, Cin, Cout, (int)km.size() / 8, base + o_w, base + o_b, y, G, (int)(tiles < ctx->cus ? tiles : ctx->cus),
-                       (hipStream_t)stream);
+    // any (Cin, Cout) (with_grad/linear.py:87-133 takes any): the product is cut into K blocks of <= 256 input columns (accumulated in
+    // the outputs) and N blocks of 256 / 128 output columns (a last partial block runs zero-padded and stores only its valid columns)
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t tiles = (N + 31) / 32;
+    const int grid = (int)(tiles < ctx->cus ? tiles : ctx->cus);
+    for (int n0 = 0; n0 < Cout; n0 += 256) {
+        const int nvalid = Cout - n0 < 256 ? Cout - n0 : 256, nblk = nvalid > 128 ? 256 : 128;
+        for (int k0 = 0; k0 < Cin; k0 += 256) {
+            const int kc = Cin - k0 < 256 ? Cin - k0 : 256;
+            std::vector<float> blob;
+            std::vector<int> km;
+            for (int k = 0; k < roundup(kc, 8); ++k) km.push_back(k < kc ? k0 + k : -1);
+            // the block's weights [kc, nblk]: columns n0 .. n0 + nvalid of W (row stride Cout), zero beyond
+            std::vector<float> wblk((size_t)Cin * nblk, 0.f);              // (W and b are HOST arrays, include/neddf_hip.h)
+            for (int k = k0; k < k0 + kc; ++k)
+                for (int n = 0; n < nvalid; ++n) wblk[(size_t)k * nblk + n] = W[(size_t)k * Cout + n0 + n];
+            Src src{ wblk.data(), Cin, nblk, false };
+            size_t o_w = pack_layer(blob, src, km, nblk, 0, nullptr);
+            std::vector<float> bv(nblk, 0.f);
+            if (b && k0 == 0) memcpy(bv.data(), b + n0, (size_t)nvalid * sizeof(float));
+            size_t o_b = put(blob, bv.data(), nblk);
+            if (int rc = ensure(ctx, ctx->features, blob.size() * sizeof(float))) return rc;
+            HIPCHK(hipStreamSynchronize(s));                  // the previous block's launch is done with the buffer; blob is a host temporary
+            HIPCHK(hipMemcpyAsync(ctx->features.p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+            const float *base = (const float *)ctx->features.p;
+            launch_linear_grad(x + k0, J + k0, N, kc, Cin, nblk, (int)km.size() / 8, base + o_w, base + o_b, y + n0, G + n0, Cout, nvalid, k0 > 0, grid, s);
+        }
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -532,6 +532,15 @@ def test_layer_ops(dev, orc):
     oy, oG = orc.linear_grad(xx, JJ, ww, bb)
     assert_close(N(y), oy, 1e-5, 1e-5, "linear 200->256 y")
     assert_close(N(G), oG, 1e-5, 1e-5, "linear 200->256 G")
+    # any (Cin, Cout) since round 4 (with_grad/linear.py:87-133 takes any): K blocks of 256 accumulate, N blocks of 256 / 128, ragged tails
+    for cin, cout in ((316, 256), (700, 387), (5, 3), (256, 1), (343, 640)):
+        xx = rng.standard_normal((53, cin)).astype(np.float32); JJ = rng.standard_normal((53, 3, cin)).astype(np.float32)
+        ww = (rng.standard_normal((cin, cout)) * 0.1).astype(np.float32); bb = rng.standard_normal(cout).astype(np.float32)
+        y, G = LinearGradFunction.apply(T(xx, dev), T(JJ, dev), T(ww, dev), T(bb, dev))
+        oy, oG = orc.linear_grad(xx, JJ, ww, bb)
+        assert y.shape == (53, cout) and G.shape == (53, 3, cout)
+        assert_close(N(y), oy, 2e-5, 2e-5, "linear %d->%d y" % (cin, cout))
+        assert_close(N(G), oG, 2e-5, 2e-5, "linear %d->%d G" % (cin, cout))
 
 
 def test_field_grid_views(dev, bunny_weights):
