@@ -102,7 +102,14 @@ constexpr bool kAblate = false;
 #endif
 // Phase time stamps (-DNEDDF_STAMP, `make stamp`): lane 0 of every wave of the first kStampBlocks workgroups records s_memtime at
 // the phase boundaries of its kStampTile-th tile; neddf_capi.hip dumps them after the launch, tools/stamp_timeline.py prints them.
-#ifdef NEDDF_STAMP
+#if defined(NEDDF_STAMP) && defined(NEDDF_STAMP_PAIRS)
+// pair mode (tools/stamp_pairs.py): four consecutive tiles of workgroups {0..3, 256..259} -- with 512 workgroups on 256 CUs, b and b + 256
+// are the candidates for sharing a CU (slot 0 carries HW_ID | XCC_ID << 32 to check) -- to see how the two workgroups' phases line up
+#define NEDDF_STAMP_DECL int sidx_ = 1, stile_ = 0; unsigned long long *sbuf_ = (a.stamps && blockIdx.x < 512 && (blockIdx.x & 255) < 4 && lane == 0) ? a.stamps + ((size_t)((blockIdx.x & 255) + 4 * (blockIdx.x >> 8)) * 8 + wave) * (kStampSlots * kStampPairTiles) : nullptr; \
+    if (sbuf_) sbuf_[0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32)
+#define NEDDF_STAMP_TILE() do { ++stile_; } while (0)
+#define STAMP() do { if (sbuf_ && stile_ >= kStampTile && stile_ < kStampTile + kStampPairTiles && sidx_ < kStampSlots * kStampPairTiles) sbuf_[sidx_++] = __builtin_readcyclecounter(); } while (0)
+#elif defined(NEDDF_STAMP)
 #define NEDDF_STAMP_DECL int sidx_ = 0, stile_ = 0; unsigned long long *sbuf_ = (a.stamps && blockIdx.x < kStampBlocks && lane == 0) ? a.stamps + ((size_t)blockIdx.x * 8 + wave) * kStampSlots : nullptr
 #define NEDDF_STAMP_TILE() do { sidx_ = 0; ++stile_; } while (0)
 #define STAMP() do { if (sbuf_ && stile_ == kStampTile && sidx_ < kStampSlots) sbuf_[sidx_++] = __builtin_readcyclecounter(); } while (0)

@@ -80,6 +80,7 @@ struct DdfArgs {
     unsigned long long *stamps = nullptr; // -DNEDDF_STAMP builds only (`make stamp`, tools/stamp_timeline.py): phase time stamps of a few workgroups
 };
 constexpr int kStampBlocks = 8, kStampSlots = 160, kStampTile = 6;      // workgroups stamped, stamps per wave, which tile of the workgroup
+constexpr int kStampPairTiles = 4;     // NEDDF_STAMP_PAIRS builds: tiles kStampTile .. + 3 of workgroups {0..3, 256..259} (a CU's two workgroups), slot 0 = HW_ID
 
 // Colour trunk of NeDDF (neddf.py:243-300).
 struct ColArgs {

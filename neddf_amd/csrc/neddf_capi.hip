@@ -572,7 +572,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
             a.rev_scratch = (float *)ctx->rev_scratch.p;
 #ifdef NEDDF_STAMP
             static unsigned long long *d_stamps = nullptr;
-            const size_t stamp_bytes = (size_t)kStampBlocks * 8 * kStampSlots * sizeof(unsigned long long);
+            const size_t stamp_bytes = (size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles * sizeof(unsigned long long);
             if (!d_stamps) HIPCHK(hipMalloc((void **)&d_stamps, stamp_bytes));
             HIPCHK(hipMemsetAsync(d_stamps, 0, stamp_bytes, s));
             a.stamps = d_stamps;
@@ -588,7 +588,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
 #ifdef NEDDF_STAMP
             if (const char *path = getenv("NEDDF_STAMP_FILE")) {        // the LAST launch's stamps (a diagnostic build: synchronising here is fine)
                 HIPCHK(hipStreamSynchronize(s));
-                std::vector<unsigned long long> h((size_t)kStampBlocks * 8 * kStampSlots);
+                std::vector<unsigned long long> h((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles);
                 HIPCHK(hipMemcpy(h.data(), d_stamps, stamp_bytes, hipMemcpyDeviceToHost));
                 if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), 1, stamp_bytes, fp); fclose(fp); }
             }

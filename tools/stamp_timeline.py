@@ -14,7 +14,7 @@ import numpy as np
 BLOCKS, WAVES, SLOTS = 8, 8, 160
 path = sys.argv[1]
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-raw = np.fromfile(path, dtype=np.uint64).reshape(BLOCKS, WAVES, SLOTS)[:, :4].astype(np.int64)
+raw = np.fromfile(path, dtype=np.uint64).reshape(BLOCKS, WAVES, -1)[:, :4, :SLOTS].astype(np.int64)      # (the buffer holds 4 x SLOTS per wave for the pair mode)
 names = ["encode", "bar"]
 for l in range(L):
     names += ["F%d product" % l, "F%d bar" % l, "F%d epilogue" % l, "F%d bar" % l]
