@@ -14,8 +14,6 @@ PY
 run bf16_2x2x4 "X=1" "--dtype bf16"
 run bf16_2x2x8 "NEDDF_REV_GEO_BF16=2x2x8" "--dtype bf16"
 run bf16_2x3x4 "NEDDF_REV_GEO_BF16=2x3x4" "--dtype bf16"
-run bf16_2x3x8 "NEDDF_REV_GEO_BF16=2x3x8" "--dtype bf16"
-run bf16_2x4x8 "NEDDF_REV_GEO_BF16=2x4x8" "--dtype bf16"
+run bf16_4x2x4 "NEDDF_REV_GEO_BF16=4x2x4" "--dtype bf16"
 run split_2x2x4 "X=1" "--dtype f16_split"
 run split_2x2x8 "NEDDF_REV_GEO_SPLIT=2x2x8" "--dtype f16_split"
-run split_2x3x8 "NEDDF_REV_GEO_SPLIT=2x3x8" "--dtype f16_split"
