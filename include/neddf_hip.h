@@ -58,9 +58,9 @@ typedef struct {
     int embed_pos_rank;       /* <= 10 */
     int embed_dir_rank;       /* <= 4  */
     int layer_count;          /* NeDDF: ddf_layer_count, NeRF: layer_count */
-    int layer_width;          /* must be 256 */
+    int layer_width;          /* rendering: 1..512; training: 256, or 512 for NeDDF / NeRF (narrower ones zero-padded by the caller) */
     int col_layer_count;      /* NeDDF only */
-    int col_layer_width;      /* NeDDF only, must be 256 */
+    int col_layer_width;      /* NeDDF (== layer_width) and NeuS */
     int n_skips;
     int skips[8];
     int activation;           /* NEDDF_ACT_* */

@@ -25,16 +25,16 @@ constexpr int kLdPe = 64, kLdDir = 64, kLdNarrow = 4;      // row strides of the
 
 // The training kernels (train_kernels.hip) are built for the hidden width of every shipped configuration, 256: tiles, fused layer
 // chains and weight-gradient products are 256 columns wide.  Narrower networks reach these entry points zero-padded to 256
-// (neddf_amd/network.py _train_tensors: exact).  Round 4: a NeDDF up to hidden width 512 (the reference trains whatever it
-// constructs, neddf.py:52-66) arrives padded to 512 and takes the PER-LAYER route with every product cut into 256 x 256 blocks
+// (neddf_amd/network.py _train_tensors: exact).  Round 4: a NeDDF or NeRF up to hidden width 512 (the reference trains whatever it
+// constructs, neddf.py:52-66, nerf.py:34-44) arrives padded to 512 and takes the PER-LAYER route with every product cut into 256 x 256 blocks
 // (K blocks accumulate in the output, the activation / its backward runs on the last one): the same kernels, correct at any
-// multiple of 256, without the fused chains' speed.  NeRF / NeuS and anything wider are refused loudly rather than computed wrongly.
+// multiple of 256, without the fused chains' speed.  NeuS above 256 and anything wider are refused loudly rather than computed wrongly.
 int train_supported(neddf_ctx *ctx, const Field &f)
 {
-    const int wmax = f.d.kind == NEDDF_FIELD_NEDDF ? 2 * kWidth : kWidth;
+    const int wmax = f.d.kind == NEDDF_FIELD_NEUS ? kWidth : 2 * kWidth;
     if (f.d.layer_width % kWidth != 0 || f.d.layer_width < kWidth || f.d.layer_width > wmax ||
         (f.d.kind != NEDDF_FIELD_NERF && f.d.col_layer_width != f.d.layer_width))
-        return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels take hidden widths 256 (every field kind) and 512 (NeDDF): pass narrower networks zero-padded (neddf_amd does); NeRF / NeuS above 256 and anything above 512 cannot train (rendering supports 1..512)");
+        return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels take hidden widths 256 (every field kind) and 512 (NeDDF, NeRF): pass other widths zero-padded (neddf_amd does); NeuS above 256 and anything above 512 cannot train (rendering supports 1..512)");
     if (6 * f.d.embed_dir_rank > kLdDir) return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels take embed_dir_rank <= 10");
     return 0;
 }
@@ -103,6 +103,7 @@ int amax_begin(neddf_ctx *ctx, int split, AmaxSlots &m, hipStream_t s)
 // ---- plain NeRF field (nerf.py:107-165): value rows only, nn.Linear weights [out, in] -------------------------------
 struct NerfPlan {
     int E, Ed, Cpe, Cdir, n, i_dens, i_c0, i_c1, in_c0;
+    int WH, HC;                 // hidden width the kernels see (256 or 512) and the colour head's hidden width WH / 2 (one 256-column block)
     int64_t N;
     size_t o_pe, o_ed, o_zd, o_zc, o_hc, o_z[kMaxLayers], o_h[kMaxLayers], total;
 };
@@ -113,7 +114,8 @@ int make_nerf_plan(neddf_ctx *ctx, int slot, int64_t N, int n_tensors, NerfPlan 
     if (int rc = train_supported(ctx, f)) return rc;
     p.E = f.d.embed_pos_rank; p.Ed = f.d.embed_dir_rank;
     p.Cpe = 6 * p.E; p.Cdir = 6 * p.Ed; p.n = f.d.layer_count;
-    p.i_dens = p.n; p.i_c0 = p.n + 1; p.i_c1 = p.n + 2; p.in_c0 = kWidth + p.Cdir;
+    p.WH = f.d.layer_width; p.HC = p.WH / 2;
+    p.i_dens = p.n; p.i_c0 = p.n + 1; p.i_c1 = p.n + 2; p.in_c0 = p.WH + p.Cdir;
     if (n_tensors >= 0 && n_tensors != p.n + 3) return fail(ctx, NEDDF_EINVAL, "NeRF: wrong tensor count");
     p.N = N;
     size_t o = 0;
@@ -123,61 +125,72 @@ int make_nerf_plan(neddf_ctx *ctx, int slot, int64_t N, int n_tensors, NerfPlan 
     p.o_zd = take((size_t)N * kLdNarrow);
     p.o_zc = take((size_t)N * kWidth);
     p.o_hc = take((size_t)N * kWidth);
-    for (int l = 0; l < p.n; ++l) { p.o_z[l] = take((size_t)N * kWidth); p.o_h[l] = take((size_t)N * kWidth); }
+    for (int l = 0; l < p.n; ++l) { p.o_z[l] = take((size_t)N * p.WH); p.o_h[l] = take((size_t)N * p.WH); }
     p.total = o;
     return 0;
 }
 
+// Every product of the NeRF route is cut into 256 x 256 blocks like the NeDDF per-layer route (one block each at hidden width 256,
+// K blocks accumulating in the output and the activation with the last one at 512); nn.Linear weights [out, in] are read through strides.
 int nerf_forward(neddf_ctx *ctx, int slot, const float *const *W, const float *const *B, int n_tensors, const float *pos, const float *dir,
                  const float *var, int64_t N, float *ws, float *density, float *color, hipStream_t s)
 {
     NerfPlan p;
     if (int rc = make_nerf_plan(ctx, slot, N, n_tensors, p)) return rc;
     const Field &f = ctx->field[slot];
-    const int act = f.d.activation, cus = ctx->cus;
+    const int act = f.d.activation, cus = ctx->cus, WH = p.WH, NBK = WH / kWidth, HC = p.HC;
     const int sp = f.d.weight_dtype == NEDDF_DTYPE_F16_SPLIT;
     if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ttmp, ((size_t)N * kLdNarrow + kWidth) * sizeof(float))) return rc;
-    float *wp = (float *)ctx->tpack.p, *wp2 = wp + kPackFloats;
+    float *wp = (float *)ctx->tpack.p;
     float *CR = (float *)ctx->ttmp.p, *bias_c0 = CR + (size_t)N * kLdNarrow;
     float *PE = ws + p.o_pe, *Ed = ws + p.o_ed;
     EncodeDesc enc;
     fill_enc(enc, f);
     launch_pe_values(pos, dir, var, N, enc, PE, kLdPe, Ed, kLdDir, s);
     const int kpe = (p.Cpe + 3) & ~3, kdir = (p.Cdir + 3) & ~3;
+    // Z[N, ldz] (+)= X[N, Kin] x (input columns k_off .. of the [nrows_out, in_total] weight)^T for output rows 0 .. nout_valid (padded to a
+    // multiple of 256): Kin <= 256 is one K block of `kload` loaded columns, otherwise Kin = WH
+    auto gemm_fw = [&](const float *X, int ldx, int kload, int Kin, const float *Wsrc, int in_total, int k_off, int nout_valid, const float *bias,
+                       float *Z, int ldz, int acc0, int act_kind, float *H) {
+        const int KB = Kin <= kWidth ? 1 : Kin / kWidth, kc = Kin <= kWidth ? Kin : kWidth, kl = Kin <= kWidth ? kload : kWidth;
+        const int NB = (nout_valid + kWidth - 1) / kWidth;
+        for (int nb = 0; nb < NB; ++nb)
+            for (int kb = 0; kb < KB; ++kb) {
+                const bool last = kb == KB - 1;
+                const int nv = nout_valid - nb * kWidth < kWidth ? nout_valid - nb * kWidth : kWidth;
+                launch_pack(sp, Wsrc, 1, in_total, k_off + kb * kWidth, nb * kWidth, kc, nv, kWidth, wp, s);
+                launch_rows_gemm(sp, X + kb * kWidth, N, ldx, kl, wp, gemm_ksteps(kc, sp), (kb == 0 && bias) ? bias + nb * kWidth : nullptr, 1,
+                                 Z + nb * kWidth, ldz, (acc0 || kb > 0) ? 1 : 0, last ? act_kind : -1, (last && H) ? H + nb * kWidth : nullptr, cus, s);
+            }
+    };
     for (int l = 0; l < p.n; ++l) {             // nerf.py:151-155
         float *Z = ws + p.o_z[l], *H = ws + p.o_h[l];
         const bool wide = l > 0 && in_skips(f.d, l - 1);
-        const int in_total = l == 0 ? p.Cpe : (wide ? kWidth + p.Cpe : kWidth);
-        if (l == 0) {
-            launch_pack(sp, W[0], 1, in_total, 0, 0, p.Cpe, kWidth, kWidth, wp, s);
-            launch_rows_gemm(sp, PE, N, kLdPe, kpe, wp, gemm_ksteps(p.Cpe, sp), B[0], 1, Z, kWidth, 0, act, H, cus, s);
-        } else if (!wide) {
-            launch_pack(sp, W[l], 1, in_total, 0, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(sp, ws + p.o_h[l - 1], N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 1, Z, kWidth, 0, act, H, cus, s);
-        } else {        // cat([hx, embed_pos]): the hidden state feeds input columns 0..255, the encoding 256..
-            launch_pack(sp, W[l], 1, in_total, 0, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(sp, ws + p.o_h[l - 1], N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 1, Z, kWidth, 0, -1, nullptr, cus, s);
-            launch_pack(sp, W[l], 1, in_total, kWidth, 0, p.Cpe, kWidth, kWidth, wp2, s);
-            launch_rows_gemm(sp, PE, N, kLdPe, kpe, wp2, gemm_ksteps(p.Cpe, sp), nullptr, 1, Z, kWidth, 1, act, H, cus, s);
+        const int in_total = l == 0 ? p.Cpe : (wide ? WH + p.Cpe : WH);
+        if (l == 0) gemm_fw(PE, kLdPe, kpe, p.Cpe, W[0], in_total, 0, WH, B[0], Z, WH, 0, act, H);
+        else if (!wide) gemm_fw(ws + p.o_h[l - 1], WH, WH, WH, W[l], in_total, 0, WH, B[l], Z, WH, 0, act, H);
+        else {          // cat([hx, embed_pos]): the hidden state feeds input columns 0 .. WH-1, the encoding WH ..
+            gemm_fw(ws + p.o_h[l - 1], WH, WH, WH, W[l], in_total, 0, WH, B[l], Z, WH, 0, -1, nullptr);
+            gemm_fw(PE, kLdPe, kpe, p.Cpe, W[l], in_total, WH, WH, nullptr, Z, WH, 1, act, H);
         }
     }
     const float *Hlast = ws + p.o_h[p.n - 1];
-    NarrowW dens{};
-    dens.nc = 1; dens.wstride = 1; dens.kcount = kWidth;
-    dens.w[0] = W[p.i_dens]; dens.b[0] = B[p.i_dens];
-    launch_narrow_forward(Hlast, kWidth, N, dens, 1, ws + p.o_zd, kLdNarrow, s);
+    for (int kb = 0; kb < NBK; ++kb) {
+        NarrowW dens{};
+        dens.nc = 1; dens.wstride = 1; dens.kcount = kWidth;
+        dens.w[0] = W[p.i_dens] + kb * kWidth; dens.b[0] = kb == 0 ? B[p.i_dens] : nullptr;
+        launch_narrow_forward(Hlast + kb * kWidth, WH, N, dens, 1, ws + p.o_zd, kLdNarrow, s, 0, kb > 0);
+    }
     if (density) launch_density_head(f.d.density_activation, ws + p.o_zd, kLdNarrow, N, nullptr, density, 1, s);
-    // colour head: Linear(256 + dir, 128) -> ReLU -> Linear(128, 3); the 128 outputs are computed as 256 with zero weights
+    // colour head: Linear(WH + dir, WH / 2) -> ReLU -> Linear(WH / 2, 3); the WH / 2 outputs are one 256-column block (zero weights beyond them)
     HIPCHK(hipMemsetAsync(bias_c0, 0, kWidth * sizeof(float), s));
-    HIPCHK(hipMemcpyAsync(bias_c0, B[p.i_c0], (kWidth / 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
-    launch_pack(sp, W[p.i_c0], 1, p.in_c0, 0, 0, kWidth, kWidth / 2, kWidth, wp, s);
-    launch_rows_gemm(sp, Hlast, N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), bias_c0, 1, ws + p.o_zc, kWidth, 0, -1, nullptr, cus, s);
-    launch_pack(sp, W[p.i_c0], 1, p.in_c0, kWidth, 0, p.Cdir, kWidth / 2, kWidth, wp2, s);
-    launch_rows_gemm(sp, Ed, N, kLdDir, kdir, wp2, gemm_ksteps(p.Cdir, sp), nullptr, 1, ws + p.o_zc, kWidth, 1, NEDDF_ACT_RELU, ws + p.o_hc, cus, s);
+    HIPCHK(hipMemcpyAsync(bias_c0, B[p.i_c0], (size_t)HC * sizeof(float), hipMemcpyDeviceToDevice, s));
+    gemm_fw(Hlast, WH, WH, WH, W[p.i_c0], p.in_c0, 0, HC, bias_c0, ws + p.o_zc, kWidth, 0, -1, nullptr);
+    gemm_fw(Ed, kLdDir, kdir, p.Cdir, W[p.i_c0], p.in_c0, WH, HC, nullptr, ws + p.o_zc, kWidth, 1, NEDDF_ACT_RELU, ws + p.o_hc);
     NarrowW c1{};
-    c1.nc = 3; c1.wstride = 1; c1.kcount = kWidth / 2;
-    for (int c = 0; c < 3; ++c) { c1.w[c] = W[p.i_c1] + c * (kWidth / 2); c1.b[c] = B[p.i_c1] + c; }
+    c1.nc = 3; c1.wstride = 1; c1.kcount = HC;
+    for (int c = 0; c < 3; ++c) { c1.w[c] = W[p.i_c1] + c * HC; c1.b[c] = B[p.i_c1] + c; }
     launch_narrow_forward(ws + p.o_hc, kWidth, N, c1, 1, CR, kLdNarrow, s);
     if (color) launch_copy3(CR, kLdNarrow, color, 3, N, s);
     HIPCHK(hipGetLastError());
@@ -190,56 +203,73 @@ int nerf_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors
     NerfPlan p;
     if (int rc = make_nerf_plan(ctx, slot, N, n_tensors, p)) return rc;
     const Field &f = ctx->field[slot];
-    const int act = f.d.activation, cus = ctx->cus, half = kWidth / 2;
+    const int act = f.d.activation, cus = ctx->cus, WH = p.WH, NBK = WH / kWidth, HC = p.HC;
     const int sp = f.d.weight_dtype == NEDDF_DTYPE_F16_SPLIT;
     if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
-    if (int rc = ensure(ctx, ctx->ttmp, (size_t)N * (2 * kWidth + 2 * kLdNarrow) * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->ttmp, (size_t)N * (2 * WH + 2 * kLdNarrow) * sizeof(float))) return rc;
     float *wp = (float *)ctx->tpack.p;
-    float *dA = (float *)ctx->ttmp.p, *dB = dA + (size_t)N * kWidth, *GC = dB + (size_t)N * kWidth, *GD = GC + (size_t)N * kLdNarrow;
+    float *dA = (float *)ctx->ttmp.p, *dB = dA + (size_t)N * WH, *GC = dB + (size_t)N * WH, *GD = GC + (size_t)N * kLdNarrow;
     const float *PE = ws + p.o_pe, *Ed = ws + p.o_ed, *Hlast = ws + p.o_h[p.n - 1];
     HIPCHK(hipMemsetAsync(GC, 0, (size_t)N * 2 * kLdNarrow * sizeof(float), s));      // GC and GD
     if (g_color) launch_copy3(g_color, 3, GC, kLdNarrow, N, s);
-    // colour head, second layer + the ReLU in front of it (dA = dZ of the first colour layer; the padded columns stay zero)
+    // colour head, second layer + the ReLU in front of it (dA = dZ of the first colour layer as one [N, 256] block; padded columns stay zero)
     NarrowW c1{};
-    c1.nc = 3; c1.wstride = 1; c1.kcount = half;
-    for (int c = 0; c < 3; ++c) c1.w[c] = W[p.i_c1] + c * half;
+    c1.nc = 3; c1.wstride = 1; c1.kcount = HC;
+    for (int c = 0; c < 3; ++c) c1.w[c] = W[p.i_c1] + c * HC;
     AmaxSlots am;
     if (int rc = amax_begin(ctx, sp, am, s)) return rc;
     float *mA = am.take();          // max |dA| of the gradient matrix currently in dA
     launch_narrow_backward_act(GC, kLdNarrow, N, c1, nullptr, 0, NEDDF_ACT_RELU, 1, ws + p.o_zc, dA, kWidth, s, mA);
     {
-        float *wc[3] = { gW[p.i_c1], gW[p.i_c1] + half, gW[p.i_c1] + 2 * half }, *bc[3] = { gB[p.i_c1], gB[p.i_c1] + 1, gB[p.i_c1] + 2 };
-        launch_narrow_dw(ws + p.o_hc, kWidth, GC, kLdNarrow, N, 3, wc, 1, bc, 1, half, s);
+        float *wc[3] = { gW[p.i_c1], gW[p.i_c1] + HC, gW[p.i_c1] + 2 * HC }, *bc[3] = { gB[p.i_c1], gB[p.i_c1] + 1, gB[p.i_c1] + 2 };
+        launch_narrow_dw(ws + p.o_hc, kWidth, GC, kLdNarrow, N, 3, wc, 1, bc, 1, HC, s);
     }
-    // first colour layer (weights [128, 256 + dir])
-    launch_dw(sp, Hlast, kWidth, kWidth, dA, kWidth, N, gW[p.i_c0], 1, p.in_c0, half, gB[p.i_c0], 1, cus, s, mA, am.dw_tmp);
-    launch_dw(sp, Ed, kLdDir, p.Cdir, dA, kWidth, N, gW[p.i_c0] + kWidth, 1, p.in_c0, half, nullptr, 1, cus, s, mA, am.dw_tmp);
-    launch_pack(sp, W[p.i_c0], p.in_c0, 1, 0, 0, half, kWidth, kWidth, wp, s);                // rows = the 128 outputs, columns = hidden inputs
-    launch_rows_gemm(sp, dA, N, kWidth, half, wp, gemm_ksteps(half, sp), nullptr, 1, dB, kWidth, 0, -1, nullptr, cus, s, mA);
-    // density head, then the last trunk activation: dA = dZ of the last trunk layer
+    // first colour layer (weights [WH / 2, WH + dir]): weight gradients per 256-row block of the hidden input, then dHlast = dA x W_c0[:, 0:WH]
+    for (int kb = 0; kb < NBK; ++kb)
+        launch_dw(sp, Hlast + kb * kWidth, WH, kWidth, dA, kWidth, N, gW[p.i_c0] + kb * kWidth, 1, p.in_c0, HC, kb == 0 ? gB[p.i_c0] : nullptr, 1, cus, s, mA, am.dw_tmp);
+    launch_dw(sp, Ed, kLdDir, p.Cdir, dA, kWidth, N, gW[p.i_c0] + WH, 1, p.in_c0, HC, nullptr, 1, cus, s, mA, am.dw_tmp);
+    for (int nb = 0; nb < NBK; ++nb) {
+        launch_pack(sp, W[p.i_c0], p.in_c0, 1, 0, nb * kWidth, HC, kWidth, kWidth, wp, s);     // rows = the WH / 2 outputs, columns = hidden inputs of block nb
+        launch_rows_gemm(sp, dA, N, kWidth, HC, wp, gemm_ksteps(HC, sp), nullptr, 1, dB + nb * kWidth, WH, 0, -1, nullptr, cus, s, mA);
+    }
+    // density head, then the last trunk activation: dA = dZ of the last trunk layer ([N, WH] from here on)
     if (g_density) launch_density_head(f.d.density_activation, ws + p.o_zd, kLdNarrow, N, g_density, GD, kLdNarrow, s);
-    NarrowW dens{};
-    dens.nc = 1; dens.wstride = 1; dens.kcount = kWidth;
-    dens.w[0] = W[p.i_dens];
     mA = am.take();
-    launch_narrow_backward_act(GD, kLdNarrow, N, dens, dB, 1, act, 1, ws + p.o_z[p.n - 1], dA, kWidth, s, mA);
-    {
-        float *wd[1] = { gW[p.i_dens] }, *bd[1] = { gB[p.i_dens] };
-        launch_narrow_dw(Hlast, kWidth, GD, kLdNarrow, N, 1, wd, 1, bd, 1, kWidth, s);
+    for (int kb = 0; kb < NBK; ++kb) {
+        NarrowW dens{};
+        dens.nc = 1; dens.wstride = 1; dens.kcount = kWidth;
+        dens.w[0] = W[p.i_dens] + kb * kWidth;
+        launch_narrow_backward_act(GD, kLdNarrow, N, dens, dB + kb * kWidth, 1, act, 1, ws + p.o_z[p.n - 1] + kb * kWidth, dA + kb * kWidth, WH, s, mA);
+        float *wd[1] = { gW[p.i_dens] + kb * kWidth }, *bd[1] = { gB[p.i_dens] };
+        launch_narrow_dw(Hlast + kb * kWidth, WH, GD, kLdNarrow, N, 1, wd, 1, kb == 0 ? bd : nullptr, 1, kWidth, s);
     }
     // trunk
+    auto dw_blocks = [&](const float *X, int ldx, int Kin, float *gWl, int in_total, int col_off, float *gBl) {       // gW[n, col_off + k] += dA^T X
+        const int KB = Kin <= kWidth ? 1 : Kin / kWidth, kc = Kin <= kWidth ? Kin : kWidth;
+        for (int nb = 0; nb < NBK; ++nb)
+            for (int kb = 0; kb < KB; ++kb)
+                launch_dw(sp, X + kb * kWidth, ldx, kc, dA + nb * kWidth, WH, N, gWl + (size_t)nb * kWidth * in_total + col_off + kb * kWidth, 1, in_total, kWidth,
+                          (kb == 0 && gBl) ? gBl + nb * kWidth : nullptr, 1, cus, s, mA, am.dw_tmp);
+    };
     for (int l = p.n - 1; l >= 0; --l) {
         const bool wide = l > 0 && in_skips(f.d, l - 1);
-        const int in_total = l == 0 ? p.Cpe : (wide ? kWidth + p.Cpe : kWidth);
+        const int in_total = l == 0 ? p.Cpe : (wide ? WH + p.Cpe : WH);
         if (l == 0) {
-            launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, N, gW[0], 1, in_total, kWidth, gB[0], 1, cus, s, mA, am.dw_tmp);
+            dw_blocks(PE, kLdPe, p.Cpe, gW[0], in_total, 0, gB[0]);
             break;
         }
-        launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, N, gW[l], 1, in_total, kWidth, gB[l], 1, cus, s, mA, am.dw_tmp);
-        if (wide) launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, N, gW[l] + kWidth, 1, in_total, kWidth, nullptr, 1, cus, s, mA, am.dw_tmp);
-        launch_pack(sp, W[l], in_total, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
+        dw_blocks(ws + p.o_h[l - 1], WH, WH, gW[l], in_total, 0, gB[l]);
+        if (wide) dw_blocks(PE, kLdPe, p.Cpe, gW[l], in_total, WH, nullptr);
         float *mB = am.take();
-        launch_rows_gemm_actback(sp, dA, N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 1, act, ws + p.o_z[l - 1], dB, kWidth, cus, s, mA, mB);
+        for (int nb = 0; nb < NBK; ++nb)             // dB[:, nb] = actback(Z_{l-1}[:, nb]; sum_kb dA[:, kb] x W[kb rows, nb columns])
+            for (int kb = 0; kb < NBK; ++kb) {
+                launch_pack(sp, W[l], in_total, 1, kb * kWidth, nb * kWidth, kWidth, kWidth, kWidth, wp, s);
+                if (kb == NBK - 1)
+                    launch_rows_gemm_actback(sp, dA + kb * kWidth, N, WH, kWidth, wp, gemm_ksteps(kWidth, sp), 1, act, ws + p.o_z[l - 1] + nb * kWidth,
+                                             dB + nb * kWidth, WH, cus, s, mA, mB, kb > 0);
+                else
+                    launch_rows_gemm(sp, dA + kb * kWidth, N, WH, kWidth, wp, gemm_ksteps(kWidth, sp), nullptr, 1, dB + nb * kWidth, WH, kb > 0, -1, nullptr, cus, s, mA);
+            }
         float *t = dA; dA = dB; dB = t;
         mA = mB;
     }

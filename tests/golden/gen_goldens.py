@@ -858,6 +858,39 @@ def gen_train_wide():
     save("train_wide.npz", **arrs)
 
 
+def gen_train_wide_nerf():
+    """The NeRF companion of gen_train_wide (nerf.py:34-44 builds any width; the colour head's hidden width is layer_width // 2):
+    NeRF 384 (tanhExp, one skip: trains zero-padded to 512, colour head 192 -> 256) and NeRF 512 (ReLU, two skips,
+    `embed_dir_rank` 6) under plain torch autograd (nerf.py:107-165); random upstream gradients on both outputs, 33 sample points."""
+    arrs = {}
+    rng = np.random.default_rng(2028)
+    shape = (3, 11)
+    pos, dd, var = synth.random_sampling(shape[0], shape[1], seed=59, cone=True)
+    arrs.update(pos=pos, dir=dd, var=var)
+    for tag, kw in (("nerf384", dict(embed_pos_rank=6, embed_dir_rank=4, layer_count=5, layer_width=384, activation_type="tanhExp",
+                                     density_activation_type="ReLU", skips=[2], lowpass_alpha_offset=10)),
+                    ("nerf512", dict(embed_pos_rank=8, embed_dir_rank=6, layer_count=6, layer_width=512, activation_type="ReLU",
+                                     density_activation_type="LeakyReLU", skips=[1, 3], lowpass_alpha_offset=10))):
+        net = NeRF(**kw)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_state(
+            kw["embed_pos_rank"], kw["embed_dir_rank"], kw["layer_count"], kw["layer_width"], tuple(kw["skips"]), seed=41).items()})
+        net.set_iter(1500)
+        ups = {"density": torch.from_numpy(rng.standard_normal(shape).astype(np.float32)),
+               "color": torch.from_numpy(rng.standard_normal(shape + (3,)).astype(np.float32))}
+        with torch.enable_grad():
+            net.zero_grad()
+            o = net(Sampling(torch.from_numpy(pos.copy()), torch.from_numpy(dd), torch.from_numpy(var)))
+            sum((o[k] * ups[k]).sum() for k in ups).backward()
+        pre = tag + "_"
+        arrs[pre + "config"] = np.array(json.dumps(kw))
+        for k in ups:
+            arrs[pre + "g_" + k] = npy(ups[k])
+            arrs[pre + "out_" + k] = npy(o[k])
+        _grad_records(arrs, pre, net, 797, ("layers.0.weight", "layers.0.bias", "layers.3.bias", "outL_density.weight", "outL_color.0.bias",
+                                           "outL_color.2.weight", "outL_color.2.bias"))
+    save("train_wide_nerf.npz", **arrs)
+
+
 # --------------------------------------------------------------------------
 def gen_dataset():
     """the reference's own NeRFSyntheticDataset (nerf_synthetic_dataset.py:25-84, with cv2.imread backed
@@ -1047,6 +1080,10 @@ if __name__ == "__main__":
         from neddf.ray import Sampling  # noqa: F401
         gen_train_wide()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "train_wide_nerf":
+        from neddf.ray import Sampling  # noqa: F401
+        gen_train_wide_nerf()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "train_widths":
         gen_train_widths()
         sys.exit(0)
@@ -1085,3 +1122,4 @@ if __name__ == "__main__":
     gen_train_wide()
     gen_negbias()
     gen_fp64()          # last: switches torch's default dtype while it runs
+    gen_train_wide_nerf()

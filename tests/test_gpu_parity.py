@@ -822,12 +822,18 @@ def test_width_and_rank_limits_fail_loudly(dev):
         wide(s)["color"].sum().backward()
         assert all(p.grad is not None and tuple(p.grad.shape) == tuple(p.shape) for p in wide.parameters())
     nerf = neddf_amd.NeRF(embed_pos_rank=4, embed_dir_rank=2, layer_count=4, layer_width=384, activation_type="ReLU", density_activation_type="ReLU",
-                          skips=[1]).to(dev)                                         # NeRF / NeuS above 256: rendering yes, training refused loudly
+                          skips=[1]).to(dev)                                         # NeRF above 256: the same (colour head 192 -> one 256 block)
     nerf.set_iter(-1)
     assert bool(torch.isfinite(nerf(s)["density"]).all())
     with torch.enable_grad():
+        nerf(s)["color"].sum().backward()
+        assert all(p.grad is not None and tuple(p.grad.shape) == tuple(p.shape) for p in nerf.parameters())
+    neus = neddf_amd.NeuS(embed_pos_rank=4, embed_dir_rank=2, sdf_layer_count=4, sdf_layer_width=384, col_layer_count=2, col_layer_width=384,
+                          activation_type="ReLU", skips=[1]).to(dev)                 # NeuS above 256: rendering yes, training refused loudly
+    assert bool(torch.isfinite(neus(s)["density"]).all())
+    with torch.enable_grad():
         with pytest.raises(NeddfError):
-            nerf(s)
+            neus(s)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "f16_split"])
