@@ -55,8 +55,8 @@ typedef struct neddf_ctx neddf_ctx;
  * NeDDF (neddf/network/neddf.py:52-66) and NeRF (neddf/network/nerf.py:34-44). */
 typedef struct {
     int kind;                 /* NEDDF_FIELD_* */
-    int embed_pos_rank;       /* <= 10 */
-    int embed_dir_rank;       /* <= 4  */
+    int embed_pos_rank;       /* 1..10 */
+    int embed_dir_rank;       /* >= 1; both encodings + 32 columns must fit a 512-column tile row (training: <= 10) */
     int layer_count;          /* NeDDF: ddf_layer_count, NeRF: layer_count */
     int layer_width;          /* rendering: 1..512; training: 256, or 512 for NeDDF / NeRF (narrower ones zero-padded by the caller) */
     int col_layer_count;      /* NeDDF only */

@@ -140,8 +140,16 @@ static std::vector<int> hidden_map(int width, int wp, int base)
 }
 
 // engine width of a hidden width: the next multiple of 128 (four waves x 32-column MFMA tiles).  The padding columns carry zero
-// weights and biases, so they hold a(0) = 0 under every activation of the reference and feed zero rows downstream: exact
-static int engine_width(int width) { return roundup(width, 128); }
+// weights and biases, so they hold a(0) = 0 under every activation of the reference and feed zero rows downstream: exact.
+// A tile row also has to hold both encodings next to a 32-column block (enc_columns): a narrow network with long encodings takes the next
+// engine width that does
+static int enc_columns(const neddf_field_desc &d) { return 2 * roundup(3 * d.embed_pos_rank, 4) + 2 * roundup(3 * d.embed_dir_rank, 4) + 32; }
+static int engine_width(int width, const neddf_field_desc &d)
+{
+    int w = roundup(width, 128);
+    while (w < enc_columns(d)) w += 128;
+    return w;
+}
 
 // engine columns of the [sin half | cos half] encoding -> reference feature index base+...
 static void enc_map(std::vector<int> &m, int rank, int K, int base)
@@ -158,7 +166,7 @@ static int build_neddf(neddf_ctx *ctx, Field &f, const float *const *W, const fl
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n_trunk = d.layer_count - 1, n_col = d.col_layer_count - 1;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
     const int operands = d.weight_dtype;      // 0 fp32, 1 bf16, 2 split fp16
-    const int Wd = d.layer_width, WP = engine_width(Wd);      // hidden width of the reference network / of the tile engine
+    const int Wd = d.layer_width, WP = engine_width(Wd, d);      // hidden width of the reference network / of the tile engine
     if (d.col_layer_width != Wd)
         return fail(ctx, NEDDF_EUNSUPPORTED, "NeDDF: col_layer_width must equal ddf_layer_width (the reference's layer_col_out takes ddf_layer_width inputs, "
                                              "neddf.py:145: its own forward fails otherwise)");
@@ -272,7 +280,7 @@ static int build_neus(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
     const int operands = d.weight_dtype;
     // sdf and colour trunks may have different widths (neus.py:80-99); both run on one engine width, zero-padded
-    const int Ws = d.layer_width, Wc = d.col_layer_width, WP = engine_width(Ws > Wc ? Ws : Wc);
+    const int Ws = d.layer_width, Wc = d.col_layer_width, WP = engine_width(Ws > Wc ? Ws : Wc, d);
     if (n_tensors != n_sdf + n_col + 2) return fail(ctx, NEDDF_EINVAL, "NeuS: wrong tensor count");
     if (n_sdf < 1 || n_sdf > kMaxLayers || n_col < 1 || n_col > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: layer count out of range");
     if (d.activation == NEDDF_ACT_LEAKY) return fail(ctx, NEDDF_EUNSUPPORTED, "NeuS: activation must be ReLU or tanhExp");
@@ -397,7 +405,7 @@ static int build_nerf(neddf_ctx *ctx, Field &f, const float *const *W, const flo
     const int E = d.embed_pos_rank, Ed = d.embed_dir_rank, n = d.layer_count;
     const int KH = roundup(3 * E, 4), KD = roundup(3 * Ed, 4), Cpe = 6 * E, Cdir = 6 * Ed;
     const int operands = d.weight_dtype, step = operands ? 16 : 8;
-    const int Wn = d.layer_width, WP = engine_width(Wn);
+    const int Wn = d.layer_width, WP = engine_width(Wn, d);
     const int Wh = Wn / 2, HC = roundup(Wh > 0 ? Wh : 1, 128);      // colour head's hidden layer (nerf.py:99-103: layer_width // 2) and its engine width
     if (n_tensors != n + 3) return fail(ctx, NEDDF_EINVAL, "NeRF: wrong tensor count");
     if (n < 1 || n > kMaxLayers) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: layer count out of range");
@@ -720,8 +728,8 @@ int neddf_set_field(neddf_ctx *ctx, int slot, const neddf_field_desc *desc, cons
     if (desc->kind == NEDDF_FIELD_NERF && desc->layer_width < 2) return fail(ctx, NEDDF_EUNSUPPORTED, "NeRF: layer_width must be at least 2 (the colour head is layer_width // 2 wide)");
     if (desc->embed_pos_rank < 1 || desc->embed_pos_rank > 10 || desc->embed_dir_rank < 1)
         return fail(ctx, NEDDF_EUNSUPPORTED, "embed_pos_rank must be in [1,10] and embed_dir_rank >= 1");
-    if (2 * roundup(3 * desc->embed_pos_rank, 4) + 2 * roundup(3 * desc->embed_dir_rank, 4) + 32 > roundup(wmax, 128))
-        return fail(ctx, NEDDF_EUNSUPPORTED, "embed_dir_rank: the encodings do not fit one tile row of this hidden width");
+    if (enc_columns(*desc) > kMaxWidth)
+        return fail(ctx, NEDDF_EUNSUPPORTED, "embed_dir_rank: the encodings do not fit one tile row of the widest engine (512 columns)");
     if (desc->n_skips < 0 || desc->n_skips > 8) return fail(ctx, NEDDF_EINVAL, "bad n_skips");
     if (desc->activation < 0 || desc->activation > 2 || desc->density_activation < 0 || desc->density_activation > 2)
         return fail(ctx, NEDDF_EINVAL, "bad activation id");

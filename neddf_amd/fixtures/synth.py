@@ -146,3 +146,45 @@ def wide_sampling(n_rays, n_samples, seed, reach=6.0):
     pos[n_rays // 2:] = far[n_rays // 2:]
     var[::2] = 0.0
     return pos, d, var
+
+
+def random_arch(seed, train=False):
+    """(kind, constructor keywords) of one architecture the reference's constructors accept (neddf.py:52-66, nerf.py:34-44,
+    neus.py:30-41), drawn from `seed`: kinds cycle NeDDF / NeRF / NeuS; hidden width 8 .. 512, 2 .. 7 layers, up to three skip
+    connections, any activation on trunk and density head, encoding ranks 1 .. 10.  train=True keeps NeuS within what the training
+    kernels take (hidden widths up to 256)."""
+    rng = np.random.default_rng(seed)
+    kind = ("neddf", "nerf", "neus")[seed % 3]
+    widths = [8, 24, 40, 64, 72, 100, 128, 160, 200, 256, 264, 320, 384, 448, 512]
+    if train and kind == "neus":
+        widths = widths[:10]
+    width = int(rng.choice(widths))
+    n = int(rng.integers(2, 8))
+    # a skip index names a hidden layer that is followed by another: NeRF / NeuS have n of them, NeDDF n - 1 (its `ddf_layer_count`
+    # counts the output layer, neddf.py:128-136) -- the reference's own forward fails beyond that
+    n_hidden = n - 1 if kind == "neddf" else n
+    skips = (sorted(int(x) for x in rng.choice(np.arange(0, n_hidden - 1), size=int(rng.integers(0, min(3, n_hidden - 1) + 1)), replace=False))
+             if n_hidden > 1 else [])
+    act = str(rng.choice(["ReLU", "LeakyReLU", "tanhExp"]))
+    dact = str(rng.choice(["ReLU", "LeakyReLU", "tanhExp"]))
+    E, Ed = int(rng.integers(1, 11)), int(rng.integers(1, 11))
+    if kind == "neddf":
+        return kind, dict(embed_pos_rank=E, embed_dir_rank=Ed, ddf_layer_count=n, ddf_layer_width=width, col_layer_count=int(rng.integers(2, 6)),
+                          col_layer_width=width, d_near=0.01, activation_type=act, density_activation_type=dact, skips=skips, lowpass_alpha_offset=10)
+    if kind == "nerf":
+        return kind, dict(embed_pos_rank=E, embed_dir_rank=Ed, layer_count=n, layer_width=width + (width & 1), activation_type=act,
+                          density_activation_type=dact, skips=skips, lowpass_alpha_offset=10)
+    wc = int(rng.choice([16, 64, 128, 256] + ([] if train else [320, 512])))
+    return kind, dict(embed_pos_rank=E, embed_dir_rank=Ed, sdf_layer_count=n, sdf_layer_width=width, col_layer_count=int(rng.integers(1, 5)),
+                      col_layer_width=wc, init_variance=float(rng.uniform(0.1, 0.6)), activation_type=str(rng.choice(["ReLU", "tanhExp"])), skips=skips)
+
+
+def arch_state(kind, kw, seed):
+    """The seeded state dict of random_arch's (kind, kw)."""
+    if kind == "neddf":
+        return neddf_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["ddf_layer_count"], kw["ddf_layer_width"], kw["col_layer_count"],
+                           kw["col_layer_width"], tuple(kw["skips"]), seed=seed)
+    if kind == "nerf":
+        return nerf_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["layer_count"], kw["layer_width"], tuple(kw["skips"]), seed=seed)
+    return neus_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["sdf_layer_count"], kw["sdf_layer_width"], kw["col_layer_count"],
+                      kw["col_layer_width"], tuple(kw["skips"]), kw["init_variance"], seed=seed)

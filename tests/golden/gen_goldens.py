@@ -891,6 +891,39 @@ def gen_train_wide_nerf():
     save("train_wide_nerf.npz", **arrs)
 
 
+def gen_train_random():
+    """Thirty architectures drawn at random from what the reference's constructors accept (synth.random_arch(seed, train=True): field kind,
+    hidden width 8 .. 512, 2 .. 7 layers, up to three skips, any activation, encoding ranks 1 .. 10) through the reference's own
+    forward + backward (NeDDF: hand-written (value, Jacobian) backward passes; NeRF: autograd; NeuS: double backward) with random
+    upstream gradients on every output, a ragged number of points each.  Per parameter tensor: gradient norm + one random projection."""
+    arrs = {}
+    kinds = {"neddf": (NeDDF, ("distance", "density", "color", "fields_penalty", "aux_grad"), 2500),
+             "nerf": (NeRF, ("density", "color"), 1500), "neus": (NeuS, ("sdf", "density", "color"), None)}
+    for seed in range(100, 130):
+        kind, kw = synth.random_arch(seed, train=True)
+        cls, keys, it = kinds[kind]
+        rng = np.random.default_rng(5000 + seed)
+        shape = (int(rng.integers(1, 6)), int(rng.integers(1, 30)))
+        pos, dd, var = synth.random_sampling(shape[0], shape[1], seed=6000 + seed, cone=kind != "neus")
+        net = cls(**kw)
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.arch_state(kind, kw, 7000 + seed).items()})
+        if it is not None:
+            net.set_iter(it)
+        ups = {k: torch.from_numpy(rng.standard_normal(shape + ((3,) if k == "color" else ())).astype(np.float32)) for k in keys}
+        with torch.enable_grad():
+            net.zero_grad()
+            o = net(Sampling(torch.from_numpy(pos.copy()), torch.from_numpy(dd), torch.from_numpy(var)))
+            sum((o[k] * ups[k]).sum() for k in ups).backward()
+        pre = "s%d_" % seed
+        arrs.update({pre + "pos": pos, pre + "dir": dd, pre + "var": var, pre + "config": np.array(json.dumps(dict(kind=kind, kw=kw)))})
+        for k in ups:
+            arrs[pre + "g_" + k] = npy(ups[k])
+            arrs[pre + "out_" + k] = npy(o[k])
+        _grad_records(arrs, pre, net, 8000 + seed)
+        print("  train_random seed %d %s %s" % (seed, kind, json.dumps(kw)))
+    save("train_random.npz", **arrs)
+
+
 # --------------------------------------------------------------------------
 def gen_dataset():
     """the reference's own NeRFSyntheticDataset (nerf_synthetic_dataset.py:25-84, with cv2.imread backed
@@ -1084,6 +1117,10 @@ if __name__ == "__main__":
         from neddf.ray import Sampling  # noqa: F401
         gen_train_wide_nerf()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "train_random":
+        from neddf.ray import Sampling  # noqa: F401
+        gen_train_random()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "train_widths":
         gen_train_widths()
         sys.exit(0)
@@ -1123,3 +1160,4 @@ if __name__ == "__main__":
     gen_negbias()
     gen_fp64()          # last: switches torch's default dtype while it runs
     gen_train_wide_nerf()
+    gen_train_random()

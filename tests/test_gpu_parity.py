@@ -793,8 +793,8 @@ def test_c2_single_pass_vs_oracle(dev, orc, bunny_weights):
 
 
 def test_width_and_rank_limits_fail_loudly(dev):
-    """The engine takes hidden widths 1..512 (zero-padded to a multiple of 128); beyond that -- and for training NeRF / NeuS above width
-    256 (NeDDF trains up to 512 since round 4; narrower networks train zero-padded) -- the C ABI refuses with NEDDF_EUNSUPPORTED
+    """The engine takes hidden widths 1..512 (zero-padded to a multiple of 128); beyond that -- and for training NeuS above width
+    256 (NeDDF and NeRF train up to 512 since round 4; narrower networks train zero-padded) -- the C ABI refuses with NEDDF_EUNSUPPORTED
     instead of computing something else.  A NeDDF whose two
     widths differ is refused like the reference's own forward would fail (neddf.py:145)."""
     import neddf_amd
@@ -869,6 +869,46 @@ def test_widest_engine_vs_oracle(dev, orc, dtype):
         on = nerf(s)
         for k in ("density", "color"):
             assert_close(N(on[k]), rn[k], 1e-4, 2e-5, "NeRF %d %s %s" % (width, dtype, k))
+
+
+@pytest.mark.parametrize("seed", list(range(60)))
+def test_random_architectures_vs_oracle(dev, orc, seed):
+    """Round 4: sixty architectures drawn at random from what the reference's constructors accept -- field kind, hidden width 8 .. 512
+    (zero-padded onto the 128 / 256 / 384 / 512 engines), 2 .. 7 layers, up to three skip connections at any depth, any of the three
+    activations on trunk and density head, encoding ranks 1 .. 10 for positions and directions (a narrow network with long encodings
+    takes the next engine width whose tile row holds them), a ragged number of points -- against the oracle (pinned on
+    the reference's goldens at widths 128 .. 384 through this same code path).  Seeds cycle NeDDF (both differentiation modes) / NeRF /
+    NeuS; fp32 and split-fp16 operands at the same gates."""
+    import neddf_amd
+    kind, kw = synth.random_arch(seed)
+    rng = np.random.default_rng(1000 + seed)
+    rays, samples = int(rng.integers(1, 9)), int(rng.integers(1, 50))
+    pos, d, var = synth.random_sampling(rays, samples, seed=2000 + seed)
+    s = smp(dict(pos=pos, dir=d, var=var), dev)
+    if kind == "neddf":
+        sd = synth.neddf_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["ddf_layer_count"], kw["ddf_layer_width"], kw["col_layer_count"],
+                               kw["col_layer_width"], tuple(kw["skips"]), seed=3000 + seed)
+        net, ref = neddf_amd.NeDDF(**kw), orc.NeDDFOracle(sd, **kw).forward(pos, d, var)
+    elif kind == "nerf":
+        sd = synth.nerf_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["layer_count"], kw["layer_width"], tuple(kw["skips"]), seed=3000 + seed)
+        net, ref = neddf_amd.NeRF(**kw), orc.NeRFOracle(sd, **kw).forward(pos, d, var)
+    else:
+        sd = synth.neus_state(kw["embed_pos_rank"], kw["embed_dir_rank"], kw["sdf_layer_count"], kw["sdf_layer_width"], kw["col_layer_count"],
+                              kw["col_layer_width"], tuple(kw["skips"]), kw["init_variance"], seed=3000 + seed)
+        net, ref = neddf_amd.NeuS(**kw), orc.NeuSOracle(sd, **kw).forward(pos, d)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    net.to(dev)
+    if kind != "neus":
+        net.set_iter(-1)
+    for dtype in ("fp32", "f16_split"):
+        net.weight_dtype = dtype
+        for mode in (("full", "minimal") if kind == "neddf" else ("full",)):
+            if kind == "neddf":
+                net.output_mode = mode
+            o = net(s)
+            assert o["density"].shape == (rays, samples)
+            for k in o:
+                assert_close(N(o[k]), ref[k], 1e-4, 2e-5, "seed %d %s %s %s %s %s" % (seed, kind, json.dumps(kw), dtype, mode, k))
 
 
 def test_c3_full_frame_hierarchical_properties(dev, bunny_weights):
