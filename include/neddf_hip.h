@@ -58,7 +58,7 @@ typedef struct {
     int embed_pos_rank;       /* 1..10 */
     int embed_dir_rank;       /* >= 1; both encodings + 32 columns must fit a 512-column tile row (training: <= 10) */
     int layer_count;          /* NeDDF: ddf_layer_count, NeRF: layer_count */
-    int layer_width;          /* rendering: 1..512; training: 256, or 512 for NeDDF / NeRF (narrower ones zero-padded by the caller) */
+    int layer_width;          /* rendering: 1..512; training: 256 or 512 (other widths zero-padded by the caller) */
     int col_layer_count;      /* NeDDF only */
     int col_layer_width;      /* NeDDF (== layer_width) and NeuS */
     int n_skips;

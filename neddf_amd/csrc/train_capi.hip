@@ -25,16 +25,15 @@ constexpr int kLdPe = 64, kLdDir = 64, kLdNarrow = 4;      // row strides of the
 
 // The training kernels (train_kernels.hip) are built for the hidden width of every shipped configuration, 256: tiles, fused layer
 // chains and weight-gradient products are 256 columns wide.  Narrower networks reach these entry points zero-padded to 256
-// (neddf_amd/network.py _train_tensors: exact).  Round 4: a NeDDF or NeRF up to hidden width 512 (the reference trains whatever it
-// constructs, neddf.py:52-66, nerf.py:34-44) arrives padded to 512 and takes the PER-LAYER route with every product cut into 256 x 256 blocks
+// (neddf_amd/network.py _train_tensors: exact).  Round 4: a field up to hidden width 512 (the reference trains whatever it
+// constructs, neddf.py:52-66, nerf.py:34-44, neus.py:30-41) arrives padded to 512 and takes the PER-LAYER route with every product cut into 256 x 256 blocks
 // (K blocks accumulate in the output, the activation / its backward runs on the last one): the same kernels, correct at any
-// multiple of 256, without the fused chains' speed.  NeuS above 256 and anything wider are refused loudly rather than computed wrongly.
+// multiple of 256, without the fused chains' speed.  Anything wider is refused loudly rather than computed wrongly.
 int train_supported(neddf_ctx *ctx, const Field &f)
 {
-    const int wmax = f.d.kind == NEDDF_FIELD_NEUS ? kWidth : 2 * kWidth;
-    if (f.d.layer_width % kWidth != 0 || f.d.layer_width < kWidth || f.d.layer_width > wmax ||
+    if (f.d.layer_width % kWidth != 0 || f.d.layer_width < kWidth || f.d.layer_width > 2 * kWidth ||
         (f.d.kind != NEDDF_FIELD_NERF && f.d.col_layer_width != f.d.layer_width))
-        return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels take hidden widths 256 (every field kind) and 512 (NeDDF, NeRF): pass other widths zero-padded (neddf_amd does); NeuS above 256 and anything above 512 cannot train (rendering supports 1..512)");
+        return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels take hidden widths 256 and 512 (NeDDF / NeuS: both trunks at the same one): pass other widths zero-padded (neddf_amd does); anything above 512 cannot train (rendering supports 1..512)");
     if (6 * f.d.embed_dir_rank > kLdDir) return fail(ctx, NEDDF_EUNSUPPORTED, "the training kernels take embed_dir_rank <= 10");
     return 0;
 }
@@ -285,6 +284,7 @@ int nerf_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors
 static_assert(kActTanhExp == NEDDF_ACT_TANHEXP, "activation ids");
 struct NeusPlan {
     int E, Ed, Cpe, Cdir, Ca, ldxa, n_sdf, n_col, i_cout, i_var, in_c0;
+    int WH;                     // hidden width the kernels see, both trunks (256 or 512)
     int64_t N, R;
     size_t o_pe, o_ed, o_xa, o_zo, o_z[kMaxLayers], o_h[kMaxLayers], o_zc[kMaxLayers], o_hc[kMaxLayers], total;
 };
@@ -296,7 +296,8 @@ int make_neus_plan(neddf_ctx *ctx, int slot, int64_t N, int n_tensors, NeusPlan 
     p.E = f.d.embed_pos_rank; p.Ed = f.d.embed_dir_rank;
     p.Cpe = 6 * p.E; p.Cdir = 6 * p.Ed; p.Ca = 6 + p.Cdir; p.ldxa = roundup(p.Ca, 8);
     p.n_sdf = f.d.layer_count; p.n_col = f.d.col_layer_count;
-    p.i_cout = p.n_sdf + p.n_col; p.i_var = p.i_cout + 1; p.in_c0 = p.Ca + kWidth;
+    p.WH = f.d.layer_width;
+    p.i_cout = p.n_sdf + p.n_col; p.i_var = p.i_cout + 1; p.in_c0 = p.Ca + p.WH;
     if (n_tensors >= 0 && n_tensors != p.n_sdf + p.n_col + 2) return fail(ctx, NEDDF_EINVAL, "NeuS: wrong tensor count");
     p.N = N; p.R = 4 * N;
     size_t o = 0;
@@ -305,8 +306,8 @@ int make_neus_plan(neddf_ctx *ctx, int slot, int64_t N, int n_tensors, NeusPlan 
     p.o_ed = take((size_t)N * kLdDir);
     p.o_xa = take((size_t)N * p.ldxa);
     p.o_zo = take((size_t)N * kLdNarrow);
-    for (int l = 0; l < p.n_sdf; ++l) { p.o_z[l] = take((size_t)p.R * kWidth); p.o_h[l] = take((size_t)p.R * kWidth); }
-    for (int l = 0; l < p.n_col; ++l) { p.o_zc[l] = take((size_t)N * kWidth); p.o_hc[l] = take((size_t)N * kWidth); }
+    for (int l = 0; l < p.n_sdf; ++l) { p.o_z[l] = take((size_t)p.R * p.WH); p.o_h[l] = take((size_t)p.R * p.WH); }
+    for (int l = 0; l < p.n_col; ++l) { p.o_zc[l] = take((size_t)N * p.WH); p.o_hc[l] = take((size_t)N * p.WH); }
     p.total = o;
     return 0;
 }
@@ -317,7 +318,7 @@ void neus_point_args(NeusPointArgs &a, const Field &f, const NeusPlan &p, const 
     a.N = p.N; a.act = f.d.activation; a.Cdir = p.Cdir;
     a.variance = W[p.i_var];
     a.Ed = ws + p.o_ed; a.ldd = kLdDir;
-    a.Hlast = ws + p.o_h[p.n_sdf - 1]; a.Zlast = ws + p.o_z[p.n_sdf - 1];
+    a.Hlast = ws + p.o_h[p.n_sdf - 1]; a.Zlast = ws + p.o_z[p.n_sdf - 1]; a.ldh = p.WH;
     a.XA = ws + p.o_xa; a.ldxa = p.ldxa;
     a.ZC = ws + p.o_zo; a.ldc = kLdNarrow;
 }
@@ -328,7 +329,7 @@ int neus_forward(neddf_ctx *ctx, int slot, const float *const *W, const float *c
     NeusPlan p;
     if (int rc = make_neus_plan(ctx, slot, N, n_tensors, p)) return rc;
     const Field &f = ctx->field[slot];
-    const int act = f.d.activation, cus = ctx->cus;
+    const int act = f.d.activation, cus = ctx->cus, WH = p.WH, NBK = WH / kWidth;
     const int sp = f.d.weight_dtype == NEDDF_DTYPE_F16_SPLIT;
     if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ttmp, ((size_t)p.R * kLdPe + (size_t)N * 4) * sizeof(float))) return rc;
@@ -345,7 +346,20 @@ int neus_forward(neddf_ctx *ctx, int slot, const float *const *W, const float *c
     int n_wide = 0;
     for (int l = 1; l < p.n_sdf; ++l) n_wide += in_skips(f.d, l - 1) ? 1 : 0;
     static const bool unfused = [] { const char *e = getenv("NEDDF_TRAIN_UNFUSED"); return e && atoi(e) != 0; }();
-    if (!unfused && n_wide <= 1) {      // the sdf trunk (neus.py:121-125) as one fused layer stack (train_kernels.h MlpForwardArgs)
+    // Z[rows, WH] (+)= X[rows, Kin] x (input columns k_off .. of the [WH, in_total] weight)^T, 256 x 256 blocks: Kin <= 256 is one K
+    // block of `kload` loaded columns, otherwise Kin = WH; K blocks accumulate in Z, the activation runs with the last one
+    auto gemm_fw = [&](const float *X, int64_t rows, int ldx, int kload, int Kin, const float *Wsrc, int in_total, int k_off, const float *bias,
+                       int period, float *Z, int acc0, int act_kind, float *H) {
+        const int KB = Kin <= kWidth ? 1 : Kin / kWidth, kc = Kin <= kWidth ? Kin : kWidth, kl = Kin <= kWidth ? kload : kWidth;
+        for (int nb = 0; nb < NBK; ++nb)
+            for (int kb = 0; kb < KB; ++kb) {
+                const bool last = kb == KB - 1;
+                launch_pack(sp, Wsrc, 1, in_total, k_off + kb * kWidth, nb * kWidth, kc, kWidth, kWidth, wp, s);
+                launch_rows_gemm(sp, X + kb * kWidth, rows, ldx, kl, wp, gemm_ksteps(kc, sp), (kb == 0 && bias) ? bias + nb * kWidth : nullptr, period,
+                                 Z + nb * kWidth, WH, (acc0 || kb > 0) ? 1 : 0, last ? act_kind : -1, (last && H) ? H + nb * kWidth : nullptr, cus, s);
+            }
+    };
+    if (!unfused && n_wide <= 1 && WH == kWidth) {      // the sdf trunk (neus.py:121-125) as one fused layer stack (train_kernels.h MlpForwardArgs)
         if (int rc = ensure(ctx, ctx->tpack, (size_t)(kMaxLayers + 2) * kPackFloats * sizeof(float))) return rc;
         wp = (float *)ctx->tpack.p; wp2 = wp + kPackFloats;
         float *pack_at = wp;
@@ -375,43 +389,36 @@ int neus_forward(neddf_ctx *ctx, int slot, const float *const *W, const float *c
     for (int l = 0; l < p.n_sdf; ++l) {             // neus.py:121-125
         float *Z = ws + p.o_z[l], *H = ws + p.o_h[l];
         const bool wide = l > 0 && in_skips(f.d, l - 1);
-        const int in_total = l == 0 ? p.Cpe : (wide ? kWidth + p.Cpe : kWidth);
-        if (l == 0) {
-            launch_pack(sp, W[0], 1, in_total, 0, 0, p.Cpe, kWidth, kWidth, wp, s);
-            launch_rows_gemm(sp, PE, p.R, kLdPe, kpe, wp, gemm_ksteps(p.Cpe, sp), B[0], 4, Z, kWidth, 0, act, H, cus, s);
-        } else if (!wide) {
-            launch_pack(sp, W[l], 1, in_total, 0, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(sp, ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 4, Z, kWidth, 0, act, H, cus, s);
-        } else {        // cat([hx, embed_pos]): hidden state first
-            launch_pack(sp, W[l], 1, in_total, 0, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(sp, ws + p.o_h[l - 1], p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), B[l], 4, Z, kWidth, 0, -1, nullptr, cus, s);
-            launch_pack(sp, W[l], 1, in_total, kWidth, 0, p.Cpe, kWidth, kWidth, wp2, s);
-            launch_rows_gemm(sp, PE, p.R, kLdPe, kpe, wp2, gemm_ksteps(p.Cpe, sp), nullptr, 4, Z, kWidth, 1, act, H, cus, s);
+        const int in_total = l == 0 ? p.Cpe : (wide ? WH + p.Cpe : WH);
+        if (l == 0) gemm_fw(PE, p.R, kLdPe, kpe, p.Cpe, W[0], in_total, 0, B[0], 4, Z, 0, act, H);
+        else if (!wide) gemm_fw(ws + p.o_h[l - 1], p.R, WH, WH, WH, W[l], in_total, 0, B[l], 4, Z, 0, act, H);
+        else {          // cat([hx, embed_pos]): hidden state first
+            gemm_fw(ws + p.o_h[l - 1], p.R, WH, WH, WH, W[l], in_total, 0, B[l], 4, Z, 0, -1, nullptr);
+            gemm_fw(PE, p.R, kLdPe, kpe, p.Cpe, W[l], in_total, WH, nullptr, 4, Z, 1, act, H);
         }
     }
+    (void)wp2;
     NeusPointArgs a;
     neus_point_args(a, f, p, W, ws);
     a.pos = pos; a.sdf = sdf; a.density = density; a.color = color;
     launch_neus_head_forward(a, s);
-    // colour trunk on value rows (neus.py:146-152): the features are the value rows of the last sdf layer (row stride 4 x 256)
+    // colour trunk on value rows (neus.py:146-152): the features are the value rows of the last sdf layer (row stride 4 x WH)
     const float *Hlast = ws + p.o_h[p.n_sdf - 1];
     for (int l = 0; l < p.n_col; ++l) {
         float *Z = ws + p.o_zc[l], *H = ws + p.o_hc[l];
         const float *Wl = W[p.n_sdf + l], *Bl = B[p.n_sdf + l];
         if (l == 0) {
-            launch_pack(sp, Wl, 1, p.in_c0, 0, 0, p.Ca, kWidth, kWidth, wp, s);
-            launch_rows_gemm(sp, ws + p.o_xa, N, p.ldxa, p.ldxa, wp, gemm_ksteps(p.Ca, sp), Bl, 1, Z, kWidth, 0, -1, nullptr, cus, s);
-            launch_pack(sp, Wl, 1, p.in_c0, p.Ca, 0, kWidth, kWidth, kWidth, wp2, s);
-            launch_rows_gemm(sp, Hlast, N, 4 * kWidth, kWidth, wp2, gemm_ksteps(kWidth, sp), nullptr, 1, Z, kWidth, 1, act, H, cus, s);
-        } else {
-            launch_pack(sp, Wl, 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wp, s);
-            launch_rows_gemm(sp, ws + p.o_hc[l - 1], N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), Bl, 1, Z, kWidth, 0, act, H, cus, s);
-        }
+            gemm_fw(ws + p.o_xa, N, p.ldxa, p.ldxa, p.Ca, Wl, p.in_c0, 0, Bl, 1, Z, 0, -1, nullptr);
+            gemm_fw(Hlast, N, 4 * WH, WH, WH, Wl, p.in_c0, p.Ca, nullptr, 1, Z, 1, act, H);
+        } else
+            gemm_fw(ws + p.o_hc[l - 1], N, WH, WH, WH, Wl, WH, 0, Bl, 1, Z, 0, act, H);
     }
-    NarrowW cout{};
-    cout.nc = 3; cout.wstride = 1; cout.kcount = kWidth;
-    for (int c = 0; c < 3; ++c) { cout.w[c] = W[p.i_cout] + c * kWidth; cout.b[c] = B[p.i_cout] + c; }
-    launch_narrow_forward(ws + p.o_hc[p.n_col - 1], kWidth, N, cout, 1, ws + p.o_zo, kLdNarrow, s);
+    for (int kb = 0; kb < NBK; ++kb) {
+        NarrowW cout{};
+        cout.nc = 3; cout.wstride = 1; cout.kcount = kWidth;
+        for (int c = 0; c < 3; ++c) { cout.w[c] = W[p.i_cout] + c * WH + kb * kWidth; cout.b[c] = kb == 0 ? B[p.i_cout] + c : nullptr; }
+        launch_narrow_forward(ws + p.o_hc[p.n_col - 1] + kb * kWidth, WH, N, cout, 1, ws + p.o_zo, kLdNarrow, s, 0, kb > 0);
+    }
     if (color) launch_neus_color_forward(a, s);
     HIPCHK(hipGetLastError());
     return 0;
@@ -423,51 +430,71 @@ int neus_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors
     NeusPlan p;
     if (int rc = make_neus_plan(ctx, slot, N, n_tensors, p)) return rc;
     const Field &f = ctx->field[slot];
-    const int act = f.d.activation, act4 = neus_backward_act_kind(act), cus = ctx->cus;
+    const int act = f.d.activation, act4 = neus_backward_act_kind(act), cus = ctx->cus, WH = p.WH, NBK = WH / kWidth;
     const int sp = f.d.weight_dtype == NEDDF_DTYPE_F16_SPLIT;
     if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
-    if (int rc = ensure(ctx, ctx->ttmp, ((size_t)p.R * 2 * kWidth + (size_t)N * 2 * kLdNarrow) * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->ttmp, ((size_t)p.R * 2 * WH + (size_t)N * 2 * kLdNarrow) * sizeof(float))) return rc;
     float *wp = (float *)ctx->tpack.p;
-    float *dA = (float *)ctx->ttmp.p, *dB = dA + (size_t)p.R * kWidth, *GC = dB + (size_t)p.R * kWidth, *DG = GC + (size_t)N * kLdNarrow;
+    float *dA = (float *)ctx->ttmp.p, *dB = dA + (size_t)p.R * WH, *GC = dB + (size_t)p.R * WH, *DG = GC + (size_t)N * kLdNarrow;
     const float *PE = ws + p.o_pe, *Hlast = ws + p.o_h[p.n_sdf - 1];
     NeusPointArgs a;
     neus_point_args(a, f, p, W, ws);
     a.g_sdf = g_sdf; a.g_density = g_density; a.g_color = g_color;
     a.GC = GC; a.g_variance = gW[p.i_var];
     launch_neus_color_backward(a, s);               // GC = g_color a'(ZC); variance gradient
-    // colour trunk, value rows ([N, 256] matrices; dA holds dZ of the layer in flight)
-    NarrowW cout{};
-    cout.nc = 3; cout.wstride = 1; cout.kcount = kWidth;
-    for (int c = 0; c < 3; ++c) cout.w[c] = W[p.i_cout] + c * kWidth;
     AmaxSlots am;
     if (int rc = amax_begin(ctx, sp, am, s)) return rc;
     float *mA = am.take();          // max |dA| of the gradient matrix currently in dA
-    launch_narrow_backward_act(GC, kLdNarrow, N, cout, nullptr, 0, act, 1, ws + p.o_zc[p.n_col - 1], dA, kWidth, s, mA);
-    {
-        float *wc[3] = { gW[p.i_cout], gW[p.i_cout] + kWidth, gW[p.i_cout] + 2 * kWidth }, *bc[3] = { gB[p.i_cout], gB[p.i_cout] + 1, gB[p.i_cout] + 2 };
-        launch_narrow_dw(ws + p.o_hc[p.n_col - 1], kWidth, GC, kLdNarrow, N, 3, wc, 1, bc, 1, kWidth, s);
+    // gW[n, col_off + k] += dA[rows, WH]^T X[rows, Kin] in 256 x 256 blocks (+ the bias gradient with the first K block)
+    auto dw_blocks = [&](const float *X, int64_t rows, int ldx, int Kin, float *gWl, int in_total, int col_off, float *gBl, int period) {
+        const int KB = Kin <= kWidth ? 1 : Kin / kWidth, kc = Kin <= kWidth ? Kin : kWidth;
+        for (int nb = 0; nb < NBK; ++nb)
+            for (int kb = 0; kb < KB; ++kb)
+                launch_dw(sp, X + kb * kWidth, ldx, kc, dA + nb * kWidth, WH, rows, gWl + (size_t)nb * kWidth * in_total + col_off + kb * kWidth, 1, in_total, kWidth,
+                          (kb == 0 && gBl) ? gBl + nb * kWidth : nullptr, period, cus, s, mA, am.dw_tmp);
+    };
+    // dB[rows, WH] = actback(Zprev; dA x (input columns k_off .. k_off + WH of the [WH, in_total] weight)) (act_kind < 0: no activation)
+    auto gemm_bw = [&](int64_t rows, const float *Wsrc, int in_total, int k_off, int period, int act_kind, const float *Zprev, float *mB) {
+        for (int nb = 0; nb < NBK; ++nb)
+            for (int kb = 0; kb < NBK; ++kb) {
+                launch_pack(sp, Wsrc, in_total, 1, kb * kWidth, k_off + nb * kWidth, kWidth, kWidth, kWidth, wp, s);      // rows = outputs, columns = inputs
+                if (kb == NBK - 1 && act_kind >= 0)
+                    launch_rows_gemm_actback(sp, dA + kb * kWidth, rows, WH, kWidth, wp, gemm_ksteps(kWidth, sp), period, act_kind, Zprev + nb * kWidth,
+                                             dB + nb * kWidth, WH, cus, s, mA, mB, kb > 0);
+                else
+                    launch_rows_gemm(sp, dA + kb * kWidth, rows, WH, kWidth, wp, gemm_ksteps(kWidth, sp), nullptr, 1, dB + nb * kWidth, WH, kb > 0, -1, nullptr, cus, s, mA);
+            }
+    };
+    // colour trunk, value rows ([N, WH] matrices; dA holds dZ of the layer in flight)
+    for (int kb = 0; kb < NBK; ++kb) {
+        NarrowW cout{};
+        cout.nc = 3; cout.wstride = 1; cout.kcount = kWidth;
+        for (int c = 0; c < 3; ++c) cout.w[c] = W[p.i_cout] + c * WH + kb * kWidth;
+        launch_narrow_backward_act(GC, kLdNarrow, N, cout, nullptr, 0, act, 1, ws + p.o_zc[p.n_col - 1] + kb * kWidth, dA + kb * kWidth, WH, s, mA);
+        float *wc[3] = { gW[p.i_cout] + kb * kWidth, gW[p.i_cout] + WH + kb * kWidth, gW[p.i_cout] + 2 * WH + kb * kWidth };
+        float *bc[3] = { gB[p.i_cout], gB[p.i_cout] + 1, gB[p.i_cout] + 2 };
+        launch_narrow_dw(ws + p.o_hc[p.n_col - 1] + kb * kWidth, WH, GC, kLdNarrow, N, 3, wc, 1, kb == 0 ? bc : nullptr, 1, kWidth, s);
     }
     for (int l = p.n_col - 1; l >= 1; --l) {
-        const float *Wl = W[p.n_sdf + l];
-        launch_dw(sp, ws + p.o_hc[l - 1], kWidth, kWidth, dA, kWidth, N, gW[p.n_sdf + l], 1, kWidth, kWidth, gB[p.n_sdf + l], 1, cus, s, mA, am.dw_tmp);
-        launch_pack(sp, Wl, kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);                // rows = outputs, columns = inputs
+        dw_blocks(ws + p.o_hc[l - 1], N, WH, WH, gW[p.n_sdf + l], WH, 0, gB[p.n_sdf + l], 1);
         float *mB = am.take();
-        launch_rows_gemm_actback(sp, dA, N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 1, act, ws + p.o_zc[l - 1], dB, kWidth, cus, s, mA, mB);
+        gemm_bw(N, W[p.n_sdf + l], WH, 0, 1, act, ws + p.o_zc[l - 1], mB);
         float *t = dA; dA = dB; dB = t;
         mA = mB;
     }
-    {   // first colour layer: weights [256, pos 3 | embed_dir | gradient 3 | features 256]
+    {   // first colour layer: weights [WH, pos 3 | embed_dir | gradient 3 | features WH]
         const float *W0 = W[p.n_sdf];
         float *gW0 = gW[p.n_sdf];
-        launch_dw(sp, ws + p.o_xa, p.ldxa, p.Ca, dA, kWidth, N, gW0, 1, p.in_c0, kWidth, gB[p.n_sdf], 1, cus, s, mA, am.dw_tmp);
-        launch_dw(sp, Hlast, 4 * kWidth, kWidth, dA, kWidth, N, gW0 + p.Ca, 1, p.in_c0, kWidth, nullptr, 1, cus, s, mA, am.dw_tmp);
+        dw_blocks(ws + p.o_xa, N, p.ldxa, p.Ca, gW0, p.in_c0, 0, gB[p.n_sdf], 1);
+        dw_blocks(Hlast, N, 4 * WH, WH, gW0, p.in_c0, p.Ca, nullptr, 1);
         // of the small inputs only the normal depends on parameters: DG[n, k] = dA[n, :] . W0[:, 3 + Cdir + k]
-        NarrowW wn{};
-        wn.nc = 3; wn.wstride = p.in_c0; wn.kcount = kWidth;
-        for (int c = 0; c < 3; ++c) wn.w[c] = W0 + 3 + p.Cdir + c;
-        launch_narrow_forward(dA, kWidth, N, wn, 1, DG, kLdNarrow, s);
-        launch_pack(sp, W0, p.in_c0, 1, 0, p.Ca, kWidth, kWidth, kWidth, wp, s);
-        launch_rows_gemm(sp, dA, N, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), nullptr, 1, dB, kWidth, 0, -1, nullptr, cus, s, mA);   // dF
+        for (int kb = 0; kb < NBK; ++kb) {
+            NarrowW wn{};
+            wn.nc = 3; wn.wstride = p.in_c0; wn.kcount = kWidth;
+            for (int c = 0; c < 3; ++c) wn.w[c] = W0 + (size_t)kb * kWidth * p.in_c0 + 3 + p.Cdir + c;
+            launch_narrow_forward(dA + kb * kWidth, WH, N, wn, 1, DG, kLdNarrow, s, 0, kb > 0);
+        }
+        gemm_bw(N, W0, p.in_c0, p.Ca, 1, -1, nullptr, nullptr);      // dF
     }
     // heads: dZ of the last sdf layer on (value, Jacobian) rows
     mA = am.take();
@@ -475,16 +502,15 @@ int neus_backward(neddf_ctx *ctx, int slot, const float *const *W, int n_tensors
     launch_neus_head_backward(a, s);
     for (int l = p.n_sdf - 1; l >= 0; --l) {
         const bool wide = l > 0 && in_skips(f.d, l - 1);
-        const int in_total = l == 0 ? p.Cpe : (wide ? kWidth + p.Cpe : kWidth);
+        const int in_total = l == 0 ? p.Cpe : (wide ? WH + p.Cpe : WH);
         if (l == 0) {
-            launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, p.R, gW[0], 1, in_total, kWidth, gB[0], 4, cus, s, mA, am.dw_tmp);
+            dw_blocks(PE, p.R, kLdPe, p.Cpe, gW[0], in_total, 0, gB[0], 4);
             break;
         }
-        launch_dw(sp, ws + p.o_h[l - 1], kWidth, kWidth, dA, kWidth, p.R, gW[l], 1, in_total, kWidth, gB[l], 4, cus, s, mA, am.dw_tmp);
-        if (wide) launch_dw(sp, PE, kLdPe, p.Cpe, dA, kWidth, p.R, gW[l] + kWidth, 1, in_total, kWidth, nullptr, 4, cus, s, mA, am.dw_tmp);
-        launch_pack(sp, W[l], in_total, 1, 0, 0, kWidth, kWidth, kWidth, wp, s);
+        dw_blocks(ws + p.o_h[l - 1], p.R, WH, WH, gW[l], in_total, 0, gB[l], 4);
+        if (wide) dw_blocks(PE, p.R, kLdPe, p.Cpe, gW[l], in_total, WH, nullptr, 4);
         float *mB = am.take();
-        launch_rows_gemm_actback(sp, dA, p.R, kWidth, kWidth, wp, gemm_ksteps(kWidth, sp), 4, act4, ws + p.o_z[l - 1], dB, kWidth, cus, s, mA, mB);
+        gemm_bw(p.R, W[l], in_total, 0, 4, act4, ws + p.o_z[l - 1], mB);
         float *t = dA; dA = dB; dB = t;
         mA = mB;
     }

@@ -176,16 +176,17 @@ struct NeusPointArgs {
     const float *variance;                // device scalar (the `variance` parameter)
     const float *pos;                     // [N, 3]
     const float *Ed; int ldd;             // direction encoding [N, ldd]
-    const float *Hlast, *Zlast;           // last sdf layer, activated / pre-activation, [4N, 256] (value + Jacobian rows)
+    const float *Hlast, *Zlast;           // last sdf layer, activated / pre-activation, [4N, ldh] (value + Jacobian rows)
+    int ldh;                              // hidden width the kernels see: 256 or 512 (also the row stride of dF and dZ)
     float *XA; int ldxa;                  // colour-trunk small input [N, ldxa] = [pos | embed_dir | gradient | 0]
     const float *ZC; int ldc;             // raw colour rows [N, ldc] (cols 0..2)
     float *sdf, *density, *color;         // outputs [N], [N], [N, 3]
     // backward
     const float *g_sdf, *g_density, *g_color;
     float *GC;                            // [N, ldc]: gradient of the raw colour rows
-    const float *dF;                      // [N, 256]: gradient of the features from the colour trunk
+    const float *dF;                      // [N, ldh]: gradient of the features from the colour trunk
     const float *DG; int lddg;            // [N, lddg] (cols 0..2): gradient of the normal from the colour trunk
-    float *dZ;                            // [4N, 256]
+    float *dZ;                            // [4N, ldh]
     float *g_variance;                    // accumulated
     float *amax_out;                      // max |dZ| (range scaling of split-fp16 operands) or NULL
 };

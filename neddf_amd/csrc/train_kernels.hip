@@ -1428,11 +1428,11 @@ __global__ void neus_head_forward_kernel(NeusPointArgs a)
     if (i >= a.N * a.ldxa) return;
     const int64_t n = i / a.ldxa;
     const int c = (int)(i - n * a.ldxa);
-    const float *h = a.Hlast + n * 4 * kWidth;
+    const float *h = a.Hlast + n * 4 * a.ldh;
     float v = 0.f;
     if (c < 3) v = a.pos[n * 3 + c];
     else if (c < 3 + a.Cdir) v = a.Ed[n * a.ldd + c - 3];
-    else if (c < 6 + a.Cdir) v = h[(1 + c - 3 - a.Cdir) * kWidth];
+    else if (c < 6 + a.Cdir) v = h[(1 + c - 3 - a.Cdir) * a.ldh];
     a.XA[i] = v;
     if (c == 0) {
         const float sdf = h[0];
@@ -1480,7 +1480,7 @@ __global__ __launch_bounds__(256) void neus_color_backward_kernel(NeusPointArgs 
         for (int c = 3; c < a.ldc; ++c) gc[c] = 0.f;
         if (a.g_density) {
             float rho, ds, dv;
-            neus_density(10.0f * a.variance[0], a.Hlast[n * 4 * kWidth], rho, ds, dv);
+            neus_density(10.0f * a.variance[0], a.Hlast[n * 4 * a.ldh], rho, ds, dv);
             gv = 10.0f * a.g_density[n] * dv;
         }
     }
@@ -1493,23 +1493,24 @@ void launch_neus_color_backward(const NeusPointArgs &a, hipStream_t s)
     if (a.N > 0) hipLaunchKernelGGL(neus_color_backward_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, s, a);
 }
 
-// dZ[4N, 256] of the last sdf layer: the colour trunk's gradient of the features (dF, value rows) and of the normal (DG, feature 0
+// dZ[4N, ldh] of the last sdf layer: the colour trunk's gradient of the features (dF, value rows) and of the normal (DG, feature 0
 // of the Jacobian rows), the upstream gradients of sdf and density (feature 0 of the value row), through the last activation.
 __global__ void neus_head_backward_kernel(NeusPointArgs a, int act_kind)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.N * (kWidth / 4)) return;
-    const int64_t n = i >> 6;
-    const int c4 = (int)(i & 63);
+    const int per = a.ldh / 4;          // 64 or 128 threads per point: whole waves either way
+    if (i >= a.N * per) return;
+    const int64_t n = i / per;
+    const int c4 = (int)(i - n * per);
     const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
-    f32x4v g[4] = { *(const f32x4v *)(a.dF + n * kWidth + 4 * c4), zero, zero, zero }, z[4];
+    f32x4v g[4] = { *(const f32x4v *)(a.dF + n * a.ldh + 4 * c4), zero, zero, zero }, z[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) z[r] = *(const f32x4v *)(a.Zlast + (n * 4 + r) * kWidth + 4 * c4);
+    for (int r = 0; r < 4; ++r) z[r] = *(const f32x4v *)(a.Zlast + (n * 4 + r) * a.ldh + 4 * c4);
     if (c4 == 0) {
         float gs = a.g_sdf ? a.g_sdf[n] : 0.f;
         if (a.g_density) {
             float rho, ds, dv;
-            neus_density(10.0f * a.variance[0], a.Hlast[n * 4 * kWidth], rho, ds, dv);
+            neus_density(10.0f * a.variance[0], a.Hlast[n * 4 * a.ldh], rho, ds, dv);
             gs = fmaf(a.g_density[n], ds, gs);
         }
         g[0][0] += gs;
@@ -1519,16 +1520,16 @@ __global__ void neus_head_backward_kernel(NeusPointArgs a, int act_kind)
     float lmax = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        *(f32x4v *)(a.dZ + (n * 4 + r) * kWidth + 4 * c4) = g[r];
+        *(f32x4v *)(a.dZ + (n * 4 + r) * a.ldh + 4 * c4) = g[r];
 #pragma unroll
         for (int u = 0; u < 4; ++u) lmax = fmaxf(lmax, fabsf(g[r][u]));
     }
-    if (a.amax_out) publish_amax(a.amax_out, lmax);     // 64 threads per point: whole waves
+    if (a.amax_out) publish_amax(a.amax_out, lmax);
 }
 int neus_backward_act_kind(int act) { return act == kActTanhExp ? kActTanhExpPlain2 : act; }
 void launch_neus_head_backward(const NeusPointArgs &a, hipStream_t s)
 {
-    int64_t t = a.N * (kWidth / 4);
+    int64_t t = a.N * (a.ldh / 4);
     if (t > 0) hipLaunchKernelGGL(neus_head_backward_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, a, neus_backward_act_kind(a.act));
 }
 // ----------------------------------------------------------------------------

@@ -151,13 +151,11 @@ def wide_sampling(n_rays, n_samples, seed, reach=6.0):
 def random_arch(seed, train=False):
     """(kind, constructor keywords) of one architecture the reference's constructors accept (neddf.py:52-66, nerf.py:34-44,
     neus.py:30-41), drawn from `seed`: kinds cycle NeDDF / NeRF / NeuS; hidden width 8 .. 512, 2 .. 7 layers, up to three skip
-    connections, any activation on trunk and density head, encoding ranks 1 .. 10.  train=True keeps NeuS within what the training
-    kernels take (hidden widths up to 256)."""
+    connections, any activation on trunk and density head, encoding ranks 1 .. 10.  (`train` is kept for the callers' readability:
+    every draw trains since round 4.)"""
     rng = np.random.default_rng(seed)
     kind = ("neddf", "nerf", "neus")[seed % 3]
     widths = [8, 24, 40, 64, 72, 100, 128, 160, 200, 256, 264, 320, 384, 448, 512]
-    if train and kind == "neus":
-        widths = widths[:10]
     width = int(rng.choice(widths))
     n = int(rng.integers(2, 8))
     # a skip index names a hidden layer that is followed by another: NeRF / NeuS have n of them, NeDDF n - 1 (its `ddf_layer_count`
@@ -174,7 +172,7 @@ def random_arch(seed, train=False):
     if kind == "nerf":
         return kind, dict(embed_pos_rank=E, embed_dir_rank=Ed, layer_count=n, layer_width=width + (width & 1), activation_type=act,
                           density_activation_type=dact, skips=skips, lowpass_alpha_offset=10)
-    wc = int(rng.choice([16, 64, 128, 256] + ([] if train else [320, 512])))
+    wc = int(rng.choice([16, 64, 128, 256, 320, 512]))
     return kind, dict(embed_pos_rank=E, embed_dir_rank=Ed, sdf_layer_count=n, sdf_layer_width=width, col_layer_count=int(rng.integers(1, 5)),
                       col_layer_width=wc, init_variance=float(rng.uniform(0.1, 0.6)), activation_type=str(rng.choice(["ReLU", "tanhExp"])), skips=skips)
 

@@ -139,11 +139,11 @@ class BaseNeuralField(ABC, nn.Module):
 
     # ---- training at hidden widths other than 256 ---------------------------------------------------------------------
     # The training kernels are built for hidden width 256 (every field kind) and, on their per-layer route in 256 x 256 blocks,
-    # 512 (NeDDF, NeRF; csrc/train_capi.hip train_supported).  Any other width trains ZERO-PADDED to the next of the two: every parameter
+    # 512 (csrc/train_capi.hip train_supported).  Any other width trains ZERO-PADDED to the next of the two: every parameter
     # tensor is padded with differentiable torch ops (narrow / cat), the kernels see the padded network, and autograd slices the
     # parameter gradients back.  Exact: a padded unit has zero weights and bias, so it outputs a(0) = 0 under every activation of
     # the reference, feeds zero weight rows downstream and receives a zero gradient; the real parameters' gradients are what the
-    # reference computes (tests/golden/train_widths.npz: 128 / 192 / 384 / 512).  NeuS above 256 and anything above 512 are
+    # reference computes (tests/golden/train_widths.npz: 128 / 192 / 384 / 512).  Anything above 512 is
     # refused by the library.
     def _train_layout(self):
         """None, or (weight layouts, bias layouts): per tensor, per axis, the [(length, padded_length)] segments."""
@@ -443,9 +443,12 @@ class NeuS(BaseNeuralField):
         dummy = torch.zeros(1)
         return [m.weight for m in mods] + [self.variance.reshape(1)], [m.bias for m in mods] + [dummy]
 
+    def _train_engine_width(self) -> int:
+        return TRAIN_ENGINE_WIDTH if max(self.sdf_layer_width, self.col_layer_width) <= TRAIN_ENGINE_WIDTH else 2 * TRAIN_ENGINE_WIDTH
+
     def _train_layout(self):
-        Ws, Wc, E = self.sdf_layer_width, self.col_layer_width, TRAIN_ENGINE_WIDTH
-        if (Ws >= E and Wc >= E) or Ws > E or Wc > E:
+        Ws, Wc, E = self.sdf_layer_width, self.col_layer_width, self._train_engine_width()
+        if (Ws >= E and Wc >= E) or Ws > E or Wc > E:     # both at E: no padding; wider than 512: the library refuses
             return None
         cpe, small = 6 * self.pe_pos.embed_dim, 6 + 6 * self.pe_dir.embed_dim
         hs, hc, same = [(Ws, E)], [(Wc, E)], lambda n: [(n, n)]

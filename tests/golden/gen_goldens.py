@@ -892,14 +892,14 @@ def gen_train_wide_nerf():
 
 
 def gen_train_random():
-    """Thirty architectures drawn at random from what the reference's constructors accept (synth.random_arch(seed, train=True): field kind,
+    """Forty-two architectures drawn at random from what the reference's constructors accept (synth.random_arch(seed, train=True): field kind,
     hidden width 8 .. 512, 2 .. 7 layers, up to three skips, any activation, encoding ranks 1 .. 10) through the reference's own
     forward + backward (NeDDF: hand-written (value, Jacobian) backward passes; NeRF: autograd; NeuS: double backward) with random
     upstream gradients on every output, a ragged number of points each.  Per parameter tensor: gradient norm + one random projection."""
     arrs = {}
     kinds = {"neddf": (NeDDF, ("distance", "density", "color", "fields_penalty", "aux_grad"), 2500),
              "nerf": (NeRF, ("density", "color"), 1500), "neus": (NeuS, ("sdf", "density", "color"), None)}
-    for seed in range(100, 130):
+    for seed in range(100, 142):
         kind, kw = synth.random_arch(seed, train=True)
         cls, keys, it = kinds[kind]
         rng = np.random.default_rng(5000 + seed)
