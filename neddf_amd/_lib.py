@@ -137,6 +137,22 @@ def require_device(t, what):
         raise NeddfError("%s must live on a HIP device (got %s); the MI355X path has no CPU fallback" % (what, t.device))
 
 
+# NEDDF_GUARD=1 (the bounds probe, include/neddf_hip.h neddf_debug_check_guards): the buffers the CALLER hands to the training entry
+# points -- the workspace and the gradient tensors -- get poisoned bands of their own, checked after every call
+_GUARD = os.environ.get("NEDDF_GUARD", "0") == "1"
+_GUARD_WORDS, _GUARD_PATTERN = 1024, 0x5AD0BEEF
+
+
+def _guard_fill(t):
+    t.view(torch.int32).fill_(_GUARD_PATTERN)
+
+
+def _guard_check(t, what):
+    bad = int((t.view(torch.int32) != _GUARD_PATTERN).sum().item())
+    if bad:
+        raise NeddfError("NEDDF_GUARD: %d word(s) written beyond %s" % (bad, what))
+
+
 def f32c(t):
     return t.contiguous() if t.dtype == torch.float32 else t.to(torch.float32).contiguous()
 
@@ -383,13 +399,21 @@ class Context:
         def buf(*shape):
             return torch.empty(*shape, device=dev, dtype=torch.float32)
 
-        ws = buf(max(int(n_ws), 1))
+        n_ws = max(int(n_ws), 1)
+        if _GUARD:
+            full = buf(n_ws + _GUARD_WORDS)
+            _guard_fill(full[n_ws:])
+            ws = full[:n_ws]            # ws._base is `full`: train_field_backward checks the band again
+        else:
+            ws = buf(n_ws)
         density, color = buf(N), buf(N, 3)
         distance, pen, aux = (None, None, None) if radiance_only else ((buf(N), None, None) if sdf else (buf(N), buf(N), buf(N)))
         wa, ba = self._dev_ptrs(weights, "weights"), self._dev_ptrs(biases, "biases")
         self.check(self.lib.neddf_train_field_forward(self.h, slot, wa, ba, len(weights), _ptr(pos), _ptr(dir), _ptr(var), N,
                                                       _ptr(ws), _ptr(distance), _ptr(density), _ptr(color), _ptr(pen), _ptr(aux),
                                                       self.stream()))
+        if _GUARD:
+            _guard_check(ws._base[n_ws:], "the training workspace (forward)")
         return ws, distance, density, color, pen, aux
 
     def train_field_backward(self, slot, weights, biases, N, ws, g_distance, g_density, g_color, g_penalty, g_aux):
@@ -397,16 +421,26 @@ class Context:
         gs = [None if g is None else f32c(g) for g in (g_distance, g_density, g_color, g_penalty, g_aux)]
         # one zero fill for all gradients (the kernels accumulate into them): views into a flat buffer, 16-byte aligned pieces
         offs, at = [], 0
+        gap = 64 if _GUARD else 0       # guard mode: a poisoned band behind every gradient tensor
         for t in list(weights) + list(biases):
             offs.append(at)
-            at += (t.numel() + 3) & ~3
+            at += ((t.numel() + 3) & ~3) + gap
         flat = torch.zeros(at, device=weights[0].device, dtype=torch.float32)
         views = [flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, list(weights) + list(biases))]
+        if _GUARD:
+            for o, t in zip(offs, list(weights) + list(biases)):
+                _guard_fill(flat[o + ((t.numel() + 3) & ~3):o + ((t.numel() + 3) & ~3) + gap])
         gw, gb = views[:len(weights)], views[len(weights):]
         wa, ba = self._dev_ptrs(weights, "weights"), self._dev_ptrs(biases, "biases")
         gwa, gba = self._dev_ptrs(gw, "weight gradients"), self._dev_ptrs(gb, "bias gradients")
         self.check(self.lib.neddf_train_field_backward(self.h, slot, wa, ba, len(weights), N, _ptr(ws), _ptr(gs[0]), _ptr(gs[1]),
                                                        _ptr(gs[2]), _ptr(gs[3]), _ptr(gs[4]), gwa, gba, self.stream()))
+        if _GUARD:
+            for i, (o, t) in enumerate(zip(offs, list(weights) + list(biases))):
+                e = o + ((t.numel() + 3) & ~3)
+                _guard_check(flat[e:e + gap], "gradient tensor %d" % i)
+            if ws._base is not None:
+                _guard_check(ws._base[ws.numel():], "the training workspace (backward)")
         return gw, gb
 
     def composite_backward(self, dists, density, color, max_dist, g_weight, g_depth, g_color, g_trans):

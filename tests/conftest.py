@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _bounds_probe_after_each_test():
+    """Under NEDDF_GUARD=1 (the bounds probe that stands in for a GPU-side sanitizer) every test is followed by a check of every
+    poisoned band of every context: `NEDDF_GUARD=1 python -m pytest tests -m gpu` turns the whole suite into an out-of-bounds sweep."""
+    yield
+    if os.environ.get("NEDDF_GUARD", "0") != "1":
+        return
+    from neddf_amd._lib import Context
+    for ctx in list(Context._instances.values()):
+        bands, bad = ctx.check_guards()
+        assert bad == 0, "NEDDF_GUARD: %d byte(s) written into %d guard bands" % (bad, bands)
+
+
 def golden(name):
     if name == "bunny_weights.npz":         # ships with the product (bench.py / smoke() measure on it): neddf_amd/fixtures
         from neddf_amd.fixtures import BUNNY_SMOKE_WEIGHTS
