@@ -904,32 +904,40 @@ struct NarrowGrad {
     float *b[4];          // scalar bias gradients (or NULL)
     int kcount;           // input features present (<= 256)
 };
-template <bool PM>      // PM: X point-major (ld 256); rows_per_wg is a multiple of 4
+template <bool PM>      // PM: X point-major (ld 256); rows_per_wg is a multiple of 16
 __global__ __launch_bounds__(kThreads) void narrow_dw_kernel(const float *X, int ldx, const float *G, int ldg, int64_t R, int64_t rows_per_wg,
                                                              NarrowGrad o, int bias_period)
 {
     const int k = threadIdx.x;
     const int64_t rb = (int64_t)blockIdx.x * rows_per_wg, re = rb + rows_per_wg < R ? rb + rows_per_wg : R;
     float acc[4] = { 0.f, 0.f, 0.f, 0.f }, bs[4] = { 0.f, 0.f, 0.f, 0.f };
-    for (int64_t r0 = rb; r0 < re; r0 += 4) {           // four independent row loads in flight
-        float x[4];
+    for (int64_t r0 = rb; r0 < re; r0 += 16) {          // sixteen rows (four points) per pass: four independent 16-byte loads in flight
+        float x[16];
         if (PM) {
-            const f32x4v v = *(const f32x4v *)(X + (r0 >> 2) * (4 * kWidth) + 4 * k);      // R is a multiple of 4: the point is whole
 #pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = v[u];
+            for (int pt = 0; pt < 4; ++pt) {
+                const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
+                const f32x4v v = r0 + 4 * pt < re ? *(const f32x4v *)(X + ((r0 >> 2) + pt) * (4 * kWidth) + 4 * k) : zero;     // R is a multiple of 4: points are whole
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[4 * pt + u] = v[u];
+            }
         } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = r0 + u < re ? X[(r0 + u) * ldx + k] : 0.f;
+            for (int u = 0; u < 16; ++u) x[u] = r0 + u < re ? X[(r0 + u) * ldx + k] : 0.f;
         }
+        // the sixteen rows of G (ldg = 4: 64 floats) as ONE coalesced load per wave, broadcast with readlane: per-thread loads of the
+        // same address would be 16 x nc more vector-memory instructions than the X stream itself
+        float gl = 0.f;
+        if (ldg == 4) { const int64_t gi = r0 * 4 + (k & 63); gl = gi < re * 4 ? G[gi] : 0.f; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const int64_t r = r0 + u;
             if (r >= re) break;
             const bool vr = ((int)r & (bias_period - 1)) == 0;      // bias_period is 1 or 4
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (c < o.nc) {
-                    float g = G[r * ldg + c];
+                    const float g = ldg == 4 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl), u * 4 + c)) : G[r * ldg + c];
                     acc[c] = fmaf(x[u], g, acc[c]);
                     if (vr) bs[c] += g;
                 }
@@ -947,9 +955,11 @@ void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t 
     NarrowGrad o{};
     o.nc = nc; o.wstride = wstride; o.kcount = kcount;
     for (int c = 0; c < nc; ++c) { o.w[c] = w[c]; o.b[c] = b ? b[c] : nullptr; }
+    // every workgroup ends with 256 x nc same-address atomics into the one gradient: few, long workgroups (four per CU keep 64 KB of
+    // loads in flight per CU, enough for the HBM rate) instead of many short ones
     int grid = (int)((R + 255) / 256);
-    if (grid > 4096) grid = 4096;
-    int64_t rows_per_wg = ((R + grid - 1) / grid + 3) & ~(int64_t)3;
+    if (grid > 1024) grid = 1024;
+    int64_t rows_per_wg = ((R + grid - 1) / grid + 15) & ~(int64_t)15;
     if (x_point_major) hipLaunchKernelGGL(narrow_dw_kernel<true>, dim3(grid), dim3(kThreads), 0, s, X, ldx, G, ldg, R, rows_per_wg, o, bias_period);
     else hipLaunchKernelGGL(narrow_dw_kernel<false>, dim3(grid), dim3(kThreads), 0, s, X, ldx, G, ldg, R, rows_per_wg, o, bias_period);
 }
@@ -1583,7 +1593,35 @@ void launch_pack(int split, const float *src, int64_t sk, int64_t sn, int k_off,
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, src, sk, sn, k_off, n_off, kcount, ncount, nout, ks, dst);
 }
 
-// narrow heads (1..4 output columns from a 256-wide input): one wavefront per row
+// narrow heads (1..4 output columns from a 256-wide input): one wavefront per four rows.  A lane holds four features of each row, so
+// the wave has 16 partial sums per lane (4 rows x 4 columns) to add across 64 lanes: a reduce-scatter butterfly (xor 32, 16, 8, 4: each
+// step sends half of the lane's values to the partner and keeps the other half) leaves ONE value per lane after 15 exchanges, two plain
+// steps finish it -- 17 cross-lane moves instead of 96.  Value u * 4 + c ends in the lanes whose bits 5..2 spell it.
+__device__ __forceinline__ float narrow_reduce16(float (&v)[16], int lane)
+{
+    float a8[8], a4[4], a2[2];
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float keep = b5 ? v[8 + i] : v[i], send = b5 ? v[i] : v[8 + i];
+        a8[i] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b4 ? a8[4 + i] : a8[i], send = b4 ? a8[i] : a8[4 + i];
+        a4[i] = keep + __shfl_xor(send, 16, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b3 ? a4[2 + i] : a4[i], send = b3 ? a4[i] : a4[2 + i];
+        a2[i] = keep + __shfl_xor(send, 8, 64);
+    }
+    float r = (b2 ? a2[1] : a2[0]) + __shfl_xor(b2 ? a2[0] : a2[1], 4, 64);
+    r += __shfl_xor(r, 2, 64);
+    r += __shfl_xor(r, 1, 64);
+    return r;
+}
+
 template <bool PM>      // PM: X point-major (ld 256, R a multiple of 4): the wave's four rows are one point
 __global__ __launch_bounds__(256) void narrow_forward_kernel(const float *X, int ldx, int64_t R, NarrowW w, int bias_period, float *Y, int ldy, int accumulate)
 {
@@ -1593,38 +1631,42 @@ __global__ __launch_bounds__(256) void narrow_forward_kernel(const float *X, int
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int q = 0; q < 4; ++q) wv[c][q] = (c < w.nc && 4 * lane + q < w.kcount) ? w.w[c][(size_t)(4 * lane + q) * w.wstride] : 0.f;
+    // the value this lane ends up with: row `mu` of the group, output column `mc`
+    const int idx = ((lane >> 5) & 1) << 3 | ((lane >> 4) & 1) << 2 | ((lane >> 3) & 1) << 1 | ((lane >> 2) & 1), mu = idx >> 2, mc = idx & 3;
+    const float mbias = (mc < w.nc && w.b[mc]) ? w.b[mc][0] : 0.f;
     const int64_t nw = (int64_t)gridDim.x * 4, w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    for (int64_t base = w0 * 4; base < R; base += nw * 4) {         // four rows per wave per pass
-        f32x4v x[4];
+    const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
+    auto fetch = [&](int64_t base, f32x4v (&x)[4]) {        // PM: x[q] = the four rows of feature 4 lane + q; else x[u] = four features of row u
         if (PM) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {       // feature 4 lane + q: its four rows
-                const f32x4v v = *(const f32x4v *)(X + (base >> 2) * (4 * kWidth) + 4 * (4 * lane + q));
-#pragma unroll
-                for (int u = 0; u < 4; ++u) x[u][q] = v[u];
-            }
+            for (int q = 0; q < 4; ++q) x[q] = base < R ? *(const f32x4v *)(X + (base >> 2) * (4 * kWidth) + 4 * (4 * lane + q)) : zero;
         } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
-                x[u] = base + u < R ? *(const f32x4v *)(X + (base + u) * ldx + 4 * lane) : zero;
-            }
+            for (int u = 0; u < 4; ++u) x[u] = base + u < R ? *(const f32x4v *)(X + (base + u) * ldx + 4 * lane) : zero;
         }
+    };
+    f32x4v xn[4];
+    fetch(w0 * 4, xn);
+    for (int64_t base = w0 * 4; base < R; base += nw * 4) {         // four rows per wave per pass, the next four in flight
+        f32x4v x[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (base + u >= R) break;
-            for (int c = 0; c < w.nc; ++c) {
-                float s = 0.f;
+        for (int q = 0; q < 4; ++q) x[q] = xn[q];
+        fetch(base + nw * 4, xn);
+        float v[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) s = fmaf(x[u][q], wv[c][q], s);
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-                if (lane == 0) {         // accumulate: the input is wider than 256 columns and this call adds one more 256-column block
-                    float *y = Y + (base + u) * ldy + c;
-                    const float v = s + ((w.b[c] && ((int)(base + u) & (bias_period - 1)) == 0) ? w.b[c][0] : 0.f);
-                    *y = accumulate ? *y + v : v;
-                }
+            for (int c = 0; c < 4; ++c) {
+                float sum = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sum = fmaf(PM ? x[q][u] : x[u][q], wv[c][q], sum);
+                v[u * 4 + c] = sum;
             }
+        const float r = narrow_reduce16(v, lane);
+        if ((lane & 3) == 0 && mc < w.nc && base + mu < R) {        // accumulate: the input is wider than 256 columns and this call adds one more block
+            float *y = Y + (base + mu) * ldy + mc;
+            const float val = r + ((((int)(base + mu) & (bias_period - 1)) == 0) ? mbias : 0.f);
+            *y = accumulate ? *y + val : val;
         }
     }
 }
