@@ -911,33 +911,58 @@ __global__ __launch_bounds__(kThreads) void narrow_dw_kernel(const float *X, int
     const int k = threadIdx.x;
     const int64_t rb = (int64_t)blockIdx.x * rows_per_wg, re = rb + rows_per_wg < R ? rb + rows_per_wg : R;
     float acc[4] = { 0.f, 0.f, 0.f, 0.f }, bs[4] = { 0.f, 0.f, 0.f, 0.f };
-    for (int64_t r0 = rb; r0 < re; r0 += 16) {          // sixteen rows (four points) per pass: four independent 16-byte loads in flight
-        float x[16];
-        if (PM) {
+    if (PM && ldg == 4) {
+        // Sixteen rows (four points) per pass, the next sixteen in flight; the rows of G (64 floats) as ONE coalesced load per wave,
+        // broadcast with readlane (per-thread loads of the same address would be 16 x nc more vector-memory instructions than the X
+        // stream itself).  Rows beyond `re` read as zero (R is a multiple of 4: points are whole), so the loop has no branches.
+        const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
+        f32x4v xn[4];
+        float gn;
+        auto fetch = [&](int64_t r0) {
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
-                const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
-                const f32x4v v = r0 + 4 * pt < re ? *(const f32x4v *)(X + ((r0 >> 2) + pt) * (4 * kWidth) + 4 * k) : zero;     // R is a multiple of 4: points are whole
+            for (int pt = 0; pt < 4; ++pt) xn[pt] = r0 + 4 * pt < re ? *(const f32x4v *)(X + ((r0 >> 2) + pt) * (4 * kWidth) + 4 * k) : zero;
+            const int64_t gi = r0 * 4 + (k & 63);
+            gn = gi < re * 4 ? G[gi] : 0.f;
+        };
+        fetch(rb);
+        for (int64_t r0 = rb; r0 < re; r0 += 16) {
+            f32x4v x[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) x[4 * pt + u] = v[u];
+            for (int pt = 0; pt < 4; ++pt) x[pt] = xn[pt];
+            const int gl = __builtin_bit_cast(int, gn);
+            fetch(r0 + 16);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const bool vr = (u & (bias_period - 1)) == 0;       // bias_period is 1 or 4; r0 is a multiple of 16
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < o.nc) {
+                        const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gl, u * 4 + c));
+                        acc[c] = fmaf(x[u >> 2][u & 3], g, acc[c]);
+                        bs[c] += vr ? g : 0.f;
+                    }
             }
+        }
+    } else
+    for (int64_t r0 = rb; r0 < re; r0 += 4) {
+        float x[4];
+        if (PM) {
+            const f32x4v v = *(const f32x4v *)(X + (r0 >> 2) * (4 * kWidth) + 4 * k);      // R is a multiple of 4: the point is whole
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = v[u];
         } else {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) x[u] = r0 + u < re ? X[(r0 + u) * ldx + k] : 0.f;
+            for (int u = 0; u < 4; ++u) x[u] = r0 + u < re ? X[(r0 + u) * ldx + k] : 0.f;
         }
-        // the sixteen rows of G (ldg = 4: 64 floats) as ONE coalesced load per wave, broadcast with readlane: per-thread loads of the
-        // same address would be 16 x nc more vector-memory instructions than the X stream itself
-        float gl = 0.f;
-        if (ldg == 4) { const int64_t gi = r0 * 4 + (k & 63); gl = gi < re * 4 ? G[gi] : 0.f; }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const int64_t r = r0 + u;
             if (r >= re) break;
             const bool vr = ((int)r & (bias_period - 1)) == 0;      // bias_period is 1 or 4
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (c < o.nc) {
-                    const float g = ldg == 4 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl), u * 4 + c)) : G[r * ldg + c];
+                    float g = G[r * ldg + c];
                     acc[c] = fmaf(x[u], g, acc[c]);
                     if (vr) bs[c] += g;
                 }
@@ -955,10 +980,9 @@ void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t 
     NarrowGrad o{};
     o.nc = nc; o.wstride = wstride; o.kcount = kcount;
     for (int c = 0; c < nc; ++c) { o.w[c] = w[c]; o.b[c] = b ? b[c] : nullptr; }
-    // every workgroup ends with 256 x nc same-address atomics into the one gradient: few, long workgroups (four per CU keep 64 KB of
-    // loads in flight per CU, enough for the HBM rate) instead of many short ones
+    // every workgroup ends with 256 x nc same-address atomics into the one gradient: few, long workgroups (eight per CU) instead of many short ones
     int grid = (int)((R + 255) / 256);
-    if (grid > 1024) grid = 1024;
+    if (grid > 2048) grid = 2048;
     int64_t rows_per_wg = ((R + grid - 1) / grid + 15) & ~(int64_t)15;
     if (x_point_major) hipLaunchKernelGGL(narrow_dw_kernel<true>, dim3(grid), dim3(kThreads), 0, s, X, ldx, G, ldg, R, rows_per_wg, o, bias_period);
     else hipLaunchKernelGGL(narrow_dw_kernel<false>, dim3(grid), dim3(kThreads), 0, s, X, ldx, G, ldg, R, rows_per_wg, o, bias_period);
