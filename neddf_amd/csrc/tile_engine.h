@@ -162,7 +162,10 @@ struct OpsF16SplitT {
     typedef hfrag2 afrag;
     typedef hfrag2 bfrag;
     static constexpr int kPlanes = 2, kPlane = WID + 8;
-    static constexpr int kLd = 2 * (WID + 8);
+    // row = [first terms: WID + 8 | remainders: WID + 8 | 8 of padding]: 2 (WID + 8) halves alone are a stride of 8 dwords mod 64 and
+    // the sixteen rows of a ds_read_b128 wave quarter hit each bank twice (34 % of this policy's LDS cycles were conflicts,
+    // profiles/r04_pmc_c2_slab.csv); with the padding the stride is 12 dwords mod 64 and the sixteen 16-byte fragments tile the 64 banks
+    static constexpr int kLd = 2 * (WID + 8) + 8;
     static constexpr int kStep = 16;
     static constexpr int kSub = 3;
     static constexpr bool kFast = false;
