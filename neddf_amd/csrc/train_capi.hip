@@ -9,7 +9,6 @@
 #include "capi_internal.h"
 #include "train_kernels.h"
 
-#include <cstring>
 #include <stdlib.h>
 
 namespace {
@@ -731,10 +730,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         cout.nc = 3; cout.wstride = 3; cout.kcount = kWidth;
         for (int c = 0; c < 3; ++c) cout.w[c] = W[p.i_cout] + c;
         const float *HClast = ws + p.o_hc[nC - 1], *Hlast = ws + p.o_h[nT - 1];
-        // the heads' weight gradients ride in the chains' prologues (MlpBackwardArgs.top_dw); NEDDF_TRAIN_HEADS_DW=separate keeps the
-        // stand-alone kernel (one more pass over H_top) for A/B measurements
-        static const bool heads_sep = [] { const char *e = getenv("NEDDF_TRAIN_HEADS_DW"); return e && !strcmp(e, "separate"); }();
-        if (heads_sep) {
+        {
             float *wc[3] = { gW[p.i_cout], gW[p.i_cout] + 1, gW[p.i_cout] + 2 }, *bc[3] = { gB[p.i_cout], gB[p.i_cout] + 1, gB[p.i_cout] + 2 };
             launch_narrow_dw(HClast, kWidth, GCR, kLdNarrow, p.R, 3, wc, 3, bc, 4, kWidth, s, 1);
         }
@@ -743,10 +739,6 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
             m.R = p.R; m.n_layers = nC; m.act_kind = act;
             // prologue: dZ of the last colour layer = activation backward of the head's upstream gradient (3 raw colour columns)
             m.top_G = GCR; m.top_ldg = kLdNarrow; m.top_nc = 3; m.top_wstride = 3;
-            if (!heads_sep) {
-                m.top_dwstride = 3;
-                for (int c = 0; c < 3; ++c) { m.top_dw[c] = gW[p.i_cout] + c; m.top_db[c] = gB[p.i_cout] + c; }
-            }
             for (int c = 0; c < 3; ++c) m.top_w[c] = cout.w[c];
             m.top_Z = ws + p.o_zc[nC - 1]; m.top_out = dZc(nC - 1);
             for (int l = 1; l < nC; ++l) {
@@ -760,17 +752,13 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
             dwj.add(ws + p.o_hc[l - 1], kWidth, kWidth, 1, dZc(l), kWidth, gW[nT + l], kWidth, 1, kWidth, gB[nT + l], 4);
         dwj.add(ws + p.o_xa, p.ldxa, p.Ca, 0, dZc(0), kWidth, gW[nT], kWidth, 1, kWidth, gB[nT], 4);
         dwj.add(Hlast, kWidth, kWidth, 1, dZc(0), kWidth, gW[nT] + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4);
-        if (heads_sep) {
+        {
             float *wh[2] = { gW[p.i_ddf], gW[p.i_aux] }, *bh[2] = { gB[p.i_ddf], gB[p.i_aux] };
             launch_narrow_dw(Hlast, kWidth, GZH, kLdNarrow, p.R, 2, wh, 1, bh, 4, kWidth, s, 1);
         }
         {   // distance trunk
             MlpBackwardArgs m{};
             m.R = p.R; m.n_layers = nT; m.act_kind = act;
-            if (!heads_sep) {
-                m.top_dwstride = 1;
-                m.top_dw[0] = gW[p.i_ddf]; m.top_dw[1] = gW[p.i_aux]; m.top_db[0] = gB[p.i_ddf]; m.top_db[1] = gB[p.i_aux];
-            }
             // prologue: dZ of the last trunk layer = activation backward of (gradient of the features from the colour trunk -- only the
             // feature segment of its first layer propagates: the small colour inputs carry no parameters -- + the distance / aux heads)
             float *wf = next_pack();

@@ -97,10 +97,6 @@ struct MlpBackwardArgs {
     const float *top_G; int top_ldg, top_nc;              // narrow upstream gradient [R, top_ldg], top_nc <= 3 columns (the heads' raw outputs)
     const float *top_w[3]; int top_wstride;               // column c of the heads' weights: top_w[c][feature * top_wstride]
     const float *top_Z;                   // pre-activations of the top layer [R, 256]
-    // optional: the heads' own weight / bias gradients, taken in the same prologue (H_top = a(Z_top) is recomputed from the Z the
-    // prologue loads anyway: no second pass over an [R, 256] matrix): top_dw[c][feature * top_dwstride] += sum_r H_top[r, feature] top_G[r, c],
-    // top_db[c] += sum over value rows of top_G[r, c]
-    float *top_dw[3]; int top_dwstride; float *top_db[3];
     float *top_out;                       // [R, 256]
     int n_layers;
     const float *wT[kMaxLayers];          // [l >= 1] packed (hidden rows of W_l)^T, 256 x 256

@@ -532,7 +532,6 @@ __device__ __forceinline__ void mlp_backward_epilogue(const f32x16 (&acc)[2][2],
         }
 }
 
-constexpr int kHeadSumFloats = 3 * kWidth + 4;      // LDS behind the tile: the heads' weight-gradient sums [3][256] + three bias sums
 template <int KIND>      // backward kind of the stack's activation: one straight-line epilogue per kernel, not four behind run-time branches
 __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBackwardArgs a)
 {
@@ -545,14 +544,6 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
     const float *act_lane = act_lane_ptr<Ops>(act, lane);
     const int j = lane & 31, h = lane >> 5;
     const int64_t ntiles = (a.R + ROWS - 1) / ROWS;
-    // the heads' weight gradients of this workgroup's tiles (top_dw) are summed in LDS behind the tile ([head][column], then the three
-    // bias sums): registers that lived through the layer loop would spill there
-    float *hsum = smem + ROWS * LD;
-    const bool heads_dw = a.top_dw[0] != nullptr;
-    if (heads_dw) {
-        for (int i = tid; i < kHeadSumFloats; i += kThreads) hsum[i] = 0.f;
-        __syncthreads();
-    }
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * ROWS;
         __syncthreads();                // the previous tile is done with the LDS tile
@@ -588,40 +579,6 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
             // colour trunk's feature gradient + a kernel that adds the heads and applies the top activation's backward)
             f32x16 zp[MT][NT], acc[MT][NT];
             load_z(a.top_Z, zp);
-            if (heads_dw) {             // before the accumulators are live: H_top rows of a point = (y, y' z1, y' z2, y' z3) (the forward's
-                float sw[3][NT] = { { 0.f, 0.f }, { 0.f, 0.f }, { 0.f, 0.f } }, sb[3] = { 0.f, 0.f, 0.f };      // epilogue), dotted with its G rows
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float gv[4][3];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int64_t row = r0 + mt * 32 + 8 * g + 4 * h + r;
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) gv[r][c] = (c < a.top_nc && row < a.R) ? a.top_G[row * a.top_ldg + c] : 0.f;
-                        }
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            float y, dy;
-                            act_grad<(KIND == 3 ? 2 : KIND)>(zp[mt][t][4 * g], y, dy);
-                            const float hv[4] = { y, dy * zp[mt][t][4 * g + 1], dy * zp[mt][t][4 * g + 2], dy * zp[mt][t][4 * g + 3] };
-#pragma unroll
-                            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) sw[c][t] = fmaf(hv[r], gv[r][c], sw[c][t]);
-                        }
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) sb[c] += gv[0][c];         // bias gradient: value rows only
-                    }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (c >= a.top_nc) break;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) atomicAdd(hsum + c * kWidth + wave * NT * 32 + t * 32 + j, sw[c][t]);     // both lane halves
-                    if (wave == 0 && j == 0) atomicAdd(hsum + 3 * kWidth + c, sb[c]);
-                }
-            }
             acc_init<MT, NT, false>(acc, nullptr, wave, lane);
             if (a.top_src) {
                 stage(a.top_src);
@@ -668,20 +625,13 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
             if (l > 1) __syncthreads(); // the next layer reads what this epilogue wrote
         }
     }
-    if (heads_dw) {             // one atomic per column, head and workgroup
-        __syncthreads();
-        for (int c = 0; c < a.top_nc; ++c) {
-            atomicAdd(a.top_dw[c] + (size_t)tid * a.top_dwstride, hsum[c * kWidth + tid]);
-            if (tid == 0 && a.top_db[c]) atomicAdd(a.top_db[c], hsum[3 * kWidth + c]);
-        }
-    }
 }
 
 void launch_mlp_backward(const MlpBackwardArgs &a, int cus, hipStream_t s)
 {
     if (a.R <= 0 || (a.n_layers < 2 && a.dZtop)) return;         // a one-layer stack still has a prologue to run
     ablate_init();
-    constexpr size_t lds = ((size_t)64 * OpsF32::kLd + kHeadSumFloats) * sizeof(float);
+    constexpr size_t lds = (size_t)64 * OpsF32::kLd * sizeof(float);
     static bool once = ((void)hipFuncSetAttribute((const void *)mlp_backward_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                         (void)hipFuncSetAttribute((const void *)mlp_backward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                         (void)hipFuncSetAttribute((const void *)mlp_backward_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
