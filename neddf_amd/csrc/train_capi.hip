@@ -572,6 +572,12 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     const int kpe = (p.Cpe + 3) & ~3;       // loaded width of the encoding matrix (pad columns are zero)
     float *pack_at = wp;
     auto next_pack = [&]() { float *r = pack_at; pack_at += kPackFloats; return r; };
+    // weight fragments of a fused stack: fp32 in one launch per stack (PackBatch), split fp16 matrix by matrix
+    PackBatch pb;
+    auto pack = [&](const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, float *dst) {
+        if (sp) launch_pack(1, src, sk, sn, k_off, n_off, kcount, ncount, nout, dst, s);
+        else pb.add(src, sk, sn, k_off, n_off, kcount, ncount, nout, dst, s);
+    };
     // distance trunk (neddf.py:206-218); the fused kernel holds one skip partial, architectures with more take the per-layer route
     int n_wide = 0;
     for (int l = 1; l < p.n_trunk; ++l) n_wide += in_skips(f.d, l - 1) ? 1 : 0;
@@ -607,21 +613,22 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
         m.R = p.R; m.X0 = PEs; m.ld0 = kLdPe; m.kload0 = kpe; m.ksteps0 = gemm_ksteps(p.Cpe, sp);
         m.n_layers = p.n_trunk; m.skip_layer = -1; m.act_kind = act; m.point_major = pm;
         float *w0 = next_pack();
-        launch_pack(sp, W[0], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, w0, s);
+        pack(W[0], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, w0);
         m.wp0 = w0;
         for (int l = 0; l < p.n_trunk; ++l) {
             const bool wide = l > 0 && in_skips(f.d, l - 1);
             m.bias[l] = B[l]; m.Z[l] = ws + p.o_z[l]; m.H[l] = ws + p.o_h[l];
             if (l == 0) continue;
             float *wl = next_pack();
-            launch_pack(sp, W[l], kWidth, 1, wide ? p.Cpe : 0, 0, kWidth, kWidth, kWidth, wl, s);
+            pack(W[l], kWidth, 1, wide ? p.Cpe : 0, 0, kWidth, kWidth, kWidth, wl);
             m.wp[l] = wl;
             if (wide) {         // hx = cat([embed_pos_scaled, hx]): the encoding feeds rows 0 .. Cpe-1 of the weight
                 float *wsk = next_pack();
-                launch_pack(sp, W[l], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wsk, s);
+                pack(W[l], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wsk);
                 m.skip_layer = l; m.wp_skip = wsk;
             }
         }
+        pb.flush(s);
         launch_mlp_forward(sp, m, ctx->cus, s);
     } else {
         for (int l = 0; l < p.n_trunk; ++l) {
@@ -651,16 +658,17 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
         m.X1 = Hlast; m.n_layers = p.n_col; m.skip_layer = -1; m.act_kind = act; m.point_major = pm;
         pack_at = wp;           // same stream: the trunk kernel is done with the buffer when these packs run
         float *w0 = next_pack(), *w1 = next_pack();
-        launch_pack(sp, W[p.n_trunk], kWidth, 1, 0, 0, p.Ca, kWidth, kWidth, w0, s);
-        launch_pack(sp, W[p.n_trunk], kWidth, 1, p.Ca, 0, kWidth, kWidth, kWidth, w1, s);
+        pack(W[p.n_trunk], kWidth, 1, 0, 0, p.Ca, kWidth, kWidth, w0);
+        pack(W[p.n_trunk], kWidth, 1, p.Ca, 0, kWidth, kWidth, kWidth, w1);
         m.wp0 = w0; m.wp1 = w1;
         for (int l = 0; l < p.n_col; ++l) {
             m.bias[l] = B[p.n_trunk + l]; m.Z[l] = ws + p.o_zc[l]; m.H[l] = ws + p.o_hc[l];
             if (l == 0) continue;
             float *wl = next_pack();
-            launch_pack(sp, W[p.n_trunk + l], kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wl, s);
+            pack(W[p.n_trunk + l], kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wl);
             m.wp[l] = wl;
         }
+        pb.flush(s);
         launch_mlp_forward(sp, m, ctx->cus, s);
     } else {
         for (int l = 0; l < p.n_col; ++l) {
@@ -723,6 +731,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         a.g_distance = g_distance; a.g_density = g_density; a.g_color = g_color; a.g_penalty = g_penalty; a.g_aux = g_aux_grad;
         a.GZH = GZH; a.GCR = GCR;
         launch_point_backward(a, s);
+        PackBatch pbk;         // the transposed weight fragments of a chain: one launch per chain
         DwJobs dwj{};          // every weight-gradient product of this pass: one job-parallel launch at the end (launch_dw_jobs)
         dwj.R = p.R;
         // colour head: LinearGradFunction.backward (linear.py:62-88) on [HC | JC] rows, then the last colour activation
@@ -743,9 +752,10 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
             m.top_Z = ws + p.o_zc[nC - 1]; m.top_out = dZc(nC - 1);
             for (int l = 1; l < nC; ++l) {
                 float *wl = next_pack();
-                launch_pack(0, W[nT + l], 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wl, s);             // W_l^T
+                pbk.add(W[nT + l], 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wl, s);             // W_l^T
                 m.wT[l] = wl; m.Z[l - 1] = ws + p.o_zc[l - 1]; m.dZ[l - 1] = dZc(l - 1);
             }
+            pbk.flush(s);
             launch_mlp_backward(m, ctx->cus, s);
         }
         for (int l = nC - 1; l >= 1; --l)
@@ -762,7 +772,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
             // prologue: dZ of the last trunk layer = activation backward of (gradient of the features from the colour trunk -- only the
             // feature segment of its first layer propagates: the small colour inputs carry no parameters -- + the distance / aux heads)
             float *wf = next_pack();
-            launch_pack(0, W[nT], 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wf, s);                  // (feature rows of W_c0)^T
+            pbk.add(W[nT], 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wf, s);                  // (feature rows of W_c0)^T
             m.top_src = dZc(0); m.top_wT = wf;
             m.top_G = GZH; m.top_ldg = kLdNarrow; m.top_nc = 2; m.top_wstride = 1;
             m.top_w[0] = W[p.i_ddf]; m.top_w[1] = W[p.i_aux];
@@ -770,9 +780,10 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
             for (int l = 1; l < nT; ++l) {
                 const bool wide = in_skips(f.d, l - 1);
                 float *wl = next_pack();
-                launch_pack(0, W[l], 1, kWidth, 0, wide ? p.Cpe : 0, kWidth, kWidth, kWidth, wl, s);   // (hidden rows of W_l)^T
+                pbk.add(W[l], 1, kWidth, 0, wide ? p.Cpe : 0, kWidth, kWidth, kWidth, wl, s);   // (hidden rows of W_l)^T
                 m.wT[l] = wl; m.Z[l - 1] = ws + p.o_z[l - 1]; m.dZ[l - 1] = dZt(l - 1);
             }
+            pbk.flush(s);
             launch_mlp_backward(m, ctx->cus, s);
         }
         for (int l = nT - 1; l >= 0; --l) {

@@ -40,6 +40,15 @@ struct TrainPointArgs {
 // split != 0: split-fp16 fragments (tile_engine.h OpsF16Split), roundup(kcount, 16) / 16 super-steps
 void launch_pack(int split, const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, float *dst,
                  hipStream_t s);
+// the same for every matrix of a layer stack in ONE launch (fp32 fragments; the per-matrix launches of a step were 42 x 5 us in a row)
+struct PackJob { const float *src; int64_t sk, sn; int k_off, n_off, kcount, ncount, nout, ks; float *dst; };
+constexpr int kMaxPackJobs = 16;
+struct PackBatch {
+    int n = 0;
+    PackJob job[kMaxPackJobs];
+    void add(const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, float *dst, hipStream_t s);
+    void flush(hipStream_t s);
+};
 inline int gemm_ksteps(int K, int split) { return split ? (K + 15) / 16 : (K + 7) / 8; }
 
 // Y[R,256] (+)= X[R, 0:kload) x Wpacked (+ bias); kload = loaded width (multiple of 4, <= ldx, zero beyond the logical K);

@@ -1617,6 +1617,39 @@ void launch_pack(int split, const float *src, int64_t sk, int64_t sn, int k_off,
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, src, sk, sn, k_off, n_off, kcount, ncount, nout, ks, dst);
 }
 
+struct PackJobs { PackJob job[kMaxPackJobs]; };
+__global__ void pack_batch_kernel(const PackJobs jobs)
+{
+    const PackJob &jb = jobs.job[blockIdx.y];
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)jb.ks * 8 * jb.nout) return;
+    int r = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    int64_t rest = idx >> 8;
+    int S = (int)(rest % jb.ks);
+    int wt = (int)(rest / jb.ks);
+    int n = wt * 32 + (lane & 31);
+    int k = 8 * S + 4 * (lane >> 5) + r;
+    jb.dst[idx] = (k < jb.kcount && n < jb.ncount) ? jb.src[(int64_t)(jb.k_off + k) * jb.sk + (int64_t)(jb.n_off + n) * jb.sn] : 0.f;
+}
+void PackBatch::add(const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, float *dst, hipStream_t s)
+{
+    if (n == kMaxPackJobs) flush(s);
+    job[n++] = PackJob{ src, sk, sn, k_off, n_off, kcount, ncount, nout, (kcount + 7) / 8, dst };
+}
+void PackBatch::flush(hipStream_t s)
+{
+    if (!n) return;
+    PackJobs jobs{};
+    int64_t tmax = 0;
+    for (int i = 0; i < n; ++i) {
+        jobs.job[i] = job[i];
+        const int64_t t = (int64_t)job[i].ks * 8 * job[i].nout;
+        if (t > tmax) tmax = t;
+    }
+    hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)((tmax + 255) / 256), (unsigned)n), dim3(256), 0, s, jobs);
+    n = 0;
+}
+
 // narrow heads (1..4 output columns from a 256-wide input): one wavefront per four rows.  A lane holds four features of each row, so
 // the wave has 16 partial sums per lane (4 rows x 4 columns) to add across 64 lanes: a reduce-scatter butterfly (xor 32, 16, 8, 4: each
 // step sends half of the lane's values to the partner and keeps the other half) leaves ONE value per lane after 15 exchanges, two plain
