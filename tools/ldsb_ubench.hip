@@ -90,6 +90,94 @@ __global__ __launch_bounds__(512, 1) void product_kernel(const u32x4 *wfrag, flo
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// the same with a ring of NBUF slabs of SKS k-steps each, the DMA running NBUF - 1 slabs ahead, a counted vmcnt and a raw barrier per slab
+template <int SKS, int NBUF>
+__global__ __launch_bounds__(512, 1) void ring_kernel(const u32x4 *wfrag, float *out, long long *cyc, int layers)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short *act = (unsigned short *)smem;
+    unsigned char *ring = smem + kRows * kLd * 2;
+    constexpr int SLAB = SKS * 8 * 1024, SPL = 16 / SKS;          // bytes per slab, slabs per layer
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cs = wave & 3, half = wave >> 2;
+    for (int i = tid; i < kRows * kLd; i += 512) act[i] = (unsigned short)(0x3c00 + (i & 63));
+    __syncthreads();
+    const unsigned short *ap = act + (size_t)(half * 64 + (lane & 31)) * kLd + 8 * (lane >> 5);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
+    auto issue = [&](int slab) {           // slab index over all layers; this wave's SKS of its SKS * 8 fragments
+        const int layer = slab / SPL, g = slab - layer * SPL, buf = slab % NBUF;
+        const u32x4 *src = wfrag + ((size_t)(layer & 1) * 16 * 8 + (size_t)g * SKS * 8) * 64;
+#pragma unroll
+        for (int q = 0; q < SKS; ++q) {
+            const int f = wave * SKS + q;
+            glds16(src + (size_t)f * 64 + lane, ring + buf * SLAB + f * 1024);
+        }
+    };
+    const long long t0 = clock64();
+#pragma unroll
+    for (int s0 = 0; s0 < NBUF - 1; ++s0) issue(s0);
+    if (NBUF == 2) __builtin_amdgcn_s_waitcnt(0x0f70);
+    else __builtin_amdgcn_s_waitcnt(0x0f70 | (SKS * (NBUF - 2)));
+    __builtin_amdgcn_s_barrier();
+    const int nslabs = layers * SPL;
+    for (int slab = 0; slab < nslabs; ++slab) {
+        issue(slab + NBUF - 1);
+        const int g = slab % SPL;
+        const unsigned char *bb = ring + (slab % NBUF) * SLAB;
+#pragma unroll
+        for (int ks = 0; ks < SKS; ++ks) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a[m] = *(const bf16x8 *)(ap + (size_t)m * 32 * kLd + (g * SKS + ks) * 16);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b[t] = *(const bf16x8 *)(bb + ((ks * 4 + cs) * 2 + t) * 1024 + lane * 16);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[t], acc[m][t], 0, 0, 0);
+        }
+        // the slab read next must have landed: everything but the NBUF - 2 newest slabs' pieces of this wave
+        __builtin_amdgcn_s_waitcnt(0x0f70 | (SKS * (NBUF - 2)));
+        __builtin_amdgcn_s_barrier();
+    }
+    const long long t1 = clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += acc[m][t][i];
+    out[(size_t)blockIdx.x * 512 + tid] = s;
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int SKS, int NBUF>
+static void run_ring(const u32x4 *w, float *out, long long *cyc, int cus, int layers)
+{
+    const size_t lds = (size_t)kRows * kLd * 2 + (size_t)NBUF * SKS * 8 * 1024;
+    (void)hipFuncSetAttribute((const void *)ring_kernel<SKS, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    float best = 1e9f;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((ring_kernel<SKS, NBUF>), dim3(cus), dim3(512), lds, 0, w, out, cyc, layers);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double flop = 2.0 * 128 * 256 * 256 * layers * cus;
+    printf("ring: %d k-steps per slab x %d slabs (%3zu KB LDS)  %8.3f ms  %6.0f cycles per layer at 2.4 GHz  %7.1f TF  (%.2f of 2.5 PF)\n", SKS, NBUF,
+           lds / 1024, best, best * 1e-3 * 2.4e9 / layers, flop / (best * 1e-3) * 1e-12, flop / (best * 1e-3) / 2.5e15);
+}
+
 int main()
 {
     hipDeviceProp_t prop;
@@ -125,5 +213,11 @@ int main()
                mode == 0 ? "B via LDS-DMA ring (shared)" : "B L2 -> VGPR per wave (today)", best, mean / layers, flop / (best * 1e-3) * 1e-12,
                flop / (best * 1e-3) / 2.5e15);
     }
+    run_ring<4, 2>(w, out, cyc, cus, layers);
+    run_ring<2, 2>(w, out, cyc, cus, layers);
+    run_ring<2, 3>(w, out, cyc, cus, layers);
+    run_ring<2, 4>(w, out, cyc, cus, layers);
+    run_ring<1, 4>(w, out, cyc, cus, layers);
+    run_ring<1, 8>(w, out, cyc, cus, layers);
     return 0;
 }
