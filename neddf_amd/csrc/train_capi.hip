@@ -333,7 +333,7 @@ int neus_forward(neddf_ctx *ctx, int slot, const float *const *W, const float *c
     const int sp = f.d.weight_dtype == NEDDF_DTYPE_F16_SPLIT;
     if (int rc = ensure(ctx, ctx->tpack, 2 * kPackFloats * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ttmp, ((size_t)p.R * kLdPe + (size_t)N * 4) * sizeof(float))) return rc;
-    float *wp = (float *)ctx->tpack.p, *wp2 = wp + kPackFloats;
+    float *wp = (float *)ctx->tpack.p;
     float *PEs = (float *)ctx->ttmp.p, *var0 = PEs + (size_t)p.R * kLdPe;
     float *PE = ws + p.o_pe, *Ed = ws + p.o_ed;
     // plain PositionalEncoding (neus.py:118-119): no variance weights, no low-pass schedule
@@ -361,7 +361,7 @@ int neus_forward(neddf_ctx *ctx, int slot, const float *const *W, const float *c
     };
     if (!unfused && n_wide <= 1 && WH == kWidth) {      // the sdf trunk (neus.py:121-125) as one fused layer stack (train_kernels.h MlpForwardArgs)
         if (int rc = ensure(ctx, ctx->tpack, (size_t)(kMaxLayers + 2) * kPackFloats * sizeof(float))) return rc;
-        wp = (float *)ctx->tpack.p; wp2 = wp + kPackFloats;
+        wp = (float *)ctx->tpack.p;
         float *pack_at = wp;
         auto next_pack = [&]() { float *r = pack_at; pack_at += kPackFloats; return r; };
         MlpForwardArgs m{};
@@ -397,7 +397,6 @@ int neus_forward(neddf_ctx *ctx, int slot, const float *const *W, const float *c
             gemm_fw(PE, p.R, kLdPe, kpe, p.Cpe, W[l], in_total, WH, nullptr, 4, Z, 1, act, H);
         }
     }
-    (void)wp2;
     NeusPointArgs a;
     neus_point_args(a, f, p, W, ws);
     a.pos = pos; a.sdf = sdf; a.density = density; a.color = color;
