@@ -375,6 +375,38 @@ def test_render_image_small(dev, bunny_weights):
     assert_close(N(img["depth"]), g["ds_depth"], 1e-4, 1e-5, "downsampled depth")
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_render_image_is_the_chunk_loop_over_render_rays(dev, bunny_weights, seed):
+    """`render_image` as the reference defines it (nerf_render.py:190-249): row-major uv (idx = v * w + u) times `downsampling`, a loop over
+    chunks of `chunk` rays -- the short last one included -- each a `render_rays` call that draws its own uniforms, concatenated and
+    reshaped to [h, w, C].  Random sizes, downsampling and chunk lengths; the product's batched path (65 536 rays per call, uniforms
+    drawn in the reference's chunk order) must give the same pixels as that loop under the same torch seed."""
+    rng = np.random.default_rng(70 + seed)
+    ds = int(rng.choice([1, 1, 2, 3]))
+    w, h = int(rng.integers(3, 41)) * ds + int(rng.integers(0, ds)), int(rng.integers(3, 31)) * ds + int(rng.integers(0, ds))
+    chunk = int(rng.choice([7, 64, 100, 333, 512, 5000]))
+    # (sample counts from 32: with a handful of samples per ray the intervals are so long that the density's 1e-4 between the two field
+    # kernels -- see below -- shows in the pixel: 2e-4 at 12 + 9 samples)
+    r = bunny_render(dev, bunny_weights, sample_coarse=int(rng.integers(32, 65)), sample_fine=int(rng.integers(32, 129)))
+    g = golden("bunny_image_small.npz")
+    cam = make_camera(g, dev)
+    torch.manual_seed(100 + seed)
+    img = r.render_image(w, h, cam, ["color", "depth", "transmittance"], ds, chunk)
+    ww, hh = w // ds, h // ds
+    us = torch.arange(ww, device=dev).reshape(1, ww).expand(hh, ww).reshape(-1) * ds
+    vs = torch.arange(hh, device=dev).reshape(hh, 1).expand(hh, ww).reshape(-1) * ds
+    uv = torch.stack([us, vs], 1)
+    torch.manual_seed(100 + seed)
+    with torch.no_grad():
+        parts = [r.render_rays(uv[i:i + chunk], cam) for i in range(0, uv.shape[0], chunk)]
+    for k in ("color", "depth", "transmittance"):
+        ref = torch.cat([p[k] for p in parts], 0).reshape(hh, ww, -1)
+        assert img[k].shape == ref.shape, (k, img[k].shape, ref.shape)
+        # (not bit for bit: render_rays also returns weights and penalties, which takes the forward-mode field kernel, render_image the
+        # reverse-mode one -- the same function in another summation order; a wrong pixel or draw order would be off by O(1))
+        assert_close(N(img[k]), N(ref), 1e-4, 1e-5, "%s: %d x %d / %d, chunk %d" % (k, w, h, ds, chunk))
+
+
 def test_nerf_render_rays(dev):
     """Two separate NeRF nets, point sampling, float uv (tests/render/test_nerf_render.py:48-68 shape)."""
     import neddf_amd
