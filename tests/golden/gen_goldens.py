@@ -924,6 +924,36 @@ def gen_train_random():
     save("train_random.npz", **arrs)
 
 
+def gen_fields_random():
+    """The sixty architectures of the random rendering sweep (synth.random_arch(seed), seeds 0 .. 59: tests/test_gpu_parity.py
+    test_random_architectures_vs_oracle) through the REFERENCE's forward in evaluation mode, on that test's own points: pins the
+    oracle -- and the HIP path directly -- on every one of them, not only on the fixed architectures of gen_fields."""
+    arrs = {}
+    classes = {"neddf": NeDDF, "nerf": NeRF, "neus": NeuS}
+    for seed in range(60):
+        kind, kw = synth.random_arch(seed)
+        rng = np.random.default_rng(1000 + seed)
+        rays, samples = int(rng.integers(1, 9)), int(rng.integers(1, 50))
+        pos, dd, var = synth.random_sampling(rays, samples, seed=2000 + seed)
+        net = classes[kind](**kw)
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.arch_state(kind, kw, 3000 + seed).items()})
+        if kind != "neus":
+            net.set_iter(-1)
+        net.eval()
+        smp_ = Sampling(torch.from_numpy(pos.copy()), torch.from_numpy(dd), torch.from_numpy(var))
+        if kind == "neus":              # its normal is torch.autograd.grad of the sdf (neus.py:127-139): needs grad mode even in evaluation
+            with torch.enable_grad():
+                o = net(smp_)
+        else:
+            with torch.no_grad():
+                o = net(smp_)
+        pre = "s%d_" % seed
+        arrs[pre + "config"] = np.array(json.dumps(dict(kind=kind, kw=kw)))
+        for k, v in o.items():
+            arrs[pre + "out_" + k] = npy(v.detach())
+    save("fields_random.npz", **arrs)
+
+
 # --------------------------------------------------------------------------
 def gen_dataset():
     """the reference's own NeRFSyntheticDataset (nerf_synthetic_dataset.py:25-84, with cv2.imread backed
@@ -1117,6 +1147,10 @@ if __name__ == "__main__":
         from neddf.ray import Sampling  # noqa: F401
         gen_train_wide_nerf()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fields_random":
+        from neddf.ray import Sampling  # noqa: F401
+        gen_fields_random()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "train_random":
         from neddf.ray import Sampling  # noqa: F401
         gen_train_random()
@@ -1161,3 +1195,4 @@ if __name__ == "__main__":
     gen_fp64()          # last: switches torch's default dtype while it runs
     gen_train_wide_nerf()
     gen_train_random()
+    gen_fields_random()

@@ -908,11 +908,13 @@ def test_random_architectures_vs_oracle(dev, orc, seed):
     """Round 4: sixty architectures drawn at random from what the reference's constructors accept -- field kind, hidden width 8 .. 512
     (zero-padded onto the 128 / 256 / 384 / 512 engines), 2 .. 7 layers, up to three skip connections at any depth, any of the three
     activations on trunk and density head, encoding ranks 1 .. 10 for positions and directions (a narrow network with long encodings
-    takes the next engine width whose tile row holds them), a ragged number of points -- against the oracle (pinned on
-    the reference's goldens at widths 128 .. 384 through this same code path).  Seeds cycle NeDDF (both differentiation modes) / NeRF /
+    takes the next engine width whose tile row holds them), a ragged number of points -- against the oracle AND against the reference's
+    own forward on the same weights and points (tests/golden/fields_random.npz, which also pins the oracle there: tests/test_oracle.py).  Seeds cycle NeDDF (both differentiation modes) / NeRF /
     NeuS; fp32 and split-fp16 operands at the same gates."""
     import neddf_amd
     kind, kw = synth.random_arch(seed)
+    gold = golden("fields_random.npz")          # the reference's own forward on this architecture and these points (gen_goldens.py fields_random)
+    assert json.loads(str(gold["s%d_config" % seed])) == dict(kind=kind, kw=kw)
     rng = np.random.default_rng(1000 + seed)
     rays, samples = int(rng.integers(1, 9)), int(rng.integers(1, 50))
     pos, d, var = synth.random_sampling(rays, samples, seed=2000 + seed)
@@ -940,7 +942,9 @@ def test_random_architectures_vs_oracle(dev, orc, seed):
             o = net(s)
             assert o["density"].shape == (rays, samples)
             for k in o:
-                assert_close(N(o[k]), ref[k], 1e-4, 2e-5, "seed %d %s %s %s %s %s" % (seed, kind, json.dumps(kw), dtype, mode, k))
+                what = "seed %d %s %s %s %s %s" % (seed, kind, json.dumps(kw), dtype, mode, k)
+                assert_close(N(o[k]), ref[k], 1e-4, 2e-5, what + " vs oracle")
+                assert_close(N(o[k]), gold["s%d_out_%s" % (seed, k)], 1e-4, 2e-5, what + " vs the reference")
 
 
 @pytest.mark.parametrize("seed", list(range(24)))

@@ -292,3 +292,31 @@ def test_neddf_negative_bias_render_rays():
     o = orc.render_rays(net, net, r["uv"], r["R"], r["T"], r["calib"], r["u_coarse"], r["u_fine"], 2.0, 6.0, 6.0, "cone")
     for k in ("color", "depth", "transmittance", "color_coarse", "depth_coarse", "weight_coarse", "fields_penalty"):
         assert_close(o[k], r["out_" + k], 1e-4, 1e-5, "negbias render_rays " + k)
+
+
+@pytest.mark.parametrize("block", [0, 1, 2, 3])
+def test_oracle_on_random_architectures(block):
+    """Round 4: the oracle against the REFERENCE on the sixty randomly drawn architectures of the rendering sweep (synth.random_arch, seeds
+    0 .. 59: field kind, hidden width 8 .. 512, 2 .. 7 layers, up to three skips, any activation, encoding ranks 1 .. 10; goldens:
+    tests/golden/gen_goldens.py fields_random, the reference's forward in evaluation mode).  This is what pins the checker of
+    tests/test_gpu_parity.py::test_random_architectures_vs_oracle on those architectures, fifteen per block."""
+    g = golden("fields_random.npz")
+    for seed in range(15 * block, 15 * block + 15):
+        pre = "s%d_" % seed
+        cfg = json.loads(str(g[pre + "config"]))
+        kind, kw = cfg["kind"], cfg["kw"]
+        assert (kind, kw) == synth.random_arch(seed)
+        rng = np.random.default_rng(1000 + seed)
+        rays, samples = int(rng.integers(1, 9)), int(rng.integers(1, 50))
+        pos, d, var = synth.random_sampling(rays, samples, seed=2000 + seed)
+        sd = synth.arch_state(kind, kw, 3000 + seed)
+        if kind == "neddf":
+            o = orc.NeDDFOracle(sd, **kw).forward(pos, d, var)
+        elif kind == "nerf":
+            o = orc.NeRFOracle(sd, **kw).forward(pos, d, var)
+        else:
+            o = orc.NeuSOracle(sd, **kw).forward(pos, d)
+        keys = [k[len(pre) + 4:] for k in g.files if k.startswith(pre + "out_")]
+        assert keys
+        for k in keys:
+            assert_close(o[k], g[pre + "out_" + k], 1e-4, 2e-5, "seed %d %s %s %s" % (seed, kind, json.dumps(kw), k))
