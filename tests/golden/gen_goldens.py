@@ -954,6 +954,51 @@ def gen_fields_random():
     save("fields_random.npz", **arrs)
 
 
+def gen_render_random():
+    """The twenty-four configurations of the rendering sweep (synth.random_render_config) through the REFERENCE's `render_rays`
+    (nerf_render.py:109-188).  Its uniforms are the two torch.rand draws of the call, captured by drawing them first and rewinding the
+    generator; the pose is what Camera.update_transform makes of the drawn rotation vector (stored as R, T: what the reference used)."""
+    arrs = {}
+    for seed in range(24):
+        c = synth.random_render_config(seed)
+        kind, kw = c["kind"], c["kw"]
+        render = NeRFRender(network_config=dict(kw, _target_=c["target"]), sample_coarse=c["n_c"], sample_fine=c["n_f"], dist_near=c["near"],
+                            dist_far=c["far"], max_dist=c["max_dist"], use_coarse_network=c["two"], sampling_type="cone" if c["cone"] else "point")
+        sd_f = synth.arch_state(kind, kw, 500 + seed)
+        render.network_fine.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_f.items()})
+        if c["two"]:
+            render.network_coarse.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.arch_state(kind, kw, 600 + seed).items()})
+        render.set_iter(-1)
+        cam = Camera(PinholeCalib(c["calib"]), np.r_[c["rotvec"], c["t"]].astype(np.float32))
+        cam.update_transform()
+        uv = torch.from_numpy(c["uv"])
+        torch.manual_seed(50 + seed)
+        state = torch.get_rng_state()
+        U_c, U_f = torch.rand(c["n"], c["n_c"] + 1), torch.rand(c["n"], c["n_f"] + 1)
+        torch.set_rng_state(state)
+        pre = "s%d_" % seed
+        try:
+            if kind == "neus":
+                with torch.enable_grad():
+                    out = render.render_rays(uv, cam)
+            else:
+                with torch.no_grad():
+                    out = render.render_rays(uv, cam)
+        except RuntimeError as e:
+            # the reference cannot run every combination its constructors accept: NeDDF over POINT samples dies in
+            # `sample_dir.view(-1, 3)` on the expanded direction tensor (neddf.py:210, ray.py:118-126); such a seed keeps its inputs
+            # and is compared against the oracle only
+            out = {}
+            arrs[pre + "reference_error"] = np.array(str(e)[:200])
+            print("  render_random seed %d: the reference raised %s" % (seed, str(e)[:80]))
+        arrs.update({pre + "R": npy(cam.R), pre + "T": npy(cam.T), pre + "u_coarse": npy(U_c), pre + "u_fine": npy(U_f),
+                     pre + "config": np.array(json.dumps(dict(kind=kind, kw=kw, n_c=c["n_c"], n_f=c["n_f"], two=c["two"], cone=c["cone"])))})
+        for k, v in out.items():
+            arrs[pre + "out_" + k] = npy(v.detach())
+        print("  render_random seed %d %s rays %d coarse %d fine %d two %d cone %d" % (seed, kind, c["n"], c["n_c"], c["n_f"], c["two"], c["cone"]))
+    save("render_random.npz", **arrs)
+
+
 # --------------------------------------------------------------------------
 def gen_dataset():
     """the reference's own NeRFSyntheticDataset (nerf_synthetic_dataset.py:25-84, with cv2.imread backed
@@ -1147,6 +1192,9 @@ if __name__ == "__main__":
         from neddf.ray import Sampling  # noqa: F401
         gen_train_wide_nerf()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "render_random":
+        gen_render_random()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "fields_random":
         from neddf.ray import Sampling  # noqa: F401
         gen_fields_random()
@@ -1196,3 +1244,4 @@ if __name__ == "__main__":
     gen_train_wide_nerf()
     gen_train_random()
     gen_fields_random()
+    gen_render_random()

@@ -320,3 +320,27 @@ def test_oracle_on_random_architectures(block):
         assert keys
         for k in keys:
             assert_close(o[k], g[pre + "out_" + k], 1e-4, 2e-5, "seed %d %s %s %s" % (seed, kind, json.dumps(kw), k))
+
+
+def test_oracle_render_rays_on_random_configurations():
+    """Round 4: the oracle's `render_rays` against the REFERENCE's on the random configurations of the rendering sweep
+    (synth.random_render_config; goldens: gen_goldens.py render_random -- the twenty of twenty-four the reference can run)."""
+    g = golden("render_random.npz")
+    checked = 0
+    for seed in range(24):
+        pre = "s%d_" % seed
+        if pre + "reference_error" in g.files:
+            continue
+        c = synth.random_render_config(seed)
+        kind, kw = c["kind"], c["kw"]
+        oc = {"neddf": orc.NeDDFOracle, "nerf": orc.NeRFOracle, "neus": orc.NeuSOracle}[kind]
+        sd_f = synth.arch_state(kind, kw, 500 + seed)
+        sd_c = synth.arch_state(kind, kw, 600 + seed) if c["two"] else sd_f
+        o = orc.render_rays(oc(sd_c, **kw), oc(sd_f, **kw), c["uv"], g[pre + "R"], g[pre + "T"], c["calib"].astype(np.float32), g[pre + "u_coarse"],
+                            g[pre + "u_fine"], c["near"], c["far"], c["max_dist"], "cone" if c["cone"] else "point")
+        keys = [k[len(pre) + 4:] for k in g.files if k.startswith(pre + "out_")]
+        assert len(keys) >= 8
+        for k in keys:
+            assert_close(o[k], g[pre + "out_" + k], 1e-4, 1e-5, "seed %d %s %s" % (seed, kind, k))
+        checked += 1
+    assert checked == 20
