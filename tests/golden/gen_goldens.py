@@ -999,6 +999,56 @@ def gen_render_random():
     save("render_random.npz", **arrs)
 
 
+def gen_stages_random():
+    """The two per-ray stages of the reference on random shapes and hostile inputs: `sample_pdf` (base_neural_render.py:27-115; its
+    uniforms captured by drawing first and rewinding the generator) for 2 .. 130 knots, 1 .. 200 samples, with and without the coarse
+    knots, weights with zeros, negatives, NaNs, spikes and denormal-small values, repeated distances; `integrate_volume_render`
+    (:117-172) for 2 .. 300 samples with negative and saturating densities."""
+    render = NeRFRender(network_config=dict(_target_="neddf.network.NeRF", embed_pos_rank=2, embed_dir_rank=1, layer_count=2, layer_width=8,
+                                            activation_type="ReLU", density_activation_type="ReLU", skips=[], lowpass_alpha_offset=10),
+                        sample_coarse=4, sample_fine=4, dist_near=2.0, dist_far=6.0, max_dist=6.0, use_coarse_network=False, sampling_type="point")
+    arrs = {}
+    for seed in range(16):
+        rng = np.random.default_rng(8100 + seed)
+        B, n, nf = int(rng.integers(1, 13)), int(rng.integers(3, 131)), int(rng.integers(1, 201))
+        cat = bool(seed % 2 == 0)
+        dists = np.sort(rng.uniform(0.5, 7.0, (B, n + 1)).astype(np.float32), axis=1)
+        w = (rng.uniform(0, 1, (B, n)) ** int(rng.integers(1, 9))).astype(np.float32)
+        kind = seed % 4
+        if kind == 1:
+            w[rng.uniform(0, 1, w.shape) < 0.3] = 0.0
+            w[0] = 0.0
+        if kind == 2:
+            w[rng.uniform(0, 1, w.shape) < 0.2] *= -1.0
+            w[B - 1, n // 2] = np.nan
+        if kind == 3:
+            w *= 1e-12
+            dists[0, 1:4] = dists[0, 1]             # repeated knots
+        torch.manual_seed(900 + seed)
+        state = torch.get_rng_state()
+        u = torch.rand(B, nf)
+        torch.set_rng_state(state)
+        wt = torch.from_numpy(w.copy())
+        out = render.sample_pdf(torch.from_numpy(dists), wt, nf, cat_coarse=cat)
+        pre = "sp%d_" % seed
+        arrs.update({pre + "dists": dists, pre + "w": w, pre + "u": npy(u), pre + "cat": np.int32(cat), pre + "out": npy(out),
+                     pre + "wafter": npy(wt)})
+        S = int(rng.integers(2, 301))
+        d2 = np.sort(rng.uniform(2.0, 6.0, (B, S)).astype(np.float32), axis=1)
+        dens = rng.uniform(-2.0, 30.0, (B, S)).astype(np.float32)
+        if kind == 1:
+            dens[0] = 1e4
+        if kind == 2:
+            dens[:, ::3] = -5.0
+        col = rng.uniform(-1.0, 2.0, (B, S, 3)).astype(np.float32)
+        r = render.integrate_volume_render(torch.from_numpy(d2), torch.from_numpy(dens), torch.from_numpy(col))
+        pre = "iv%d_" % seed
+        arrs.update({pre + "dists": d2, pre + "dens": dens, pre + "col": col, pre + "weight": npy(r["weight"]), pre + "depth": npy(r["depth"]),
+                     pre + "color": npy(r["color"]), pre + "trans": npy(r["transmittance"])})
+    arrs["max_dist"] = np.float32(render.max_dist)
+    save("stages_random.npz", **arrs)
+
+
 # --------------------------------------------------------------------------
 def gen_dataset():
     """the reference's own NeRFSyntheticDataset (nerf_synthetic_dataset.py:25-84, with cv2.imread backed
@@ -1192,6 +1242,9 @@ if __name__ == "__main__":
         from neddf.ray import Sampling  # noqa: F401
         gen_train_wide_nerf()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "stages_random":
+        gen_stages_random()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "render_random":
         gen_render_random()
         sys.exit(0)
@@ -1245,3 +1298,4 @@ if __name__ == "__main__":
     gen_train_random()
     gen_fields_random()
     gen_render_random()
+    gen_stages_random()

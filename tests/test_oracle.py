@@ -344,3 +344,23 @@ def test_oracle_render_rays_on_random_configurations():
             assert_close(o[k], g[pre + "out_" + k], 1e-4, 1e-5, "seed %d %s %s" % (seed, kind, k))
         checked += 1
     assert checked == 20
+
+
+def test_oracle_stages_on_random_inputs():
+    """Round 4: `sample_pdf` and `integrate_volume_render` of the oracle against the REFERENCE on sixteen random shapes with hostile
+    inputs (gen_goldens.py stages_random: 3 .. 130 knots, 1 .. 200 samples, with / without the coarse knots; zero, negative, NaN,
+    denormal-small weights, repeated knots; 2 .. 300 compositing samples with negative and saturating densities).  Samples and the
+    sanitised weights bit for bit; compositing at the gates of the fixed-shape tests."""
+    g = golden("stages_random.npz")
+    for seed in range(16):
+        pre = "sp%d_" % seed
+        w = g[pre + "w"].copy()
+        out, ids, fb = orc.sample_pdf(g[pre + "dists"], w, g[pre + "u"], bool(g[pre + "cat"]))
+        assert np.array_equal(out, g[pre + "out"], equal_nan=True), seed
+        assert np.array_equal(w, g[pre + "wafter"], equal_nan=True), seed
+        pre = "iv%d_" % seed
+        o = orc.integrate(g[pre + "dists"], g[pre + "dens"], g[pre + "col"], float(g["max_dist"]))
+        assert_close(o["weight"], g[pre + "weight"], 2e-5, 3e-7, "seed %d weight" % seed)
+        assert_close(o["color"], g[pre + "color"], 2e-5, 2e-6, "seed %d color" % seed)
+        assert_close(o["depth"], g[pre + "depth"], 2e-5, 2e-6, "seed %d depth" % seed)
+        assert_close(o["transmittance"], g[pre + "trans"], 2e-5, 1e-9, "seed %d transmittance" % seed)
