@@ -1049,6 +1049,38 @@ def gen_stages_random():
     save("stages_random.npz", **arrs)
 
 
+def gen_rays_random():
+    """`Camera.create_rays` (camera.py:155-187, pinhole_calib.py:51-74) and `Ray.get_sampling_cones / get_sampling_points`
+    (ray.py:88-194) of the reference for twelve random pinhole cameras, poses, pixel sets of every dtype the callers use (int64 in
+    evaluation, int16 in training, float in the reference's tests) and 2 .. 64 sorted distances per ray, with random cone radii."""
+    from scipy.spatial.transform import Rotation
+    arrs = {}
+    for seed in range(12):
+        rng = np.random.default_rng(8300 + seed)
+        n, S = int(rng.integers(1, 25)), int(rng.integers(2, 65))
+        W, H = int(rng.integers(8, 1200)), int(rng.integers(8, 1200))
+        calib = np.array([rng.uniform(0.4, 3.0) * W, rng.uniform(0.4, 3.0) * W, 0.5 * W + rng.uniform(-5, 5), 0.5 * H + rng.uniform(-5, 5)])
+        rotvec = Rotation.random(random_state=int(rng.integers(0, 1 << 30))).as_rotvec().astype(np.float32)
+        t = rng.uniform(-4.0, 4.0, 3).astype(np.float32)
+        uv_i = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], 1)
+        kind = ("int64", "int16", "float32", "int32")[seed % 4]
+        uv = (uv_i.astype(np.float32) + rng.uniform(0, 1, (n, 2)).astype(np.float32)) if kind == "float32" else uv_i.astype(kind)
+        cam = Camera(PinholeCalib(calib), np.r_[rotvec, t].astype(np.float32))
+        cam.update_transform()
+        rays = cam.create_rays(torch.from_numpy(uv))
+        dists = np.sort(rng.uniform(0.1, 9.0, (n, S)).astype(np.float32), axis=1)
+        radius = float(rng.uniform(1e-4, 2e-3))
+        sc = rays.get_sampling_cones(torch.from_numpy(dists), radius)
+        sp = rays.get_sampling_points(torch.from_numpy(dists))
+        pre = "s%d_" % seed
+        arrs.update({pre + "calib": calib, pre + "R": npy(cam.R), pre + "T": npy(cam.T), pre + "uv": uv, pre + "dists": dists,
+                     pre + "radius": np.float64(radius), pre + "ray_dir": npy(rays.ray_dir), pre + "ray_orig": npy(rays.ray_orig),
+                     pre + "cone_pos": npy(sc.sample_pos), pre + "cone_var": npy(sc.diag_variance), pre + "point_pos": npy(sp.sample_pos)})
+        # (sample_dir is the ray direction broadcast, the point samples' variance is zero: asserted here, not stored)
+        assert torch.equal(sc.sample_dir, rays.ray_dir.unsqueeze(1).expand_as(sc.sample_dir)) and float(sp.diag_variance.abs().max()) == 0.0
+    save("rays_random.npz", **arrs)
+
+
 # --------------------------------------------------------------------------
 def gen_dataset():
     """the reference's own NeRFSyntheticDataset (nerf_synthetic_dataset.py:25-84, with cv2.imread backed
@@ -1242,6 +1274,9 @@ if __name__ == "__main__":
         from neddf.ray import Sampling  # noqa: F401
         gen_train_wide_nerf()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rays_random":
+        gen_rays_random()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "stages_random":
         gen_stages_random()
         sys.exit(0)
@@ -1299,3 +1334,4 @@ if __name__ == "__main__":
     gen_fields_random()
     gen_render_random()
     gen_stages_random()
+    gen_rays_random()

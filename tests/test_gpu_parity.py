@@ -193,6 +193,28 @@ def test_resample_edges(ctx, dev, orc):
     assert np.array_equal(N(ids), oi) and np.array_equal(N(out), oo)
 
 
+def test_rays_on_random_cameras(ctx, dev, orc):
+    """Round 4: ray generation and cone / point sampling for twelve random pinhole cameras, poses, pixel dtypes and distance sets with
+    random cone radii: bit-identical to the oracle, and within the fixed-shape tests' gates of the REFERENCE's `create_rays` /
+    `get_sampling_cones` / `get_sampling_points` (tests/golden/rays_random.npz)."""
+    g = golden("rays_random.npz")
+    for seed in range(12):
+        pre = "s%d_" % seed
+        cd = cam_desc(dict(R=g[pre + "R"], T=g[pre + "T"], calib=g[pre + "calib"].astype(np.float32)))
+        rd, ro = ctx.raygen(T(g[pre + "uv"], dev), cd)
+        ord_, oro = orc.create_rays(g[pre + "uv"], g[pre + "R"], g[pre + "T"], g[pre + "calib"])
+        assert np.array_equal(N(rd), ord_) and np.array_equal(N(ro), oro), seed
+        assert_close(N(rd), g[pre + "ray_dir"], 1e-6, 1e-7, "seed %d ray_dir" % seed)
+        assert np.array_equal(N(ro), g[pre + "ray_orig"]), seed
+        for radius, tag in ((float(g[pre + "radius"]), "cone"), (None, "point")):
+            pos, d, var = ctx.sampling(T(g[pre + "ray_dir"], dev), T(g[pre + "ray_orig"], dev), T(g[pre + "dists"], dev), radius)
+            op, od, ov = orc.sampling(g[pre + "ray_dir"], g[pre + "ray_orig"], g[pre + "dists"], radius)
+            assert np.array_equal(N(pos), op) and np.array_equal(N(d), od) and np.array_equal(N(var), ov), (seed, tag)
+            assert_close(N(pos), g[pre + tag + "_pos"], 1e-6, 1e-7, "seed %d %s pos" % (seed, tag))
+            if radius is not None:
+                assert_close(N(var), g[pre + "cone_var"], 1e-4, 1e-12, "seed %d cone var" % seed)
+
+
 def test_stages_on_random_inputs_vs_the_reference(ctx, dev):
     """Round 4: the importance-resample and compositing kernels against the REFERENCE's `sample_pdf` / `integrate_volume_render` on sixteen
     random shapes with hostile inputs (tests/golden/stages_random.npz: 3 .. 130 knots, 1 .. 200 samples, with / without the coarse

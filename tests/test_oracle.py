@@ -364,3 +364,22 @@ def test_oracle_stages_on_random_inputs():
         assert_close(o["color"], g[pre + "color"], 2e-5, 2e-6, "seed %d color" % seed)
         assert_close(o["depth"], g[pre + "depth"], 2e-5, 2e-6, "seed %d depth" % seed)
         assert_close(o["transmittance"], g[pre + "trans"], 2e-5, 1e-9, "seed %d transmittance" % seed)
+
+
+def test_oracle_rays_on_random_cameras():
+    """Round 4: `create_rays` and the cone / point sampling of the oracle against the REFERENCE for twelve random pinhole cameras, poses,
+    pixel dtypes (int64 / int16 / int32 / float) and distance sets with random cone radii (gen_goldens.py rays_random), at the gates
+    of the fixed-shape tests above."""
+    g = golden("rays_random.npz")
+    for seed in range(12):
+        pre = "s%d_" % seed
+        rd, ro = orc.create_rays(g[pre + "uv"], g[pre + "R"], g[pre + "T"], g[pre + "calib"])
+        assert_close(rd, g[pre + "ray_dir"], 1e-6, 1e-7, "seed %d ray_dir" % seed)
+        assert np.array_equal(ro, g[pre + "ray_orig"]), seed
+        pos, d, var = orc.sampling(g[pre + "ray_dir"], g[pre + "ray_orig"], g[pre + "dists"], float(g[pre + "radius"]))
+        assert_close(pos, g[pre + "cone_pos"], 1e-6, 1e-7, "seed %d cone pos" % seed)
+        assert_close(var, g[pre + "cone_var"], 1e-4, 1e-12, "seed %d cone var" % seed)
+        assert np.array_equal(d, np.broadcast_to(g[pre + "ray_dir"][:, None, :], d.shape)), seed
+        pos, d, var = orc.sampling(g[pre + "ray_dir"], g[pre + "ray_orig"], g[pre + "dists"], None)
+        assert_close(pos, g[pre + "point_pos"], 1e-6, 1e-7, "seed %d point pos" % seed)
+        assert float(np.abs(var).max()) == 0.0
