@@ -220,3 +220,18 @@ def random_render_config(seed):
     c["t"] = rng.uniform(-1.0, 1.0, 3).astype(np.float32)
     c["target"] = {"neddf": "neddf.network.NeDDF", "nerf": "neddf.network.NeRF", "neus": "neddf.network.NeuS"}[kind]
     return c
+
+
+def random_train_render_config(seed):
+    """random_render_config restricted to what the REFERENCE can take a training step on: NeDDF over cone samples (over point samples
+    its forward dies, neddf.py:210), ReLU density (with negative coarse weights sample_pdf's in-place sanitisation invalidates the
+    reference's own autograd graph, base_neural_render.py:52-55), and small sample counts (NeuS is a double backward)."""
+    c = random_render_config(200 + seed)
+    if c["kind"] == "neddf":
+        c["cone"] = True
+    if "density_activation_type" in c["kw"]:
+        c["kw"]["density_activation_type"] = "ReLU"
+    c["n"] = min(c["n"], 24)
+    c["uv"] = c["uv"][:c["n"]]
+    c["n_c"], c["n_f"] = 2 + c["n_c"] % 38, 1 + c["n_f"] % 60
+    return c

@@ -1081,6 +1081,46 @@ def gen_rays_random():
     save("rays_random.npz", **arrs)
 
 
+def gen_train_render_random():
+    """`render_rays` under autograd + backward of the REFERENCE (nerf_render.py:109-188 with the hand-written / autograd backward passes)
+    on eight random configurations (synth.random_train_render_config: kinds, one or two networks, cone / point, sample counts, cameras),
+    random upstream gradients on every returned tensor.  Stores the outputs and, per parameter tensor of the fine (and coarse) network,
+    gradient norm + one random projection; the uniforms are replayed in the test by the same torch seed."""
+    arrs = {}
+    for seed in range(8):
+        c = synth.random_train_render_config(seed)
+        kind, kw = c["kind"], c["kw"]
+        render = NeRFRender(network_config=dict(kw, _target_=c["target"]), sample_coarse=c["n_c"], sample_fine=c["n_f"], dist_near=c["near"],
+                            dist_far=c["far"], max_dist=c["max_dist"], use_coarse_network=c["two"], sampling_type="cone" if c["cone"] else "point")
+        render.network_fine.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.arch_state(kind, kw, 500 + seed).items()})
+        if c["two"]:
+            render.network_coarse.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.arch_state(kind, kw, 600 + seed).items()})
+        if kind != "neus":
+            render.set_iter(1500)
+        cam = Camera(PinholeCalib(c["calib"]), np.r_[c["rotvec"], c["t"]].astype(np.float32))
+        cam.update_transform()
+        uv = torch.from_numpy(c["uv"])
+        rng = np.random.default_rng(8500 + seed)
+        torch.manual_seed(70 + seed)
+        with torch.enable_grad():
+            render.zero_grad()
+            out = render.render_rays(uv, cam)
+            ups = {k: torch.from_numpy(rng.standard_normal(tuple(v.shape)).astype(np.float32)) for k, v in out.items()}
+            sum((out[k] * ups[k]).sum() for k in out).backward()
+        pre = "s%d_" % seed
+        arrs.update({pre + "R": npy(cam.R), pre + "T": npy(cam.T),
+                     pre + "config": np.array(json.dumps(dict(kind=kind, kw=kw, n_c=c["n_c"], n_f=c["n_f"], two=c["two"], cone=c["cone"]))),
+                     pre + "keys": np.array(json.dumps(list(out.keys())))})
+        for k in out:
+            arrs[pre + "out_" + k] = npy(out[k].detach())
+            arrs[pre + "g_" + k] = npy(ups[k])
+        _grad_records(arrs, pre + "fine_", render.network_fine, 8600 + seed)
+        if c["two"]:
+            _grad_records(arrs, pre + "coarse_", render.network_coarse, 8700 + seed)
+        print("  train_render_random seed %d %s rays %d coarse %d fine %d two %d cone %d" % (seed, kind, c["n"], c["n_c"], c["n_f"], c["two"], c["cone"]))
+    save("train_render_random.npz", **arrs)
+
+
 # --------------------------------------------------------------------------
 def gen_dataset():
     """the reference's own NeRFSyntheticDataset (nerf_synthetic_dataset.py:25-84, with cv2.imread backed
@@ -1274,6 +1314,9 @@ if __name__ == "__main__":
         from neddf.ray import Sampling  # noqa: F401
         gen_train_wide_nerf()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "train_render_random":
+        gen_train_render_random()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "rays_random":
         gen_rays_random()
         sys.exit(0)
@@ -1335,3 +1378,4 @@ if __name__ == "__main__":
     gen_render_random()
     gen_stages_random()
     gen_rays_random()
+    gen_train_render_random()
