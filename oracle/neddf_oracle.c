@@ -7,7 +7,11 @@
  *
  * Parity is PINNED: every function below is checked in tests/test_oracle.py
  * against golden vectors produced by importing the reference PyTorch code
- * (tests/golden/gen_goldens.py, run where /root/reference exists).
+ * (tests/golden/gen_goldens.py, run where /root/reference exists): the shipped
+ * network stage by stage, fixed synthetic architectures, edge cases, and -- since
+ * round 4 -- sixty randomly drawn architectures, twenty random render_rays
+ * configurations, sixteen hostile sample_pdf / compositing inputs and twelve
+ * random cameras, each through the reference's own functions.
  *
  * Each function cites the reference file:line it restates (paths relative to
  * the reference checkout).  Arithmetic is fp32 with the same operation order as
