@@ -157,6 +157,191 @@ __global__ __launch_bounds__(512, 1) void ring_kernel(const u32x4 *wfrag, float 
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// the ring kernel with the fragments of k-step ks + 1 read from LDS before the MFMAs of k-step ks (hand software pipeline inside a slab)
+template <int SKS, int NBUF>
+__global__ __launch_bounds__(512, 1) void ring_kernel_sp(const u32x4 *wfrag, float *out, long long *cyc, int layers)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short *act = (unsigned short *)smem;
+    unsigned char *ring = smem + kRows * kLd * 2;
+    constexpr int SLAB = SKS * 8 * 1024, SPL = 16 / SKS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cs = wave & 3, half = wave >> 2;
+    for (int i = tid; i < kRows * kLd; i += 512) act[i] = (unsigned short)(0x3c00 + (i & 63));
+    __syncthreads();
+    const unsigned short *ap = act + (size_t)(half * 64 + (lane & 31)) * kLd + 8 * (lane >> 5);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
+    auto issue = [&](int slab) {
+        const int layer = slab / SPL, g = slab - layer * SPL, buf = slab % NBUF;
+        const u32x4 *src = wfrag + ((size_t)(layer & 1) * 16 * 8 + (size_t)g * SKS * 8) * 64;
+#pragma unroll
+        for (int q = 0; q < SKS; ++q) {
+            const int f = wave * SKS + q;
+            glds16(src + (size_t)f * 64 + lane, ring + buf * SLAB + f * 1024);
+        }
+    };
+    const long long t0 = clock64();
+#pragma unroll
+    for (int s0 = 0; s0 < NBUF - 1; ++s0) issue(s0);
+    __builtin_amdgcn_s_waitcnt(0x0f70 | (SKS * (NBUF - 2)));
+    __builtin_amdgcn_s_barrier();
+    const int nslabs = layers * SPL;
+    for (int slab = 0; slab < nslabs; ++slab) {
+        issue(slab + NBUF - 1);
+        const int g = slab % SPL;
+        const unsigned char *bb = ring + (slab % NBUF) * SLAB;
+        bf16x8 a[2][2], b[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) a[0][m] = *(const bf16x8 *)(ap + (size_t)m * 32 * kLd + (g * SKS) * 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b[0][t] = *(const bf16x8 *)(bb + ((0 * 4 + cs) * 2 + t) * 1024 + lane * 16);
+#pragma unroll
+        for (int ks = 0; ks < SKS; ++ks) {
+            if (ks + 1 < SKS) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a[(ks + 1) & 1][m] = *(const bf16x8 *)(ap + (size_t)m * 32 * kLd + (g * SKS + ks + 1) * 16);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) b[(ks + 1) & 1][t] = *(const bf16x8 *)(bb + (((ks + 1) * 4 + cs) * 2 + t) * 1024 + lane * 16);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][m], b[ks & 1][t], acc[m][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70 | (SKS * (NBUF - 2)));
+        __builtin_amdgcn_s_barrier();
+    }
+    const long long t1 = clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += acc[m][t][i];
+    out[(size_t)blockIdx.x * 512 + tid] = s;
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+// ... and with the FIRST fragments of the next slab read before the barrier that ends this one (ring of four slabs: a slab is waited for
+// one barrier earlier than it is consumed, so its data is visible a whole slab ahead)
+template <int SKS>
+__global__ __launch_bounds__(512, 1) void ring_kernel_xb(const u32x4 *wfrag, float *out, long long *cyc, int layers)
+{
+    constexpr int NBUF = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short *act = (unsigned short *)smem;
+    unsigned char *ring = smem + kRows * kLd * 2;
+    constexpr int SLAB = SKS * 8 * 1024, SPL = 16 / SKS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cs = wave & 3, half = wave >> 2;
+    for (int i = tid; i < kRows * kLd; i += 512) act[i] = (unsigned short)(0x3c00 + (i & 63));
+    __syncthreads();
+    const unsigned short *ap = act + (size_t)(half * 64 + (lane & 31)) * kLd + 8 * (lane >> 5);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
+    auto issue = [&](int slab) {
+        const int layer = slab / SPL, g = slab - layer * SPL, buf = slab % NBUF;
+        const u32x4 *src = wfrag + ((size_t)(layer & 1) * 16 * 8 + (size_t)g * SKS * 8) * 64;
+#pragma unroll
+        for (int q = 0; q < SKS; ++q) {
+            const int f = wave * SKS + q;
+            glds16(src + (size_t)f * 64 + lane, ring + buf * SLAB + f * 1024);
+        }
+    };
+    auto read = [&](int slab, int ks, bf16x8 (&a)[2], bf16x8 (&b)[2]) {
+        const int g = slab % SPL;
+        const unsigned char *bb = ring + (slab % NBUF) * SLAB;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) a[m] = *(const bf16x8 *)(ap + (size_t)m * 32 * kLd + (g * SKS + ks) * 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b[t] = *(const bf16x8 *)(bb + ((ks * 4 + cs) * 2 + t) * 1024 + lane * 16);
+    };
+    const long long t0 = clock64();
+    issue(0); issue(1); issue(2);
+    __builtin_amdgcn_s_waitcnt(0x0f70 | SKS);          // slabs 0 and 1 landed
+    __builtin_amdgcn_s_barrier();
+    bf16x8 a[2][2], b[2][2];
+    read(0, 0, a[0], b[0]);
+    const int nslabs = layers * SPL;
+    for (int slab = 0; slab < nslabs; ++slab) {
+        issue(slab + 3);
+#pragma unroll
+        for (int ks = 0; ks < SKS; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;       // SKS is even: every slab starts in set 0
+            if (ks + 1 < SKS) read(slab, ks + 1, a[nxt], b[nxt]);
+            else read(slab + 1, 0, a[nxt], b[nxt]);     // visible since the barrier that ended slab - 1
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m], b[cur][t], acc[m][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70 | SKS);      // everything but the slab issued in this iteration has landed: slab + 2 is complete
+        __builtin_amdgcn_s_barrier();
+    }
+    const long long t1 = clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += acc[m][t][i];
+    out[(size_t)blockIdx.x * 512 + tid] = s;
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int SKS>
+static void run_ring_xb(const u32x4 *w, float *out, long long *cyc, int cus, int layers)
+{
+    const size_t lds = (size_t)kRows * kLd * 2 + (size_t)4 * SKS * 8 * 1024;
+    (void)hipFuncSetAttribute((const void *)ring_kernel_xb<SKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    float best = 1e9f;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((ring_kernel_xb<SKS>), dim3(cus), dim3(512), lds, 0, w, out, cyc, layers);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double flop = 2.0 * 128 * 256 * 256 * layers * cus;
+    printf("ring of 4 + prefetch across the barrier: %d k-steps per slab (%3zu KB LDS)  %8.3f ms  %6.0f cycles per layer  %7.1f TF  (%.2f of 2.5 PF)\n",
+           SKS, lds / 1024, best, best * 1e-3 * 2.4e9 / layers, flop / (best * 1e-3) * 1e-12, flop / (best * 1e-3) / 2.5e15);
+}
+
+template <int SKS, int NBUF>
+static void run_ring_sp(const u32x4 *w, float *out, long long *cyc, int cus, int layers)
+{
+    const size_t lds = (size_t)kRows * kLd * 2 + (size_t)NBUF * SKS * 8 * 1024;
+    (void)hipFuncSetAttribute((const void *)ring_kernel_sp<SKS, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    float best = 1e9f;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((ring_kernel_sp<SKS, NBUF>), dim3(cus), dim3(512), lds, 0, w, out, cyc, layers);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double flop = 2.0 * 128 * 256 * 256 * layers * cus;
+    printf("ring + fragment prefetch: %d k-steps per slab x %d slabs  %8.3f ms  %6.0f cycles per layer  %7.1f TF  (%.2f of 2.5 PF)\n", SKS, NBUF,
+           best, best * 1e-3 * 2.4e9 / layers, flop / (best * 1e-3) * 1e-12, flop / (best * 1e-3) / 2.5e15);
+}
+
 template <int SKS, int NBUF>
 static void run_ring(const u32x4 *w, float *out, long long *cyc, int cus, int layers)
 {
@@ -219,5 +404,8 @@ int main()
     run_ring<2, 4>(w, out, cyc, cus, layers);
     run_ring<1, 4>(w, out, cyc, cus, layers);
     run_ring<1, 8>(w, out, cyc, cus, layers);
+    run_ring_sp<4, 2>(w, out, cyc, cus, layers);
+    run_ring_sp<2, 3>(w, out, cyc, cus, layers);
+    run_ring_xb<2>(w, out, cyc, cus, layers);
     return 0;
 }
