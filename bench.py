@@ -308,12 +308,28 @@ def self_launch(args):
     raise SystemExit(rc)
 
 
+def _kernel_matches(name, kernel_substr, dtype, masked):
+    """Is `name` (a demangled kernel name from rocprofv3) the dominant kernel of this run?  ddf_rev_kernel<MT, NW, WPS, Ops, MASKY, FUSED>:
+    the operand policy and the MASKY flag (ReLU / LeakyReLU: y' as mask bits) select the instantiation; FUSED defaults to false."""
+    if kernel_substr not in name:
+        return False
+    if ("OpsBF16" in name) != (dtype == "bf16") or ("OpsF16Split" in name) != (dtype == "f16_split"):
+        return False
+    if kernel_substr != "ddf_rev_kernel":
+        return True
+    head = name.split("(")[0]
+    flags = [a.strip() for a in head[head.index("<") + 1:head.rindex(">")].split(",") if a.strip() in ("true", "false")]
+    return bool(flags) and (flags[0] == "true") == masked
+
+
 def measured_traffic(kernel_substr, dtype, masked):
-    """NEDDF_BENCH_PMC=1: HBM bytes per launch of the dominant kernel measured NOW -- two rocprofv3 --pmc passes (FETCH_SIZE, then
-    WRITE_SIZE: the TCC has four counter slots, FETCH_SIZE takes three) over tools/pmc_probe.py, which renders one 65 536-ray
-    slab of the same workload (4 launches of 2^21 points).  bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: both counters are in
-    KB, and on gfx950 FETCH_SIZE reports half of a wide coalesced read stream (MI355X_MICROARCH.md, HBM / rocprofv3 section).
-    Counter passes run with --kernel-trace only (no hip / hsa / memory-copy tracing)."""
+    """HBM bytes per launch of the dominant kernel measured NOW (default at N = 1 when rocprofv3 is on PATH; NEDDF_BENCH_PMC=0 skips it) --
+    two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE: the TCC has four counter slots, FETCH_SIZE takes three) over
+    tools/pmc_probe.py, which renders one 65 536-ray x 128-sample slab of the same workload (ONE launch of 2^23 points at the default
+    launch size).  bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: both counters are in KB, and on gfx950 FETCH_SIZE reports half of a
+    wide coalesced read stream (MI355X_MICROARCH.md, HBM / rocprofv3 section).  Counter passes run with --kernel-trace only (no hip /
+    hsa / memory-copy tracing).  A dispatch may come as several rows (per XCD / dimension): values are SUMMED per Dispatch_Id and the
+    mean is over distinct dispatches."""
     import csv
     import glob
     import shutil
@@ -324,25 +340,25 @@ def measured_traffic(kernel_substr, dtype, masked):
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="neddf_pmc_", dir="/tmp")
-        env = dict(os.environ, TMPDIR="/tmp", NEDDF_PROBE_DTYPE={"f32": "fp32"}.get(dtype, dtype))
-        env.pop("NEDDF_BENCH_PMC", None)
+        env = dict(os.environ, TMPDIR="/tmp", NEDDF_PROBE_DTYPE={"f32": "fp32"}.get(dtype, dtype), NEDDF_BENCH_PMC="0")
         subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", out, "--output-format", "csv", "--", sys.executable,
                         os.path.join(ROOT, "tools", "pmc_probe.py"), "1"], cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL,
-                       stderr=subprocess.DEVNULL, timeout=600)
-        per = []
+                       stderr=subprocess.DEVNULL, timeout=300)
+        per = {}
         for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(path)):
-                k = r["Kernel_Name"]
-                if kernel_substr in k and r["Counter_Name"] == counter and ("OpsBF16" in k) == (dtype == "bf16") and \
-                        ("OpsF16Split" in k) == (dtype == "f16_split") and (kernel_substr != "ddf_rev_kernel" or k.split("(")[0].rstrip("> ").endswith("true") == masked):
-                    per.append(float(r["Counter_Value"]))
+                if r["Counter_Name"] == counter and _kernel_matches(r["Kernel_Name"], kernel_substr, dtype, masked):
+                    key = (path, r.get("Dispatch_Id", len(per)))
+                    per[key] = per.get(key, 0.0) + float(r["Counter_Value"])
         shutil.rmtree(out, ignore_errors=True)
         if not per:
             raise RuntimeError("no %s rows for %s" % (counter, kernel_substr))
-        vals[counter] = sum(per) / len(per)
+        vals[counter] = sum(per.values()) / len(per)
         vals[counter + "_dispatches"] = len(per)
+    if vals["FETCH_SIZE_dispatches"] != vals["WRITE_SIZE_dispatches"]:
+        raise RuntimeError("the two counter passes saw different dispatch counts: %r" % (vals,))
     vals["hbm_bytes_per_launch"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-    vals["points_per_dispatch"] = 65536.0 * 128 / (vals["FETCH_SIZE_dispatches"] / 1.0)     # tools/pmc_probe.py renders ONE 65 536-ray x 128-sample slab
+    vals["points_per_dispatch"] = 65536.0 * 128 / vals["FETCH_SIZE_dispatches"]     # tools/pmc_probe.py renders ONE 65 536-ray x 128-sample slab
     return vals
 
 
@@ -650,8 +666,7 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             want = "ddf_rev_kernel" if reverse else "ddf_trunk_kernel"
             masked = render.bench_network_config["activation_type"] != "tanhExp"      # ReLU / LeakyReLU: the mask-bit kernel
-            ent = next(v for k, v in pmc.items() if want in k and ("OpsBF16" in k) == (args.dtype == "bf16")
-                       and (want != "ddf_rev_kernel" or k.rstrip(">").endswith("true") == masked))
+            ent = next(v for k, v in pmc.items() if _kernel_matches(k, want, args.dtype, masked))
             # the committed pass measured launches of ent["points_per_launch"] points; this run's launches may be larger (the per-point
             # traffic of these kernels does not depend on the launch size: per-workgroup scratch, per-point hand-off)
             per_launch = pts / max(tm["ddf_launches"], 1)
@@ -661,10 +676,18 @@ def main():
             line["roofline"]["points_per_launch"] = per_launch
             line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
             line["roofline"]["traffic_source"] = ("static: %s (a committed rocprofv3 --pmc pass of this kernel and launch size, not measured in "
-                                                  "this run; NEDDF_BENCH_PMC=1 measures it in the run)" % ent["source"])
-            if os.environ.get("NEDDF_BENCH_PMC") == "1":
+                                                  "this run -- the in-run PMC pass was switched off or unavailable)" % ent["source"])
+            import shutil
+            # measured in the run by default (two extra passes over a one-slab probe, outside the timed region, ~1 min);
+            # NEDDF_BENCH_PMC=0 keeps the committed table, =1 insists (a missing rocprofv3 is then reported in traffic_source)
+            pmc_env = os.environ.get("NEDDF_BENCH_PMC", "")
+            if pmc_env == "1" or (pmc_env != "0" and world == 1 and shutil.which("rocprofv3") is not None):
                 try:
                     m = measured_traffic(want, args.dtype, masked)
+                    # the probe's launches must be of this run's size (one 65 536-ray slab = one launch at the default cap): per-point traffic
+                    # of these kernels moved by +55 % between 2^21- and 2^23-point launches, so a mismatch is an error, not a scale factor
+                    if not 0.5 < m["points_per_dispatch"] / per_launch < 2.0:
+                        raise RuntimeError("probe dispatches hold %.0f points, this run's launches %.0f" % (m["points_per_dispatch"], per_launch))
                     m["hbm_bytes_per_launch"] *= per_launch / m["points_per_dispatch"]
                     line["roofline"]["traffic"] = m["hbm_bytes_per_launch"]
                     line["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, "
@@ -674,7 +697,7 @@ def main():
                     line["roofline"]["traffic_static"] = ent["hbm_bytes_per_launch"]
                     ent = dict(ent, hbm_bytes_per_launch=m["hbm_bytes_per_launch"])
                 except Exception as e:
-                    line["roofline"]["traffic_source"] += "; NEDDF_BENCH_PMC=1 failed: %r" % (e,)
+                    line["roofline"]["traffic_source"] += "; the in-run PMC pass failed: %r" % (e,)
             line["roofline"]["algorithmic_hbm_bytes_per_launch"] = ent["algorithmic_bytes_per_launch"]
             # the same launch against the HBM roofline (the 16-bit policies are partly bound by the y' round trip)
             ms = line["roofline"]["avg_launch_ms"]
@@ -724,7 +747,7 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
-        print(json.dumps(line), flush=True)
+        os.write(1, (json.dumps(line) + "\n").encode())       # ONE write(2): the line cannot interleave with another process on the pipe
 
 
 def rng_inclusive(render, cam, n_rays, dev):

@@ -139,7 +139,13 @@ def require_device(t, what):
 
 # NEDDF_GUARD=1 (the bounds probe, include/neddf_hip.h neddf_debug_check_guards): the buffers the CALLER hands to the training entry
 # points -- the workspace and the gradient tensors -- get poisoned bands of their own, checked after every call
-_GUARD = os.environ.get("NEDDF_GUARD", "0") == "1"
+def guard_mode():
+    """NEDDF_GUARD parsed by ONE rule on both sides of the ABI: the library's atoi(value) != 0 (capi_internal.h guard_mode)."""
+    m = __import__("re").match(r"\s*([+-]?\d+)", os.environ.get("NEDDF_GUARD", "0"))
+    return bool(m and int(m.group(1)) != 0)
+
+
+_GUARD = guard_mode()
 _GUARD_WORDS, _GUARD_PATTERN = 1024, 0x5AD0BEEF
 
 

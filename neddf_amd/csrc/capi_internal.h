@@ -59,6 +59,9 @@ struct CommState {
     bool pending = false;
     bool lost = false;           // the communicator was aborted with a gather in flight: the next wait reports it
     DevBuf pad;                  // [nranks * pad_rows * channels] staging for ragged slabs
+    bool in_place = false;       // ragged slabs by one grouped set of broadcasts instead of the padded staging route: decided ONCE
+                                 // at neddf_comm_init from every rank's own capability / NEDDF_GATHER_INPLACE (all ranks must agree)
+    bool force_ragged = false;   // NEDDF_GATHER_FORCE_RAGGED=1 (test hook): equal slabs take the ragged route too
 };
 
 // Every entry point that launches or allocates runs on the ctx's device and leaves the caller's current device as it
@@ -130,6 +133,7 @@ static inline int ensure(neddf_ctx *ctx, DevBuf &b, size_t bytes)
         HIPCHK(hipDeviceSynchronize());      // nothing in flight may still use the old block
         HIPCHK(hipFree(b.base ? b.base : b.p));
         b.p = nullptr; b.cap = 0; b.base = nullptr;
+        if (&b == &ctx->arena) ctx->carve_guards.clear();      // the bands behind the last render's carves lived in the freed block
     }
     if (guard_mode()) {         // exact size (rounded to 16 B) between two poisoned bands: one element past either end lands in a band
         const size_t want = (bytes + 15) & ~(size_t)15;

@@ -32,6 +32,7 @@ typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclI
 #include <chrono>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "capi_internal.h"
 
@@ -180,6 +181,33 @@ int neddf_comm_init(neddf_ctx *ctx, int rank, int nranks, const void *h_id)
         neddf_comm_release(ctx);
         return fail(ctx, NEDDF_EHIP, why);
     }
+    // The route of a ragged gather is a property of the COMMUNICATOR, not of a call: ranks that chose differently (an environment
+    // variable set on one of them, an RCCL without the group calls on another) would issue mismatched collectives and hang.  Every
+    // rank contributes "I can and want to gather in place" (NEDDF_GATHER_INPLACE=1 + the three optional symbols); the route is in
+    // place only if ALL of them said so -- agreed with the one collective every route needs anyway.  Default: the padded staging
+    // route (equal-count all-gather + compaction copies), the one that has run on hardware.
+    const char *ip = getenv("NEDDF_GATHER_INPLACE"), *fr = getenv("NEDDF_GATHER_FORCE_RAGGED");
+    const int mine = (ip && atoi(ip) != 0 && r->Broadcast && r->GroupStart && r->GroupEnd) ? 1 : 0;
+    c.force_ragged = fr && atoi(fr) != 0;
+    c.in_place = mine != 0;
+    if (nranks > 1) {
+        int rc = ensure(ctx, c.pad, sizeof(int) * (size_t)(nranks + 1));
+        std::vector<int> all((size_t)nranks, 0);
+        if (!rc) {
+            int *d = (int *)c.pad.p;
+            e = hipMemcpyAsync(d, &mine, sizeof(int), hipMemcpyHostToDevice, c.stream);
+            ncclResult_t ne = ncclSuccess;
+            if (e == hipSuccess) ne = r->AllGather(d, d + 1, 1, ncclInt32, comm, c.stream);
+            if (e == hipSuccess && ne == ncclSuccess) e = hipMemcpyAsync(all.data(), d + 1, sizeof(int) * (size_t)nranks, hipMemcpyDeviceToHost, c.stream);
+            if (e == hipSuccess && ne == ncclSuccess) e = hipStreamSynchronize(c.stream);
+            if (e != hipSuccess || ne != ncclSuccess) {
+                const std::string why = std::string("comm_init: agreeing on the gather route: ") + (ne != ncclSuccess ? r->GetErrorString(ne) : hipGetErrorString(e));
+                neddf_comm_release(ctx);
+                return fail(ctx, NEDDF_ECOMM, why);
+            }
+        } else { neddf_comm_release(ctx); return rc; }
+        for (int v : all) if (!v) c.in_place = false;
+    }
     return 0;
 }
 
@@ -231,12 +259,12 @@ int neddf_gather_pixels_granular(neddf_ctx *ctx, const float *d_local, int64_t n
         if (h - l > pad) pad = h - l;
     }
     const size_t row = (size_t)channels * sizeof(float);
-    // Ragged slabs (chunk-granular shards: 1 250 chunks of an 800 x 800 frame over 8 ranks are 157 or 156 each) are gathered IN
-    // PLACE: one grouped set of broadcasts, rank q's slab from its own buffer straight to its offset of every rank's d_all -- the
-    // all-gather-v idiom; no staging copy, no padding, no compaction.  NEDDF_GATHER_STAGED=1 (or an RCCL without the group
-    // calls) keeps round 3's route: equal-count all-gather through a padded staging buffer + one compaction copy per rank.
-    static const bool staged_env = [] { const char *e = getenv("NEDDF_GATHER_STAGED"); return e && atoi(e) != 0; }();
-    const bool in_place = ragged && !staged_env && r->Broadcast && r->GroupStart && r->GroupEnd;
+    if (c.force_ragged) ragged = true;          // test hook: one rank (or equal slabs) through the ragged routes
+    // Ragged slabs (chunk-granular shards: 1 250 chunks of an 800 x 800 frame over 8 ranks are 157 or 156 each), default route:
+    // equal-count all-gather through a padded staging buffer + one compaction copy per rank.  Opt-in (NEDDF_GATHER_INPLACE=1 on
+    // EVERY rank, agreed at neddf_comm_init): one grouped set of broadcasts, rank q's slab from its own buffer straight to its
+    // offset of every rank's d_all -- the all-gather-v idiom; no staging copy, no padding, no compaction.
+    const bool in_place = ragged && c.in_place;
     if (ragged && !in_place)
         if (int rc = ensure(ctx, c.pad, (size_t)(c.nranks + 1) * pad * row)) return rc;
     // the communication stream picks up after what `stream` has enqueued so far (the render of this slab) ...
@@ -244,37 +272,50 @@ int neddf_gather_pixels_granular(neddf_ctx *ctx, const float *d_local, int64_t n
     HIPCHK(hipStreamWaitEvent(c.stream, c.ready, 0));
     // ... and after the previous gather's consumers: the caller waited (neddf_comm_wait) before touching its buffers
     tick(ctx, c.stream, NEDDF_STAGE_GATHER, true);
+    // the collective(s); an error leaves through `rc` so that the timing pair opened above is always closed
+    int rc = 0;
+    auto nccl_fail = [&](const char *what, ncclResult_t e_) { if (!rc) rc = fail(ctx, NEDDF_ECOMM, std::string(what) + ": " + r->GetErrorString(e_)); };
+    auto hip_fail = [&](const char *what, hipError_t e_) { if (!rc) { ctx->err = std::string(what) + ": " + hipGetErrorString(e_); rc = NEDDF_EHIP; } };
     if (!ragged) {
-        RCCLCHK(r->AllGather(d_local, d_all, (size_t)pad * channels, ncclFloat, (ncclComm_t)c.comm, c.stream));
+        const ncclResult_t e_ = r->AllGather(d_local, d_all, (size_t)pad * channels, ncclFloat, (ncclComm_t)c.comm, c.stream);
+        if (e_ != ncclSuccess) nccl_fail("ncclAllGather", e_);
     } else if (in_place) {
-        RCCLCHK(r->GroupStart());
-        ncclResult_t first = ncclSuccess;
-        for (int q = 0; q < c.nranks; ++q) {
-            int64_t l, h;
-            neddf_shard_range_granular(n_total, granule, q, c.nranks, &l, &h);
-            if (h <= l) continue;               // more ranks than chunks: that rank contributes nothing
-            char *dst = (char *)d_all + l * row;
-            const ncclResult_t e = r->Broadcast(q == c.rank ? (const void *)d_local : (const void *)dst, dst, (size_t)(h - l) * channels, ncclFloat, q,
-                                                (ncclComm_t)c.comm, c.stream);
-            if (e != ncclSuccess && first == ncclSuccess) first = e;
-        }
-        const ncclResult_t ge = r->GroupEnd();          // always closed, also after a failed member
-        if (first != ncclSuccess) return fail(ctx, NEDDF_ECOMM, std::string("ncclBroadcast (grouped gather): ") + r->GetErrorString(first));
-        if (ge != ncclSuccess) return fail(ctx, NEDDF_ECOMM, std::string("ncclGroupEnd: ") + r->GetErrorString(ge));
+        ncclResult_t first = r->GroupStart();
+        if (first == ncclSuccess) {
+            for (int q = 0; q < c.nranks; ++q) {
+                int64_t l, h;
+                neddf_shard_range_granular(n_total, granule, q, c.nranks, &l, &h);
+                if (h <= l) continue;               // more ranks than chunks: that rank contributes nothing
+                char *dst = (char *)d_all + l * row;
+                const ncclResult_t e_ = r->Broadcast(q == c.rank ? (const void *)d_local : (const void *)dst, dst, (size_t)(h - l) * channels, ncclFloat, q,
+                                                     (ncclComm_t)c.comm, c.stream);
+                if (e_ != ncclSuccess && first == ncclSuccess) first = e_;
+            }
+            const ncclResult_t ge = r->GroupEnd();          // always closed, also after a failed member
+            if (first != ncclSuccess) nccl_fail("ncclBroadcast (grouped gather)", first);
+            else if (ge != ncclSuccess) nccl_fail("ncclGroupEnd", ge);
+        } else nccl_fail("ncclGroupStart", first);
     } else {
         // equal-count all-gather through [send: pad rows | recv: nranks * pad rows], then one compaction copy per rank
         char *send = (char *)c.pad.p, *recv = send + pad * row;
-        if (hi > lo) HIPCHK(hipMemcpyAsync(send, d_local, (size_t)(hi - lo) * row, hipMemcpyDeviceToDevice, c.stream));
-        RCCLCHK(r->AllGather(send, recv, (size_t)pad * channels, ncclFloat, (ncclComm_t)c.comm, c.stream));
-        for (int q = 0; q < c.nranks; ++q) {
+        hipError_t he = hipSuccess;
+        if (hi > lo) he = hipMemcpyAsync(send, d_local, (size_t)(hi - lo) * row, hipMemcpyDeviceToDevice, c.stream);
+        if (he != hipSuccess) hip_fail("hipMemcpyAsync (gather staging)", he);
+        if (!rc) {
+            const ncclResult_t e_ = r->AllGather(send, recv, (size_t)pad * channels, ncclFloat, (ncclComm_t)c.comm, c.stream);
+            if (e_ != ncclSuccess) nccl_fail("ncclAllGather (staged)", e_);
+        }
+        for (int q = 0; q < c.nranks && !rc; ++q) {
             int64_t l, h;
             neddf_shard_range_granular(n_total, granule, q, c.nranks, &l, &h);
-            if (h > l)
-                HIPCHK(hipMemcpyAsync((char *)d_all + l * row, recv + (size_t)q * pad * row, (size_t)(h - l) * row,
-                                      hipMemcpyDeviceToDevice, c.stream));
+            if (h > l) {
+                he = hipMemcpyAsync((char *)d_all + l * row, recv + (size_t)q * pad * row, (size_t)(h - l) * row, hipMemcpyDeviceToDevice, c.stream);
+                if (he != hipSuccess) hip_fail("hipMemcpyAsync (gather compaction)", he);
+            }
         }
     }
     tick(ctx, c.stream, NEDDF_STAGE_GATHER, false);
+    if (rc) return rc;
     HIPCHK(hipEventRecord(c.done, c.stream));
     c.pending = true;
     return 0;

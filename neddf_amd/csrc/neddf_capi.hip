@@ -547,7 +547,21 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     // eval-minimal: 9.1 GB at 2^23 of the 288 GB); NEDDF_FIELD_CHUNK_LOG2 overrides.
     static const int chunk_log2 = [] { const char *e = getenv("NEDDF_FIELD_CHUNK_LOG2"); int v = e ? atoi(e) : 23; return v < 16 ? 16 : (v > 25 ? 25 : v); }();
     const int64_t chunk_cap = full ? (1 << 19) : ((int64_t)1 << chunk_log2);
-    const int64_t chunk = N < chunk_cap ? N : chunk_cap;
+    int64_t chunk = N < chunk_cap ? N : chunk_cap;
+    // The hand-off of one launch (features + per-point record: 1 088 B per point eval-minimal at width 256, 9.1 GB at 2^23 points,
+    // twice that at engine width 512) is bounded by what the DEVICE has free, not by a constant: several contexts or ranks on one
+    // device, or a part with less HBM, get smaller launches (-0.8 .. -2.8 % each halving, profiles/r04_launch_size.txt) instead
+    // of NEDDF_EHIP -- at most a quarter of the free memory (counting what this context's own blocks give back when they grow).
+    if (!fused) {
+        const size_t per_point = ((size_t)fr * wid + kPtAux) * sizeof(float);
+        if (ctx->features.cap < (size_t)chunk * fr * wid * sizeof(float) || ctx->ptaux.cap < (size_t)chunk * kPtAux * sizeof(float)) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                free_b += ctx->features.cap + ctx->ptaux.cap;
+                while (chunk > (1 << 16) && (size_t)chunk * per_point + (size_t)chunk * per_point / 8 > free_b / 4) chunk >>= 1;
+            }
+        }
+    }
     // activations' element type and planes: fp32 1024 B, bf16 512 B, split bf16 (two planes) 1024 B per row
     if (!fused) {
         if (int rc = ensure(ctx, ctx->features, (size_t)chunk * fr * wid * sizeof(float))) return rc;

@@ -33,7 +33,7 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 #define NEDDF_ACT_SPLIT 0
 #endif
 #ifndef NEDDF_ACT_F32
-#define NEDDF_ACT_F32 1
+#define NEDDF_ACT_F32 2
 #endif
 #ifndef NEDDF_ACT_SPLIT
 #define NEDDF_ACT_SPLIT 2
@@ -52,11 +52,13 @@ struct OpsF32T {
     static constexpr int kStep = 8;          // k values per super-step
     static constexpr int kSub = 4;           // MFMA instructions per fragment
     static constexpr bool kFast = false;     // reference-exact elementwise math
-    // tanhExp in the fused kernels as t = 1 - 2 / (e^(2 e^x) + 1) for every x (device_math.h tanhexp_grad_fast: 11 instructions instead of
-    // 23; fp32 MFMA and VALU work do not overlap, so the activation is wall time).  Its absolute error (~1e-7 |x| where e^x is small)
-    // is fp32 rounding noise at the scale of the activations: on the shipped network density / distance / colour sit as close to the
-    // fp64 evaluation as with the branch-exact form (profiles/r03_fast_tanhexp.txt; tests/test_gpu_parity.py holds density to 2.5x the
-    // reference's own fp32 error either way).  The stand-alone ops (nn_module) and the training kernels keep the branch-exact form.
+    // tanhExp in the fused kernels: the middle form (device_math.h tanhexp_grad_mid, 17 instructions: closed form where it keeps
+    // relative accuracy, a fitted odd polynomial below e^x = 0.2).  Rounds 3-4 shipped the closed form alone (mode 1, 11 instructions,
+    // +1.4 % rays/s: fp32 MFMA and VALU work do not overlap, so the activation is wall time); on the negative-bias stress network its
+    // density error was 2.0x the reference's own fp32 error against fp64 -- inside every gate, but with no margin to speak of.  The
+    // middle form is as close to fp64 as the branch-exact build to the printed digits (profiles/r04_act_modes.txt), so the parity
+    // path pays the 1.4 % and the tests hold density to 1.5x (was 2.5x).  The stand-alone ops and the training kernels keep the
+    // branch-exact form; -DNEDDF_ACT_F32=1 builds the closed form for A/B.
     static constexpr int kActMode = NEDDF_ACT_F32;
     static constexpr int kPlanes = 1, kPlane = 0;
     static constexpr bool kLean = false;     // room for register-resident extras (skip partial, feature prefetch)

@@ -94,7 +94,12 @@ def main(argv=None) -> None:
         sync_parameters(state)
         assert_replicas_identical(state)
         if os.environ.get("NEDDF_RUN_PRINT_SIGNATURE"):
-            print("replica_signature[%d]=%.17g" % (rank, float(sum(t.double().sum() for t in state))), flush=True)
+            # one write(2) per rank (ranks under a launcher share one pipe: text and newline written separately interleave), and a
+            # file per rank beside the run directory for whoever wants it without parsing a shared stream
+            sig = "replica_signature[%d]=%.17g" % (rank, float(sum(t.double().sum() for t in state)))
+            (run_dir / ("replica_signature.%d" % rank)).write_text(sig + "\n")
+            sys.stdout.flush()
+            os.write(1, ("\n" + sig + "\n").encode())
         seed_everything(3408 + rank)          # from here on every rank draws its own cameras and pixels
     trainer.run_train()
     if world > 1:

@@ -275,7 +275,7 @@ def test_neddf_bunny_field(dev, orc, bunny_weights, bunny_stages):
         exact = g64[tag + "_density"]
         e_ref = float(np.abs(g[tag + "_density"].astype(np.float64) - exact).max())
         e_hip = float(np.abs(N(o["density"]).astype(np.float64) - exact).max())
-        assert e_hip <= 2.5 * e_ref, (tag, e_hip, e_ref)
+        assert e_hip <= 1.5 * e_ref, (tag, e_hip, e_ref)
         assert float(np.abs(N(o["distance"]).astype(np.float64) - g64[tag + "_distance"]).max()) <= 2e-6
     # minimal mode = same values, no penalty key
     net.output_mode = "minimal"
@@ -294,7 +294,7 @@ def test_neddf_bunny_field(dev, orc, bunny_weights, bunny_stages):
     g64 = golden("bunny_field_fp64.npz")
     e_ref = float(np.abs(g["f_density"].astype(np.float64) - g64["f_density"]).max())
     e_min = float(np.abs(N(o2["density"]).astype(np.float64) - g64["f_density"]).max())
-    assert e_min <= 2.5 * e_ref, (e_min, e_ref)
+    assert e_min <= 1.5 * e_ref, (e_min, e_ref)
 
 
 @pytest.mark.parametrize("name", ["neddf_relu", "neddf_tanhexp", "neddf_leaky", "neddf_w128", "neddf_w384", "neddf_w192", "neddf_skips2"])
@@ -303,7 +303,7 @@ def test_neddf_synth(dev, orc, name):
     shipped architecture, a LeakyReLU variant, and -- the constructors take any width / skip list (neddf.py:52-66) -- hidden
     widths 128, 192 (runs zero-padded on the 256-wide engine) and 384, and two skip connections.  Both differentiation modes
     (full = forward-mode Jacobian rows, minimal = reverse-mode distance gradient), eval and a warm-up iteration.  Gates: the
-    north-star 1e-4 rel + the 1e-5 abs floor of SURVEY N7 on every output; density additionally stays within 2.5x of the
+    north-star 1e-4 rel + the 1e-5 abs floor of SURVEY N7 on every output; density additionally stays within 1.5x of the
     reference's OWN fp32 error against the same network evaluated in double (the *_fp64 fields of the fixture)."""
     g = golden(name + ".npz")
     kw = json.loads(str(g["config"]))
@@ -321,7 +321,7 @@ def test_neddf_synth(dev, orc, name):
         for k in ("distance", "aux_grad", "color", "density", "fields_penalty"):
             assert_close(N(o[k]), g["%s_%s" % (tag, k)], 1e-4, 1e-5, "%s %s %s vs golden" % (name, tag, k))
             assert_close(N(o[k]), ref[k], 1e-4, 1e-5, "%s %s %s vs oracle" % (name, tag, k))
-        assert float(np.abs(N(o["density"]).astype(np.float64) - exact).max()) <= 2.5 * e_ref + 1e-7, (name, tag, "full density vs fp64")
+        assert float(np.abs(N(o["density"]).astype(np.float64) - exact).max()) <= 1.5 * e_ref + 1e-7, (name, tag, "full density vs fp64")
         # the eval-minimal path (reverse-mode distance gradient, ddf_rev_kernel) on the same architecture / iteration state
         net.output_mode = "minimal"
         o2 = net(smp(g, dev))
@@ -329,7 +329,7 @@ def test_neddf_synth(dev, orc, name):
         assert "fields_penalty" not in o2
         for k in ("distance", "aux_grad", "color", "density"):
             assert_close(N(o2[k]), g["%s_%s" % (tag, k)], 1e-4, 1e-5, "%s %s %s minimal vs golden" % (name, tag, k))
-        assert float(np.abs(N(o2["density"]).astype(np.float64) - exact).max()) <= 2.5 * e_ref + 1e-7, (name, tag, "minimal density vs fp64")
+        assert float(np.abs(N(o2["density"]).astype(np.float64) - exact).max()) <= 1.5 * e_ref + 1e-7, (name, tag, "minimal density vs fp64")
 
 
 @pytest.mark.parametrize("name", ["nerf_relu", "nerf_tanhexp", "nerf_w128", "nerf_w384", "nerf_skips2"])
@@ -709,8 +709,8 @@ def test_forward_mode_kernels_in_subprocess():
 def test_reduced_cost_activation_against_the_branch_exact_build(dev):
     """`make exactact` (built by __graft_entry__.build()): the fused kernels of the fp32 / split-fp16 policies with the reference's
     branch-exact tanhExp.  (1) The exact build holds every gate of the stress fixture and of the shipped network -- the exact path
-    stays tested; (2) on the negative-bias fixture the shipped forms stay within the stated factors of it: the fp32 policy's closed
-    form at most 2.5x the exact build's density error against fp64, the split-fp16 policy's polynomial form at most 1.3x."""
+    stays tested; (2) on the negative-bias fixture the shipped forms stay within the stated factors of it: both policies'
+    middle form (closed form + fitted polynomial below e^x = 0.2) at most 1.3x the exact build's density error against fp64."""
     import os
     import re
     import subprocess
@@ -730,7 +730,7 @@ def test_reduced_cost_activation_against_the_branch_exact_build(dev):
         for m in re.finditer(r"negbias (\w+) (\w+): density error vs fp64 -- reference fp32 ([0-9.e+-]+), full ([0-9.e+-]+), minimal ([0-9.e+-]+)", p.stdout):
             errs[(name, m.group(1), m.group(2))] = max(float(m.group(4)), float(m.group(5)))
     assert len(errs) == 8, errs
-    for dtype, factor in (("fp32", 2.5), ("f16_split", 1.3)):
+    for dtype, factor in (("fp32", 1.3), ("f16_split", 1.3)):
         for tag in ("eval", "it2500"):
             assert errs[("shipped", dtype, tag)] <= factor * errs[("exact", dtype, tag)] + 1e-7, (dtype, tag, errs)
 
@@ -1216,7 +1216,7 @@ def test_neddf_negative_bias_regime(dev, orc, dtype):
     does (tests/golden/gen_goldens.py::gen_negbias: 81 % of the pre-activations below -1, median -6.3, minimum -23; D from
     0.014; |pos| to 6 under a rank-10 encoding = sincos arguments to 3 072 rad; zero-variance points).  Both differentiation
     modes, eval and a warm-up iteration, fp32 and split-fp16 operands: every output at the north-star gate (1e-4 rel + 1e-5 abs)
-    against the reference's fp32 golden, density additionally within 2.5x of the reference's OWN fp32 error against its
+    against the reference's fp32 golden, density additionally within 1.5x of the reference's OWN fp32 error against its
     evaluation in double."""
     g, kw, sd = _negbias()
     net = neddf_module(kw, sd, dev)
@@ -1242,7 +1242,7 @@ def test_neddf_negative_bias_regime(dev, orc, dtype):
         print("\nnegbias %s %s: density error vs fp64 -- reference fp32 %.3g, full %.3g, minimal %.3g; distance %.3g (reference %.3g)" % (
             dtype, tag, e_ref, e_full, e_min, float(np.abs(N(o2["distance"]).astype(np.float64) - g[tag + "_distance_fp64"]).max()),
             float(np.abs(g[tag + "_distance"].astype(np.float64) - g[tag + "_distance_fp64"]).max())))
-        assert e_full <= 2.5 * e_ref + 1e-7 and e_min <= 2.5 * e_ref + 1e-7, (dtype, tag, e_ref, e_full, e_min)
+        assert e_full <= 1.5 * e_ref + 1e-7 and e_min <= 1.5 * e_ref + 1e-7, (dtype, tag, e_ref, e_full, e_min)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "f16_split"])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small fixed workload for counter collection: one 65 536-ray slab of the C2
-configuration (128 samples/ray) = 4 distance-trunk + 4 colour-trunk launches of
-2^21 points each.  Used under `rocprofv3 --pmc ... --kernel-trace`."""
+configuration (128 samples/ray) = one distance-trunk + one colour-trunk launch of
+2^23 points at the default launch size (NEDDF_FIELD_CHUNK_LOG2 = 23).  Used under `rocprofv3 --pmc ... --kernel-trace`."""
 import os
 import sys
 
