@@ -920,6 +920,461 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
     }
 }
 
+// One column pass of ddf_rev2_kernel's products with the weight fragments in a ring of D registers sets that runs D super-steps
+// ahead ACROSS the two passes of a layer (a wave's two column tiles are contiguous in the packed weights: one linear stream of
+// 2 k fragments).  A bf16 super-step is four MFMAs = 128 matrix cycles; an L2 round trip under load is 500-800: two super-steps of
+// distance (dense_pipeline3) leave every product waiting on its operands, eight cover the latency with 8 KB in flight per wave.
+// With one column tile per pass a fragment is four registers, so the ring costs 32.
+template <int MT, class Ops, int D>
+__device__ __forceinline__ void dense_ring_pass(f32x16 (&acc)[MT][1], const typename Ops::act_t *act_lane, const WeightStream &w,
+                                                typename Ops::bfrag (&b)[D], int s0, int k, int s_last)
+{
+    static_assert(D % 2 == 0, "the A fragments ping-pong");
+    typename Ops::afrag a[2][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[0][mt] = Ops::load_a(act_lane + mt * 32 * Ops::kLd);
+    const typename Ops::act_t *ap = act_lane;
+    for (int S = 0; S < k; S += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[(u + 1) & 1][mt] = Ops::load_a(ap + (u + 1) * Ops::kStep + mt * 32 * Ops::kLd);
+            __builtin_amdgcn_sched_barrier(0);
+            typename Ops::bfrag bb[1] = { b[u] };
+            dense_mfma<MT, 1, Ops>(acc, a[u & 1], bb);
+            const int nxt = s0 + S + u + D;
+            b[u] = stream_load<typename Ops::bfrag>(w, (unsigned)(nxt < s_last ? nxt : s_last));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ap += D * Ops::kStep;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// ddf_rev2_kernel -- the reverse-mode distance gradient on 128-POINT tiles at TWO workgroups per CU (bf16 operands, round 5).
+//
+// What paces the 16-bit policies' products is the L2 -> VGPR weight stream: a 64-point tile asks the CU's vector memory path for
+// 64 B/clk at full matrix rate and the path delivers at most 63 (profiles/r04_l2_stream_ubench.txt), shared with the y' round trip
+// and the CU's other workgroup.  128 points per fetched fragment halve it.  Rounds 2-4 found no shape for that: 128 accumulators +
+// the y' sets per wave spill (403 registers), one 8-wave workgroup per CU has nothing to cover its barriers and epilogues, and an
+// LDS ring shared by wave pairs puts a CU's eight waves into the same phase (docs/lab_notebook.md R4.11).  This kernel keeps four
+// waves per workgroup and two workgroups per CU -- one's vector epilogue beside the other's matrix phase -- and walks a layer's
+// output in TWO COLUMN PASSES per wave (32 of its 64 columns at a time, all 128 rows: 64 accumulators): the first pass's results
+// wait as 32 registers of packed bf16 pairs while the second pass is multiplied, then both go to the tile in LDS.  Each weight
+// fragment is still fetched once per tile and feeds four M-tiles; the activations are read twice from LDS (128 B/clk/CU at
+// full matrix rate, half of ds_read_b128's rate).  y' of tanhExp travels as EIGHT bits per element (y8_pack4: half of bf16's bytes
+// at bf16's absolute error); ReLU / LeakyReLU as mask bits.  The encoding has no LDS tile of its own here (two 128-row tiles fill
+// the CU's LDS): a skip layer takes it back from the scratch into the tile's first columns, holding both passes' accumulators
+// across that reload (the one place with 128 live accumulators; no y' set is live then).
+// Same packed weights, same scratch, same outputs as ddf_rev_kernel<2, 4, 2, OpsBF16, *>.
+// MT = 4 at two workgroups per CU is that shape; MT = 2 (64 points, 32 accumulators per pass) leaves room for THREE or FOUR workgroups
+// per CU (168 / 128 registers per wave): more waves per SIMD to put one's vector work beside another's matrix work.
+template <class Ops, bool MASKY, int MT, int WPS>
+__global__ __launch_bounds__(256, WPS) void ddf_rev2_kernel(const DdfArgs a)
+{
+    typedef typename Ops::act_t act_t;
+    typedef typename Ops::bfrag frag;
+    constexpr int WID = Ops::kWid, NW = 4, THREADS = 64 * NW, ROWS = MT * 32, P = ROWS, LD = Ops::kLd;
+    static_assert(WID == 64 * NW, "two column passes of 32 per wave");
+    static_assert(MT == 2 || MT == 4, "64- or 128-point tiles");
+    constexpr int NBLK = 2 * MT, BPW = NBLK / NW;      // 32 x 32 blocks of the [P, 64] encoding gradient per wave
+    constexpr int PARTS = THREADS / ROWS;              // threads per point in the tail
+#ifndef NEDDF_REV2_RING
+#define NEDDF_REV2_RING 0       // measured: a ring of 8 on 128-point tiles is SLOWER (25.8 vs 23.5 ms per launch) -- the products do not wait on L2 latency
+#endif
+    constexpr int kRing = NEDDF_REV2_RING;            // weight fragments in flight per wave (dense_ring_pass)
+    constexpr float kInvW = 1.0f / Ops::kWScale;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    act_t *act = (act_t *)smem;
+    float *hd = (float *)(act + ROWS * LD);     // [2 k-halves][2 heads][ROWS] head dot products
+    float *lp = hd + 6 * ROWS;                  // [16]: low-pass scales, ctl at + 12
+    float *tailp = lp + 16;                     // [PARTS][3][ROWS] partial position gradients (768 floats)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
+    float *base = a.rev_scratch + (size_t)blockIdx.x * ((size_t)a.n_layers * P * WID + (size_t)P * 192 + (size_t)P * WID);
+    // y' slots: one byte per element (tanhExp) or one bit (masks), a layer after the other; then the 64-column side arrays
+    unsigned char *yp = (unsigned char *)base;
+    constexpr size_t kYBytes = (size_t)ROWS * WID;
+    // (the last layer has no y' slot: its place and the next hold g_L = w_ddf * y'_L as bf16 pairs while the features are handed off)
+    u32x4 *gslot = (u32x4 *)(yp + (size_t)(a.n_layers - 1) * kYBytes);
+    float *pj = base + (size_t)(a.n_layers + 1) * (kYBytes / 4);  // [ROWS][64] dPE/dx factors: [q] sine half, [32 + q] cosine half
+    float *pv = pj + ROWS * 64;                                 // [ROWS][64] the encoding itself, for the skip layers
+    float *pg = pv + ROWS * 64;                                 // [ROWS][64] the skip layers' share of the encoding gradient, parked
+    if (tid == 0) {
+#pragma unroll
+        for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
+    }
+    const int kin = Ops::kStep * a.layer[0].ksteps;
+    const int K3 = 3 * a.enc.E, KH = a.enc.KH;
+    const unsigned k3magic = (1u << 20) / (unsigned)K3 + 1u;   // item / K3 for item < 4096, K3 <= 30: (item * magic) >> 20 is exact
+    const int64_t ntiles = (a.n_points + P - 1) / P;
+    const int KS = a.ks_hidden;
+    const int ct0 = wave * 2;                                   // this wave's two column tiles: ct0, ct0 + 1
+
+    int *ctl = (int *)(lp + 12);
+    int64_t tile = sched_begin(a.sched, a.sched_flags, ctl, tid);
+    while (tile < ntiles) {
+        const int64_t p0 = tile * P;
+        // the tile's positions / variances: one coalesced request per array into LDS (the tail's partial-sum area, free until then) --
+        // the encoding loop below then waits on nothing but LDS (per-item global loads were a chain of dependent L2 round trips)
+        for (int idx = tid; idx < 6 * ROWS; idx += THREADS) {
+            const int k = idx < 3 * ROWS ? idx : idx - 3 * ROWS, p = (k * 43691) >> 17, d = k - 3 * p;      // k / 3 for k < 384
+            const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
+            tailp[idx] = idx < 3 * ROWS ? a.pos[gp * 3 + d] : (a.neus ? 0.0f : a.var[gp * 3 + d]);
+        }
+        zero_cols<Ops, THREADS>(act, ROWS, kin, tid);
+        __syncthreads();
+        int next_tile = 0;
+        if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
+        // scaled integrated encoding (neddf.py:193-204), value rows; the factors of its Jacobian and a copy go to the scratch
+        for (int item = tid; item < P * K3; item += THREADS) {
+            const int p = (int)(((unsigned)item * k3magic) >> 20), q = item - p * K3;
+            const int e = (q * 11) >> 5, d = q - 3 * e;
+            float vs, vc, js, jc;
+            if (a.neus) pe_pair<false, Ops::kFast>(e, tailp[p * 3 + d], 0.0f, lp[e], vs, vc, js, jc);      // plain PE (neus.py:118)
+            else pe_pair<true, Ops::kFast>(e, tailp[p * 3 + d], tailp[3 * ROWS + p * 3 + d], lp[e], vs, vc, js, jc);
+            Ops::put(act + p * LD + q, vs);
+            Ops::put(act + p * LD + KH + q, vc);
+            pj[p * 64 + q] = js;
+            pj[p * 64 + 32 + q] = jc;
+            pv[p * 64 + q] = vs;               // same column order as the LDS tile: [sine half (KH) | cosine half (KH)]
+            pv[p * 64 + KH + q] = vc;
+        }
+        __syncthreads();
+
+        // ---- forward, value rows
+        for (int l = 0; l < a.n_layers; ++l) {
+            const LayerW &L = a.layer[l];
+            const bool last = l + 1 == a.n_layers, skip = L.stash >= 0;
+            unsigned char *ysl = yp + (size_t)l * kYBytes;
+            f32x16 accA[MT][1], accB[MT][1];
+            unsigned ypk[MT][8];
+            // the epilogue of one column tile: activation, y -> packed pairs (HOLD) or the LDS tile, y' -> its slot (or the seed g_L)
+            auto epilogue = [&](f32x16 (&acc)[MT][1], int t, bool hold) {
+                const int ct = ct0 + t;
+                const float ws = last ? a.w_ddf_out[ct * 32 + j] : 1.0f;
+                unsigned mw[2] = { 0u, 0u };
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    act_t *o = act + (mt * 32 + 4 * h) * LD + ct * 32 + j;
+                    f32x16 dv;
+                    unsigned gl[8];
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) {
+                        const int r = 8 * (q >> 2) + (q & 3);
+                        float y[2], dy[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            float z = acc[mt][0][q + u];
+                            if constexpr (Ops::kWScale != 1.0f) z *= kInvW;
+                            if constexpr (MASKY) {
+                                if (a.activation == 0) act_grad<0, Ops::kActMode>(z, y[u], dy[u]);
+                                else act_grad<1, Ops::kActMode>(z, y[u], dy[u]);
+                                mw[mt >> 1] |= (dy[u] == 1.0f ? 1u : 0u) << (16 * (mt & 1) + q + u);
+                            } else act_grad<2, Ops::kActMode>(z, y[u], dy[u]);
+                            dv[q + u] = dy[u];
+                        }
+                        if (hold) ypk[mt][q >> 1] = Ops::pack2(y[0], y[1]);
+                        else Ops::put2(o + r * LD, o + (r + 1) * LD, y[0], y[1]);
+                        if (last) gl[q >> 1] = Ops::pack2(ws * dy[0], ws * dy[1]);
+                    }
+                    if (last) {     // the seed of the reverse pass waits in the scratch: held in registers it would be live through every layer
+                        gslot[(((size_t)ct * MT + mt) * 2 + 0) * 64 + lane] = (u32x4){ gl[0], gl[1], gl[2], gl[3] };
+                        gslot[(((size_t)ct * MT + mt) * 2 + 1) * 64 + lane] = (u32x4){ gl[4], gl[5], gl[6], gl[7] };
+                    }
+                    if constexpr (!MASKY) {
+                        if (!last) ((u32x4 *)ysl)[((size_t)ct * MT + mt) * 64 + lane] = y8_pack16(dv);
+                    }
+                }
+                if constexpr (MASKY) {
+                    if (!last) {
+                        ((unsigned *)ysl)[((size_t)ct * 2 + 0) * 64 + lane] = mw[0];
+                        if constexpr (MT > 2) ((unsigned *)ysl)[((size_t)ct * 2 + 1) * 64 + lane] = mw[1];
+                    }
+                }
+            };
+            acc_init<MT, 1, false>(accA, L.bias, ct0, lane, Ops::kWScale);
+            if (kRing > 0 && L.ksteps % (kRing > 0 ? kRing : 1) == 0) {        // (every width-wide product; the narrow first layer takes the plain pipeline)
+                const WeightStream wst = weight_stream((const frag *)L.wp + (size_t)ct0 * L.ksteps * 64 + lane);
+                frag ring[kRing > 0 ? kRing : 2];
+#pragma unroll
+                for (int u = 0; u < kRing; ++u) ring[u] = stream_load<frag>(wst, (unsigned)u);
+                dense_ring_pass<MT, Ops, (kRing > 0 ? kRing : 2)>(accA, act_lane, wst, ring, 0, L.ksteps, 2 * L.ksteps - 1);
+                if (!skip) epilogue(accA, 0, true);
+                acc_init<MT, 1, false>(accB, L.bias, ct0 + 1, lane, Ops::kWScale);
+                dense_ring_pass<MT, Ops, (kRing > 0 ? kRing : 2)>(accB, act_lane, wst, ring, L.ksteps, L.ksteps, 2 * L.ksteps - 1);
+            } else {
+                dense<MT, 1, Ops>(accA, act_lane, (const frag *)L.wp + (size_t)ct0 * L.ksteps * 64 + lane, L.ksteps);
+                if (!skip) epilogue(accA, 0, true);
+                acc_init<MT, 1, false>(accB, L.bias, ct0 + 1, lane, Ops::kWScale);
+                dense<MT, 1, Ops>(accB, act_lane, (const frag *)L.wp + (size_t)(ct0 + 1) * L.ksteps * 64 + lane, L.ksteps);
+            }
+            __syncthreads();                            // every wave finished reading the hidden state
+            if (skip) {     // cat([encoding, h]) (neddf.py:217-219): the encoding comes back from the scratch into the tile's first columns
+                const StashW &sw = a.stash[L.stash];
+                for (int i = tid; i < ROWS * (kin / 4); i += THREADS) {
+                    const int r = i / (kin / 4), c = i - r * (kin / 4);
+                    f32x4v v = { 0.f, 0.f, 0.f, 0.f };
+                    if (4 * c < 64) v = *(const f32x4v *)(pv + r * 64 + 4 * c);
+                    // columns [K3, KH) and [KH + K3, 2 KH) of the scratch rows were never written: mask them
+                    float x[4] = { v[0], v[1], v[2], v[3] };
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int cc = 4 * c + u, qq = cc < KH ? cc : cc - KH;
+                        Ops::put(act + r * LD + cc, (cc < 2 * KH && qq < K3) ? x[u] : 0.f);
+                    }
+                }
+                __syncthreads();
+                dense<MT, 1, Ops>(accA, act_lane + sw.col0, (const frag *)sw.wp + (size_t)ct0 * sw.ksteps * 64 + lane, sw.ksteps);
+                dense<MT, 1, Ops>(accB, act_lane + sw.col0, (const frag *)sw.wp + (size_t)(ct0 + 1) * sw.ksteps * 64 + lane, sw.ksteps);
+                __syncthreads();                        // every wave finished reading the encoding columns
+                epilogue(accA, 0, false);
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    act_t *o = act + (mt * 32 + 4 * h) * LD + ct0 * 32 + j;
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) Ops::put_packed2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, ypk[mt][q >> 1]);
+                }
+            }
+            epilogue(accB, 1, false);
+            __syncthreads();
+        }
+        // ---- heads on the features (value only) and the feature hand-off to the colour kernel
+        for (int item = tid; item < 4 * ROWS; item += THREADS) {       // 2 k-halves x 2 heads x ROWS rows
+            const int part = item / (2 * ROWS), head = (item / ROWS) & 1, row = item % ROWS;
+            const f32x4v *w = (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out) + part * (WID / 8);
+            const act_t *ar = act + row * LD + part * (WID / 2);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < WID / 8; ++k) {
+                float x[4];
+                Ops::load4(ar + 4 * k, x);
+                f32x4v ww = w[k];
+                s0 = fmaf(x[0], ww[0], s0); s1 = fmaf(x[1], ww[1], s1);
+                s2 = fmaf(x[2], ww[2], s2); s3 = fmaf(x[3], ww[3], s3);
+            }
+            hd[item] = (s0 + s1) + (s2 + s3);
+        }
+        {
+            constexpr int CE = 16 / sizeof(act_t), CPP = WID / CE, CPR = Ops::kPlanes * CPP;
+            act_t *features = (act_t *)a.features;
+            for (int idx = tid; features && idx < P * CPR; idx += THREADS) {
+                const int p = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
+                if (p0 + p < a.n_points) {
+                    f32x4v v = *(const f32x4v *)(act + p * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));
+                    *(f32x4v *)(features + (size_t)(p0 + p) * (Ops::kPlanes * WID) + CE * c4) = v;
+                }
+            }
+        }
+        __syncthreads();                // the features are consumed: the tile now carries gradients
+        // ---- reverse pass: g_L -> LDS
+        // (requested before the barrier above could not be: the same lanes wrote them in the last epilogue, so program order suffices)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                act_t *o = act + (mt * 32 + 4 * h) * LD + (ct0 + t) * 32 + j;
+                const u32x4 g0 = gslot[(((size_t)(ct0 + t) * MT + mt) * 2 + 0) * 64 + lane], g1 = gslot[(((size_t)(ct0 + t) * MT + mt) * 2 + 1) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    Ops::put_packed2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, g0[q >> 1]);
+                    Ops::put_packed2(o + (8 * ((q + 8) >> 2) + (q & 3)) * LD, o + (8 * ((q + 8) >> 2) + (q & 3) + 1) * LD, g1[q >> 1]);
+                }
+            }
+        __syncthreads();
+        f32x4v *gpe_park = (f32x4v *)pg + (size_t)wave * BPW * 4 * 64 + lane;
+        bool parked = false;
+        for (int l = a.n_layers - 1; l >= 1; --l) {
+            if (a.layer[l].stash >= 0) {    // cat([encoding, h]): the encoding rows of W_l take their share of g_l (every skip layer adds its own)
+#pragma unroll
+                for (int i = 0; i < BPW; ++i) {
+                    const int b = wave * BPW + i;
+                    f32x16 gs[1][1];
+                    if (parked) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4v v = gpe_park[(i * 4 + g) * 64];
+                            gs[0][0][4 * g] = v[0]; gs[0][0][4 * g + 1] = v[1]; gs[0][0][4 * g + 2] = v[2]; gs[0][0][4 * g + 3] = v[3];
+                        }
+                    } else acc_init<1, 1, false>(gs, nullptr, wave, lane);
+                    dense<1, 1, Ops>(gs, act_lane + (b >> 1) * 32 * LD, (const frag *)a.wT_pe_skip[a.layer[l].stash] + (size_t)(b & 1) * KS * 64 + lane, KS);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4v v = { gs[0][0][4 * g], gs[0][0][4 * g + 1], gs[0][0][4 * g + 2], gs[0][0][4 * g + 3] };
+                        gpe_park[(i * 4 + g) * 64] = v;
+                    }
+                }
+                parked = true;
+            }
+            // g_{l-1} = (g_l W_l^T) * y'_{l-1}, two column passes like the forward layers
+            const unsigned char *ysl = yp + (size_t)(l - 1) * kYBytes;
+            f32x16 acc[MT][1];
+            unsigned gp0[MT][8];
+            auto scaled = [&](int t, bool hold) {      // acc * y' of column tile ct0 + t -> packed pairs (hold) or the LDS tile
+                const int ct = ct0 + t;
+                unsigned mw[2] = { 0u, 0u };
+                u32x4 yq[MT];
+                if constexpr (MASKY) {
+                    mw[0] = ((const unsigned *)ysl)[((size_t)ct * 2 + 0) * 64 + lane];
+                    if constexpr (MT > 2) mw[1] = ((const unsigned *)ysl)[((size_t)ct * 2 + 1) * 64 + lane];
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) yq[mt] = ((const u32x4 *)ysl)[((size_t)ct * MT + mt) * 64 + lane];
+                }
+                if (!hold) __syncthreads();             // every wave finished reading g_l (the second pass's product is behind us)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    act_t *o = act + (mt * 32 + 4 * h) * LD + ct * 32 + j;
+                    if (!hold && t == 1) {              // the first pass's pairs go out next to the second's
+                        act_t *o0 = o - 32;
+#pragma unroll
+                        for (int q = 0; q < 16; q += 2) Ops::put_packed2(o0 + (8 * (q >> 2) + (q & 3)) * LD, o0 + (8 * (q >> 2) + (q & 3) + 1) * LD, gp0[mt][q >> 1]);
+                    }
+                    float f[16];
+                    if constexpr (MASKY) {
+                        const unsigned bits = mw[mt >> 1] >> (16 * (mt & 1));
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) f[q] = mask_factor<Ops>((bits >> q) & 1u, a.activation);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f[4 * g] = y8_get<0>(yq[mt][g]); f[4 * g + 1] = y8_get<1>(yq[mt][g]);
+                            f[4 * g + 2] = y8_get<2>(yq[mt][g]); f[4 * g + 3] = y8_get<3>(yq[mt][g]);
+                        }
+                        if constexpr (Ops::kWScale != 1.0f) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) f[q] *= kInvW;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) {
+                        const int r = 8 * (q >> 2) + (q & 3);
+                        if (hold) gp0[mt][q >> 1] = Ops::pack2(acc[mt][0][q] * f[q], acc[mt][0][q + 1] * f[q + 1]);
+                        else Ops::put2(o + r * LD, o + (r + 1) * LD, acc[mt][0][q] * f[q], acc[mt][0][q + 1] * f[q + 1]);
+                    }
+                }
+            };
+            acc_init<MT, 1, false>(acc, nullptr, wave, lane);
+            if (kRing > 0 && KS % (kRing > 0 ? kRing : 1) == 0) {
+                const WeightStream wst = weight_stream((const frag *)a.wT[l] + (size_t)ct0 * KS * 64 + lane);
+                frag ring[kRing > 0 ? kRing : 2];
+#pragma unroll
+                for (int u = 0; u < kRing; ++u) ring[u] = stream_load<frag>(wst, (unsigned)u);
+                dense_ring_pass<MT, Ops, (kRing > 0 ? kRing : 2)>(acc, act_lane, wst, ring, 0, KS, 2 * KS - 1);
+                scaled(0, true);
+                acc_init<MT, 1, false>(acc, nullptr, wave, lane);
+                dense_ring_pass<MT, Ops, (kRing > 0 ? kRing : 2)>(acc, act_lane, wst, ring, KS, KS, 2 * KS - 1);
+            } else {
+                dense<MT, 1, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)ct0 * KS * 64 + lane, KS);
+                scaled(0, true);
+                acc_init<MT, 1, false>(acc, nullptr, wave, lane);
+                dense<MT, 1, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)(ct0 + 1) * KS * 64 + lane, KS);
+            }
+            scaled(1, false);
+            __syncthreads();
+        }
+        f32x16 gpe[BPW][1];
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int b = wave * BPW + i;
+            f32x16 one[1][1];
+            if (parked) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4v v = gpe_park[(i * 4 + g) * 64];
+                    one[0][0][4 * g] = v[0]; one[0][0][4 * g + 1] = v[1]; one[0][0][4 * g + 2] = v[2]; one[0][0][4 * g + 3] = v[3];
+                }
+            } else acc_init<1, 1, false>(one, nullptr, wave, lane);
+            dense<1, 1, Ops>(one, act_lane + (b >> 1) * 32 * LD, (const frag *)a.wT_pe0 + (size_t)(b & 1) * KS * 64 + lane, KS);       // g_0 W_0^T
+            gpe[i][0] = one[0][0];
+        }
+        __syncthreads();                // every wave finished reading g_0
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int b = wave * BPW + i;
+            act_t *o = act + ((b >> 1) * 32 + 4 * h) * LD + (b & 1) * 32 + j;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float g = gpe[i][0][q];
+                if constexpr (Ops::kWScale != 1.0f) g *= kInvW;
+                Ops::put(o + (8 * (q >> 2) + (q & 3)) * LD, g);
+            }
+        }
+        __syncthreads();
+        // ---- per point: grad_x z_D = sum over the encoding channels of g_pe * dPE/dx (two threads per point, every other frequency each),
+        // then the head arithmetic (neddf.py:220-241)
+        {
+            const int part = tid / ROWS, p = tid & (ROWS - 1);
+            const act_t *gr = act + p * LD;
+            const float *pjr = pj + p * 64;
+            float gz[3] = { 0.f, 0.f, 0.f };
+            for (int e = part; e < a.enc.E; e += PARTS)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int q = 3 * e + d;
+                    gz[d] = fmaf(Ops::get(gr + q), pjr[q], gz[d]);
+                    gz[d] = fmaf(Ops::get(gr + KH + q), pjr[32 + q], gz[d]);
+                }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) tailp[(part * 3 + d) * ROWS + p] = gz[d];
+        }
+        __syncthreads();
+        if (tid < P && p0 + tid < a.n_points) {
+            const int64_t gp = p0 + tid;
+            float gz[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                gz[d] = tailp[d * ROWS + tid];
+#pragma unroll
+                for (int q = 1; q < PARTS; ++q) gz[d] += tailp[(q * 3 + d) * ROWS + tid];
+            }
+            const float z = (hd[tid] + hd[2 * ROWS + tid]) + a.b_ddf_out;
+            const float az = (hd[ROWS + tid] + hd[3 * ROWS + tid]) + a.b_aux_out;
+            if (a.neus) {       // NeuS: the "distance head" is e_0, so z is the sdf and gz its position gradient (neus.py:132-156)
+                const float ex = expf(-a.neus_v10 * z), den = 1 + ex;
+                const float rho = a.neus_v10 * ex * (1.0f / (den * den));
+                if (a.ptaux) {
+                    float *pa = a.ptaux + gp * kPtAux;
+                    f32x4v v0 = { z, rho, 0.f, gz[0] };
+                    f32x4v v1 = { gz[1], gz[2], 0.f, 0.f };
+                    ((f32x4v *)pa)[0] = v0; ((f32x4v *)pa)[1] = v1;
+                }
+                if (a.distance) a.distance[gp] = z;
+                if (a.density) a.density[gp] = rho;
+            } else {
+                float sp, dsp, t, dsg;
+                softplus_grad(z, sp, dsp);               // softplus.py:38-49
+                const float D = sp + a.d_near;
+                const float dg0 = dsp * gz[0], dg1 = dsp * gz[1], dg2 = dsp * gz[2];
+                sigmoid_grad(az, t, dsg);                // sigmoid.py:38-43
+                const float aux = a.aux_grad_scale * t;
+                const float q2 = dg0 * dg0 + dg1 * dg1 + dg2 * dg2;
+                const float dgn = sqrtf(q2);
+                const float dDdt = sqrtf(q2 + aux * aux);              // neddf.py:234-238
+                const float Dinv = 1.0f / D;
+                const float rho = act_val_rt(a.density_activation, Dinv * (1 - dDdt));   // :239-240
+                const float ninv = 1.0f / (dgn + 1e-7f);               // :241
+                if (a.ptaux) {
+                    float *pa = a.ptaux + gp * kPtAux;
+                    f32x4v v0 = { D, rho, aux, ninv * dg0 };
+                    f32x4v v1 = { ninv * dg1, ninv * dg2, z, az };
+                    f32x4v v2 = { dg0, dg1, dg2, 0.f };
+                    f32x4v v3 = { 0.f, 0.f, dgn, dDdt };
+                    ((f32x4v *)pa)[0] = v0; ((f32x4v *)pa)[1] = v1; ((f32x4v *)pa)[2] = v2; ((f32x4v *)pa)[3] = v3;
+                }
+                if (a.distance) a.distance[gp] = D;
+                if (a.density) a.density[gp] = rho;
+                if (a.aux_grad) a.aux_grad[gp] = aux;
+            }
+        }
+        if (tid == 0) ctl[0] = next_tile;
+        __syncthreads();
+        tile = ctl[0];
+    }
+}
+
 // ----------------------------------------------------------------------------
 // NeDDF colour trunk.  ROWS4 = false: eval-minimal, one row per point (the
 // colour Jacobian is dead code in eval); ROWS4 = true:
@@ -1484,6 +1939,16 @@ static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s, const Co
     else hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, true>), dim3(grid), dim3(64 * NW), rev_lds_bytes<Ops>(MT), s, a, none);
 }
 
+template <class Ops, int MT, int WPS>
+static void launch_ddf_rev2(const DdfArgs &a, int grid, hipStream_t s)
+{
+    static bool once = (set_lds((const void *)ddf_rev2_kernel<Ops, false, MT, WPS>, lds_bytes<Ops>(MT)),
+                        set_lds((const void *)ddf_rev2_kernel<Ops, true, MT, WPS>, lds_bytes<Ops>(MT)), true);
+    (void)once;
+    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev2_kernel<Ops, false, MT, WPS>), dim3(grid), dim3(256), lds_bytes<Ops>(MT), s, a);
+    else hipLaunchKernelGGL((ddf_rev2_kernel<Ops, true, MT, WPS>), dim3(grid), dim3(256), lds_bytes<Ops>(MT), s, a);
+}
+
 // Tile shape of the reverse-mode kernel at width 256 per operand policy: (MT, NW, WPS) = (2, 4, 2) under fp32; the 16-bit policies
 // take NEDDF_REV_GEO="MTxNWxWPS" (probes: eight waves per workgroup = 32 columns per wave, three workgroups per CU)
 static Geo geo_rev(int operands)
@@ -1491,7 +1956,7 @@ static Geo geo_rev(int operands)
     static Geo g[3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
     if (!g[0].mt) {
         g[0] = Geo{ 2, 2, 4 };
-        g[1] = parse_geo("NEDDF_REV_GEO_BF16", Geo{ 2, 2, 4 }, { { 2, 2, 4 }, { 4, 2, 4 }, { 2, 2, 8 }, { 2, 3, 4 } });
+        g[1] = parse_geo("NEDDF_REV_GEO_BF16", Geo{ 2, 2, 4 }, { { 2, 2, 4 }, { 4, 2, 4 }, { 2, 2, 8 }, { 2, 3, 4 }, { 2, 4, 4 } });
         g[2] = parse_geo("NEDDF_REV_GEO_SPLIT", Geo{ 2, 2, 4 }, { { 2, 2, 4 }, { 2, 2, 8 } });
     }
     return g[operands < 0 || operands > 2 ? 0 : operands];
@@ -1509,7 +1974,7 @@ static void launch_ddf_rev_w(const DdfArgs &a, int grid, hipStream_t s, const Co
 }
 
 // the shapes that can take the colour trunk on their tile (four waves per workgroup: every shipped shape; the eight-wave probes cannot)
-bool ddf_rev_can_fuse(int operands, int width) { return width != 256 || (geo_rev(operands).nw == 4 && geo_rev(operands).wps == 2); }
+bool ddf_rev_can_fuse(int operands, int width) { return width != 256 || (geo_rev(operands).mt == 2 && geo_rev(operands).nw == 4 && geo_rev(operands).wps == 2); }
 
 void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *col)
 {
@@ -1523,8 +1988,14 @@ void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *co
     }
     if (a.operands == 1) {
         NEDDF_GEO_CASE(2, 2, 8) return launch_ddf_rev_t<2, 8, 2, OpsBF16>(a, grid, s);
-        NEDDF_GEO_CASE(2, 3, 4) return launch_ddf_rev_t<2, 4, 3, OpsBF16>(a, grid, s);
-        NEDDF_GEO_CASE(4, 2, 4) return launch_ddf_rev_t<4, 4, 2, OpsBF16>(a, grid, s);
+        // two column passes per wave (ddf_rev2_kernel): 128-point tiles, or 64-point tiles at three / four workgroups per CU
+        NEDDF_GEO_CASE(4, 2, 4) return launch_ddf_rev2<OpsBF16, 4, 2>(a, grid, s);
+        NEDDF_GEO_CASE(2, 3, 4) return launch_ddf_rev2<OpsBF16, 2, 3>(a, grid, s);
+        NEDDF_GEO_CASE(2, 4, 4) return launch_ddf_rev2<OpsBF16, 2, 4>(a, grid, s);
+        {
+            static const bool two_pass = [] { const char *e = getenv("NEDDF_REV2"); return e && atoi(e) != 0; }();
+            if (two_pass && g.mt == 2 && g.wps == 2 && g.nw == 4) return launch_ddf_rev2<OpsBF16, 2, 2>(a, grid, s);
+        }
         return launch_ddf_rev_t<2, 4, 2, OpsBF16>(a, grid, s, col);
     }
     launch_ddf_rev_t<2, 4, 2, OpsF32>(a, grid, s, col);
