@@ -440,23 +440,38 @@ __device__ __forceinline__ void rev_forward_epilogue_rt(f32x16 (&acc)[MT][NT], t
 // tile's first columns receive [embed_pos | embed_dir | normal] (the unscaled encoding is the saved scaled one times 2^(e-1): exact,
 // no second sincos), the small-input product joins the parked one, and the remaining colour layers and the 256 -> 3 head follow.
 // No [N, 256] feature matrix, no per-point record, no second launch: the hand-off of 1 088 B per point never reaches HBM.
-template <int MT, int NW, int WPS, class Ops, bool MASKY, bool FUSED = false>
-__global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const DdfArgs a, const ColArgs c)
+// TEAMS = 2 (16-bit policies, round 5): ONE workgroup of eight waves per CU, two TEAMS of four waves, each on a 64-point tile of its
+// own (own LDS region, own scratch slot) running this very code -- with team 1 ONE BARRIER BEHIND team 0.  s_barrier counts arrivals,
+// not program locations: team 1 enters the tile loop through one extra barrier (team 0 leaves it through one), so its k-th barrier
+// pairs with team 0's (k + 1)-th and every phase boundary of a team is still a barrier all of its waves reach together.  The phases of
+// a tile alternate matrix work (a product) and vector work (an epilogue): with the teams one phase apart, a SIMD's two waves are in
+// COMPLEMENTARY phases by construction -- one's bf16 / f16 MFMAs beside the other's VALU, which gfx950 overlaps completely (R4.1) --
+// where two independent workgroups drift through every relative phase (both in their epilogues half of the time).  Tiles are handed
+// out in pairs (one queue entry = tiles 2 k and 2 k + 1) so that both teams run the same number of barriers; a missing last tile is
+// dummy work with every store masked.
+template <int MT, int NW, int WPS, class Ops, bool MASKY, bool FUSED = false, int TEAMS = 1>
+__global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void ddf_rev_kernel(const DdfArgs a, const ColArgs c)
 {
     typedef typename Ops::act_t act_t;
     typedef typename Ops::bfrag frag;
     constexpr int WID = Ops::kWid, NT = WID / 32 / NW, THREADS = 64 * NW, ROWS = MT * 32, P = ROWS, LD = Ops::kLd;
+    static_assert(TEAMS == 1 || (TEAMS == 2 && !FUSED && NW == 4), "twin teams: two four-wave teams, two-kernel route");
+    // LDS of one team: the tile, the small arrays behind it, the encoding's own tile (rev_lds_bytes)
+    constexpr size_t TEAM_BYTES = (size_t)ROWS * LD * sizeof(act_t) + (size_t)kRevSmallFloats * sizeof(float) +
+                                  (Ops::kEncInLds ? (size_t)ROWS * kEncLd * sizeof(act_t) : 0);
+    static_assert(TEAM_BYTES % 16 == 0, "a team's LDS region keeps the 16-byte alignment of the fragments");
     static_assert(NT >= 1 && NT * 32 * NW == WID, "engine width = NW waves x NT column tiles of 32");
     // 32 x 32 blocks of the [P, 64] encoding gradient per wave; a 32-point tile has two blocks for four waves: the upper waves idle there
     constexpr int NBLK = 2 * MT, BPW = NBLK >= NW ? NBLK / NW : 1;
     static_assert(BPW * NW == NBLK || NBLK < NW, "the encoding gradient's blocks must divide over the waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    act_t *act = (act_t *)smem;
+    const int team = TEAMS > 1 ? (int)threadIdx.x / THREADS : 0;
+    act_t *act = (act_t *)((char *)smem + (size_t)team * TEAM_BYTES);
     float *hd = (float *)(act + ROWS * LD);  // [2 k-halves][2 heads][ROWS] head dot products
     float *lp = hd + 6 * ROWS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = TEAMS > 1 ? (int)threadIdx.x % THREADS : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
-    float *yp = a.rev_scratch + (size_t)blockIdx.x * ((size_t)a.n_layers * P * WID + (size_t)P * 192 + (size_t)P * WID);
+    float *yp = a.rev_scratch + ((size_t)blockIdx.x * TEAMS + team) * ((size_t)a.n_layers * P * WID + (size_t)P * 192 + (size_t)P * WID);
     float *pj = yp + (size_t)a.n_layers * ROWS * WID;           // [ROWS][64] dPE/dx factors: [q] sine half, [32 + q] cosine half
     float *pv = pj + ROWS * 64;                                  // [ROWS][64] the encoding itself, for the skip layer (and the colour trunk's inputs)
     float *pg = pv + ROWS * 64;                                  // [ROWS][64] the skip layers' share of the encoding gradient, parked
@@ -473,6 +488,11 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
     }
     const int kin = Ops::kStep * a.layer[0].ksteps;
     const int K3 = 3 * a.enc.E, KH = a.enc.KH;
+    // four-wave workgroups stage the tile's inputs in LDS and spread the tail over every thread (round 5); the eight-wave probes keep the
+    // per-item loads (their 3 x 512 floats of tail partials do not fit behind the tile)
+    constexpr bool STAGED = NW == 4 && MT <= 4;
+    constexpr int PARTS = THREADS / ROWS;               // threads per point in the tail
+    const unsigned k3magic = (1u << 20) / (unsigned)K3 + 1u;
     const int64_t ntiles = (a.n_points + P - 1) / P;
     // super-steps of a 256-wide product, as a RUN-TIME value (the argument block carries it, DdfArgs::ks_hidden): with the compile-time constant hipcc
     // unrolls the reverse products completely, materialises one 64-bit address per weight fragment, spills them and reloads each
@@ -485,30 +505,50 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
     const bool ynone = NEDDF_ABL(a.sched_flags, 256);
     constexpr bool masked = MASKY;                  // ReLU / LeakyReLU: y' is one bit per element (rev_forward_epilogue)
 
-    int *ctl = (int *)(lp + 12);
+    // the queue entry travels through team 0's control word (team 1 reads it one barrier after team 0 wrote it, a whole tile before the next write)
+    int *ctl = (int *)((float *)((act_t *)smem + ROWS * LD) + 6 * ROWS + 12);
     NEDDF_STAMP_DECL;
-    int64_t tile = sched_begin(a.sched, a.sched_flags, ctl, tid);
-    while (tile < ntiles) {
+    int64_t unit = sched_begin(a.sched, a.sched_flags, ctl, (int)threadIdx.x);         // a tile, or a pair of tiles (TEAMS = 2)
+    if (TEAMS > 1 && team == 1) __syncthreads();     // team 1 runs one barrier behind
+    while (unit * TEAMS < ntiles) {
+        const int64_t tile = unit * TEAMS + team;
         NEDDF_STAMP_TILE();
         STAMP();                                    // 0: tile start
         const int64_t p0 = tile * P;
         LayerPre<NT, Ops> pre;
         layer_prefetch<NT, Ops>(pre, a.layer[0].wp, a.layer[0].bias, a.layer[0].ksteps, wave, lane);
+        if constexpr (STAGED) {
+            // the tile's positions / variances in ONE coalesced request per array into LDS (the colour-dot area, free until the end of
+            // the tile): the encoding loop below then waits on LDS only -- per-item global loads were a chain of dependent L2 round trips
+            // (8 per thread and tile: 14 k of a bf16 tile's 191 k cycles, profiles/r04_stamp_timeline_bf16.txt)
+            for (int idx = tid; idx < 6 * ROWS; idx += THREADS) {
+                const int k = idx < 3 * ROWS ? idx : idx - 3 * ROWS, p = (k * 43691) >> 17, d = k - 3 * p;      // k / 3 for k < 3 * 128
+                const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
+                chd[idx] = idx < 3 * ROWS ? a.pos[gp * 3 + d] : (a.neus ? 0.0f : a.var[gp * 3 + d]);
+            }
+        }
         zero_cols<Ops, THREADS>(act, ROWS, kin, tid);
         if constexpr (Ops::kEncInLds) {
             for (int i = tid; i < ROWS * 64; i += THREADS) Ops::zero(enc_tile + (i >> 6) * kEncLd + (i & 63));
         }
         __syncthreads();
         int next_tile = 0;
-        if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
+        if (threadIdx.x == 0) next_tile = sched_next(a.sched, a.sched_flags, unit);
         // scaled integrated encoding (neddf.py:193-204), value rows; the factors of its Jacobian go to the scratch
         for (int item = tid; item < P * K3; item += THREADS) {
-            const int p = item / K3, q = item - p * K3;
-            const int e = q / 3, d = q - 3 * e;
-            const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
+            // item / K3 for item < 4096, K3 <= 30: (item * magic) >> 20 is exact; q / 3 for q < 30: (q * 11) >> 5
+            const int p = STAGED ? (int)(((unsigned)item * k3magic) >> 20) : item / K3, q = item - p * K3;
+            const int e = STAGED ? (q * 11) >> 5 : q / 3, d = q - 3 * e;
+            float px, vx;
+            if constexpr (STAGED) {
+                px = chd[p * 3 + d]; vx = chd[3 * ROWS + p * 3 + d];
+            } else {
+                const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
+                px = a.pos[gp * 3 + d]; vx = a.neus ? 0.0f : a.var[gp * 3 + d];
+            }
             float vs, vc, js, jc;
-            if (a.neus) pe_pair<false, Ops::kFast>(e, a.pos[gp * 3 + d], 0.0f, lp[e], vs, vc, js, jc);      // plain PE (neus.py:118)
-            else pe_pair<true, Ops::kFast>(e, a.pos[gp * 3 + d], a.var[gp * 3 + d], lp[e], vs, vc, js, jc);
+            if (a.neus) pe_pair<false, Ops::kFast>(e, px, 0.0f, lp[e], vs, vc, js, jc);      // plain PE (neus.py:118)
+            else pe_pair<true, Ops::kFast>(e, px, vx, lp[e], vs, vc, js, jc);
             Ops::put(act + p * LD + q, vs);
             Ops::put(act + p * LD + KH + q, vc);
             if constexpr (Ops::kEncInLds) {
@@ -773,18 +813,41 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
         __syncthreads();
         // ---- per point: grad_x z_D = sum over the encoding channels of g_pe * dPE/dx, then the head arithmetic (neddf.py:220-241)
         float nrm[3] = { 0.f, 0.f, 0.f };          // FUSED: the normal of this thread's point, input of the colour trunk
-        if (tid < P && p0 + tid < a.n_points) {
-            const int64_t gp = p0 + tid;
-            const act_t *gr = act + tid * LD;
-            const float *pjr = pj + tid * 64;
-            float gz[3] = { 0.f, 0.f, 0.f };
-            for (int e = 0; e < a.enc.E; ++e)
+        if constexpr (STAGED) {     // PARTS threads per point, every PARTS-th frequency each: the 60-term contraction was one wave's work while three idled
+            const int part = tid / ROWS, p = tid - part * ROWS;
+            const act_t *gr = act + p * LD;
+            const float *pjr = pj + p * 64;
+            float gp_[3] = { 0.f, 0.f, 0.f };
+            for (int e = part; e < a.enc.E; e += PARTS)
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     const int q = 3 * e + d;
-                    gz[d] = fmaf(Ops::get(gr + q), pjr[q], gz[d]);
-                    gz[d] = fmaf(Ops::get(gr + KH + q), pjr[32 + q], gz[d]);
+                    gp_[d] = fmaf(Ops::get(gr + q), pjr[q], gp_[d]);
+                    gp_[d] = fmaf(Ops::get(gr + KH + q), pjr[32 + q], gp_[d]);
                 }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) chd[(part * 3 + d) * ROWS + p] = gp_[d];
+            __syncthreads();
+        }
+        if (tid < P && p0 + tid < a.n_points) {
+            const int64_t gp = p0 + tid;
+            float gz[3] = { 0.f, 0.f, 0.f };
+            if constexpr (STAGED) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int q = 0; q < PARTS; ++q) gz[d] += chd[(q * 3 + d) * ROWS + tid];
+            } else {
+                const act_t *gr = act + tid * LD;
+                const float *pjr = pj + tid * 64;
+                for (int e = 0; e < a.enc.E; ++e)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const int q = 3 * e + d;
+                        gz[d] = fmaf(Ops::get(gr + q), pjr[q], gz[d]);
+                        gz[d] = fmaf(Ops::get(gr + KH + q), pjr[32 + q], gz[d]);
+                    }
+            }
             const float z = (hd[tid] + hd[2 * ROWS + tid]) + a.b_ddf_out;
             const float az = (hd[ROWS + tid] + hd[3 * ROWS + tid]) + a.b_aux_out;
             if (a.neus) {       // NeuS: the "distance head" is e_0, so z is the sdf and gz its position gradient (neus.py:132-156)
@@ -913,11 +976,12 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_rev_kernel(const Dd
             }
             STAMP();                    // colour trunk done
         }
-        if (tid == 0) ctl[0] = next_tile;
+        if (threadIdx.x == 0) ctl[0] = next_tile;
         __syncthreads();
-        tile = ctl[0];
+        unit = ctl[0];
         STAMP();                        // tile end
     }
+    if (TEAMS > 1 && team == 0) __syncthreads();     // ... and team 0 waits for it at the end
 }
 
 // One column pass of ddf_rev2_kernel's products with the weight fragments in a ring of D registers sets that runs D super-steps
@@ -969,7 +1033,7 @@ __device__ __forceinline__ void dense_ring_pass(f32x16 (&acc)[MT][1], const type
 // Same packed weights, same scratch, same outputs as ddf_rev_kernel<2, 4, 2, OpsBF16, *>.
 // MT = 4 at two workgroups per CU is that shape; MT = 2 (64 points, 32 accumulators per pass) leaves room for THREE or FOUR workgroups
 // per CU (168 / 128 registers per wave): more waves per SIMD to put one's vector work beside another's matrix work.
-template <class Ops, bool MASKY, int MT, int WPS>
+template <class Ops, bool MASKY, int MT, int WPS, bool Y8 = true>
 __global__ __launch_bounds__(256, WPS) void ddf_rev2_kernel(const DdfArgs a)
 {
     typedef typename Ops::act_t act_t;
@@ -995,10 +1059,10 @@ __global__ __launch_bounds__(256, WPS) void ddf_rev2_kernel(const DdfArgs a)
     float *base = a.rev_scratch + (size_t)blockIdx.x * ((size_t)a.n_layers * P * WID + (size_t)P * 192 + (size_t)P * WID);
     // y' slots: one byte per element (tanhExp) or one bit (masks), a layer after the other; then the 64-column side arrays
     unsigned char *yp = (unsigned char *)base;
-    constexpr size_t kYBytes = (size_t)ROWS * WID;
-    // (the last layer has no y' slot: its place and the next hold g_L = w_ddf * y'_L as bf16 pairs while the features are handed off)
+    constexpr size_t kYBytes = (size_t)ROWS * WID * (Y8 ? 1 : 2);       // (Y8 = false: bf16 pairs, the shipped kernel's format, for A/B)
+    // (the last layer has no y' slot: behind the others sits g_L = w_ddf * y'_L as bf16 pairs while the features are handed off)
     u32x4 *gslot = (u32x4 *)(yp + (size_t)(a.n_layers - 1) * kYBytes);
-    float *pj = base + (size_t)(a.n_layers + 1) * (kYBytes / 4);  // [ROWS][64] dPE/dx factors: [q] sine half, [32 + q] cosine half
+    float *pj = base + ((size_t)(a.n_layers - 1) * kYBytes + (size_t)ROWS * WID * 2) / 4;  // [ROWS][64] dPE/dx factors: [q] sine half, [32 + q] cosine half
     float *pv = pj + ROWS * 64;                                 // [ROWS][64] the encoding itself, for the skip layers
     float *pg = pv + ROWS * 64;                                 // [ROWS][64] the skip layers' share of the encoding gradient, parked
     if (tid == 0) {
@@ -1084,7 +1148,18 @@ __global__ __launch_bounds__(256, WPS) void ddf_rev2_kernel(const DdfArgs a)
                         gslot[(((size_t)ct * MT + mt) * 2 + 1) * 64 + lane] = (u32x4){ gl[4], gl[5], gl[6], gl[7] };
                     }
                     if constexpr (!MASKY) {
-                        if (!last) ((u32x4 *)ysl)[((size_t)ct * MT + mt) * 64 + lane] = y8_pack16(dv);
+                        if (!last) {
+                            if constexpr (Y8) ((u32x4 *)ysl)[((size_t)ct * MT + mt) * 64 + lane] = y8_pack16(dv);
+                            else {
+#pragma unroll
+                                for (int c2 = 0; c2 < 2; ++c2) {
+                                    u32x4 w;
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) w[i] = Ops::pack2(dv[8 * c2 + 2 * i], dv[8 * c2 + 2 * i + 1]);
+                                    ((u32x4 *)ysl)[(((size_t)ct * MT + mt) * 2 + c2) * 64 + lane] = w;
+                                }
+                            }
+                        }
                     }
                 }
                 if constexpr (MASKY) {
@@ -1215,13 +1290,19 @@ __global__ __launch_bounds__(256, WPS) void ddf_rev2_kernel(const DdfArgs a)
             auto scaled = [&](int t, bool hold) {      // acc * y' of column tile ct0 + t -> packed pairs (hold) or the LDS tile
                 const int ct = ct0 + t;
                 unsigned mw[2] = { 0u, 0u };
-                u32x4 yq[MT];
+                u32x4 yq[MT][Y8 ? 1 : 2];
                 if constexpr (MASKY) {
                     mw[0] = ((const unsigned *)ysl)[((size_t)ct * 2 + 0) * 64 + lane];
                     if constexpr (MT > 2) mw[1] = ((const unsigned *)ysl)[((size_t)ct * 2 + 1) * 64 + lane];
                 } else {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) yq[mt] = ((const u32x4 *)ysl)[((size_t)ct * MT + mt) * 64 + lane];
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if constexpr (Y8) yq[mt][0] = ((const u32x4 *)ysl)[((size_t)ct * MT + mt) * 64 + lane];
+                        else {
+                            yq[mt][0] = ((const u32x4 *)ysl)[(((size_t)ct * MT + mt) * 2 + 0) * 64 + lane];
+                            yq[mt][1] = ((const u32x4 *)ysl)[(((size_t)ct * MT + mt) * 2 + 1) * 64 + lane];
+                        }
+                    }
                 }
                 if (!hold) __syncthreads();             // every wave finished reading g_l (the second pass's product is behind us)
 #pragma unroll
@@ -1240,8 +1321,14 @@ __global__ __launch_bounds__(256, WPS) void ddf_rev2_kernel(const DdfArgs a)
                     } else {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            f[4 * g] = y8_get<0>(yq[mt][g]); f[4 * g + 1] = y8_get<1>(yq[mt][g]);
-                            f[4 * g + 2] = y8_get<2>(yq[mt][g]); f[4 * g + 3] = y8_get<3>(yq[mt][g]);
+                            if constexpr (Y8) {
+                                f[4 * g] = y8_get<0>(yq[mt][0][g]); f[4 * g + 1] = y8_get<1>(yq[mt][0][g]);
+                                f[4 * g + 2] = y8_get<2>(yq[mt][0][g]); f[4 * g + 3] = y8_get<3>(yq[mt][0][g]);
+                            } else {
+                                const unsigned w0 = yq[mt][g >> 1][2 * (g & 1)], w1 = yq[mt][g >> 1][2 * (g & 1) + 1];
+                                f[4 * g] = __builtin_bit_cast(float, w0 << 16); f[4 * g + 1] = __builtin_bit_cast(float, w0 & 0xffff0000u);
+                                f[4 * g + 2] = __builtin_bit_cast(float, w1 << 16); f[4 * g + 3] = __builtin_bit_cast(float, w1 & 0xffff0000u);
+                            }
                         }
                         if constexpr (Ops::kWScale != 1.0f) {
 #pragma unroll
@@ -1939,13 +2026,29 @@ static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s, const Co
     else hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, true>), dim3(grid), dim3(64 * NW), rev_lds_bytes<Ops>(MT), s, a, none);
 }
 
+// twin teams (ddf_rev_kernel<..., TEAMS = 2>): `grid` counts tiles in flight = scratch slots = teams; one workgroup carries two
+template <int MT, class Ops>
+static void launch_ddf_rev_teams(const DdfArgs &a, int grid, hipStream_t s)
+{
+    static bool once = (set_lds((const void *)ddf_rev_kernel<MT, 4, 2, Ops, false, false, 2>, 2 * rev_lds_bytes<Ops>(MT)),
+                        set_lds((const void *)ddf_rev_kernel<MT, 4, 2, Ops, true, false, 2>, 2 * rev_lds_bytes<Ops>(MT)), true);
+    (void)once;
+    const ColArgs none{};
+    const int wgs = (grid + 1) / 2;
+    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, 4, 2, Ops, false, false, 2>), dim3(wgs), dim3(512), 2 * rev_lds_bytes<Ops>(MT), s, a, none);
+    else hipLaunchKernelGGL((ddf_rev_kernel<MT, 4, 2, Ops, true, false, 2>), dim3(wgs), dim3(512), 2 * rev_lds_bytes<Ops>(MT), s, a, none);
+}
+
 template <class Ops, int MT, int WPS>
 static void launch_ddf_rev2(const DdfArgs &a, int grid, hipStream_t s)
 {
     static bool once = (set_lds((const void *)ddf_rev2_kernel<Ops, false, MT, WPS>, lds_bytes<Ops>(MT)),
+                        set_lds((const void *)ddf_rev2_kernel<Ops, false, MT, WPS, false>, lds_bytes<Ops>(MT)),
                         set_lds((const void *)ddf_rev2_kernel<Ops, true, MT, WPS>, lds_bytes<Ops>(MT)), true);
     (void)once;
-    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev2_kernel<Ops, false, MT, WPS>), dim3(grid), dim3(256), lds_bytes<Ops>(MT), s, a);
+    static const bool y16 = [] { const char *e = getenv("NEDDF_REV2_Y16"); return e && atoi(e) != 0; }();      // y' as bf16 pairs (A/B)
+    if (a.activation == 2 && y16) hipLaunchKernelGGL((ddf_rev2_kernel<Ops, false, MT, WPS, false>), dim3(grid), dim3(256), lds_bytes<Ops>(MT), s, a);
+    else if (a.activation == 2) hipLaunchKernelGGL((ddf_rev2_kernel<Ops, false, MT, WPS>), dim3(grid), dim3(256), lds_bytes<Ops>(MT), s, a);
     else hipLaunchKernelGGL((ddf_rev2_kernel<Ops, true, MT, WPS>), dim3(grid), dim3(256), lds_bytes<Ops>(MT), s, a);
 }
 
@@ -1982,6 +2085,12 @@ void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *co
     if (a.width == 384) return launch_ddf_rev_w<384>(a, grid, s, col);
     if (a.width == 512) return launch_ddf_rev_w<512>(a, grid, s, col);
     const Geo g = geo_rev(a.operands);          // (mt, wps, nw)
+    // NEDDF_REV_TEAMS: bit 0 bf16, bit 1 split fp16 -- the two workgroups of a CU as two phase-offset teams of ONE workgroup
+    static const int teams = [] { const char *e = getenv("NEDDF_REV_TEAMS"); return e ? atoi(e) : 0; }();
+    if (!col && g.mt == 2 && g.wps == 2 && g.nw == 4) {
+        if (a.operands == 1 && (teams & 1)) return launch_ddf_rev_teams<2, OpsBF16>(a, grid, s);
+        if (a.operands == 2 && (teams & 2)) return launch_ddf_rev_teams<2, OpsF16Split>(a, grid, s);
+    }
     if (a.operands == 2) {
         NEDDF_GEO_CASE(2, 2, 8) return launch_ddf_rev_t<2, 8, 2, OpsF16Split>(a, grid, s);
         return launch_ddf_rev_t<2, 4, 2, OpsF16Split>(a, grid, s, col);
