@@ -362,6 +362,16 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
 // first-layer product (one accumulator set)
 size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points, int width) { return (size_t)n_layers * points * width + (size_t)points * 192 + (size_t)points * width; }
 
+// -DNEDDF_STREAM_Y=1: the y' round trip and the feature hand-off of the reverse-mode kernel as non-temporal accesses (A/B switch)
+#ifndef NEDDF_STREAM_Y
+#define NEDDF_STREAM_Y 0
+#endif
+constexpr bool kStreamY = NEDDF_STREAM_Y != 0;       // measured: slower (fp32 -1 %, bf16 -8.6 %, split -0.9 %): the round trip lives on the L2 / MALL
+// -DNEDDF_REV_PREFETCH=1: the reverse products' first weight fragments requested a phase ahead, like the forward products' (A/B switch)
+#ifndef NEDDF_REV_PREFETCH
+#define NEDDF_REV_PREFETCH 0
+#endif
+constexpr bool kRevPrefetch = NEDDF_REV_PREFETCH != 0;
 constexpr int kRevSmallFloats = 3 * 512 + 16;      // head dots / lp / ctl / colour dots behind the tile (lds_bytes: small + 16; MT <= 8)
 template <int KIND, bool LAST, int MT, int NT, class Ops>
 __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *yp, const float *wseed, int wave,
@@ -402,8 +412,8 @@ __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], type
     // is rounded to bf16 anyway): at that policy's speed the fp32 round trip (26 GB per launch) would be the kernel's bound
     if (!LAST && (!kAblate || yp)) {
         if constexpr (KIND == 2) {
-            if constexpr (Ops::kStash16) stash_store16<MT, NT>(acc, yp, wave, lane, ymask);
-            else stash_store<MT, NT>(acc, yp, wave, lane, ymask);
+            if constexpr (Ops::kStash16) stash_store16<MT, NT, kStreamY>(acc, yp, wave, lane, ymask);
+            else stash_store<MT, NT, kStreamY>(acc, yp, wave, lane, ymask);
         } else {
             // ReLU / LeakyReLU: y' takes two values, so ONE BIT per element travels (16 per accumulator tile, two tiles per
             // dword: 8 bytes per lane and layer instead of 256) -- 12 KB per workgroup for six layers, 6 MB per launch grid: it
@@ -592,6 +602,8 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
                 dense<MT, NT, Ops>(acc, act_lane + sw.col0, (const frag *)sw.wp + (size_t)wave * NT * sw.ksteps * 64 + lane, sw.ksteps);
             }
             if (l + 1 < a.n_layers) layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
+            else if (kRevPrefetch && !FUSED && a.n_layers > 1)    // ... and the reverse pass's first product likewise (its weights are known now)
+                layer_prefetch<NT, Ops>(pre, a.wT[a.n_layers - 1], nullptr, KS, wave, lane);
             STAMP();                                // forward layer l: 3 + 4l product done
             __syncthreads();
             STAMP();                                //                  4 + 4l barrier passed
@@ -632,7 +644,8 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
                 const int p = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
                 if (p0 + p < a.n_points) {
                     f32x4v v = *(const f32x4v *)(act + p * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));
-                    *(f32x4v *)(features + (size_t)(p0 + p) * (Ops::kPlanes * WID) + CE * c4) = v;
+                    if constexpr (kStreamY) __builtin_nontemporal_store(v, (f32x4v *)(features + (size_t)(p0 + p) * (Ops::kPlanes * WID) + CE * c4));
+                    else *(f32x4v *)(features + (size_t)(p0 + p) * (Ops::kPlanes * WID) + CE * c4) = v;
                 }
             }
         }
@@ -694,16 +707,17 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    if constexpr (Ops::kStash16) stash_load16(dst[t], (const u32x4 *)ysrc + ((mt * NT + t) * 2) * 64);
+                    if constexpr (Ops::kStash16) stash_load16<kStreamY>(dst[t], (const u32x4 *)ysrc + ((mt * NT + t) * 2) * 64);
                     else
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            f32x4v v = ysrc[((mt * NT + t) * 4 + g) * 64];
+                            f32x4v v = kStreamY ? __builtin_nontemporal_load(&ysrc[((mt * NT + t) * 4 + g) * 64]) : ysrc[((mt * NT + t) * 4 + g) * 64];
                             dst[t][4 * g] = v[0]; dst[t][4 * g + 1] = v[1]; dst[t][4 * g + 2] = v[2]; dst[t][4 * g + 3] = v[3];
                         }
                 }
             };
-            acc_init<MT, NT, false>(acc, nullptr, wave, lane);
+            if (kRevPrefetch && !FUSED) acc_init_pre<MT, NT, false, Ops>(acc, pre);        // (bias-free: zeros)
+            else acc_init<MT, NT, false>(acc, nullptr, wave, lane);
             constexpr int NMW = (MT * NT + 1) / 2;
             unsigned mw[NMW];
             if constexpr (masked) {     // ReLU / LeakyReLU: the layer's mask bits (rev_forward_epilogue), requested ahead of the product
@@ -712,6 +726,12 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
                 for (int w = 0; w < NMW; ++w) mw[w] = msrc[w * 64];
             }
             STAMP();                    // reverse layer: +0 skip share / setup done
+            if (kRevPrefetch && !FUSED) {
+                // the first fragments of this product were requested a phase ago (before the last epilogue / the y' multiply of the layer
+                // above); the next product's go out now, to land during this layer's y' multiply and its barriers
+                dense_pre<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS, pre);
+                if (l > 1) layer_prefetch<NT, Ops>(pre, a.wT[l - 1], nullptr, KS, wave, lane);
+            } else
             dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
             STAMP();                    //                +1 product done
             if constexpr (masked) {
@@ -736,11 +756,11 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
                 constexpr int NB = MT * NT;
                 f32x16 y1[2];
                 auto load_blk = [&](f32x16 &dst, int i) {
-                    if constexpr (Ops::kStash16) stash_load16(dst, (const u32x4 *)ysrc + (i * 2) * 64);
+                    if constexpr (Ops::kStash16) stash_load16<kStreamY>(dst, (const u32x4 *)ysrc + (i * 2) * 64);
                     else
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            f32x4v v = ysrc[(i * 4 + g) * 64];
+                            f32x4v v = kStreamY ? __builtin_nontemporal_load(&ysrc[(i * 4 + g) * 64]) : ysrc[(i * 4 + g) * 64];
                             dst[4 * g] = v[0]; dst[4 * g + 1] = v[1]; dst[4 * g + 2] = v[2]; dst[4 * g + 3] = v[3];
                         }
                 };

@@ -473,7 +473,9 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[MT][NT], const float *bia
 }
 
 // (mtmask: -1; the timing probes of -DNEDDF_ABLATE builds pass 0 to fold every M-tile onto the first one's slot)
-template <int MT, int NT>
+// STREAM: non-temporal stores (the y' round trip of the reverse-mode kernel: written once, read once a tile later -- it should not
+// push the weights, which every tile re-reads, out of the L2)
+template <int MT, int NT, bool STREAM = false>
 __device__ __forceinline__ void stash_store(const f32x16 (&acc)[MT][NT], float *slot, int wave, int lane, int mtmask = -1)
 {
     f32x4v *dst = (f32x4v *)slot + (size_t)wave * (MT * NT * 4) * 64 + lane;
@@ -484,12 +486,13 @@ __device__ __forceinline__ void stash_store(const f32x16 (&acc)[MT][NT], float *
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4v v = { acc[mt][t][4 * g], acc[mt][t][4 * g + 1], acc[mt][t][4 * g + 2], acc[mt][t][4 * g + 3] };
-                dst[(((mt & mtmask) * NT + t) * 4 + g) * 64] = v;
+                if constexpr (STREAM) __builtin_nontemporal_store(v, &dst[(((mt & mtmask) * NT + t) * 4 + g) * 64]);
+                else dst[(((mt & mtmask) * NT + t) * 4 + g) * 64] = v;
             }
 }
 
 // the same in bf16: 16 accumulators = two 16-byte chunks per lane
-template <int MT, int NT>
+template <int MT, int NT, bool STREAM = false>
 __device__ __forceinline__ void stash_store16(const f32x16 (&acc)[MT][NT], float *slot, int wave, int lane, int mtmask = -1)
 {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -505,15 +508,17 @@ __device__ __forceinline__ void stash_store16(const f32x16 (&acc)[MT][NT], float
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     v[i] = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){ acc[mt][t][8 * c + 2 * i], acc[mt][t][8 * c + 2 * i + 1] }, bf16x2));
-                dst[(((mt & mtmask) * NT + t) * 2 + c) * 64] = v;
+                if constexpr (STREAM) __builtin_nontemporal_store(v, &dst[(((mt & mtmask) * NT + t) * 2 + c) * 64]);
+                else dst[(((mt & mtmask) * NT + t) * 2 + c) * 64] = v;
             }
 }
 
+template <bool STREAM = false>
 __device__ __forceinline__ void stash_load16(f32x16 &dst, const u32x4 *src)     // src: this lane's first chunk of the accumulator tile
 {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        const u32x4 v = src[c * 64];
+        const u32x4 v = STREAM ? __builtin_nontemporal_load(&src[c * 64]) : src[c * 64];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             dst[8 * c + 2 * i] = __builtin_bit_cast(float, v[i] << 16);
