@@ -184,6 +184,37 @@ __device__ __forceinline__ float exp_acc(float x)
     return fmaf(e, r * 0.693147182464599609375f, e);
 }
 
+// Ray.get_sampling_cones ray.py:128-194 / get_sampling_points ray.py:88-126 for sample j of a ray whose S distances start at d: the
+// moments along the ray (t_mu, t_var) and across it (r_var).  ONE definition for the stand-alone sampling kernel (render_kernels.hip)
+// and for the field kernels that take their sample points straight from the rays (field_kernels.hip): only + - * / in the same order,
+// every translation unit is built with -ffp-contract=off, so both give the same bits.
+template <bool CONE>
+__device__ __forceinline__ void sample_moments(const float *d, int j, int S, float r2, float &t_mu, float &t_var, float &r_var)
+{
+    const float dn = d[j];
+    t_mu = dn; t_var = 0.f; r_var = 0.f;
+    if (CONE) {
+        float df = (j + 1 < S) ? d[j + 1] : (2 * d[S - 1] - d[S - 2]);
+        float mu = 0.5f * (dn + df);
+        float sg = 0.5f * (df - dn);
+        float mu2 = mu * mu, s2 = sg * sg, s4 = s2 * s2;
+        float minv = 1.0f / (3 * mu2 + s2 + 1e-7f);
+        const float c13 = (float)(1.0 / 3), c415 = (float)(4.0 / 15), c512 = (float)(5.0 / 12);
+        t_mu = mu + (2 * mu * s2) * minv;
+        t_var = c13 * s2 - c415 * s4 * (12 * mu2 - s2) * (minv * minv);
+        r_var = r2 * (0.25f * mu2 + c512 * s2 - c415 * s4 * minv);
+    }
+}
+
+// ... and one coordinate of the sample: position o + d t_mu, variance t_var d^2 + r_var (1 - d^2) (zero for point samples)
+template <bool CONE>
+__device__ __forceinline__ void sample_coord(float dd, float oo, float t_mu, float t_var, float r_var, float &pos, float &var)
+{
+    const float dsq = dd * dd;
+    pos = oo + dd * t_mu;
+    var = CONE ? t_var * dsq + r_var * (1.0f - dsq) : 0.0f;
+}
+
 template <bool GRADSCALE, bool FAST = false>
 __device__ __forceinline__ void pe_pair(int e, float x, float v, float lowpass, float &vs, float &vc, float &js, float &jc)
 {

@@ -42,7 +42,7 @@ namespace neddf {
 // Region must be pre-zeroed.  GRADSCALE selects embed_pos_scaled (neddf.py:200-204).
 template <bool ROWS4, bool GRADSCALE, class Ops = OpsF32, int THREADS = kThreads>
 __device__ __forceinline__ void encode_pos(typename Ops::act_t *act, int col0, const EncodeDesc &enc, const float *lp, const float *pos,
-                                           const float *var, int64_t p0, int64_t N, int P, int tid, bool use_var = true)
+                                           const float *var, int64_t p0, int64_t N, int P, int tid, bool use_var = true, int stride = 3)
 {
     const int K3 = 3 * enc.E, KH = enc.KH;
     for (int item = tid; item < P * K3; item += THREADS) {
@@ -50,7 +50,7 @@ __device__ __forceinline__ void encode_pos(typename Ops::act_t *act, int col0, c
         int e = q / 3, d = q - 3 * e;
         int64_t gp = p0 + p < N ? p0 + p : N - 1;
         float vs, vc, js, jc;
-        pe_pair<GRADSCALE, Ops::kFast>(e, pos[gp * 3 + d], use_var ? var[gp * 3 + d] : 0.0f, lp[e], vs, vc, js, jc);
+        pe_pair<GRADSCALE, Ops::kFast>(e, pos[gp * stride + d], use_var ? var[gp * stride + d] : 0.0f, lp[e], vs, vc, js, jc);
         constexpr int LD = Ops::kLd;
         if (ROWS4) {
             typename Ops::act_t *r0 = act + (4 * p) * LD + col0 + q;
@@ -69,7 +69,7 @@ __device__ __forceinline__ void encode_pos(typename Ops::act_t *act, int col0, c
 // PositionalEncoding of the view direction (positional_encoding.py:51-65), value rows only.
 template <bool ROWS4, class Ops = OpsF32, int THREADS = kThreads>
 __device__ __forceinline__ void encode_dir(typename Ops::act_t *act, int col0, const EncodeDesc &enc, const float *dir, int64_t p0,
-                                           int64_t N, int P, int tid)
+                                           int64_t N, int P, int tid, int stride = 3)
 {
     const int K3 = 3 * enc.Ed, KD = enc.KD;
     for (int item = tid; item < P * K3; item += THREADS) {
@@ -77,8 +77,8 @@ __device__ __forceinline__ void encode_dir(typename Ops::act_t *act, int col0, c
         int e = q / 3, d = q - 3 * e;
         int64_t gp = p0 + p < N ? p0 + p : N - 1;
         float sn, cs;
-        if (Ops::kFast) fast_sincos((float)(1 << e) * dir[gp * 3 + d], sn, cs);
-        else sincos_cw((float)(1 << e) * dir[gp * 3 + d], sn, cs);
+        if (Ops::kFast) fast_sincos((float)(1 << e) * dir[gp * stride + d], sn, cs);
+        else sincos_cw((float)(1 << e) * dir[gp * stride + d], sn, cs);
         typename Ops::act_t *r0 = act + (ROWS4 ? 4 * p : p) * Ops::kLd + col0 + q;
         Ops::put(r0, sn);
         Ops::put(r0 + KD, cs);
@@ -118,6 +118,23 @@ constexpr bool kAblate = false;
 #define NEDDF_STAMP_TILE() do { } while (0)
 #define STAMP() do { } while (0)
 #endif
+
+// position / variance / direction of point `gpt` of the [B, S] sample grid, straight from the rays (kernels.h RaySrc)
+__device__ __forceinline__ void ray_point(const RaySrc &r, int64_t gpt, float (&pos)[3], float (&var)[3], float (&dir)[3])
+{
+    const int64_t b = gpt / r.S;
+    const int j = (int)(gpt - b * r.S);
+    float t_mu, t_var, r_var;
+    if (r.cone) sample_moments<true>(r.dists + b * r.S, j, r.S, r.r2, t_mu, t_var, r_var);
+    else sample_moments<false>(r.dists + b * r.S, j, r.S, r.r2, t_mu, t_var, r_var);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float dd = r.rd[3 * b + k];
+        if (r.cone) sample_coord<true>(dd, r.ro[3 * b + k], t_mu, t_var, r_var, pos[k], var[k]);
+        else sample_coord<false>(dd, r.ro[3 * b + k], t_mu, t_var, r_var, pos[k], var[k]);
+        dir[k] = r.view ? r.view[3 * b + k] : dd;
+    }
+}
 
 __device__ __forceinline__ int64_t sched_begin(int *sched, int flags, int *ctl, int tid)
 {
@@ -531,6 +548,15 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
             // the tile's positions / variances in ONE coalesced request per array into LDS (the colour-dot area, free until the end of
             // the tile): the encoding loop below then waits on LDS only -- per-item global loads were a chain of dependent L2 round trips
             // (8 per thread and tile: 14 k of a bf16 tile's 191 k cycles, profiles/r04_stamp_timeline_bf16.txt)
+            if (a.rays.rd) {        // the points come from the rays: cone / point moments here, no sampling tensors (kernels.h RaySrc)
+                if (tid < ROWS) {
+                    const int64_t gp = p0 + tid < a.n_points ? p0 + tid : a.n_points - 1;
+                    float ps[3], vr[3], dr[3];
+                    ray_point(a.rays, a.rays.base + gp, ps, vr, dr);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { chd[tid * 3 + k] = ps[k]; chd[3 * ROWS + tid * 3 + k] = a.neus ? 0.0f : vr[k]; }
+                }
+            } else
             for (int idx = tid; idx < 6 * ROWS; idx += THREADS) {
                 const int k = idx < 3 * ROWS ? idx : idx - 3 * ROWS, p = (k * 43691) >> 17, d = k - 3 * p;      // k / 3 for k < 3 * 128
                 const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
@@ -900,6 +926,15 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
             f32x4v v1 = { ninv * dg1, ninv * dg2, z, az };
             f32x4v v2 = { dg0, dg1, dg2, 0.f };
             f32x4v v3 = { 0.f, 0.f, dgn, dDdt };
+            if constexpr (STAGED) {
+                if (a.rays.rd) {    // the colour kernel's inputs ride in the slots it does not read in eval-minimal mode (PA_R_*)
+                    float ps[3], vr[3], dr[3];
+                    ray_point(a.rays, a.rays.base + gp, ps, vr, dr);
+                    v0[0] = dr[0]; v0[1] = dr[1]; v0[2] = dr[2];
+                    v2[0] = ps[0]; v2[1] = ps[1]; v2[2] = ps[2]; v2[3] = vr[0];
+                    v3[0] = vr[1]; v3[1] = vr[2];
+                }
+            }
             ((f32x4v *)pa)[0] = v0; ((f32x4v *)pa)[1] = v1; ((f32x4v *)pa)[2] = v2; ((f32x4v *)pa)[3] = v3;
             }
             if (a.distance) a.distance[gp] = D;
@@ -1529,6 +1564,14 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
                 Ops::put(act + (RPP * p) * LD + 3 + d, a.ptaux[gp * kPtAux + PA_N0 + d]);
             }
             encode_dir<ROWS4, Ops, THREADS>(act, 8, a.enc, a.dir, p0, a.n_points, P, tid);
+        } else if (!ROWS4 && a.rays) {     // the sample point rides in the per-point record (kernels.h PA_R_*)
+            encode_pos<ROWS4, false, Ops, THREADS>(act, 0, a.enc, lp, a.ptaux + PA_R_POS, a.ptaux + PA_R_VAR, p0, a.n_points, P, tid, true, kPtAux);
+            encode_dir<ROWS4, Ops, THREADS>(act, c_dir, a.enc, a.ptaux + PA_R_DIR, p0, a.n_points, P, tid, kPtAux);
+            for (int i = tid; i < P * 3; i += THREADS) {
+                int p = i / 3, d = i - 3 * p;
+                int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
+                Ops::put(act + (RPP * p) * LD + c_n + d, a.ptaux[gp * kPtAux + PA_N0 + d]);
+            }
         } else {
             encode_pos<ROWS4, false, Ops, THREADS>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
             encode_dir<ROWS4, Ops, THREADS>(act, c_dir, a.enc, a.dir, p0, a.n_points, P, tid);
@@ -2097,6 +2140,14 @@ static void launch_ddf_rev_w(const DdfArgs &a, int grid, hipStream_t s, const Co
 }
 
 // the shapes that can take the colour trunk on their tile (four waves per workgroup: every shipped shape; the eight-wave probes cannot)
+bool ddf_rev_takes_rays(int operands, int width)
+{
+    if (width != 256) return true;                      // launch_ddf_rev_w: four waves
+    const Geo g = geo_rev(operands);
+    if (!(g.mt == 2 && g.wps == 2 && g.nw == 4)) return false;      // the eight-wave probes and ddf_rev2_kernel read the tensors
+    static const bool two_pass = [] { const char *e = getenv("NEDDF_REV2"); return e && atoi(e) != 0; }();
+    return !(two_pass && operands == 1);
+}
 bool ddf_rev_can_fuse(int operands, int width) { return width != 256 || (geo_rev(operands).mt == 2 && geo_rev(operands).nw == 4 && geo_rev(operands).wps == 2); }
 
 void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *col)

@@ -18,7 +18,23 @@ constexpr int kPtAux = 16;           // floats per point handed from the distanc
 // floats of one stash slot of one workgroup: 4 waves x (MT=4 x NT=2 x 4 float4) x 64 lanes x 4
 constexpr size_t kStashFloatsPerWg = (size_t)kWaves * (4 * 2 * 4) * 64 * 4;
 
-// per-point record written by the distance-trunk kernel (float index)
+// Sample points taken straight from the rays (round 5: SURVEY section 7 step 6, the cone moments in the field prologue): the
+// reverse-mode distance kernel derives position / variance / direction of point i from ray i / S and its distances
+// (device_math.h sample_moments: the stand-alone sampling kernel's own arithmetic, bit for bit) and hands them to the colour
+// kernel INSIDE the per-point record it writes anyway -- the [N, 3] x 3 sampling tensors (36 B per point written and 60 B read)
+// and the sampling launch disappear from neddf_render_rays' eval-minimal route.
+struct RaySrc {
+    const float *rd = nullptr, *ro = nullptr, *view = nullptr, *dists = nullptr;   // [B, 3], [B, 3], [B, 3] or NULL, [B, S]
+    int S = 0;              // samples per ray
+    float r2 = 0.f;         // ray_radius^2 (cone sampling)
+    int cone = 0;
+    int64_t base = 0;       // index of this launch's first point in the [B, S] grid
+    double radius = -1.0;   // host side: the caller's ray radius as given (launch_sampling squares it itself), < 0 for point samples
+};
+
+// per-point record written by the distance-trunk kernel (float index); with RaySrc in eval-minimal mode the slots the colour kernel
+// does not read there carry the sample point: PA_R_DIR (0..2), PA_R_POS (8..10), PA_R_VAR (11..13)
+enum { PA_R_DIR = 0, PA_R_POS = 8, PA_R_VAR = 11 };
 enum { PA_D = 0, PA_RHO = 1, PA_AUX = 2, PA_N0 = 3, PA_N1 = 4, PA_N2 = 5, PA_DDF_RAW = 6, PA_AUX_RAW = 7,
        PA_DG0 = 8, PA_DG1 = 9, PA_DG2 = 10, PA_AGG0 = 11, PA_AGG1 = 12, PA_AGG2 = 13, PA_DGN = 14, PA_DDDT = 15 };
 
@@ -77,6 +93,7 @@ struct DdfArgs {
     int feat_rows;                        // 1 (value row) or 4 (value + Jacobian rows)
     float *ptaux;                         // [n_points][kPtAux]
     float *distance, *density, *aux_grad; // optional outputs [n_points]
+    RaySrc rays;                          // rays.rd != NULL: pos / dir / var are NULL, the points come from the rays (ddf_rev_kernel, four waves)
     unsigned long long *stamps = nullptr; // -DNEDDF_STAMP builds only (`make stamp`, tools/stamp_timeline.py): phase time stamps of a few workgroups
 };
 constexpr int kStampBlocks = 8, kStampSlots = 160, kStampTile = 6;      // workgroups stamped, stamps per wave, which tile of the workgroup
@@ -104,6 +121,7 @@ struct ColArgs {
     int *sched;                           // as DdfArgs::sched
     int sched_flags;
     float *color;                         // [n_points][3]
+    int rays;                             // 1: pos / var / dir are read from the per-point record (PA_R_*), the pointers above are NULL
     float *penalty;                       // [n_points] (full mode) or NULL
     float distance_range_max;
     float penalty_weight[6];
@@ -140,6 +158,7 @@ size_t field_lds_bytes(int mt);
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s);
 void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *col = nullptr);   // col: the colour trunk on the same tile (one field kernel)
 bool ddf_rev_can_fuse(int operands, int width);
+bool ddf_rev_takes_rays(int operands, int width);      // the shape in use derives its sample points from RaySrc (four-wave ddf_rev_kernel)
 size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points, int width);
 int ddf_rev_points(int operands, int width);        // sample points per tile of ddf_rev_kernel under an operand policy / engine width
 int ddf_rev_wgs_per_cu(int operands, int width);

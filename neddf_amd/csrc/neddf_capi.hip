@@ -492,9 +492,11 @@ struct UseMark {
     ~UseMark() { (void)mark_use(ctx, f, s); }
 };
 
+// rays != NULL (neddf_render_rays): the N points are the [B, S] sample grid of these rays; pos / dir / var are then WORKSPACE -- filled by
+// the sampling kernel when the route cannot take its points from the rays, untouched when it can (kernels.h RaySrc)
 static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float *dir, const float *var, int64_t N,
                          int out_mode, float *distance, float *density, float *color, float *penalty, float *aux,
-                         hipStream_t s)
+                         hipStream_t s, const RaySrc *rays = nullptr)
 {
     if (slot < 0 || slot >= NEDDF_NUM_SLOTS || !ctx->field[slot].valid) return fail(ctx, NEDDF_ENOFIELD, "no field in slot");
     if (N <= 0) return 0;
@@ -507,7 +509,12 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     const int grid_cap_col = ctx->cus * col_wgs_per_cu(dt, wid);
     const int n_parked = f.d.kind == NEDDF_FIELD_NERF ? f.nerf.n_stash : f.ddf.n_stash;      // early partials a kernel may park per workgroup
     if (int rc = ensure(ctx, ctx->scratch, (size_t)(grid_cap > grid_cap_ddf ? grid_cap : grid_cap_ddf) * (n_parked > 1 ? n_parked : 1) * kStashFloatsPerWg * sizeof(float))) return rc;
+    auto sample_now = [&]() {       // the sampling tensors after all (a route that reads them)
+        STAGE(ctx, s, NEDDF_STAGE_SAMPLING, launch_sampling(rays->rd, rays->ro, rays->view, rays->dists, N / rays->S, rays->S,
+                                                              rays->radius, (float *)pos, (float *)dir, (float *)var, s));
+    };
     if (f.d.kind == NEDDF_FIELD_NERF) {
+        if (rays) sample_now();
         NerfArgs a = f.nerf;
         fill_enc(a.enc, f);
         a.pos = pos; a.dir = dir; a.var = var; a.n_points = N;
@@ -541,6 +548,12 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     // is opt-in: NEDDF_FUSED=1 (tests/test_gpu_parity.py::test_fused_field_kernel_in_subprocess holds it to the same gates).
     static const bool fuse_enabled = [] { const char *e = getenv("NEDDF_FUSED"); return e && atoi(e) != 0; }();
     const bool fused = fuse_enabled && reverse && color && f.d.kind == NEDDF_FIELD_NEDDF && ddf_rev_can_fuse(dt, wid);
+    // Sample points straight from the rays (the cone moments in the field prologue): the reverse-mode distance
+    // kernel derives them in its prologue and hands them to the colour kernel in the per-point record; NEDDF_RAYS_IN_FIELD=0 keeps the
+    // sampling tensors (the A/B partner: tests/test_gpu_parity.py holds both routes bit-identical)
+    const char *rif = getenv("NEDDF_RAYS_IN_FIELD");
+    const bool use_rays = rays && (!rif || atoi(rif) != 0) && reverse && !fused && f.d.kind == NEDDF_FIELD_NEDDF && ddf_rev_takes_rays(dt, wid);
+    if (rays && !use_rays) sample_now();
     // Points per launch of the field kernels.  Every launch boundary drains the persistent grid (workgroups finish up to one tile
     // apart) and refills it: at 2^21 points a 65 536-ray x 128-sample call was four launch pairs, at 2^23 it is one -- fp32 +0.8 %,
     // split fp16 +0.7 %, bf16 +2.8 % (profiles/r04_launch_size.txt).  The hand-off buffers grow with it (1 088 B per point
@@ -575,6 +588,11 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         DdfArgs a = f.ddf;
         fill_enc(a.enc, f);
         a.pos = pos + off * 3; a.dir = dir + off * 3; a.var = var + off * 3; a.n_points = n;
+        if (use_rays) {
+            a.pos = a.dir = a.var = nullptr;
+            a.rays = *rays;
+            a.rays.base = rays->base + off;
+        }
         a.aux_grad_scale = f.aux_grad_scale;
         a.scratch = (float *)ctx->scratch.p;
         a.features = ((color || full) && !fused) ? (float *)ctx->features.p : nullptr;      // no colour kernel follows: no hand-off
@@ -623,6 +641,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
             ColArgs c = f.col;
             fill_enc(c.enc, f);
             c.pos = a.pos; c.dir = a.dir; c.var = a.var; c.n_points = n;
+            c.rays = use_rays ? 1 : 0;
             c.features = a.features; c.feat_rows = fr; c.ptaux = a.ptaux;
             c.distance_range_max = f.distance_range_max;
             c.penalty = full ? penalty + off : nullptr;
@@ -908,13 +927,17 @@ static int render_pass(neddf_ctx *ctx, int slot, const float *rd, const float *r
                        const neddf_render_params *rp, float *pos, float *dir, float *var, float *dens, float *col, float *pen,
                        float *w_out, float *depth, float *color, float *trans, float *pen_out, int *nan_flag, hipStream_t s)
 {
-    STAGE(ctx, s, NEDDF_STAGE_SAMPLING, launch_sampling(rd, ro, view, dists, B, S, rp->cone_sampling ? rp->ray_radius : -1.0, pos, dir, var, s));
+    RaySrc rays;
+    rays.rd = rd; rays.ro = ro; rays.view = view; rays.dists = dists; rays.S = S;
+    rays.cone = rp->cone_sampling ? 1 : 0;
+    rays.radius = rp->cone_sampling ? rp->ray_radius : -1.0;
+    rays.r2 = (float)(rp->ray_radius * rp->ray_radius);          // launch_sampling's own (float)(radius * radius)
     const bool want_pen = pen_out && ctx->field[slot].d.kind == NEDDF_FIELD_NEDDF;
     // a pass whose pixels nobody asked for (the coarse pass of render_image: only its resampling weights are consumed) needs the
     // densities only -- the colour trunk is skipped (the reference evaluates and discards it)
     const bool want_col = depth || color || trans || want_pen;
     int rc = field_forward(ctx, slot, pos, dir, var, B * S, want_pen ? NEDDF_OUT_FULL : NEDDF_OUT_MINIMAL, nullptr, dens, want_col ? col : nullptr,
-                           want_pen ? pen : nullptr, nullptr, s);
+                           want_pen ? pen : nullptr, nullptr, s, &rays);
     if (rc) return rc;
     STAGE(ctx, s, NEDDF_STAGE_COMPOSITE, launch_composite(dists, dens, want_col ? col : nullptr, B, S, rp->max_dist, w_out, depth, color, trans, nan_flag, s));
     if (want_pen) STAGE(ctx, s, NEDDF_STAGE_PENALTY, launch_integrate_penalty(dists, pen, B, S, pen_out, s));

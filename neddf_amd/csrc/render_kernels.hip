@@ -7,6 +7,7 @@
 // order of the reference's eager torch ops so that, given the same inputs,
 // results are bit-identical to the oracle wherever only +,-,*,/,sqrt occur.
 #include "kernels.h"
+#include "device_math.h"
 #include <math.h>
 
 namespace neddf {
@@ -81,26 +82,13 @@ __global__ void sampling_kernel(const float *rd, const float *ro, const float *v
     int64_t b = i / S;
     int j = (int)(i - b * S);
     const float *d = dists + b * S;
-    float dn = d[j];
-    float t_mu = dn, t_var = 0.f, r_var = 0.f;
-    if (CONE) {
-        float df = (j + 1 < S) ? d[j + 1] : (2 * d[S - 1] - d[S - 2]);
-        float mu = 0.5f * (dn + df);
-        float sg = 0.5f * (df - dn);
-        float mu2 = mu * mu, s2 = sg * sg, s4 = s2 * s2;
-        float minv = 1.0f / (3 * mu2 + s2 + 1e-7f);
-        const float c13 = (float)(1.0 / 3), c415 = (float)(4.0 / 15), c512 = (float)(5.0 / 12);
-        t_mu = mu + (2 * mu * s2) * minv;
-        t_var = c13 * s2 - c415 * s4 * (12 * mu2 - s2) * (minv * minv);
-        r_var = r2 * (0.25f * mu2 + c512 * s2 - c415 * s4 * minv);
-    }
+    float t_mu, t_var, r_var;
+    sample_moments<CONE>(d, j, S, r2, t_mu, t_var, r_var);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         float dd = rd[3 * b + k];
-        float dsq = dd * dd;
-        pos[3 * i + k] = ro[3 * b + k] + dd * t_mu;
+        sample_coord<CONE>(dd, ro[3 * b + k], t_mu, t_var, r_var, pos[3 * i + k], var[3 * i + k]);
         dir[3 * i + k] = view ? view[3 * b + k] : dd;      // NDC rays: the field sees the world-space viewing direction
-        var[3 * i + k] = CONE ? t_var * dsq + r_var * (1.0f - dsq) : 0.0f;
     }
 }
 

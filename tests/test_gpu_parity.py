@@ -387,6 +387,72 @@ def test_render_rays_end_to_end(dev, bunny_weights, bunny_stages):
     assert psnr > 80.0, psnr
 
 
+_RAYS_WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import neddf_amd
+from neddf_amd.fixtures import BUNNY_SMOKE_CFG, BUNNY_SMOKE_RENDER, bunny_smoke_weights
+dev = torch.device("cuda:0")
+wts = bunny_smoke_weights()
+fx = 0.5 * 800 / np.tan(0.5 * 0.6911112070083618)
+for sampling in ("cone", "point"):
+    kw = dict(BUNNY_SMOKE_RENDER, sampling_type=sampling)
+    r = neddf_amd.NeRFRender(dict(BUNNY_SMOKE_CFG, _target_="neddf.network.NeDDF"), **kw)
+    r.network_fine.load_state_dict({k: torch.from_numpy(v) for k, v in wts.items()})
+    r.to(dev); r.set_iter(-1)
+    cam = neddf_amd.Camera(neddf_amd.PinholeCalib(np.array([fx, fx, 400.0, 400.0])), None).to(dev)
+    cam.R, cam.T = torch.eye(3, device=dev), torch.tensor([0.0, 0.0, 4.0], device=dev)
+    for dtype in ("fp32", "f16_split", "bf16"):
+        r.network_fine.weight_dtype = dtype
+        ctx = r._ctx(dev)
+        for n in (1, 63, 1000, 2049):
+            torch.manual_seed(n)
+            uv = torch.randint(0, 800, (n, 2), device=dev)
+            uc, uf = torch.rand(n, 65, device=dev), torch.rand(n, 129, device=dev)
+            outs = {}
+            for route in ("1", "0"):
+                os.environ["NEDDF_RAYS_IN_FIELD"] = route
+                with torch.no_grad():
+                    outs[route] = {k: v.clone() for k, v in r._render(ctx, uv, cam, uc, uf, full=False).items()}
+            for k in outs["1"]:
+                assert torch.equal(outs["1"][k], outs["0"][k]), (sampling, dtype, n, k, float((outs["1"][k] - outs["0"][k]).abs().max()))
+        # the single-pass image path on a slab that is not a multiple of any tile
+        outs = {}
+        for route in ("1", "0"):
+            os.environ["NEDDF_RAYS_IN_FIELD"] = route
+            torch.manual_seed(7)
+            with torch.no_grad():
+                o = r.render_image_single_pass(800, 800, cam, 128, pixel_range=(777, 777 + 3001))
+            outs[route] = {k: v.clone() for k, v in o.items()}
+        for k in outs["1"]:
+            assert torch.equal(outs["1"][k], outs["0"][k]), (sampling, dtype, "single pass", k)
+print("RAYS_OK")
+"""
+
+
+@pytest.mark.parametrize("chunk_log2", [None, 16])
+def test_sample_points_from_rays_route_is_bit_identical(tmp_path, chunk_log2):
+    """in the eval-minimal route the reverse-mode distance kernel takes its sample points straight from the rays
+    (cone / point moments in its prologue, handed to the colour kernel inside the per-point record) instead of reading the [N, 3] x 3
+    sampling tensors.  Same arithmetic in the same order (device_math.h sample_moments, -ffp-contract=off): the rendered outputs of
+    both routes (NEDDF_RAYS_IN_FIELD=0 keeps the tensors) must be BIT-identical -- cone and point sampling, every operand policy,
+    ragged batches, the single-pass image path; and with 2^16-point launches (several launches per call: the per-launch point offset)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    w = tmp_path / "rays_worker.py"
+    w.write_text(_RAYS_WORKER)
+    env = dict(os.environ)
+    env.pop("NEDDF_RAYS_IN_FIELD", None)
+    if chunk_log2:
+        env["NEDDF_FIELD_CHUNK_LOG2"] = str(chunk_log2)
+    p = subprocess.run([sys.executable, str(w), ROOT], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "RAYS_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 def test_render_rays_api_and_rng_order(dev, bunny_weights, bunny_stages):
     """Public render_rays draws torch.rand [B,Sc+1] then [B,Sf+1] on the CPU generator like the reference."""
     g = bunny_stages
