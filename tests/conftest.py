@@ -70,6 +70,59 @@ def _bounds_probe_after_each_test():
         assert bad == 0, "NEDDF_GUARD: %d byte(s) written into %d guard bands" % (bad, bands)
 
 
+def free_port():
+    """A TCP port nobody is bound to right now (asked of the kernel), for the rendezvous of a multi-process test: ports derived from the
+    process id collide with whatever an earlier run left in TIME_WAIT -- a flake that stops a `pytest -x` run for nothing."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+_RENDEZVOUS_NOISE = ("Connection reset", "Connection refused", "connect()", "Address already in use", "timed out", "Timed out", "Broken pipe",
+                     "failed to connect", "Socket Timeout", "EADDRINUSE", "store->get", "TCPStore", "rendezvous")
+
+
+def run_ranks(make_cmd, world, env=None, timeout=600, attempts=2):
+    """Start `world` worker processes (make_cmd(rank, port) -> argv), wait for all of them, return their outputs.  The rendezvous port comes
+    from the kernel (free_port); a run that dies of the RENDEZVOUS itself -- a connection error before any assertion of the worker could
+    speak -- is repeated once on a fresh port and the first attempt's output is kept in /tmp/neddf_rendezvous_flake.log: a socket-level
+    hiccup of the test box is not a finding about the product, and under `pytest -x` it would hide every test behind it.  Assertion
+    failures of a worker are never retried."""
+    import subprocess
+    outs = []
+    for attempt in range(attempts):
+        port = str(free_port())
+        import tempfile
+        import time
+        logs = [tempfile.TemporaryFile() for _ in range(world)]
+        procs = [subprocess.Popen(make_cmd(r, port), stdout=logs[r], stderr=subprocess.STDOUT, env=env) for r in range(world)]
+        t0, died = time.time(), None
+        while any(p.poll() is None for p in procs):          # a rank that died leaves its peers in a collective: they get 10 s, then go
+            if died is None and any(p.poll() not in (None, 0) for p in procs):
+                died = time.time()
+            if time.time() - t0 > timeout or (died is not None and time.time() - died > 10.0):
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+            time.sleep(0.1)
+        outs = []
+        for f in logs:
+            f.seek(0)
+            outs.append(f.read().decode(errors="replace"))
+            f.close()
+        bad = [o for p, o in zip(procs, outs) if p.returncode != 0]
+        if not bad:
+            return outs
+        text = "\n".join(bad)
+        if attempt + 1 < attempts and "AssertionError" not in text and any(k in text for k in _RENDEZVOUS_NOISE):
+            with open("/tmp/neddf_rendezvous_flake.log", "a") as f:
+                f.write("---- world %d, attempt %d ----\n%s\n" % (world, attempt, text[-6000:]))
+            continue
+        raise AssertionError("a rank failed:\n" + text[-6000:])
+    return outs
+
+
 def golden(name):
     if name == "bunny_weights.npz":         # ships with the product (bench.py / smoke() measure on it): neddf_amd/fixtures
         from neddf_amd.fixtures import BUNNY_SMOKE_WEIGHTS

@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import pytest
 import torch
-from conftest import ROOT, assert_close, golden
+from conftest import ROOT, assert_close, free_port, golden
 
 pytestmark = pytest.mark.gpu
 
@@ -78,14 +78,10 @@ print("rank", rank, "ok", "rccl" if rccl else "gloo-shared-gpu")
 def _run_world(tmp_path, world):
     script = tmp_path / "shard_worker.py"
     script.write_text(_SHARD_WORKER)
-    port = str(29700 + (os.getpid() * 3 + world) % 1500)
+    from conftest import run_ranks
     out = str(tmp_path / ("img_w%d" % world))
     env = dict(os.environ, NEDDF_BENCH_PMC="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(world), out], stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, env=env) for r in range(world)]
-    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
-    for p, o in zip(procs, logs):
-        assert p.returncode == 0, o
+    run_ranks(lambda r, port: [sys.executable, str(script), ROOT, port, str(r), str(world), out], world, env=env, timeout=600)
     return [np.load(out + ".%d.npz" % r) for r in range(world)]
 
 
@@ -209,7 +205,7 @@ def test_bench_collective_path_on_one_rank():
     bootstrapped through it, pixel all-gather on the communication stream with the host-side deadline wait, max-over-ranks."""
     import json
     env = dict(os.environ, NEDDF_BENCH_PMC="0", HSA_ENABLE_IPC_MODE_LEGACY="0", NEDDF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(29600 + os.getpid() % 300))
+               MASTER_PORT=str(free_port()))
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env,
                        capture_output=True, text=True, timeout=900)
@@ -263,7 +259,7 @@ def test_run_eval_under_a_launcher_matches_single_process(tmp_path):
     script = os.path.join(ROOT, "neddf", "scripts", "run_eval.py")
     outs = {}
     for tag, launcher in (("one", []), ("two", ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                                                "--master-port", str(29900 + os.getpid() % 90)])):
+                                                "--master-port", str(free_port())])):
         run = tmp_path / tag
         (run / ".hydra").mkdir(parents=True)
         (run / "models").mkdir()
@@ -299,7 +295,7 @@ def test_run_script_two_ranks_data_parallel(tmp_path):
     if torch.cuda.device_count() < 2:
         env["NEDDF_DIST_BACKEND"] = "gloo"
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(29700 + os.getpid() % 90), script, "trainer=test", "dataset.dataset_dir=data/tiny/",
+                        "--master-port", str(free_port()), script, "trainer=test", "dataset.dataset_dir=data/tiny/",
                         "trainer.batch_size=16", "trainer.epoch_max=1", "trainer.epoch_save_model=1", "trainer.epoch_test_rendering=1",
                         "trainer.epoch_save_fields=1"], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
@@ -387,7 +383,7 @@ def test_c_client_of_the_abi(tmp_path):
 
 def _bench_line(extra_args, extra_env):
     import json
-    env = dict(os.environ, NEDDF_BENCH_PMC="0", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29300 + os.getpid() % 300))
+    env = dict(os.environ, NEDDF_BENCH_PMC="0", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     env.update(extra_env)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)

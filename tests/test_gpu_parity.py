@@ -1220,7 +1220,7 @@ def test_rccl_collectives_single_rank(tmp_path):
     script = tmp_path / "rccl_worker.py"
     script.write_text(_RCCL_WORKER)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, str(script), ROOT, str(29600 + os.getpid() % 1000)], env=env, capture_output=True, text=True,
+    p = subprocess.run([sys.executable, str(script), ROOT, str(__import__("conftest").free_port())], env=env, capture_output=True, text=True,
                        timeout=300)
     assert p.returncode == 0 and "rccl ok" in p.stdout, p.stdout + p.stderr
 

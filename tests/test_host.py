@@ -317,12 +317,8 @@ print("rank", rank, "ok")
 def test_sharded_gather_two_ranks_gloo(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    port = str(29500 + (os.getpid() * 7 + world) % 2000)
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(world)], stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(world)]
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o
+    from conftest import run_ranks
+    run_ranks(lambda r, port: [sys.executable, str(script), ROOT, port, str(r), str(world)], world, timeout=240)
 
 
 def _make_dataset(root, n=2, w=20, h=16, seed=0, split="test"):
