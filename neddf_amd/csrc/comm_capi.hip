@@ -190,7 +190,9 @@ int neddf_comm_init(neddf_ctx *ctx, int rank, int nranks, const void *h_id)
     const int mine = (ip && atoi(ip) != 0 && r->Broadcast && r->GroupStart && r->GroupEnd) ? 1 : 0;
     c.force_ragged = fr && atoi(fr) != 0;
     c.in_place = mine != 0;
-    if (nranks > 1) {
+    // (the agreement is a collective of its own: it runs only where the opt-in was asked for -- NEDDF_GATHER_INPLACE=1 must be set on
+    // every rank or on none --, so the default start-up of a communicator issues nothing but ncclCommInitRank)
+    if (nranks > 1 && mine) {
         int rc = ensure(ctx, c.pad, sizeof(int) * (size_t)(nranks + 1));
         std::vector<int> all((size_t)nranks, 0);
         if (!rc) {
