@@ -402,12 +402,60 @@ __device__ __forceinline__ void dense_pipeline3(f32x16 (&acc)[MT][NT], typename 
     }
 }
 
+// The same with the weight fragments DB - 1 super-steps ahead (ring of DB sets) and the LDS fragments DA - 1 ahead (ring of DA): a probe
+// of how far the 16-bit products wait on L2 latency (-DNEDDF_PF_B=<DB> -DNEDDF_PF_A=<DA>; dense_pipeline3 is DB = 3, DA = 2).
+template <int MT, int NT, class Ops, int DB, int DA>
+__device__ __forceinline__ void dense_pipeline_deep(f32x16 (&acc)[MT][NT], typename Ops::afrag (&a0)[MT], typename Ops::bfrag (&b0)[NT],
+                                                    const typename Ops::act_t *act_lane, const WeightStream &wl, int ksteps)
+{
+    static_assert(DB >= 2 && DA >= 2, "at least one super-step ahead");
+    constexpr int U = DB * DA;              // unroll: both rings return to slot 0
+    typename Ops::afrag a[DA][MT];
+    typename Ops::bfrag b[DB][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[0][mt] = a0[mt];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[0][t] = b0[t];
+#pragma unroll
+    for (int d = 1; d < DB - 1; ++d)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[d][t] = stream_load<typename Ops::bfrag>(wl, (unsigned)(t * ksteps + (d < ksteps ? d : ksteps - 1)));
+#pragma unroll
+    for (int d = 1; d < DA - 1; ++d)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[d][mt] = Ops::load_a(act_lane + d * Ops::kStep + mt * 32 * Ops::kLd);
+    const typename Ops::act_t *ap = act_lane;
+    for (int S = 0; S < ksteps; S += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (S + u >= ksteps) break;                 // wave-uniform
+            const int sb = S + u + DB - 1 < ksteps ? S + u + DB - 1 : ksteps - 1;     // (clamped: the index could leave the allocation)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[(u + DB - 1) % DB][t] = stream_load<typename Ops::bfrag>(wl, (unsigned)(t * ksteps + sb));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[(u + DA - 1) % DA][mt] = Ops::load_a(ap + (u + DA - 1) * Ops::kStep + mt * 32 * Ops::kLd);
+            __builtin_amdgcn_sched_barrier(0);
+            dense_mfma<MT, NT, Ops>(acc, a[u % DA], b[u % DB]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ap += U * Ops::kStep;
+    }
+}
+
+#ifndef NEDDF_PF_B
+#define NEDDF_PF_B 3
+#endif
+#ifndef NEDDF_PF_A
+#define NEDDF_PF_A 2
+#endif
+
 template <int MT, int NT, class Ops = OpsF32>
 __device__ __forceinline__ void dense_pipeline(f32x16 (&acc)[MT][NT], typename Ops::afrag (&a0)[MT], typename Ops::bfrag (&b0)[NT],
                                                const typename Ops::act_t *act_lane, const WeightStream &wl, int ksteps)
 {
     if constexpr (Ops::kDeepPrefetch && !kFarTiles<MT, Ops>) {
-        dense_pipeline3<MT, NT, Ops>(acc, a0, b0, act_lane, wl, ksteps);
+        if constexpr (NEDDF_PF_B == 3 && NEDDF_PF_A == 2) dense_pipeline3<MT, NT, Ops>(acc, a0, b0, act_lane, wl, ksteps);
+        else dense_pipeline_deep<MT, NT, Ops, NEDDF_PF_B, NEDDF_PF_A>(acc, a0, b0, act_lane, wl, ksteps);
         return;
     }
     typename Ops::afrag a1[MT];
