@@ -1546,11 +1546,15 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
 
     int *ctl = (int *)(lp + 12);
     int64_t tile = sched_begin(a.sched, a.sched_flags, ctl, tid);
+    NEDDF_STAMP_DECL;           // (stamp builds: tools/stamp_timeline_col.py names the phases)
     while (tile < ntiles) {
         const int64_t p0 = tile * P;
+        NEDDF_STAMP_TILE();
+        STAMP();                                    // 0: tile start
         // layer 0, small-input segment: [embed_pos | embed_dir | norm_dir] (neddf.py:243)
         zero_cols<Ops, THREADS>(act, ROWS, ka, tid);
         __syncthreads();
+        STAMP();                                    // 1: columns zeroed + barrier
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
         // timing ablations of the colour kernel (-DNEDDF_ABLATE builds only, results invalid): 1024 no input encodings, 2048 no
@@ -1581,7 +1585,9 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
                 Ops::put(act + (RPP * p) * LD + c_n + d, a.ptaux[gp * kPtAux + PA_N0 + d]);
             }
         }
+        STAMP();                                    // 2: encodings done
         __syncthreads();
+        STAMP();                                    // 3: barrier passed
         f32x16 acc[MT][NT];
         // layer 0, feature segment: in the eval-minimal 64-row tile the trunk features are requested now
         // (global -> VGPR) and land in LDS after the small-input dense; the other variants lack the registers
@@ -1617,7 +1623,9 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
         if (!NEDDF_ABL(a.sched_flags, 4096)) dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wp_a + (size_t)wave * NT * a.ksteps_a * 64 + lane, a.ksteps_a);
         LayerPre<NT, Ops> pre;
         layer_prefetch<NT, Ops>(pre, a.layer[0].wp, nullptr, a.layer[0].ksteps, wave, lane);
+        STAMP();                                    // 4: features requested, small-input product done
         __syncthreads();
+        STAMP();                                    // 5: barrier passed
         if constexpr (FPRE) {
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
@@ -1628,16 +1636,22 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
             for (int idx = tid; idx < ROWS * CPR; idx += THREADS)
                 *lds_chunk(idx) = *feature_src(idx);
         }
+        STAMP();                                    // 6: features in LDS
         __syncthreads();
+        STAMP();                                    // 7: barrier passed
         for (int l = 0; l < a.n_layers; ++l) {                     // neddf.py:254-256
             const LayerW &L = a.layer[l];
             if (l > 0) acc_init_pre<MT, NT, ROWS4, Ops>(acc, pre);
             dense_pre<MT, NT, Ops>(acc, act_lane, (const frag *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane, L.ksteps, pre);
             if (l + 1 < a.n_layers)
                 layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
+            STAMP();                                // layer l: 8 + 4l product done
             __syncthreads();
+            STAMP();                                //          9 + 4l barrier passed
             epilogue_rt<MT, NT, ROWS4, Ops>(acc, act, NEDDF_ABL(a.sched_flags, 16384) ? 0 : a.activation, wave, lane);
+            STAMP();                                //          10 + 4l epilogue done
             __syncthreads();
+            STAMP();                                //          11 + 4l barrier passed
         }
         // layer_col_out 256 -> 3 (neddf.py:257), no output activation.  Every thread works: NPART = THREADS / ROWS threads share a
         // row, each over WID / NPART consecutive features.  With 64-row tiles the part index is the wave index, so the weights are
@@ -1663,7 +1677,9 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
             }
             hd[tid * 3 + 0] = c0; hd[tid * 3 + 1] = c1; hd[tid * 3 + 2] = c2;
         }
+        STAMP();                                    // H: head dot products done
         __syncthreads();
+        STAMP();                                    // H + 1: barrier passed
         if (tid < P && p0 + tid < a.n_points) {
             const int64_t gp = p0 + tid;
             float c[RPP][3];
@@ -1710,8 +1726,10 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
                 a.penalty[gp] = tot;
             }
         }
+        STAMP();                                    // H + 2: outputs written
         if (tid == 0) ctl[0] = next_tile;
         __syncthreads();
+        STAMP();                                    // H + 3: tile end
         tile = ctl[0];
     }
 }

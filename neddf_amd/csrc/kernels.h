@@ -126,6 +126,7 @@ struct ColArgs {
     float distance_range_max;
     float penalty_weight[6];
     int penalty_has[6];
+    unsigned long long *stamps = nullptr; // -DNEDDF_STAMP builds only: phase time stamps of the colour kernel (NEDDF_STAMP_FILE_COL, tools/stamp_timeline_col.py)
 };
 
 // Plain NeRF field (nerf.py:107-165), value rows only.

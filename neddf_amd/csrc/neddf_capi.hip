@@ -655,7 +655,22 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
             c.sched = (int *)ctx->sched.p + kSchedInts;
             c.sched_flags = sched_flags();
             HIPCHK(hipMemsetAsync(c.sched, 0, kSchedInts * sizeof(int), s));
+#ifdef NEDDF_STAMP
+            static unsigned long long *d_cstamps = nullptr;
+            const size_t cstamp_bytes = (size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles * sizeof(unsigned long long);
+            if (!d_cstamps) HIPCHK(hipMalloc((void **)&d_cstamps, cstamp_bytes));
+            HIPCHK(hipMemsetAsync(d_cstamps, 0, cstamp_bytes, s));
+            c.stamps = d_cstamps;
+#endif
             STAGE(ctx, s, NEDDF_STAGE_COL, launch_col(c, (int)(ctiles < grid_cap_col ? ctiles : grid_cap_col), full, s));
+#ifdef NEDDF_STAMP
+            if (const char *path = getenv("NEDDF_STAMP_FILE_COL")) {    // the LAST colour launch's stamps (tools/stamp_timeline_col.py)
+                HIPCHK(hipStreamSynchronize(s));
+                std::vector<unsigned long long> h((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles);
+                HIPCHK(hipMemcpy(h.data(), d_cstamps, cstamp_bytes, hipMemcpyDeviceToHost));
+                if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), 1, cstamp_bytes, fp); fclose(fp); }
+            }
+#endif
         }
     }
     HIPCHK(hipGetLastError());
