@@ -105,18 +105,30 @@ constexpr bool kAblate = false;
 #if defined(NEDDF_STAMP) && defined(NEDDF_STAMP_PAIRS)
 // pair mode (tools/stamp_pairs.py): four consecutive tiles of workgroups {0..3, 256..259} -- with 512 workgroups on 256 CUs, b and b + 256
 // are the candidates for sharing a CU (slot 0 carries HW_ID | XCC_ID << 32 to check) -- to see how the two workgroups' phases line up
-#define NEDDF_STAMP_DECL int sidx_ = 1, stile_ = 0; unsigned long long *sbuf_ = (a.stamps && blockIdx.x < 512 && (blockIdx.x & 255) < 4 && lane == 0) ? a.stamps + ((size_t)((blockIdx.x & 255) + 4 * (blockIdx.x >> 8)) * 8 + wave) * (kStampSlots * kStampPairTiles) : nullptr; \
+#define NEDDF_STAMP_DECL int sidx_ = 1, stile_ = 0; const unsigned long long swall0_ = wall_clock64(); unsigned long long *sbuf_ = (a.stamps && blockIdx.x < 512 && (blockIdx.x & 255) < 4 && lane == 0) ? a.stamps + ((size_t)((blockIdx.x & 255) + 4 * (blockIdx.x >> 8)) * 8 + wave) * (kStampSlots * kStampPairTiles) : nullptr; \
     if (sbuf_) sbuf_[0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32)
 #define NEDDF_STAMP_TILE() do { ++stile_; } while (0)
 #define STAMP() do { if (sbuf_ && stile_ >= kStampTile && stile_ < kStampTile + kStampPairTiles && sidx_ < kStampSlots * kStampPairTiles) sbuf_[sidx_++] = __builtin_readcyclecounter(); } while (0)
+#define STAMP_WALL(k) do { } while (0)
 #elif defined(NEDDF_STAMP)
-#define NEDDF_STAMP_DECL int sidx_ = 0, stile_ = 0; unsigned long long *sbuf_ = (a.stamps && blockIdx.x < kStampBlocks && lane == 0) ? a.stamps + ((size_t)blockIdx.x * 8 + wave) * kStampSlots : nullptr
+#define NEDDF_STAMP_DECL int sidx_ = 0, stile_ = 0; const unsigned long long swall0_ = wall_clock64(); unsigned long long *sbuf_ = (a.stamps && blockIdx.x < kStampBlocks && lane == 0) ? a.stamps + ((size_t)blockIdx.x * 8 + wave) * kStampSlots : nullptr
 #define NEDDF_STAMP_TILE() do { sidx_ = 0; ++stile_; } while (0)
-#define STAMP() do { if (sbuf_ && stile_ == kStampTile && sidx_ < kStampSlots) sbuf_[sidx_++] = __builtin_readcyclecounter(); } while (0)
+#define STAMP() do { if (sbuf_ && stile_ == kStampTile && sidx_ < kStampSlots - 2) sbuf_[sidx_++] = __builtin_readcyclecounter(); } while (0)
+// the constant 100 MHz clock (s_memrealtime) at the start (k = 0) and the end (k = 1) of the stamped tile, in the last two slots: cycles of
+// the tile over its wall time = the shader clock the part actually held while this kernel ran (tools/stamp_timeline*.py print it)
+#define STAMP_WALL(k) do { if (sbuf_ && stile_ == kStampTile) sbuf_[kStampSlots - 2 + (k)] = wall_clock64(); } while (0)
+#endif
+#if defined(NEDDF_STAMP)
+// at the end of the kernel: how many tiles this workgroup took from the queue, and where it ran
+#define NEDDF_STAMP_EXIT() do { if (a.stamps && threadIdx.x == 0 && blockIdx.x < kStampWgTail) { unsigned long long *t_ = a.stamps + (size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles + blockIdx.x; \
+    t_[0] = (unsigned long long)(stile_ & 0xfffff) | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) << 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 24); \
+    t_[kStampWgTail] = swall0_; t_[2 * kStampWgTail] = wall_clock64(); } } while (0)      /* + its first and last moment on the constant 100 MHz clock */
 #else
+#define NEDDF_STAMP_EXIT() do { } while (0)
 #define NEDDF_STAMP_DECL
 #define NEDDF_STAMP_TILE() do { } while (0)
 #define STAMP() do { } while (0)
+#define STAMP_WALL(k) do { } while (0)
 #endif
 
 // position / variance / direction of point `gpt` of the [B, S] sample grid, straight from the rays (kernels.h RaySrc)
@@ -540,6 +552,7 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
     while (unit * TEAMS < ntiles) {
         const int64_t tile = unit * TEAMS + team;
         NEDDF_STAMP_TILE();
+        STAMP_WALL(0);
         STAMP();                                    // 0: tile start
         const int64_t p0 = tile * P;
         LayerPre<NT, Ops> pre;
@@ -1035,7 +1048,9 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
         __syncthreads();
         unit = ctl[0];
         STAMP();                        // tile end
+        STAMP_WALL(1);
     }
+    NEDDF_STAMP_EXIT();
     if (TEAMS > 1 && team == 0) __syncthreads();     // ... and team 0 waits for it at the end
 }
 
@@ -1550,6 +1565,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
     while (tile < ntiles) {
         const int64_t p0 = tile * P;
         NEDDF_STAMP_TILE();
+        STAMP_WALL(0);
         STAMP();                                    // 0: tile start
         // layer 0, small-input segment: [embed_pos | embed_dir | norm_dir] (neddf.py:243)
         zero_cols<Ops, THREADS>(act, ROWS, ka, tid);
@@ -1730,8 +1746,10 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
         if (tid == 0) ctl[0] = next_tile;
         __syncthreads();
         STAMP();                                    // H + 3: tile end
+        STAMP_WALL(1);
         tile = ctl[0];
     }
+    NEDDF_STAMP_EXIT();
 }
 
 // ----------------------------------------------------------------------------

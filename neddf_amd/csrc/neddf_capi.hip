@@ -504,9 +504,12 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     UseMark mark{ ctx, f, s };
     const int dt = f.d.weight_dtype;
     const int wid = f.d.kind == NEDDF_FIELD_NERF ? f.nerf.width : f.ddf.width;        // engine width
-    const int grid_cap = ctx->cus * nerf_wgs_per_cu(wid);
-    const int grid_cap_ddf = ctx->cus * field_wgs_per_cu(dt, wid);
-    const int grid_cap_col = ctx->cus * col_wgs_per_cu(dt, wid);
+    // NEDDF_GRID_SLACK_PCT=<p> (probe): p % more workgroups than the CUs' slots in the persistent field grids (see tools/residency_probe.hip)
+    static const int slack_pct = [] { const char *e = getenv("NEDDF_GRID_SLACK_PCT"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 300 ? 300 : v); }();
+    auto with_slack = [&](int wgs) { return (int)((int64_t)wgs * (100 + slack_pct) / 100); };
+    const int grid_cap = with_slack(ctx->cus * nerf_wgs_per_cu(wid));
+    const int grid_cap_ddf = with_slack(ctx->cus * field_wgs_per_cu(dt, wid));
+    const int grid_cap_col = with_slack(ctx->cus * col_wgs_per_cu(dt, wid));
     const int n_parked = f.d.kind == NEDDF_FIELD_NERF ? f.nerf.n_stash : f.ddf.n_stash;      // early partials a kernel may park per workgroup
     if (int rc = ensure(ctx, ctx->scratch, (size_t)(grid_cap > grid_cap_ddf ? grid_cap : grid_cap_ddf) * (n_parked > 1 ? n_parked : 1) * kStashFloatsPerWg * sizeof(float))) return rc;
     auto sample_now = [&]() {       // the sampling tensors after all (a route that reads them)
@@ -605,14 +608,14 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         a.sched_flags = sched_flags();
         HIPCHK(hipMemsetAsync(a.sched, 0, kSchedInts * sizeof(int), s));
         if (reverse) {          // one scalar's gradient: reverse mode, 64 or 128 points per tile (field_kernels.hip ddf_rev_kernel)
-            const int pts = ddf_rev_points(dt, wid), wgs = ddf_rev_wgs_per_cu(dt, wid) * ctx->cus;
+            const int pts = ddf_rev_points(dt, wid), wgs = with_slack(ddf_rev_wgs_per_cu(dt, wid) * ctx->cus);
             const int64_t tiles = (n + pts - 1) / pts;
             const int grid = (int)(tiles < wgs ? tiles : wgs);
             if (int rc = ensure(ctx, ctx->rev_scratch, (size_t)wgs * ddf_rev_scratch_floats_per_wg(a.n_layers, pts, wid) * sizeof(float))) return rc;
             a.rev_scratch = (float *)ctx->rev_scratch.p;
 #ifdef NEDDF_STAMP
             static unsigned long long *d_stamps = nullptr;
-            const size_t stamp_bytes = (size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles * sizeof(unsigned long long);
+            const size_t stamp_bytes = ((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles + 3 * kStampWgTail) * sizeof(unsigned long long);
             if (!d_stamps) HIPCHK(hipMalloc((void **)&d_stamps, stamp_bytes));
             HIPCHK(hipMemsetAsync(d_stamps, 0, stamp_bytes, s));
             a.stamps = d_stamps;
@@ -628,7 +631,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
 #ifdef NEDDF_STAMP
             if (const char *path = getenv("NEDDF_STAMP_FILE")) {        // the LAST launch's stamps (a diagnostic build: synchronising here is fine)
                 HIPCHK(hipStreamSynchronize(s));
-                std::vector<unsigned long long> h((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles);
+                std::vector<unsigned long long> h((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles + 3 * kStampWgTail);
                 HIPCHK(hipMemcpy(h.data(), d_stamps, stamp_bytes, hipMemcpyDeviceToHost));
                 if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), 1, stamp_bytes, fp); fclose(fp); }
             }
@@ -657,7 +660,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
             HIPCHK(hipMemsetAsync(c.sched, 0, kSchedInts * sizeof(int), s));
 #ifdef NEDDF_STAMP
             static unsigned long long *d_cstamps = nullptr;
-            const size_t cstamp_bytes = (size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles * sizeof(unsigned long long);
+            const size_t cstamp_bytes = ((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles + 3 * kStampWgTail) * sizeof(unsigned long long);
             if (!d_cstamps) HIPCHK(hipMalloc((void **)&d_cstamps, cstamp_bytes));
             HIPCHK(hipMemsetAsync(d_cstamps, 0, cstamp_bytes, s));
             c.stamps = d_cstamps;
@@ -666,7 +669,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
 #ifdef NEDDF_STAMP
             if (const char *path = getenv("NEDDF_STAMP_FILE_COL")) {    // the LAST colour launch's stamps (tools/stamp_timeline_col.py)
                 HIPCHK(hipStreamSynchronize(s));
-                std::vector<unsigned long long> h((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles);
+                std::vector<unsigned long long> h((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles + 3 * kStampWgTail);
                 HIPCHK(hipMemcpy(h.data(), d_cstamps, cstamp_bytes, hipMemcpyDeviceToHost));
                 if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), 1, cstamp_bytes, fp); fclose(fp); }
             }

@@ -14,7 +14,9 @@ import numpy as np
 BLOCKS, WAVES, SLOTS = 8, 8, 160
 path = sys.argv[1]
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-raw = np.fromfile(path, dtype=np.uint64).reshape(BLOCKS, WAVES, -1)[:, :4, :SLOTS].astype(np.int64)      # (the buffer holds 4 x SLOTS per wave for the pair mode)
+# (`make stamp`: wave w of workgroup b writes at (8 b + w) * SLOTS; the buffer is allocated four times that size for the pair mode of
+# `make stamppairs`, tools/stamp_pairs.py)
+raw = np.fromfile(path, dtype=np.uint64)[:BLOCKS * WAVES * SLOTS].reshape(BLOCKS, WAVES, SLOTS)[:, :4, :].astype(np.int64)
 names = ["encode", "bar"]
 for l in range(L):
     names += ["F%d product" % l, "F%d bar" % l, "F%d epilogue" % l, "F%d bar" % l]
@@ -34,6 +36,11 @@ if (ok[:, :, 1:] == 0).any():
 d = np.diff(ok, axis=2).astype(np.float64)          # [block][wave][phase]
 tot = (ok[:, :, -1] - ok[:, :, 0]).astype(np.float64)
 print("tile span per wave (cycles): mean %.0f  min %.0f  max %.0f   (%d workgroups x 4 waves)" % (tot.mean(), tot.min(), tot.max(), BLOCKS))
+# the constant 100 MHz clock at the start and the end of the stamped tile (last two slots): the shader clock the part held
+wall = (raw[:, :, SLOTS - 1] - raw[:, :, SLOTS - 2]).astype(np.float64)
+if (wall > 0).all():
+    ghz = tot / (wall / 100e6) / 1e9
+    print("shader clock while the tile ran (cycles of the tile / its time on the constant 100 MHz clock): mean %.3f GHz  min %.3f  max %.3f" % (ghz.mean(), ghz.min(), ghz.max()))
 print("%-20s %10s %10s %10s %7s" % ("phase", "mean", "min", "max", "share"))
 groups = {}
 for i, nm in enumerate(names):

@@ -17,7 +17,8 @@ BLOCKS, WAVES, SLOTS = 8, 8, 160
 path = sys.argv[1]
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 NW = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-raw = np.fromfile(path, dtype=np.uint64).reshape(BLOCKS, WAVES, -1)[:, :NW, :SLOTS].astype(np.int64)
+# (wave w of workgroup b writes at (8 b + w) * SLOTS; the buffer is allocated four times that size for the pair mode)
+raw = np.fromfile(path, dtype=np.uint64)[:BLOCKS * WAVES * SLOTS].reshape(BLOCKS, WAVES, SLOTS)[:, :NW, :].astype(np.int64)
 names = ["zero small-input columns + bar", "encode pos / dir / normal", "bar", "feature request + small-input product", "bar",
          "features -> LDS", "bar"]
 for l in range(L):
@@ -30,6 +31,11 @@ if (ok[:, :, 1:] == 0).any():
 d = np.diff(ok, axis=2).astype(np.float64)          # [block][wave][phase]
 tot = (ok[:, :, -1] - ok[:, :, 0]).astype(np.float64)
 print("tile span per wave (cycles): mean %.0f  min %.0f  max %.0f   (%d workgroups x %d waves)" % (tot.mean(), tot.min(), tot.max(), BLOCKS, NW))
+# the constant 100 MHz clock at the start and the end of the stamped tile (last two slots): the shader clock the part held
+wall = (raw[:, :, SLOTS - 1] - raw[:, :, SLOTS - 2]).astype(np.float64)
+if (wall > 0).all():
+    ghz = tot / (wall / 100e6) / 1e9
+    print("shader clock while the tile ran (cycles of the tile / its time on the constant 100 MHz clock): mean %.3f GHz  min %.3f  max %.3f" % (ghz.mean(), ghz.min(), ghz.max()))
 print("%-40s %10s %10s %10s %7s" % ("phase", "mean", "min", "max", "share"))
 groups = {}
 for i, nm in enumerate(names):
