@@ -1,5 +1,9 @@
 #!/bin/bash
-# Round 5 probe: the fp32 field kernels with eight waves on the 64-row tile (four waves per SIMD instead of two)
+# Round 5 probe: the fp32 field kernels with eight waves on the 64-row tile (four waves per SIMD instead of two).
+# The two switches were local to the probe and are NOT in the tree (lab notebook R5.17: distance kernel -3.7 %, colour kernel +0.7 %):
+#   geo_rev():   g[0] = parse_geo("NEDDF_REV_GEO_F32", Geo{ 2, 2, 4 }, { { 2, 2, 4 }, { 2, 2, 8 } });
+#   launch_ddf_rev():  NEDDF_GEO_CASE(2, 2, 8) return launch_ddf_rev_t<2, 8, 2, OpsF32>(a, grid, s);
+#   geo_col(0):  parse_geo("NEDDF_F32_COL_GEO", Geo{ 2, 2, 4 }, { { 2, 2, 4 }, { 2, 2, 8 } });   launch_col(): launch_col_g<2, 2, 8, OpsF32>
 ROOT=$PWD
 O=$ROOT/gpurun_out/r5geo8
 mkdir -p $O
