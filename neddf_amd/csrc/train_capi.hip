@@ -29,6 +29,14 @@ constexpr int kLdPe = 64, kLdDir = 64, kLdNarrow = 4;      // row strides of the
 // constructs, neddf.py:52-66, nerf.py:34-44, neus.py:30-41) arrives padded to 512 and takes the PER-LAYER route with every product cut into 256 x 256 blocks
 // (K blocks accumulate in the output, the activation / its backward runs on the last one): the same kernels, correct at any
 // multiple of 256, without the fused chains' speed.  Anything wider is refused loudly rather than computed wrongly.
+// NEDDF_TRAIN_SPLIT_FUSED=0: the split-fp16 policy's backward pass as one GEMM kernel per layer on row-major matrices (rounds 1-4)
+// instead of the fused input-gradient chains on point-major ones (round 5: mlp_backward_split_kernel)
+bool split_fused()
+{
+    static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_SPLIT_FUSED"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 int train_supported(neddf_ctx *ctx, const Field &f)
 {
     if (f.d.layer_width % kWidth != 0 || f.d.layer_width < kWidth || f.d.layer_width > 2 * kWidth ||
@@ -584,7 +592,9 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     // the fused backward (neddf_train_field_backward takes that route under the same condition)
     const int WH = p.WH, NBK = WH / kWidth;      // hidden width the kernels see, in 256-column blocks
     const bool fused = !unfused && n_wide <= 1 && WH == kWidth;       // (the fused chains are 256 wide)
-    const int pm = (!sp && fused) ? 1 : 0;
+    // (round 5: the split-fp16 policy takes the same fused, point-major route; NEDDF_TRAIN_SPLIT_FUSED=0 keeps its per-layer backward
+    // and the row-major matrices that reads -- the A/B partner)
+    const int pm = (fused && (!sp || split_fused())) ? 1 : 0;
     // Z[R, WH] (+)= X[R, Kin] x (rows k_off .. k_off + Kin of the [in, WH] weight) (+ bias on value rows); H = a(Z) when act_kind >= 0.
     // Kin <= 256: one K block of `kload` loaded columns; otherwise Kin = WH in 256-row blocks.  Every block is one rows_gemm launch:
     // K blocks accumulate in Z, the activation runs with the last one
@@ -714,7 +724,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     int n_wide = 0;
     for (int l = 1; l < p.n_trunk; ++l) n_wide += in_skips(f.d, l - 1) ? 1 : 0;
     const int WH = p.WH, NBK = WH / kWidth;
-    if (!sp && !unfused && n_wide <= 1 && WH == kWidth) {      // (= the forward's condition for point-major hidden states)
+    if ((!sp || split_fused()) && !unfused && n_wide <= 1 && WH == kWidth) {      // (= the forward's condition for point-major hidden states)
         const int nT = p.n_trunk, nC = p.n_col;
         const size_t slot = (size_t)p.R * kWidth;
         if (int rc = ensure(ctx, ctx->tpack, (size_t)(nT + nC + 1) * kPackFloats * sizeof(float))) return rc;
@@ -730,9 +740,25 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         a.g_distance = g_distance; a.g_density = g_density; a.g_color = g_color; a.g_penalty = g_penalty; a.g_aux = g_aux_grad;
         a.GZH = GZH; a.GCR = GCR;
         launch_point_backward(a, s);
-        PackBatch pbk;         // the transposed weight fragments of a chain: one launch per chain
+        PackBatch pbk;         // the transposed weight fragments of a chain: one launch per chain (fp32; split fp16: matrix by matrix)
+        auto pack_t = [&](const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, float *dst) {
+            if (sp) launch_pack(1, src, sk, sn, k_off, n_off, kcount, ncount, nout, dst, s);
+            else pbk.add(src, sk, sn, k_off, n_off, kcount, ncount, nout, dst, s);
+        };
         DwJobs dwj{};          // every weight-gradient product of this pass: one job-parallel launch at the end (launch_dw_jobs)
         dwj.R = p.R;
+        // split fp16: every gradient matrix leaves max |dZ| in a device scalar (the chain kernel publishes it), its weight-gradient
+        // products -- one launch each, after the chain that wrote the matrix -- scale their G operand by it
+        AmaxSlots am;
+        if (int rc = amax_begin(ctx, sp, am, s)) return rc;
+        float *mZc[kMaxLayers] = {}, *mZt[kMaxLayers] = {};
+        for (int l = 0; l < nC; ++l) mZc[l] = am.take();
+        for (int l = 0; l < nT; ++l) mZt[l] = am.take();
+        auto add_dw = [&](const float *X, int ldx, int K, int x_pm, const float *G, const float *amax_g, float *dW, int64_t sk, int64_t sn, int nvalid,
+                          float *db, int period) {
+            if (sp) launch_dw(1, X, ldx, K, G, kWidth, p.R, dW, sk, sn, nvalid, db, period, ctx->cus, s, amax_g, am.dw_tmp, x_pm, 1);
+            else dwj.add(X, ldx, K, x_pm, G, kWidth, dW, sk, sn, nvalid, db, period);
+        };
         // colour head: LinearGradFunction.backward (linear.py:62-88) on [HC | JC] rows, then the last colour activation
         NarrowW cout{};
         cout.nc = 3; cout.wstride = 3; cout.kcount = kWidth;
@@ -748,19 +774,19 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
             // prologue: dZ of the last colour layer = activation backward of the head's upstream gradient (3 raw colour columns)
             m.top_G = GCR; m.top_ldg = kLdNarrow; m.top_nc = 3; m.top_wstride = 3;
             for (int c = 0; c < 3; ++c) m.top_w[c] = cout.w[c];
-            m.top_Z = ws + p.o_zc[nC - 1]; m.top_out = dZc(nC - 1);
+            m.top_Z = ws + p.o_zc[nC - 1]; m.top_out = dZc(nC - 1); m.amax_top = mZc[nC - 1];
             for (int l = 1; l < nC; ++l) {
                 float *wl = next_pack();
-                pbk.add(W[nT + l], 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wl, s);             // W_l^T
-                m.wT[l] = wl; m.Z[l - 1] = ws + p.o_zc[l - 1]; m.dZ[l - 1] = dZc(l - 1);
+                pack_t(W[nT + l], 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wl);             // W_l^T
+                m.wT[l] = wl; m.Z[l - 1] = ws + p.o_zc[l - 1]; m.dZ[l - 1] = dZc(l - 1); m.amax_dZ[l - 1] = mZc[l - 1];
             }
             pbk.flush(s);
-            launch_mlp_backward(m, ctx->cus, s);
+            launch_mlp_backward(sp, m, ctx->cus, s);
         }
         for (int l = nC - 1; l >= 1; --l)
-            dwj.add(ws + p.o_hc[l - 1], kWidth, kWidth, 1, dZc(l), kWidth, gW[nT + l], kWidth, 1, kWidth, gB[nT + l], 4);
-        dwj.add(ws + p.o_xa, p.ldxa, p.Ca, 0, dZc(0), kWidth, gW[nT], kWidth, 1, kWidth, gB[nT], 4);
-        dwj.add(Hlast, kWidth, kWidth, 1, dZc(0), kWidth, gW[nT] + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4);
+            add_dw(ws + p.o_hc[l - 1], kWidth, kWidth, 1, dZc(l), mZc[l], gW[nT + l], kWidth, 1, kWidth, gB[nT + l], 4);
+        add_dw(ws + p.o_xa, p.ldxa, p.Ca, 0, dZc(0), mZc[0], gW[nT], kWidth, 1, kWidth, gB[nT], 4);
+        add_dw(Hlast, kWidth, kWidth, 1, dZc(0), mZc[0], gW[nT] + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4);
         {
             float *wh[2] = { gW[p.i_ddf], gW[p.i_aux] }, *bh[2] = { gB[p.i_ddf], gB[p.i_aux] };
             launch_narrow_dw(Hlast, kWidth, GZH, kLdNarrow, p.R, 2, wh, 1, bh, 4, kWidth, s, 1);
@@ -771,29 +797,29 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
             // prologue: dZ of the last trunk layer = activation backward of (gradient of the features from the colour trunk -- only the
             // feature segment of its first layer propagates: the small colour inputs carry no parameters -- + the distance / aux heads)
             float *wf = next_pack();
-            pbk.add(W[nT], 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wf, s);                  // (feature rows of W_c0)^T
+            pack_t(W[nT], 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wf);                  // (feature rows of W_c0)^T
             m.top_src = dZc(0); m.top_wT = wf;
             m.top_G = GZH; m.top_ldg = kLdNarrow; m.top_nc = 2; m.top_wstride = 1;
             m.top_w[0] = W[p.i_ddf]; m.top_w[1] = W[p.i_aux];
-            m.top_Z = ws + p.o_z[nT - 1]; m.top_out = dZt(nT - 1);
+            m.top_Z = ws + p.o_z[nT - 1]; m.top_out = dZt(nT - 1); m.amax_top = mZt[nT - 1];
             for (int l = 1; l < nT; ++l) {
                 const bool wide = in_skips(f.d, l - 1);
                 float *wl = next_pack();
-                pbk.add(W[l], 1, kWidth, 0, wide ? p.Cpe : 0, kWidth, kWidth, kWidth, wl, s);   // (hidden rows of W_l)^T
-                m.wT[l] = wl; m.Z[l - 1] = ws + p.o_z[l - 1]; m.dZ[l - 1] = dZt(l - 1);
+                pack_t(W[l], 1, kWidth, 0, wide ? p.Cpe : 0, kWidth, kWidth, kWidth, wl);   // (hidden rows of W_l)^T
+                m.wT[l] = wl; m.Z[l - 1] = ws + p.o_z[l - 1]; m.dZ[l - 1] = dZt(l - 1); m.amax_dZ[l - 1] = mZt[l - 1];
             }
             pbk.flush(s);
-            launch_mlp_backward(m, ctx->cus, s);
+            launch_mlp_backward(sp, m, ctx->cus, s);
         }
         for (int l = nT - 1; l >= 0; --l) {
             const bool wide = l > 0 && in_skips(f.d, l - 1);
-            if (l == 0 || wide) dwj.add(PEs, kLdPe, p.Cpe, 0, dZt(l), kWidth, gW[l], kWidth, 1, kWidth, gB[l], 4);
+            if (l == 0 || wide) add_dw(PEs, kLdPe, p.Cpe, 0, dZt(l), mZt[l], gW[l], kWidth, 1, kWidth, gB[l], 4);
             if (l > 0)
-                dwj.add(ws + p.o_h[l - 1], kWidth, kWidth, 1, dZt(l), kWidth, gW[l] + (size_t)(wide ? p.Cpe : 0) * kWidth, kWidth, 1, kWidth,
-                          wide ? nullptr : gB[l], 4);
+                add_dw(ws + p.o_h[l - 1], kWidth, kWidth, 1, dZt(l), mZt[l], gW[l] + (size_t)(wide ? p.Cpe : 0) * kWidth, kWidth, 1, kWidth,
+                       wide ? nullptr : gB[l], 4);
         }
         if (dwj.overflow) return fail(ctx, NEDDF_EUNSUPPORTED, "more weight-gradient products than DwJobs holds (train_kernels.h kMaxDwJobs)");
-        launch_dw_jobs(dwj, ctx->cus, s);
+        if (!sp) launch_dw_jobs(dwj, ctx->cus, s);
         HIPCHK(hipGetLastError());
         return 0;
     }

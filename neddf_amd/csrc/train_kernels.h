@@ -112,8 +112,13 @@ struct MlpBackwardArgs {
     const float *Z[kMaxLayers];           // pre-activations [R, 256]; l = 0 .. n_layers-2 are read
     float *dZ[kMaxLayers];                // outputs [R, 256], l = 0 .. n_layers-2
     int act_kind;                         // backward kind of act_grad2 (0 ReLU, 1 LeakyReLU, 2 tanhExp, 3 tanhExp as NeuS differentiates it)
+    // split-fp16 policy (launch_mlp_backward(split = 1, ...), prologue form only): top_wT / wT are split-packed, every product's gradient
+    // operand is range-scaled per 64-row tile inside the kernel, and each gradient matrix leaves max |dZ| in a device scalar for the
+    // weight-gradient products that follow (launch_dw's amax_g); NULL slots are skipped
+    float *amax_dZ[kMaxLayers];           // for dZ[l]
+    float *amax_top;                      // for top_out
 };
-void launch_mlp_backward(const MlpBackwardArgs &a, int cus, hipStream_t s);
+void launch_mlp_backward(int split, const MlpBackwardArgs &a, int cus, hipStream_t s);
 
 // dW[k * sk + n * sn] += sum_r X[r, k] G[r, n], k < K <= 256, n < nvalid <= 256; db[n] += sum over rows r % bias_period == 0 of G[r, n]
 // dZ[R,256] = activation backward (pre-activations Zprev, row period, kind) of X[R, 0:kload) x Wpacked: the input-gradient GEMM of
@@ -149,7 +154,8 @@ struct DwJobs {
 };
 void launch_dw_jobs(DwJobs &jobs, int cus, hipStream_t s);
 void launch_dw(int split, const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
-               int bias_period, int cus, hipStream_t s, const float *amax_g = nullptr, float *scaled_tmp = nullptr);
+               int bias_period, int cus, hipStream_t s, const float *amax_g = nullptr, float *scaled_tmp = nullptr, int x_point_major = 0,
+               int g_point_major = 0);        // (point-major operands: split policy only, 256 columns, R % 4 == 0)
 // scaled_tmp: [256, 256] floats of scratch, required with amax_g (the scaled product is formed there, then added to dW unscaled)
 // heads (1..4 output columns, input width 256): column c of the weight gradient is w[c][k * wstride], b[c] its bias gradient
 void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t R, int nc, float *const *w, int wstride, float *const *b,

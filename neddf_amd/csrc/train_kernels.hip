@@ -79,6 +79,14 @@ __device__ __forceinline__ void act_backward_group(int kind, int period, const f
 // Every kernel that writes a gradient matrix therefore also leaves max |dZ| in a device scalar (one atomic per wave), and every
 // split-operand GEMM that consumes the matrix multiplies it by the power of two that brings that maximum to [2^13, 2^14) while
 // staging it, and the accumulators by the inverse on the way out -- both exact.  (The fp32 MFMA path needs none of this.)
+__device__ __forceinline__ float operand_scale_of(float amax)
+{
+    const int e = (int)((__builtin_bit_cast(unsigned int, amax) >> 23) & 0xffu);       // biased exponent of the maximum
+    if (e == 0 || e == 255) return 1.0f;            // zero / denormal / non-finite: leave the operand alone
+    int shift = 13 + 127 - e;
+    shift = shift > 100 ? 100 : (shift < -100 ? -100 : shift);
+    return __builtin_bit_cast(float, (unsigned int)(127 + shift) << 23);
+}
 __device__ __forceinline__ float operand_scale(const float *amax)
 {
     if (!amax) return 1.0f;
@@ -493,7 +501,8 @@ void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t
 {
     if (a.R <= 0) return;
     ablate_init();
-    if (split) launch_mlp_forward_ops<OpsF16Split, false, false>(a, cus, s);      // (the split policy's per-layer backward reads row-major matrices)
+    if (split && a.point_major) launch_mlp_forward_ops<OpsF16Split, false, true>(a, cus, s);      // (round 5: the split policy's fused NeDDF route)
+    else if (split) launch_mlp_forward_ops<OpsF16Split, false, false>(a, cus, s);      // (the per-layer backward reads row-major matrices)
     else if (a.point_major) launch_mlp_forward_ops<OpsF32, true, true>(a, cus, s);
     else launch_mlp_forward_ops<OpsF32, true, false>(a, cus, s);
 }
@@ -627,10 +636,216 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
     }
 }
 
-void launch_mlp_backward(const MlpBackwardArgs &a, int cus, hipStream_t s)
+// ----------------------------------------------------------------------------
+// The same chain under the split-fp16 policy (round 5; train_kernels.h MlpBackwardArgs with `split`): every product is three fp16 MFMAs on
+// operands of two fp16 terms, the activation backward stays fp32 on the accumulators.  Gradient matrices sit at 1e-5 .. 1e-8 (a mean over
+// rays), below what two fp16 terms resolve, so every gradient tile that enters a product is RANGE-SCALED by a power of two -- like the
+// per-layer route does per matrix (operand_scale), but per 64-row TILE, the only maximum a fused chain can know: the epilogue runs in
+// two passes around the barrier it needs anyway -- (1) the new gradient into the accumulator registers and out to dZ_l (unscaled fp32),
+// the lane / wave maximum of |dZ_l| into LDS; barrier (every wave is done reading the old tile AND the four wave maxima are visible);
+// (2) scaled by the tile's power of two, split into two fp16 terms, into the LDS tile.  The accumulators of the next product carry
+// that scale and the weights' 2^10: both come off (exactly) at the start of the next epilogue.  Each dZ_l also leaves its global
+// maximum in a device scalar for the weight-gradient products that follow (dw_split_kernel scales its G operand by it).
+template <int KIND>
+__global__ __launch_bounds__(kThreads, 2) void mlp_backward_split_kernel(const MlpBackwardArgs a)
+{
+    typedef OpsF16Split Ops;
+    typedef typename Ops::bfrag frag;
+    typedef typename Ops::act_t act_t;
+    constexpr int MT = 2, NT = 2, ROWS = MT * 32, LD = Ops::kLd, KS = kWidth / Ops::kStep;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    act_t *act = (act_t *)smem;
+    float *smax = (float *)(act + ROWS * LD);           // [4]: the waves' maxima of the gradient tile in flight
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t ntiles = (a.R + ROWS - 1) / ROWS;
+    auto wave_max = [&](float v) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+        return v;
+    };
+    auto publish = [&](float *amax_out, float wmax) {       // (see publish_amax: look first, most waves skip the same-address atomic)
+        if (amax_out && lane == 0 && wmax > *(volatile const float *)amax_out) atomicMax((int *)amax_out, __builtin_bit_cast(int, wmax));
+    };
+    auto tile_scale = [&]() { return operand_scale_of(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))); };
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * ROWS;
+        __syncthreads();                // the previous tile is done with the LDS tile (and with smax)
+        // Z of this lane's accumulator positions: the four rows of a point for one feature = one 16-byte load in the point-major layout
+        auto load_z = [&](const float *Z, f32x16 (&zp)[MT][NT]) {
+            const float *zb = Z + ((r0 >> 2) + h) * (4 * kWidth) + (wave * NT * 32 + j) * 4;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4v v = { 0.f, 0.f, 0.f, 0.f };
+                        if (r0 + mt * 32 + 8 * g + 4 * h < a.R) v = __builtin_nontemporal_load((const f32x4v *)(zb + (mt * 8 + 2 * g) * (4 * kWidth) + t * 128));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zp[mt][t][4 * g + r] = v[r];
+                    }
+        };
+        // pass 1 of an epilogue: acc (upstream gradient of H_l in this lane's accumulator positions, already unscaled) -> dZ_l through the
+        // activation backward, in place; out to the point-major matrix; returns the lane's maximum of |dZ_l|
+        auto backward_values = [&](f32x16 (&acc)[MT][NT], const f32x16 (&zp)[MT][NT], float *dZl) {
+            float lmax = 0.f;
+            float *gb = dZl + ((r0 >> 2) + h) * (4 * kWidth) + (wave * NT * 32 + j) * 4;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float dy, d2;
+                        act_grad2<KIND>(zp[mt][t][4 * g], dy, d2);
+                        const float g0 = acc[mt][t][4 * g], g1 = acc[mt][t][4 * g + 1], g2 = acc[mt][t][4 * g + 2], g3 = acc[mt][t][4 * g + 3];
+                        float sj = g1 * zp[mt][t][4 * g + 1];
+                        sj += g2 * zp[mt][t][4 * g + 2];
+                        sj += g3 * zp[mt][t][4 * g + 3];
+                        const float ov[4] = { g0 * dy + sj * d2, g1 * dy, g2 * dy, g3 * dy };
+                        const bool in = r0 + mt * 32 + 8 * g + 4 * h < a.R;
+                        if (in) __builtin_nontemporal_store(f32x4v{ ov[0], ov[1], ov[2], ov[3] }, (f32x4v *)(gb + (mt * 8 + 2 * g) * (4 * kWidth) + t * 128));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            acc[mt][t][4 * g + r] = in ? ov[r] : 0.f;
+                            lmax = fmaxf(lmax, fabsf(acc[mt][t][4 * g + r]));
+                        }
+                    }
+            return lmax;
+        };
+        // pass 2: the gradient tile, scaled and split, into LDS
+        auto to_lds = [&](const f32x16 (&acc)[MT][NT], float scale) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) Ops::put(o + (8 * (q >> 2) + (q & 3)) * LD, acc[mt][t][q] * scale);
+                }
+        };
+        float s_cur = 1.0f;             // the power of two the gradient tile in LDS carries
+        {
+            // prologue: the top layer's gradient (MlpBackwardArgs: top_src x top_wT + the narrow heads, then the top activation's backward)
+            f32x16 zp[MT][NT], acc[MT][NT];
+            load_z(a.top_Z, zp);
+            acc_init<MT, NT, false>(acc, nullptr, wave, lane);
+            float unscale = 1.0f / Ops::kWScale;
+            if (a.top_src) {
+                // 64 rows of the point-major gradient matrix -> registers, their maximum -> the tile's scale -> the LDS tile
+                // (read twice -- the second time from L2 -- rather than held: 64 registers next to Z and the accumulators would spill)
+                constexpr int NV = (ROWS / 4) * kWidth / kThreads;
+                auto piece = [&](int i) {
+                    const int idx = tid + i * kThreads, p = idx >> 8, c = idx & 255;
+                    f32x4v v = { 0.f, 0.f, 0.f, 0.f };
+                    if (r0 + 4 * p < a.R) v = *(const f32x4v *)(a.top_src + ((r0 >> 2) + p) * (4 * kWidth) + 4 * c);
+                    return v;
+                };
+                float lmax = 0.f;
+#pragma unroll 4
+                for (int i = 0; i < NV; ++i) {
+                    const f32x4v v = piece(i);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) lmax = fmaxf(lmax, fabsf(v[q]));
+                }
+                const float wmax = wave_max(lmax);
+                if (lane == 0) smax[wave] = wmax;
+                __syncthreads();
+                const float sc = tile_scale();
+#pragma unroll 4
+                for (int i = 0; i < NV; ++i) {
+                    const int idx = tid + i * kThreads, p = idx >> 8, c = idx & 255;
+                    const f32x4v v = piece(i);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Ops::put(act + (4 * p + q) * LD + c, v[q] * sc);
+                }
+                __syncthreads();
+                dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.top_wT + (size_t)wave * NT * KS * 64 + lane, KS);
+                unscale = pow2_inverse(sc) * (1.0f / Ops::kWScale);
+            }
+            float hw[3][NT];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) hw[c][t] = c < a.top_nc ? a.top_w[c][(size_t)(wave * NT * 32 + t * 32 + j) * a.top_wstride] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = r0 + mt * 32 + 8 * g + 4 * h + r;
+                        float gv[3] = { 0.f, 0.f, 0.f };
+                        if (row < a.R)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                if (c < a.top_nc) gv[c] = a.top_G[row * a.top_ldg + c];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            float v = acc[mt][t][4 * g + r] * unscale;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) v = fmaf(gv[c], hw[c][t], v);
+                            acc[mt][t][4 * g + r] = v;
+                        }
+                    }
+            const float wmax = wave_max(backward_values(acc, zp, a.top_out));
+            publish(a.amax_top, wmax);
+            if (a.n_layers >= 2) {
+                if (lane == 0) smax[wave] = wmax;
+                __syncthreads();        // every wave finished reading the staged matrix; the maxima are visible
+                s_cur = tile_scale();
+                to_lds(acc, s_cur);
+                __syncthreads();
+            }
+        }
+        for (int l = a.n_layers - 1; l >= 1; --l) {
+            f32x16 zp[MT][NT];
+            load_z(a.Z[l - 1], zp);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc[MT][NT];
+            acc_init<MT, NT, false>(acc, nullptr, wave, lane);
+            dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
+            const float unscale = pow2_inverse(s_cur) * (1.0f / Ops::kWScale);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[mt][t][q] *= unscale;
+            const float wmax = wave_max(backward_values(acc, zp, a.dZ[l - 1]));
+            publish(a.amax_dZ[l - 1], wmax);
+            if (l > 1) {
+                if (lane == 0) smax[wave] = wmax;
+                __syncthreads();        // every wave finished reading dZ_l; the maxima are visible
+                s_cur = tile_scale();
+                to_lds(acc, s_cur);
+                __syncthreads();        // the next layer reads what this epilogue wrote
+            }
+        }
+    }
+}
+
+void launch_mlp_backward(int split, const MlpBackwardArgs &a, int cus, hipStream_t s)
 {
     if (a.R <= 0 || (a.n_layers < 2 && a.dZtop)) return;         // a one-layer stack still has a prologue to run
     ablate_init();
+    if (split) {        // (prologue form only: the NeDDF route, the one caller)
+        constexpr size_t lds = (size_t)64 * OpsF16Split::kLd * sizeof(OpsF16Split::act_t) + 16 * sizeof(float);
+        static bool once = ((void)hipFuncSetAttribute((const void *)mlp_backward_split_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                            (void)hipFuncSetAttribute((const void *)mlp_backward_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                            (void)hipFuncSetAttribute((const void *)mlp_backward_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                            (void)hipFuncSetAttribute((const void *)mlp_backward_split_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        (void)once;
+        const int64_t tiles = (a.R + 63) / 64;
+        const dim3 grid((unsigned)(tiles < 2 * cus ? tiles : 2 * cus));
+        if (a.act_kind == 0) hipLaunchKernelGGL(mlp_backward_split_kernel<0>, grid, dim3(kThreads), lds, s, a);
+        else if (a.act_kind == 1) hipLaunchKernelGGL(mlp_backward_split_kernel<1>, grid, dim3(kThreads), lds, s, a);
+        else if (a.act_kind == 2) hipLaunchKernelGGL(mlp_backward_split_kernel<2>, grid, dim3(kThreads), lds, s, a);
+        else hipLaunchKernelGGL(mlp_backward_split_kernel<3>, grid, dim3(kThreads), lds, s, a);
+        return;
+    }
     constexpr size_t lds = (size_t)64 * OpsF32::kLd * sizeof(float);
     static bool once = ((void)hipFuncSetAttribute((const void *)mlp_backward_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                         (void)hipFuncSetAttribute((const void *)mlp_backward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
@@ -993,11 +1208,14 @@ void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t 
 // ([column][row], two fp16 planes each): thread c owns column c, loads it one row at a time (a wave reads 256 contiguous
 // bytes of a row), splits in registers and stores eight rows per 16-byte LDS write.  32-row chunks, next chunk in flight
 // during the MFMAs, whole K x 256 output in accumulators as in dw_tile_kernel.
-template <int KT>
+// XPM / GPM: the operand is a POINT-MAJOR [R, 256] matrix (train_kernels.h MlpForwardArgs.point_major): column tid of the four rows of
+// a point is one 16-byte load (R % 4 == 0, chunks start at multiples of 32)
+template <int KT, bool XPM = false, bool GPM = false>
 __global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, int ldx, int K, const float *G, int ldg, int64_t R,
                                                                int64_t rows_per_wg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
                                                                int bias_period, const float *amax_g)
 {
+    static_assert(!XPM || KT == 8, "a point-major X has 256 columns");
     constexpr int RC = 32, LDT = RC + 8;            // halves per transposed column: 80 B, 16-byte aligned row octets
     const float gs = operand_scale(amax_g);      // G is a gradient matrix: range-scaled while staged; the launcher undoes it
     constexpr int KP = 32 * KT;
@@ -1021,11 +1239,28 @@ __global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, i
     const bool xcol = tid < KP && tid < K;          // thread tid stages column tid of X (if any) and column tid of G
     float xr[RC], gr[RC];
     auto fetch = [&](int64_t c0) {
+        if constexpr (XPM || GPM) {
+#pragma unroll
+            for (int p = 0; p < RC / 4; ++p) {
+                const bool in = c0 + 4 * p < re;
+                const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
+                if constexpr (XPM) {
+                    const f32x4v v = (in && xcol) ? *(const f32x4v *)(X + ((c0 >> 2) + p) * (4 * kWidth) + 4 * tid) : zero;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xr[4 * p + q] = v[q];
+                }
+                if constexpr (GPM) {
+                    const f32x4v v = in ? *(const f32x4v *)(G + ((c0 >> 2) + p) * (4 * kWidth) + 4 * tid) : zero;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gr[4 * p + q] = v[q];
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < RC; ++r) {
             const bool in = c0 + r < re;
-            xr[r] = (in && xcol) ? X[(c0 + r) * ldx + tid] : 0.f;
-            gr[r] = in ? G[(c0 + r) * ldg + tid] : 0.f;
+            if constexpr (!XPM) xr[r] = (in && xcol) ? X[(c0 + r) * ldx + tid] : 0.f;
+            if constexpr (!GPM) gr[r] = in ? G[(c0 + r) * ldg + tid] : 0.f;
         }
     };
     auto stage = [&](const float (&v)[RC], _Float16 *ph, _Float16 *pm, float scale) {        // column tid: 32 rows -> 4 + 4 LDS writes of 8 halves
@@ -1099,28 +1334,41 @@ __global__ void dw_unscale_add_kernel(const float *T, int K, int nvalid, float *
     if (n < nvalid) dW[k * sk + n * sn] += T[i] * pow2_inverse(operand_scale(amax_g));
 }
 
-template <int KT>
+template <int KT, bool XPM = false, bool GPM = false>
 static void launch_dw_split(const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid,
                             float *db, int bias_period, int cus, hipStream_t s, const float *amax_g)
 {
     const size_t lds = (size_t)2 * (32 * KT + kWidth) * 40 * sizeof(_Float16);
-    static bool once = ((void)hipFuncSetAttribute((const void *)dw_split_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    static bool once = ((void)hipFuncSetAttribute((const void *)dw_split_kernel<KT, XPM, GPM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   (int)((size_t)2 * (32 * KT + kWidth) * 40 * sizeof(_Float16))), true);
     (void)once;
     int64_t chunks = (R + 31) / 32;
     int grid = (int)(chunks < cus ? chunks : cus);
     int64_t rows_per_wg = ((chunks + grid - 1) / grid) * 32;
-    hipLaunchKernelGGL((dw_split_kernel<KT>), dim3(grid), dim3(kThreads), lds, s, X, ldx, K, G, ldg, R, rows_per_wg, dW, sk, sn, nvalid, db,
+    hipLaunchKernelGGL((dw_split_kernel<KT, XPM, GPM>), dim3(grid), dim3(kThreads), lds, s, X, ldx, K, G, ldg, R, rows_per_wg, dW, sk, sn, nvalid, db,
                        bias_period, amax_g);
 }
 
 // dW[k * sk + n * sn] += sum_r X[r, k] G[r, n] for k < K <= 256, n < nvalid <= 256 (G has 256 columns, the rest zero);
 // (sk, sn) = (256, 1) for LinearGradLayer weights [in, out], (1, in_total) for nn.Linear weights [out, in]
 void launch_dw(int split, const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid,
-               float *db, int bias_period, int cus, hipStream_t s, const float *amax_g, float *scaled_tmp)
+               float *db, int bias_period, int cus, hipStream_t s, const float *amax_g, float *scaled_tmp, int x_point_major, int g_point_major)
 {
     if (R <= 0 || K <= 0) return;
     if (bias_period != 1 && bias_period != 2 && bias_period != 4) return;       // the kernels test row phases with a mask
+    if (split && g_point_major) {       // round 5: the split policy's fused NeDDF route keeps its hidden states and gradients point-major
+        const bool scaled = amax_g && scaled_tmp;
+        float *out = scaled ? scaled_tmp : dW;
+        const int64_t osk = scaled ? kWidth : sk, osn = scaled ? 1 : sn;
+        if (scaled) (void)hipMemsetAsync(scaled_tmp, 0, (size_t)K * kWidth * sizeof(float), s);
+        const float *am = scaled ? amax_g : nullptr;
+        if (x_point_major) launch_dw_split<8, true, true>(X, ldx, K, G, ldg, R, out, osk, osn, nvalid, db, bias_period, cus, s, am);
+        else if (K <= 64) launch_dw_split<2, false, true>(X, ldx, K, G, ldg, R, out, osk, osn, nvalid, db, bias_period, cus, s, am);
+        else if (K <= 96) launch_dw_split<3, false, true>(X, ldx, K, G, ldg, R, out, osk, osn, nvalid, db, bias_period, cus, s, am);
+        else launch_dw_split<8, false, true>(X, ldx, K, G, ldg, R, out, osk, osn, nvalid, db, bias_period, cus, s, am);
+        if (scaled) hipLaunchKernelGGL(dw_unscale_add_kernel, dim3((K * kWidth + 255) / 256), dim3(256), 0, s, scaled_tmp, K, nvalid, dW, sk, sn, amax_g);
+        return;
+    }
     if (split) {
         // with a range-scaled G the product lands in a dense [K, 256] scratch first and is added to dW divided by the scale
         const bool scaled = amax_g && scaled_tmp;
