@@ -5,7 +5,7 @@ O=$ROOT/gpurun_out/r5train
 mkdir -p $O
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
 cd /tmp
-for dt in f32 f16_split; do
+for dt in ${DTYPES:-f32 f16_split}; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$dt -o t -- python $ROOT/bench.py --workload train --dtype $dt --steps 8 --warmup 3 > $O/train_$dt.log 2>&1
   cp $(find $O/prof_$dt -name "*kernel_stats.csv" | head -1) $O/train_kernel_stats_$dt.csv
   rm -rf $O/prof_$dt
