@@ -31,6 +31,18 @@ constexpr int kLdPe = 64, kLdDir = 64, kLdNarrow = 4;      // row strides of the
 // multiple of 256, without the fused chains' speed.  Anything wider is refused loudly rather than computed wrongly.
 // NEDDF_TRAIN_SPLIT_FUSED=0: the split-fp16 policy's backward pass as one GEMM kernel per layer on row-major matrices (rounds 1-4)
 // instead of the fused input-gradient chains on point-major ones (round 5: mlp_backward_split_kernel)
+// NEDDF_TRAIN_WIDE_FUSED=1 (probe, fp32 policy): fields that train padded to 512 columns (hidden widths 257 .. 512) on 512-wide fused
+// chains (round 5: mlp_forward_kernel / mlp_backward_kernel over the width, 32-row tiles) instead of the per-layer route with every
+// product cut into 256 x 256 blocks (round 4).  Parity-green and MEASURED 2.3x SLOWER (NeDDF 8 + 4 layers, 265 k points, forward +
+// backward: 373 ms against 162 ms; 256 wide: 36 ms): a chain's twelve 512 x 512 matrices are 12 MB of packed weights (+ 12 MB of
+// transposes), three times the 4 MB L2 of an XCD, and every 32-row tile streams all of them -- where the blocked route streams ONE
+// L2-resident 256 x 256 block against all rows per launch.  The default for wide fields therefore stays the blocked route.
+bool wide_fused()
+{
+    static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_WIDE_FUSED"); return e && atoi(e) != 0; }();
+    return on;
+}
+
 bool split_fused()
 {
     static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_SPLIT_FUSED"); return !(e && atoi(e) == 0); }();
@@ -566,7 +578,8 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     const int act = f.d.activation;
     const int sp = f.d.weight_dtype == NEDDF_DTYPE_F16_SPLIT;      // GEMM operands as two fp16 terms (tile_engine.h)
     // packed weights of a whole layer stack: [layer][256 x 256] + the narrow first-layer / skip segments
-    if (int rc = ensure(ctx, ctx->tpack, (size_t)(kMaxLayers + 2) * kPackFloats * sizeof(float))) return rc;
+    const size_t packf = (size_t)p.WH * p.WH;       // one packed hidden x hidden matrix (kPackFloats at width 256)
+    if (int rc = ensure(ctx, ctx->tpack, (size_t)(kMaxLayers + 2) * packf * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->ttmp, ((size_t)p.R * (kLdPe + kLdNarrow) + (size_t)N * kLdDir) * sizeof(float))) return rc;
     float *wp = (float *)ctx->tpack.p;
     float *PEu = (float *)ctx->ttmp.p, *Ed = PEu + (size_t)p.R * kLdPe, *ZH = Ed + (size_t)N * kLdDir;
@@ -578,7 +591,7 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     static const bool unfused = [] { const char *e = getenv("NEDDF_TRAIN_UNFUSED"); return e && atoi(e) != 0; }();
     const int kpe = (p.Cpe + 3) & ~3;       // loaded width of the encoding matrix (pad columns are zero)
     float *pack_at = wp;
-    auto next_pack = [&]() { float *r = pack_at; pack_at += kPackFloats; return r; };
+    auto next_pack = [&]() { float *r = pack_at; pack_at += packf; return r; };
     // weight fragments of a fused stack: fp32 in one launch per stack (PackBatch), split fp16 matrix by matrix
     PackBatch pb;
     auto pack = [&](const float *src, int64_t sk, int64_t sn, int k_off, int n_off, int kcount, int ncount, int nout, float *dst) {
@@ -591,7 +604,8 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     // fp32 policy, both stacks fused: the hidden states are kept point-major (train_kernels.h MlpForwardArgs.point_major), the layout of
     // the fused backward (neddf_train_field_backward takes that route under the same condition)
     const int WH = p.WH, NBK = WH / kWidth;      // hidden width the kernels see, in 256-column blocks
-    const bool fused = !unfused && n_wide <= 1 && WH == kWidth;       // (the fused chains are 256 wide)
+    // the fused chains are 256 wide, and -- round 5, fp32 policy -- 512 wide for the fields that train padded to 512 (wide_fused)
+    const bool fused = !unfused && n_wide <= 1 && (WH == kWidth || (WH == 2 * kWidth && !sp && wide_fused()));
     // (round 5: the split-fp16 policy takes the same fused, point-major route; NEDDF_TRAIN_SPLIT_FUSED=0 keeps its per-layer backward
     // and the row-major matrices that reads -- the A/B partner)
     const int pm = (fused && (!sp || split_fused())) ? 1 : 0;
@@ -614,26 +628,27 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
         const float *w0[4] = { w.w[0], w.w[1], w.w[2], w.w[3] }, *b0[4] = { w.b[0], w.b[1], w.b[2], w.b[3] };
         for (int kb = 0; kb < NBK; ++kb) {
             for (int c = 0; c < w.nc; ++c) { w.w[c] = w0[c] + (size_t)kb * kWidth * w.wstride; w.b[c] = kb == 0 ? b0[c] : nullptr; }
-            launch_narrow_forward(X + kb * kWidth, WH, p.R, w, 4, Y, kLdNarrow, s, x_pm, kb > 0);
+            // (column block kb of a point-major matrix starts 4 x 256 kb floats into a point)
+            launch_narrow_forward(X + (x_pm ? 4 : 1) * kb * kWidth, WH, p.R, w, 4, Y, kLdNarrow, s, x_pm, kb > 0);
         }
     };
     if (fused) {
         MlpForwardArgs m{};
         m.R = p.R; m.X0 = PEs; m.ld0 = kLdPe; m.kload0 = kpe; m.ksteps0 = gemm_ksteps(p.Cpe, sp);
-        m.n_layers = p.n_trunk; m.skip_layer = -1; m.act_kind = act; m.point_major = pm;
+        m.n_layers = p.n_trunk; m.skip_layer = -1; m.act_kind = act; m.point_major = pm; m.width = WH;
         float *w0 = next_pack();
-        pack(W[0], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, w0);
+        pack(W[0], WH, 1, 0, 0, p.Cpe, WH, WH, w0);
         m.wp0 = w0;
         for (int l = 0; l < p.n_trunk; ++l) {
             const bool wide = l > 0 && in_skips(f.d, l - 1);
             m.bias[l] = B[l]; m.Z[l] = ws + p.o_z[l]; m.H[l] = ws + p.o_h[l];
             if (l == 0) continue;
             float *wl = next_pack();
-            pack(W[l], kWidth, 1, wide ? p.Cpe : 0, 0, kWidth, kWidth, kWidth, wl);
+            pack(W[l], WH, 1, wide ? p.Cpe : 0, 0, WH, WH, WH, wl);
             m.wp[l] = wl;
             if (wide) {         // hx = cat([embed_pos_scaled, hx]): the encoding feeds rows 0 .. Cpe-1 of the weight
                 float *wsk = next_pack();
-                pack(W[l], kWidth, 1, 0, 0, p.Cpe, kWidth, kWidth, wsk);
+                pack(W[l], WH, 1, 0, 0, p.Cpe, WH, WH, wsk);
                 m.skip_layer = l; m.wp_skip = wsk;
             }
         }
@@ -664,17 +679,17 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     if (fused) {
         MlpForwardArgs m{};
         m.R = p.R; m.X0 = ws + p.o_xa; m.ld0 = p.ldxa; m.kload0 = p.ldxa; m.ksteps0 = gemm_ksteps(p.Ca, sp);
-        m.X1 = Hlast; m.n_layers = p.n_col; m.skip_layer = -1; m.act_kind = act; m.point_major = pm;
+        m.X1 = Hlast; m.n_layers = p.n_col; m.skip_layer = -1; m.act_kind = act; m.point_major = pm; m.width = WH;
         pack_at = wp;           // same stream: the trunk kernel is done with the buffer when these packs run
         float *w0 = next_pack(), *w1 = next_pack();
-        pack(W[p.n_trunk], kWidth, 1, 0, 0, p.Ca, kWidth, kWidth, w0);
-        pack(W[p.n_trunk], kWidth, 1, p.Ca, 0, kWidth, kWidth, kWidth, w1);
+        pack(W[p.n_trunk], WH, 1, 0, 0, p.Ca, WH, WH, w0);
+        pack(W[p.n_trunk], WH, 1, p.Ca, 0, WH, WH, WH, w1);
         m.wp0 = w0; m.wp1 = w1;
         for (int l = 0; l < p.n_col; ++l) {
             m.bias[l] = B[p.n_trunk + l]; m.Z[l] = ws + p.o_zc[l]; m.H[l] = ws + p.o_hc[l];
             if (l == 0) continue;
             float *wl = next_pack();
-            pack(W[p.n_trunk + l], kWidth, 1, 0, 0, kWidth, kWidth, kWidth, wl);
+            pack(W[p.n_trunk + l], WH, 1, 0, 0, WH, WH, WH, wl);
             m.wp[l] = wl;
         }
         pb.flush(s);
@@ -724,16 +739,17 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     int n_wide = 0;
     for (int l = 1; l < p.n_trunk; ++l) n_wide += in_skips(f.d, l - 1) ? 1 : 0;
     const int WH = p.WH, NBK = WH / kWidth;
-    if ((!sp || split_fused()) && !unfused && n_wide <= 1 && WH == kWidth) {      // (= the forward's condition for point-major hidden states)
+    if ((!sp || split_fused()) && !unfused && n_wide <= 1 && (WH == kWidth || (WH == 2 * kWidth && !sp && wide_fused()))) {      // (= the forward's condition for point-major hidden states)
         const int nT = p.n_trunk, nC = p.n_col;
-        const size_t slot = (size_t)p.R * kWidth;
-        if (int rc = ensure(ctx, ctx->tpack, (size_t)(nT + nC + 1) * kPackFloats * sizeof(float))) return rc;
+        const size_t slot = (size_t)p.R * WH, packf = (size_t)WH * WH;
+        const int B4 = 4 * kWidth;      // a 256-column block of a point-major [R, WH] matrix starts B4 x (block index) floats into a point
+        if (int rc = ensure(ctx, ctx->tpack, (size_t)(nT + nC + 1) * packf * sizeof(float))) return rc;
         if (int rc = ensure(ctx, ctx->ttmp, ((size_t)(nT + nC + 1) * slot + (size_t)p.R * 2 * kLdNarrow) * sizeof(float))) return rc;
         float *tb = (float *)ctx->ttmp.p, *pack_at = (float *)ctx->tpack.p;
         auto dZc = [&](int l) { return tb + (size_t)l * slot; };
         auto dZt = [&](int l) { return tb + (size_t)(nC + l) * slot; };
         float *dFeat = tb + (size_t)(nC + nT) * slot, *GZH = dFeat + slot, *GCR = GZH + (size_t)p.R * kLdNarrow;
-        auto next_pack = [&]() { float *r = pack_at; pack_at += kPackFloats; return r; };
+        auto next_pack = [&]() { float *r = pack_at; pack_at += packf; return r; };
         const float *PEs = ws + p.o_pes;
         TrainPointArgs a;
         point_args(a, f, p, ws);
@@ -745,7 +761,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
             if (sp) launch_pack(1, src, sk, sn, k_off, n_off, kcount, ncount, nout, dst, s);
             else pbk.add(src, sk, sn, k_off, n_off, kcount, ncount, nout, dst, s);
         };
-        DwJobs dwj{};          // every weight-gradient product of this pass: one job-parallel launch at the end (launch_dw_jobs)
+        DwJobs dwj{};          // the weight-gradient products of this pass, job-parallel: one launch per kMaxDwJobs of them (launch_dw_jobs)
         dwj.R = p.R;
         // split fp16: every gradient matrix leaves max |dZ| in a device scalar (the chain kernel publishes it), its weight-gradient
         // products -- one launch each, after the chain that wrote the matrix -- scale their G operand by it
@@ -754,10 +770,32 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         float *mZc[kMaxLayers] = {}, *mZt[kMaxLayers] = {};
         for (int l = 0; l < nC; ++l) mZc[l] = am.take();
         for (int l = 0; l < nT; ++l) mZt[l] = am.take();
-        auto add_dw = [&](const float *X, int ldx, int K, int x_pm, const float *G, const float *amax_g, float *dW, int64_t sk, int64_t sn, int nvalid,
-                          float *db, int period) {
-            if (sp) launch_dw(1, X, ldx, K, G, kWidth, p.R, dW, sk, sn, nvalid, db, period, ctx->cus, s, amax_g, am.dw_tmp, x_pm, 1);
-            else dwj.add(X, ldx, K, x_pm, G, kWidth, dW, sk, sn, nvalid, db, period);
+        // one 256 x 256 (or K x 256) weight-gradient product: G is a 256-column block of a point-major gradient matrix
+        auto add_dw = [&](const float *X, int ldx, int K, int x_pm, const float *G, const float *amax_g, float *dW, int nvalid, float *db) {
+            if (sp) launch_dw(1, X, ldx, K, G, WH, p.R, dW, WH, 1, nvalid, db, 4, ctx->cus, s, amax_g, am.dw_tmp, x_pm, 1);
+            else {
+                if (dwj.n == kMaxDwJobs) { launch_dw_jobs(dwj, ctx->cus, s); dwj.n = 0; }        // (every G in the list has been produced: the jobs follow their chain)
+                dwj.add(X, ldx, K, x_pm, G, WH, dW, WH, 1, nvalid, db, 4);
+            }
+        };
+        // dW[row0 + k, n] += X^T G for a point-major hidden X [R, WH] / a narrow row-major X [R, ldx] (K columns), every 256 x 256 block
+        auto dw_hidden = [&](const float *X, const float *G, const float *amax_g, float *dWrow0, float *db) {
+            for (int nb = 0; nb < NBK; ++nb)
+                for (int kb = 0; kb < NBK; ++kb)
+                    add_dw(X + (size_t)B4 * kb, WH, kWidth, 1, G + (size_t)B4 * nb, amax_g, dWrow0 + (size_t)kb * kWidth * WH + nb * kWidth, kWidth,
+                           (kb == 0 && db) ? db + nb * kWidth : nullptr);
+        };
+        auto dw_narrow = [&](const float *X, int ldx, int K, const float *G, const float *amax_g, float *dWrow0, float *db) {
+            for (int nb = 0; nb < NBK; ++nb)
+                add_dw(X, ldx, K, 0, G + (size_t)B4 * nb, amax_g, dWrow0 + nb * kWidth, kWidth, db ? db + nb * kWidth : nullptr);
+        };
+        // heads' weight gradients: X point-major, one launch per 256-column block of it
+        auto heads_dw = [&](const float *X, const float *G, int nc, float *const *w, int wstride, float *const *b) {
+            for (int kb = 0; kb < NBK; ++kb) {
+                float *wk[4] = { nullptr, nullptr, nullptr, nullptr };
+                for (int c = 0; c < nc; ++c) wk[c] = w[c] + (size_t)kb * kWidth * wstride;
+                launch_narrow_dw(X + (size_t)B4 * kb, WH, G, kLdNarrow, p.R, nc, wk, wstride, kb == 0 ? b : nullptr, 4, kWidth, s, 1);
+            }
         };
         // colour head: LinearGradFunction.backward (linear.py:62-88) on [HC | JC] rows, then the last colour activation
         NarrowW cout{};
@@ -766,38 +804,37 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         const float *HClast = ws + p.o_hc[nC - 1], *Hlast = ws + p.o_h[nT - 1];
         {
             float *wc[3] = { gW[p.i_cout], gW[p.i_cout] + 1, gW[p.i_cout] + 2 }, *bc[3] = { gB[p.i_cout], gB[p.i_cout] + 1, gB[p.i_cout] + 2 };
-            launch_narrow_dw(HClast, kWidth, GCR, kLdNarrow, p.R, 3, wc, 3, bc, 4, kWidth, s, 1);
+            heads_dw(HClast, GCR, 3, wc, 3, bc);
         }
         {   // colour trunk: dZ of every layer in one kernel
             MlpBackwardArgs m{};
-            m.R = p.R; m.n_layers = nC; m.act_kind = act;
+            m.R = p.R; m.n_layers = nC; m.act_kind = act; m.width = WH;
             // prologue: dZ of the last colour layer = activation backward of the head's upstream gradient (3 raw colour columns)
             m.top_G = GCR; m.top_ldg = kLdNarrow; m.top_nc = 3; m.top_wstride = 3;
             for (int c = 0; c < 3; ++c) m.top_w[c] = cout.w[c];
             m.top_Z = ws + p.o_zc[nC - 1]; m.top_out = dZc(nC - 1); m.amax_top = mZc[nC - 1];
             for (int l = 1; l < nC; ++l) {
                 float *wl = next_pack();
-                pack_t(W[nT + l], 1, kWidth, 0, 0, kWidth, kWidth, kWidth, wl);             // W_l^T
+                pack_t(W[nT + l], 1, WH, 0, 0, WH, WH, WH, wl);             // W_l^T
                 m.wT[l] = wl; m.Z[l - 1] = ws + p.o_zc[l - 1]; m.dZ[l - 1] = dZc(l - 1); m.amax_dZ[l - 1] = mZc[l - 1];
             }
             pbk.flush(s);
             launch_mlp_backward(sp, m, ctx->cus, s);
         }
-        for (int l = nC - 1; l >= 1; --l)
-            add_dw(ws + p.o_hc[l - 1], kWidth, kWidth, 1, dZc(l), mZc[l], gW[nT + l], kWidth, 1, kWidth, gB[nT + l], 4);
-        add_dw(ws + p.o_xa, p.ldxa, p.Ca, 0, dZc(0), mZc[0], gW[nT], kWidth, 1, kWidth, gB[nT], 4);
-        add_dw(Hlast, kWidth, kWidth, 1, dZc(0), mZc[0], gW[nT] + (size_t)p.Ca * kWidth, kWidth, 1, kWidth, nullptr, 4);
+        for (int l = nC - 1; l >= 1; --l) dw_hidden(ws + p.o_hc[l - 1], dZc(l), mZc[l], gW[nT + l], gB[nT + l]);
+        dw_narrow(ws + p.o_xa, p.ldxa, p.Ca, dZc(0), mZc[0], gW[nT], gB[nT]);
+        dw_hidden(Hlast, dZc(0), mZc[0], gW[nT] + (size_t)p.Ca * WH, nullptr);
         {
             float *wh[2] = { gW[p.i_ddf], gW[p.i_aux] }, *bh[2] = { gB[p.i_ddf], gB[p.i_aux] };
-            launch_narrow_dw(Hlast, kWidth, GZH, kLdNarrow, p.R, 2, wh, 1, bh, 4, kWidth, s, 1);
+            heads_dw(Hlast, GZH, 2, wh, 1, bh);
         }
         {   // distance trunk
             MlpBackwardArgs m{};
-            m.R = p.R; m.n_layers = nT; m.act_kind = act;
+            m.R = p.R; m.n_layers = nT; m.act_kind = act; m.width = WH;
             // prologue: dZ of the last trunk layer = activation backward of (gradient of the features from the colour trunk -- only the
             // feature segment of its first layer propagates: the small colour inputs carry no parameters -- + the distance / aux heads)
             float *wf = next_pack();
-            pack_t(W[nT], 1, kWidth, 0, p.Ca, kWidth, kWidth, kWidth, wf);                  // (feature rows of W_c0)^T
+            pack_t(W[nT], 1, WH, 0, p.Ca, WH, WH, WH, wf);                  // (feature rows of W_c0)^T
             m.top_src = dZc(0); m.top_wT = wf;
             m.top_G = GZH; m.top_ldg = kLdNarrow; m.top_nc = 2; m.top_wstride = 1;
             m.top_w[0] = W[p.i_ddf]; m.top_w[1] = W[p.i_aux];
@@ -805,7 +842,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
             for (int l = 1; l < nT; ++l) {
                 const bool wide = in_skips(f.d, l - 1);
                 float *wl = next_pack();
-                pack_t(W[l], 1, kWidth, 0, wide ? p.Cpe : 0, kWidth, kWidth, kWidth, wl);   // (hidden rows of W_l)^T
+                pack_t(W[l], 1, WH, 0, wide ? p.Cpe : 0, WH, WH, WH, wl);   // (hidden rows of W_l)^T
                 m.wT[l] = wl; m.Z[l - 1] = ws + p.o_z[l - 1]; m.dZ[l - 1] = dZt(l - 1); m.amax_dZ[l - 1] = mZt[l - 1];
             }
             pbk.flush(s);
@@ -813,10 +850,8 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         }
         for (int l = nT - 1; l >= 0; --l) {
             const bool wide = l > 0 && in_skips(f.d, l - 1);
-            if (l == 0 || wide) add_dw(PEs, kLdPe, p.Cpe, 0, dZt(l), mZt[l], gW[l], kWidth, 1, kWidth, gB[l], 4);
-            if (l > 0)
-                add_dw(ws + p.o_h[l - 1], kWidth, kWidth, 1, dZt(l), mZt[l], gW[l] + (size_t)(wide ? p.Cpe : 0) * kWidth, kWidth, 1, kWidth,
-                       wide ? nullptr : gB[l], 4);
+            if (l == 0 || wide) dw_narrow(PEs, kLdPe, p.Cpe, dZt(l), mZt[l], gW[l], gB[l]);
+            if (l > 0) dw_hidden(ws + p.o_h[l - 1], dZt(l), mZt[l], gW[l] + (size_t)(wide ? p.Cpe : 0) * WH, wide ? nullptr : gB[l]);
         }
         if (dwj.overflow) return fail(ctx, NEDDF_EUNSUPPORTED, "more weight-gradient products than DwJobs holds (train_kernels.h kMaxDwJobs)");
         if (!sp) launch_dw_jobs(dwj, ctx->cus, s);

@@ -85,6 +85,7 @@ struct MlpForwardArgs {
     // forward's 13 ms per training step (profiles/r03_train_ablation.txt).  The NeDDF fp32 training route uses it end to end
     // (forward, backward chain, weight gradients, heads); every other route keeps row-major matrices.
     int point_major;
+    int width;                            // 0 / 256: the [R, 256] matrices above; 512 (round 5, fp32 + point_major only): [R, 512] matrices, 512 x 512 packed weights
 };
 void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t s);
 
@@ -117,6 +118,7 @@ struct MlpBackwardArgs {
     // weight-gradient products that follow (launch_dw's amax_g); NULL slots are skipped
     float *amax_dZ[kMaxLayers];           // for dZ[l]
     float *amax_top;                      // for top_out
+    int width;                            // 0 / 256, or 512 (round 5, fp32 only): every [R, 256] above is [R, 512], every packed matrix 512 x 512
 };
 void launch_mlp_backward(int split, const MlpBackwardArgs &a, int cus, hipStream_t s);
 

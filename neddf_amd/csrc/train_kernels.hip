@@ -323,13 +323,13 @@ template <int KIND, bool FULL, bool LAST, int MT, int NT, class Ops, bool PM>
 __device__ __forceinline__ void mlp_epilogue(const f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *Zl, float *Hl, int64_t r0,
                                              int64_t R, int wave, int lane)
 {
-    constexpr int LD = Ops::kLd;
+    constexpr int LD = Ops::kLd, W = Ops::kWid;         // W: columns of the [R, W] matrices (the engine width: 256, or 512 for wide fields)
     constexpr float unscale = 1.0f / Ops::kWScale;
     const int j = lane & 31, h = lane >> 5;
     // one 64-bit base per lane; everything else is a compile-time offset from it
-    const int64_t base = (r0 + 4 * h) * kWidth + wave * NT * 32 + j;
+    const int64_t base = (r0 + 4 * h) * W + wave * NT * 32 + j;
     float *zb = Zl + base, *hb = Hl + base;
-    const int64_t pbase = ((r0 >> 2) + h) * (4 * kWidth) + (wave * NT * 32 + j) * 4;      // point r0 / 4 + h, this lane's first column
+    const int64_t pbase = ((r0 >> 2) + h) * (4 * W) + (wave * NT * 32 + j) * 4;      // point r0 / 4 + h, this lane's first column
     float *zpm = Zl + pbase, *hpm = Hl + pbase;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -345,17 +345,17 @@ __device__ __forceinline__ void mlp_epilogue(const f32x16 (&acc)[MT][NT], typena
                 if (DW_ABL(64)) { y = z[0]; dy = 1.f; } else
                 act_grad<KIND>(z[0], y, dy);
                 const float hv[4] = { y, dy * z[1], dy * z[2], dy * z[3] };
-                const int off = (mt * 32 + 8 * g) * kWidth + t * 32;
+                const int off = (mt * 32 + 8 * g) * W + t * 32;
                 if (FULL || r0 + mt * 32 + 8 * g + 4 * h < R) {     // R is a multiple of 4: a point's rows are all inside or all outside
                     if constexpr (PM) {
-                        const int poff = (mt * 8 + 2 * g) * (4 * kWidth) + t * 128;
+                        const int poff = (mt * 8 + 2 * g) * (4 * W) + t * 128;
                         if (!DW_ABL(16)) __builtin_nontemporal_store(f32x4v{ z[0], z[1], z[2], z[3] }, (f32x4v *)(zpm + poff));
                         if (!DW_ABL(32)) __builtin_nontemporal_store(f32x4v{ hv[0], hv[1], hv[2], hv[3] }, (f32x4v *)(hpm + poff));
                     } else
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (!DW_ABL(16)) zb[off + r * kWidth] = z[r];
-                        if (!DW_ABL(32)) hb[off + r * kWidth] = hv[r];
+                        if (!DW_ABL(16)) zb[off + r * W] = z[r];
+                        if (!DW_ABL(32)) hb[off + r * W] = hv[r];
                     }
                 }
                 if (!LAST && !DW_ABL(128)) {
@@ -373,7 +373,9 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
 {
     typedef typename Ops::act_t act_t;
     typedef typename Ops::bfrag frag;
-    constexpr int MT = 2, NT = 2, ROWS = MT * 32, LD = Ops::kLd;
+    // 256 columns: 64-row tiles, two column tiles per wave; 512 (round 5: wide fields, fp32): 32-row tiles, four column tiles per wave --
+    // the same accumulator file and the same 66 KB LDS tile, two workgroups per CU either way (the rendering engine's rule, geo_w)
+    constexpr int W = Ops::kWid, MT = W <= 256 ? 2 : 1, NT = W / 128, ROWS = MT * 32, LD = Ops::kLd;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     act_t *act = (act_t *)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -394,11 +396,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
             Ops::zero(act + r * LD + 4 * c4cols + c);
         }
     };
-    auto stage_pm = [&](const float *X, int64_t r0) {        // 64 rows of a point-major [R, 256] matrix -> the row-major LDS tile
-        for (int idx = tid; idx < (ROWS / 4) * kWidth; idx += kThreads) {
-            const int p = idx >> 8, c = idx & 255;
+    auto stage_pm = [&](const float *X, int64_t r0) {        // the tile's rows of a point-major [R, W] matrix -> the row-major LDS tile
+        for (int idx = tid; idx < (ROWS / 4) * W; idx += kThreads) {
+            const int p = idx / W, c = idx - p * W;
             f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-            if (r0 + 4 * p < a.R) v = *(const f32x4v *)(X + ((r0 >> 2) + p) * (4 * kWidth) + 4 * c);
+            if (r0 + 4 * p < a.R) v = *(const f32x4v *)(X + ((r0 >> 2) + p) * (4 * W) + 4 * c);
 #pragma unroll
             for (int q = 0; q < 4; ++q) Ops::put(act + (4 * p + q) * LD + c, v[q]);
         }
@@ -430,9 +432,9 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
         dense<MT, NT, Ops>(acc, act_lane, frags(a.wp0, a.ksteps0), a.ksteps0);
         if (a.X1) {
             __syncthreads();
-            if constexpr (PM) stage_pm(a.X1, r0); else stage(a.X1, kWidth, kWidth / 4, kWidth, r0);
+            if constexpr (PM) stage_pm(a.X1, r0); else stage(a.X1, W, W / 4, W, r0);
             __syncthreads();
-            dense<MT, NT, Ops>(acc, act_lane, frags(a.wp1, kWidth / Ops::kStep), kWidth / Ops::kStep);
+            dense<MT, NT, Ops>(acc, act_lane, frags(a.wp1, W / Ops::kStep), W / Ops::kStep);
         }
         for (int l = 0; l < a.n_layers; ++l) {
             if (l > 0) {
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
                     }
                 }
                 if (!DW_ABL(4096))
-                dense<MT, NT, Ops>(acc, act_lane, frags(a.wp[l], kWidth / Ops::kStep), kWidth / Ops::kStep);
+                dense<MT, NT, Ops>(acc, act_lane, frags(a.wp[l], W / Ops::kStep), W / Ops::kStep);
                 if constexpr (!HOLD) {
                     if (l == a.skip_layer) {
                         __syncthreads();            // every wave finished reading the hidden state
@@ -490,10 +492,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
 template <class Ops, bool HOLD, bool PM>
 static void launch_mlp_forward_ops(const MlpForwardArgs &a, int cus, hipStream_t s)
 {
-    constexpr size_t lds = (size_t)64 * Ops::kLd * sizeof(typename Ops::act_t);
+    constexpr int ROWS = Ops::kWid <= 256 ? 64 : 32;
+    constexpr size_t lds = (size_t)ROWS * Ops::kLd * sizeof(typename Ops::act_t);
     static bool once = ((void)hipFuncSetAttribute((const void *)mlp_forward_kernel<Ops, HOLD, PM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
-    const int64_t tiles = (a.R + 63) / 64;
+    const int64_t tiles = (a.R + ROWS - 1) / ROWS;
     hipLaunchKernelGGL((mlp_forward_kernel<Ops, HOLD, PM>), dim3((unsigned)(tiles < 2 * cus ? tiles : 2 * cus)), dim3(kThreads), lds, s, a);
 }
 
@@ -501,6 +504,10 @@ void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t
 {
     if (a.R <= 0) return;
     ablate_init();
+    if (a.width == 512) {       // round 5: wide fields (fp32, point-major) on the fused chain too
+        launch_mlp_forward_ops<OpsF32T<512>, true, true>(a, cus, s);
+        return;
+    }
     if (split && a.point_major) launch_mlp_forward_ops<OpsF16Split, false, true>(a, cus, s);      // (round 5: the split policy's fused NeDDF route)
     else if (split) launch_mlp_forward_ops<OpsF16Split, false, false>(a, cus, s);      // (the per-layer backward reads row-major matrices)
     else if (a.point_major) launch_mlp_forward_ops<OpsF32, true, true>(a, cus, s);
@@ -510,13 +517,13 @@ void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t
 // ----------------------------------------------------------------------------
 // Fused input-gradient chain of a layer stack (train_kernels.h MlpBackwardArgs): see the header.  64-row tiles, two workgroups
 // per CU, fp32 MFMA.
-template <int KIND>
-__device__ __forceinline__ void mlp_backward_epilogue(const f32x16 (&acc)[2][2], const f32x16 (&zp)[2][2], float *act, float *dZl, int64_t r0,
+template <int KIND, int W = kWidth, int MT = 2, int NT = 2>
+__device__ __forceinline__ void mlp_backward_epilogue(const f32x16 (&acc)[MT][NT], const f32x16 (&zp)[MT][NT], float *act, float *dZl, int64_t r0,
                                                       int64_t R, int wave, int lane)
 {
-    constexpr int MT = 2, NT = 2, LD = OpsF32::kLd;
+    constexpr int LD = OpsF32T<W>::kLd;
     const int j = lane & 31, h = lane >> 5;
-    float *gb = dZl + ((r0 >> 2) + h) * (4 * kWidth) + (wave * NT * 32 + j) * 4;      // point-major: point r0 / 4 + h, this lane's first column
+    float *gb = dZl + ((r0 >> 2) + h) * (4 * W) + (wave * NT * 32 + j) * 4;      // point-major: point r0 / 4 + h, this lane's first column
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -534,19 +541,20 @@ __device__ __forceinline__ void mlp_backward_epilogue(const f32x16 (&acc)[2][2],
                 sj += g3 * zp[mt][t][4 * g + 3];
                 const float ov[4] = { g0 * dy + sj * d2, g1 * dy, g2 * dy, g3 * dy };
                 if (r0 + mt * 32 + 8 * g + 4 * h < R && !DW_ABL(256))
-                    __builtin_nontemporal_store(f32x4v{ ov[0], ov[1], ov[2], ov[3] }, (f32x4v *)(gb + (mt * 8 + 2 * g) * (4 * kWidth) + t * 128));
+                    __builtin_nontemporal_store(f32x4v{ ov[0], ov[1], ov[2], ov[3] }, (f32x4v *)(gb + (mt * 8 + 2 * g) * (4 * W) + t * 128));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (!DW_ABL(2048)) o[(8 * g + r) * LD] = ov[r];
             }
         }
 }
 
-template <int KIND>      // backward kind of the stack's activation: one straight-line epilogue per kernel, not four behind run-time branches
+// W = 512 (round 5): the [R, 512] matrices of a wide field on 32-row tiles, four column tiles per wave (see mlp_forward_kernel)
+template <int KIND, int W = kWidth>      // backward kind of the stack's activation: one straight-line epilogue per kernel, not four behind run-time branches
 __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBackwardArgs a)
 {
-    typedef OpsF32 Ops;
+    typedef OpsF32T<W> Ops;
     typedef typename Ops::bfrag frag;
-    constexpr int MT = 2, NT = 2, ROWS = MT * 32, LD = Ops::kLd, KS = kWidth / Ops::kStep;
+    constexpr int MT = W <= 256 ? 2 : 1, NT = W / 128, ROWS = MT * 32, LD = Ops::kLd, KS = W / Ops::kStep;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *act = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -556,18 +564,18 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * ROWS;
         __syncthreads();                // the previous tile is done with the LDS tile
-        auto stage = [&](const float *src) {            // 64 rows of a point-major matrix -> the row-major LDS tile
-            for (int idx = tid; idx < (ROWS / 4) * kWidth; idx += kThreads) {
-                const int p = idx >> 8, c = idx & 255;
+        auto stage = [&](const float *src) {            // the tile's rows of a point-major matrix -> the row-major LDS tile
+            for (int idx = tid; idx < (ROWS / 4) * W; idx += kThreads) {
+                const int p = idx / W, c = idx - p * W;
                 f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-                if (r0 + 4 * p < a.R) v = *(const f32x4v *)(src + ((r0 >> 2) + p) * (4 * kWidth) + 4 * c);
+                if (r0 + 4 * p < a.R) v = *(const f32x4v *)(src + ((r0 >> 2) + p) * (4 * W) + 4 * c);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) act[(4 * p + q) * LD + c] = v[q];
             }
         };
         // Z of this lane's accumulator positions: the four rows of a point for one feature = one 16-byte load in the point-major layout
         auto load_z = [&](const float *Z, f32x16 (&zp)[MT][NT]) {
-            const float *zb = Z + ((r0 >> 2) + h) * (4 * kWidth) + (wave * NT * 32 + j) * 4;
+            const float *zb = Z + ((r0 >> 2) + h) * (4 * W) + (wave * NT * 32 + j) * 4;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-                        if (r0 + mt * 32 + 8 * g + 4 * h < a.R && !DW_ABL(512)) v = __builtin_nontemporal_load((const f32x4v *)(zb + (mt * 8 + 2 * g) * (4 * kWidth) + t * 128));
+                        if (r0 + mt * 32 + 8 * g + 4 * h < a.R && !DW_ABL(512)) v = __builtin_nontemporal_load((const f32x4v *)(zb + (mt * 8 + 2 * g) * (4 * W) + t * 128));
 #pragma unroll
                         for (int r = 0; r < 4; ++r) zp[mt][t][4 * g + r] = v[r];
                     }
@@ -617,7 +625,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
 #pragma unroll
                             for (int c = 0; c < 3; ++c) acc[mt][t][4 * g + r] = fmaf(gv[c], hw[c][t], acc[mt][t][4 * g + r]);
                     }
-            mlp_backward_epilogue<KIND>(acc, zp, act, a.top_out, r0, a.R, wave, lane);
+            mlp_backward_epilogue<KIND, W, MT, NT>(acc, zp, act, a.top_out, r0, a.R, wave, lane);
             __syncthreads();
         }
         for (int l = a.n_layers - 1; l >= 1; --l) {
@@ -630,7 +638,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
             if (!DW_ABL(4096))
             dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
             __syncthreads();            // every wave finished reading dZ_l
-            mlp_backward_epilogue<KIND>(acc, zp, act, a.dZ[l - 1], r0, a.R, wave, lane);
+            mlp_backward_epilogue<KIND, W, MT, NT>(acc, zp, act, a.dZ[l - 1], r0, a.R, wave, lane);
             if (l > 1) __syncthreads(); // the next layer reads what this epilogue wrote
         }
     }
@@ -846,6 +854,21 @@ void launch_mlp_backward(int split, const MlpBackwardArgs &a, int cus, hipStream
         else hipLaunchKernelGGL(mlp_backward_split_kernel<3>, grid, dim3(kThreads), lds, s, a);
         return;
     }
+    if (a.width == 512) {       // wide fields (round 5): 32-row tiles of [R, 512] matrices
+        constexpr size_t lds5 = (size_t)32 * OpsF32T<512>::kLd * sizeof(float);
+        static bool once5 = ((void)hipFuncSetAttribute((const void *)mlp_backward_kernel<0, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5),
+                             (void)hipFuncSetAttribute((const void *)mlp_backward_kernel<1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5),
+                             (void)hipFuncSetAttribute((const void *)mlp_backward_kernel<2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5),
+                             (void)hipFuncSetAttribute((const void *)mlp_backward_kernel<3, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5), true);
+        (void)once5;
+        const int64_t tiles5 = (a.R + 31) / 32;
+        const dim3 grid5((unsigned)(tiles5 < 2 * cus ? tiles5 : 2 * cus));
+        if (a.act_kind == 0) hipLaunchKernelGGL((mlp_backward_kernel<0, 512>), grid5, dim3(kThreads), lds5, s, a);
+        else if (a.act_kind == 1) hipLaunchKernelGGL((mlp_backward_kernel<1, 512>), grid5, dim3(kThreads), lds5, s, a);
+        else if (a.act_kind == 2) hipLaunchKernelGGL((mlp_backward_kernel<2, 512>), grid5, dim3(kThreads), lds5, s, a);
+        else hipLaunchKernelGGL((mlp_backward_kernel<3, 512>), grid5, dim3(kThreads), lds5, s, a);
+        return;
+    }
     constexpr size_t lds = (size_t)64 * OpsF32::kLd * sizeof(float);
     static bool once = ((void)hipFuncSetAttribute((const void *)mlp_backward_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                         (void)hipFuncSetAttribute((const void *)mlp_backward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
@@ -907,14 +930,16 @@ __device__ __forceinline__ void dw_tile_rows(const float *X, int ldx, int K, con
     // (point-major: piece i = point i of the chunk, column tid; the chunk's first element is at c0 * 256 either way)
     int xoff[XPF], goff[GPF];
 #pragma unroll
+    // (point-major operands: ldx / ldg = the columns of the WHOLE matrix -- 256, or 512 for a wide field, whose 256-column block the
+    // caller selects through the base pointer --, so a point is 4 ld floats in memory; in LDS a chunk keeps PS floats per point)
     for (int i = 0; i < XPF; ++i) {
         const int idx = tid + i * kThreads, r = idx / (KP / 4), c = idx - r * (KP / 4);
-        xoff[i] = XPM ? i * PS + 4 * tid : ((r < RC && c < k4) ? r * ldx + 4 * c : -1);
+        xoff[i] = XPM ? i * 4 * ldx + 4 * tid : ((r < RC && c < k4) ? r * ldx + 4 * c : -1);
     }
 #pragma unroll
     for (int i = 0; i < GPF; ++i) {
         const int idx = tid + i * kThreads;
-        goff[i] = GPM ? i * PS + 4 * tid : (idx >> 6) * ldg + 4 * (idx & 63);
+        goff[i] = GPM ? i * 4 * ldg + 4 * tid : (idx >> 6) * ldg + 4 * (idx & 63);
     }
     auto xrow = [&](int i) { return XPM ? 4 * i : (tid + i * kThreads) / (KP / 4); };       // first chunk row of piece i
     auto grow = [&](int i) { return GPM ? 4 * i : (tid + i * kThreads) >> 6; };
@@ -1135,7 +1160,7 @@ __global__ __launch_bounds__(kThreads) void narrow_dw_kernel(const float *X, int
         float gn;
         auto fetch = [&](int64_t r0) {
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) xn[pt] = r0 + 4 * pt < re ? *(const f32x4v *)(X + ((r0 >> 2) + pt) * (4 * kWidth) + 4 * k) : zero;
+            for (int pt = 0; pt < 4; ++pt) xn[pt] = r0 + 4 * pt < re ? *(const f32x4v *)(X + ((r0 >> 2) + pt) * (4 * (int64_t)ldx) + 4 * k) : zero;
             const int64_t gi = r0 * 4 + (k & 63);
             gn = gi < re * 4 ? G[gi] : 0.f;
         };
@@ -1162,7 +1187,7 @@ __global__ __launch_bounds__(kThreads) void narrow_dw_kernel(const float *X, int
     for (int64_t r0 = rb; r0 < re; r0 += 4) {
         float x[4];
         if (PM) {
-            const f32x4v v = *(const f32x4v *)(X + (r0 >> 2) * (4 * kWidth) + 4 * k);      // R is a multiple of 4: the point is whole
+            const f32x4v v = *(const f32x4v *)(X + (r0 >> 2) * (4 * (int64_t)ldx) + 4 * k);      // R is a multiple of 4: the point is whole
 #pragma unroll
             for (int u = 0; u < 4; ++u) x[u] = v[u];
         } else {
@@ -1944,7 +1969,7 @@ __global__ __launch_bounds__(256) void narrow_forward_kernel(const float *X, int
     auto fetch = [&](int64_t base, f32x4v (&x)[4]) {        // PM: x[q] = the four rows of feature 4 lane + q; else x[u] = four features of row u
         if (PM) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = base < R ? *(const f32x4v *)(X + (base >> 2) * (4 * kWidth) + 4 * (4 * lane + q)) : zero;
+            for (int q = 0; q < 4; ++q) x[q] = base < R ? *(const f32x4v *)(X + (base >> 2) * (4 * (int64_t)ldx) + 4 * (4 * lane + q)) : zero;
         } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u) x[u] = base + u < R ? *(const f32x4v *)(X + (base + u) * ldx + 4 * lane) : zero;
