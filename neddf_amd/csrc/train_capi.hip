@@ -43,6 +43,13 @@ bool wide_fused()
     return on;
 }
 
+// NEDDF_TRAIN_SPLIT_DW_JOBS=0: the split-fp16 fused route's weight gradients as one launch per product (A/B partner of the job-parallel launch)
+bool split_dw_jobs()
+{
+    static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_SPLIT_DW_JOBS"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 bool split_fused()
 {
     static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_SPLIT_FUSED"); return !(e && atoi(e) == 0); }();
@@ -112,7 +119,7 @@ int amax_begin(neddf_ctx *ctx, int split, AmaxSlots &m, hipStream_t s)
 {
     m = AmaxSlots{};
     if (!split) return 0;
-    if (int rc = ensure(ctx, ctx->tamax, (kAmaxSlots + kPackFloats) * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->tamax, (kAmaxSlots + (size_t)kMaxDwJobs * kPackFloats) * sizeof(float))) return rc;      // (dw_tmp: one [256, 256] scratch per job of a list)
     HIPCHK(hipMemsetAsync(ctx->tamax.p, 0, kAmaxSlots * sizeof(float), s));
     m.base = (float *)ctx->tamax.p;
     m.dw_tmp = m.base + kAmaxSlots;
@@ -770,13 +777,16 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         float *mZc[kMaxLayers] = {}, *mZt[kMaxLayers] = {};
         for (int l = 0; l < nC; ++l) mZc[l] = am.take();
         for (int l = 0; l < nT; ++l) mZt[l] = am.take();
+        auto flush_dw = [&]() {
+            if (sp) launch_dw_split_jobs(dwj, am.dw_tmp, ctx->cus, s);
+            else launch_dw_jobs(dwj, ctx->cus, s);
+        };
         // one 256 x 256 (or K x 256) weight-gradient product: G is a 256-column block of a point-major gradient matrix
         auto add_dw = [&](const float *X, int ldx, int K, int x_pm, const float *G, const float *amax_g, float *dW, int nvalid, float *db) {
-            if (sp) launch_dw(1, X, ldx, K, G, WH, p.R, dW, WH, 1, nvalid, db, 4, ctx->cus, s, amax_g, am.dw_tmp, x_pm, 1);
-            else {
-                if (dwj.n == kMaxDwJobs) { launch_dw_jobs(dwj, ctx->cus, s); dwj.n = 0; }        // (every G in the list has been produced: the jobs follow their chain)
-                dwj.add(X, ldx, K, x_pm, G, WH, dW, WH, 1, nvalid, db, 4);
-            }
+            if (sp && !split_dw_jobs()) { launch_dw(1, X, ldx, K, G, WH, p.R, dW, WH, 1, nvalid, db, 4, ctx->cus, s, amax_g, am.dw_tmp, x_pm, 1); return; }
+            if (dwj.n == kMaxDwJobs) { flush_dw(); dwj.n = 0; }        // (every G in the list has been produced: the jobs follow their chain)
+            dwj.add(X, ldx, K, x_pm, G, WH, dW, WH, 1, nvalid, db, 4);
+            dwj.job[dwj.n - 1].amax_g = amax_g;
         };
         // dW[row0 + k, n] += X^T G for a point-major hidden X [R, WH] / a narrow row-major X [R, ldx] (K columns), every 256 x 256 block
         auto dw_hidden = [&](const float *X, const float *G, const float *amax_g, float *dWrow0, float *db) {
@@ -854,7 +864,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
             if (l > 0) dw_hidden(ws + p.o_h[l - 1], dZt(l), mZt[l], gW[l] + (size_t)(wide ? p.Cpe : 0) * WH, wide ? nullptr : gB[l]);
         }
         if (dwj.overflow) return fail(ctx, NEDDF_EUNSUPPORTED, "more weight-gradient products than DwJobs holds (train_kernels.h kMaxDwJobs)");
-        if (!sp) launch_dw_jobs(dwj, ctx->cus, s);
+        flush_dw();
         HIPCHK(hipGetLastError());
         return 0;
     }

@@ -137,6 +137,10 @@ struct DwJob {
     float *db; int bias_period;           // db[n] += sum over rows r % bias_period == 0 of G[r, n] (or NULL)
     int x_point_major;                    // X is a point-major [R, 256] matrix (MlpForwardArgs.point_major); G always is, R % 4 == 0
     int wg0;                              // first workgroup of the product (set by launch_dw_jobs)
+    // split-fp16 policy (launch_dw_split_jobs): max |G| of the gradient matrix (device scalar, or NULL) and a zeroed [256, 256] scratch
+    // the range-scaled product lands in before it is added to dW divided by the scale
+    const float *amax_g;
+    float *tmp;
 };
 constexpr int kMaxDwJobs = 32;
 // the fused NeDDF backward registers one job per trunk layer (distance + colour trunks: <= 2 * kMaxLayers), the wide halves of
@@ -150,11 +154,14 @@ struct DwJobs {
     void add(const float *X, int ldx, int K, int x_point_major, const float *G, int ldg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
              int bias_period)
     {
-        if (n < kMaxDwJobs) job[n++] = DwJob{ X, ldx, K, G, ldg, dW, sk, sn, nvalid, db, bias_period, x_point_major, 0 };
+        if (n < kMaxDwJobs) job[n++] = DwJob{ X, ldx, K, G, ldg, dW, sk, sn, nvalid, db, bias_period, x_point_major, 0, nullptr, nullptr };
         else overflow = true;
     }
 };
 void launch_dw_jobs(DwJobs &jobs, int cus, hipStream_t s);
+// the same list under the split-fp16 policy (round 5): three fp16 MFMAs per multiply-add on operands of two fp16 terms, G range-scaled by
+// its job's amax_g; `tmp` = jobs.n x [256, 256] floats of scratch (zeroed here), one unscale-and-add pass over all jobs at the end
+void launch_dw_split_jobs(DwJobs &jobs, float *tmp, int cus, hipStream_t s);
 void launch_dw(int split, const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
                int bias_period, int cus, hipStream_t s, const float *amax_g = nullptr, float *scaled_tmp = nullptr, int x_point_major = 0,
                int g_point_major = 0);        // (point-major operands: split policy only, 256 columns, R % 4 == 0)

@@ -1235,10 +1235,11 @@ void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t 
 // during the MFMAs, whole K x 256 output in accumulators as in dw_tile_kernel.
 // XPM / GPM: the operand is a POINT-MAJOR [R, 256] matrix (train_kernels.h MlpForwardArgs.point_major): column tid of the four rows of
 // a point is one 16-byte load (R % 4 == 0, chunks start at multiples of 32)
-template <int KT, bool XPM = false, bool GPM = false>
-__global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, int ldx, int K, const float *G, int ldg, int64_t R,
-                                                               int64_t rows_per_wg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
-                                                               int bias_period, const float *amax_g)
+// (KTN <= KT: the LDS layout and the accumulator file are those of KT k-tiles, KTN of them carry data and are multiplied -- so that the
+// job-parallel kernel below serves products of different K from one allocation, like dw_tile_rows)
+template <int KT, bool XPM = false, bool GPM = false, int KTN = KT>
+__device__ __forceinline__ void dw_split_rows(const float *X, int ldx, int K, const float *G, int ldg, int64_t rb, int64_t re,
+                                              float *dW, int64_t sk, int64_t sn, int nvalid, float *db, int bias_period, const float *amax_g)
 {
     static_assert(!XPM || KT == 8, "a point-major X has 256 columns");
     constexpr int RC = 32, LDT = RC + 8;            // halves per transposed column: 80 B, 16-byte aligned row octets
@@ -1250,8 +1251,6 @@ __global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, i
     _Float16 *Xh = (_Float16 *)smem, *Xm = Xh + KP * LDT, *Gh = Xm + KP * LDT, *Gm = Gh + kWidth * LDT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int n0 = wave * 64;
-    const int64_t rb = (int64_t)blockIdx.x * rows_per_wg;
-    const int64_t re = rb + rows_per_wg < R ? rb + rows_per_wg : R;
     if (rb >= re) return;
     f32x16 acc[KT][2];
 #pragma unroll
@@ -1284,8 +1283,8 @@ __global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, i
 #pragma unroll
         for (int r = 0; r < RC; ++r) {
             const bool in = c0 + r < re;
-            if constexpr (!XPM) xr[r] = (in && xcol) ? X[(c0 + r) * ldx + tid] : 0.f;
-            if constexpr (!GPM) gr[r] = in ? G[(c0 + r) * ldg + tid] : 0.f;
+            if constexpr (!XPM) xr[r] = (in && xcol) ? X[(c0 + r) * (int64_t)ldx + tid] : 0.f;
+            if constexpr (!GPM) gr[r] = in ? G[(c0 + r) * (int64_t)ldg + tid] : 0.f;
         }
     };
     auto stage = [&](const float (&v)[RC], _Float16 *ph, _Float16 *pm, float scale) {        // column tid: 32 rows -> 4 + 4 LDS writes of 8 halves
@@ -1306,7 +1305,7 @@ __global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, i
     fetch(rb);
     for (int64_t c0 = rb; c0 < re; c0 += RC) {
         __syncthreads();
-        if (tid < KP) stage(xr, Xh, Xm, 1.0f);
+        if (tid < 32 * KTN) stage(xr, Xh, Xm, 1.0f);
         stage(gr, Gh, Gm, gs);
         if (db) {
 #pragma unroll
@@ -1326,7 +1325,7 @@ __global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, i
                 bm[t] = *(const h8 *)(Gm + (n0 + 32 * t + j) * LDT + ro);
             }
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
+            for (int kt = 0; kt < KTN; ++kt) {
                 const h8 ah = *(const h8 *)(Xh + (32 * kt + j) * LDT + ro), am = *(const h8 *)(Xm + (32 * kt + j) * LDT + ro);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -1338,7 +1337,7 @@ __global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, i
         }
     }
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int kt = 0; kt < KTN; ++kt)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1347,6 +1346,76 @@ __global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, i
                 if (k < K && n < nvalid) atomicAdd(&dW[k * sk + n * sn], acc[kt][t][q]);
             }
     if (db && tid < nvalid) atomicAdd(&db[tid], bsum);
+}
+
+template <int KT, bool XPM = false, bool GPM = false>
+__global__ __launch_bounds__(kThreads, 1) void dw_split_kernel(const float *X, int ldx, int K, const float *G, int ldg, int64_t R,
+                                                               int64_t rows_per_wg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
+                                                               int bias_period, const float *amax_g)
+{
+    const int64_t rb = (int64_t)blockIdx.x * rows_per_wg;
+    dw_split_rows<KT, XPM, GPM>(X, ldx, K, G, ldg, rb, rb + rows_per_wg < R ? rb + rows_per_wg : R, dW, sk, sn, nvalid, db, bias_period, amax_g);
+}
+
+// Job-parallel split-fp16 weight gradients (round 5; train_kernels.h launch_dw_split_jobs): every product of a backward pass in ONE
+// launch, the workgroups divided among the products as in dw_jobs_kernel -- one 65 536-atomic epilogue per workgroup and pass instead
+// of one per workgroup and product.  A job with amax_g accumulates its range-scaled product into its own dense [K, 256] scratch.
+__global__ __launch_bounds__(kThreads, 1) void dw_split_jobs_kernel(const DwJobs jobs)
+{
+    int jb = 0;
+    while (jb + 1 < jobs.n && (int)blockIdx.x >= jobs.job[jb + 1].wg0) ++jb;
+    const DwJob &J = jobs.job[jb];
+    const int w = (int)blockIdx.x - J.wg0, nw = (jb + 1 < jobs.n ? jobs.job[jb + 1].wg0 : (int)gridDim.x) - J.wg0;
+    const int64_t chunks = (jobs.R + 31) / 32, per = (chunks + nw - 1) / nw;
+    const int64_t rb = (int64_t)w * per * 32, re_ = rb + per * 32;
+    const int64_t re = re_ < jobs.R ? re_ : jobs.R;
+    const bool scaled = J.amax_g && J.tmp;
+    float *out = scaled ? J.tmp : J.dW;
+    const int64_t osk = scaled ? kWidth : J.sk, osn = scaled ? 1 : J.sn;
+    const float *am = scaled ? J.amax_g : nullptr;
+    if (J.x_point_major) dw_split_rows<8, true, true, 8>(J.X, J.ldx, J.K, J.G, J.ldg, rb, re, out, osk, osn, J.nvalid, J.db, J.bias_period, am);
+    else if (J.K <= 64) dw_split_rows<8, false, true, 2>(J.X, J.ldx, J.K, J.G, J.ldg, rb, re, out, osk, osn, J.nvalid, J.db, J.bias_period, am);
+    else if (J.K <= 96) dw_split_rows<8, false, true, 3>(J.X, J.ldx, J.K, J.G, J.ldg, rb, re, out, osk, osn, J.nvalid, J.db, J.bias_period, am);
+    else dw_split_rows<8, false, true, 8>(J.X, J.ldx, J.K, J.G, J.ldg, rb, re, out, osk, osn, J.nvalid, J.db, J.bias_period, am);
+}
+
+// dW += tmp / scale(amax) for every scaled job of the list: block (x, y) = 256 elements x of job y
+__global__ void dw_unscale_add_jobs_kernel(const DwJobs jobs)
+{
+    const DwJob &J = jobs.job[blockIdx.y];
+    if (!(J.amax_g && J.tmp)) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= J.K * kWidth) return;
+    const int k = i >> 8, n = i & 255;
+    if (n < J.nvalid) J.dW[k * J.sk + n * J.sn] += J.tmp[i] * pow2_inverse(operand_scale(J.amax_g));
+}
+
+void launch_dw_split_jobs(DwJobs &jobs, float *tmp, int cus, hipStream_t s)
+{
+    if (jobs.n <= 0 || jobs.R <= 0) return;
+    // workgroups in proportion to the products' cost.  Under this policy the staging of G (256 columns split into two fp16 terms per
+    // chunk, whatever K) outweighs the matrix work: measured per launch 0.226 / 0.258 / 0.346 ms for K <= 64 / <= 96 / 256
+    // (profiles/r05_train_step_kernel_stats_f16_split_fused.csv) -- with the fp32 route's weights (128 : 160 : 320) the narrow products
+    // finished 1.6x late and the launch was 4.4 ms SLOWER than one launch per product
+    float cost[kMaxDwJobs], total = 0.f;
+    for (int i = 0; i < jobs.n; ++i) { const int K = jobs.job[i].K; cost[i] = K <= 64 ? 226.0f : K <= 96 ? 258.0f : 346.0f; total += cost[i]; }
+    int grid = cus > jobs.n ? cus : jobs.n, at = 0;
+    for (int i = 0; i < jobs.n; ++i) {
+        jobs.job[i].wg0 = at;
+        int share = (int)(cost[i] / total * grid + 0.5f);
+        if (share < 1) share = 1;
+        const int left = jobs.n - 1 - i;
+        if (at + share > grid - left) share = grid - left - at;
+        at += share;
+        if (jobs.job[i].amax_g) jobs.job[i].tmp = tmp + (size_t)i * kWidth * kWidth;
+    }
+    grid = at;
+    (void)hipMemsetAsync(tmp, 0, (size_t)jobs.n * kWidth * kWidth * sizeof(float), s);
+    constexpr size_t lds = (size_t)2 * (32 * 8 + kWidth) * 40 * sizeof(_Float16);
+    static bool once = ((void)hipFuncSetAttribute((const void *)dw_split_jobs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL(dw_split_jobs_kernel, dim3(grid), dim3(kThreads), lds, s, jobs);
+    hipLaunchKernelGGL(dw_unscale_add_jobs_kernel, dim3(kWidth * kWidth / 256, jobs.n), dim3(256), 0, s, jobs);
 }
 
 // dW[k * sk + n * sn] += T[k, n] / scale(amax): the accumulators of dw_split_kernel stay in the accumulation registers this way
