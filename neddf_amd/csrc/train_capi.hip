@@ -29,17 +29,21 @@ constexpr int kLdPe = 64, kLdDir = 64, kLdNarrow = 4;      // row strides of the
 // constructs, neddf.py:52-66, nerf.py:34-44, neus.py:30-41) arrives padded to 512 and takes the PER-LAYER route with every product cut into 256 x 256 blocks
 // (K blocks accumulate in the output, the activation / its backward runs on the last one): the same kernels, correct at any
 // multiple of 256, without the fused chains' speed.  Anything wider is refused loudly rather than computed wrongly.
-// NEDDF_TRAIN_SPLIT_FUSED=0: the split-fp16 policy's backward pass as one GEMM kernel per layer on row-major matrices (rounds 1-4)
-// instead of the fused input-gradient chains on point-major ones (round 5: mlp_backward_split_kernel)
-// NEDDF_TRAIN_WIDE_FUSED=1 (probe, fp32 policy): fields that train padded to 512 columns (hidden widths 257 .. 512) on 512-wide fused
-// chains (round 5: mlp_forward_kernel / mlp_backward_kernel over the width, 32-row tiles) instead of the per-layer route with every
-// product cut into 256 x 256 blocks (round 4).  Parity-green and MEASURED 2.3x SLOWER (NeDDF 8 + 4 layers, 265 k points, forward +
-// backward: 373 ms against 162 ms; 256 wide: 36 ms): a chain's twelve 512 x 512 matrices are 12 MB of packed weights (+ 12 MB of
-// transposes), three times the 4 MB L2 of an XCD, and every 32-row tile streams all of them -- where the blocked route streams ONE
-// L2-resident 256 x 256 block against all rows per launch.  The default for wide fields therefore stays the blocked route.
+
+// NEDDF_TRAIN_WIDE_FUSED=0: fields that train padded to 512 columns (hidden widths 257 .. 512) keep round 4's per-layer route with every
+// product cut into 256 x 256 blocks instead of the 512-wide fused chains (round 5, fp32 policy: mlp_forward_kernel / mlp_backward_kernel
+// over the width on 32-row tiles, point-major [R, 512] matrices, one weight-gradient launch per 256 x 256 block).  Measured (NeDDF
+// 8 + 4 layers, 265 k points, forward + backward): 131 ms fused against 162 ms blocked -- after the first version, whose weight
+// gradients went through the job-parallel launch, had taken 373 ms (see wide_dw_jobs).  The split-fp16 policy keeps the blocked route.
 bool wide_fused()
 {
-    static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_WIDE_FUSED"); return e && atoi(e) != 0; }();
+    static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_WIDE_FUSED"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
+bool wide_dw_jobs()          // NEDDF_TRAIN_WIDE_DW_JOBS=1: the wide fused route's weight gradients through the job-parallel launch after all (A/B)
+{
+    static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_WIDE_DW_JOBS"); return e && atoi(e) != 0; }();
     return on;
 }
 
@@ -50,6 +54,8 @@ bool split_dw_jobs()
     return on;
 }
 
+// NEDDF_TRAIN_SPLIT_FUSED=0: the split-fp16 policy's backward pass as one GEMM kernel per layer on row-major matrices (rounds 1-4)
+// instead of the fused input-gradient chains on point-major ones (round 5: mlp_backward_split_kernel)
 bool split_fused()
 {
     static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_SPLIT_FUSED"); return !(e && atoi(e) == 0); }();
@@ -784,6 +790,9 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         // one 256 x 256 (or K x 256) weight-gradient product: G is a 256-column block of a point-major gradient matrix
         auto add_dw = [&](const float *X, int ldx, int K, int x_pm, const float *G, const float *amax_g, float *dW, int nvalid, float *db) {
             if (sp && !split_dw_jobs()) { launch_dw(1, X, ldx, K, G, WH, p.R, dW, WH, 1, nvalid, db, 4, ctx->cus, s, amax_g, am.dw_tmp, x_pm, 1); return; }
+            // 512 columns (fp32 probe route): one launch per 256 x 256 block -- the job-parallel launch spreads 46 blocks of 2.2 GB
+            // matrices over 8 workgroups each and ran at a sixth of its speed (287 ms per step against 45 ms of products)
+            if (!sp && WH != kWidth && !wide_dw_jobs()) { launch_dw(0, X, ldx, K, G, WH, p.R, dW, WH, 1, nvalid, db, 4, ctx->cus, s, nullptr, nullptr, x_pm, 1); return; }
             if (dwj.n == kMaxDwJobs) { flush_dw(); dwj.n = 0; }        // (every G in the list has been produced: the jobs follow their chain)
             dwj.add(X, ldx, K, x_pm, G, WH, dW, WH, 1, nvalid, db, 4);
             dwj.job[dwj.n - 1].amax_g = amax_g;

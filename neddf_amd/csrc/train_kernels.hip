@@ -1065,13 +1065,13 @@ __device__ __forceinline__ void dw_tile_rows(const float *X, int ldx, int K, con
     }
 }
 
-template <int KT>
+template <int KT, int KTN = KT, bool XPM = false, bool GPM = false>
 __global__ __launch_bounds__(kThreads, 1) void dw_tile_kernel(const float *X, int ldx, int K, const float *G, int ldg, int64_t R,
                                                               int64_t rows_per_wg, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
                                                               int bias_period)
 {
     const int64_t rb = (int64_t)blockIdx.x * rows_per_wg;
-    dw_tile_rows<KT>(X, ldx, K, G, ldg, rb, rb + rows_per_wg < R ? rb + rows_per_wg : R, dW, sk, sn, nvalid, db, bias_period);
+    dw_tile_rows<KT, KTN, XPM, GPM>(X, ldx, K, G, ldg, rb, rb + rows_per_wg < R ? rb + rows_per_wg : R, dW, sk, sn, nvalid, db, bias_period);
 }
 
 // Job-parallel weight gradients (train_kernels.h DwJobs): every product of a backward pass in ONE launch, each workgroup working on ONE
@@ -1120,19 +1120,19 @@ void launch_dw_jobs(DwJobs &jobs, int cus, hipStream_t s)
     hipLaunchKernelGGL(dw_jobs_kernel, dim3(grid), dim3(kThreads), lds, s, jobs);
 }
 
-template <int KT>
+template <int KT, int KTN = KT, bool XPM = false, bool GPM = false>
 static void launch_dw_tile(const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid,
                            float *db, int bias_period, int cus, hipStream_t s)
 {
     constexpr int KP = 32 * KT, LDX = ((KP + 32) % 64 == 32) ? KP + 32 : KP + 64, LDG = kWidth + 32;
     const size_t lds = (size_t)32 * (LDX + LDG) * sizeof(float);
-    static bool once = ((void)hipFuncSetAttribute((const void *)dw_tile_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32 * (LDX + LDG) * sizeof(float))), true);
+    static bool once = ((void)hipFuncSetAttribute((const void *)dw_tile_kernel<KT, KTN, XPM, GPM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32 * (LDX + LDG) * sizeof(float))), true);
     (void)once;
     int64_t chunks = (R + 31) / 32;
     int grid = (int)(chunks < cus ? chunks : cus);
     int64_t rows_per_wg = ((chunks + grid - 1) / grid) * 32;
     ablate_init();
-    hipLaunchKernelGGL((dw_tile_kernel<KT>), dim3(grid), dim3(kThreads), lds, s, X, ldx, K, G, ldg, R, rows_per_wg, dW, sk, sn, nvalid, db, bias_period);
+    hipLaunchKernelGGL((dw_tile_kernel<KT, KTN, XPM, GPM>), dim3(grid), dim3(kThreads), lds, s, X, ldx, K, G, ldg, R, rows_per_wg, dW, sk, sn, nvalid, db, bias_period);
 }
 
 // Heads with 1..4 output columns: dW_c[k] += sum_r X[r, k] G[r, c], db_c += sum over value rows of G[r, c].
@@ -1473,6 +1473,13 @@ void launch_dw(int split, const float *X, int ldx, int K, const float *G, int ld
         else if (K <= 96) launch_dw_split<3>(X, ldx, K, G, ldg, R, out, osk, osn, nvalid, db, bias_period, cus, s, scaled ? amax_g : nullptr);
         else launch_dw_split<8>(X, ldx, K, G, ldg, R, out, osk, osn, nvalid, db, bias_period, cus, s, scaled ? amax_g : nullptr);
         if (scaled) hipLaunchKernelGGL(dw_unscale_add_kernel, dim3((K * kWidth + 255) / 256), dim3(256), 0, s, scaled_tmp, K, nvalid, dW, sk, sn, amax_g);
+        return;
+    }
+    if (g_point_major) {        // (fp32, one launch per product on point-major operands: the wide fused route, whose 46 products the job-parallel launch serves badly)
+        if (x_point_major) launch_dw_tile<8, 8, true, true>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
+        else if (K <= 64) launch_dw_tile<8, 2, false, true>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
+        else if (K <= 96) launch_dw_tile<8, 3, false, true>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
+        else launch_dw_tile<8, 8, false, true>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
         return;
     }
     if (K <= 64) launch_dw_tile<2>(X, ldx, K, G, ldg, R, dW, sk, sn, nvalid, db, bias_period, cus, s);
