@@ -41,6 +41,12 @@ bool wide_fused()
     return on;
 }
 
+bool dw_jobs_256()           // NEDDF_TRAIN_DW_JOBS=0: the 256-wide fp32 route's weight gradients one launch per product (A/B partner of dw_jobs_kernel)
+{
+    static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_DW_JOBS"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 bool wide_dw_jobs()          // NEDDF_TRAIN_WIDE_DW_JOBS=1: the wide fused route's weight gradients through the job-parallel launch after all (A/B)
 {
     static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_WIDE_DW_JOBS"); return e && atoi(e) != 0; }();
@@ -792,7 +798,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
             if (sp && !split_dw_jobs()) { launch_dw(1, X, ldx, K, G, WH, p.R, dW, WH, 1, nvalid, db, 4, ctx->cus, s, amax_g, am.dw_tmp, x_pm, 1); return; }
             // 512 columns (fp32 probe route): one launch per 256 x 256 block -- the job-parallel launch spreads 46 blocks of 2.2 GB
             // matrices over 8 workgroups each and ran at a sixth of its speed (287 ms per step against 45 ms of products)
-            if (!sp && WH != kWidth && !wide_dw_jobs()) { launch_dw(0, X, ldx, K, G, WH, p.R, dW, WH, 1, nvalid, db, 4, ctx->cus, s, nullptr, nullptr, x_pm, 1); return; }
+            if (!sp && ((WH != kWidth && !wide_dw_jobs()) || (WH == kWidth && !dw_jobs_256()))) { launch_dw(0, X, ldx, K, G, WH, p.R, dW, WH, 1, nvalid, db, 4, ctx->cus, s, nullptr, nullptr, x_pm, 1); return; }
             if (dwj.n == kMaxDwJobs) { flush_dw(); dwj.n = 0; }        // (every G in the list has been produced: the jobs follow their chain)
             dwj.add(X, ldx, K, x_pm, G, WH, dW, WH, 1, nvalid, db, 4);
             dwj.job[dwj.n - 1].amax_g = amax_g;
