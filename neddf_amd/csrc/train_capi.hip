@@ -31,10 +31,10 @@ constexpr int kLdPe = 64, kLdDir = 64, kLdNarrow = 4;      // row strides of the
 // multiple of 256, without the fused chains' speed.  Anything wider is refused loudly rather than computed wrongly.
 
 // NEDDF_TRAIN_WIDE_FUSED=0: fields that train padded to 512 columns (hidden widths 257 .. 512) keep round 4's per-layer route with every
-// product cut into 256 x 256 blocks instead of the 512-wide fused chains (round 5, fp32 policy: mlp_forward_kernel / mlp_backward_kernel
+// product cut into 256 x 256 blocks instead of the 512-wide fused chains (round 5: mlp_forward_kernel / mlp_backward_kernel / mlp_backward_split_kernel
 // over the width on 32-row tiles, point-major [R, 512] matrices, one weight-gradient launch per 256 x 256 block).  Measured (NeDDF
 // 8 + 4 layers, 265 k points, forward + backward): 131 ms fused against 162 ms blocked -- after the first version, whose weight
-// gradients went through the job-parallel launch, had taken 373 ms (see wide_dw_jobs).  The split-fp16 policy keeps the blocked route.
+// gradients went through the job-parallel launch, had taken 373 ms (see wide_dw_jobs); split fp16: 71 against 124 ms.
 bool wide_fused()
 {
     static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_WIDE_FUSED"); return !(e && atoi(e) == 0); }();
@@ -624,7 +624,7 @@ int neddf_train_field_forward(neddf_ctx *ctx, int slot, const float *const *W, c
     // the fused backward (neddf_train_field_backward takes that route under the same condition)
     const int WH = p.WH, NBK = WH / kWidth;      // hidden width the kernels see, in 256-column blocks
     // the fused chains are 256 wide, and -- round 5, fp32 policy -- 512 wide for the fields that train padded to 512 (wide_fused)
-    const bool fused = !unfused && n_wide <= 1 && (WH == kWidth || (WH == 2 * kWidth && !sp && wide_fused()));
+    const bool fused = !unfused && n_wide <= 1 && (WH == kWidth || (WH == 2 * kWidth && wide_fused() && (!sp || split_fused())));
     // (round 5: the split-fp16 policy takes the same fused, point-major route; NEDDF_TRAIN_SPLIT_FUSED=0 keeps its per-layer backward
     // and the row-major matrices that reads -- the A/B partner)
     const int pm = (fused && (!sp || split_fused())) ? 1 : 0;
@@ -758,7 +758,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
     int n_wide = 0;
     for (int l = 1; l < p.n_trunk; ++l) n_wide += in_skips(f.d, l - 1) ? 1 : 0;
     const int WH = p.WH, NBK = WH / kWidth;
-    if ((!sp || split_fused()) && !unfused && n_wide <= 1 && (WH == kWidth || (WH == 2 * kWidth && !sp && wide_fused()))) {      // (= the forward's condition for point-major hidden states)
+    if ((!sp || split_fused()) && !unfused && n_wide <= 1 && (WH == kWidth || (WH == 2 * kWidth && wide_fused()))) {      // (= the forward's condition for point-major hidden states)
         const int nT = p.n_trunk, nC = p.n_col;
         const size_t slot = (size_t)p.R * WH, packf = (size_t)WH * WH;
         const int B4 = 4 * kWidth;      // a 256-column block of a point-major [R, WH] matrix starts B4 x (block index) floats into a point
@@ -795,7 +795,7 @@ int neddf_train_field_backward(neddf_ctx *ctx, int slot, const float *const *W, 
         };
         // one 256 x 256 (or K x 256) weight-gradient product: G is a 256-column block of a point-major gradient matrix
         auto add_dw = [&](const float *X, int ldx, int K, int x_pm, const float *G, const float *amax_g, float *dW, int nvalid, float *db) {
-            if (sp && !split_dw_jobs()) { launch_dw(1, X, ldx, K, G, WH, p.R, dW, WH, 1, nvalid, db, 4, ctx->cus, s, amax_g, am.dw_tmp, x_pm, 1); return; }
+            if (sp && (!split_dw_jobs() || WH != kWidth)) { launch_dw(1, X, ldx, K, G, WH, p.R, dW, WH, 1, nvalid, db, 4, ctx->cus, s, amax_g, am.dw_tmp, x_pm, 1); return; }
             // 512 columns (fp32 probe route): one launch per 256 x 256 block -- the job-parallel launch spreads 46 blocks of 2.2 GB
             // matrices over 8 workgroups each and ran at a sixth of its speed (287 ms per step against 45 ms of products)
             if (!sp && ((WH != kWidth && !wide_dw_jobs()) || (WH == kWidth && !dw_jobs_256()))) { launch_dw(0, X, ldx, K, G, WH, p.R, dW, WH, 1, nvalid, db, 4, ctx->cus, s, nullptr, nullptr, x_pm, 1); return; }

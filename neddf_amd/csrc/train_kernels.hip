@@ -504,8 +504,9 @@ void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t
 {
     if (a.R <= 0) return;
     ablate_init();
-    if (a.width == 512) {       // round 5: wide fields (fp32, point-major) on the fused chain too
-        launch_mlp_forward_ops<OpsF32T<512>, true, true>(a, cus, s);
+    if (a.width == 512) {       // round 5: wide fields (point-major) on the fused chain too
+        if (split) launch_mlp_forward_ops<OpsF16SplitT<512>, false, true>(a, cus, s);
+        else launch_mlp_forward_ops<OpsF32T<512>, true, true>(a, cus, s);
         return;
     }
     if (split && a.point_major) launch_mlp_forward_ops<OpsF16Split, false, true>(a, cus, s);      // (round 5: the split policy's fused NeDDF route)
@@ -654,13 +655,13 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
 // (2) scaled by the tile's power of two, split into two fp16 terms, into the LDS tile.  The accumulators of the next product carry
 // that scale and the weights' 2^10: both come off (exactly) at the start of the next epilogue.  Each dZ_l also leaves its global
 // maximum in a device scalar for the weight-gradient products that follow (dw_split_kernel scales its G operand by it).
-template <int KIND>
+template <int KIND, int W = kWidth>
 __global__ __launch_bounds__(kThreads, 2) void mlp_backward_split_kernel(const MlpBackwardArgs a)
 {
-    typedef OpsF16Split Ops;
+    typedef OpsF16SplitT<W> Ops;
     typedef typename Ops::bfrag frag;
     typedef typename Ops::act_t act_t;
-    constexpr int MT = 2, NT = 2, ROWS = MT * 32, LD = Ops::kLd, KS = kWidth / Ops::kStep;
+    constexpr int MT = W <= 256 ? 2 : 1, NT = W / 128, ROWS = MT * 32, LD = Ops::kLd, KS = W / Ops::kStep;      // (512: 32-row tiles, see mlp_forward_kernel)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     act_t *act = (act_t *)smem;
     float *smax = (float *)(act + ROWS * LD);           // [4]: the waves' maxima of the gradient tile in flight
@@ -682,7 +683,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_split_kernel(const M
         __syncthreads();                // the previous tile is done with the LDS tile (and with smax)
         // Z of this lane's accumulator positions: the four rows of a point for one feature = one 16-byte load in the point-major layout
         auto load_z = [&](const float *Z, f32x16 (&zp)[MT][NT]) {
-            const float *zb = Z + ((r0 >> 2) + h) * (4 * kWidth) + (wave * NT * 32 + j) * 4;
+            const float *zb = Z + ((r0 >> 2) + h) * (4 * W) + (wave * NT * 32 + j) * 4;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_split_kernel(const M
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-                        if (r0 + mt * 32 + 8 * g + 4 * h < a.R) v = __builtin_nontemporal_load((const f32x4v *)(zb + (mt * 8 + 2 * g) * (4 * kWidth) + t * 128));
+                        if (r0 + mt * 32 + 8 * g + 4 * h < a.R) v = __builtin_nontemporal_load((const f32x4v *)(zb + (mt * 8 + 2 * g) * (4 * W) + t * 128));
 #pragma unroll
                         for (int r = 0; r < 4; ++r) zp[mt][t][4 * g + r] = v[r];
                     }
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_split_kernel(const M
         // activation backward, in place; out to the point-major matrix; returns the lane's maximum of |dZ_l|
         auto backward_values = [&](f32x16 (&acc)[MT][NT], const f32x16 (&zp)[MT][NT], float *dZl) {
             float lmax = 0.f;
-            float *gb = dZl + ((r0 >> 2) + h) * (4 * kWidth) + (wave * NT * 32 + j) * 4;
+            float *gb = dZl + ((r0 >> 2) + h) * (4 * W) + (wave * NT * 32 + j) * 4;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_split_kernel(const M
                         sj += g3 * zp[mt][t][4 * g + 3];
                         const float ov[4] = { g0 * dy + sj * d2, g1 * dy, g2 * dy, g3 * dy };
                         const bool in = r0 + mt * 32 + 8 * g + 4 * h < a.R;
-                        if (in) __builtin_nontemporal_store(f32x4v{ ov[0], ov[1], ov[2], ov[3] }, (f32x4v *)(gb + (mt * 8 + 2 * g) * (4 * kWidth) + t * 128));
+                        if (in) __builtin_nontemporal_store(f32x4v{ ov[0], ov[1], ov[2], ov[3] }, (f32x4v *)(gb + (mt * 8 + 2 * g) * (4 * W) + t * 128));
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             acc[mt][t][4 * g + r] = in ? ov[r] : 0.f;
@@ -744,11 +745,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_split_kernel(const M
             if (a.top_src) {
                 // 64 rows of the point-major gradient matrix -> registers, their maximum -> the tile's scale -> the LDS tile
                 // (read twice -- the second time from L2 -- rather than held: 64 registers next to Z and the accumulators would spill)
-                constexpr int NV = (ROWS / 4) * kWidth / kThreads;
+                constexpr int NV = (ROWS / 4) * W / kThreads;
                 auto piece = [&](int i) {
-                    const int idx = tid + i * kThreads, p = idx >> 8, c = idx & 255;
+                    const int idx = tid + i * kThreads, p = idx / W, c = idx - p * W;
                     f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-                    if (r0 + 4 * p < a.R) v = *(const f32x4v *)(a.top_src + ((r0 >> 2) + p) * (4 * kWidth) + 4 * c);
+                    if (r0 + 4 * p < a.R) v = *(const f32x4v *)(a.top_src + ((r0 >> 2) + p) * (4 * W) + 4 * c);
                     return v;
                 };
                 float lmax = 0.f;
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_split_kernel(const M
                 const float sc = tile_scale();
 #pragma unroll 4
                 for (int i = 0; i < NV; ++i) {
-                    const int idx = tid + i * kThreads, p = idx >> 8, c = idx & 255;
+                    const int idx = tid + i * kThreads, p = idx / W, c = idx - p * W;
                     const f32x4v v = piece(i);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) Ops::put(act + (4 * p + q) * LD + c, v[q] * sc);
@@ -839,6 +840,21 @@ void launch_mlp_backward(int split, const MlpBackwardArgs &a, int cus, hipStream
 {
     if (a.R <= 0 || (a.n_layers < 2 && a.dZtop)) return;         // a one-layer stack still has a prologue to run
     ablate_init();
+    if (split && a.width == 512) {      // wide fields under the split policy (round 5)
+        constexpr size_t lds5 = (size_t)32 * OpsF16SplitT<512>::kLd * sizeof(OpsF16Split::act_t) + 16 * sizeof(float);
+        static bool once5 = ((void)hipFuncSetAttribute((const void *)mlp_backward_split_kernel<0, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5),
+                             (void)hipFuncSetAttribute((const void *)mlp_backward_split_kernel<1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5),
+                             (void)hipFuncSetAttribute((const void *)mlp_backward_split_kernel<2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5),
+                             (void)hipFuncSetAttribute((const void *)mlp_backward_split_kernel<3, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5), true);
+        (void)once5;
+        const int64_t tiles5 = (a.R + 31) / 32;
+        const dim3 grid5((unsigned)(tiles5 < 2 * cus ? tiles5 : 2 * cus));
+        if (a.act_kind == 0) hipLaunchKernelGGL((mlp_backward_split_kernel<0, 512>), grid5, dim3(kThreads), lds5, s, a);
+        else if (a.act_kind == 1) hipLaunchKernelGGL((mlp_backward_split_kernel<1, 512>), grid5, dim3(kThreads), lds5, s, a);
+        else if (a.act_kind == 2) hipLaunchKernelGGL((mlp_backward_split_kernel<2, 512>), grid5, dim3(kThreads), lds5, s, a);
+        else hipLaunchKernelGGL((mlp_backward_split_kernel<3, 512>), grid5, dim3(kThreads), lds5, s, a);
+        return;
+    }
     if (split) {        // (prologue form only: the NeDDF route, the one caller)
         constexpr size_t lds = (size_t)64 * OpsF16Split::kLd * sizeof(OpsF16Split::act_t) + 16 * sizeof(float);
         static bool once = ((void)hipFuncSetAttribute((const void *)mlp_backward_split_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
@@ -1269,12 +1285,12 @@ __device__ __forceinline__ void dw_split_rows(const float *X, int ldx, int K, co
                 const bool in = c0 + 4 * p < re;
                 const f32x4v zero = { 0.f, 0.f, 0.f, 0.f };
                 if constexpr (XPM) {
-                    const f32x4v v = (in && xcol) ? *(const f32x4v *)(X + ((c0 >> 2) + p) * (4 * kWidth) + 4 * tid) : zero;
+                    const f32x4v v = (in && xcol) ? *(const f32x4v *)(X + ((c0 >> 2) + p) * (4 * (int64_t)ldx) + 4 * tid) : zero;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) xr[4 * p + q] = v[q];
                 }
                 if constexpr (GPM) {
-                    const f32x4v v = in ? *(const f32x4v *)(G + ((c0 >> 2) + p) * (4 * kWidth) + 4 * tid) : zero;
+                    const f32x4v v = in ? *(const f32x4v *)(G + ((c0 >> 2) + p) * (4 * (int64_t)ldg) + 4 * tid) : zero;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) gr[4 * p + q] = v[q];
                 }
