@@ -16,6 +16,7 @@
 #include "tile_engine.h"
 #include "train_kernels.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -840,6 +841,10 @@ void launch_mlp_backward(int split, const MlpBackwardArgs &a, int cus, hipStream
 {
     if (a.R <= 0 || (a.n_layers < 2 && a.dZtop)) return;         // a one-layer stack still has a prologue to run
     ablate_init();
+    if (split && a.dZtop) {             // a caller's error, not a data condition: the split chain exists in its prologue form only
+        fprintf(stderr, "neddf: launch_mlp_backward(split = 1) takes the top gradient through top_G / top_src, not dZtop\n");
+        abort();
+    }
     if (split && a.width == 512) {      // wide fields under the split policy (round 5)
         constexpr size_t lds5 = (size_t)32 * OpsF16SplitT<512>::kLd * sizeof(OpsF16Split::act_t) + 16 * sizeof(float);
         static bool once5 = ((void)hipFuncSetAttribute((const void *)mlp_backward_split_kernel<0, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5),
