@@ -267,13 +267,20 @@ __global__ __launch_bounds__(64) void resample_kernel(const float *dists, float 
     float l1 = 0.f;
     for (int j = 0; j < nw; ++j) l1 += fabsf(w[j]);
     l1 = l1 < 1e-12f ? 1e-12f : l1;
-    // cumsum in double, each output rounded to fp32 (N2): lane j owns cdf[j+1], summed in index order
-    for (int j = lane; j < nw; j += 64) {
+    // cumsum in double, each output rounded to fp32 (N2), summed in index order.  The order is the result (double addition does not
+    // associate), so the chain stays sequential: the quotients in parallel, then ONE lane adds them up -- n dependent additions per
+    // ray (rounds 1-4: every lane re-summed its own prefixes, n^2 / 128 quotients and additions per lane: the same bits, but quadratic
+    // in sample_coarse)
+    for (int j = lane; j < nw; j += 64) srt[j] = w[j] / l1;
+    __syncthreads();
+    if (lane == 0) {
         double acc = 0.0;
-        for (int k = 0; k <= j; ++k) acc += (double)(w[k] / l1);
-        cdf[j + 1] = (float)acc;
+        cdf[0] = 0.0f;
+        for (int k = 0; k < nw; ++k) {
+            acc += (double)srt[k];
+            cdf[k + 1] = (float)acc;
+        }
     }
-    if (lane == 0) cdf[0] = 0.0f;
     __syncthreads();
     bool bad = false;
     for (int s = lane; s < nf; s += 64) {
