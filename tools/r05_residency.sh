@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round 5: are all workgroup slots of the persistent field grids occupied?  tools/residency_probe.hip (where the workgroups of a
 # 512-workgroup grid with the field kernels' footprint land) + bench.py with NEDDF_GRID_SLACK_PCT more workgroups than slots.
+# Build the probe first (in the build container; tools/bin/ travels with the snapshot):
+#   mkdir -p tools/bin && hipcc --offload-arch=gfx950 -O2 -o tools/bin/residency_probe tools/residency_probe.hip
 ROOT=$PWD
 O=$ROOT/gpurun_out/r5res
 mkdir -p $O
