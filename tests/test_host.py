@@ -779,3 +779,23 @@ def test_jet_colour_map_follows_opencv_rounding():
     assert (t[32:96, 0] == 255).all() and t[32, 1] == 0 and t[33, 1] == 4
     g = np.array([[0, 255], [64, 191]], np.uint8)
     assert jet_bgr(g).shape == (2, 2, 3) and jet_bgr(g).dtype == np.uint8
+
+
+def test_documented_environment_switches_exist():
+    """Every NEDDF_* switch INTEGRATION.md documents is read somewhere in the product, the bench, the tests or the tools (a probe whose
+    switch was removed must leave the table too), and the diagnostic ones the table leaves out are the known few."""
+    import glob
+    import re
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"`(NEDDF_[A-Z0-9_]+)", doc)))
+    assert len(names) >= 30
+    src = ""
+    for pat in ("neddf_amd/**/*.py", "neddf_amd/csrc/*.hip", "neddf_amd/csrc/*.h", "neddf_amd/csrc/Makefile", "bench.py", "tests/*.py", "tools/*.py", "tools/*.sh"):
+        for f in glob.glob(os.path.join(ROOT, pat), recursive=True):
+            src += open(f, errors="ignore").read()
+    missing = [n for n in names if n not in src]
+    assert not missing, "documented but read nowhere: %s" % missing
+    used = set(re.findall(r'getenv\("(NEDDF_[A-Z0-9_]+)"\)', src))
+    internal = {"NEDDF_DW_ABLATE", "NEDDF_SCHED", "NEDDF_GUARD_SELFTEST", "NEDDF_STAMP_FILE", "NEDDF_STAMP_FILE_COL"}       # ablation / stamp builds, the probe's own self-test
+    undocumented = sorted(u for u in used if u not in doc and u not in internal)
+    assert not undocumented, "read by the library but missing from INTEGRATION.md: %s" % undocumented
