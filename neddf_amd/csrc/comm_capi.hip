@@ -182,17 +182,17 @@ int neddf_comm_init(neddf_ctx *ctx, int rank, int nranks, const void *h_id)
         return fail(ctx, NEDDF_EHIP, why);
     }
     // The route of a ragged gather is a property of the COMMUNICATOR, not of a call: ranks that chose differently (an environment
-    // variable set on one of them, an RCCL without the group calls on another) would issue mismatched collectives and hang.  Every
-    // rank contributes "I can and want to gather in place" (NEDDF_GATHER_INPLACE=1 + the three optional symbols); the route is in
-    // place only if ALL of them said so -- agreed with the one collective every route needs anyway.  Default: the padded staging
-    // route (equal-count all-gather + compaction copies), the one that has run on hardware.
+    // variable set on one of them, an RCCL without the group calls on another) would issue mismatched collectives and hang.  EVERY
+    // rank of a communicator with more than one rank joins ONE 4-byte all-gather here, unconditionally -- a rank that skipped it
+    // because it lacks the wish or the symbols would leave its peers inside it -- and contributes "I can and want to gather in
+    // place" (NEDDF_GATHER_INPLACE=1 + the three optional symbols); the route is in place only if ALL of them said so, otherwise
+    // every rank takes the padded staging route (equal-count all-gather + compaction copies).  It is also the communicator's first
+    // collective: a broken fabric shows at start-up, not under the first frame.
     const char *ip = getenv("NEDDF_GATHER_INPLACE"), *fr = getenv("NEDDF_GATHER_FORCE_RAGGED");
     const int mine = (ip && atoi(ip) != 0 && r->Broadcast && r->GroupStart && r->GroupEnd) ? 1 : 0;
     c.force_ragged = fr && atoi(fr) != 0;
     c.in_place = mine != 0;
-    // (the agreement is a collective of its own: it runs only where the opt-in was asked for -- NEDDF_GATHER_INPLACE=1 must be set on
-    // every rank or on none --, so the default start-up of a communicator issues nothing but ncclCommInitRank)
-    if (nranks > 1 && mine) {
+    if (nranks > 1) {
         int rc = ensure(ctx, c.pad, sizeof(int) * (size_t)(nranks + 1));
         std::vector<int> all((size_t)nranks, 0);
         if (!rc) {

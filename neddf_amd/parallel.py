@@ -141,14 +141,41 @@ def gather_pixels(local: Tensor, n_total: int, group=None, force_collective: boo
         return handle.wait() if wait else handle
     sizes = [shard_range(n_total, r, world, granule) for r in range(world)]
     pad = max(hi - lo for lo, hi in sizes)
+    ragged = not all(hi - lo == pad for lo, hi in sizes)
+    if ragged and _host_route_in_place(group):
+        # the library's opt-in route restated for host tensors: rank q's slab straight to its offset of every rank's buffer
+        rank = dist.get_rank(group)
+        full = local.new_empty(n_total, local.shape[1])
+        full[sizes[rank][0]:sizes[rank][1]] = local
+        for q, (lo, hi) in enumerate(sizes):
+            if hi > lo:                     # more ranks than chunks: that rank contributes nothing
+                dist.broadcast(full[lo:hi], src=dist.get_global_rank(group, q) if group is not None else q, group=group)
+        return full if wait else PixelGather(None, full)
     buf = local
     if local.shape[0] < pad:
         buf = torch.cat([local, local.new_zeros(pad - local.shape[0], local.shape[1])])
     full = local.new_empty(world * pad, local.shape[1])
     dist.all_gather_into_tensor(full, buf.contiguous(), group=group)
-    if not all(hi - lo == pad for lo, hi in sizes):
+    if ragged:
         full = torch.cat([full[r * pad:r * pad + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
     return full if wait else PixelGather(None, full)
+
+
+_HOST_ROUTE = {}
+
+
+def _host_route_in_place(group=None) -> bool:
+    """The host-tensor twin of neddf_comm_init's agreement (comm_capi.hip): the route of a ragged gather is a property of the
+    process group, agreed ONCE by every rank -- each contributes its NEDDF_GATHER_INPLACE wish, the in-place route (one broadcast
+    per slab) is taken only if all of them asked for it, otherwise all take the padded route.  A per-rank choice would issue
+    mismatched collectives."""
+    key = id(group) if group is not None else None
+    if key not in _HOST_ROUTE:
+        import os
+        wish = torch.tensor([1 if os.environ.get("NEDDF_GATHER_INPLACE", "0").strip() not in ("", "0") else 0], dtype=torch.int32)
+        dist.all_reduce(wish, op=dist.ReduceOp.MIN, group=group)
+        _HOST_ROUTE[key] = bool(wish.item())
+    return _HOST_ROUTE[key]
 
 
 def render_image_sharded(render, width: int, height: int, camera, target_types: Iterable[str], downsampling: int = 1,

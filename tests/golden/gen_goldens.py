@@ -1157,6 +1157,100 @@ def gen_dataset():
     save("dataset_bunny_mini.npz", **arrs)
 
 
+def gen_eval_harness():
+    """the reference's OWN eval harness -- `NeRFTrainer` built from the shipped bunny_smoke config with
+    the dataset pointed at tests/golden/bunny_mini (test split), `load_pretrained_model` on the shipped checkpoint, then
+    `set_iter(-1)` + `render_test(dir, camera_id, 1)` exactly as `render_all` drives it (base_trainer.py:123-188) -- on the CPU.
+    Nothing of the conversion is restated here: `cv2.imwrite` is a stub that RECORDS the arrays the reference hands it (file name
+    -> uint8 array, channels in the reference's B,G,R order), so the colour / depth / ground-truth images below are what the
+    reference would have written.  72 x 56 = 4 032 rays at chunk 1024: three full chunks and a short one of 960.
+
+    skimage is absent here.  `peak_signal_noise_ratio` / `structural_similarity` are stubs that record their ARGUMENTS (so the
+    fixture proves which arrays the reference compares, and in which order); the PSNR stored beside them is the published
+    definition skimage implements for uint8 inputs, 10 log10(255^2 / mean((a - b)^2)) in float64.  SSIM stays unpinned."""
+    captured, metric_args = {}, []
+    sys.modules["cv2"].imwrite = lambda path, arr: captured.__setitem__(os.path.basename(str(path)), np.array(arr, copy=True))
+    sk, skm = types.ModuleType("skimage"), types.ModuleType("skimage.metrics")
+
+    def psnr(a, b):
+        metric_args.append(("psnr", np.array(a, copy=True), np.array(b, copy=True)))
+        assert a.dtype == np.uint8 and b.dtype == np.uint8
+        mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+        return 10.0 * np.log10(255.0 ** 2 / mse)
+
+    def ssim(a, b, channel_axis=None):
+        metric_args.append(("ssim", np.array(a, copy=True), np.array(b, copy=True), channel_axis))
+        return float("nan")
+
+    skm.peak_signal_noise_ratio, skm.structural_similarity = psnr, ssim
+    sk.metrics = skm
+    sys.modules["skimage"], sys.modules["skimage.metrics"] = sk, skm
+    tb = types.ModuleType("torch.utils.tensorboard")
+
+    class SummaryWriter:
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+    tb.SummaryWriter = SummaryWriter
+    sys.modules["torch.utils.tensorboard"] = tb
+
+    class Cfg(dict):
+        """attribute access like omegaconf's DictConfig (base_trainer.py reads config.dataset, config.loss.functions, ...)"""
+        def __getattr__(self, k):
+            v = self[k]
+            return Cfg(v) if isinstance(v, dict) else v
+
+    from neddf.trainer import NeRFTrainer
+    import io
+    import contextlib
+    from pathlib import Path
+    cfg = yaml.safe_load(open(os.path.join(REF, "pretrained/bunny_smoke/.hydra/config.yaml")))
+    cfg["dataset"]["dataset_dir"] = os.path.join(HERE, "bunny_mini")
+    cfg["dataset"]["data_split"] = "test"                  # run_eval.py:27 override
+    tcfg = dict(cfg["trainer"], device="cpu")
+    tcfg.pop("_target_")
+    trainer = NeRFTrainer(global_config=Cfg(cfg), **tcfg)
+    # the checkpoint was saved from cuda:0 and base_trainer.py:121 calls torch.load without map_location: on this GPU-less
+    # container the storages have to be mapped to the CPU (an accommodation of the environment, not of the algorithm)
+    torch_load = torch.load
+    torch.load = lambda f, *a, **k: torch_load(f, *a, **dict(k, map_location="cpu"))
+    try:
+        trainer.load_pretrained_model(Path(REF) / "pretrained/bunny_smoke/models/model_02000.pth")
+    finally:
+        torch.load = torch_load
+    trainer.neural_render.set_iter(-1)                      # render_all, base_trainer.py:185
+    arrs = {"seed": np.int32(11), "chunk": np.int32(trainer.chunk), "num_threads": np.int32(torch.get_num_threads())}
+    for cam_id in (0, 1):
+        torch.manual_seed(11 + cam_id)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            trainer.render_test(Path("/nonexistent"), cam_id, 1)
+        line = [ln for ln in buf.getvalue().splitlines() if ln.startswith("psnr:")][0]
+        for suffix in ("rgb", "rgb_gt", "depth"):
+            arrs["cam%d_%s" % (cam_id, suffix)] = captured.pop("%03d_%s.png" % (cam_id, suffix))
+        assert not captured
+        (k0, a0, b0), (k1, a1, b1, axis) = metric_args[-2:]
+        assert k0 == "psnr" and k1 == "ssim" and axis == 2
+        for a in (a0, a1):
+            assert np.array_equal(a, arrs["cam%d_rgb" % cam_id])                     # first argument: the render
+        for b in (b0, b1):
+            assert np.array_equal(b, arrs["cam%d_rgb_gt" % cam_id])                  # second: the ground truth
+        arrs["cam%d_psnr" % cam_id] = np.float64(line.split("psnr: ")[1].split(",")[0])
+        arrs["cam%d_printout" % cam_id] = np.array(line)
+        print("  eval harness camera %d: %s  rgb %s depth %s" % (cam_id, line, arrs["cam%d_rgb" % cam_id].shape,
+                                                                  arrs["cam%d_depth" % cam_id].shape))
+    # half-resolution render of camera 0 (the trainer's periodic test rendering, nerf_trainer.py: render_test(dir, id, 2)):
+    # no metrics printed, the ground truth written at full size
+    torch.manual_seed(13)
+    trainer.render_test(Path("/nonexistent"), 0, 2)
+    for suffix in ("rgb", "rgb_gt", "depth"):
+        arrs["ds2_%s" % suffix] = captured.pop("000_%s.png" % suffix)
+    save("eval_harness.npz", **arrs)
+
+
 def gen_grids(render):
     """NeRFRender.render_field_slice (nerf_render.py:263-336; scalar fields as the uint8 image handed to
     cv2.applyColorMap) and BaseNeuralField.voxelize (base_neuralfield.py:49-79) of the shipped bunny_smoke field."""
@@ -1354,6 +1448,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dataset":
         gen_dataset()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "eval_harness":
+        gen_eval_harness()
+        sys.exit(0)
     r = gen_bunny()
     if len(sys.argv) > 1 and sys.argv[1] == "grids":
         gen_grids(r)
@@ -1379,3 +1476,4 @@ if __name__ == "__main__":
     gen_stages_random()
     gen_rays_random()
     gen_train_render_random()
+    gen_eval_harness()  # replaces cv2.imwrite / skimage / tensorboard stubs: keep it last

@@ -215,7 +215,7 @@ class Cam:
     device = torch.device("cpu")
     def descriptor(self):
         return None
-W, H, CHUNK = 12, 10, 50                           # the geometry of tests/golden/bunny_image_small.npz
+W, H, CHUNK = (int(v) for v in os.environ.get("NEDDF_TEST_FRAME", "12,10,50").split(","))   # default: the geometry of tests/golden/bunny_image_small.npz
 torch.manual_seed(0)
 uc, uf = [], []
 for b0 in range(0, W * H, CHUNK):                  # nerf_render.py:237-244 + :137 + base_neural_render.py:75
@@ -234,6 +234,15 @@ assert lo % CHUNK == 0
 first = (lo // CHUNK) * CHUNK
 chunks_touched = range(first, min(W * H, ((hi + CHUNK - 1) // CHUNK) * CHUNK), CHUNK)
 assert stub.drawn == (hi - lo) * 194, (stub.drawn, hi - lo)     # only the slab's rows reach the device
+# the gather of a chunk-granular (ragged) frame on the route this process group agreed on: padded staging by default, one broadcast per
+# slab when EVERY rank asked for NEDDF_GATHER_INPLACE=1 -- a single dissenter keeps all ranks on the padded route instead of hanging them
+from neddf_amd import parallel
+want_in_place = os.environ.get("NEDDF_TEST_EXPECT_INPLACE") == "1"
+if -(-W * H // CHUNK) % world and world > 1:
+    assert parallel._host_route_in_place() == want_in_place, "route agreement"
+pix = torch.arange(W * H * 5, dtype=torch.float32).reshape(W * H, 5)
+got = gather_pixels(pix[lo:hi].clone(), W * H, granule=CHUNK)
+assert torch.equal(got, pix), "chunk-granular gather mismatch"
 
 class FakeRender:                                  # the HIP renderer replaced by a pure function of the pixel index
     def render_image(self, width, height, camera, keys, downsampling, chunk, pixel_range=None):
@@ -319,6 +328,29 @@ def test_sharded_gather_two_ranks_gloo(tmp_path, world):
     script.write_text(_WORKER)
     from conftest import run_ranks
     run_ranks(lambda r, port: [sys.executable, str(script), ROOT, port, str(r), str(world)], world, timeout=240)
+
+
+@pytest.mark.parametrize("route", ["staged", "in_place", "one_dissenter"])
+def test_sharded_gather_eight_ranks_ragged_gloo(tmp_path, route):
+    """BASELINE.json configs[3]'s rank count, rehearsed on the CPU: 8 ranks, a 37 x 29 frame at chunk 100 = 11 chunks (the last one 73
+    rays) -> slabs of 2, 2, 2, 1, 1, 1, 1, 1 chunks -- the first world size at which a strong-scaled 800 x 800 frame (1 250 chunks ->
+    157 / 156 per rank) is ragged.  Both routes of the ragged gather (padded staging; one broadcast per slab under
+    NEDDF_GATHER_INPLACE=1 on every rank), and the agreement that keeps every rank on the padded route when ONE rank did not ask for
+    the in-place one (comm_capi.hip's neddf_comm_init makes the same vote over RCCL).  The slab uniforms, the generator's end state
+    and the data-parallel helpers run at world 8 with it."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    from conftest import run_ranks
+    world = 8
+    envs = []
+    for r in range(world):
+        e = dict(os.environ, NEDDF_TEST_FRAME="37,29,100", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        e.pop("NEDDF_GATHER_INPLACE", None)
+        if route == "in_place" or (route == "one_dissenter" and r != 5):
+            e["NEDDF_GATHER_INPLACE"] = "1"
+        e["NEDDF_TEST_EXPECT_INPLACE"] = "1" if route == "in_place" else "0"
+        envs.append(e)
+    run_ranks(lambda r, port: [sys.executable, str(script), ROOT, port, str(r), str(world)], world, env=envs, timeout=420)
 
 
 def _make_dataset(root, n=2, w=20, h=16, seed=0, split="test"):

@@ -383,3 +383,60 @@ def test_oracle_rays_on_random_cameras():
         pos, d, var = orc.sampling(g[pre + "ray_dir"], g[pre + "ray_orig"], g[pre + "dists"], None)
         assert_close(pos, g[pre + "point_pos"], 1e-6, 1e-7, "seed %d point pos" % seed)
         assert float(np.abs(var).max()) == 0.0
+
+
+def _uint8_gate(got, want, what):
+    """<= 1 count on <= 0.5 % of the values: a 1e-4 difference on the float side of `astype(uint8)` can move a value across an
+    integer boundary; a wrong constant, channel order or depth scale moves (nearly) all of them."""
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert got.shape == want.shape and got.dtype == want.dtype == np.uint8, (what, got.shape, want.shape)
+    assert d.max() <= 1 and np.mean(d > 0) <= 0.005, "%s: max |diff| %d counts, %.3f %% of values differ" % (what, d.max(), 100 * np.mean(d > 0))
+
+
+def test_eval_harness_outputs_vs_reference(bunny_weights):
+    """SURVEY 8 A1 / 8f item 1 against the REFERENCE'S OWN harness: tests/golden/eval_harness.npz holds the uint8 arrays the
+    reference's `NeRFTrainer.render_test` (base_trainer.py:123-174) handed to `cv2.imwrite` for tests/golden/bunny_mini's two test
+    views (72 x 56, chunk 1024: a short last chunk), and the PSNR it printed.  Here: the oracle renders view 0 with the uniforms in
+    the reference's chunk order and the conversion constants are applied -- colour `clamp(c * 255)`, depth
+    `clamp((d - 2) / 4 * 50000 / 256)`, B,G,R order, ground truth = premultiplied colour -- and the PSNR of the stored arrays is
+    recomputed by the product's `metrics.peak_signal_noise_ratio`."""
+    import torch
+    from neddf_amd.dataset import NeRFSyntheticDataset
+    from neddf_amd.metrics import peak_signal_noise_ratio
+    from scipy.spatial.transform import Rotation
+    import os
+    from conftest import GOLDEN
+    g = golden("eval_harness.npz")
+    ds = NeRFSyntheticDataset(os.path.join(GOLDEN, "bunny_mini"), "test", use_mask=True)
+    for cam in (0, 1):
+        assert np.array_equal(ds[cam]["rgb_images"].astype(np.uint8), g["cam%d_rgb_gt" % cam])
+        assert abs(peak_signal_noise_ratio(g["cam%d_rgb" % cam], g["cam%d_rgb_gt" % cam]) - float(g["cam%d_psnr" % cam])) < 1e-9
+        assert str(g["cam%d_printout" % cam]).startswith("psnr: %s, ssim: " % repr(float(g["cam%d_psnr" % cam])))
+    h, w = g["cam0_rgb"].shape[:2]
+    assert (w, h) == (72, 56) and g["cam0_depth"].shape == (h, w, 1)
+    item = ds[0]
+    p = np.asarray(item["camera_params"], np.float64)
+    R = Rotation.from_rotvec(p[:3]).as_matrix().astype(np.float32)
+    Tr = p[3:6].astype(np.float32)
+    calib = np.asarray(item["camera_calib_params"], np.float32)
+    us, vs = np.meshgrid(np.arange(w), np.arange(h))
+    uv = np.stack([us.reshape(-1), vs.reshape(-1)], 1).astype(np.int64)          # nerf_render.py:222-231: idx = v * w + u
+    net = orc.NeDDFOracle(bunny_weights, **BUNNY_CFG)
+    net.set_iter(-1)
+    chunk = int(g["chunk"])
+    torch.manual_seed(int(g["seed"]))
+    col, dep = [], []
+    for lo in range(0, uv.shape[0], chunk):
+        n = min(chunk, uv.shape[0] - lo)
+        uc, uf = torch.rand(n, 65).numpy(), torch.rand(n, 129).numpy()           # nerf_render.py:137, base_neural_render.py:75
+        o = orc.render_rays(net, net, uv[lo:lo + n], R, Tr, calib, uc, uf, 2.0, 6.0, 6.0, "cone")
+        col.append(o["color"]); dep.append(o["depth"])
+    col = np.concatenate(col).reshape(h, w, 3)
+    dep = np.concatenate(dep).reshape(h, w, 1)
+    f32 = np.float32
+    rgb = np.clip(col * f32(255), 0, 255).astype(np.uint8)
+    dpt = np.clip((dep - f32(2.0)) / f32(4.0) * f32(50000) / f32(256), 0, 255).astype(np.uint8)
+    _uint8_gate(rgb, g["cam0_rgb"], "colour image")
+    _uint8_gate(dpt, g["cam0_depth"], "depth image")
+    assert len(np.unique(g["cam0_rgb"])) > 50 and len(np.unique(g["cam0_depth"])) > 20      # the frame is not flat
+    assert abs(peak_signal_noise_ratio(rgb, g["cam0_rgb_gt"]) - float(g["cam0_psnr"])) < 0.01
