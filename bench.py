@@ -596,9 +596,7 @@ def main():
         pts = n_local * samples_per_ray * args.steps              # field evaluations on this rank
         ddf_s = tm["ddf_ms"] / 1e3
         # the library's rule (neddf_capi.hip field_forward): fp32 eval-minimal takes the reverse-mode kernel unless switched off
-        rev_mask = int(os.environ.get("NEDDF_DDF_REVERSE_DTYPES", "7"))
-        reverse = (bool((rev_mask >> {"f32": 0, "bf16": 1, "f16_split": 2}[args.dtype]) & 1) and os.environ.get("NEDDF_DDF_REVERSE", "1") != "0"
-                   and os.environ.get("NEDDF_TILE_MT", "2") != "4")
+        reverse = os.environ.get("NEDDF_DDF_REVERSE", "1") != "0"
         flop_fwd, flop_rev, flop_col = field_flops(render.bench_network_config)
         DDF_FLOP_PER_POINT = flop_rev if reverse else flop_fwd
         achieved = pts * DDF_FLOP_PER_POINT / ddf_s / 1e12 if ddf_s > 0 else 0.0

@@ -26,6 +26,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libneddf_hip.so is built with -fvisibility=hidden: the entry points declared between this push and the pop at the end of the
+ * file are its whole export list (tests/test_host.py holds `nm -D` to exactly these names). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define NEDDF_ABI_VERSION 5
 
@@ -328,6 +333,9 @@ int neddf_composite_backward(neddf_ctx *ctx, const float *d_dists, const float *
                              const float *d_g_color, const float *d_g_transmittance, float *d_g_density,
                              float *d_g_point_color, void *stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,8 @@ struct neddf_ctx {
     std::string err;
     Field field[NEDDF_NUM_SLOTS];
     DevBuf features, ptaux, scratch, arena, flags, sched;
+    int64_t handoff_chunk = 0;   // field_forward: launch size last settled for a hand-off of `handoff_row` bytes per point (0: none yet) --
+    size_t handoff_row = 0;      // the free-memory probe runs when the hand-off would have to GROW, not on every call
     DevBuf rflags;               // importance resampling: one NaN-fallback flag per group of rays
     DevBuf rev_scratch;          // reverse-mode distance kernel: per-workgroup y' of every layer + encoding Jacobian
     DevBuf tpack, ttmp;          // training step: packed weights of the layer in flight, gradient ping-pong buffers

@@ -29,10 +29,6 @@
 #include "device_math.h"
 #include "tile_engine.h"
 
-#include <stdio.h>
-#include <stdlib.h>
-
-#include <initializer_list>
 
 namespace neddf {
 
@@ -89,17 +85,8 @@ __device__ __forceinline__ void encode_dir(typename Ops::act_t *act, int col0, c
 // Tile scheduling: tiles are pulled from a global queue (one atomicAdd per tile,
 // issued a whole tile ahead of its use) instead of a static stride, so workgroups
 // that progress unevenly (two share a CU) do not unbalance the launch tail.
-// sched_flags (NEDDF_SCHED): bit 1 = dynamic queue (default on).  Bits 2..6 switch off phases of the distance
-// kernel for timing ablations (results invalid); they exist only in builds with -DNEDDF_ABLATE (`make ABLATE=1`, used
-// by tools/ablate_probe.py) and compile to nothing in the shipped library.
+// sched_flags bit 1 = dynamic queue (always on in the shipped library).
 // ctl[0] = next tile index, written by thread 0.
-#ifdef NEDDF_ABLATE
-#define NEDDF_ABL(flags, bit) ((flags) & (bit))
-constexpr bool kAblate = true;
-#else
-#define NEDDF_ABL(flags, bit) 0
-constexpr bool kAblate = false;
-#endif
 // Phase time stamps (-DNEDDF_STAMP, `make stamp`): lane 0 of every wave of the first kStampBlocks workgroups records s_memtime at
 // the phase boundaries of its kStampTile-th tile; neddf_capi.hip dumps them after the launch, tools/stamp_timeline.py prints them.
 #if defined(NEDDF_STAMP) && defined(NEDDF_STAMP_PAIRS)
@@ -202,10 +189,8 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
         __syncthreads();
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);     // consumed at the end of this tile
-        if (!(NEDDF_ABL(a.sched_flags, 32))) {
-            if (a.neus) encode_pos<true, false, Ops, THREADS>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid, false);   // plain PE (neus.py:118)
-            else encode_pos<true, true, Ops, THREADS>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
-        }
+        if (a.neus) encode_pos<true, false, Ops, THREADS>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid, false);   // plain PE (neus.py:118)
+        else encode_pos<true, true, Ops, THREADS>(act, 0, a.enc, lp, a.pos, a.var, p0, a.n_points, P, tid);
         __syncthreads();
 
         f32x16 acc[MT][NT];
@@ -250,7 +235,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
                 if (!done && !REENCODE) stash_add<MT, NT>(acc, scratch + (size_t)L.stash * kStashFloatsPerWg, wave, lane);
             }
             const frag *wl = (const frag *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane;
-            if (!(NEDDF_ABL(a.sched_flags, 8))) dense_pre<MT, NT, Ops>(acc, act_lane, wl, L.ksteps, pre);
+            dense_pre<MT, NT, Ops>(acc, act_lane, wl, L.ksteps, pre);
             if constexpr (REENCODE) {
                 if (L.stash >= 0) {
                     const StashW &sw = a.stash[L.stash];
@@ -266,15 +251,9 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
             }
             if (l + 1 < a.n_layers)                 // next layer's first fragments fly during the epilogue
                 layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
-            if (!(NEDDF_ABL(a.sched_flags, 64))) __syncthreads();   // every wave finished reading the previous activations
-            if (!(NEDDF_ABL(a.sched_flags, 4))) epilogue_rt<MT, NT, true, Ops>(acc, act, a.activation, wave, lane);
-            if (!(NEDDF_ABL(a.sched_flags, 64))) __syncthreads();
-        }
-        if (NEDDF_ABL(a.sched_flags, 16)) {                   // ablation: skip heads / hand-off
-            if (tid == 0) ctl[0] = next_tile;
+            __syncthreads();                        // every wave finished reading the previous activations
+            epilogue_rt<MT, NT, true, Ops>(acc, act, a.activation, wave, lane);
             __syncthreads();
-            tile = ctl[0];
-            continue;
         }
         if (a.neus) {       // NeuS: sdf = feature 0 of the last activated layer, normal = its Jacobian rows (neus.py:132-145)
             if (tid < P && p0 + tid < a.n_points) {
@@ -382,29 +361,17 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
 // after its product); and the activation is evaluated per element instead of once per four accumulator rows.
 // Used when the caller wants no penalties / Jacobian outputs (render_image, render_rays without fields_penalty); the
 // forward-mode kernel above serves the training-mode outputs.
-// Tile shape (MT M-tiles = 32 MT points per tile, NW waves, WPS workgroups per CU): 64 points, 4 waves, two workgroups per CU
-// under every operand policy.  The kernel is written over the shape because the obvious alternative was measured: 128-point
-// tiles on one 8-wave workgroup per CU (half the L2 -> VGPR weight stream per point) are SLOWER for the 16-bit policies (split
-// fp16 14.5 vs 12.4 ms, bf16 8.4 vs 8.4 ms per launch): with one workgroup per CU nothing covers its barriers and the y'
-// round trip, and two 128-point workgroups do not fit (bf16: 403 spilled registers at 128 accumulators + the y' sets).
-// y' of every layer + [encoding Jacobian factors | encoding copy | parked encoding gradient] (64 columns each) + the fused colour trunk's parked
-// first-layer product (one accumulator set)
-size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points, int width) { return (size_t)n_layers * points * width + (size_t)points * 192 + (size_t)points * width; }
+// Tile shape: MT M-tiles = 32 MT points per tile (64 at engine width 128 / 256, 32 at 384 / 512), four waves, two workgroups per CU
+// under every operand policy.  The alternatives were built and measured in rounds 2-5 (docs/lab_notebook.md R4.2, R5.3-R5.8): 128-point
+// tiles on eight waves or in two column passes per wave, three / four workgroups per CU, twin teams one barrier apart, the colour
+// trunk fused onto this tile -- equal or slower, removed from the product tree in round 6.
+// Per-workgroup scratch: y' of every layer + [encoding Jacobian factors | encoding copy | parked encoding gradient] (64 columns each)
+size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points, int width) { return (size_t)n_layers * points * width + (size_t)points * 192; }
 
-// -DNEDDF_STREAM_Y=1: the y' round trip and the feature hand-off of the reverse-mode kernel as non-temporal accesses (A/B switch)
-#ifndef NEDDF_STREAM_Y
-#define NEDDF_STREAM_Y 0
-#endif
-constexpr bool kStreamY = NEDDF_STREAM_Y != 0;       // measured: slower (fp32 -1 %, bf16 -8.6 %, split -0.9 %): the round trip lives on the L2 / MALL
-// -DNEDDF_REV_PREFETCH=1: the reverse products' first weight fragments requested a phase ahead, like the forward products' (A/B switch)
-#ifndef NEDDF_REV_PREFETCH
-#define NEDDF_REV_PREFETCH 0
-#endif
-constexpr bool kRevPrefetch = NEDDF_REV_PREFETCH != 0;
-constexpr int kRevSmallFloats = 3 * 512 + 16;      // head dots / lp / ctl / colour dots behind the tile (lds_bytes: small + 16; MT <= 8)
+constexpr int kRevSmallFloats = 3 * 512 + 16;      // head dots / lp / ctl / staged inputs and tail partials behind the tile (lds_bytes: small + 16)
 template <int KIND, bool LAST, int MT, int NT, class Ops>
 __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *yp, const float *wseed, int wave,
-                                                     int lane, int ymask)
+                                                     int lane)
 {
     constexpr int LD = Ops::kLd;
     constexpr bool MASK = KIND != 2 && !LAST;       // ReLU / LeakyReLU: y' leaves as one bit per element, built on the fly
@@ -439,10 +406,10 @@ __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], type
     // y' leaves in the accumulators' own fragment order (16 bytes per lane, 1 KiB per wave and store): only this workgroup's
     // same lanes read it back, so nothing needs it row-major.  Under the bf16 policy it travels as bf16 (the product it enters
     // is rounded to bf16 anyway): at that policy's speed the fp32 round trip (26 GB per launch) would be the kernel's bound
-    if (!LAST && (!kAblate || yp)) {
+    if (!LAST) {
         if constexpr (KIND == 2) {
-            if constexpr (Ops::kStash16) stash_store16<MT, NT, kStreamY>(acc, yp, wave, lane, ymask);
-            else stash_store<MT, NT, kStreamY>(acc, yp, wave, lane, ymask);
+            if constexpr (Ops::kStash16) stash_store16<MT, NT>(acc, yp, wave, lane);
+            else stash_store<MT, NT>(acc, yp, wave, lane);
         } else {
             // ReLU / LeakyReLU: y' takes two values, so ONE BIT per element travels (16 per accumulator tile, two tiles per
             // dword: 8 bytes per lane and layer instead of 256) -- 12 KB per workgroup for six layers, 6 MB per launch grid: it
@@ -465,72 +432,47 @@ __device__ __forceinline__ float mask_factor(unsigned bit, int kind)
 // MASKY kernels serve ReLU / LeakyReLU (y' as mask bits), the others tanhExp (y' as values): each carries only its own epilogues
 template <bool LAST, bool MASKY, int MT, int NT, class Ops>
 __device__ __forceinline__ void rev_forward_epilogue_rt(f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *yp, const float *wseed, int kind,
-                                                        int wave, int lane, int ymask = -1)
+                                                        int wave, int lane)
 {
     if constexpr (MASKY) {
-        if (kind == 0) rev_forward_epilogue<0, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane, ymask);
-        else rev_forward_epilogue<1, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane, ymask);
-    } else rev_forward_epilogue<2, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane, ymask);
+        if (kind == 0) rev_forward_epilogue<0, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane);
+        else rev_forward_epilogue<1, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane);
+    } else rev_forward_epilogue<2, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane);
 }
 
-// FUSED (round 4: one field kernel per slab): the colour trunk (neddf.py:243-257, value rows) runs on the SAME 64-point tile right after
-// the reverse pass -- its first layer's product with the trunk features is taken while the features still sit in LDS (before the
-// gradients overwrite them) and parked in the workgroup's scratch in accumulator layout; after the tail has produced the normal, the
-// tile's first columns receive [embed_pos | embed_dir | normal] (the unscaled encoding is the saved scaled one times 2^(e-1): exact,
-// no second sincos), the small-input product joins the parked one, and the remaining colour layers and the 256 -> 3 head follow.
-// No [N, 256] feature matrix, no per-point record, no second launch: the hand-off of 1 088 B per point never reaches HBM.
-// TEAMS = 2 (16-bit policies, round 5): ONE workgroup of eight waves per CU, two TEAMS of four waves, each on a 64-point tile of its
-// own (own LDS region, own scratch slot) running this very code -- with team 1 ONE BARRIER BEHIND team 0.  s_barrier counts arrivals,
-// not program locations: team 1 enters the tile loop through one extra barrier (team 0 leaves it through one), so its k-th barrier
-// pairs with team 0's (k + 1)-th and every phase boundary of a team is still a barrier all of its waves reach together.  The phases of
-// a tile alternate matrix work (a product) and vector work (an epilogue): with the teams one phase apart, a SIMD's two waves are in
-// COMPLEMENTARY phases by construction -- one's bf16 / f16 MFMAs beside the other's VALU, which gfx950 overlaps completely (R4.1) --
-// where two independent workgroups drift through every relative phase (both in their epilogues half of the time).  Tiles are handed
-// out in pairs (one queue entry = tiles 2 k and 2 k + 1) so that both teams run the same number of barriers; a missing last tile is
-// dummy work with every store masked.
-template <int MT, int NW, int WPS, class Ops, bool MASKY, bool FUSED = false, int TEAMS = 1>
-__global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void ddf_rev_kernel(const DdfArgs a, const ColArgs c)
+template <int MT, class Ops, bool MASKY>
+__global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
 {
     typedef typename Ops::act_t act_t;
     typedef typename Ops::bfrag frag;
-    constexpr int WID = Ops::kWid, NT = WID / 32 / NW, THREADS = 64 * NW, ROWS = MT * 32, P = ROWS, LD = Ops::kLd;
-    static_assert(TEAMS == 1 || (TEAMS == 2 && !FUSED && NW == 4), "twin teams: two four-wave teams, two-kernel route");
-    // LDS of one team: the tile, the small arrays behind it, the encoding's own tile (rev_lds_bytes)
-    constexpr size_t TEAM_BYTES = (size_t)ROWS * LD * sizeof(act_t) + (size_t)kRevSmallFloats * sizeof(float) +
-                                  (Ops::kEncInLds ? (size_t)ROWS * kEncLd * sizeof(act_t) : 0);
-    static_assert(TEAM_BYTES % 16 == 0, "a team's LDS region keeps the 16-byte alignment of the fragments");
-    static_assert(NT >= 1 && NT * 32 * NW == WID, "engine width = NW waves x NT column tiles of 32");
+    constexpr int NW = kWaves, WID = Ops::kWid, NT = WID / 32 / NW, THREADS = kThreads, ROWS = MT * 32, P = ROWS, LD = Ops::kLd;
+    static_assert(NT >= 1 && NT * 32 * NW == WID, "engine width = four waves x NT column tiles of 32");
+    static_assert(MT == 1 || MT == 2, "32- or 64-point tiles");
     // 32 x 32 blocks of the [P, 64] encoding gradient per wave; a 32-point tile has two blocks for four waves: the upper waves idle there
     constexpr int NBLK = 2 * MT, BPW = NBLK >= NW ? NBLK / NW : 1;
     static_assert(BPW * NW == NBLK || NBLK < NW, "the encoding gradient's blocks must divide over the waves");
+    constexpr int PARTS = THREADS / ROWS;               // threads per point in the tail
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int team = TEAMS > 1 ? (int)threadIdx.x / THREADS : 0;
-    act_t *act = (act_t *)((char *)smem + (size_t)team * TEAM_BYTES);
+    act_t *act = (act_t *)smem;
     float *hd = (float *)(act + ROWS * LD);  // [2 k-halves][2 heads][ROWS] head dot products
     float *lp = hd + 6 * ROWS;
-    const int tid = TEAMS > 1 ? (int)threadIdx.x % THREADS : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
-    float *yp = a.rev_scratch + ((size_t)blockIdx.x * TEAMS + team) * ((size_t)a.n_layers * P * WID + (size_t)P * 192 + (size_t)P * WID);
+    float *yp = a.rev_scratch + (size_t)blockIdx.x * ((size_t)a.n_layers * P * WID + (size_t)P * 192);
     float *pj = yp + (size_t)a.n_layers * ROWS * WID;           // [ROWS][64] dPE/dx factors: [q] sine half, [32 + q] cosine half
-    float *pv = pj + ROWS * 64;                                  // [ROWS][64] the encoding itself, for the skip layer (and the colour trunk's inputs)
+    float *pv = pj + ROWS * 64;                                  // [ROWS][64] the encoding itself, for the skip layer
     float *pg = pv + ROWS * 64;                                  // [ROWS][64] the skip layers' share of the encoding gradient, parked
-    float *cpark = pg + ROWS * 64;                               // [ROWS][WID] FUSED: the colour trunk's first-layer product with the features
-    float *chd = lp + 16;                                        // FUSED: [THREADS][3] partial colour dots (behind lp / ctl)
+    float *stg = lp + 16;                                        // [6 ROWS] staged positions / variances, later [PARTS][3][ROWS] tail partials (behind lp / ctl)
     // Ops::kEncInLds (bf16: the tile is half the bytes): the encoding also lives in a narrow LDS tile of its own for the whole tile, so a
     // skip layer multiplies it from there -- no reload from the scratch, no extra barriers (14.1 k -> 6.5 k cycles for that layer)
     act_t *enc_tile = (act_t *)(hd + kRevSmallFloats);
     const act_t *enc_lane = act_lane_ptr<EncView<Ops>>(enc_tile, lane);
-    static_assert(!FUSED || NW == 4, "the fused colour phases are laid out for four waves");
     if (tid == 0) {
 #pragma unroll
         for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
     }
     const int kin = Ops::kStep * a.layer[0].ksteps;
     const int K3 = 3 * a.enc.E, KH = a.enc.KH;
-    // four-wave workgroups stage the tile's inputs in LDS and spread the tail over every thread (round 5); the eight-wave probes keep the
-    // per-item loads (their 3 x 512 floats of tail partials do not fit behind the tile)
-    constexpr bool STAGED = NW == 4 && MT <= 4;
-    constexpr int PARTS = THREADS / ROWS;               // threads per point in the tail
     const unsigned k3magic = (1u << 20) / (unsigned)K3 + 1u;
     const int64_t ntiles = (a.n_points + P - 1) / P;
     // super-steps of a 256-wide product, as a RUN-TIME value (the argument block carries it, DdfArgs::ks_hidden): with the compile-time constant hipcc
@@ -538,43 +480,33 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
     // behind an s_waitcnt vmcnt(0) -- which serialises the operand prefetch of half of the kernel's matrix work
     const int KS = a.ks_hidden;
     const int j = lane & 31, h = lane >> 5;
-    // timing probes of the y' round trip (-DNEDDF_ABLATE builds only, results invalid): 128 = every layer shares one slot
-    // (footprint / 6), 512 = and every M-tile folds onto the first (footprint / 12: L2-resident), 256 = no y' traffic at all
-    const int ylstep = NEDDF_ABL(a.sched_flags, 128) ? 0 : 1, ymask = NEDDF_ABL(a.sched_flags, 512) ? 0 : -1;
-    const bool ynone = NEDDF_ABL(a.sched_flags, 256);
-    constexpr bool masked = MASKY;                  // ReLU / LeakyReLU: y' is one bit per element (rev_forward_epilogue)
 
-    // the queue entry travels through team 0's control word (team 1 reads it one barrier after team 0 wrote it, a whole tile before the next write)
-    int *ctl = (int *)((float *)((act_t *)smem + ROWS * LD) + 6 * ROWS + 12);
+    int *ctl = (int *)(lp + 12);
     NEDDF_STAMP_DECL;
-    int64_t unit = sched_begin(a.sched, a.sched_flags, ctl, (int)threadIdx.x);         // a tile, or a pair of tiles (TEAMS = 2)
-    if (TEAMS > 1 && team == 1) __syncthreads();     // team 1 runs one barrier behind
-    while (unit * TEAMS < ntiles) {
-        const int64_t tile = unit * TEAMS + team;
+    int64_t tile = sched_begin(a.sched, a.sched_flags, ctl, tid);
+    while (tile < ntiles) {
         NEDDF_STAMP_TILE();
         STAMP_WALL(0);
         STAMP();                                    // 0: tile start
         const int64_t p0 = tile * P;
         LayerPre<NT, Ops> pre;
         layer_prefetch<NT, Ops>(pre, a.layer[0].wp, a.layer[0].bias, a.layer[0].ksteps, wave, lane);
-        if constexpr (STAGED) {
-            // the tile's positions / variances in ONE coalesced request per array into LDS (the colour-dot area, free until the end of
-            // the tile): the encoding loop below then waits on LDS only -- per-item global loads were a chain of dependent L2 round trips
-            // (8 per thread and tile: 14 k of a bf16 tile's 191 k cycles, profiles/r04_stamp_timeline_bf16.txt)
-            if (a.rays.rd) {        // the points come from the rays: cone / point moments here, no sampling tensors (kernels.h RaySrc)
-                if (tid < ROWS) {
-                    const int64_t gp = p0 + tid < a.n_points ? p0 + tid : a.n_points - 1;
-                    float ps[3], vr[3], dr[3];
-                    ray_point(a.rays, a.rays.base + gp, ps, vr, dr);
+        // the tile's positions / variances in ONE coalesced request per array into LDS (the tail's partial-sum area, free until the end of
+        // the tile): the encoding loop below then waits on LDS only -- per-item global loads were a chain of dependent L2 round trips
+        // (8 per thread and tile: 14 k of a bf16 tile's 191 k cycles, profiles/r04_stamp_timeline_bf16.txt)
+        if (a.rays.rd) {        // the points come from the rays: cone / point moments here, no sampling tensors (kernels.h RaySrc)
+            if (tid < ROWS) {
+                const int64_t gp = p0 + tid < a.n_points ? p0 + tid : a.n_points - 1;
+                float ps[3], vr[3], dr[3];
+                ray_point(a.rays, a.rays.base + gp, ps, vr, dr);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { chd[tid * 3 + k] = ps[k]; chd[3 * ROWS + tid * 3 + k] = a.neus ? 0.0f : vr[k]; }
-                }
-            } else
-            for (int idx = tid; idx < 6 * ROWS; idx += THREADS) {
-                const int k = idx < 3 * ROWS ? idx : idx - 3 * ROWS, p = (k * 43691) >> 17, d = k - 3 * p;      // k / 3 for k < 3 * 128
-                const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
-                chd[idx] = idx < 3 * ROWS ? a.pos[gp * 3 + d] : (a.neus ? 0.0f : a.var[gp * 3 + d]);
+                for (int k = 0; k < 3; ++k) { stg[tid * 3 + k] = ps[k]; stg[3 * ROWS + tid * 3 + k] = a.neus ? 0.0f : vr[k]; }
             }
+        } else
+        for (int idx = tid; idx < 6 * ROWS; idx += THREADS) {
+            const int k = idx < 3 * ROWS ? idx : idx - 3 * ROWS, p = (k * 43691) >> 17, d = k - 3 * p;      // k / 3 for k < 3 * 128
+            const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
+            stg[idx] = idx < 3 * ROWS ? a.pos[gp * 3 + d] : (a.neus ? 0.0f : a.var[gp * 3 + d]);
         }
         zero_cols<Ops, THREADS>(act, ROWS, kin, tid);
         if constexpr (Ops::kEncInLds) {
@@ -582,19 +514,13 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
         }
         __syncthreads();
         int next_tile = 0;
-        if (threadIdx.x == 0) next_tile = sched_next(a.sched, a.sched_flags, unit);
+        if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
         // scaled integrated encoding (neddf.py:193-204), value rows; the factors of its Jacobian go to the scratch
         for (int item = tid; item < P * K3; item += THREADS) {
             // item / K3 for item < 4096, K3 <= 30: (item * magic) >> 20 is exact; q / 3 for q < 30: (q * 11) >> 5
-            const int p = STAGED ? (int)(((unsigned)item * k3magic) >> 20) : item / K3, q = item - p * K3;
-            const int e = STAGED ? (q * 11) >> 5 : q / 3, d = q - 3 * e;
-            float px, vx;
-            if constexpr (STAGED) {
-                px = chd[p * 3 + d]; vx = chd[3 * ROWS + p * 3 + d];
-            } else {
-                const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
-                px = a.pos[gp * 3 + d]; vx = a.neus ? 0.0f : a.var[gp * 3 + d];
-            }
+            const int p = (int)(((unsigned)item * k3magic) >> 20), q = item - p * K3;
+            const int e = (q * 11) >> 5, d = q - 3 * e;
+            const float px = stg[p * 3 + d], vx = stg[3 * ROWS + p * 3 + d];
             float vs, vc, js, jc;
             if (a.neus) pe_pair<false, Ops::kFast>(e, px, 0.0f, lp[e], vs, vc, js, jc);      // plain PE (neus.py:118)
             else pe_pair<true, Ops::kFast>(e, px, vx, lp[e], vs, vc, js, jc);
@@ -641,12 +567,10 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
                 dense<MT, NT, Ops>(acc, act_lane + sw.col0, (const frag *)sw.wp + (size_t)wave * NT * sw.ksteps * 64 + lane, sw.ksteps);
             }
             if (l + 1 < a.n_layers) layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
-            else if (kRevPrefetch && !FUSED && a.n_layers > 1)    // ... and the reverse pass's first product likewise (its weights are known now)
-                layer_prefetch<NT, Ops>(pre, a.wT[a.n_layers - 1], nullptr, KS, wave, lane);
             STAMP();                                // forward layer l: 3 + 4l product done
             __syncthreads();
             STAMP();                                //                  4 + 4l barrier passed
-            if (l + 1 < a.n_layers) rev_forward_epilogue_rt<false, MASKY, MT, NT, Ops>(acc, act, ynone ? nullptr : yp + (size_t)(l * ylstep) * ROWS * WID, nullptr, a.activation, wave, lane, ymask);
+            if (l + 1 < a.n_layers) rev_forward_epilogue_rt<false, MASKY, MT, NT, Ops>(acc, act, yp + (size_t)l * ROWS * WID, nullptr, a.activation, wave, lane);
             else rev_forward_epilogue_rt<true, MASKY, MT, NT, Ops>(acc, act, nullptr, a.w_ddf_out, a.activation, wave, lane);
             STAMP();                                //                  5 + 4l epilogue done
             __syncthreads();
@@ -669,22 +593,14 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
             }
             hd[item] = (s0 + s1) + (s2 + s3);
         }
-        if constexpr (FUSED) {
-            // colour layer 0, feature segment (neddf.py:243: cat[..., features]): the features are this tile right now; the seed of the
-            // reverse pass stays in `acc` (parking it in the last layer's y' slot instead measured 3 % slower: r04_fused_field_kernel.txt)
-            f32x16 cacc[MT][NT];
-            acc_init<MT, NT, false>(cacc, c.layer[0].bias, wave, lane, Ops::kWScale);
-            dense<MT, NT, Ops>(cacc, act_lane, (const frag *)c.layer[0].wp + (size_t)wave * NT * c.layer[0].ksteps * 64 + lane, c.layer[0].ksteps);
-            stash_store<MT, NT>(cacc, cpark, wave, lane);
-        } else {
+        {
             constexpr int CE = 16 / sizeof(act_t), CPP = WID / CE, CPR = Ops::kPlanes * CPP;
             act_t *features = (act_t *)a.features;
             for (int idx = tid; features && idx < P * CPR; idx += THREADS) {
                 const int p = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
                 if (p0 + p < a.n_points) {
                     f32x4v v = *(const f32x4v *)(act + p * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));
-                    if constexpr (kStreamY) __builtin_nontemporal_store(v, (f32x4v *)(features + (size_t)(p0 + p) * (Ops::kPlanes * WID) + CE * c4));
-                    else *(f32x4v *)(features + (size_t)(p0 + p) * (Ops::kPlanes * WID) + CE * c4) = v;
+                    *(f32x4v *)(features + (size_t)(p0 + p) * (Ops::kPlanes * WID) + CE * c4) = v;
                 }
             }
         }
@@ -730,50 +646,34 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
                 }
                 parked = true;
             }
-            // y'_{l-1} of this lane's accumulator positions comes back M-tile by M-tile through two register sets: the first two
-            // are requested after the product (requesting them before it -- 64 more live registers -- measured no faster: the
-            // CU's other waves cover the latency), the others while the previous M-tile is multiplied and stored
-            f32x16 yb[MT >= 4 ? 1 : 2][MT >= 4 ? 1 : NT];
-            const f32x4v *ysrc = (const f32x4v *)(yp + (size_t)((l - 1) * ylstep) * ROWS * WID) + (size_t)wave * (MT * NT * (Ops::kStash16 ? 2 : 4)) * 64 + lane;
+            // y'_{l-1} of this lane's accumulator positions comes back M-tile by M-tile through two register sets, requested after the
+            // product (requesting them before it -- 64 more live registers -- measured no faster: the CU's other waves cover the latency)
+            f32x16 yb[2][NT];
+            const f32x4v *ysrc = (const f32x4v *)(yp + (size_t)(l - 1) * ROWS * WID) + (size_t)wave * (MT * NT * (Ops::kStash16 ? 2 : 4)) * 64 + lane;
             auto load_y = [&](f32x16 (&dst)[NT], int mt) {
-                mt &= ymask;
-                if (ynone) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) dst[t][q] = 1.0f;
-                    return;
-                }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    if constexpr (Ops::kStash16) stash_load16<kStreamY>(dst[t], (const u32x4 *)ysrc + ((mt * NT + t) * 2) * 64);
+                    if constexpr (Ops::kStash16) stash_load16(dst[t], (const u32x4 *)ysrc + ((mt * NT + t) * 2) * 64);
                     else
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            f32x4v v = kStreamY ? __builtin_nontemporal_load(&ysrc[((mt * NT + t) * 4 + g) * 64]) : ysrc[((mt * NT + t) * 4 + g) * 64];
+                            f32x4v v = ysrc[((mt * NT + t) * 4 + g) * 64];
                             dst[t][4 * g] = v[0]; dst[t][4 * g + 1] = v[1]; dst[t][4 * g + 2] = v[2]; dst[t][4 * g + 3] = v[3];
                         }
                 }
             };
-            if (kRevPrefetch && !FUSED) acc_init_pre<MT, NT, false, Ops>(acc, pre);        // (bias-free: zeros)
-            else acc_init<MT, NT, false>(acc, nullptr, wave, lane);
+            acc_init<MT, NT, false>(acc, nullptr, wave, lane);
             constexpr int NMW = (MT * NT + 1) / 2;
             unsigned mw[NMW];
-            if constexpr (masked) {     // ReLU / LeakyReLU: the layer's mask bits (rev_forward_epilogue), requested ahead of the product
-                const unsigned *msrc = (const unsigned *)(yp + (size_t)((l - 1) * ylstep) * ROWS * WID) + (size_t)wave * NMW * 64 + lane;
+            if constexpr (MASKY) {      // ReLU / LeakyReLU: the layer's mask bits (rev_forward_epilogue), requested ahead of the product
+                const unsigned *msrc = (const unsigned *)(yp + (size_t)(l - 1) * ROWS * WID) + (size_t)wave * NMW * 64 + lane;
 #pragma unroll
                 for (int w = 0; w < NMW; ++w) mw[w] = msrc[w * 64];
             }
             STAMP();                    // reverse layer: +0 skip share / setup done
-            if (kRevPrefetch && !FUSED) {
-                // the first fragments of this product were requested a phase ago (before the last epilogue / the y' multiply of the layer
-                // above); the next product's go out now, to land during this layer's y' multiply and its barriers
-                dense_pre<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS, pre);
-                if (l > 1) layer_prefetch<NT, Ops>(pre, a.wT[l - 1], nullptr, KS, wave, lane);
-            } else
             dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
             STAMP();                    //                +1 product done
-            if constexpr (masked) {
+            if constexpr (MASKY) {
                 __syncthreads();        // every wave finished reading g_l
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -789,55 +689,23 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
                     }
                 __syncthreads();
             } else {
-            if constexpr (MT >= 4) {
-                // 128-point tiles: 128 accumulator registers leave no room for two M-tiles of y' -- one 32 x 32 block at a time through two
-                // 16-register sets, block i + 2 requested while block i is multiplied and stored
-                constexpr int NB = MT * NT;
-                f32x16 y1[2];
-                auto load_blk = [&](f32x16 &dst, int i) {
-                    if constexpr (Ops::kStash16) stash_load16<kStreamY>(dst, (const u32x4 *)ysrc + (i * 2) * 64);
-                    else
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            f32x4v v = kStreamY ? __builtin_nontemporal_load(&ysrc[(i * 4 + g) * 64]) : ysrc[(i * 4 + g) * 64];
-                            dst[4 * g] = v[0]; dst[4 * g + 1] = v[1]; dst[4 * g + 2] = v[2]; dst[4 * g + 3] = v[3];
-                        }
-                };
-                load_blk(y1[0], 0);
-                load_blk(y1[1], 1);
+                load_y(yb[0], 0);
+                if (MT > 1) load_y(yb[1], 1);
                 __syncthreads();            // every wave finished reading g_l
-                STAMP();
+                STAMP();                    //                +2 barrier passed
 #pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int mt = i / NT, t = i % NT;
-                    act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int q = 0; q < 16; q += 2)
-                        Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, acc[mt][t][q] * y1[i & 1][q],
-                                  acc[mt][t][q + 1] * y1[i & 1][q + 1]);
-                    if (i + 2 < NB) load_blk(y1[i & 1], i + 2);
-                }
-            } else {
-            load_y(yb[0], 0);
-            if (MT > 1) load_y(yb[1], 1);
-            __syncthreads();            // every wave finished reading g_l
-            STAMP();                    //                +2 barrier passed
+                    for (int t = 0; t < NT; ++t) {
+                        act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
-#pragma unroll
-                    for (int q = 0; q < 16; q += 2)
-                        Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, acc[mt][t][q] * yb[mt & 1][t][q],
-                                  acc[mt][t][q + 1] * yb[mt & 1][t][q + 1]);
-                }
-                if (mt + 2 < MT) load_y(yb[mt & 1], mt + 2);
-            }
-            }
-            STAMP();                    //                +3 y' multiply + store done
-            __syncthreads();
-            STAMP();                    //                +4 barrier passed
+                        for (int q = 0; q < 16; q += 2)
+                            Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, acc[mt][t][q] * yb[mt & 1][t][q],
+                                      acc[mt][t][q + 1] * yb[mt & 1][t][q + 1]);
+                    }
+                STAMP();                    //                +3 y' multiply + store done
+                __syncthreads();
+                STAMP();                    //                +4 barrier passed
             }
         }
         f32x16 gpe[BPW][1];
@@ -870,9 +738,9 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
             }
         }
         __syncthreads();
-        // ---- per point: grad_x z_D = sum over the encoding channels of g_pe * dPE/dx, then the head arithmetic (neddf.py:220-241)
-        float nrm[3] = { 0.f, 0.f, 0.f };          // FUSED: the normal of this thread's point, input of the colour trunk
-        if constexpr (STAGED) {     // PARTS threads per point, every PARTS-th frequency each: the 60-term contraction was one wave's work while three idled
+        // ---- per point: grad_x z_D = sum over the encoding channels of g_pe * dPE/dx (PARTS threads per point, every PARTS-th frequency
+        // each: the 60-term contraction was one wave's work while three idled), then the head arithmetic (neddf.py:220-241)
+        {
             const int part = tid / ROWS, p = tid - part * ROWS;
             const act_t *gr = act + p * LD;
             const float *pjr = pj + p * 64;
@@ -885,28 +753,16 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
                     gp_[d] = fmaf(Ops::get(gr + KH + q), pjr[32 + q], gp_[d]);
                 }
 #pragma unroll
-            for (int d = 0; d < 3; ++d) chd[(part * 3 + d) * ROWS + p] = gp_[d];
+            for (int d = 0; d < 3; ++d) stg[(part * 3 + d) * ROWS + p] = gp_[d];
             __syncthreads();
         }
         if (tid < P && p0 + tid < a.n_points) {
             const int64_t gp = p0 + tid;
             float gz[3] = { 0.f, 0.f, 0.f };
-            if constexpr (STAGED) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d)
+            for (int d = 0; d < 3; ++d)
 #pragma unroll
-                    for (int q = 0; q < PARTS; ++q) gz[d] += chd[(q * 3 + d) * ROWS + tid];
-            } else {
-                const act_t *gr = act + tid * LD;
-                const float *pjr = pj + tid * 64;
-                for (int e = 0; e < a.enc.E; ++e)
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        const int q = 3 * e + d;
-                        gz[d] = fmaf(Ops::get(gr + q), pjr[q], gz[d]);
-                        gz[d] = fmaf(Ops::get(gr + KH + q), pjr[32 + q], gz[d]);
-                    }
-            }
+                for (int q = 0; q < PARTS; ++q) gz[d] += stg[(q * 3 + d) * ROWS + tid];
             const float z = (hd[tid] + hd[2 * ROWS + tid]) + a.b_ddf_out;
             const float az = (hd[ROWS + tid] + hd[3 * ROWS + tid]) + a.b_aux_out;
             if (a.neus) {       // NeuS: the "distance head" is e_0, so z is the sdf and gz its position gradient (neus.py:132-156)
@@ -916,588 +772,6 @@ __global__ __launch_bounds__(64 * NW * TEAMS, TEAMS > 1 ? 1 : WPS * NW / 4) void
                 f32x4v v0 = { z, rho, 0.f, gz[0] };
                 f32x4v v1 = { gz[1], gz[2], 0.f, 0.f };
                 ((f32x4v *)pa)[0] = v0; ((f32x4v *)pa)[1] = v1;
-                if (a.distance) a.distance[gp] = z;
-                if (a.density) a.density[gp] = rho;
-            } else {
-            float sp, dsp, t, dsg;
-            softplus_grad(z, sp, dsp);               // softplus.py:38-49
-            const float D = sp + a.d_near;
-            const float dg0 = dsp * gz[0], dg1 = dsp * gz[1], dg2 = dsp * gz[2];
-            sigmoid_grad(az, t, dsg);                // sigmoid.py:38-43
-            const float aux = a.aux_grad_scale * t;
-            const float q2 = dg0 * dg0 + dg1 * dg1 + dg2 * dg2;
-            const float dgn = sqrtf(q2);
-            const float dDdt = sqrtf(q2 + aux * aux);              // neddf.py:234-238
-            const float Dinv = 1.0f / D;
-            const float rho = act_val_rt(a.density_activation, Dinv * (1 - dDdt));   // :239-240
-            const float ninv = 1.0f / (dgn + 1e-7f);               // :241
-            if constexpr (FUSED) {
-                nrm[0] = ninv * dg0; nrm[1] = ninv * dg1; nrm[2] = ninv * dg2;
-            } else {
-            float *pa = a.ptaux + gp * kPtAux;
-            f32x4v v0 = { D, rho, aux, ninv * dg0 };
-            f32x4v v1 = { ninv * dg1, ninv * dg2, z, az };
-            f32x4v v2 = { dg0, dg1, dg2, 0.f };
-            f32x4v v3 = { 0.f, 0.f, dgn, dDdt };
-            if constexpr (STAGED) {
-                if (a.rays.rd) {    // the colour kernel's inputs ride in the slots it does not read in eval-minimal mode (PA_R_*)
-                    float ps[3], vr[3], dr[3];
-                    ray_point(a.rays, a.rays.base + gp, ps, vr, dr);
-                    v0[0] = dr[0]; v0[1] = dr[1]; v0[2] = dr[2];
-                    v2[0] = ps[0]; v2[1] = ps[1]; v2[2] = ps[2]; v2[3] = vr[0];
-                    v3[0] = vr[1]; v3[1] = vr[2];
-                }
-            }
-            ((f32x4v *)pa)[0] = v0; ((f32x4v *)pa)[1] = v1; ((f32x4v *)pa)[2] = v2; ((f32x4v *)pa)[3] = v3;
-            }
-            if (a.distance) a.distance[gp] = D;
-            if (a.density) a.density[gp] = rho;
-            if (a.aux_grad) a.aux_grad[gp] = aux;
-            }
-        }
-        STAMP();                        // tail: encoding gradient, head arithmetic, outputs done
-        if constexpr (FUSED) {
-            // ---- colour trunk on this tile (neddf.py:243-257, value rows; col_trunk_kernel<false> is the stand-alone form)
-            __syncthreads();            // every thread finished reading the encoding gradient rows
-            const int c_dir = 2 * KH, KD = a.enc.KD, c_n = c_dir + 2 * KD, K3d = 3 * a.enc.Ed;
-            const int ka = Ops::kStep * c.ksteps_a;
-            // layer 0, small-input segment [embed_pos | embed_dir | normal]; every column below ka is written exactly once (values or zero padding)
-            for (int i = tid; i < P * 2 * KH; i += THREADS) {       // embed_pos = the saved embed_pos_scaled x (0.5 * 2^e): exact (neddf.py:193-204)
-                const int p = (unsigned)i / (unsigned)(2 * KH), cc = i - p * 2 * KH;
-                const int q = cc < KH ? cc : cc - KH;
-                float v = 0.f;
-                if (q < K3) v = pv[p * 64 + cc] * (0.5f * (float)(1 << (q / 3)));
-                Ops::put(act + p * LD + cc, v);
-            }
-            for (int i = tid; i < P * KD; i += THREADS) {           // embed_dir (positional_encoding.py:51-65)
-                const int p = (unsigned)i / (unsigned)KD, q = i - p * KD;
-                float sn = 0.f, cs = 0.f;
-                if (q < K3d) {
-                    const int e = q / 3, d = q - 3 * e;
-                    const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
-                    if (Ops::kFast) fast_sincos((float)(1 << e) * a.dir[gp * 3 + d], sn, cs);
-                    else sincos_cw((float)(1 << e) * a.dir[gp * 3 + d], sn, cs);
-                }
-                Ops::put(act + p * LD + c_dir + q, sn);
-                Ops::put(act + p * LD + c_dir + KD + q, cs);
-            }
-            for (int i = tid; i < P * (ka - c_n); i += THREADS) {   // normal (written by the thread that derived it) + zero padding
-                const int p = (unsigned)i / (unsigned)(ka - c_n), cc = i - p * (ka - c_n);
-                if (cc >= 3) Ops::zero(act + p * LD + c_n + cc);
-            }
-            if (tid < P) {
-#pragma unroll
-                for (int d = 0; d < 3; ++d) Ops::put(act + tid * LD + c_n + d, nrm[d]);
-            }
-            // the parked feature product comes back while the inputs settle
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4v v = ((const f32x4v *)cpark + (size_t)wave * (MT * NT * 4) * 64 + lane)[((mt * NT + t) * 4 + g) * 64];
-                        acc[mt][t][4 * g] = v[0]; acc[mt][t][4 * g + 1] = v[1]; acc[mt][t][4 * g + 2] = v[2]; acc[mt][t][4 * g + 3] = v[3];
-                    }
-            __syncthreads();
-            dense<MT, NT, Ops>(acc, act_lane, (const frag *)c.wp_a + (size_t)wave * NT * c.ksteps_a * 64 + lane, c.ksteps_a);
-            for (int l = 0; l < c.n_layers; ++l) {                  // neddf.py:254-256 (prefetching the next layer's first fragments as
-                if (l > 0) {                                        // col_trunk_kernel does measured slower here: register pressure)
-                    acc_init<MT, NT, false>(acc, c.layer[l].bias, wave, lane, Ops::kWScale);
-                    dense<MT, NT, Ops>(acc, act_lane, (const frag *)c.layer[l].wp + (size_t)wave * NT * c.layer[l].ksteps * 64 + lane, c.layer[l].ksteps);
-                }
-                __syncthreads();
-                epilogue_rt<MT, NT, false, Ops>(acc, act, c.activation, wave, lane);
-                __syncthreads();
-            }
-            // layer_col_out 256 -> 3 (neddf.py:257): NPART threads share a row (col_trunk_kernel)
-            constexpr int NPART = THREADS / ROWS, KPART = WID / NPART;
-            static_assert(NPART >= 1 && NPART * ROWS == THREADS && KPART % 4 == 0, "the colour head splits a row over THREADS / ROWS threads");
-            {
-                const int part = ROWS == 64 ? __builtin_amdgcn_readfirstlane(wave) : tid / ROWS, row = tid - (tid / ROWS) * ROWS;
-                const act_t *ar = act + row * LD + part * KPART;
-                const float *w = c.w_out + part * KPART * 3;
-                float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-#pragma unroll 4
-                for (int k = 0; k < KPART / 4; ++k) {
-                    float x[4];
-                    Ops::load4(ar + 4 * k, x);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        c0 = fmaf(x[u], w[(4 * k + u) * 3 + 0], c0);
-                        c1 = fmaf(x[u], w[(4 * k + u) * 3 + 1], c1);
-                        c2 = fmaf(x[u], w[(4 * k + u) * 3 + 2], c2);
-                    }
-                }
-                chd[tid * 3 + 0] = c0; chd[tid * 3 + 1] = c1; chd[tid * 3 + 2] = c2;
-            }
-            __syncthreads();
-            if (tid < P && p0 + tid < a.n_points) {
-                const int64_t gp = p0 + tid;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    float sum = c.b_out[k];
-#pragma unroll
-                    for (int q = 0; q < NPART; ++q) sum += chd[(q * ROWS + tid) * 3 + k];
-                    c.color[gp * 3 + k] = sum;
-                }
-            }
-            STAMP();                    // colour trunk done
-        }
-        if (threadIdx.x == 0) ctl[0] = next_tile;
-        __syncthreads();
-        unit = ctl[0];
-        STAMP();                        // tile end
-        STAMP_WALL(1);
-    }
-    NEDDF_STAMP_EXIT();
-    if (TEAMS > 1 && team == 0) __syncthreads();     // ... and team 0 waits for it at the end
-}
-
-// One column pass of ddf_rev2_kernel's products with the weight fragments in a ring of D registers sets that runs D super-steps
-// ahead ACROSS the two passes of a layer (a wave's two column tiles are contiguous in the packed weights: one linear stream of
-// 2 k fragments).  A bf16 super-step is four MFMAs = 128 matrix cycles; an L2 round trip under load is 500-800: two super-steps of
-// distance (dense_pipeline3) leave every product waiting on its operands, eight cover the latency with 8 KB in flight per wave.
-// With one column tile per pass a fragment is four registers, so the ring costs 32.
-template <int MT, class Ops, int D>
-__device__ __forceinline__ void dense_ring_pass(f32x16 (&acc)[MT][1], const typename Ops::act_t *act_lane, const WeightStream &w,
-                                                typename Ops::bfrag (&b)[D], int s0, int k, int s_last)
-{
-    static_assert(D % 2 == 0, "the A fragments ping-pong");
-    typename Ops::afrag a[2][MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[0][mt] = Ops::load_a(act_lane + mt * 32 * Ops::kLd);
-    const typename Ops::act_t *ap = act_lane;
-    for (int S = 0; S < k; S += D) {
-#pragma unroll
-        for (int u = 0; u < D; ++u) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[(u + 1) & 1][mt] = Ops::load_a(ap + (u + 1) * Ops::kStep + mt * 32 * Ops::kLd);
-            __builtin_amdgcn_sched_barrier(0);
-            typename Ops::bfrag bb[1] = { b[u] };
-            dense_mfma<MT, 1, Ops>(acc, a[u & 1], bb);
-            const int nxt = s0 + S + u + D;
-            b[u] = stream_load<typename Ops::bfrag>(w, (unsigned)(nxt < s_last ? nxt : s_last));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        ap += D * Ops::kStep;
-    }
-}
-
-// ----------------------------------------------------------------------------
-// ddf_rev2_kernel -- the reverse-mode distance gradient on 128-POINT tiles at TWO workgroups per CU (bf16 operands, round 5).
-//
-// What paces the 16-bit policies' products is the L2 -> VGPR weight stream: a 64-point tile asks the CU's vector memory path for
-// 64 B/clk at full matrix rate and the path delivers at most 63 (profiles/r04_l2_stream_ubench.txt), shared with the y' round trip
-// and the CU's other workgroup.  128 points per fetched fragment halve it.  Rounds 2-4 found no shape for that: 128 accumulators +
-// the y' sets per wave spill (403 registers), one 8-wave workgroup per CU has nothing to cover its barriers and epilogues, and an
-// LDS ring shared by wave pairs puts a CU's eight waves into the same phase (docs/lab_notebook.md R4.11).  This kernel keeps four
-// waves per workgroup and two workgroups per CU -- one's vector epilogue beside the other's matrix phase -- and walks a layer's
-// output in TWO COLUMN PASSES per wave (32 of its 64 columns at a time, all 128 rows: 64 accumulators): the first pass's results
-// wait as 32 registers of packed bf16 pairs while the second pass is multiplied, then both go to the tile in LDS.  Each weight
-// fragment is still fetched once per tile and feeds four M-tiles; the activations are read twice from LDS (128 B/clk/CU at
-// full matrix rate, half of ds_read_b128's rate).  y' of tanhExp travels as EIGHT bits per element (y8_pack4: half of bf16's bytes
-// at bf16's absolute error); ReLU / LeakyReLU as mask bits.  The encoding has no LDS tile of its own here (two 128-row tiles fill
-// the CU's LDS): a skip layer takes it back from the scratch into the tile's first columns, holding both passes' accumulators
-// across that reload (the one place with 128 live accumulators; no y' set is live then).
-// Same packed weights, same scratch, same outputs as ddf_rev_kernel<2, 4, 2, OpsBF16, *>.
-// MT = 4 at two workgroups per CU is that shape; MT = 2 (64 points, 32 accumulators per pass) leaves room for THREE or FOUR workgroups
-// per CU (168 / 128 registers per wave): more waves per SIMD to put one's vector work beside another's matrix work.
-template <class Ops, bool MASKY, int MT, int WPS, bool Y8 = true>
-__global__ __launch_bounds__(256, WPS) void ddf_rev2_kernel(const DdfArgs a)
-{
-    typedef typename Ops::act_t act_t;
-    typedef typename Ops::bfrag frag;
-    constexpr int WID = Ops::kWid, NW = 4, THREADS = 64 * NW, ROWS = MT * 32, P = ROWS, LD = Ops::kLd;
-    static_assert(WID == 64 * NW, "two column passes of 32 per wave");
-    static_assert(MT == 2 || MT == 4, "64- or 128-point tiles");
-    constexpr int NBLK = 2 * MT, BPW = NBLK / NW;      // 32 x 32 blocks of the [P, 64] encoding gradient per wave
-    constexpr int PARTS = THREADS / ROWS;              // threads per point in the tail
-#ifndef NEDDF_REV2_RING
-#define NEDDF_REV2_RING 0       // measured: a ring of 8 on 128-point tiles is SLOWER (25.8 vs 23.5 ms per launch) -- the products do not wait on L2 latency
-#endif
-    constexpr int kRing = NEDDF_REV2_RING;            // weight fragments in flight per wave (dense_ring_pass)
-    constexpr float kInvW = 1.0f / Ops::kWScale;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    act_t *act = (act_t *)smem;
-    float *hd = (float *)(act + ROWS * LD);     // [2 k-halves][2 heads][ROWS] head dot products
-    float *lp = hd + 6 * ROWS;                  // [16]: low-pass scales, ctl at + 12
-    float *tailp = lp + 16;                     // [PARTS][3][ROWS] partial position gradients (768 floats)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
-    float *base = a.rev_scratch + (size_t)blockIdx.x * ((size_t)a.n_layers * P * WID + (size_t)P * 192 + (size_t)P * WID);
-    // y' slots: one byte per element (tanhExp) or one bit (masks), a layer after the other; then the 64-column side arrays
-    unsigned char *yp = (unsigned char *)base;
-    constexpr size_t kYBytes = (size_t)ROWS * WID * (Y8 ? 1 : 2);       // (Y8 = false: bf16 pairs, the shipped kernel's format, for A/B)
-    // (the last layer has no y' slot: behind the others sits g_L = w_ddf * y'_L as bf16 pairs while the features are handed off)
-    u32x4 *gslot = (u32x4 *)(yp + (size_t)(a.n_layers - 1) * kYBytes);
-    float *pj = base + ((size_t)(a.n_layers - 1) * kYBytes + (size_t)ROWS * WID * 2) / 4;  // [ROWS][64] dPE/dx factors: [q] sine half, [32 + q] cosine half
-    float *pv = pj + ROWS * 64;                                 // [ROWS][64] the encoding itself, for the skip layers
-    float *pg = pv + ROWS * 64;                                 // [ROWS][64] the skip layers' share of the encoding gradient, parked
-    if (tid == 0) {
-#pragma unroll
-        for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
-    }
-    const int kin = Ops::kStep * a.layer[0].ksteps;
-    const int K3 = 3 * a.enc.E, KH = a.enc.KH;
-    const unsigned k3magic = (1u << 20) / (unsigned)K3 + 1u;   // item / K3 for item < 4096, K3 <= 30: (item * magic) >> 20 is exact
-    const int64_t ntiles = (a.n_points + P - 1) / P;
-    const int KS = a.ks_hidden;
-    const int ct0 = wave * 2;                                   // this wave's two column tiles: ct0, ct0 + 1
-
-    int *ctl = (int *)(lp + 12);
-    int64_t tile = sched_begin(a.sched, a.sched_flags, ctl, tid);
-    while (tile < ntiles) {
-        const int64_t p0 = tile * P;
-        // the tile's positions / variances: one coalesced request per array into LDS (the tail's partial-sum area, free until then) --
-        // the encoding loop below then waits on nothing but LDS (per-item global loads were a chain of dependent L2 round trips)
-        for (int idx = tid; idx < 6 * ROWS; idx += THREADS) {
-            const int k = idx < 3 * ROWS ? idx : idx - 3 * ROWS, p = (k * 43691) >> 17, d = k - 3 * p;      // k / 3 for k < 384
-            const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
-            tailp[idx] = idx < 3 * ROWS ? a.pos[gp * 3 + d] : (a.neus ? 0.0f : a.var[gp * 3 + d]);
-        }
-        zero_cols<Ops, THREADS>(act, ROWS, kin, tid);
-        __syncthreads();
-        int next_tile = 0;
-        if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
-        // scaled integrated encoding (neddf.py:193-204), value rows; the factors of its Jacobian and a copy go to the scratch
-        for (int item = tid; item < P * K3; item += THREADS) {
-            const int p = (int)(((unsigned)item * k3magic) >> 20), q = item - p * K3;
-            const int e = (q * 11) >> 5, d = q - 3 * e;
-            float vs, vc, js, jc;
-            if (a.neus) pe_pair<false, Ops::kFast>(e, tailp[p * 3 + d], 0.0f, lp[e], vs, vc, js, jc);      // plain PE (neus.py:118)
-            else pe_pair<true, Ops::kFast>(e, tailp[p * 3 + d], tailp[3 * ROWS + p * 3 + d], lp[e], vs, vc, js, jc);
-            Ops::put(act + p * LD + q, vs);
-            Ops::put(act + p * LD + KH + q, vc);
-            pj[p * 64 + q] = js;
-            pj[p * 64 + 32 + q] = jc;
-            pv[p * 64 + q] = vs;               // same column order as the LDS tile: [sine half (KH) | cosine half (KH)]
-            pv[p * 64 + KH + q] = vc;
-        }
-        __syncthreads();
-
-        // ---- forward, value rows
-        for (int l = 0; l < a.n_layers; ++l) {
-            const LayerW &L = a.layer[l];
-            const bool last = l + 1 == a.n_layers, skip = L.stash >= 0;
-            unsigned char *ysl = yp + (size_t)l * kYBytes;
-            f32x16 accA[MT][1], accB[MT][1];
-            unsigned ypk[MT][8];
-            // the epilogue of one column tile: activation, y -> packed pairs (HOLD) or the LDS tile, y' -> its slot (or the seed g_L)
-            auto epilogue = [&](f32x16 (&acc)[MT][1], int t, bool hold) {
-                const int ct = ct0 + t;
-                const float ws = last ? a.w_ddf_out[ct * 32 + j] : 1.0f;
-                unsigned mw[2] = { 0u, 0u };
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    act_t *o = act + (mt * 32 + 4 * h) * LD + ct * 32 + j;
-                    f32x16 dv;
-                    unsigned gl[8];
-#pragma unroll
-                    for (int q = 0; q < 16; q += 2) {
-                        const int r = 8 * (q >> 2) + (q & 3);
-                        float y[2], dy[2];
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            float z = acc[mt][0][q + u];
-                            if constexpr (Ops::kWScale != 1.0f) z *= kInvW;
-                            if constexpr (MASKY) {
-                                if (a.activation == 0) act_grad<0, Ops::kActMode>(z, y[u], dy[u]);
-                                else act_grad<1, Ops::kActMode>(z, y[u], dy[u]);
-                                mw[mt >> 1] |= (dy[u] == 1.0f ? 1u : 0u) << (16 * (mt & 1) + q + u);
-                            } else act_grad<2, Ops::kActMode>(z, y[u], dy[u]);
-                            dv[q + u] = dy[u];
-                        }
-                        if (hold) ypk[mt][q >> 1] = Ops::pack2(y[0], y[1]);
-                        else Ops::put2(o + r * LD, o + (r + 1) * LD, y[0], y[1]);
-                        if (last) gl[q >> 1] = Ops::pack2(ws * dy[0], ws * dy[1]);
-                    }
-                    if (last) {     // the seed of the reverse pass waits in the scratch: held in registers it would be live through every layer
-                        gslot[(((size_t)ct * MT + mt) * 2 + 0) * 64 + lane] = (u32x4){ gl[0], gl[1], gl[2], gl[3] };
-                        gslot[(((size_t)ct * MT + mt) * 2 + 1) * 64 + lane] = (u32x4){ gl[4], gl[5], gl[6], gl[7] };
-                    }
-                    if constexpr (!MASKY) {
-                        if (!last) {
-                            if constexpr (Y8) ((u32x4 *)ysl)[((size_t)ct * MT + mt) * 64 + lane] = y8_pack16(dv);
-                            else {
-#pragma unroll
-                                for (int c2 = 0; c2 < 2; ++c2) {
-                                    u32x4 w;
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) w[i] = Ops::pack2(dv[8 * c2 + 2 * i], dv[8 * c2 + 2 * i + 1]);
-                                    ((u32x4 *)ysl)[(((size_t)ct * MT + mt) * 2 + c2) * 64 + lane] = w;
-                                }
-                            }
-                        }
-                    }
-                }
-                if constexpr (MASKY) {
-                    if (!last) {
-                        ((unsigned *)ysl)[((size_t)ct * 2 + 0) * 64 + lane] = mw[0];
-                        if constexpr (MT > 2) ((unsigned *)ysl)[((size_t)ct * 2 + 1) * 64 + lane] = mw[1];
-                    }
-                }
-            };
-            acc_init<MT, 1, false>(accA, L.bias, ct0, lane, Ops::kWScale);
-            if (kRing > 0 && L.ksteps % (kRing > 0 ? kRing : 1) == 0) {        // (every width-wide product; the narrow first layer takes the plain pipeline)
-                const WeightStream wst = weight_stream((const frag *)L.wp + (size_t)ct0 * L.ksteps * 64 + lane);
-                frag ring[kRing > 0 ? kRing : 2];
-#pragma unroll
-                for (int u = 0; u < kRing; ++u) ring[u] = stream_load<frag>(wst, (unsigned)u);
-                dense_ring_pass<MT, Ops, (kRing > 0 ? kRing : 2)>(accA, act_lane, wst, ring, 0, L.ksteps, 2 * L.ksteps - 1);
-                if (!skip) epilogue(accA, 0, true);
-                acc_init<MT, 1, false>(accB, L.bias, ct0 + 1, lane, Ops::kWScale);
-                dense_ring_pass<MT, Ops, (kRing > 0 ? kRing : 2)>(accB, act_lane, wst, ring, L.ksteps, L.ksteps, 2 * L.ksteps - 1);
-            } else {
-                dense<MT, 1, Ops>(accA, act_lane, (const frag *)L.wp + (size_t)ct0 * L.ksteps * 64 + lane, L.ksteps);
-                if (!skip) epilogue(accA, 0, true);
-                acc_init<MT, 1, false>(accB, L.bias, ct0 + 1, lane, Ops::kWScale);
-                dense<MT, 1, Ops>(accB, act_lane, (const frag *)L.wp + (size_t)(ct0 + 1) * L.ksteps * 64 + lane, L.ksteps);
-            }
-            __syncthreads();                            // every wave finished reading the hidden state
-            if (skip) {     // cat([encoding, h]) (neddf.py:217-219): the encoding comes back from the scratch into the tile's first columns
-                const StashW &sw = a.stash[L.stash];
-                for (int i = tid; i < ROWS * (kin / 4); i += THREADS) {
-                    const int r = i / (kin / 4), c = i - r * (kin / 4);
-                    f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-                    if (4 * c < 64) v = *(const f32x4v *)(pv + r * 64 + 4 * c);
-                    // columns [K3, KH) and [KH + K3, 2 KH) of the scratch rows were never written: mask them
-                    float x[4] = { v[0], v[1], v[2], v[3] };
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int cc = 4 * c + u, qq = cc < KH ? cc : cc - KH;
-                        Ops::put(act + r * LD + cc, (cc < 2 * KH && qq < K3) ? x[u] : 0.f);
-                    }
-                }
-                __syncthreads();
-                dense<MT, 1, Ops>(accA, act_lane + sw.col0, (const frag *)sw.wp + (size_t)ct0 * sw.ksteps * 64 + lane, sw.ksteps);
-                dense<MT, 1, Ops>(accB, act_lane + sw.col0, (const frag *)sw.wp + (size_t)(ct0 + 1) * sw.ksteps * 64 + lane, sw.ksteps);
-                __syncthreads();                        // every wave finished reading the encoding columns
-                epilogue(accA, 0, false);
-            } else {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    act_t *o = act + (mt * 32 + 4 * h) * LD + ct0 * 32 + j;
-#pragma unroll
-                    for (int q = 0; q < 16; q += 2) Ops::put_packed2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, ypk[mt][q >> 1]);
-                }
-            }
-            epilogue(accB, 1, false);
-            __syncthreads();
-        }
-        // ---- heads on the features (value only) and the feature hand-off to the colour kernel
-        for (int item = tid; item < 4 * ROWS; item += THREADS) {       // 2 k-halves x 2 heads x ROWS rows
-            const int part = item / (2 * ROWS), head = (item / ROWS) & 1, row = item % ROWS;
-            const f32x4v *w = (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out) + part * (WID / 8);
-            const act_t *ar = act + row * LD + part * (WID / 2);
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < WID / 8; ++k) {
-                float x[4];
-                Ops::load4(ar + 4 * k, x);
-                f32x4v ww = w[k];
-                s0 = fmaf(x[0], ww[0], s0); s1 = fmaf(x[1], ww[1], s1);
-                s2 = fmaf(x[2], ww[2], s2); s3 = fmaf(x[3], ww[3], s3);
-            }
-            hd[item] = (s0 + s1) + (s2 + s3);
-        }
-        {
-            constexpr int CE = 16 / sizeof(act_t), CPP = WID / CE, CPR = Ops::kPlanes * CPP;
-            act_t *features = (act_t *)a.features;
-            for (int idx = tid; features && idx < P * CPR; idx += THREADS) {
-                const int p = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
-                if (p0 + p < a.n_points) {
-                    f32x4v v = *(const f32x4v *)(act + p * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));
-                    *(f32x4v *)(features + (size_t)(p0 + p) * (Ops::kPlanes * WID) + CE * c4) = v;
-                }
-            }
-        }
-        __syncthreads();                // the features are consumed: the tile now carries gradients
-        // ---- reverse pass: g_L -> LDS
-        // (requested before the barrier above could not be: the same lanes wrote them in the last epilogue, so program order suffices)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                act_t *o = act + (mt * 32 + 4 * h) * LD + (ct0 + t) * 32 + j;
-                const u32x4 g0 = gslot[(((size_t)(ct0 + t) * MT + mt) * 2 + 0) * 64 + lane], g1 = gslot[(((size_t)(ct0 + t) * MT + mt) * 2 + 1) * 64 + lane];
-#pragma unroll
-                for (int q = 0; q < 8; q += 2) {
-                    Ops::put_packed2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, g0[q >> 1]);
-                    Ops::put_packed2(o + (8 * ((q + 8) >> 2) + (q & 3)) * LD, o + (8 * ((q + 8) >> 2) + (q & 3) + 1) * LD, g1[q >> 1]);
-                }
-            }
-        __syncthreads();
-        f32x4v *gpe_park = (f32x4v *)pg + (size_t)wave * BPW * 4 * 64 + lane;
-        bool parked = false;
-        for (int l = a.n_layers - 1; l >= 1; --l) {
-            if (a.layer[l].stash >= 0) {    // cat([encoding, h]): the encoding rows of W_l take their share of g_l (every skip layer adds its own)
-#pragma unroll
-                for (int i = 0; i < BPW; ++i) {
-                    const int b = wave * BPW + i;
-                    f32x16 gs[1][1];
-                    if (parked) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            f32x4v v = gpe_park[(i * 4 + g) * 64];
-                            gs[0][0][4 * g] = v[0]; gs[0][0][4 * g + 1] = v[1]; gs[0][0][4 * g + 2] = v[2]; gs[0][0][4 * g + 3] = v[3];
-                        }
-                    } else acc_init<1, 1, false>(gs, nullptr, wave, lane);
-                    dense<1, 1, Ops>(gs, act_lane + (b >> 1) * 32 * LD, (const frag *)a.wT_pe_skip[a.layer[l].stash] + (size_t)(b & 1) * KS * 64 + lane, KS);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4v v = { gs[0][0][4 * g], gs[0][0][4 * g + 1], gs[0][0][4 * g + 2], gs[0][0][4 * g + 3] };
-                        gpe_park[(i * 4 + g) * 64] = v;
-                    }
-                }
-                parked = true;
-            }
-            // g_{l-1} = (g_l W_l^T) * y'_{l-1}, two column passes like the forward layers
-            const unsigned char *ysl = yp + (size_t)(l - 1) * kYBytes;
-            f32x16 acc[MT][1];
-            unsigned gp0[MT][8];
-            auto scaled = [&](int t, bool hold) {      // acc * y' of column tile ct0 + t -> packed pairs (hold) or the LDS tile
-                const int ct = ct0 + t;
-                unsigned mw[2] = { 0u, 0u };
-                u32x4 yq[MT][Y8 ? 1 : 2];
-                if constexpr (MASKY) {
-                    mw[0] = ((const unsigned *)ysl)[((size_t)ct * 2 + 0) * 64 + lane];
-                    if constexpr (MT > 2) mw[1] = ((const unsigned *)ysl)[((size_t)ct * 2 + 1) * 64 + lane];
-                } else {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        if constexpr (Y8) yq[mt][0] = ((const u32x4 *)ysl)[((size_t)ct * MT + mt) * 64 + lane];
-                        else {
-                            yq[mt][0] = ((const u32x4 *)ysl)[(((size_t)ct * MT + mt) * 2 + 0) * 64 + lane];
-                            yq[mt][1] = ((const u32x4 *)ysl)[(((size_t)ct * MT + mt) * 2 + 1) * 64 + lane];
-                        }
-                    }
-                }
-                if (!hold) __syncthreads();             // every wave finished reading g_l (the second pass's product is behind us)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    act_t *o = act + (mt * 32 + 4 * h) * LD + ct * 32 + j;
-                    if (!hold && t == 1) {              // the first pass's pairs go out next to the second's
-                        act_t *o0 = o - 32;
-#pragma unroll
-                        for (int q = 0; q < 16; q += 2) Ops::put_packed2(o0 + (8 * (q >> 2) + (q & 3)) * LD, o0 + (8 * (q >> 2) + (q & 3) + 1) * LD, gp0[mt][q >> 1]);
-                    }
-                    float f[16];
-                    if constexpr (MASKY) {
-                        const unsigned bits = mw[mt >> 1] >> (16 * (mt & 1));
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) f[q] = mask_factor<Ops>((bits >> q) & 1u, a.activation);
-                    } else {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            if constexpr (Y8) {
-                                f[4 * g] = y8_get<0>(yq[mt][0][g]); f[4 * g + 1] = y8_get<1>(yq[mt][0][g]);
-                                f[4 * g + 2] = y8_get<2>(yq[mt][0][g]); f[4 * g + 3] = y8_get<3>(yq[mt][0][g]);
-                            } else {
-                                const unsigned w0 = yq[mt][g >> 1][2 * (g & 1)], w1 = yq[mt][g >> 1][2 * (g & 1) + 1];
-                                f[4 * g] = __builtin_bit_cast(float, w0 << 16); f[4 * g + 1] = __builtin_bit_cast(float, w0 & 0xffff0000u);
-                                f[4 * g + 2] = __builtin_bit_cast(float, w1 << 16); f[4 * g + 3] = __builtin_bit_cast(float, w1 & 0xffff0000u);
-                            }
-                        }
-                        if constexpr (Ops::kWScale != 1.0f) {
-#pragma unroll
-                            for (int q = 0; q < 16; ++q) f[q] *= kInvW;
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 16; q += 2) {
-                        const int r = 8 * (q >> 2) + (q & 3);
-                        if (hold) gp0[mt][q >> 1] = Ops::pack2(acc[mt][0][q] * f[q], acc[mt][0][q + 1] * f[q + 1]);
-                        else Ops::put2(o + r * LD, o + (r + 1) * LD, acc[mt][0][q] * f[q], acc[mt][0][q + 1] * f[q + 1]);
-                    }
-                }
-            };
-            acc_init<MT, 1, false>(acc, nullptr, wave, lane);
-            if (kRing > 0 && KS % (kRing > 0 ? kRing : 1) == 0) {
-                const WeightStream wst = weight_stream((const frag *)a.wT[l] + (size_t)ct0 * KS * 64 + lane);
-                frag ring[kRing > 0 ? kRing : 2];
-#pragma unroll
-                for (int u = 0; u < kRing; ++u) ring[u] = stream_load<frag>(wst, (unsigned)u);
-                dense_ring_pass<MT, Ops, (kRing > 0 ? kRing : 2)>(acc, act_lane, wst, ring, 0, KS, 2 * KS - 1);
-                scaled(0, true);
-                acc_init<MT, 1, false>(acc, nullptr, wave, lane);
-                dense_ring_pass<MT, Ops, (kRing > 0 ? kRing : 2)>(acc, act_lane, wst, ring, KS, KS, 2 * KS - 1);
-            } else {
-                dense<MT, 1, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)ct0 * KS * 64 + lane, KS);
-                scaled(0, true);
-                acc_init<MT, 1, false>(acc, nullptr, wave, lane);
-                dense<MT, 1, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)(ct0 + 1) * KS * 64 + lane, KS);
-            }
-            scaled(1, false);
-            __syncthreads();
-        }
-        f32x16 gpe[BPW][1];
-#pragma unroll
-        for (int i = 0; i < BPW; ++i) {
-            const int b = wave * BPW + i;
-            f32x16 one[1][1];
-            if (parked) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4v v = gpe_park[(i * 4 + g) * 64];
-                    one[0][0][4 * g] = v[0]; one[0][0][4 * g + 1] = v[1]; one[0][0][4 * g + 2] = v[2]; one[0][0][4 * g + 3] = v[3];
-                }
-            } else acc_init<1, 1, false>(one, nullptr, wave, lane);
-            dense<1, 1, Ops>(one, act_lane + (b >> 1) * 32 * LD, (const frag *)a.wT_pe0 + (size_t)(b & 1) * KS * 64 + lane, KS);       // g_0 W_0^T
-            gpe[i][0] = one[0][0];
-        }
-        __syncthreads();                // every wave finished reading g_0
-#pragma unroll
-        for (int i = 0; i < BPW; ++i) {
-            const int b = wave * BPW + i;
-            act_t *o = act + ((b >> 1) * 32 + 4 * h) * LD + (b & 1) * 32 + j;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float g = gpe[i][0][q];
-                if constexpr (Ops::kWScale != 1.0f) g *= kInvW;
-                Ops::put(o + (8 * (q >> 2) + (q & 3)) * LD, g);
-            }
-        }
-        __syncthreads();
-        // ---- per point: grad_x z_D = sum over the encoding channels of g_pe * dPE/dx (two threads per point, every other frequency each),
-        // then the head arithmetic (neddf.py:220-241)
-        {
-            const int part = tid / ROWS, p = tid & (ROWS - 1);
-            const act_t *gr = act + p * LD;
-            const float *pjr = pj + p * 64;
-            float gz[3] = { 0.f, 0.f, 0.f };
-            for (int e = part; e < a.enc.E; e += PARTS)
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const int q = 3 * e + d;
-                    gz[d] = fmaf(Ops::get(gr + q), pjr[q], gz[d]);
-                    gz[d] = fmaf(Ops::get(gr + KH + q), pjr[32 + q], gz[d]);
-                }
-#pragma unroll
-            for (int d = 0; d < 3; ++d) tailp[(part * 3 + d) * ROWS + p] = gz[d];
-        }
-        __syncthreads();
-        if (tid < P && p0 + tid < a.n_points) {
-            const int64_t gp = p0 + tid;
-            float gz[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                gz[d] = tailp[d * ROWS + tid];
-#pragma unroll
-                for (int q = 1; q < PARTS; ++q) gz[d] += tailp[(q * 3 + d) * ROWS + tid];
-            }
-            const float z = (hd[tid] + hd[2 * ROWS + tid]) + a.b_ddf_out;
-            const float az = (hd[ROWS + tid] + hd[3 * ROWS + tid]) + a.b_aux_out;
-            if (a.neus) {       // NeuS: the "distance head" is e_0, so z is the sdf and gz its position gradient (neus.py:132-156)
-                const float ex = expf(-a.neus_v10 * z), den = 1 + ex;
-                const float rho = a.neus_v10 * ex * (1.0f / (den * den));
-                if (a.ptaux) {
-                    float *pa = a.ptaux + gp * kPtAux;
-                    f32x4v v0 = { z, rho, 0.f, gz[0] };
-                    f32x4v v1 = { gz[1], gz[2], 0.f, 0.f };
-                    ((f32x4v *)pa)[0] = v0; ((f32x4v *)pa)[1] = v1;
-                }
                 if (a.distance) a.distance[gp] = z;
                 if (a.density) a.density[gp] = rho;
             } else {
@@ -1513,23 +787,32 @@ __global__ __launch_bounds__(256, WPS) void ddf_rev2_kernel(const DdfArgs a)
                 const float Dinv = 1.0f / D;
                 const float rho = act_val_rt(a.density_activation, Dinv * (1 - dDdt));   // :239-240
                 const float ninv = 1.0f / (dgn + 1e-7f);               // :241
-                if (a.ptaux) {
-                    float *pa = a.ptaux + gp * kPtAux;
-                    f32x4v v0 = { D, rho, aux, ninv * dg0 };
-                    f32x4v v1 = { ninv * dg1, ninv * dg2, z, az };
-                    f32x4v v2 = { dg0, dg1, dg2, 0.f };
-                    f32x4v v3 = { 0.f, 0.f, dgn, dDdt };
-                    ((f32x4v *)pa)[0] = v0; ((f32x4v *)pa)[1] = v1; ((f32x4v *)pa)[2] = v2; ((f32x4v *)pa)[3] = v3;
+                float *pa = a.ptaux + gp * kPtAux;
+                f32x4v v0 = { D, rho, aux, ninv * dg0 };
+                f32x4v v1 = { ninv * dg1, ninv * dg2, z, az };
+                f32x4v v2 = { dg0, dg1, dg2, 0.f };
+                f32x4v v3 = { 0.f, 0.f, dgn, dDdt };
+                if (a.rays.rd) {    // the colour kernel's inputs ride in the slots it does not read in eval-minimal mode (PA_R_*)
+                    float ps[3], vr[3], dr[3];
+                    ray_point(a.rays, a.rays.base + gp, ps, vr, dr);
+                    v0[0] = dr[0]; v0[1] = dr[1]; v0[2] = dr[2];
+                    v2[0] = ps[0]; v2[1] = ps[1]; v2[2] = ps[2]; v2[3] = vr[0];
+                    v3[0] = vr[1]; v3[1] = vr[2];
                 }
+                ((f32x4v *)pa)[0] = v0; ((f32x4v *)pa)[1] = v1; ((f32x4v *)pa)[2] = v2; ((f32x4v *)pa)[3] = v3;
                 if (a.distance) a.distance[gp] = D;
                 if (a.density) a.density[gp] = rho;
                 if (a.aux_grad) a.aux_grad[gp] = aux;
             }
         }
+        STAMP();                        // tail: encoding gradient, head arithmetic, outputs done
         if (tid == 0) ctl[0] = next_tile;
         __syncthreads();
         tile = ctl[0];
+        STAMP();                        // tile end
+        STAMP_WALL(1);
     }
+    NEDDF_STAMP_EXIT();
 }
 
 // ----------------------------------------------------------------------------
@@ -1573,10 +856,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
         STAMP();                                    // 1: columns zeroed + barrier
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
-        // timing ablations of the colour kernel (-DNEDDF_ABLATE builds only, results invalid): 1024 no input encodings, 2048 no
-        // feature load, 4096 no small-input product, 8192 no 256 -> 3 head, 16384 ReLU in place of the configured activation
-        if (NEDDF_ABL(a.sched_flags, 1024)) {
-        } else if (a.mode == 1) {      // NeuS: [pos | gradient | pad | embed_dir] (neus.py:146-149)
+        if (a.mode == 1) {      // NeuS: [pos | gradient | pad | embed_dir] (neus.py:146-149)
             for (int i = tid; i < P * 3; i += THREADS) {
                 int p = i / 3, d = i - 3 * p;
                 int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
@@ -1624,19 +904,13 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
             int64_t src = ROWS4 ? grow : grow * a.feat_rows;      // value row of [n][feat_rows][256]
             return (const f32x4v *)((const act_t *)a.features + (size_t)src * (Ops::kPlanes * WID) + CE * c4);
         };
-        const bool abl_nofeat = NEDDF_ABL(a.sched_flags, 2048);
         if constexpr (FPRE) {
-            if (!abl_nofeat) {
 #pragma unroll
-                for (int i = 0; i < NF; ++i) fpre[i] = *feature_src(tid + i * THREADS);
-            } else {
-#pragma unroll
-                for (int i = 0; i < NF; ++i) fpre[i] = f32x4v{ 0.f, 0.f, 0.f, 0.f };
-            }
+            for (int i = 0; i < NF; ++i) fpre[i] = *feature_src(tid + i * THREADS);
             __builtin_amdgcn_sched_barrier(0);
         }
         acc_init<MT, NT, ROWS4>(acc, a.layer[0].bias, wave, lane, Ops::kWScale);
-        if (!NEDDF_ABL(a.sched_flags, 4096)) dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wp_a + (size_t)wave * NT * a.ksteps_a * 64 + lane, a.ksteps_a);
+        dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wp_a + (size_t)wave * NT * a.ksteps_a * 64 + lane, a.ksteps_a);
         LayerPre<NT, Ops> pre;
         layer_prefetch<NT, Ops>(pre, a.layer[0].wp, nullptr, a.layer[0].ksteps, wave, lane);
         STAMP();                                    // 4: features requested, small-input product done
@@ -1648,7 +922,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
                 int idx = tid + i * THREADS;
                 *lds_chunk(idx) = fpre[i];
             }
-        } else if (!abl_nofeat) {
+        } else {
             for (int idx = tid; idx < ROWS * CPR; idx += THREADS)
                 *lds_chunk(idx) = *feature_src(idx);
         }
@@ -1664,7 +938,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
             STAMP();                                // layer l: 8 + 4l product done
             __syncthreads();
             STAMP();                                //          9 + 4l barrier passed
-            epilogue_rt<MT, NT, ROWS4, Ops>(acc, act, NEDDF_ABL(a.sched_flags, 16384) ? 0 : a.activation, wave, lane);
+            epilogue_rt<MT, NT, ROWS4, Ops>(acc, act, a.activation, wave, lane);
             STAMP();                                //          10 + 4l epilogue done
             __syncthreads();
             STAMP();                                //          11 + 4l barrier passed
@@ -1675,7 +949,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
         // loads made this head 2.8 % of the kernel (profiles/r03_col_ablation.txt)
         constexpr int NPART = THREADS / ROWS, KPART = WID / NPART;
         static_assert(NPART >= 1 && NPART * ROWS == THREADS && KPART % 4 == 0, "the colour head splits a row over THREADS / ROWS threads");
-        if (!NEDDF_ABL(a.sched_flags, 8192)) {
+        {
             const int part = ROWS == 64 ? __builtin_amdgcn_readfirstlane(wave) : tid / ROWS, row = tid - (tid / ROWS) * ROWS;
             const act_t *ar = act + row * LD + part * KPART;
             const float *w = a.w_out + part * KPART * 3;
@@ -1970,77 +1244,35 @@ static size_t lds_bytes(int mt)      // the tile + the kernels' small scratch be
 }
 size_t field_lds_bytes(int mt) { return lds_bytes<OpsF32>(mt); }
 
-// Tile geometry (MT, WPS, NW) per operand policy -- see ddf_trunk_kernel.
-//   fp32        (2, 2, 4): 64-row tiles, two workgroups per CU (one workgroup's VALU epilogue overlaps the other's MFMA stream;
-//               measured on MI355X, C2 workload: 134 TF vs 118 TF for (4, 1, 4); 32-row tiles at three / four workgroups
-//               per CU -- more waves to cover barriers and epilogues -- reach 124 / 119 TF: two accumulator tiles per wave
-//               leave the MFMA stream too little independent work).  NEDDF_TILE_MT=4 selects (4, 1, 4).
-//   bf16        (4, 2, 4): 128-row tiles (half the LDS bytes of fp32) at two workgroups per CU: each fetched weight fragment
-//               feeds four M-tiles (7.78 ms per 2^21-point launch against 8.42 ms for (2, 2, 4)).
-//   split fp16  (2, 2, 4): two fp16 planes = the LDS bytes of fp32, same shape as fp32.
-// NEDDF_BF16_GEO / NEDDF_SPLIT_GEO = "MTxWPSxNW" select another compiled shape.  The eight-wave shapes (NW = 8: two waves per
-// SIMD, 32 columns each, so that a fetched fragment feeds four M-tiles at HALF the per-wave weight stream) were built to test
-// whether the vector-cache weight stream paces the 16-bit dense phase; measured on MI355X (profiles/r02_geometry_sweep.md) they
-// are slower -- bf16 (4, 2, 8) 8.34 ms, (4, 1, 8) 9.03 ms; split fp16 (4, 1, 8) 21.6 ms against 19.9 ms -- so the stream is
-// not the limiter, the un-overlapped VALU epilogue is; they stay selectable for that evidence only.
-struct Geo {
-    int mt, wps, nw;
-};
-static int g_mt = 0;
-static int tile_mt()
-{
-    if (!g_mt) {
-        const char *e = getenv("NEDDF_TILE_MT");
-        g_mt = (e && atoi(e) == 4) ? 4 : 2;
-    }
-    return g_mt;
-}
-static Geo parse_geo(const char *env, Geo dflt, std::initializer_list<Geo> allowed)
-{
-    const char *e = getenv(env);
-    if (!e) return dflt;
-    Geo g{ 0, 0, 0 };
-    if (sscanf(e, "%dx%dx%d", &g.mt, &g.wps, &g.nw) != 3) return dflt;
-    for (const Geo &a : allowed) if (a.mt == g.mt && a.wps == g.wps && a.nw == g.nw) return g;
-    fprintf(stderr, "libneddf_hip: %s=%s is not a compiled geometry, using %dx%dx%d\n", env, e, dflt.mt, dflt.wps, dflt.nw);
-    return dflt;
-}
-static Geo geo(int operands)
-{
-    static Geo g[3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
-    if (!g[0].mt) {
-        const Geo base = tile_mt() == 2 ? Geo{ 2, 2, 4 } : Geo{ 4, 1, 4 };
-        g[0] = base;
-        g[1] = tile_mt() == 2 ? parse_geo("NEDDF_BF16_GEO", Geo{ 4, 2, 4 }, { { 4, 2, 8 }, { 4, 1, 8 }, { 4, 2, 4 }, { 2, 2, 4 }, { 4, 1, 4 } }) : base;
-        g[2] = tile_mt() == 2 ? parse_geo("NEDDF_SPLIT_GEO", Geo{ 2, 2, 4 }, { { 4, 1, 8 }, { 2, 2, 4 }, { 4, 1, 4 } }) : base;
-    }
-    return g[operands < 0 || operands > 2 ? 0 : operands];
-}
+// Tile geometry (MT, WPS, NW) per operand policy at engine width 256 -- see ddf_trunk_kernel.  One compiled shape per kernel and
+// policy: the fastest of the sweeps of rounds 1-5 (profiles/r02_geometry_sweep.md, docs/lab_notebook.md R4.2, R5.3-R5.8; the other
+// shapes and their switches left the product tree in round 6).
+//   forward-mode distance trunk / colour trunk (Jacobian rows, training-mode outputs)
+//     fp32        (2, 2, 4): 64-row tiles, two workgroups per CU (one workgroup's VALU epilogue beside the other's MFMA stream:
+//                 134 TF against 118 TF for one 128-row workgroup per CU, 124 / 119 TF for 32-row tiles at three / four)
+//     bf16        (4, 2, 4): 128-row tiles (half the LDS bytes of fp32): each fetched weight fragment feeds four M-tiles;
+//                 its colour trunk (4, 2, 8): the value-row-only epilogue is light enough for eight waves to pay
+//     split fp16  (2, 2, 4): two fp16 planes = the LDS bytes of fp32, same shape as fp32
+//   reverse-mode distance kernel: 64-point tiles, four waves, two workgroups per CU under every policy (ddf_rev_kernel)
 // Engine widths other than 256 (hidden width padded to 128 / 384 / 512; the reference's constructors take any width,
 // neddf.py:52-66, nerf.py:34-44) have ONE shape per width under every operand policy: 64-row tiles at 128 columns, 32-row tiles
 // at 384 / 512 (the LDS tile and the accumulators grow with the width: 32 x 516 floats and 4 column tiles per wave at 512 are
-// the footprint of the 64 x 260 tile with 2 column tiles at 256) -- always two workgroups per CU, so that one workgroup's
-// barriers and epilogues are covered by the other's matrix work, as at width 256.
+// the footprint of the 64 x 260 tile with 2 column tiles at 256) -- always two workgroups per CU.
+struct Geo {
+    int mt, wps, nw;
+};
 static Geo geo_w(int width) { return width == 128 ? Geo{ 2, 2, 4 } : Geo{ 1, 2, 4 }; }
-static Geo geo(int operands, int width) { return width == 256 ? geo(operands) : geo_w(width); }
-// The colour trunk follows the distance trunk's shape except under bf16, where its value-row-only epilogue is light enough for
-// the eight-wave shape to pay (1.71 ms against 1.82 ms per 2^21-point launch; NEDDF_BF16_COL_GEO).
-static Geo geo_col(int operands)
-{
-    static Geo g{ 0, 0, 0 };
-    if (operands != 1 || tile_mt() != 2) return geo(operands);
-    if (!g.mt) g = parse_geo("NEDDF_BF16_COL_GEO", Geo{ 4, 2, 8 }, { { 4, 2, 8 }, { 4, 1, 8 }, { 4, 2, 4 }, { 2, 2, 4 }, { 4, 1, 4 } });
-    return g;
-}
-static Geo geo_col(int operands, int width) { return width == 256 ? geo_col(operands) : geo_w(width); }
-static Geo geo_nerf(int width) { return width == 256 ? (tile_mt() == 2 ? Geo{ 2, 2, 4 } : Geo{ 4, 1, 4 }) : geo_w(width); }
+static Geo geo(int operands, int width) { return width != 256 ? geo_w(width) : (operands == 1 ? Geo{ 4, 2, 4 } : Geo{ 2, 2, 4 }); }
+static Geo geo_col(int operands, int width) { return width != 256 ? geo_w(width) : (operands == 1 ? Geo{ 4, 2, 8 } : Geo{ 2, 2, 4 }); }
+static Geo geo_nerf(int width) { return width == 256 ? Geo{ 2, 2, 4 } : geo_w(width); }
 int field_wgs_per_cu(int operands, int width) { return geo(operands, width).wps; }
 int col_wgs_per_cu(int operands, int width) { return geo_col(operands, width).wps; }
 int ddf_points_per_tile(int operands, int width) { return geo(operands, width).mt * 8; }
 int col_points_per_tile(bool rows4, int operands, int width) { return rows4 ? geo_col(operands, width).mt * 8 : geo_col(operands, width).mt * 32; }
 int nerf_points_per_tile(int width) { return geo_nerf(width).mt * 32; }
 int nerf_wgs_per_cu(int width) { return geo_nerf(width).wps; }
-bool ddf_rev_available() { return tile_mt() == 2; }      // NEDDF_TILE_MT=4 (one 128-row workgroup per CU) keeps the forward-mode kernels
+int ddf_rev_points(int, int width) { return (width == 128 || width == 256) ? 64 : 32; }
+int ddf_rev_wgs_per_cu(int, int) { return 2; }
 
 static void set_lds(const void *fn, size_t bytes)
 {
@@ -2065,15 +1297,13 @@ static void launch_col_g(const ColArgs &a, int grid, bool rows4, hipStream_t s)
     else hipLaunchKernelGGL((col_trunk_kernel<false, MT, WPS, Ops, NW>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a);
 }
 
-#define NEDDF_GEO_CASE(MT_, WPS_, NW_) if (g.mt == MT_ && g.wps == WPS_ && g.nw == NW_)
-
-// one shape per non-256 engine width (geo_w), every operand policy
+// the three operand policies over one engine width; MT etc. follow geo() / geo_col() above
 template <int WID>
 static void launch_ddf_w(const DdfArgs &a, int grid, hipStream_t s)
 {
-    constexpr int MT = WID == 128 ? 2 : 1;
+    constexpr int MT = WID <= 256 ? 2 : 1;
     if (a.operands == 2) launch_ddf_g<MT, 2, 4, OpsF16SplitT<WID>>(a, grid, s);
-    else if (a.operands == 1) launch_ddf_g<MT, 2, 4, OpsBF16T<WID>>(a, grid, s);
+    else if (a.operands == 1) launch_ddf_g<(WID == 256 ? 4 : MT), 2, 4, OpsBF16T<WID>>(a, grid, s);
     else launch_ddf_g<MT, 2, 4, OpsF32T<WID>>(a, grid, s);
 }
 
@@ -2082,148 +1312,50 @@ void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
     if (a.width == 128) return launch_ddf_w<128>(a, grid, s);
     if (a.width == 384) return launch_ddf_w<384>(a, grid, s);
     if (a.width == 512) return launch_ddf_w<512>(a, grid, s);
-    const Geo g = geo(a.operands);
-    if (a.operands == 2) {
-        NEDDF_GEO_CASE(4, 1, 8) return launch_ddf_g<4, 1, 8, OpsF16Split>(a, grid, s);
-        NEDDF_GEO_CASE(2, 2, 4) return launch_ddf_g<2, 2, 4, OpsF16Split>(a, grid, s);
-        return launch_ddf_g<4, 1, 4, OpsF16Split>(a, grid, s);
-    }
-    if (a.operands == 1) {
-        NEDDF_GEO_CASE(4, 2, 8) return launch_ddf_g<4, 2, 8, OpsBF16>(a, grid, s);
-        NEDDF_GEO_CASE(4, 1, 8) return launch_ddf_g<4, 1, 8, OpsBF16>(a, grid, s);
-        NEDDF_GEO_CASE(4, 2, 4) return launch_ddf_g<4, 2, 4, OpsBF16>(a, grid, s);
-        NEDDF_GEO_CASE(2, 2, 4) return launch_ddf_g<2, 2, 4, OpsBF16>(a, grid, s);
-        return launch_ddf_g<4, 1, 4, OpsBF16>(a, grid, s);
-    }
-    NEDDF_GEO_CASE(2, 2, 4) return launch_ddf_g<2, 2, 4, OpsF32>(a, grid, s);
-    return launch_ddf_g<4, 1, 4, OpsF32>(a, grid, s);
+    launch_ddf_w<256>(a, grid, s);
 }
 
-// reverse-mode kernel: its tile shape per operand policy (see ddf_rev_kernel)
+// reverse-mode kernel (see ddf_rev_kernel)
 template <class Ops>
 static size_t rev_lds_bytes(int mt) { return lds_bytes<Ops>(mt) + (Ops::kEncInLds ? (size_t)mt * 32 * kEncLd * sizeof(typename Ops::act_t) : 0); }
 
-template <int MT, int NW, int WPS, class Ops>
-static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *col = nullptr)
-{
-    // tanhExp: y' round trip as values; ReLU / LeakyReLU: as mask bits (the kernel's header).  col: the colour trunk runs on the same tile (FUSED)
-    if constexpr (NW == 4) {
-        if (col) {
-            static bool oncef = (set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, false, true>, rev_lds_bytes<Ops>(MT)),
-                                 set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, true, true>, rev_lds_bytes<Ops>(MT)), true);
-            (void)oncef;
-            if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, false, true>), dim3(grid), dim3(64 * NW), rev_lds_bytes<Ops>(MT), s, a, *col);
-            else hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, true, true>), dim3(grid), dim3(64 * NW), rev_lds_bytes<Ops>(MT), s, a, *col);
-            return;
-        }
-    }
-    static bool once = (set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, false>, rev_lds_bytes<Ops>(MT)),
-                        set_lds((const void *)ddf_rev_kernel<MT, NW, WPS, Ops, true>, rev_lds_bytes<Ops>(MT)), true);
-    (void)once;
-    const ColArgs none{};
-    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, false>), dim3(grid), dim3(64 * NW), rev_lds_bytes<Ops>(MT), s, a, none);
-    else hipLaunchKernelGGL((ddf_rev_kernel<MT, NW, WPS, Ops, true>), dim3(grid), dim3(64 * NW), rev_lds_bytes<Ops>(MT), s, a, none);
-}
-
-// twin teams (ddf_rev_kernel<..., TEAMS = 2>): `grid` counts tiles in flight = scratch slots = teams; one workgroup carries two
 template <int MT, class Ops>
-static void launch_ddf_rev_teams(const DdfArgs &a, int grid, hipStream_t s)
+static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s)
 {
-    static bool once = (set_lds((const void *)ddf_rev_kernel<MT, 4, 2, Ops, false, false, 2>, 2 * rev_lds_bytes<Ops>(MT)),
-                        set_lds((const void *)ddf_rev_kernel<MT, 4, 2, Ops, true, false, 2>, 2 * rev_lds_bytes<Ops>(MT)), true);
+    // tanhExp: y' round trip as values; ReLU / LeakyReLU: as mask bits (the kernel's header)
+    static bool once = (set_lds((const void *)ddf_rev_kernel<MT, Ops, false>, rev_lds_bytes<Ops>(MT)),
+                        set_lds((const void *)ddf_rev_kernel<MT, Ops, true>, rev_lds_bytes<Ops>(MT)), true);
     (void)once;
-    const ColArgs none{};
-    const int wgs = (grid + 1) / 2;
-    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, 4, 2, Ops, false, false, 2>), dim3(wgs), dim3(512), 2 * rev_lds_bytes<Ops>(MT), s, a, none);
-    else hipLaunchKernelGGL((ddf_rev_kernel<MT, 4, 2, Ops, true, false, 2>), dim3(wgs), dim3(512), 2 * rev_lds_bytes<Ops>(MT), s, a, none);
+    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, Ops, false>), dim3(grid), dim3(kThreads), rev_lds_bytes<Ops>(MT), s, a);
+    else hipLaunchKernelGGL((ddf_rev_kernel<MT, Ops, true>), dim3(grid), dim3(kThreads), rev_lds_bytes<Ops>(MT), s, a);
 }
-
-template <class Ops, int MT, int WPS>
-static void launch_ddf_rev2(const DdfArgs &a, int grid, hipStream_t s)
-{
-    static bool once = (set_lds((const void *)ddf_rev2_kernel<Ops, false, MT, WPS>, lds_bytes<Ops>(MT)),
-                        set_lds((const void *)ddf_rev2_kernel<Ops, false, MT, WPS, false>, lds_bytes<Ops>(MT)),
-                        set_lds((const void *)ddf_rev2_kernel<Ops, true, MT, WPS>, lds_bytes<Ops>(MT)), true);
-    (void)once;
-    static const bool y16 = [] { const char *e = getenv("NEDDF_REV2_Y16"); return e && atoi(e) != 0; }();      // y' as bf16 pairs (A/B)
-    if (a.activation == 2 && y16) hipLaunchKernelGGL((ddf_rev2_kernel<Ops, false, MT, WPS, false>), dim3(grid), dim3(256), lds_bytes<Ops>(MT), s, a);
-    else if (a.activation == 2) hipLaunchKernelGGL((ddf_rev2_kernel<Ops, false, MT, WPS>), dim3(grid), dim3(256), lds_bytes<Ops>(MT), s, a);
-    else hipLaunchKernelGGL((ddf_rev2_kernel<Ops, true, MT, WPS>), dim3(grid), dim3(256), lds_bytes<Ops>(MT), s, a);
-}
-
-// Tile shape of the reverse-mode kernel at width 256 per operand policy: (MT, NW, WPS) = (2, 4, 2) under fp32; the 16-bit policies
-// take NEDDF_REV_GEO="MTxNWxWPS" (probes: eight waves per workgroup = 32 columns per wave, three workgroups per CU)
-static Geo geo_rev(int operands)
-{
-    static Geo g[3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
-    if (!g[0].mt) {
-        g[0] = Geo{ 2, 2, 4 };
-        g[1] = parse_geo("NEDDF_REV_GEO_BF16", Geo{ 2, 2, 4 }, { { 2, 2, 4 }, { 4, 2, 4 }, { 2, 2, 8 }, { 2, 3, 4 }, { 2, 4, 4 } });
-        g[2] = parse_geo("NEDDF_REV_GEO_SPLIT", Geo{ 2, 2, 4 }, { { 2, 2, 4 }, { 2, 2, 8 } });
-    }
-    return g[operands < 0 || operands > 2 ? 0 : operands];
-}
-int ddf_rev_points(int operands, int width) { return width == 256 ? geo_rev(operands).mt * 32 : geo_w(width).mt * 32; }
-int ddf_rev_wgs_per_cu(int operands, int width) { return width == 256 ? geo_rev(operands).wps : 2; }
 
 template <int WID>
-static void launch_ddf_rev_w(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *col)
+static void launch_ddf_rev_w(const DdfArgs &a, int grid, hipStream_t s)
 {
-    constexpr int MT = WID == 128 ? 2 : 1;
-    if (a.operands == 2) launch_ddf_rev_t<MT, 4, 2, OpsF16SplitT<WID>>(a, grid, s, col);
-    else if (a.operands == 1) launch_ddf_rev_t<MT, 4, 2, OpsBF16T<WID>>(a, grid, s, col);
-    else launch_ddf_rev_t<MT, 4, 2, OpsF32T<WID>>(a, grid, s, col);
+    constexpr int MT = WID <= 256 ? 2 : 1;
+    if (a.operands == 2) launch_ddf_rev_t<MT, OpsF16SplitT<WID>>(a, grid, s);
+    else if (a.operands == 1) launch_ddf_rev_t<MT, OpsBF16T<WID>>(a, grid, s);
+    else launch_ddf_rev_t<MT, OpsF32T<WID>>(a, grid, s);
 }
 
-// the shapes that can take the colour trunk on their tile (four waves per workgroup: every shipped shape; the eight-wave probes cannot)
-bool ddf_rev_takes_rays(int operands, int width)
+void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s)
 {
-    if (width != 256) return true;                      // launch_ddf_rev_w: four waves
-    const Geo g = geo_rev(operands);
-    if (!(g.mt == 2 && g.wps == 2 && g.nw == 4)) return false;      // the eight-wave probes and ddf_rev2_kernel read the tensors
-    static const bool two_pass = [] { const char *e = getenv("NEDDF_REV2"); return e && atoi(e) != 0; }();
-    return !(two_pass && operands == 1);
-}
-bool ddf_rev_can_fuse(int operands, int width) { return width != 256 || (geo_rev(operands).mt == 2 && geo_rev(operands).nw == 4 && geo_rev(operands).wps == 2); }
-
-void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *col)
-{
-    if (a.width == 128) return launch_ddf_rev_w<128>(a, grid, s, col);
-    if (a.width == 384) return launch_ddf_rev_w<384>(a, grid, s, col);
-    if (a.width == 512) return launch_ddf_rev_w<512>(a, grid, s, col);
-    const Geo g = geo_rev(a.operands);          // (mt, wps, nw)
-    // NEDDF_REV_TEAMS: bit 0 bf16, bit 1 split fp16 -- the two workgroups of a CU as two phase-offset teams of ONE workgroup
-    static const int teams = [] { const char *e = getenv("NEDDF_REV_TEAMS"); return e ? atoi(e) : 0; }();
-    if (!col && g.mt == 2 && g.wps == 2 && g.nw == 4) {
-        if (a.operands == 1 && (teams & 1)) return launch_ddf_rev_teams<2, OpsBF16>(a, grid, s);
-        if (a.operands == 2 && (teams & 2)) return launch_ddf_rev_teams<2, OpsF16Split>(a, grid, s);
-    }
-    if (a.operands == 2) {
-        NEDDF_GEO_CASE(2, 2, 8) return launch_ddf_rev_t<2, 8, 2, OpsF16Split>(a, grid, s);
-        return launch_ddf_rev_t<2, 4, 2, OpsF16Split>(a, grid, s, col);
-    }
-    if (a.operands == 1) {
-        NEDDF_GEO_CASE(2, 2, 8) return launch_ddf_rev_t<2, 8, 2, OpsBF16>(a, grid, s);
-        // two column passes per wave (ddf_rev2_kernel): 128-point tiles, or 64-point tiles at three / four workgroups per CU
-        NEDDF_GEO_CASE(4, 2, 4) return launch_ddf_rev2<OpsBF16, 4, 2>(a, grid, s);
-        NEDDF_GEO_CASE(2, 3, 4) return launch_ddf_rev2<OpsBF16, 2, 3>(a, grid, s);
-        NEDDF_GEO_CASE(2, 4, 4) return launch_ddf_rev2<OpsBF16, 2, 4>(a, grid, s);
-        {
-            static const bool two_pass = [] { const char *e = getenv("NEDDF_REV2"); return e && atoi(e) != 0; }();
-            if (two_pass && g.mt == 2 && g.wps == 2 && g.nw == 4) return launch_ddf_rev2<OpsBF16, 2, 2>(a, grid, s);
-        }
-        return launch_ddf_rev_t<2, 4, 2, OpsBF16>(a, grid, s, col);
-    }
-    launch_ddf_rev_t<2, 4, 2, OpsF32>(a, grid, s, col);
+    if (a.width == 128) return launch_ddf_rev_w<128>(a, grid, s);
+    if (a.width == 384) return launch_ddf_rev_w<384>(a, grid, s);
+    if (a.width == 512) return launch_ddf_rev_w<512>(a, grid, s);
+    launch_ddf_rev_w<256>(a, grid, s);
 }
 
 template <int WID>
 static void launch_col_w(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 {
-    constexpr int MT = WID == 128 ? 2 : 1;
+    constexpr int MT = WID <= 256 ? 2 : 1;
     if (a.operands == 2) launch_col_g<MT, 2, 4, OpsF16SplitT<WID>>(a, grid, rows4, s);
-    else if (a.operands == 1) launch_col_g<MT, 2, 4, OpsBF16T<WID>>(a, grid, rows4, s);
-    else launch_col_g<MT, 2, 4, OpsF32T<WID>>(a, grid, rows4, s);
+    else if (a.operands == 1) {
+        if constexpr (WID == 256) launch_col_g<4, 2, 8, OpsBF16>(a, grid, rows4, s);
+        else launch_col_g<MT, 2, 4, OpsBF16T<WID>>(a, grid, rows4, s);
+    } else launch_col_g<MT, 2, 4, OpsF32T<WID>>(a, grid, rows4, s);
 }
 
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)
@@ -2231,21 +1363,7 @@ void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s)
     if (a.width == 128) return launch_col_w<128>(a, grid, rows4, s);
     if (a.width == 384) return launch_col_w<384>(a, grid, rows4, s);
     if (a.width == 512) return launch_col_w<512>(a, grid, rows4, s);
-    const Geo g = geo_col(a.operands);
-    if (a.operands == 2) {
-        NEDDF_GEO_CASE(4, 1, 8) return launch_col_g<4, 1, 8, OpsF16Split>(a, grid, rows4, s);
-        NEDDF_GEO_CASE(2, 2, 4) return launch_col_g<2, 2, 4, OpsF16Split>(a, grid, rows4, s);
-        return launch_col_g<4, 1, 4, OpsF16Split>(a, grid, rows4, s);
-    }
-    if (a.operands == 1) {
-        NEDDF_GEO_CASE(4, 2, 8) return launch_col_g<4, 2, 8, OpsBF16>(a, grid, rows4, s);
-        NEDDF_GEO_CASE(4, 1, 8) return launch_col_g<4, 1, 8, OpsBF16>(a, grid, rows4, s);
-        NEDDF_GEO_CASE(4, 2, 4) return launch_col_g<4, 2, 4, OpsBF16>(a, grid, rows4, s);
-        NEDDF_GEO_CASE(2, 2, 4) return launch_col_g<2, 2, 4, OpsBF16>(a, grid, rows4, s);
-        return launch_col_g<4, 1, 4, OpsBF16>(a, grid, rows4, s);
-    }
-    NEDDF_GEO_CASE(2, 2, 4) return launch_col_g<2, 2, 4, OpsF32>(a, grid, rows4, s);
-    return launch_col_g<4, 1, 4, OpsF32>(a, grid, rows4, s);
+    launch_col_w<256>(a, grid, rows4, s);
 }
 
 template <int MT, int WPS, class Ops>
@@ -2256,17 +1374,10 @@ static void launch_nerf_g(const NerfArgs &a, int grid, hipStream_t s)
     hipLaunchKernelGGL((nerf_kernel<MT, WPS, Ops>), dim3(grid), dim3(kThreads), lds_bytes<Ops>(MT), s, a);
 }
 
-template <class Ops>
-static void launch_nerf_t(const NerfArgs &a, int grid, hipStream_t s)
-{
-    if (tile_mt() == 2) launch_nerf_g<2, 2, Ops>(a, grid, s);
-    else launch_nerf_g<4, 1, Ops>(a, grid, s);
-}
-
 template <int WID>
 static void launch_nerf_w(const NerfArgs &a, int grid, hipStream_t s)
 {
-    constexpr int MT = WID == 128 ? 2 : 1;
+    constexpr int MT = WID <= 256 ? 2 : 1;
     if (a.operands == 2) launch_nerf_g<MT, 2, OpsF16SplitT<WID>>(a, grid, s);
     else if (a.operands == 1) launch_nerf_g<MT, 2, OpsBF16T<WID>>(a, grid, s);
     else launch_nerf_g<MT, 2, OpsF32T<WID>>(a, grid, s);
@@ -2277,9 +1388,7 @@ void launch_nerf(const NerfArgs &a, int grid, hipStream_t s)
     if (a.width == 128) return launch_nerf_w<128>(a, grid, s);
     if (a.width == 384) return launch_nerf_w<384>(a, grid, s);
     if (a.width == 512) return launch_nerf_w<512>(a, grid, s);
-    if (a.operands == 2) launch_nerf_t<OpsF16Split>(a, grid, s);
-    else if (a.operands) launch_nerf_t<OpsBF16>(a, grid, s);
-    else launch_nerf_t<OpsF32>(a, grid, s);
+    launch_nerf_w<256>(a, grid, s);
 }
 
 }  // namespace neddf

@@ -86,14 +86,14 @@ struct DdfArgs {
     const float *wT_pe_skip[kMaxStash];   // ... and the encoding rows^T of the skip layer that owns stash[s]
     int skip_layer;                       // a trunk layer whose input is cat([encoding, h]) (the last one), or -1
     int ks_hidden;                        // super-steps of a width-wide product under this operand policy
-    float *rev_scratch;                   // per workgroup: y' of every layer [n_layers][P][256] + encoding Jacobian and copy [P][128]
+    float *rev_scratch;                   // per workgroup: y' of every layer [n_layers][P][width] + encoding Jacobian, copy and parked gradient [P][192]
     int *sched;                           // [0] tile queue head (zeroed before each launch)
-    int sched_flags;                      // bit 1: dynamic tile queue; higher bits: timing ablations, -DNEDDF_ABLATE builds only
+    int sched_flags;                      // bit 1: dynamic tile queue (always set by the library)
     float *features;                      // [n_points][feat_rows][width]
     int feat_rows;                        // 1 (value row) or 4 (value + Jacobian rows)
     float *ptaux;                         // [n_points][kPtAux]
     float *distance, *density, *aux_grad; // optional outputs [n_points]
-    RaySrc rays;                          // rays.rd != NULL: pos / dir / var are NULL, the points come from the rays (ddf_rev_kernel, four waves)
+    RaySrc rays;                          // rays.rd != NULL: pos / dir / var are NULL, the points come from the rays (ddf_rev_kernel)
     unsigned long long *stamps = nullptr; // -DNEDDF_STAMP builds only (`make stamp`, tools/stamp_timeline.py): phase time stamps of a few workgroups
 };
 #ifndef NEDDF_STAMP_TILE_INDEX
@@ -162,13 +162,10 @@ struct CameraArg {
 
 size_t field_lds_bytes(int mt);
 void launch_ddf(const DdfArgs &a, int grid, hipStream_t s);
-void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s, const ColArgs *col = nullptr);   // col: the colour trunk on the same tile (one field kernel)
-bool ddf_rev_can_fuse(int operands, int width);
-bool ddf_rev_takes_rays(int operands, int width);      // the shape in use derives its sample points from RaySrc (four-wave ddf_rev_kernel)
+void launch_ddf_rev(const DdfArgs &a, int grid, hipStream_t s);
 size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points, int width);
 int ddf_rev_points(int operands, int width);        // sample points per tile of ddf_rev_kernel under an operand policy / engine width
 int ddf_rev_wgs_per_cu(int operands, int width);
-bool ddf_rev_available();
 void launch_col(const ColArgs &a, int grid, bool rows4, hipStream_t s);
 void launch_nerf(const NerfArgs &a, int grid, hipStream_t s);
 int ddf_points_per_tile(int operands, int width);

@@ -25,21 +25,7 @@ static char g_err[256] = "no context";
 
 void neddf_comm_release(neddf_ctx *ctx);       // comm_capi.hip
 
-// NEDDF_SCHED: bit 1 dynamic tile queue (default on).  The phase-ablation bits of the distance kernel are honoured only by
-// -DNEDDF_ABLATE builds (field_kernels.hip); the shipped library masks them off.
-static int sched_flags()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("NEDDF_SCHED");
-#ifdef NEDDF_ABLATE
-        v = e ? atoi(e) & 32766 : 2;
-#else
-        v = e ? atoi(e) & 2 : 2;
-#endif
-    }
-    return v;
-}
+static int sched_flags() { return 2; }       // bit 1: dynamic tile queue (kernels.h DdfArgs::sched_flags)
 
 
 // ---------------------------------------------------------------------------
@@ -504,12 +490,10 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     UseMark mark{ ctx, f, s };
     const int dt = f.d.weight_dtype;
     const int wid = f.d.kind == NEDDF_FIELD_NERF ? f.nerf.width : f.ddf.width;        // engine width
-    // NEDDF_GRID_SLACK_PCT=<p> (probe): p % more workgroups than the CUs' slots in the persistent field grids (see tools/residency_probe.hip)
-    static const int slack_pct = [] { const char *e = getenv("NEDDF_GRID_SLACK_PCT"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 300 ? 300 : v); }();
-    auto with_slack = [&](int wgs) { return (int)((int64_t)wgs * (100 + slack_pct) / 100); };
-    const int grid_cap = with_slack(ctx->cus * nerf_wgs_per_cu(wid));
-    const int grid_cap_ddf = with_slack(ctx->cus * field_wgs_per_cu(dt, wid));
-    const int grid_cap_col = with_slack(ctx->cus * col_wgs_per_cu(dt, wid));
+    // persistent grids: every workgroup slot of the device filled once (all 512 are resident, two per CU: tools/residency_probe.hip)
+    const int grid_cap = ctx->cus * nerf_wgs_per_cu(wid);
+    const int grid_cap_ddf = ctx->cus * field_wgs_per_cu(dt, wid);
+    const int grid_cap_col = ctx->cus * col_wgs_per_cu(dt, wid);
     const int n_parked = f.d.kind == NEDDF_FIELD_NERF ? f.nerf.n_stash : f.ddf.n_stash;      // early partials a kernel may park per workgroup
     if (int rc = ensure(ctx, ctx->scratch, (size_t)(grid_cap > grid_cap_ddf ? grid_cap : grid_cap_ddf) * (n_parked > 1 ? n_parked : 1) * kStashFloatsPerWg * sizeof(float))) return rc;
     auto sample_now = [&]() {       // the sampling tensors after all (a route that reads them)
@@ -538,24 +522,14 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     // Eval-minimal NeDDF needs the gradient of one scalar (the distance) only: reverse mode halves the matrix work
     // (NEDDF_DDF_REVERSE=0 keeps the forward-mode Jacobian rows, which the penalties of the full mode need anyway)
     static const bool rev_enabled = [] { const char *e = getenv("NEDDF_DDF_REVERSE"); return !e || atoi(e) != 0; }();
-    // bit per operand policy (1 fp32, 2 bf16, 4 split fp16); all three gain: fp32 27.5 vs 51.8 ms per 2^21 points, split fp16 12.4 vs
-    // 19.9 ms, bf16 6.4 vs 7.4 ms (once its y' round trip went to bf16: with fp32 y' the kernel was HBM-bound at 8.4 ms)
-    static const int rev_mask = [] { const char *e = getenv("NEDDF_DDF_REVERSE_DTYPES"); return e ? atoi(e) : 7; }();
-    const bool reverse = rev_enabled && ((rev_mask >> dt) & 1) && !full && (f.d.kind == NEDDF_FIELD_NEDDF || f.d.kind == NEDDF_FIELD_NEUS) &&
-                         ddf_rev_available();
-    // One field kernel per slab (round 4): with the distance gradient in reverse mode the colour trunk can run on
-    // the distance kernel's own tile (ddf_rev_kernel<..., FUSED>): no [N, width] feature matrix, no per-point record, no second launch.
-    // Built, parity-green and MEASURED SLOWER than the two-kernel route (fp32 34.60 vs 34.42 ms per 2^21 points, split fp16 16.46 vs
-    // 16.10, bf16 8.29 vs 8.10; profiles/r04_fused_field_kernel.txt): the fp32 matrix pipe is saturated either way (the hand-off it
-    // saves was free), and under the 16-bit policies the stand-alone colour kernel's own tile shape beats the distance kernel's.  So it
-    // is opt-in: NEDDF_FUSED=1 (tests/test_gpu_parity.py::test_fused_field_kernel_in_subprocess holds it to the same gates).
-    static const bool fuse_enabled = [] { const char *e = getenv("NEDDF_FUSED"); return e && atoi(e) != 0; }();
-    const bool fused = fuse_enabled && reverse && color && f.d.kind == NEDDF_FIELD_NEDDF && ddf_rev_can_fuse(dt, wid);
+    // (all three operand policies gain: fp32 27.5 vs 51.8 ms per 2^21 points, split fp16 12.4 vs 19.9 ms, bf16 6.4 vs 7.4 ms)
+    const bool reverse = rev_enabled && !full && (f.d.kind == NEDDF_FIELD_NEDDF || f.d.kind == NEDDF_FIELD_NEUS);
     // Sample points straight from the rays (the cone moments in the field prologue): the reverse-mode distance
     // kernel derives them in its prologue and hands them to the colour kernel in the per-point record; NEDDF_RAYS_IN_FIELD=0 keeps the
     // sampling tensors (the A/B partner: tests/test_gpu_parity.py holds both routes bit-identical)
-    const char *rif = getenv("NEDDF_RAYS_IN_FIELD");
-    const bool use_rays = rays && (!rif || atoi(rif) != 0) && reverse && !fused && f.d.kind == NEDDF_FIELD_NEDDF && ddf_rev_takes_rays(dt, wid);
+    // (read per call, a few times per frame: the bit-identity test flips it inside one process)
+    const char *rif = rays ? getenv("NEDDF_RAYS_IN_FIELD") : nullptr;
+    const bool use_rays = rays && (!rif || atoi(rif) != 0) && reverse && f.d.kind == NEDDF_FIELD_NEDDF;
     if (rays && !use_rays) sample_now();
     // Points per launch of the field kernels.  Every launch boundary drains the persistent grid (workgroups finish up to one tile
     // apart) and refills it: at 2^21 points a 65 536-ray x 128-sample call was four launch pairs, at 2^23 it is one -- fp32 +0.8 %,
@@ -568,24 +542,24 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
     // twice that at engine width 512) is bounded by what the DEVICE has free, not by a constant: several contexts or ranks on one
     // device, or a part with less HBM, get smaller launches (-0.8 .. -2.8 % each halving, profiles/r04_launch_size.txt) instead
     // of NEDDF_EHIP -- at most a quarter of the free memory (counting what this context's own blocks give back when they grow).
-    if (!fused) {
+    {
         const size_t per_point = ((size_t)fr * wid + kPtAux) * sizeof(float);
+        // a launch size settled earlier for this row size stands (the probe is a driver call: not on the hot path of every evaluation)
+        if (ctx->handoff_row == per_point && ctx->handoff_chunk > 0 && chunk > ctx->handoff_chunk) chunk = ctx->handoff_chunk;
         if (ctx->features.cap < (size_t)chunk * fr * wid * sizeof(float) || ctx->ptaux.cap < (size_t)chunk * kPtAux * sizeof(float)) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 free_b += ctx->features.cap + ctx->ptaux.cap;
+                const int64_t asked = chunk;
                 while (chunk > (1 << 16) && (size_t)chunk * per_point + (size_t)chunk * per_point / 8 > free_b / 4) chunk >>= 1;
+                if (chunk < asked) { ctx->handoff_row = per_point; ctx->handoff_chunk = chunk; }
             }
         }
     }
     // activations' element type and planes: fp32 1024 B, bf16 512 B, split bf16 (two planes) 1024 B per row
-    if (!fused) {
-        if (int rc = ensure(ctx, ctx->features, (size_t)chunk * fr * wid * sizeof(float))) return rc;
-        if (int rc = ensure(ctx, ctx->ptaux, (size_t)chunk * kPtAux * sizeof(float))) return rc;
-    }
+    if (int rc = ensure(ctx, ctx->features, (size_t)chunk * fr * wid * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->ptaux, (size_t)chunk * kPtAux * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->sched, 2 * kSchedInts * sizeof(int))) return rc;
-    DevBuf &sink = ctx->flags;      // [>= 64 B] flags live in front; colour sink handled below
-    (void)sink;
     for (int64_t off = 0; off < N; off += chunk) {
         const int64_t n = (N - off < chunk) ? N - off : chunk;
         DdfArgs a = f.ddf;
@@ -598,17 +572,17 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
         }
         a.aux_grad_scale = f.aux_grad_scale;
         a.scratch = (float *)ctx->scratch.p;
-        a.features = ((color || full) && !fused) ? (float *)ctx->features.p : nullptr;      // no colour kernel follows: no hand-off
+        a.features = (color || full) ? (float *)ctx->features.p : nullptr;      // no colour kernel follows: no hand-off
         a.feat_rows = fr;
-        a.ptaux = fused ? nullptr : (float *)ctx->ptaux.p;
+        a.ptaux = (float *)ctx->ptaux.p;
         a.distance = distance ? distance + off : nullptr;
         a.density = density ? density + off : nullptr;
         a.aux_grad = aux ? aux + off : nullptr;
         a.sched = (int *)ctx->sched.p;
         a.sched_flags = sched_flags();
         HIPCHK(hipMemsetAsync(a.sched, 0, kSchedInts * sizeof(int), s));
-        if (reverse) {          // one scalar's gradient: reverse mode, 64 or 128 points per tile (field_kernels.hip ddf_rev_kernel)
-            const int pts = ddf_rev_points(dt, wid), wgs = with_slack(ddf_rev_wgs_per_cu(dt, wid) * ctx->cus);
+        if (reverse) {          // one scalar's gradient: reverse mode, 64 or 32 points per tile (field_kernels.hip ddf_rev_kernel)
+            const int pts = ddf_rev_points(dt, wid), wgs = ddf_rev_wgs_per_cu(dt, wid) * ctx->cus;
             const int64_t tiles = (n + pts - 1) / pts;
             const int grid = (int)(tiles < wgs ? tiles : wgs);
             if (int rc = ensure(ctx, ctx->rev_scratch, (size_t)wgs * ddf_rev_scratch_floats_per_wg(a.n_layers, pts, wid) * sizeof(float))) return rc;
@@ -620,13 +594,6 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
             HIPCHK(hipMemsetAsync(d_stamps, 0, stamp_bytes, s));
             a.stamps = d_stamps;
 #endif
-            if (fused) {
-                ColArgs c = f.col;
-                fill_enc(c.enc, f);
-                c.pos = a.pos; c.dir = a.dir; c.var = a.var; c.n_points = n;
-                c.color = color + off * 3;
-                STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf_rev(a, grid, s, &c));
-            } else
             STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf_rev(a, grid, s));
 #ifdef NEDDF_STAMP
             if (const char *path = getenv("NEDDF_STAMP_FILE")) {        // the LAST launch's stamps (a diagnostic build: synchronising here is fine)
@@ -640,7 +607,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
             const int64_t tiles = (n + ddf_points_per_tile(dt, wid) - 1) / ddf_points_per_tile(dt, wid);
             STAGE(ctx, s, NEDDF_STAGE_DDF, launch_ddf(a, (int)(tiles < grid_cap_ddf ? tiles : grid_cap_ddf), s));
         }
-        if ((color || full) && !fused) {
+        if (color || full) {
             ColArgs c = f.col;
             fill_enc(c.enc, f);
             c.pos = a.pos; c.dir = a.dir; c.var = a.var; c.n_points = n;

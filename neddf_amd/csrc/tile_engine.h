@@ -122,14 +122,6 @@ struct OpsBF16T {
         const unsigned int w = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){ va, vb }, bf16x2));
         *pa = (unsigned short)w; *pb = (unsigned short)(w >> 16);
     }
-    // a pair converted now and stored later (ddf_rev2_kernel holds the first column tile's results while the second is multiplied)
-    static __device__ __forceinline__ unsigned int pack2(float va, float vb)
-    {
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        return __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){ va, vb }, bf16x2));
-    }
-    static __device__ __forceinline__ void put_packed2(act_t *pa, act_t *pb, unsigned int w) { *pa = (unsigned short)w; *pb = (unsigned short)(w >> 16); }
     // four values of one column to four consecutive rows: two packed conversions, the upper halves stored with d16_hi
     static constexpr bool kPackedRows = true;
     static __device__ __forceinline__ void put_rows4(act_t *p, int ld, float v0, float v1, float v2, float v3)
@@ -302,23 +294,6 @@ __device__ __forceinline__ void dense_load(typename Ops::afrag (&a)[MT], typenam
     for (int mt = 0; mt < MT; ++mt) a[mt] = Ops::load_a(ap + mt * 32 * Ops::kLd);
 }
 
-// ds_read offsets are 16 bits: when the tile's upper M-tiles lie beyond them (128 rows of two-plane fp16), a second advancing
-// pointer serves the upper half
-template <int MT, class Ops>
-constexpr bool kFarTiles = ((MT - 1) * 32 * Ops::kLd + Ops::kPlane + 4 * Ops::kStep) * (int)sizeof(typename Ops::act_t) > 65000;
-
-template <int MT, int NT, class Ops = OpsF32>
-__device__ __forceinline__ void dense_load2(typename Ops::afrag (&a)[MT], typename Ops::bfrag (&b)[NT], const typename Ops::act_t *ap,
-                                            const typename Ops::act_t *aq, const WeightStream &w, int ksteps, int S)
-{
-    if constexpr (kFarTiles<MT, Ops>) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = stream_load<typename Ops::bfrag>(w, (unsigned)(t * ksteps + S));
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = Ops::load_a((mt < MT / 2 ? ap + mt * 32 * Ops::kLd : aq + (mt - MT / 2) * 32 * Ops::kLd));
-    } else dense_load<MT, NT, Ops>(a, b, ap, w, ksteps, S);
-}
-
 template <int MT, int NT, class Ops = OpsF32>
 __device__ __forceinline__ void dense_mfma(f32x16 (&acc)[MT][NT], const typename Ops::afrag (&a)[MT], const typename Ops::bfrag (&b)[NT])
 {
@@ -402,85 +377,32 @@ __device__ __forceinline__ void dense_pipeline3(f32x16 (&acc)[MT][NT], typename 
     }
 }
 
-// The same with the weight fragments DB - 1 super-steps ahead (ring of DB sets) and the LDS fragments DA - 1 ahead (ring of DA): a probe
-// of how far the 16-bit products wait on L2 latency (-DNEDDF_PF_B=<DB> -DNEDDF_PF_A=<DA>; dense_pipeline3 is DB = 3, DA = 2).
-template <int MT, int NT, class Ops, int DB, int DA>
-__device__ __forceinline__ void dense_pipeline_deep(f32x16 (&acc)[MT][NT], typename Ops::afrag (&a0)[MT], typename Ops::bfrag (&b0)[NT],
-                                                    const typename Ops::act_t *act_lane, const WeightStream &wl, int ksteps)
-{
-    static_assert(DB >= 2 && DA >= 2, "at least one super-step ahead");
-    constexpr int U = DB * DA;              // unroll: both rings return to slot 0
-    typename Ops::afrag a[DA][MT];
-    typename Ops::bfrag b[DB][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[0][mt] = a0[mt];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) b[0][t] = b0[t];
-#pragma unroll
-    for (int d = 1; d < DB - 1; ++d)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b[d][t] = stream_load<typename Ops::bfrag>(wl, (unsigned)(t * ksteps + (d < ksteps ? d : ksteps - 1)));
-#pragma unroll
-    for (int d = 1; d < DA - 1; ++d)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[d][mt] = Ops::load_a(act_lane + d * Ops::kStep + mt * 32 * Ops::kLd);
-    const typename Ops::act_t *ap = act_lane;
-    for (int S = 0; S < ksteps; S += U) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (S + u >= ksteps) break;                 // wave-uniform
-            const int sb = S + u + DB - 1 < ksteps ? S + u + DB - 1 : ksteps - 1;     // (clamped: the index could leave the allocation)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) b[(u + DB - 1) % DB][t] = stream_load<typename Ops::bfrag>(wl, (unsigned)(t * ksteps + sb));
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[(u + DA - 1) % DA][mt] = Ops::load_a(ap + (u + DA - 1) * Ops::kStep + mt * 32 * Ops::kLd);
-            __builtin_amdgcn_sched_barrier(0);
-            dense_mfma<MT, NT, Ops>(acc, a[u % DA], b[u % DB]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        ap += U * Ops::kStep;
-    }
-}
-
-#ifndef NEDDF_PF_B
-#define NEDDF_PF_B 3
-#endif
-#ifndef NEDDF_PF_A
-#define NEDDF_PF_A 2
-#endif
-
 template <int MT, int NT, class Ops = OpsF32>
 __device__ __forceinline__ void dense_pipeline(f32x16 (&acc)[MT][NT], typename Ops::afrag (&a0)[MT], typename Ops::bfrag (&b0)[NT],
                                                const typename Ops::act_t *act_lane, const WeightStream &wl, int ksteps)
 {
-    if constexpr (Ops::kDeepPrefetch && !kFarTiles<MT, Ops>) {
-        if constexpr (NEDDF_PF_B == 3 && NEDDF_PF_A == 2) dense_pipeline3<MT, NT, Ops>(acc, a0, b0, act_lane, wl, ksteps);
-        else dense_pipeline_deep<MT, NT, Ops, NEDDF_PF_B, NEDDF_PF_A>(acc, a0, b0, act_lane, wl, ksteps);
+    if constexpr (Ops::kDeepPrefetch) {
+        dense_pipeline3<MT, NT, Ops>(acc, a0, b0, act_lane, wl, ksteps);
         return;
     }
     typename Ops::afrag a1[MT];
     typename Ops::bfrag b1[NT];
     // A fragments past the last super-step are fetched like the others and never used (the reads stay inside the workgroup's
     // LDS: at most two super-steps beyond a row's columns); the weight index is clamped instead, it could leave the allocation
-    // (the distance between the two pointers is hidden from the compiler, which otherwise folds them back into one induction
-    // variable + one vector add per far read)
-    int far = (MT / 2) * 32 * Ops::kLd;
-    if constexpr (kFarTiles<MT, Ops>) asm volatile("" : "+v"(far));
-    const typename Ops::act_t *ap = act_lane, *aq = act_lane + far;
+    const typename Ops::act_t *ap = act_lane;
     for (int S = 0; S < ksteps; S += 2) {
         const bool more = S + 1 < ksteps;
-        dense_load2<MT, NT, Ops>(a1, b1, ap + Ops::kStep, aq + Ops::kStep, wl, ksteps, more ? S + 1 : S);
+        dense_load<MT, NT, Ops>(a1, b1, ap + Ops::kStep, wl, ksteps, more ? S + 1 : S);
         __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
         dense_mfma<MT, NT, Ops>(acc, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            dense_load2<MT, NT, Ops>(a0, b0, ap + 2 * Ops::kStep, aq + 2 * Ops::kStep, wl, ksteps, S + 2 < ksteps ? S + 2 : S);
+            dense_load<MT, NT, Ops>(a0, b0, ap + 2 * Ops::kStep, wl, ksteps, S + 2 < ksteps ? S + 2 : S);
             __builtin_amdgcn_sched_barrier(0);
             dense_mfma<MT, NT, Ops>(acc, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
         ap += 2 * Ops::kStep;
-        if constexpr (kFarTiles<MT, Ops>) aq += 2 * Ops::kStep;
     }
 }
 
@@ -520,11 +442,8 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[MT][NT], const float *bia
     }
 }
 
-// (mtmask: -1; the timing probes of -DNEDDF_ABLATE builds pass 0 to fold every M-tile onto the first one's slot)
-// STREAM: non-temporal stores (the y' round trip of the reverse-mode kernel: written once, read once a tile later -- it should not
-// push the weights, which every tile re-reads, out of the L2)
-template <int MT, int NT, bool STREAM = false>
-__device__ __forceinline__ void stash_store(const f32x16 (&acc)[MT][NT], float *slot, int wave, int lane, int mtmask = -1)
+template <int MT, int NT>
+__device__ __forceinline__ void stash_store(const f32x16 (&acc)[MT][NT], float *slot, int wave, int lane)
 {
     f32x4v *dst = (f32x4v *)slot + (size_t)wave * (MT * NT * 4) * 64 + lane;
 #pragma unroll
@@ -534,14 +453,13 @@ __device__ __forceinline__ void stash_store(const f32x16 (&acc)[MT][NT], float *
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4v v = { acc[mt][t][4 * g], acc[mt][t][4 * g + 1], acc[mt][t][4 * g + 2], acc[mt][t][4 * g + 3] };
-                if constexpr (STREAM) __builtin_nontemporal_store(v, &dst[(((mt & mtmask) * NT + t) * 4 + g) * 64]);
-                else dst[(((mt & mtmask) * NT + t) * 4 + g) * 64] = v;
+                dst[((mt * NT + t) * 4 + g) * 64] = v;
             }
 }
 
 // the same in bf16: 16 accumulators = two 16-byte chunks per lane
-template <int MT, int NT, bool STREAM = false>
-__device__ __forceinline__ void stash_store16(const f32x16 (&acc)[MT][NT], float *slot, int wave, int lane, int mtmask = -1)
+template <int MT, int NT>
+__device__ __forceinline__ void stash_store16(const f32x16 (&acc)[MT][NT], float *slot, int wave, int lane)
 {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -556,54 +474,21 @@ __device__ __forceinline__ void stash_store16(const f32x16 (&acc)[MT][NT], float
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     v[i] = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){ acc[mt][t][8 * c + 2 * i], acc[mt][t][8 * c + 2 * i + 1] }, bf16x2));
-                if constexpr (STREAM) __builtin_nontemporal_store(v, &dst[(((mt & mtmask) * NT + t) * 2 + c) * 64]);
-                else dst[(((mt & mtmask) * NT + t) * 2 + c) * 64] = v;
+                dst[((mt * NT + t) * 2 + c) * 64] = v;
             }
 }
 
-template <bool STREAM = false>
 __device__ __forceinline__ void stash_load16(f32x16 &dst, const u32x4 *src)     // src: this lane's first chunk of the accumulator tile
 {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        const u32x4 v = STREAM ? __builtin_nontemporal_load(&src[c * 64]) : src[c * 64];
+        const u32x4 v = src[c * 64];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             dst[8 * c + 2 * i] = __builtin_bit_cast(float, v[i] << 16);
             dst[8 * c + 2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
         }
     }
-}
-
-// y' of tanhExp as EIGHT bits per element (the 128-point reverse-mode kernel of the bf16 policy, ddf_rev2_kernel): the derivative of
-// x tanh(e^x) lies in [-0.1316, 1.0620], so a linear code q = y' / step + 30 with step = 0.00475 covers [-0.1425, 1.0688] -- an
-// absolute error of at most 2.4e-3, where the bf16 it replaces has up to 2.0e-3 on [0.5, 1) and 3.9e-3 on [1, 2) -- at half the bytes
-// of the round trip that paces the 16-bit kernels.  ZERO IS A CODE POINT (q = 30): a switched-off unit (y' -> 0: most of a trained
-// network's units at a given point) contributes exactly nothing, as it does in bf16; with zero between two code points every one of
-// them carried half a step of bias (measured: PSNR against the fp32 oracle 56 dB instead of 75).  Rounding by the 2^23 trick:
-// fma(y', 1 / step, 30 + 2^23) carries round-to-nearest-even(y' / step + 30) in its low mantissa byte; three v_perm_b32 gather four of
-// them into a dword.
-constexpr float kY8Step = 0.00475f, kY8Zero = 30.0f, kY8Scale = 1.0f / kY8Step, kY8Lo = kY8Zero * kY8Step;
-__device__ __forceinline__ unsigned y8_pack4(float a, float b, float c, float d)
-{
-    constexpr float K = kY8Zero + 8388608.0f;
-    const unsigned ua = __builtin_bit_cast(unsigned, fmaf(a, kY8Scale, K)), ub = __builtin_bit_cast(unsigned, fmaf(b, kY8Scale, K));
-    const unsigned uc = __builtin_bit_cast(unsigned, fmaf(c, kY8Scale, K)), ud = __builtin_bit_cast(unsigned, fmaf(d, kY8Scale, K));
-    const unsigned lo = __builtin_amdgcn_perm(ub, ua, 0x0c0c0400u);        // [a.0, b.0, 0, 0]
-    const unsigned hi = __builtin_amdgcn_perm(ud, uc, 0x0c0c0400u);        // [c.0, d.0, 0, 0]
-    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);                     // [a.0, b.0, c.0, d.0]
-}
-__device__ __forceinline__ u32x4 y8_pack16(const f32x16 &v)
-{
-    u32x4 w;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) w[g] = y8_pack4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-    return w;
-}
-template <int K>
-__device__ __forceinline__ float y8_get(unsigned w)      // element K of a packed dword (v_cvt_f32_ubyteK + one fma)
-{
-    return fmaf((float)((w >> (8 * K)) & 0xffu), kY8Step, -kY8Lo);
 }
 
 template <int MT, int NT>

@@ -41,24 +41,12 @@ bool wide_fused()
     return on;
 }
 
-bool dw_jobs_256()           // NEDDF_TRAIN_DW_JOBS=0: the 256-wide fp32 route's weight gradients one launch per product (A/B partner of dw_jobs_kernel)
-{
-    static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_DW_JOBS"); return !(e && atoi(e) == 0); }();
-    return on;
-}
-
-bool wide_dw_jobs()          // NEDDF_TRAIN_WIDE_DW_JOBS=1: the wide fused route's weight gradients through the job-parallel launch after all (A/B)
-{
-    static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_WIDE_DW_JOBS"); return e && atoi(e) != 0; }();
-    return on;
-}
-
-// NEDDF_TRAIN_SPLIT_DW_JOBS=0: the split-fp16 fused route's weight gradients as one launch per product (A/B partner of the job-parallel launch)
-bool split_dw_jobs()
-{
-    static const bool on = [] { const char *e = getenv("NEDDF_TRAIN_SPLIT_DW_JOBS"); return !(e && atoi(e) == 0); }();
-    return on;
-}
+// Weight gradients: the 256-wide routes (fp32 and split fp16) take the job-parallel launch (dw_jobs_kernel / dw_split_jobs_kernel: one launch
+// per pass; fp32 39.1 against 39.7 ms per step, split fp16 +1 %), the 512-wide fused routes one launch per 256 x 256 block (the job-parallel
+// launch measured 6x slower with their 46 blocks).  The A/B switches of rounds 4-5 left with round 6's pruning (docs/lab_notebook.md R5.18-R5.19).
+static constexpr bool dw_jobs_256() { return true; }
+static constexpr bool wide_dw_jobs() { return false; }
+static constexpr bool split_dw_jobs() { return true; }
 
 // NEDDF_TRAIN_SPLIT_FUSED=0: the split-fp16 policy's backward pass as one GEMM kernel per layer on row-major matrices (rounds 1-4)
 // instead of the fused input-gradient chains on point-major ones (round 5: mlp_backward_split_kernel)

@@ -85,7 +85,7 @@ struct MlpForwardArgs {
     // forward's 13 ms per training step (profiles/r03_train_ablation.txt).  The NeDDF fp32 training route uses it end to end
     // (forward, backward chain, weight gradients, heads); every other route keeps row-major matrices.
     int point_major;
-    int width;                            // 0 / 256: the [R, 256] matrices above; 512 (round 5, fp32 + point_major only): [R, 512] matrices, 512 x 512 packed weights
+    int width;                            // 0 / 256: the [R, 256] matrices above; 512 (round 5; point-major matrices; fp32 and split fp16): [R, 512] matrices, 512 x 512 packed weights
 };
 void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t s);
 
@@ -118,7 +118,7 @@ struct MlpBackwardArgs {
     // weight-gradient products that follow (launch_dw's amax_g); NULL slots are skipped
     float *amax_dZ[kMaxLayers];           // for dZ[l]
     float *amax_top;                      // for top_out
-    int width;                            // 0 / 256, or 512 (round 5, fp32 only): every [R, 256] above is [R, 512], every packed matrix 512 x 512
+    int width;                            // 0 / 256, or 512 (round 5; fp32 and split fp16): every [R, 256] above is [R, 512], every packed matrix 512 x 512
 };
 void launch_mlp_backward(int split, const MlpBackwardArgs &a, int cus, hipStream_t s);
 
@@ -164,7 +164,7 @@ void launch_dw_jobs(DwJobs &jobs, int cus, hipStream_t s);
 void launch_dw_split_jobs(DwJobs &jobs, float *tmp, int cus, hipStream_t s);
 void launch_dw(int split, const float *X, int ldx, int K, const float *G, int ldg, int64_t R, float *dW, int64_t sk, int64_t sn, int nvalid, float *db,
                int bias_period, int cus, hipStream_t s, const float *amax_g = nullptr, float *scaled_tmp = nullptr, int x_point_major = 0,
-               int g_point_major = 0);        // (point-major operands: split policy only, 256 columns, R % 4 == 0)
+               int g_point_major = 0);        // (point-major operands: both policies -- the split-fp16 fused route and the fp32 512-wide one --, R % 4 == 0)
 // scaled_tmp: [256, 256] floats of scratch, required with amax_g (the scaled product is formed there, then added to dW unscaled)
 // heads (1..4 output columns, input width 256): column c of the weight gradient is w[c][k * wstride], b[c] its bias gradient
 void launch_narrow_dw(const float *X, int ldx, const float *G, int ldg, int64_t R, int nc, float *const *w, int wstride, float *const *b,

@@ -296,22 +296,6 @@ void launch_rows_gemm_actback(int split, const float *X, int64_t R, int ldx, int
                           amax_in, amax_out);
 }
 
-// timing ablations (-DNEDDF_ABLATE builds only, NEDDF_DW_ABLATE bits; results invalid).  Weight-gradient kernel: 1 no global fetch,
-// 2 no LDS staging / barriers, 4 no MFMA loop, 8 no atomic epilogue.  Fused forward: 16 no Z store, 32 no H store, 64 activation
-// replaced by a move, 128 no LDS write.  Fused backward: 256 no dZ store, 512 no Z load, 1024 activation derivatives replaced by
-// constants, 2048 no LDS write.  4096: no MFMA loops in the two.  32768: cycle counters of the fused forward (where a wave's time goes).
-#ifdef NEDDF_ABLATE
-__device__ int g_dw_ablate = 0;
-#define DW_ABL(bit) (g_dw_ablate & (bit))
-static void ablate_init()
-{
-    static bool once = [] { const char *e = getenv("NEDDF_DW_ABLATE"); int v = e ? atoi(e) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dw_ablate), &v, sizeof(v)); return true; }();
-    (void)once;
-}
-#else
-#define DW_ABL(bit) 0
-static void ablate_init() {}
-#endif
 
 // ----------------------------------------------------------------------------
 // Fused forward of a layer stack (train_kernels.h MlpForwardArgs): the inference tile engine with side stores.
@@ -343,23 +327,22 @@ __device__ __forceinline__ void mlp_epilogue(const f32x16 (&acc)[MT][NT], typena
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z[r] = acc[mt][t][4 * g + r] * unscale;
                 float y, dy;
-                if (DW_ABL(64)) { y = z[0]; dy = 1.f; } else
                 act_grad<KIND>(z[0], y, dy);
                 const float hv[4] = { y, dy * z[1], dy * z[2], dy * z[3] };
                 const int off = (mt * 32 + 8 * g) * W + t * 32;
                 if (FULL || r0 + mt * 32 + 8 * g + 4 * h < R) {     // R is a multiple of 4: a point's rows are all inside or all outside
                     if constexpr (PM) {
                         const int poff = (mt * 8 + 2 * g) * (4 * W) + t * 128;
-                        if (!DW_ABL(16)) __builtin_nontemporal_store(f32x4v{ z[0], z[1], z[2], z[3] }, (f32x4v *)(zpm + poff));
-                        if (!DW_ABL(32)) __builtin_nontemporal_store(f32x4v{ hv[0], hv[1], hv[2], hv[3] }, (f32x4v *)(hpm + poff));
+                        __builtin_nontemporal_store(f32x4v{ z[0], z[1], z[2], z[3] }, (f32x4v *)(zpm + poff));
+                        __builtin_nontemporal_store(f32x4v{ hv[0], hv[1], hv[2], hv[3] }, (f32x4v *)(hpm + poff));
                     } else
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (!DW_ABL(16)) zb[off + r * W] = z[r];
-                        if (!DW_ABL(32)) hb[off + r * W] = hv[r];
+                        zb[off + r * W] = z[r];
+                        hb[off + r * W] = hv[r];
                     }
                 }
-                if (!LAST && !DW_ABL(128)) {
+                if (!LAST) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Ops::put(o + (8 * g + r) * LD, hv[r]);
                 }
@@ -406,17 +389,6 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
             for (int q = 0; q < 4; ++q) Ops::put(act + (4 * p + q) * LD + c, v[q]);
         }
     };
-#ifdef NEDDF_ABLATE
-    // NEDDF_DW_ABLATE bit 32768: where a wave's time goes (shader clocks), printed by two workgroups at the end of the launch
-    const bool timed = DW_ABL(32768) != 0;
-    long long tk[6] = { 0, 0, 0, 0, 0, 0 }, tlast = 0, tstart = 0;
-    auto tick = [&](int k) { if (timed) { const long long t = clock64(); tk[k] += t - tlast; tlast = t; } };
-    long long treal = 0;
-    if (timed) { tlast = tstart = clock64(); treal = wall_clock64(); }
-#define FWD_TICK(k) tick(k)
-#else
-#define FWD_TICK(k)
-#endif
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * ROWS;
         __syncthreads();                // the previous tile is done with the LDS tile
@@ -448,7 +420,6 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
                             for (int t = 0; t < NT; ++t) acc[mt][t] += held[mt][t];
                     }
                 }
-                if (!DW_ABL(4096))
                 dense<MT, NT, Ops>(acc, act_lane, frags(a.wp[l], W / Ops::kStep), W / Ops::kStep);
                 if constexpr (!HOLD) {
                     if (l == a.skip_layer) {
@@ -459,9 +430,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
                     }
                 }
             }
-            FWD_TICK(0);                // staging + products (with their waits for weights -- and for the previous epilogue's stores)
             __syncthreads();            // every wave finished reading the previous activations
-            FWD_TICK(1);
             // one straight-line epilogue per (activation, interior / ragged tile, last layer or not): no per-group branches
             const bool full = r0 + ROWS <= a.R, last = l + 1 == a.n_layers;
             auto run = [&](auto kind, auto is_full, auto is_last) {
@@ -474,20 +443,9 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
             if (a.act_kind == 0) by_shape(std::integral_constant<int, 0>{});
             else if (a.act_kind == 1) by_shape(std::integral_constant<int, 1>{});
             else by_shape(std::integral_constant<int, 2>{});
-            FWD_TICK(2);
-#ifdef NEDDF_ABLATE
-            if (timed) { __builtin_amdgcn_s_waitcnt(0x0F70); tick(3); }        // vmcnt(0): the side stores have completed
-#endif
             if (l + 1 < a.n_layers) __syncthreads();        // the next layer reads what this epilogue wrote
-            FWD_TICK(4);
         }
     }
-#ifdef NEDDF_ABLATE
-    if (timed && (blockIdx.x == 0 || blockIdx.x == 301) && (threadIdx.x & 63) == 0)
-        printf("fwd wg %d wave %d R %lld layers %d: products %lld bar1 %lld epilogue %lld drain %lld bar2 %lld total %lld (%lld ticks of the 100 MHz clock)\n",
-               (int)blockIdx.x, (int)(threadIdx.x >> 6), (long long)a.R, a.n_layers, tk[0], tk[1], tk[2], tk[3], tk[4], (long long)clock64() - tstart,
-               (long long)wall_clock64() - treal);
-#endif
 }
 
 template <class Ops, bool HOLD, bool PM>
@@ -504,7 +462,6 @@ static void launch_mlp_forward_ops(const MlpForwardArgs &a, int cus, hipStream_t
 void launch_mlp_forward(int split, const MlpForwardArgs &a, int cus, hipStream_t s)
 {
     if (a.R <= 0) return;
-    ablate_init();
     if (a.width == 512) {       // round 5: wide fields (point-major) on the fused chain too
         if (split) launch_mlp_forward_ops<OpsF16SplitT<512>, false, true>(a, cus, s);
         else launch_mlp_forward_ops<OpsF32T<512>, true, true>(a, cus, s);
@@ -535,17 +492,16 @@ __device__ __forceinline__ void mlp_backward_epilogue(const f32x16 (&acc)[MT][NT
             for (int g = 0; g < 4; ++g) {
                 // rows 8 g + 4 h + {0, 1, 2, 3} of the tile = (value, d/dx, d/dy, d/dz) of one point, one feature
                 float dy, d2;
-                if (DW_ABL(1024)) { dy = 1.f; d2 = 0.5f; } else
                 act_grad2<KIND>(zp[mt][t][4 * g], dy, d2);
                 const float g0 = acc[mt][t][4 * g], g1 = acc[mt][t][4 * g + 1], g2 = acc[mt][t][4 * g + 2], g3 = acc[mt][t][4 * g + 3];
                 float sj = g1 * zp[mt][t][4 * g + 1];
                 sj += g2 * zp[mt][t][4 * g + 2];
                 sj += g3 * zp[mt][t][4 * g + 3];
                 const float ov[4] = { g0 * dy + sj * d2, g1 * dy, g2 * dy, g3 * dy };
-                if (r0 + mt * 32 + 8 * g + 4 * h < R && !DW_ABL(256))
+                if (r0 + mt * 32 + 8 * g + 4 * h < R)
                     __builtin_nontemporal_store(f32x4v{ ov[0], ov[1], ov[2], ov[3] }, (f32x4v *)(gb + (mt * 8 + 2 * g) * (4 * W) + t * 128));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (!DW_ABL(2048)) o[(8 * g + r) * LD] = ov[r];
+                for (int r = 0; r < 4; ++r) o[(8 * g + r) * LD] = ov[r];
             }
         }
 }
@@ -585,7 +541,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-                        if (r0 + mt * 32 + 8 * g + 4 * h < a.R && !DW_ABL(512)) v = __builtin_nontemporal_load((const f32x4v *)(zb + (mt * 8 + 2 * g) * (4 * W) + t * 128));
+                        if (r0 + mt * 32 + 8 * g + 4 * h < a.R) v = __builtin_nontemporal_load((const f32x4v *)(zb + (mt * 8 + 2 * g) * (4 * W) + t * 128));
 #pragma unroll
                         for (int r = 0; r < 4; ++r) zp[mt][t][4 * g + r] = v[r];
                     }
@@ -637,7 +593,6 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_kernel(const MlpBack
             __builtin_amdgcn_sched_barrier(0);
             f32x16 acc[MT][NT];
             acc_init<MT, NT, false>(acc, nullptr, wave, lane);
-            if (!DW_ABL(4096))
             dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
             __syncthreads();            // every wave finished reading dZ_l
             mlp_backward_epilogue<KIND, W, MT, NT>(acc, zp, act, a.dZ[l - 1], r0, a.R, wave, lane);
@@ -840,7 +795,6 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_backward_split_kernel(const M
 void launch_mlp_backward(int split, const MlpBackwardArgs &a, int cus, hipStream_t s)
 {
     if (a.R <= 0 || (a.n_layers < 2 && a.dZtop)) return;         // a one-layer stack still has a prologue to run
-    ablate_init();
     if (split && a.dZtop) {             // a caller's error, not a data condition: the split chain exists in its prologue form only
         fprintf(stderr, "neddf: launch_mlp_backward(split = 1) takes the top gradient through top_G / top_src, not dZtop\n");
         abort();
@@ -966,13 +920,6 @@ __device__ __forceinline__ void dw_tile_rows(const float *X, int ldx, int K, con
     auto grow = [&](int i) { return GPM ? 4 * i : (tid + i * kThreads) >> 6; };
     auto fetch = [&](int64_t c0) {
         const float *xb = X + c0 * ldx, *gb = G + c0 * ldg;
-        if (DW_ABL(1)) {
-#pragma unroll
-            for (int i = 0; i < XPF; ++i) xp[i] = f32x4v{ 1.f, 1.f, 1.f, 1.f };
-#pragma unroll
-            for (int i = 0; i < GPF; ++i) gp[i] = f32x4v{ 1.f, 1.f, 1.f, 1.f };
-            return;
-        }
         if (c0 + RC <= re) {            // a full chunk: no row tests
 #pragma unroll
             for (int i = 0; i < XPF; ++i) {
@@ -999,12 +946,12 @@ __device__ __forceinline__ void dw_tile_rows(const float *X, int ldx, int K, con
     };
     fetch(rb);
     for (int64_t c0 = rb; c0 < re; c0 += RC) {
-        if (!DW_ABL(2)) __syncthreads();
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < XPF; ++i) {
             int idx = tid + i * kThreads, r = idx / (KP / 4), c = idx - r * (KP / 4);
-            if (XPM) { if (!DW_ABL(2)) *(f32x4v *)(Xs + i * PS + 4 * tid) = xp[i]; }
-            else if (r < RC && !DW_ABL(2)) *(f32x4v *)(Xs + r * LDX + 4 * c) = xp[i];
+            if (XPM) { *(f32x4v *)(Xs + i * PS + 4 * tid) = xp[i]; }
+            else if (r < RC) *(f32x4v *)(Xs + r * LDX + 4 * c) = xp[i];
         }
 #pragma unroll
         for (int i = 0; i < GPF; ++i) {
@@ -1014,17 +961,16 @@ __device__ __forceinline__ void dw_tile_rows(const float *X, int ldx, int K, con
             // Inside the MFMA loop -- first as a 64-bit vector modulo per row pair, 280 of that loop's 314 vector instructions per
             // 64 MFMAs, then as a masked add -- every one of these instructions broke the MFMA issue chain
             if (GPM) {
-                if (!DW_ABL(2)) *(f32x4v *)(Gs + i * PS + 4 * tid) = gp[i];
+                *(f32x4v *)(Gs + i * PS + 4 * tid) = gp[i];
                 if (db) bsum[0] += bias_period == 4 ? gp[i][0] : (gp[i][0] + gp[i][1]) + (gp[i][2] + gp[i][3]);
             } else {
-                if (!DW_ABL(2)) *(f32x4v *)(Gs + (idx >> 6) * LDG + 4 * (idx & 63)) = gp[i];
+                *(f32x4v *)(Gs + (idx >> 6) * LDG + 4 * (idx & 63)) = gp[i];
                 if (db && (((idx >> 6) & (bias_period - 1)) == 0)) bsum += gp[i];
             }
         }
-        if (!DW_ABL(2)) __syncthreads();
+        __syncthreads();
         if (c0 + RC < re) fetch(c0 + RC);
         __builtin_amdgcn_sched_barrier(0);
-        if (DW_ABL(4)) continue;
         // Software pipeline over the points of the chunk (2 row pairs each): the operands of point p + 1 are requested before the
         // 4 KT MFMAs of point p issue.  Left to itself hipcc reads each pair of k-tiles right in front of its four MFMAs and waits
         // (`ds_read2_b32; s_waitcnt lgkmcnt(0)` every 4 MFMAs: the LDS latency of 16 loads per chunk row pair, un-overlapped with
@@ -1074,7 +1020,7 @@ __device__ __forceinline__ void dw_tile_rows(const float *X, int ldx, int K, con
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 int k = 32 * kt + 8 * (q >> 2) + 4 * h + (q & 3), n = n0 + 32 * t + j;
-                if (k < K && n < nvalid && !DW_ABL(8)) atomicAdd(&dW[k * sk + n * sn], acc[kt][t][q]);
+                if (k < K && n < nvalid) atomicAdd(&dW[k * sk + n * sn], acc[kt][t][q]);
             }
     }
     if (GPM) {
@@ -1137,7 +1083,6 @@ void launch_dw_jobs(DwJobs &jobs, int cus, hipStream_t s)
     const size_t lds = (size_t)32 * (LDX + LDG) * sizeof(float);
     static bool once = ((void)hipFuncSetAttribute((const void *)dw_jobs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32 * (LDX + LDG) * sizeof(float))), true);
     (void)once;
-    ablate_init();
     hipLaunchKernelGGL(dw_jobs_kernel, dim3(grid), dim3(kThreads), lds, s, jobs);
 }
 
@@ -1152,7 +1097,6 @@ static void launch_dw_tile(const float *X, int ldx, int K, const float *G, int l
     int64_t chunks = (R + 31) / 32;
     int grid = (int)(chunks < cus ? chunks : cus);
     int64_t rows_per_wg = ((chunks + grid - 1) / grid) * 32;
-    ablate_init();
     hipLaunchKernelGGL((dw_tile_kernel<KT, KTN, XPM, GPM>), dim3(grid), dim3(kThreads), lds, s, X, ldx, K, G, ldg, R, rows_per_wg, dW, sk, sn, nvalid, db, bias_period);
 }
 

@@ -456,22 +456,3 @@ def test_split_operands_saturate_instead_of_overflowing(dev):
     assert torch.isfinite(o["density"]).all() and torch.isfinite(o["color"]).all()
 
 
-@pytest.mark.parametrize("env", [{"NEDDF_REV_GEO_BF16": "4x2x4"}, {"NEDDF_REV_GEO_BF16": "2x3x4"}, {"NEDDF_REV_GEO_BF16": "2x3x4", "NEDDF_REV2_Y16": "1"},
-                                 {"NEDDF_REV_TEAMS": "3"}], ids=["two_pass_128pt", "two_pass_3wg", "two_pass_3wg_y16", "twin_teams"])
-def test_reverse_kernel_probe_shapes_in_subprocess(env):
-    """The round-5 probe shapes of the reverse-mode distance kernel stay parity-tested (built, measured, not faster
-    than the shipped shape): ddf_rev2_kernel -- two column passes per wave on 128-point tiles at two workgroups per CU, or on 64-point
-    tiles at three; y' as eight bits or as bf16 pairs -- and the twin teams one barrier apart (bf16 and split fp16).  Same gates as the
-    default: the bf16 emulation, the fp32-level gates of the split policy, the end-to-end renders."""
-    import os
-    import subprocess
-    import sys
-    from conftest import ROOT
-    sel = ["tests/test_gpu_c5.py::test_bf16_field_against_bf16_emulation", "tests/test_gpu_c5.py::test_bf16_single_layer_tight",
-           "tests/test_gpu_c5.py::test_bf16_other_architectures", "tests/test_gpu_c5.py::test_render_rays_ndc_bf16_end_to_end",
-           "tests/test_gpu_c5.py::test_split_operand_fields_meet_the_fp32_gate", "tests/test_gpu_c5.py::test_split_operand_render_rays_end_to_end",
-           "tests/test_gpu_c5.py::test_operand_policies_on_other_widths_and_activations"]
-    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu"] + sel, env=dict(os.environ, **env), cwd=ROOT, capture_output=True,
-                       text=True, timeout=900)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
-    assert "passed" in p.stdout and "skipped" not in p.stdout.splitlines()[-1], p.stdout[-500:]

@@ -765,18 +765,6 @@ def test_public_stage_methods(dev):
     assert torch.isfinite(o["color"]).all() and o["weight"].shape == (2, 257)
 
 
-def test_128_row_tile_variant_in_subprocess():
-    """NEDDF_TILE_MT=4 (one 128-row workgroup per CU, global-scratch skip partial) must give the same parity."""
-    import os
-    import subprocess
-    import sys
-    from conftest import ROOT
-    env = dict(os.environ, NEDDF_TILE_MT="4")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py"), "smoke"], env=env, capture_output=True, text=True,
-                       timeout=600)
-    assert p.returncode == 0 and "smoke ok" in p.stdout, p.stdout + p.stderr
-
-
 def test_forward_mode_kernels_in_subprocess():
     """NEDDF_DDF_REVERSE=0: the eval-minimal path on the forward-mode Jacobian kernels (the round-1 formulation, which still
     serves the training-mode outputs) must hold the same gates under every operand policy: the fp32 field and end-to-end
@@ -822,30 +810,6 @@ def test_reduced_cost_activation_against_the_branch_exact_build(dev):
     for dtype, factor in (("fp32", 1.3), ("f16_split", 1.3)):
         for tag in ("eval", "it2500"):
             assert errs[("shipped", dtype, tag)] <= factor * errs[("exact", dtype, tag)] + 1e-7, (dtype, tag, errs)
-
-
-def test_fused_field_kernel_in_subprocess():
-    """NEDDF_FUSED=1: ONE field kernel per slab -- the colour trunk on the reverse-mode distance kernel's own tile (SURVEY section 7
-    step 6; ddf_rev_kernel<..., FUSED>; opt-in because it measured 0.5-2 % slower than two kernels, profiles/r04_fused_field_kernel.txt).
-    Same gates as the default route: the reference's field goldens through the minimal mode, the synthetic architectures (widths
-    128 / 192 / 256 / 384, two skips, ReLU mask bits, tanhExp), the negative-bias regime, the end-to-end renders, ragged tile
-    tails under every operand policy, the split-fp16 gates and the full-frame invariants."""
-    import os
-    import subprocess
-    import sys
-    from conftest import ROOT
-    env = dict(os.environ, NEDDF_FUSED="1")
-    sel = ["tests/test_gpu_parity.py::test_neddf_bunny_field", "tests/test_gpu_parity.py::test_neddf_synth",
-           "tests/test_gpu_parity.py::test_neddf_negative_bias_regime", "tests/test_gpu_parity.py::test_neddf_negative_bias_render_rays",
-           "tests/test_gpu_parity.py::test_render_rays_end_to_end", "tests/test_gpu_parity.py::test_render_image_small",
-           "tests/test_gpu_parity.py::test_field_ragged_sizes_and_chunks", "tests/test_gpu_parity.py::test_full_frame_invariants",
-           "tests/test_gpu_parity.py::test_c2_single_pass_vs_oracle", "tests/test_gpu_parity.py::test_widest_engine_vs_oracle",
-           "tests/test_gpu_c5.py::test_split_operand_fields_meet_the_fp32_gate", "tests/test_gpu_c5.py::test_split_operand_render_rays_end_to_end",
-           "tests/test_gpu_c5.py::test_operand_policies_on_other_widths_and_activations", "tests/test_gpu_c5.py::test_render_rays_ndc_bf16_end_to_end"]
-    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu"] + sel, env=env, cwd=ROOT, capture_output=True, text=True,
-                       timeout=1200)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
-    assert "passed" in p.stdout and "skipped" not in p.stdout.splitlines()[-1], p.stdout[-500:]
 
 
 def test_full_frame_invariants(dev, bunny_weights):
