@@ -712,7 +712,9 @@ def main():
                                      "note": "same rays, same uniforms, outside the timed region; gate_margin = max |a-b| / (1e-4 |b| + 1e-5), "
                                              "asserted <= 1 for the fp32 and split-fp16 policies (bf16 is held to PSNR only)"}
             # a benchmark line of a renderer that disagrees with the reference is not a measurement: fail instead of printing it
-            if args.dtype != "bf16":
+            if os.environ.get("NEDDF_BENCH_PROBE") == "1":       # timing-probe libraries (make variant ... -DNEDDF_PROBE_*): results are invalid BY DESIGN
+                line["metric"] = "INVALID (timing probe build): " + line["metric"]
+            elif args.dtype != "bf16":
                 assert max(margin.values()) <= 1.0 and psnr > 120.0, "parity sample outside the 1e-4 + 1e-5 gate: %s, PSNR %.1f dB" % (margin, psnr)
             else:
                 assert psnr > 60.0, "bf16 parity sample: PSNR %.1f dB" % psnr

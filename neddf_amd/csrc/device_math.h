@@ -32,6 +32,9 @@ __device__ __forceinline__ float tanh_nonneg(float u)
 // activations, see the measurements cited at kFastAct.
 __device__ __forceinline__ void tanhexp_grad_fast(float x, float &y, float &dy)
 {
+#if defined(NEDDF_PROBE_NOACT) && NEDDF_PROBE_NOACT
+    y = x * 0.5f; dy = x * 0.25f; return;       // timing probe (variant builds only, results invalid): the epilogue without the activation's arithmetic
+#endif
     // v_med3_f32 clamps in ONE instruction (fminf costs a NaN-quieting v_max in front of its v_min)
     float ex = fast_exp(__builtin_amdgcn_fmed3f(x, -3.0e38f, 40.0f));
     float e2 = __builtin_amdgcn_exp2f(ex * 2.8853900817779268f);
@@ -131,6 +134,23 @@ __device__ __forceinline__ void softplus_grad(float z, float &y, float &dy)
     bool big = z > 20.0f;
     y = big ? z : logf(1.0f + expf(z));
     dy = big ? 1.0f : 1.0f / (1.0f + expf(-z));
+}
+
+// the same two head activations on the raw transcendental units (kFast policies: bf16 operands -- their error, ~1e-6 relative, is three
+// orders of magnitude below the policy's rounding); the library expf / logf / tanhf above are ~40 instructions each
+__device__ __forceinline__ void softplus_grad_fast(float z, float &y, float &dy)
+{
+    const bool big = z > 20.0f;
+    const float e = fast_exp(__builtin_amdgcn_fmed3f(z, -80.0f, 20.0f));
+    y = big ? z : __builtin_amdgcn_logf(1.0f + e) * 0.6931471805599453f;
+    dy = big ? 1.0f : e * __builtin_amdgcn_rcpf(1.0f + e);          // 1 / (1 + e^-z)
+}
+__device__ __forceinline__ void sigmoid_grad_fast(float a, float &y, float &dy)
+{
+    const float e = fast_exp(__builtin_amdgcn_fmed3f(-a, -80.0f, 80.0f));
+    const float t = __builtin_amdgcn_rcpf(1.0f + e);                // (1 + tanh(a / 2)) / 2
+    y = t;
+    dy = t * (1 - t);
 }
 
 // SigmoidGradFunction sigmoid.py:38-43 (s = 1)

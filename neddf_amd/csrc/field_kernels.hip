@@ -368,12 +368,56 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
 // Per-workgroup scratch: y' of every layer + [encoding Jacobian factors | encoding copy | parked encoding gradient] (64 columns each)
 size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points, int width) { return (size_t)n_layers * points * width + (size_t)points * 192; }
 
+// The barrier of the tile's per-layer phases: LDS operations complete (lgkmcnt(0)), VECTOR-MEMORY operations stay in flight.
+// __syncthreads() is a workgroup fence + barrier: hipcc drains vmcnt too, so every per-layer barrier waited for the next layer's
+// prefetched weight fragments, the y' stores of the epilogue before it or the y' loads just requested -- an L2 / HBM round trip
+// exposed ~30 times per tile.  What crosses these barriers between waves is the LDS tile only; the global scratch a phase writes is
+// read back by the same lanes (y', the parked encoding gradient), and the arrays other threads read (encoding factors, staged
+// inputs) are fenced by the full barriers that stay around them.
+#ifndef NEDDF_RAWBAR
+#define NEDDF_RAWBAR 1
+#endif
+__device__ __forceinline__ void lds_barrier()
+{
+#if NEDDF_RAWBAR
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+#ifndef NEDDF_BF16_REV_OPS
+#define NEDDF_BF16_REV_OPS OpsBF16RT        // -DNEDDF_BF16_REV_OPS=OpsBF16T: the straight-product kernel of rounds 2-5 (A/B partner)
+#endif
+#ifndef NEDDF_REV_WPS_BF16
+#define NEDDF_REV_WPS_BF16 2
+#endif
+
+// The 16 values a lane holds of one 32 x 32 accumulator block (M-tile `mt` of the points, column tile `ct` of the features) -> the LDS
+// tile act[point][feature].  Straight products (rows = points): register q is point 8 (q >> 2) + 4 h + (q & 3), feature j: sixteen
+// 2-byte / 4-byte stores, pairs sharing one packed conversion.  Transposed products (Ops::kTransposed: rows = features): register q is
+// feature 8 (q >> 2) + 4 h + (q & 3) of point j: four 8-byte stores.
+template <class Ops>
+__device__ __forceinline__ void block_to_tile(typename Ops::act_t *act, int mt, int ct, const float (&v)[16], int lane)
+{
+    constexpr int LD = Ops::kLd;
+    const int j = lane & 31, h = lane >> 5;
+    if constexpr (Ops::kTransposed) {
+        typename Ops::act_t *o = act + (mt * 32 + j) * LD + ct * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Ops::put4(o + 8 * g, v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+    } else {
+        typename Ops::act_t *o = act + (mt * 32 + 4 * h) * LD + ct * 32 + j;
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, v[q], v[q + 1]);
+    }
+}
+
+constexpr int kPjLd = 65;          // row stride of the LDS-resident Jacobian factors: odd, so that lanes on consecutive points hit consecutive banks
 constexpr int kRevSmallFloats = 3 * 512 + 16;      // head dots / lp / ctl / staged inputs and tail partials behind the tile (lds_bytes: small + 16)
 template <int KIND, bool LAST, int MT, int NT, class Ops>
 __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], typename Ops::act_t *act, float *yp, const float *wseed, int wave,
                                                      int lane)
 {
-    constexpr int LD = Ops::kLd;
     constexpr bool MASK = KIND != 2 && !LAST;       // ReLU / LeakyReLU: y' leaves as one bit per element, built on the fly
     constexpr int NMW = (MT * NT + 1) / 2;
     unsigned mbits[MASK ? NMW : 1] = { 0 };
@@ -382,33 +426,40 @@ __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], type
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int col = (wave * NT + t) * 32 + j;
-            typename Ops::act_t *o = act + (mt * 32 + 4 * h) * LD + col;
-            const float ws = LAST ? wseed[col] : 1.0f;
+            const int ct = wave * NT + t;
+            // LAST: the seed of the reverse pass dz_D / dz_L = w_ddf[feature] * y'.  Straight products: this lane's feature is ct * 32 + j;
+            // transposed: register q is feature ct * 32 + 8 (q >> 2) + 4 h + (q & 3) -- wseed is then the LDS-resident copy, read 16 bytes at a time
+            float ws[Ops::kTransposed ? 16 : 1];
+            if constexpr (LAST) {
+                if constexpr (Ops::kTransposed) {
 #pragma unroll
-            for (int q = 0; q < 16; q += 2) {       // accumulator registers q, q + 1 = rows r, r + 1 of this lane's column
-                const int r = 8 * (q >> 2) + (q & 3);
-                float y[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    float z = acc[mt][t][q + u];
-                    if constexpr (Ops::kWScale != 1.0f) z *= (1.0f / Ops::kWScale);
-                    float dy;
-                    act_grad<KIND, Ops::kActMode>(z, y[u], dy);
-                    // y' replaces the accumulator (LAST: the seed of the reverse pass, dz_D / dz_L).  The stashed copy carries the
-                    // weight scale's inverse (a power of two: exact), so the reverse epilogue is one multiply per element
-                    if constexpr (MASK) mbits[(mt * NT + t) / 2] |= (dy == 1.0f ? 1u : 0u) << (16 * ((mt * NT + t) & 1) + q + u);
-                    else acc[mt][t][q + u] = LAST ? ws * dy : dy * (1.0f / Ops::kWScale);
-                }
-                Ops::put2(o + r * LD, o + (r + 1) * LD, y[0], y[1]);
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4v w4 = *(const f32x4v *)(wseed + ct * 32 + 8 * g + 4 * h);
+                        ws[4 * g] = w4[0]; ws[4 * g + 1] = w4[1]; ws[4 * g + 2] = w4[2]; ws[4 * g + 3] = w4[3];
+                    }
+                } else ws[0] = wseed[ct * 32 + j];
             }
+            float y[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float z = acc[mt][t][q];
+                if constexpr (Ops::kWScale != 1.0f) z *= (1.0f / Ops::kWScale);
+                float dy;
+                act_grad<KIND, Ops::kActMode>(z, y[q], dy);
+                // y' replaces the accumulator (LAST: the seed).  The stashed copy carries the weight scale's inverse (a power of two:
+                // exact), so the reverse epilogue is one multiply per element
+                if constexpr (MASK) mbits[(mt * NT + t) / 2] |= (dy == 1.0f ? 1u : 0u) << (16 * ((mt * NT + t) & 1) + q);
+                else acc[mt][t][q] = LAST ? ws[Ops::kTransposed ? q : 0] * dy : dy * (1.0f / Ops::kWScale);
+            }
+            block_to_tile<Ops>(act, mt, ct, y, lane);
         }
     // y' leaves in the accumulators' own fragment order (16 bytes per lane, 1 KiB per wave and store): only this workgroup's
-    // same lanes read it back, so nothing needs it row-major.  Under the bf16 policy it travels as bf16 (the product it enters
+    // same lanes read it back, so nothing needs it row-major.  Under the bf16 policy it travels in 16 bits (the product it enters
     // is rounded to bf16 anyway): at that policy's speed the fp32 round trip (26 GB per launch) would be the kernel's bound
     if (!LAST) {
         if constexpr (KIND == 2) {
-            if constexpr (Ops::kStash16) stash_store16<MT, NT>(acc, yp, wave, lane);
+            if constexpr (Ops::kStashF16) stash_store_f16<MT, NT>(acc, yp, wave, lane);
+            else if constexpr (Ops::kStash16) stash_store16<MT, NT>(acc, yp, wave, lane);
             else stash_store<MT, NT>(acc, yp, wave, lane);
         } else {
             // ReLU / LeakyReLU: y' takes two values, so ONE BIT per element travels (16 per accumulator tile, two tiles per
@@ -440,8 +491,8 @@ __device__ __forceinline__ void rev_forward_epilogue_rt(f32x16 (&acc)[MT][NT], t
     } else rev_forward_epilogue<2, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane);
 }
 
-template <int MT, class Ops, bool MASKY>
-__global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
+template <int MT, class Ops, bool MASKY, int WPS = 2>
+__global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
 {
     typedef typename Ops::act_t act_t;
     typedef typename Ops::bfrag frag;
@@ -467,6 +518,18 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
     // skip layer multiplies it from there -- no reload from the scratch, no extra barriers (14.1 k -> 6.5 k cycles for that layer)
     act_t *enc_tile = (act_t *)(hd + kRevSmallFloats);
     const act_t *enc_lane = act_lane_ptr<EncView<Ops>>(enc_tile, lane);
+    // Ops::kTransposed: the layers' biases and the distance head's weights as LDS-resident vectors [n_layers + 1][WID] behind the encoding
+    // tile, filled once per workgroup -- an accumulator's four consecutive features take theirs with one ds_read_b128 (rev_lds_bytes)
+    float *vecs = (float *)(enc_tile + (Ops::kEncInLds ? ROWS * kEncLd : 0));
+    // ... and behind them the factors of the encoding's Jacobian [ROWS][kPjLd] (written by the encoding loop, read by the tail: they made
+    // a round trip through the global scratch -- four scattered 4-byte stores per item and an exposed L2 round trip in the tail)
+    float *pjl = vecs + (a.n_layers + 2) * WID;
+    if constexpr (Ops::kTransposed) {
+        for (int i = tid; i < (a.n_layers + 2) * WID; i += THREADS) {
+            const int l = i / WID, c = i - l * WID;
+            vecs[i] = l < a.n_layers ? (a.layer[l].bias ? a.layer[l].bias[c] : 0.0f) : (l == a.n_layers ? a.w_ddf_out[c] : a.w_aux_out[c]);
+        }
+    }
     if (tid == 0) {
 #pragma unroll
         for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
@@ -479,7 +542,7 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
     // unrolls the reverse products completely, materialises one 64-bit address per weight fragment, spills them and reloads each
     // behind an s_waitcnt vmcnt(0) -- which serialises the operand prefetch of half of the kernel's matrix work
     const int KS = a.ks_hidden;
-    const int j = lane & 31, h = lane >> 5;
+    const int h = lane >> 5;
 
     int *ctl = (int *)(lp + 12);
     NEDDF_STAMP_DECL;
@@ -508,14 +571,25 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
             const int64_t gp = p0 + p < a.n_points ? p0 + p : a.n_points - 1;
             stg[idx] = idx < 3 * ROWS ? a.pos[gp * 3 + d] : (a.neus ? 0.0f : a.var[gp * 3 + d]);
         }
-        zero_cols<Ops, THREADS>(act, ROWS, kin, tid);
-        if constexpr (Ops::kEncInLds) {
-            for (int i = tid; i < ROWS * 64; i += THREADS) Ops::zero(enc_tile + (i >> 6) * kEncLd + (i & 63));
+        // the encoding loop below writes columns [0, K3) and [KH, KH + K3) of every row: only the padding columns need zeros
+        {
+            const int g1 = KH - K3, npad = kin - 2 * K3;            // [K3, KH) and [KH + K3, kin)
+            for (int i = tid; i < ROWS * npad; i += THREADS) {
+                const int r = i / npad, k = i - r * npad;
+                Ops::zero(act + r * LD + (k < g1 ? K3 + k : KH + K3 + (k - g1)));
+            }
+            if constexpr (Ops::kEncInLds) {
+                const int npe = 64 - 2 * K3;
+                for (int i = tid; i < ROWS * npe; i += THREADS) {
+                    const int r = i / npe, k = i - r * npe;
+                    Ops::zero(enc_tile + r * kEncLd + (k < g1 ? K3 + k : KH + K3 + (k - g1)));
+                }
+            }
         }
         __syncthreads();
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
-        // scaled integrated encoding (neddf.py:193-204), value rows; the factors of its Jacobian go to the scratch
+        // scaled integrated encoding (neddf.py:193-204), value rows; the factors of its Jacobian go to the scratch (or stay in LDS)
         for (int item = tid; item < P * K3; item += THREADS) {
             // item / K3 for item < 4096, K3 <= 30: (item * magic) >> 20 is exact; q / 3 for q < 30: (q * 11) >> 5
             const int p = (int)(((unsigned)item * k3magic) >> 20), q = item - p * K3;
@@ -529,11 +603,17 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
             if constexpr (Ops::kEncInLds) {
                 Ops::put(enc_tile + p * kEncLd + q, vs);
                 Ops::put(enc_tile + p * kEncLd + KH + q, vc);
+            } else {
+                pv[p * 64 + q] = vs;               // same column order as the LDS tile: [sine half (KH) | cosine half (KH)]
+                pv[p * 64 + KH + q] = vc;
             }
-            pj[p * 64 + q] = js;
-            pj[p * 64 + 32 + q] = jc;
-            pv[p * 64 + q] = vs;               // same column order as the LDS tile: [sine half (KH) | cosine half (KH)]
-            pv[p * 64 + KH + q] = vc;
+            if constexpr (Ops::kTransposed) {
+                pjl[p * kPjLd + q] = js;
+                pjl[p * kPjLd + 32 + q] = jc;
+            } else {
+                pj[p * 64 + q] = js;
+                pj[p * 64 + 32 + q] = jc;
+            }
         }
         STAMP();                                    // 1: encoding done
         __syncthreads();
@@ -543,7 +623,17 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
         // ---- forward, value rows
         for (int l = 0; l < a.n_layers; ++l) {
             const LayerW &L = a.layer[l];
-            acc_init_pre<MT, NT, false, Ops>(acc, pre);
+            if constexpr (Ops::kTransposed) {       // bias of the four consecutive features of every register group: LDS -> accumulator registers
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4v b4 = *(const f32x4v *)(vecs + l * WID + (wave * NT + t) * 32 + 8 * g + 4 * h);
+                            acc[mt][t][4 * g] = b4[0]; acc[mt][t][4 * g + 1] = b4[1]; acc[mt][t][4 * g + 2] = b4[2]; acc[mt][t][4 * g + 3] = b4[3];
+                        }
+            } else acc_init_pre<MT, NT, false, Ops>(acc, pre);
             dense_pre<MT, NT, Ops>(acc, act_lane, (const frag *)L.wp + (size_t)wave * NT * L.ksteps * 64 + lane, L.ksteps, pre);
             if (L.stash >= 0 && Ops::kEncInLds) {       // cat([encoding, h]) (neddf.py:217-219): the encoding's own LDS tile
                 const StashW &sw = a.stash[L.stash];
@@ -568,19 +658,20 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
             }
             if (l + 1 < a.n_layers) layer_prefetch<NT, Ops>(pre, a.layer[l + 1].wp, a.layer[l + 1].bias, a.layer[l + 1].ksteps, wave, lane);
             STAMP();                                // forward layer l: 3 + 4l product done
-            __syncthreads();
+            lds_barrier();
             STAMP();                                //                  4 + 4l barrier passed
             if (l + 1 < a.n_layers) rev_forward_epilogue_rt<false, MASKY, MT, NT, Ops>(acc, act, yp + (size_t)l * ROWS * WID, nullptr, a.activation, wave, lane);
-            else rev_forward_epilogue_rt<true, MASKY, MT, NT, Ops>(acc, act, nullptr, a.w_ddf_out, a.activation, wave, lane);
+            else rev_forward_epilogue_rt<true, MASKY, MT, NT, Ops>(acc, act, nullptr, Ops::kTransposed ? vecs + a.n_layers * WID : a.w_ddf_out, a.activation, wave, lane);
             STAMP();                                //                  5 + 4l epilogue done
-            __syncthreads();
+            lds_barrier();
             STAMP();                                //                  6 + 4l barrier passed
         }
         // ---- heads on the features (value only: the distance gradient comes from the reverse pass, the aux gradient's own
         // Jacobian is not an eval output), and the feature hand-off to the colour kernel
         for (int item = tid; item < 4 * ROWS; item += THREADS) {       // 2 k-halves x 2 heads x ROWS rows
             const int part = item / (2 * ROWS), head = (item / ROWS) & 1, row = item % ROWS;
-            const f32x4v *w = (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out) + part * (WID / 8);
+            // (transposed policy: both heads' weights are LDS-resident -- wave-uniform 16-byte reads instead of a global load per step)
+            const f32x4v *w = (Ops::kTransposed ? (const f32x4v *)(vecs + (a.n_layers + head) * WID) : (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out)) + part * (WID / 8);
             const act_t *ar = act + row * LD + part * (WID / 2);
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
@@ -612,9 +703,10 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
+                float v[16];
 #pragma unroll
-                for (int q = 0; q < 16; q += 2) Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, acc[mt][t][q], acc[mt][t][q + 1]);
+                for (int q = 0; q < 16; ++q) v[q] = acc[mt][t][q];
+                block_to_tile<Ops>(act, mt, wave * NT + t, v, lane);
             }
         STAMP();                        // F + 2: g_L stored
         __syncthreads();
@@ -674,37 +766,60 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
             dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
             STAMP();                    //                +1 product done
             if constexpr (MASKY) {
-                __syncthreads();        // every wave finished reading g_l
+                lds_barrier();          // every wave finished reading g_l
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
                         const unsigned bits = mw[(mt * NT + t) / 2] >> (16 * ((mt * NT + t) & 1));
+                        float v[16];
 #pragma unroll
-                        for (int q = 0; q < 16; q += 2)
-                            Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD,
-                                      acc[mt][t][q] * mask_factor<Ops>((bits >> q) & 1u, a.activation),
-                                      acc[mt][t][q + 1] * mask_factor<Ops>((bits >> (q + 1)) & 1u, a.activation));
+                        for (int q = 0; q < 16; ++q) v[q] = acc[mt][t][q] * mask_factor<Ops>((bits >> q) & 1u, a.activation);
+                        block_to_tile<Ops>(act, mt, wave * NT + t, v, lane);
                     }
-                __syncthreads();
-            } else {
-                load_y(yb[0], 0);
-                if (MT > 1) load_y(yb[1], 1);
-                __syncthreads();            // every wave finished reading g_l
+                lds_barrier();
+            } else if constexpr (Ops::kStashF16) {
+                // y' as fp16 pairs, packed until the multiply: one mixed-precision multiply per element (v_fma_mix_f32), no unpacking
+                u32x4 yraw[MT][NT][2];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) yraw[mt][t][c] = ((const u32x4 *)ysrc)[((mt * NT + t) * 2 + c) * 64];
+                lds_barrier();              // every wave finished reading g_l (the y' just requested stays in flight)
                 STAMP();                    //                +2 barrier passed
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        act_t *o = act + (mt * 32 + 4 * h) * LD + (wave * NT + t) * 32 + j;
+                        float v[16];
 #pragma unroll
-                        for (int q = 0; q < 16; q += 2)
-                            Ops::put2(o + (8 * (q >> 2) + (q & 3)) * LD, o + (8 * (q >> 2) + (q & 3) + 1) * LD, acc[mt][t][q] * yb[mt & 1][t][q],
-                                      acc[mt][t][q + 1] * yb[mt & 1][t][q + 1]);
+                        for (int q = 0; q < 16; ++q) {
+                            const unsigned w = yraw[mt][t][q >> 3][(q & 7) >> 1];
+                            v[q] = (q & 1) ? mul_f16_half<1>(w, acc[mt][t][q]) : mul_f16_half<0>(w, acc[mt][t][q]);
+                        }
+                        block_to_tile<Ops>(act, mt, wave * NT + t, v, lane);
                     }
                 STAMP();                    //                +3 y' multiply + store done
-                __syncthreads();
+                lds_barrier();
+                STAMP();                    //                +4 barrier passed
+            } else {
+                load_y(yb[0], 0);
+                if (MT > 1) load_y(yb[1], 1);
+                lds_barrier();              // every wave finished reading g_l (the y' just requested stays in flight)
+                STAMP();                    //                +2 barrier passed
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        float v[16];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) v[q] = acc[mt][t][q] * yb[mt & 1][t][q];
+                        block_to_tile<Ops>(act, mt, wave * NT + t, v, lane);
+                    }
+                STAMP();                    //                +3 y' multiply + store done
+                lds_barrier();
                 STAMP();                    //                +4 barrier passed
             }
         }
@@ -729,13 +844,10 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
         for (int i = 0; i < BPW; ++i) {
             const int b = wave * BPW + i;
             if (NBLK < NW && b >= NBLK) break;
-            act_t *o = act + ((b >> 1) * 32 + 4 * h) * LD + (b & 1) * 32 + j;
+            float v[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float g = gpe[i][0][q];
-                if constexpr (Ops::kWScale != 1.0f) g *= (1.0f / Ops::kWScale);
-                Ops::put(o + (8 * (q >> 2) + (q & 3)) * LD, g);
-            }
+            for (int q = 0; q < 16; ++q) v[q] = Ops::kWScale != 1.0f ? gpe[i][0][q] * (1.0f / Ops::kWScale) : gpe[i][0][q];
+            block_to_tile<Ops>(act, b >> 1, b & 1, v, lane);
         }
         __syncthreads();
         // ---- per point: grad_x z_D = sum over the encoding channels of g_pe * dPE/dx (PARTS threads per point, every PARTS-th frequency
@@ -743,7 +855,7 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
         {
             const int part = tid / ROWS, p = tid - part * ROWS;
             const act_t *gr = act + p * LD;
-            const float *pjr = pj + p * 64;
+            const float *pjr = Ops::kTransposed ? pjl + p * kPjLd : pj + p * 64;
             float gp_[3] = { 0.f, 0.f, 0.f };
             for (int e = part; e < a.enc.E; e += PARTS)
 #pragma unroll
@@ -776,10 +888,12 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
                 if (a.density) a.density[gp] = rho;
             } else {
                 float sp, dsp, t, dsg;
-                softplus_grad(z, sp, dsp);               // softplus.py:38-49
+                if constexpr (Ops::kFast) softplus_grad_fast(z, sp, dsp);
+                else softplus_grad(z, sp, dsp);          // softplus.py:38-49
                 const float D = sp + a.d_near;
                 const float dg0 = dsp * gz[0], dg1 = dsp * gz[1], dg2 = dsp * gz[2];
-                sigmoid_grad(az, t, dsg);                // sigmoid.py:38-43
+                if constexpr (Ops::kFast) sigmoid_grad_fast(az, t, dsg);
+                else sigmoid_grad(az, t, dsg);           // sigmoid.py:38-43
                 const float aux = a.aux_grad_scale * t;
                 const float q2 = dg0 * dg0 + dg1 * dg1 + dg2 * dg2;
                 const float dgn = sqrtf(q2);
@@ -1272,7 +1386,7 @@ int col_points_per_tile(bool rows4, int operands, int width) { return rows4 ? ge
 int nerf_points_per_tile(int width) { return geo_nerf(width).mt * 32; }
 int nerf_wgs_per_cu(int width) { return geo_nerf(width).wps; }
 int ddf_rev_points(int, int width) { return (width == 128 || width == 256) ? 64 : 32; }
-int ddf_rev_wgs_per_cu(int, int) { return 2; }
+int ddf_rev_wgs_per_cu(int operands, int width) { return (operands == 1 && width == 256) ? NEDDF_REV_WPS_BF16 : 2; }
 
 static void set_lds(const void *fn, size_t bytes)
 {
@@ -1317,17 +1431,23 @@ void launch_ddf(const DdfArgs &a, int grid, hipStream_t s)
 
 // reverse-mode kernel (see ddf_rev_kernel)
 template <class Ops>
-static size_t rev_lds_bytes(int mt) { return lds_bytes<Ops>(mt) + (Ops::kEncInLds ? (size_t)mt * 32 * kEncLd * sizeof(typename Ops::act_t) : 0); }
+static size_t rev_lds_bytes(int mt, int n_layers)
+{
+    return lds_bytes<Ops>(mt) + (Ops::kEncInLds ? (size_t)mt * 32 * kEncLd * sizeof(typename Ops::act_t) : 0) +
+           // the LDS-resident bias / head vectors and the encoding's Jacobian factors (ddf_rev_kernel: vecs, pjl)
+           (Ops::kTransposed ? ((size_t)(n_layers + 2) * Ops::kWid + (size_t)mt * 32 * kPjLd) * sizeof(float) : 0);
+}
 
-template <int MT, class Ops>
+template <int MT, class Ops, int WPS = 2>
 static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s)
 {
     // tanhExp: y' round trip as values; ReLU / LeakyReLU: as mask bits (the kernel's header)
-    static bool once = (set_lds((const void *)ddf_rev_kernel<MT, Ops, false>, rev_lds_bytes<Ops>(MT)),
-                        set_lds((const void *)ddf_rev_kernel<MT, Ops, true>, rev_lds_bytes<Ops>(MT)), true);
+    static bool once = (set_lds((const void *)ddf_rev_kernel<MT, Ops, false, WPS>, rev_lds_bytes<Ops>(MT, kMaxLayers)),
+                        set_lds((const void *)ddf_rev_kernel<MT, Ops, true, WPS>, rev_lds_bytes<Ops>(MT, kMaxLayers)), true);
     (void)once;
-    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, Ops, false>), dim3(grid), dim3(kThreads), rev_lds_bytes<Ops>(MT), s, a);
-    else hipLaunchKernelGGL((ddf_rev_kernel<MT, Ops, true>), dim3(grid), dim3(kThreads), rev_lds_bytes<Ops>(MT), s, a);
+    const size_t lds = rev_lds_bytes<Ops>(MT, a.n_layers);
+    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, Ops, false, WPS>), dim3(grid), dim3(kThreads), lds, s, a);
+    else hipLaunchKernelGGL((ddf_rev_kernel<MT, Ops, true, WPS>), dim3(grid), dim3(kThreads), lds, s, a);
 }
 
 template <int WID>
@@ -1335,7 +1455,7 @@ static void launch_ddf_rev_w(const DdfArgs &a, int grid, hipStream_t s)
 {
     constexpr int MT = WID <= 256 ? 2 : 1;
     if (a.operands == 2) launch_ddf_rev_t<MT, OpsF16SplitT<WID>>(a, grid, s);
-    else if (a.operands == 1) launch_ddf_rev_t<MT, OpsBF16T<WID>>(a, grid, s);
+    else if (a.operands == 1) launch_ddf_rev_t<MT, NEDDF_BF16_REV_OPS<WID>, (WID == 256 ? NEDDF_REV_WPS_BF16 : 2)>(a, grid, s);
     else launch_ddf_rev_t<MT, OpsF32T<WID>>(a, grid, s);
 }
 

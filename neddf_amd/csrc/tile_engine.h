@@ -67,6 +67,7 @@ struct OpsF32T {
     static constexpr bool kStash16 = false;  // y' of the reverse-mode kernel travels in fp32
     static constexpr bool kDeepPrefetch = false;
     static constexpr bool kEncInLds = false; // no LDS to spare next to two 67 KB tiles
+    static constexpr bool kTransposed = false, kStashF16 = false;       // (see OpsBF16RT)
     static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
     static __device__ __forceinline__ void zero(act_t *p) { *p = 0.f; }
     static __device__ __forceinline__ void put4(act_t *p, const f32x4v &v) { *(f32x4v *)p = v; }     // 4 consecutive columns
@@ -104,6 +105,7 @@ struct OpsBF16T {
     static constexpr bool kStash16 = true;   // ... as bf16 here
     static constexpr bool kDeepPrefetch = true;      // weight fragments two super-steps ahead (dense_pipeline3)
     static constexpr bool kEncInLds = true;          // the reverse-mode kernel keeps the encoding in a second LDS tile for its skip layers (a bf16 tile is 33 KB)
+    static constexpr bool kTransposed = false, kStashF16 = false;
     static __device__ __forceinline__ frag load_a(const act_t *p) { return *(const frag *)p; }
     static __device__ __forceinline__ void zero(act_t *p) { *p = 0; }
     static __device__ __forceinline__ unsigned short cvt(float v)       // round to nearest even (v_cvt_pk_bf16_f32)
@@ -147,6 +149,37 @@ struct OpsBF16T {
 };
 typedef OpsBF16T<256> OpsBF16;
 
+// The bf16 policy of the REVERSE-MODE distance kernel (round 6): the products are taken TRANSPOSED.  The 32x32x16 MFMA is symmetric
+// in its operands' lane layout (lane (i, h) holds 8 consecutive k of row i of A / of column i of B), so the same two loads -- the
+// packed weight fragment, the activation fragment from LDS -- can enter in either order; with the weights as A the accumulator has
+// FEATURES in its rows and POINTS in its columns: lane (j, h) owns point j and, per register group g, the four CONSECUTIVE features
+// 8 g + 4 h .. + 3.  What that buys in the epilogues, which are this policy's bound (vector ALU 51 %, matrix pipe 30 %:
+// docs/lab_notebook.md R5.9): four activations leave as ONE ds_write_b64 (two packed conversions) instead of four ds_write_b16 --
+// 6 cycles of the LDS store path instead of 16 --, and the bias / the reverse seed become one ds_read_b128 of four consecutive
+// features from an LDS-resident vector straight into the accumulator registers instead of 64 v_mov per layer.  y' travels as fp16
+// pairs (range [-0.14, 1.07]: 11 bits instead of bf16's 8) so that the reverse pass multiplies an accumulator by its half in ONE
+// mixed-precision instruction (v_fma_mix_f32) instead of unpack + multiply.
+template <int WID>
+struct OpsBF16RT : OpsBF16T<WID> {
+    typedef OpsBF16T<WID> Base;
+    typedef typename Base::act_t act_t;
+    typedef typename Base::frag frag;
+    static constexpr bool kTransposed = true, kStashF16 = true;
+    static __device__ __forceinline__ f32x16 mfma(const frag &a, const frag &b, const f32x16 &c, int)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c, 0, 0, 0);       // weights (b) as the A operand
+    }
+    static __device__ __forceinline__ void put4(act_t *p, float v0, float v1, float v2, float v3)      // four consecutive columns, 8-byte aligned
+    {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 w = { __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){ v0, v1 }, bf16x2)),
+                    __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){ v2, v3 }, bf16x2)) };
+        *(u32x2 *)p = w;
+    }
+};
+
 // Split-fp16 operands: fp16 carries 11 mantissa bits, so TWO terms per operand (a = h + m, h rounded toward zero -- which
 // also saturates instead of overflowing --, m the remainder rounded to nearest) hold 21-22 bits, and a.w needs only the
 // three products above 2^-22 (m.h, h.m, h.h).  Weights are scaled by 2^10 on the host so that their second term stays in
@@ -179,6 +212,7 @@ struct OpsF16SplitT {
     static constexpr bool kStash16 = false;
     static constexpr bool kDeepPrefetch = false;         // measured: the colour kernel spills with a third operand set (dense_pipeline3)
     static constexpr bool kEncInLds = false;
+    static constexpr bool kTransposed = false, kStashF16 = false;
     static __device__ __forceinline__ float f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
     static __device__ __forceinline__ void put(act_t *p, float v)
     {
@@ -346,6 +380,16 @@ __device__ __forceinline__ void acc_init_pre(f32x16 (&acc)[MT][NT], const LayerP
 // (tools/r04_prefetch.sh): bf16 distance kernel 24.69 -> 23.96 ms per launch (C2 2.024 -> 2.072 M rays/s, C5 1.056 -> 1.080 M); split fp16
 // (384 matrix cycles per super-step) distance kernel 50.06 -> 49.88 ms but its colour kernel 13.40 -> 13.86 ms (the third set spills
 // there): not taken for that policy.
+// timing probes (variant builds only, results invalid): the product loop without its weight-fragment loads / without its LDS loads
+#ifndef NEDDF_PROBE_NOB
+#define NEDDF_PROBE_NOB 0
+#endif
+#ifndef NEDDF_PROBE_NOA
+#define NEDDF_PROBE_NOA 0
+#endif
+#ifndef NEDDF_PRODUCT_PRIO
+#define NEDDF_PRODUCT_PRIO 0
+#endif
 template <int MT, int NT, class Ops>
 __device__ __forceinline__ void dense_pipeline3(f32x16 (&acc)[MT][NT], typename Ops::afrag (&a0)[MT], typename Ops::bfrag (&b0)[NT],
                                                 const typename Ops::act_t *act_lane, const WeightStream &wl, int ksteps)
@@ -360,21 +404,38 @@ __device__ __forceinline__ void dense_pipeline3(f32x16 (&acc)[MT][NT], typename 
         b[1][t] = stream_load<typename Ops::bfrag>(wl, (unsigned)(t * ksteps + (ksteps > 1 ? 1 : 0)));
     }
     const typename Ops::act_t *ap = act_lane;
+#if NEDDF_PRODUCT_PRIO
+    __builtin_amdgcn_s_setprio(1);              // the product's MFMAs ahead of the SIMD's other wave's vector work
+#endif
     for (int S = 0; S < ksteps; S += 6) {
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             if (S + u >= ksteps) break;                 // wave-uniform
             const int s2 = S + u + 2 < ksteps ? S + u + 2 : ksteps - 1;     // (clamped: the index could leave the allocation)
+#if !NEDDF_PROBE_NOB
 #pragma unroll
             for (int t = 0; t < NT; ++t) b[(u + 2) % 3][t] = stream_load<typename Ops::bfrag>(wl, (unsigned)(t * ksteps + s2));
+#else
+            (void)s2;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[(u + 2) % 3][t] = b[u % 3][t];
+#endif
+#if !NEDDF_PROBE_NOA
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[(u + 1) & 1][mt] = Ops::load_a(ap + (u + 1) * Ops::kStep + mt * 32 * Ops::kLd);
+#else
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[(u + 1) & 1][mt] = a[u & 1][mt];
+#endif
             __builtin_amdgcn_sched_barrier(0);
             dense_mfma<MT, NT, Ops>(acc, a[u & 1], b[u % 3]);
             __builtin_amdgcn_sched_barrier(0);
         }
         ap += 6 * Ops::kStep;
     }
+#if NEDDF_PRODUCT_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 template <int MT, int NT, class Ops = OpsF32>
@@ -489,6 +550,38 @@ __device__ __forceinline__ void stash_load16(f32x16 &dst, const u32x4 *src)     
             dst[8 * c + 2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
         }
     }
+}
+
+// the same as fp16 pairs (OpsBF16RT): two packed conversions per four values, 16 bytes per lane and store
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int MT, int NT>
+__device__ __forceinline__ void stash_store_f16(const f32x16 (&acc)[MT][NT], float *slot, int wave, int lane)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    u32x4 *dst = (u32x4 *)slot + (size_t)wave * (MT * NT * 2) * 64 + lane;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                u32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    v[i] = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){ acc[mt][t][8 * c + 2 * i], acc[mt][t][8 * c + 2 * i + 1] }, f16x2));
+                dst[((mt * NT + t) * 2 + c) * 64] = v;
+            }
+}
+
+// x times one fp16 half of w in ONE instruction (v_fma_mix_f32: the half is widened inside the multiplier; + 0 because the instruction
+// is a fused multiply-add).  hipcc does not form it from (float)half * x, it converts and multiplies.
+template <int HI>
+__device__ __forceinline__ float mul_f16_half(unsigned w, float x)
+{
+    float d;
+    if constexpr (HI) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(x));
+    else asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(x));
+    return d;
 }
 
 template <int MT, int NT>
