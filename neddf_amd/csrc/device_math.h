@@ -120,6 +120,120 @@ __device__ __forceinline__ float act_val(float x)
     return x * tanh_nonneg(fast_exp(__builtin_amdgcn_fmed3f(x, -3.0e38f, 80.0f)));      // nn_module/tanh_exp.py:28-31; x > 20 -> x exactly, see act_grad
 }
 
+// ---- the activations over N elements at a time, stage by stage (round 6).
+// Written per element, tanhExp is ONE dependent chain of 13 instructions (clamp -> mul -> exp -> mul -> exp -> add -> rcp -> fma -> ...)
+// and hipcc's scheduler (which minimises register pressure) emits the elements one after another: every instruction waits for its
+// predecessor's result -- ~6.6 cycles per dependent instruction instead of the ~4 a wave can issue, plus an s_nop behind every
+// transcendental: the forward epilogue of the bf16 reverse-mode kernel ran at 88 cycles per element for 60 of instruction issue
+// (profiles/r06_stamp_timeline_bf16_*.txt).  Here the SAME operations run in the SAME order per element (bit-identical results), but
+// interleaved over N independent elements, with scheduling barriers between the stages so that the interleaving survives.
+#ifndef NEDDF_ACT_ILP
+#define NEDDF_ACT_ILP 4
+#endif
+#define NEDDF_STAGE() __builtin_amdgcn_sched_barrier(0)
+template <int KIND, int MODE, int N>
+__device__ __forceinline__ void act_grad_n(const float (&x)[N], float (&y)[N], float (&dy)[N])
+{
+    if constexpr (KIND == 2 && (MODE == 1 || MODE == 2) && N > 1) {
+        float ex[N], e2[N], tx[N], q[N], s[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) ex[i] = __builtin_amdgcn_fmed3f(x[i], -3.0e38f, 40.0f) * 1.4426950408889634f;
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) ex[i] = __builtin_amdgcn_exp2f(ex[i]);
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) { e2[i] = ex[i] * 2.8853900817779268f; q[i] = x[i] * ex[i]; }
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) e2[i] = __builtin_amdgcn_exp2f(e2[i]);
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) e2[i] = e2[i] + 1.0f;
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) e2[i] = __builtin_amdgcn_rcpf(e2[i]);
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) tx[i] = fmaf(-2.0f, e2[i], 1.0f);
+        if constexpr (MODE == 2) {          // the middle form: the fitted odd polynomial below e^x = 0.2 (tanhexp_grad_mid)
+            float p[N], sm[N];
+            NEDDF_STAGE();
+#pragma unroll
+            for (int i = 0; i < N; ++i) p[i] = ex[i] * ex[i];
+            NEDDF_STAGE();
+#pragma unroll
+            for (int i = 0; i < N; ++i) { sm[i] = fmaf(p[i], 0.13038349f, -0.33329707f); p[i] = p[i] * ex[i]; }
+            NEDDF_STAGE();
+#pragma unroll
+            for (int i = 0; i < N; ++i) sm[i] = fmaf(p[i], sm[i], ex[i]);
+            NEDDF_STAGE();
+#pragma unroll
+            for (int i = 0; i < N; ++i) tx[i] = ex[i] < 0.2f ? sm[i] : tx[i];
+        }
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) { s[i] = fmaf(tx[i], tx[i], -1.0f); y[i] = x[i] * tx[i]; }
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) dy[i] = fmaf(-q[i], s[i], tx[i]);
+        NEDDF_STAGE();
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) act_grad<KIND, MODE>(x[i], y[i], dy[i]);
+    }
+}
+
+template <int KIND, int MODE, int N>
+__device__ __forceinline__ void act_val_n(const float (&x)[N], float (&y)[N])
+{
+    if constexpr (KIND == 2 && (MODE == 1 || MODE == 2) && N > 1) {
+        float ex[N], e2[N], tx[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) ex[i] = __builtin_amdgcn_fmed3f(x[i], -3.0e38f, 40.0f) * 1.4426950408889634f;
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) ex[i] = __builtin_amdgcn_exp2f(ex[i]);
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) e2[i] = ex[i] * 2.8853900817779268f;
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) e2[i] = __builtin_amdgcn_exp2f(e2[i]);
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) e2[i] = e2[i] + 1.0f;
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) e2[i] = __builtin_amdgcn_rcpf(e2[i]);
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) tx[i] = fmaf(-2.0f, e2[i], 1.0f);
+        if constexpr (MODE == 2) {
+            float p[N], sm[N];
+            NEDDF_STAGE();
+#pragma unroll
+            for (int i = 0; i < N; ++i) p[i] = ex[i] * ex[i];
+            NEDDF_STAGE();
+#pragma unroll
+            for (int i = 0; i < N; ++i) { sm[i] = fmaf(p[i], 0.13038349f, -0.33329707f); p[i] = p[i] * ex[i]; }
+            NEDDF_STAGE();
+#pragma unroll
+            for (int i = 0; i < N; ++i) sm[i] = fmaf(p[i], sm[i], ex[i]);
+            NEDDF_STAGE();
+#pragma unroll
+            for (int i = 0; i < N; ++i) tx[i] = ex[i] < 0.2f ? sm[i] : tx[i];
+        }
+        NEDDF_STAGE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) y[i] = x[i] * tx[i];
+        NEDDF_STAGE();
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) y[i] = act_val<KIND, MODE>(x[i]);
+    }
+}
+
 __device__ __forceinline__ float act_val_rt(int kind, float x)
 {
     if (kind == 0) return act_val<0>(x);

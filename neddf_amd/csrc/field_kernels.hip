@@ -374,22 +374,12 @@ size_t ddf_rev_scratch_floats_per_wg(int n_layers, int points, int width) { retu
 // exposed ~30 times per tile.  What crosses these barriers between waves is the LDS tile only; the global scratch a phase writes is
 // read back by the same lanes (y', the parked encoding gradient), and the arrays other threads read (encoding factors, staged
 // inputs) are fenced by the full barriers that stay around them.
-#ifndef NEDDF_RAWBAR
-#define NEDDF_RAWBAR 1
-#endif
 __device__ __forceinline__ void lds_barrier()
 {
-#if NEDDF_RAWBAR
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
 }
 #ifndef NEDDF_BF16_REV_OPS
 #define NEDDF_BF16_REV_OPS OpsBF16RT        // -DNEDDF_BF16_REV_OPS=OpsBF16T: the straight-product kernel of rounds 2-5 (A/B partner)
-#endif
-#ifndef NEDDF_REV_WPS_BF16
-#define NEDDF_REV_WPS_BF16 2
 #endif
 
 // The 16 values a lane holds of one 32 x 32 accumulator block (M-tile `mt` of the points, column tile `ct` of the features) -> the LDS
@@ -440,16 +430,25 @@ __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], type
                 } else ws[0] = wseed[ct * 32 + j];
             }
             float y[16];
+            constexpr int ILP = NEDDF_ACT_ILP;      // elements per activation batch (device_math.h act_grad_n: the same arithmetic, interleaved)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float z = acc[mt][t][q];
-                if constexpr (Ops::kWScale != 1.0f) z *= (1.0f / Ops::kWScale);
-                float dy;
-                act_grad<KIND, Ops::kActMode>(z, y[q], dy);
-                // y' replaces the accumulator (LAST: the seed).  The stashed copy carries the weight scale's inverse (a power of two:
-                // exact), so the reverse epilogue is one multiply per element
-                if constexpr (MASK) mbits[(mt * NT + t) / 2] |= (dy == 1.0f ? 1u : 0u) << (16 * ((mt * NT + t) & 1) + q);
-                else acc[mt][t][q] = LAST ? ws[Ops::kTransposed ? q : 0] * dy : dy * (1.0f / Ops::kWScale);
+            for (int q0 = 0; q0 < 16; q0 += ILP) {
+                float z[ILP], yy[ILP], dy[ILP];
+#pragma unroll
+                for (int i = 0; i < ILP; ++i) {
+                    z[i] = acc[mt][t][q0 + i];
+                    if constexpr (Ops::kWScale != 1.0f) z[i] *= (1.0f / Ops::kWScale);
+                }
+                act_grad_n<KIND, Ops::kActMode, ILP>(z, yy, dy);
+#pragma unroll
+                for (int i = 0; i < ILP; ++i) {
+                    const int q = q0 + i;
+                    y[q] = yy[i];
+                    // y' replaces the accumulator (LAST: the seed).  The stashed copy carries the weight scale's inverse (a power of two:
+                    // exact), so the reverse epilogue is one multiply per element
+                    if constexpr (MASK) mbits[(mt * NT + t) / 2] |= (dy[i] == 1.0f ? 1u : 0u) << (16 * ((mt * NT + t) & 1) + q);
+                    else acc[mt][t][q] = LAST ? ws[Ops::kTransposed ? q : 0] * dy[i] : dy[i] * (1.0f / Ops::kWScale);
+                }
             }
             block_to_tile<Ops>(act, mt, ct, y, lane);
         }
@@ -491,8 +490,8 @@ __device__ __forceinline__ void rev_forward_epilogue_rt(f32x16 (&acc)[MT][NT], t
     } else rev_forward_epilogue<2, LAST, MT, NT, Ops>(acc, act, yp, wseed, wave, lane);
 }
 
-template <int MT, class Ops, bool MASKY, int WPS = 2>
-__global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
+template <int MT, class Ops, bool MASKY>
+__global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
 {
     typedef typename Ops::act_t act_t;
     typedef typename Ops::bfrag frag;
@@ -506,7 +505,7 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     act_t *act = (act_t *)smem;
     float *hd = (float *)(act + ROWS * LD);  // [2 k-halves][2 heads][ROWS] head dot products
-    float *lp = hd + 6 * ROWS;
+    float *lp = hd + 8 * ROWS;               // (transposed policy: [4 waves][2 heads][ROWS] partial head products)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const act_t *act_lane = act_lane_ptr<Ops>(act, lane);
     float *yp = a.rev_scratch + (size_t)blockIdx.x * ((size_t)a.n_layers * P * WID + (size_t)P * 192);
@@ -523,11 +522,41 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
     float *vecs = (float *)(enc_tile + (Ops::kEncInLds ? ROWS * kEncLd : 0));
     // ... and behind them the factors of the encoding's Jacobian [ROWS][kPjLd] (written by the encoding loop, read by the tail: they made
     // a round trip through the global scratch -- four scattered 4-byte stores per item and an exposed L2 round trip in the tail)
-    float *pjl = vecs + (a.n_layers + 2) * WID;
+    float *pjl = vecs + (a.n_layers + 1) * WID;
     if constexpr (Ops::kTransposed) {
-        for (int i = tid; i < (a.n_layers + 2) * WID; i += THREADS) {
+        for (int i = tid; i < (a.n_layers + 1) * WID; i += THREADS) {
             const int l = i / WID, c = i - l * WID;
-            vecs[i] = l < a.n_layers ? (a.layer[l].bias ? a.layer[l].bias[c] : 0.0f) : (l == a.n_layers ? a.w_ddf_out[c] : a.w_aux_out[c]);
+            vecs[i] = l < a.n_layers ? (a.layer[l].bias ? a.layer[l].bias[c] : 0.0f) : a.w_ddf_out[c];
+        }
+    }
+    // Ops::kTransposed: the two heads (neddf.py:220-230, value rows) as ONE narrow product on the matrix pipe instead of 2 x 128-term dot
+    // products per thread on the vector ALU: the A operand's rows 0..2 carry w_ddf as three bf16 terms (hi + mid + lo = the fp32 weight
+    // to 2^-24: the heads stay fp32-exact on bf16 activations, as before), rows 4..6 w_aux likewise, the other rows are zero.  The
+    // fragments of rows 0..7 are built once per workgroup into the (otherwise unused) Jacobian-factor slot of its global scratch.
+    // super-steps of a 256-wide product, as a RUN-TIME value (the argument block carries it, DdfArgs::ks_hidden): with the compile-time constant hipcc
+    // unrolls the reverse products completely, materialises one 64-bit address per weight fragment, spills them and reloads each
+    // behind an s_waitcnt vmcnt(0) -- which serialises the operand prefetch of half of the kernel's matrix work
+    const int KS = a.ks_hidden;
+    u32x4 *hfrag = (u32x4 *)pj;
+    if constexpr (Ops::kTransposed) {
+        for (int f = tid; f < KS * 16; f += THREADS) {
+            const int S = f >> 4, li = f & 15, row = li & 7, hh = li >> 3, term = row & 3;
+            const float *wv = row < 4 ? a.w_ddf_out : a.w_aux_out;
+            unsigned short bits[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float w = wv[Ops::kStep * S + 8 * hh + r];
+                unsigned short t16 = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {       // peel hi, mid, lo: each the bf16 rounding of what the previous terms left
+                    t16 = Ops::cvt(w);
+                    if (k == term) break;
+                    w -= __builtin_bit_cast(float, (unsigned int)t16 << 16);
+                }
+                bits[r] = term < 3 ? t16 : (unsigned short)0;
+            }
+            hfrag[f] = (u32x4){ bits[0] | ((unsigned)bits[1] << 16), bits[2] | ((unsigned)bits[3] << 16), bits[4] | ((unsigned)bits[5] << 16),
+                                bits[6] | ((unsigned)bits[7] << 16) };
         }
     }
     if (tid == 0) {
@@ -538,10 +567,6 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
     const int K3 = 3 * a.enc.E, KH = a.enc.KH;
     const unsigned k3magic = (1u << 20) / (unsigned)K3 + 1u;
     const int64_t ntiles = (a.n_points + P - 1) / P;
-    // super-steps of a 256-wide product, as a RUN-TIME value (the argument block carries it, DdfArgs::ks_hidden): with the compile-time constant hipcc
-    // unrolls the reverse products completely, materialises one 64-bit address per weight fragment, spills them and reloads each
-    // behind an s_waitcnt vmcnt(0) -- which serialises the operand prefetch of half of the kernel's matrix work
-    const int KS = a.ks_hidden;
     const int h = lane >> 5;
 
     int *ctl = (int *)(lp + 12);
@@ -668,10 +693,29 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
         }
         // ---- heads on the features (value only: the distance gradient comes from the reverse pass, the aux gradient's own
         // Jacobian is not an eval output), and the feature hand-off to the colour kernel
+        if constexpr (Ops::kTransposed) {
+            // wave w multiplies its quarter of k for both point tiles: rows = head terms, columns = points (8 MFMAs per wave and tile)
+            f32x16 ha[MT];
+            const int kq = KS / NW;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) ha[mt][q] = 0.f;
+            const int row = lane & 31;
+            for (int S = wave * kq; S < (wave + 1) * kq; ++S) {
+                u32x4 wf = { 0u, 0u, 0u, 0u };
+                if (row < 8) wf = hfrag[S * 16 + h * 8 + row];
+                const frag wfr = __builtin_bit_cast(frag, wf);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) ha[mt] = Ops::mfma(Ops::load_a(act_lane + mt * 32 * LD + S * Ops::kStep), wfr, ha[mt], 0);
+            }
+            // lane (j, h): registers 0..2 = the three terms of head h for point j
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hd[(wave * 2 + h) * ROWS + mt * 32 + (lane & 31)] = (ha[mt][0] + ha[mt][1]) + ha[mt][2];
+        } else
         for (int item = tid; item < 4 * ROWS; item += THREADS) {       // 2 k-halves x 2 heads x ROWS rows
             const int part = item / (2 * ROWS), head = (item / ROWS) & 1, row = item % ROWS;
-            // (transposed policy: both heads' weights are LDS-resident -- wave-uniform 16-byte reads instead of a global load per step)
-            const f32x4v *w = (Ops::kTransposed ? (const f32x4v *)(vecs + (a.n_layers + head) * WID) : (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out)) + part * (WID / 8);
+            const f32x4v *w = (const f32x4v *)(head ? a.w_aux_out : a.w_ddf_out) + part * (WID / 8);
             const act_t *ar = act + row * LD + part * (WID / 2);
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
@@ -728,8 +772,8 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
                             f32x4v v = gpe_park[(i * 4 + g) * 64];
                             gs[0][0][4 * g] = v[0]; gs[0][0][4 * g + 1] = v[1]; gs[0][0][4 * g + 2] = v[2]; gs[0][0][4 * g + 3] = v[3];
                         }
-                    } else acc_init<1, 1, false>(gs, nullptr, wave, lane);
-                    dense<1, 1, Ops>(gs, act_lane + (b >> 1) * 32 * LD, (const frag *)a.wT_pe_skip[a.layer[l].stash] + (size_t)(b & 1) * KS * 64 + lane, KS);
+                        dense<1, 1, Ops>(gs, act_lane + (b >> 1) * 32 * LD, (const frag *)a.wT_pe_skip[a.layer[l].stash] + (size_t)(b & 1) * KS * 64 + lane, KS);
+                    } else dense_from_zero<1, 1, Ops>(gs, act_lane + (b >> 1) * 32 * LD, (const frag *)a.wT_pe_skip[a.layer[l].stash] + (size_t)(b & 1) * KS * 64 + lane, KS);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4v v = { gs[0][0][4 * g], gs[0][0][4 * g + 1], gs[0][0][4 * g + 2], gs[0][0][4 * g + 3] };
@@ -754,7 +798,6 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
                         }
                 }
             };
-            acc_init<MT, NT, false>(acc, nullptr, wave, lane);
             constexpr int NMW = (MT * NT + 1) / 2;
             unsigned mw[NMW];
             if constexpr (MASKY) {      // ReLU / LeakyReLU: the layer's mask bits (rev_forward_epilogue), requested ahead of the product
@@ -763,7 +806,7 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
                 for (int w = 0; w < NMW; ++w) mw[w] = msrc[w * 64];
             }
             STAMP();                    // reverse layer: +0 skip share / setup done
-            dense<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
+            dense_from_zero<MT, NT, Ops>(acc, act_lane, (const frag *)a.wT[l] + (size_t)wave * NT * KS * 64 + lane, KS);
             STAMP();                    //                +1 product done
             if constexpr (MASKY) {
                 lds_barrier();          // every wave finished reading g_l
@@ -835,8 +878,8 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
                     f32x4v v = gpe_park[(i * 4 + g) * 64];
                     one[0][0][4 * g] = v[0]; one[0][0][4 * g + 1] = v[1]; one[0][0][4 * g + 2] = v[2]; one[0][0][4 * g + 3] = v[3];
                 }
-            } else acc_init<1, 1, false>(one, nullptr, wave, lane);
-            dense<1, 1, Ops>(one, act_lane + (b >> 1) * 32 * LD, (const frag *)a.wT_pe0 + (size_t)(b & 1) * KS * 64 + lane, KS);       // g_0 W_0^T
+                dense<1, 1, Ops>(one, act_lane + (b >> 1) * 32 * LD, (const frag *)a.wT_pe0 + (size_t)(b & 1) * KS * 64 + lane, KS);       // g_0 W_0^T
+            } else dense_from_zero<1, 1, Ops>(one, act_lane + (b >> 1) * 32 * LD, (const frag *)a.wT_pe0 + (size_t)(b & 1) * KS * 64 + lane, KS);
             gpe[i][0] = one[0][0];
         }
         __syncthreads();                // every wave finished reading g_0
@@ -875,8 +918,13 @@ __global__ __launch_bounds__(kThreads, WPS) void ddf_rev_kernel(const DdfArgs a)
             for (int d = 0; d < 3; ++d)
 #pragma unroll
                 for (int q = 0; q < PARTS; ++q) gz[d] += stg[(q * 3 + d) * ROWS + tid];
-            const float z = (hd[tid] + hd[2 * ROWS + tid]) + a.b_ddf_out;
-            const float az = (hd[ROWS + tid] + hd[3 * ROWS + tid]) + a.b_aux_out;
+            float zs, azs;
+            if constexpr (Ops::kTransposed) {       // four waves' partial products
+                zs = (hd[tid] + hd[2 * ROWS + tid]) + (hd[4 * ROWS + tid] + hd[6 * ROWS + tid]);
+                azs = (hd[ROWS + tid] + hd[3 * ROWS + tid]) + (hd[5 * ROWS + tid] + hd[7 * ROWS + tid]);
+            } else { zs = hd[tid] + hd[2 * ROWS + tid]; azs = hd[ROWS + tid] + hd[3 * ROWS + tid]; }
+            const float z = zs + a.b_ddf_out;
+            const float az = azs + a.b_aux_out;
             if (a.neus) {       // NeuS: the "distance head" is e_0, so z is the sdf and gz its position gradient (neus.py:132-156)
                 const float ex = expf(-a.neus_v10 * z), den = 1 + ex;
                 const float rho = a.neus_v10 * ex * (1.0f / (den * den));
@@ -1386,7 +1434,7 @@ int col_points_per_tile(bool rows4, int operands, int width) { return rows4 ? ge
 int nerf_points_per_tile(int width) { return geo_nerf(width).mt * 32; }
 int nerf_wgs_per_cu(int width) { return geo_nerf(width).wps; }
 int ddf_rev_points(int, int width) { return (width == 128 || width == 256) ? 64 : 32; }
-int ddf_rev_wgs_per_cu(int operands, int width) { return (operands == 1 && width == 256) ? NEDDF_REV_WPS_BF16 : 2; }
+int ddf_rev_wgs_per_cu(int, int) { return 2; }
 
 static void set_lds(const void *fn, size_t bytes)
 {
@@ -1435,19 +1483,19 @@ static size_t rev_lds_bytes(int mt, int n_layers)
 {
     return lds_bytes<Ops>(mt) + (Ops::kEncInLds ? (size_t)mt * 32 * kEncLd * sizeof(typename Ops::act_t) : 0) +
            // the LDS-resident bias / head vectors and the encoding's Jacobian factors (ddf_rev_kernel: vecs, pjl)
-           (Ops::kTransposed ? ((size_t)(n_layers + 2) * Ops::kWid + (size_t)mt * 32 * kPjLd) * sizeof(float) : 0);
+           (Ops::kTransposed ? ((size_t)(n_layers + 1) * Ops::kWid + (size_t)mt * 32 * kPjLd) * sizeof(float) : 0);
 }
 
-template <int MT, class Ops, int WPS = 2>
+template <int MT, class Ops>
 static void launch_ddf_rev_t(const DdfArgs &a, int grid, hipStream_t s)
 {
     // tanhExp: y' round trip as values; ReLU / LeakyReLU: as mask bits (the kernel's header)
-    static bool once = (set_lds((const void *)ddf_rev_kernel<MT, Ops, false, WPS>, rev_lds_bytes<Ops>(MT, kMaxLayers)),
-                        set_lds((const void *)ddf_rev_kernel<MT, Ops, true, WPS>, rev_lds_bytes<Ops>(MT, kMaxLayers)), true);
+    static bool once = (set_lds((const void *)ddf_rev_kernel<MT, Ops, false>, rev_lds_bytes<Ops>(MT, kMaxLayers)),
+                        set_lds((const void *)ddf_rev_kernel<MT, Ops, true>, rev_lds_bytes<Ops>(MT, kMaxLayers)), true);
     (void)once;
     const size_t lds = rev_lds_bytes<Ops>(MT, a.n_layers);
-    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, Ops, false, WPS>), dim3(grid), dim3(kThreads), lds, s, a);
-    else hipLaunchKernelGGL((ddf_rev_kernel<MT, Ops, true, WPS>), dim3(grid), dim3(kThreads), lds, s, a);
+    if (a.activation == 2) hipLaunchKernelGGL((ddf_rev_kernel<MT, Ops, false>), dim3(grid), dim3(kThreads), lds, s, a);
+    else hipLaunchKernelGGL((ddf_rev_kernel<MT, Ops, true>), dim3(grid), dim3(kThreads), lds, s, a);
 }
 
 template <int WID>
@@ -1455,7 +1503,7 @@ static void launch_ddf_rev_w(const DdfArgs &a, int grid, hipStream_t s)
 {
     constexpr int MT = WID <= 256 ? 2 : 1;
     if (a.operands == 2) launch_ddf_rev_t<MT, OpsF16SplitT<WID>>(a, grid, s);
-    else if (a.operands == 1) launch_ddf_rev_t<MT, NEDDF_BF16_REV_OPS<WID>, (WID == 256 ? NEDDF_REV_WPS_BF16 : 2)>(a, grid, s);
+    else if (a.operands == 1) launch_ddf_rev_t<MT, NEDDF_BF16_REV_OPS<WID>>(a, grid, s);
     else launch_ddf_rev_t<MT, OpsF32T<WID>>(a, grid, s);
 }
 

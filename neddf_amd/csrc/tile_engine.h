@@ -387,13 +387,13 @@ __device__ __forceinline__ void acc_init_pre(f32x16 (&acc)[MT][NT], const LayerP
 #ifndef NEDDF_PROBE_NOA
 #define NEDDF_PROBE_NOA 0
 #endif
-#ifndef NEDDF_PRODUCT_PRIO
-#define NEDDF_PRODUCT_PRIO 0
-#endif
-template <int MT, int NT, class Ops>
+// ZERO: the accumulators come in UNINITIALISED and the first super-step multiplies onto the constant 0 (the MFMA's C operand as an inline
+// constant) -- a product that starts from zero costs no 16 v_mov per accumulator tile (the reverse pass: 64 per layer and lane)
+template <int MT, int NT, class Ops, bool ZERO = false>
 __device__ __forceinline__ void dense_pipeline3(f32x16 (&acc)[MT][NT], typename Ops::afrag (&a0)[MT], typename Ops::bfrag (&b0)[NT],
                                                 const typename Ops::act_t *act_lane, const WeightStream &wl, int ksteps)
 {
+    static_assert(!ZERO || Ops::kSub == 1, "one MFMA per fragment pair");
     typename Ops::afrag a[2][MT];
     typename Ops::bfrag b[3][NT];
 #pragma unroll
@@ -404,9 +404,6 @@ __device__ __forceinline__ void dense_pipeline3(f32x16 (&acc)[MT][NT], typename 
         b[1][t] = stream_load<typename Ops::bfrag>(wl, (unsigned)(t * ksteps + (ksteps > 1 ? 1 : 0)));
     }
     const typename Ops::act_t *ap = act_lane;
-#if NEDDF_PRODUCT_PRIO
-    __builtin_amdgcn_s_setprio(1);              // the product's MFMAs ahead of the SIMD's other wave's vector work
-#endif
     for (int S = 0; S < ksteps; S += 6) {
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
@@ -428,14 +425,17 @@ __device__ __forceinline__ void dense_pipeline3(f32x16 (&acc)[MT][NT], typename 
             for (int mt = 0; mt < MT; ++mt) a[(u + 1) & 1][mt] = a[u & 1][mt];
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            dense_mfma<MT, NT, Ops>(acc, a[u & 1], b[u % 3]);
+            if (ZERO && u == 0 && S == 0) {             // (wave-uniform; u is unrolled: one scalar compare per six super-steps)
+                const f32x16 zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[mt][t] = Ops::mfma(a[0][mt], b[0][t], zero, 0);
+            } else dense_mfma<MT, NT, Ops>(acc, a[u & 1], b[u % 3]);
             __builtin_amdgcn_sched_barrier(0);
         }
         ap += 6 * Ops::kStep;
     }
-#if NEDDF_PRODUCT_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
 }
 
 template <int MT, int NT, class Ops = OpsF32>
@@ -488,6 +488,27 @@ __device__ __forceinline__ void dense(f32x16 (&acc)[MT][NT], const typename Ops:
     const WeightStream w = weight_stream(wl);
     dense_load<MT, NT, Ops>(a0, b0, act_lane, w, ksteps, 0);
     dense_pipeline<MT, NT, Ops>(acc, a0, b0, act_lane, w, ksteps);
+}
+
+// acc = act x W (no bias): policies with the deep pipeline start from the MFMA's zero constant, the others clear the accumulators first
+template <int MT, int NT, class Ops = OpsF32>
+__device__ __forceinline__ void dense_from_zero(f32x16 (&acc)[MT][NT], const typename Ops::act_t *act_lane, const typename Ops::bfrag *wl, int ksteps)
+{
+    if constexpr (Ops::kDeepPrefetch && Ops::kSub == 1) {
+        typename Ops::afrag a0[MT];
+        typename Ops::bfrag b0[NT];
+        const WeightStream w = weight_stream(wl);
+        dense_load<MT, NT, Ops>(a0, b0, act_lane, w, ksteps, 0);
+        dense_pipeline3<MT, NT, Ops, true>(acc, a0, b0, act_lane, w, ksteps);
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[mt][t][q] = 0.f;
+        dense<MT, NT, Ops>(acc, act_lane, wl, ksteps);
+    }
 }
 
 template <int MT, int NT, bool ROWS4>
