@@ -323,11 +323,12 @@ def _kernel_matches(name, kernel_substr, dtype, masked):
 
 
 def measured_traffic(kernel_substr, dtype, masked):
-    """HBM bytes per launch of the dominant kernel measured NOW (default at N = 1 when rocprofv3 is on PATH; NEDDF_BENCH_PMC=0 skips it) --
+    """HBM bytes per launch of the dominant kernel measured NOW (opt-in: NEDDF_BENCH_PMC=1; the default line reads the committed, calibrated table) --
     two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE: the TCC has four counter slots, FETCH_SIZE takes three) over
     tools/pmc_probe.py, which renders one 65 536-ray x 128-sample slab of the same workload (ONE launch of 2^23 points at the default
-    launch size).  bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: both counters are in KB, and on gfx950 FETCH_SIZE reports half of a
-    wide coalesced read stream (MI355X_MICROARCH.md, HBM / rocprofv3 section).  Counter passes run with --kernel-trace only (no hip /
+    launch size).  bytes = (2.000 x FETCH_SIZE + 1.000 x WRITE_SIZE) x 1024: both counters are in KB, and on gfx950 FETCH_SIZE reports half of
+    the bytes read (128-byte requests tallied at 64) -- factors calibrated ON THE BOX for this kernel's access patterns (tools/traffic_calib.hip,
+    profiles/r06_traffic_calib.txt: 2.000 / 1.000 for 16 B per lane cold, Infinity-Cache-warm, written-then-read-back, and 4 B per lane).  Counter passes run with --kernel-trace only (no hip /
     hsa / memory-copy tracing).  A dispatch may come as several rows (per XCD / dimension): values are SUMMED per Dispatch_Id and the
     mean is over distinct dispatches."""
     import csv
@@ -357,7 +358,10 @@ def measured_traffic(kernel_substr, dtype, masked):
         vals[counter + "_dispatches"] = len(per)
     if vals["FETCH_SIZE_dispatches"] != vals["WRITE_SIZE_dispatches"]:
         raise RuntimeError("the two counter passes saw different dispatch counts: %r" % (vals,))
-    vals["hbm_bytes_per_launch"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    # factors calibrated on the box (tools/traffic_calib.hip, profiles/r06_traffic_calib.txt): reads 2.000, writes 1.000
+    vals["read_bytes"] = 2.0 * vals["FETCH_SIZE"] * 1024.0
+    vals["write_bytes"] = 1.0 * vals["WRITE_SIZE"] * 1024.0
+    vals["hbm_bytes_per_launch"] = vals["read_bytes"] + vals["write_bytes"]
     vals["points_per_dispatch"] = 65536.0 * 128 / vals["FETCH_SIZE_dispatches"]     # tools/pmc_probe.py renders ONE 65 536-ray x 128-sample slab
     return vals
 
@@ -673,29 +677,45 @@ def main():
                        algorithmic_bytes_per_launch=ent["algorithmic_bytes_per_launch"] * scale)
             line["roofline"]["points_per_launch"] = per_launch
             line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
-            line["roofline"]["traffic_source"] = ("static: %s (a committed rocprofv3 --pmc pass of this kernel and launch size, not measured in "
-                                                  "this run -- the in-run PMC pass was switched off or unavailable)" % ent["source"])
-            import shutil
-            # measured in the run by default (two extra passes over a one-slab probe, outside the timed region, ~1 min);
-            # NEDDF_BENCH_PMC=0 keeps the committed table, =1 insists (a missing rocprofv3 is then reported in traffic_source)
-            pmc_env = os.environ.get("NEDDF_BENCH_PMC", "")
-            if pmc_env == "1" or (pmc_env != "0" and world == 1 and shutil.which("rocprofv3") is not None):
+            line["roofline"]["traffic_source"] = ("%s: a committed rocprofv3 --pmc pass of this kernel at this launch size (FETCH_SIZE, WRITE_SIZE in separate passes, "
+                                                  "--kernel-trace only), scaled per point; NEDDF_BENCH_PMC=1 measures it in the run instead" % ent["source"])
+            if "calibration" in ent:
+                line["roofline"]["traffic_calibration"] = ent["calibration"]
+            bd = ent.get("breakdown")
+            if bd:      # what the bytes are: the design's stores and scratch reads, and the weight fragments that missed L2 (named counters: TCC_HIT / TCC_MISS)
+                line["roofline"]["traffic_breakdown"] = {k: (v * scale if k not in ("l2_hit_rate",) else v) for k, v in bd.items()}
+            # NEDDF_BENCH_PMC=1: measured in this run (two extra passes over a one-slab probe, outside the timed region, ~1 min, while this
+            # process keeps its context); default: the committed, calibrated table above
+            if os.environ.get("NEDDF_BENCH_PMC", "") == "1" and world == 1:
                 try:
                     m = measured_traffic(want, args.dtype, masked)
                     # the probe's launches must be of this run's size (one 65 536-ray slab = one launch at the default cap): per-point traffic
                     # of these kernels moved by +55 % between 2^21- and 2^23-point launches, so a mismatch is an error, not a scale factor
                     if not 0.5 < m["points_per_dispatch"] / per_launch < 2.0:
                         raise RuntimeError("probe dispatches hold %.0f points, this run's launches %.0f" % (m["points_per_dispatch"], per_launch))
-                    m["hbm_bytes_per_launch"] *= per_launch / m["points_per_dispatch"]
+                    k = per_launch / m["points_per_dispatch"]
+                    m["hbm_bytes_per_launch"] *= k
                     line["roofline"]["traffic"] = m["hbm_bytes_per_launch"]
                     line["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, "
                                                           "--kernel-trace only) over tools/pmc_probe.py, %d dispatch(es) of one 65 536-ray slab, scaled to this run's launch size; bytes = "
-                                                          "(2 x FETCH_SIZE + WRITE_SIZE) x 1024" % m["FETCH_SIZE_dispatches"])
+                                                          "2.000 x FETCH_SIZE x 1024 + 1.000 x WRITE_SIZE x 1024 (factors calibrated on the box)" % m["FETCH_SIZE_dispatches"])
                     line["roofline"]["traffic_counters_kb"] = {"FETCH_SIZE": m["FETCH_SIZE"], "WRITE_SIZE": m["WRITE_SIZE"]}
                     line["roofline"]["traffic_static"] = ent["hbm_bytes_per_launch"]
+                    if bd:
+                        tb = line["roofline"]["traffic_breakdown"]
+                        tb.update(write=m["write_bytes"] * k, read=m["read_bytes"] * k, weight_refetch=m["read_bytes"] * k - tb["designed_read"])
+                        tb["note"] = "write / read / weight_refetch from this run's counters; the TCC hit / miss counts from the committed pass"
                     ent = dict(ent, hbm_bytes_per_launch=m["hbm_bytes_per_launch"])
                 except Exception as e:
                     line["roofline"]["traffic_source"] += "; the in-run PMC pass failed: %r" % (e,)
+            if bd:
+                tb = line["roofline"]["traffic_breakdown"]
+                line["roofline"]["traffic_explained"] = (
+                    "traffic = fabric-side bytes (L2 misses; Infinity-Cache hits included).  %.1f GB written (design: %.1f) + %.1f GB read = %.1f GB of "
+                    "per-workgroup scratch read back once (y' of every layer, parked gradients) + %.1f GB of WEIGHT fragments that missed the 4 MB L2 slices "
+                    "(%.0f %% of the %.0f GB the tiles pull through L2; TCC hit rate %.1f %%, TCC_MISS x 128 B = %.1f GB in the committed pass)"
+                    % (tb["write"] / 1e9, tb["designed_write"] / 1e9, tb["read"] / 1e9, tb["designed_read"] / 1e9, tb["weight_refetch"] / 1e9,
+                       100 * tb["weight_refetch"] / tb["weight_stream_from_l2"], tb["weight_stream_from_l2"] / 1e9, 100 * tb["l2_hit_rate"], tb["tcc_miss_x_128B"] / 1e9))
             line["roofline"]["algorithmic_hbm_bytes_per_launch"] = ent["algorithmic_bytes_per_launch"]
             # the same launch against the HBM roofline (the 16-bit policies are partly bound by the y' round trip)
             ms = line["roofline"]["avg_launch_ms"]
@@ -747,7 +767,10 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
-        os.write(1, (json.dumps(line) + "\n").encode())       # ONE write(2): the line cannot interleave with another process on the pipe
+        # ONE write of the whole line through Python's own stdout (so that a redirected sys.stdout is honoured), flushed at once: the line
+        # cannot interleave with another process's on a shared pipe
+        sys.stdout.write(json.dumps(line) + "\n")
+        sys.stdout.flush()
 
 
 def rng_inclusive(render, cam, n_rays, dev):
