@@ -91,6 +91,10 @@ class BaseTrainer:
             if self.writes_outputs:
                 print("rendering from camera {}".format(camera_id))
             self.render_test(output_dir, camera_id, 1)
+        if self.writes_outputs and len(self.dataset):
+            # (one line after the reference's own printout, not inside it: the "psnr: .., ssim: .." lines keep the reference's format)
+            print("note: PSNR is pinned on the reference's eval harness (tests/golden/eval_harness.npz); SSIM is restated from the published "
+                  "algorithm with skimage's defaults and UNPINNED (skimage is not installed here)")
 
     def render_field_slices(self, output_field_dir: Path, epoch: int = 0) -> None:
         """base_trainer.py:190-204"""
