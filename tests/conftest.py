@@ -33,7 +33,7 @@ _SPAWNING = [
     "test_sample_points_from_rays_route_is_bit_identical", "test_library_communicator_single_rank", "test_ragged_gather_routes_on_one_rank", "test_c_client_of_the_abi", "test_forward_mode_kernels_in_subprocess",
     "test_reduced_cost_activation_against_the_branch_exact_build",
     "test_split_training_per_layer_route_in_subprocess", "test_wide_blocked_training_route_in_subprocess", "test_rccl_collectives_single_rank",
-    "test_workspace_guard_bands", "test_sharded_render_is_independent_of_world_size", "test_bench_collective_path_on_one_rank",
+    "test_workspace_guard_bands", "test_sharded_render_is_independent_of_world_size", "test_sharded_render_eight_ranks_ragged", "test_bench_collective_path_on_one_rank",
     "test_bench_scaling_modes_agree_at_one_rank", "test_bench_preflight_fails_fast_and_readably", "test_smoke_under_asan",
     "test_bench_self_launch_two_ranks_shared_gpu", "test_run_eval_under_a_launcher_matches_single_process",
     "test_run_script_two_ranks_data_parallel",

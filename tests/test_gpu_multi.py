@@ -56,11 +56,14 @@ r.to(dev); r.set_iter(-1)
 cam = neddf_amd.Camera(neddf_amd.PinholeCalib(g["calib"].astype(np.float64)), None).to(dev)
 cam.R, cam.T = torch.from_numpy(g["R"]).to(dev), torch.from_numpy(g["T"]).to(dev)
 w, h, chunk = int(g["width"]), int(g["height"]), int(g["chunk"])
+frame = os.environ.get("NEDDF_TEST_FRAME")          # "W,H,CHUNK": another frame, sharded chunk-granularly (render_image_sharded) under either backend
+if frame:
+    w, h, chunk = (int(v) for v in frame.split(","))
 keys = ["color", "depth", "transmittance"]
 torch.manual_seed(int(g["seed"]))                  # every rank holds the reference's seed; the slab jumps into the stream
-if rccl:
+if rccl or frame:
     img = render_image_sharded(r, w, h, cam, keys, 1, chunk)
-    info = neddf_amd.Context.get(dev).comm_info()
+    info = neddf_amd.Context.get(dev).comm_info() if rccl else dict(nranks=world, rank=rank, rccl_version=1)
     assert world == 1 or info["nranks"] == world and info["rank"] == rank and info["rccl_version"] > 0, info
 else:
     lo, hi = shard_range(w * h, rank, world)
@@ -75,12 +78,15 @@ print("rank", rank, "ok", "rccl" if rccl else "gloo-shared-gpu")
 '''
 
 
-def _run_world(tmp_path, world):
+def _run_world(tmp_path, world, frame=None):
     script = tmp_path / "shard_worker.py"
     script.write_text(_SHARD_WORKER)
     from conftest import run_ranks
     out = str(tmp_path / ("img_w%d" % world))
     env = dict(os.environ, NEDDF_BENCH_PMC="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("NEDDF_TEST_FRAME", None)
+    if frame:
+        env["NEDDF_TEST_FRAME"] = frame
     run_ranks(lambda r, port: [sys.executable, str(script), ROOT, port, str(r), str(world), out], world, env=env, timeout=600)
     return [np.load(out + ".%d.npz" % r) for r in range(world)]
 
@@ -105,6 +111,21 @@ def test_sharded_render_is_independent_of_world_size(tmp_path):
             assert np.array_equal(frames[world][k], frames[1][k]), (world, k)   # sharding changes nothing, bit for bit
     for world in (2, 3):
         assert np.array_equal(frames[world]["end"], frames[1]["end"])
+
+
+def test_sharded_render_eight_ranks_ragged(tmp_path):
+    """BASELINE.json configs[3]'s rank count on whatever the box has: EIGHT ranks render one 37 x 29 frame at chunk 100 -- 11 chunks, the last one 73 rays:
+    slabs of 2, 2, 2, 1, 1, 1, 1, 1 chunks, the ragged case a strong-scaled 800 x 800 frame meets first at N = 8 -- through `render_image_sharded`
+    (chunk-granular slabs, each rank jumps the CPU generator to its slab, one gather of the pixels).  With eight devices the ranks form an RCCL communicator
+    and the library's own ragged gather runs (its first execution with more than one rank); on a one-GPU box they share the device and the gather is
+    staged through gloo.  Every rank must end with the frame ONE rank renders, bit for bit, and with the generator where the whole-frame draw leaves it."""
+    one = _run_world(tmp_path, 1, frame="37,29,100")[0]
+    res = _run_world(tmp_path, 8, frame="37,29,100")
+    assert one["color"].shape == (29, 37, 3) and np.isfinite(one["color"]).all()
+    for r_, d in enumerate(res):
+        for k in ("color", "depth", "transmittance"):
+            assert np.array_equal(d[k], one[k]), (r_, k, float(np.abs(d[k] - one[k]).max()))
+        assert np.array_equal(d["end"], one["end"]), r_
 
 
 def test_library_communicator_single_rank():
