@@ -387,13 +387,11 @@ __device__ __forceinline__ void acc_init_pre(f32x16 (&acc)[MT][NT], const LayerP
 #ifndef NEDDF_PROBE_NOA
 #define NEDDF_PROBE_NOA 0
 #endif
-// ZERO: the accumulators come in UNINITIALISED and the first super-step multiplies onto the constant 0 (the MFMA's C operand as an inline
-// constant) -- a product that starts from zero costs no 16 v_mov per accumulator tile (the reverse pass: 64 per layer and lane)
-template <int MT, int NT, class Ops, bool ZERO = false>
+template <int MT, int NT, class Ops>
 __device__ __forceinline__ void dense_pipeline3(f32x16 (&acc)[MT][NT], typename Ops::afrag (&a0)[MT], typename Ops::bfrag (&b0)[NT],
                                                 const typename Ops::act_t *act_lane, const WeightStream &wl, int ksteps)
 {
-    static_assert(!ZERO || Ops::kSub == 1, "one MFMA per fragment pair");
+
     typename Ops::afrag a[2][MT];
     typename Ops::bfrag b[3][NT];
 #pragma unroll
@@ -425,13 +423,7 @@ __device__ __forceinline__ void dense_pipeline3(f32x16 (&acc)[MT][NT], typename 
             for (int mt = 0; mt < MT; ++mt) a[(u + 1) & 1][mt] = a[u & 1][mt];
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            if (ZERO && u == 0 && S == 0) {             // (wave-uniform; u is unrolled: one scalar compare per six super-steps)
-                const f32x16 zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[mt][t] = Ops::mfma(a[0][mt], b[0][t], zero, 0);
-            } else dense_mfma<MT, NT, Ops>(acc, a[u & 1], b[u % 3]);
+            dense_mfma<MT, NT, Ops>(acc, a[u & 1], b[u % 3]);
             __builtin_amdgcn_sched_barrier(0);
         }
         ap += 6 * Ops::kStep;
@@ -490,25 +482,18 @@ __device__ __forceinline__ void dense(f32x16 (&acc)[MT][NT], const typename Ops:
     dense_pipeline<MT, NT, Ops>(acc, a0, b0, act_lane, w, ksteps);
 }
 
-// acc = act x W (no bias): policies with the deep pipeline start from the MFMA's zero constant, the others clear the accumulators first
+// acc = act x W (no bias).  (Starting from the MFMA's zero constant instead of cleared accumulators -- no 16 v_mov per tile -- measured SLOWER under
+// every policy: bf16 -2 %, fp32 -1 %, split fp16 -2.5 %; profiles/r06_bf16_steps.txt, r06_f32_regression_check.txt)
 template <int MT, int NT, class Ops = OpsF32>
 __device__ __forceinline__ void dense_from_zero(f32x16 (&acc)[MT][NT], const typename Ops::act_t *act_lane, const typename Ops::bfrag *wl, int ksteps)
 {
-    if constexpr (Ops::kDeepPrefetch && Ops::kSub == 1) {
-        typename Ops::afrag a0[MT];
-        typename Ops::bfrag b0[NT];
-        const WeightStream w = weight_stream(wl);
-        dense_load<MT, NT, Ops>(a0, b0, act_lane, w, ksteps, 0);
-        dense_pipeline3<MT, NT, Ops, true>(acc, a0, b0, act_lane, w, ksteps);
-    } else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[mt][t][q] = 0.f;
-        dense<MT, NT, Ops>(acc, act_lane, wl, ksteps);
-    }
+            for (int q = 0; q < 16; ++q) acc[mt][t][q] = 0.f;
+    dense<MT, NT, Ops>(acc, act_lane, wl, ksteps);
 }
 
 template <int MT, int NT, bool ROWS4>
