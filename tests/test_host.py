@@ -26,6 +26,11 @@ def test_capi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.neddf_abi_version() == _lib.ABI_VERSION
+    # -fvisibility=hidden: the declared entry points are the library's WHOLE function export list (no launcher, no helper leaks out)
+    so = os.path.join(ROOT, "neddf_amd", "csrc", "libneddf_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T"}
+    assert exported == declared, exported ^ declared
 
 
 def test_struct_layouts_match_header():
