@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const 
         // Early partials of skip layers (neddf.py:217-219).  With one skip connection (every shipped
         // config) and the 64-row tile the partial stays in registers until its layer; otherwise it is
         // parked in the per-workgroup global scratch.
-        constexpr bool REG_STASH = NW == 4 ? ((MT == 2 && WPS <= 2) || (MT == 1 && WPS <= 4)) && !Ops::kLean     // denser packings of a CU have no registers to spare
+        constexpr bool REG_STASH = NW == 4 ? ((MT == 2 && WPS <= 2) || (MT == 1 && WPS <= 4))      // denser packings of a CU have no registers to spare
                                            : (2 * MT * NT * 16 + OPREGS + 64 <= REG_BUDGET);
         // 128-row tiles at two workgroups per CU (16-bit operands: each fetched weight fragment feeds four M-tiles) have neither
         // the registers for a held partial nor the HBM bandwidth for a parked one: the skip layer re-encodes the positions into
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
             const int r = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
             return (f32x4v *)(act + r * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));
         };
-        constexpr bool FPRE = NW == 4 ? ((MT == 2 && WPS <= 2) || (MT == 1 && WPS <= 4)) && !ROWS4 && !Ops::kLean
+        constexpr bool FPRE = NW == 4 ? ((MT == 2 && WPS <= 2) || (MT == 1 && WPS <= 4)) && !ROWS4
                                       : !ROWS4 && (MT * NT * 16 + OPREGS + NF * 4 + 64 <= REG_BUDGET);
         f32x4v fpre[FPRE ? NF : 1];
         auto feature_src = [&](int idx) {

@@ -61,7 +61,6 @@ struct OpsF32T {
     // branch-exact form; -DNEDDF_ACT_F32=1 builds the closed form for A/B.
     static constexpr int kActMode = NEDDF_ACT_F32;
     static constexpr int kPlanes = 1, kPlane = 0;
-    static constexpr bool kLean = false;     // room for register-resident extras (skip partial, feature prefetch)
     static constexpr bool kPackedRows = false;
     static constexpr float kWScale = 1.0f;   // packed weights = kWScale * w
     static constexpr bool kStash16 = false;  // y' of the reverse-mode kernel travels in fp32
@@ -100,7 +99,6 @@ struct OpsBF16T {
     static constexpr bool kFast = true;      // reduced-cost elementwise math (device_math.h), invisible after bf16 rounding
     static constexpr int kActMode = 1;
     static constexpr int kPlanes = 1, kPlane = 0;
-    static constexpr bool kLean = false;
     static constexpr float kWScale = 1.0f;
     static constexpr bool kStash16 = true;   // ... as bf16 here
     static constexpr bool kDeepPrefetch = true;      // weight fragments two super-steps ahead (dense_pipeline3)
@@ -206,7 +204,6 @@ struct OpsF16SplitT {
     static constexpr bool kFast = false;
     static constexpr int kActMode = NEDDF_ACT_SPLIT;      // the middle form: this policy is sold on the fp32 gates, and the closed form alone
                                                           // triples its density error where most pre-activations are very negative (profiles/r04_act_modes.txt)
-    static constexpr bool kLean = false;                 // measured: register-resident skip partial / feature prefetch pay off here too
     static constexpr bool kPackedRows = false;
     static constexpr float kWScale = 1024.0f;            // weights are packed as 2^10 w
     static constexpr bool kStash16 = false;
