@@ -7,14 +7,17 @@
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 #define REP16(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11) OP(12) OP(13) OP(14) OP(15)
 
 template <int WHICH>
 __global__ void k(unsigned long long *out, float seed)
 {
     float r[16];
+    f32x2 p[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) r[i] = seed + 0.001f * (float)(i + threadIdx.x);
+    for (int i = 0; i < 16; ++i) { r[i] = seed + 0.001f * (float)(i + threadIdx.x); p[i] = (f32x2){ r[i], r[i] + 1.0f }; }
     __builtin_amdgcn_s_barrier();
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < 256; ++it) {
@@ -30,6 +33,12 @@ __global__ void k(unsigned long long *out, float seed)
 #define MED3(i) asm volatile("v_med3_f32 %0, %0, %0, %0" : "+v"(r[i]));
 #define LOG32(i) asm volatile("v_log_f32 %0, %0" : "+v"(r[i]));
 #define SIN32(i) asm volatile("v_sin_f32 %0, %0" : "+v"(r[i]));
+#define PKFMA32(i) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(p[i]));
+#define PKMUL32(i) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(p[i]));
+#define PKADD32(i) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(p[i]));
+        if (WHICH == 12) { REP16(PKFMA32) }
+        if (WHICH == 13) { REP16(PKMUL32) }
+        if (WHICH == 14) { REP16(PKADD32) }
         if (WHICH == 0) { REP16(EXP32) }
         if (WHICH == 1) { REP16(EXP16) }
         if (WHICH == 2) { REP16(RCP32) }
@@ -46,7 +55,7 @@ __global__ void k(unsigned long long *out, float seed)
     const unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += r[i];
+    for (int i = 0; i < 16; ++i) s += r[i] + p[i][0] + p[i][1];
     if (s == 1234.5f) out[1023] = 1;
     if (threadIdx.x == 0 && blockIdx.x == 0) out[WHICH] = t1 - t0;
 }
@@ -72,6 +81,7 @@ int main()
         run<10>("v_log_f32", d, w); run<11>("v_sin_f32", d, w);
         run<4>("v_fma_f32", d, w); run<9>("v_med3_f32", d, w); run<5>("v_pk_mul_f16", d, w); run<6>("v_pk_fma_f16", d, w);
         run<7>("v_cvt_pk_bf16_f32", d, w); run<8>("v_fma_mix_f32", d, w);
+        run<12>("v_pk_fma_f32", d, w); run<13>("v_pk_mul_f32", d, w); run<14>("v_pk_add_f32", d, w);
     }
     return 0;
 }
