@@ -92,13 +92,13 @@ __device__ __forceinline__ void encode_dir(typename Ops::act_t *act, int col0, c
 #if defined(NEDDF_STAMP) && defined(NEDDF_STAMP_PAIRS)
 // pair mode (tools/stamp_pairs.py): four consecutive tiles of workgroups {0..3, 256..259} -- with 512 workgroups on 256 CUs, b and b + 256
 // are the candidates for sharing a CU (slot 0 carries HW_ID | XCC_ID << 32 to check) -- to see how the two workgroups' phases line up
-#define NEDDF_STAMP_DECL int sidx_ = 1, stile_ = 0; const unsigned long long swall0_ = wall_clock64(); unsigned long long *sbuf_ = (a.stamps && blockIdx.x < 512 && (blockIdx.x & 255) < 4 && lane == 0) ? a.stamps + ((size_t)((blockIdx.x & 255) + 4 * (blockIdx.x >> 8)) * 8 + wave) * (kStampSlots * kStampPairTiles) : nullptr; \
+#define NEDDF_STAMP_DECL int sidx_ = 1, stile_ = 0; const unsigned long long swall0_ = wall_clock64(), scyc0_ = __builtin_readcyclecounter(); unsigned long long *sbuf_ = (a.stamps && blockIdx.x < 512 && (blockIdx.x & 255) < 4 && lane == 0) ? a.stamps + ((size_t)((blockIdx.x & 255) + 4 * (blockIdx.x >> 8)) * 8 + wave) * (kStampSlots * kStampPairTiles) : nullptr; \
     if (sbuf_) sbuf_[0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32)
 #define NEDDF_STAMP_TILE() do { ++stile_; } while (0)
 #define STAMP() do { if (sbuf_ && stile_ >= kStampTile && stile_ < kStampTile + kStampPairTiles && sidx_ < kStampSlots * kStampPairTiles) sbuf_[sidx_++] = __builtin_readcyclecounter(); } while (0)
 #define STAMP_WALL(k) do { } while (0)
 #elif defined(NEDDF_STAMP)
-#define NEDDF_STAMP_DECL int sidx_ = 0, stile_ = 0; const unsigned long long swall0_ = wall_clock64(); unsigned long long *sbuf_ = (a.stamps && blockIdx.x < kStampBlocks && lane == 0) ? a.stamps + ((size_t)blockIdx.x * 8 + wave) * kStampSlots : nullptr
+#define NEDDF_STAMP_DECL int sidx_ = 0, stile_ = 0; const unsigned long long swall0_ = wall_clock64(), scyc0_ = __builtin_readcyclecounter(); unsigned long long *sbuf_ = (a.stamps && blockIdx.x < kStampBlocks && lane == 0) ? a.stamps + ((size_t)blockIdx.x * 8 + wave) * kStampSlots : nullptr
 #define NEDDF_STAMP_TILE() do { sidx_ = 0; ++stile_; } while (0)
 #define STAMP() do { if (sbuf_ && stile_ == kStampTile && sidx_ < kStampSlots - 2) sbuf_[sidx_++] = __builtin_readcyclecounter(); } while (0)
 // the constant 100 MHz clock (s_memrealtime) at the start (k = 0) and the end (k = 1) of the stamped tile, in the last two slots: cycles of
@@ -109,7 +109,7 @@ __device__ __forceinline__ void encode_dir(typename Ops::act_t *act, int col0, c
 // at the end of the kernel: how many tiles this workgroup took from the queue, and where it ran
 #define NEDDF_STAMP_EXIT() do { if (a.stamps && threadIdx.x == 0 && blockIdx.x < kStampWgTail) { unsigned long long *t_ = a.stamps + (size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles + blockIdx.x; \
     t_[0] = (unsigned long long)(stile_ & 0xfffff) | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) << 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 24); \
-    t_[kStampWgTail] = swall0_; t_[2 * kStampWgTail] = wall_clock64(); } } while (0)      /* + its first and last moment on the constant 100 MHz clock */
+    t_[kStampWgTail] = swall0_; t_[2 * kStampWgTail] = wall_clock64(); t_[3 * kStampWgTail] = __builtin_readcyclecounter() - scyc0_; } } while (0)      /* + its first and last moment on the constant 100 MHz clock, and its shader cycles between them */
 #else
 #define NEDDF_STAMP_EXIT() do { } while (0)
 #define NEDDF_STAMP_DECL

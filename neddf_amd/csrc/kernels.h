@@ -101,7 +101,7 @@ struct DdfArgs {
 #endif
 constexpr int kStampBlocks = 8, kStampSlots = 160, kStampTile = NEDDF_STAMP_TILE_INDEX;      // workgroups stamped, stamps per wave, which tile of the workgroup
 // (-DNEDDF_STAMP_TILE_INDEX=<k>, `make stamp STAMP_TILE=<k>`: a tile in the middle or at the end of a launch instead of its 7th)
-constexpr int kStampWgTail = 4096;     // behind the stamps, three arrays of one word per workgroup: tiles it took | XCC_ID << 20 | HW_ID << 24; its first / last moment on the 100 MHz clock (tools/stamp_tiles.py)
+constexpr int kStampWgTail = 4096;     // behind the stamps, four arrays of one word per workgroup: tiles it took | XCC_ID << 20 | HW_ID << 24; its first / last moment on the 100 MHz clock; its shader cycles between the two (tools/stamp_tiles.py)
 constexpr int kStampPairTiles = 4;     // NEDDF_STAMP_PAIRS builds: tiles kStampTile .. + 3 of workgroups {0..3, 256..259} (a CU's two workgroups), slot 0 = HW_ID
 
 // Colour trunk of NeDDF (neddf.py:243-300).

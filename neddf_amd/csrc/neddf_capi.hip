@@ -589,7 +589,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
             a.rev_scratch = (float *)ctx->rev_scratch.p;
 #ifdef NEDDF_STAMP
             static unsigned long long *d_stamps = nullptr;
-            const size_t stamp_bytes = ((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles + 3 * kStampWgTail) * sizeof(unsigned long long);
+            const size_t stamp_bytes = ((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles + 4 * kStampWgTail) * sizeof(unsigned long long);
             if (!d_stamps) HIPCHK(hipMalloc((void **)&d_stamps, stamp_bytes));
             HIPCHK(hipMemsetAsync(d_stamps, 0, stamp_bytes, s));
             a.stamps = d_stamps;
@@ -598,7 +598,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
 #ifdef NEDDF_STAMP
             if (const char *path = getenv("NEDDF_STAMP_FILE")) {        // the LAST launch's stamps (a diagnostic build: synchronising here is fine)
                 HIPCHK(hipStreamSynchronize(s));
-                std::vector<unsigned long long> h((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles + 3 * kStampWgTail);
+                std::vector<unsigned long long> h((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles + 4 * kStampWgTail);
                 HIPCHK(hipMemcpy(h.data(), d_stamps, stamp_bytes, hipMemcpyDeviceToHost));
                 if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), 1, stamp_bytes, fp); fclose(fp); }
             }
@@ -627,7 +627,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
             HIPCHK(hipMemsetAsync(c.sched, 0, kSchedInts * sizeof(int), s));
 #ifdef NEDDF_STAMP
             static unsigned long long *d_cstamps = nullptr;
-            const size_t cstamp_bytes = ((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles + 3 * kStampWgTail) * sizeof(unsigned long long);
+            const size_t cstamp_bytes = ((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles + 4 * kStampWgTail) * sizeof(unsigned long long);
             if (!d_cstamps) HIPCHK(hipMalloc((void **)&d_cstamps, cstamp_bytes));
             HIPCHK(hipMemsetAsync(d_cstamps, 0, cstamp_bytes, s));
             c.stamps = d_cstamps;
@@ -636,7 +636,7 @@ static int field_forward(neddf_ctx *ctx, int slot, const float *pos, const float
 #ifdef NEDDF_STAMP
             if (const char *path = getenv("NEDDF_STAMP_FILE_COL")) {    // the LAST colour launch's stamps (tools/stamp_timeline_col.py)
                 HIPCHK(hipStreamSynchronize(s));
-                std::vector<unsigned long long> h((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles + 3 * kStampWgTail);
+                std::vector<unsigned long long> h((size_t)kStampBlocks * 8 * kStampSlots * kStampPairTiles + 4 * kStampWgTail);
                 HIPCHK(hipMemcpy(h.data(), d_cstamps, cstamp_bytes, hipMemcpyDeviceToHost));
                 if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), 1, cstamp_bytes, fp); fclose(fp); }
             }

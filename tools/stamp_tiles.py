@@ -4,7 +4,7 @@
     python tools/stamp_tiles.py <NEDDF_STAMP_FILE or NEDDF_STAMP_FILE_COL dump>
 
 Behind the phase stamps the dump carries, per workgroup: the tiles it took from the queue | XCC_ID << 20 | HW_ID << 24, and its
-first / last moment on the constant 100 MHz clock.  With a dynamic tile queue a workgroup's tile count is its speed."""
+first / last moment on the constant 100 MHz clock and its shader cycles between the two (the clock the part held over the launch).  With a dynamic tile queue a workgroup's tile count is its speed."""
 import sys
 
 import numpy as np
@@ -15,6 +15,7 @@ base = BLOCKS * WAVES * SLOTS * PAIR
 w = raw[base:base + TAIL]
 t0 = raw[base + TAIL:base + 2 * TAIL].astype(np.int64)
 t1 = raw[base + 2 * TAIL:base + 3 * TAIL].astype(np.int64)
+cyc = raw[base + 3 * TAIL:base + 4 * TAIL].astype(np.int64) if raw.size >= base + 4 * TAIL else None
 used = w != 0
 n = int(used.sum())
 tiles = (w[used] & np.uint64(0xfffff)).astype(np.int64)
@@ -28,6 +29,10 @@ print("workgroups %d, tiles %d; per workgroup: mean %.1f  min %d  p10 %d  median
 dur = (t1 - t0) / 100.0
 print("lifetime per workgroup (us): mean %.0f  min %.0f  max %.0f; started after the first by at most %.1f us; kernel %.0f us" %
       (dur.mean(), dur.min(), dur.max(), (t0.max() - start) / 100.0, (t1.max() - start) / 100.0))
+if cyc is not None and (cyc[used] > 0).all():
+    ghz = cyc[used] / (dur * 1e-6) / 1e9        # shader cycles of a workgroup's whole life over its time on the 100 MHz clock
+    print("shader clock over the LAUNCH (every workgroup's cycles / its lifetime): mean %.3f GHz  min %.3f  max %.3f; cycles per tile: mean %.0f" %
+          (ghz.mean(), ghz.min(), ghz.max(), (cyc[used] / np.maximum(tiles, 1)).mean()))
 print("tiles of workgroups 0..7:", tiles[:8].tolist())
 idx = np.nonzero(used)[0]
 print("per XCD: " + "  ".join("%d: %.1f" % (x, tiles[xcc == x].mean()) for x in sorted(set(xcc.tolist()))))
