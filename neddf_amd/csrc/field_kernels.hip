@@ -457,7 +457,11 @@ __device__ __forceinline__ void rev_forward_epilogue(f32x16 (&acc)[MT][NT], type
     // is rounded to bf16 anyway): at that policy's speed the fp32 round trip (26 GB per launch) would be the kernel's bound
     if (!LAST) {
         if constexpr (KIND == 2) {
-            if constexpr (Ops::kStashF16) stash_store_f16<MT, NT>(acc, yp, wave, lane);
+            if constexpr (Ops::kStashF16) {
+#if !(NEDDF_PROBE_NOY & 1)
+                stash_store_f16<MT, NT>(acc, yp, wave, lane);
+#endif
+            }
             else if constexpr (Ops::kStash16) stash_store16<MT, NT>(acc, yp, wave, lane);
             else stash_store<MT, NT>(acc, yp, wave, lane);
         } else {
@@ -685,7 +689,7 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
             STAMP();                                // forward layer l: 3 + 4l product done
             lds_barrier();
             STAMP();                                //                  4 + 4l barrier passed
-            if (l + 1 < a.n_layers) rev_forward_epilogue_rt<false, MASKY, MT, NT, Ops>(acc, act, yp + (size_t)l * ROWS * WID, nullptr, a.activation, wave, lane);
+            if (l + 1 < a.n_layers) rev_forward_epilogue_rt<false, MASKY, MT, NT, Ops>(acc, act, yp + (size_t)((NEDDF_PROBE_NOY & 4) ? 0 : l) * ROWS * WID, nullptr, a.activation, wave, lane);
             else rev_forward_epilogue_rt<true, MASKY, MT, NT, Ops>(acc, act, nullptr, Ops::kTransposed ? vecs + a.n_layers * WID : a.w_ddf_out, a.activation, wave, lane);
             STAMP();                                //                  5 + 4l epilogue done
             lds_barrier();
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
             // y'_{l-1} of this lane's accumulator positions comes back M-tile by M-tile through two register sets, requested after the
             // product (requesting them before it -- 64 more live registers -- measured no faster: the CU's other waves cover the latency)
             f32x16 yb[2][NT];
-            const f32x4v *ysrc = (const f32x4v *)(yp + (size_t)(l - 1) * ROWS * WID) + (size_t)wave * (MT * NT * (Ops::kStash16 ? 2 : 4)) * 64 + lane;
+            const f32x4v *ysrc = (const f32x4v *)(yp + (size_t)((NEDDF_PROBE_NOY & 4) ? 0 : l - 1) * ROWS * WID) + (size_t)wave * (MT * NT * (Ops::kStash16 ? 2 : 4)) * 64 + lane;
             auto load_y = [&](f32x16 (&dst)[NT], int mt) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -829,7 +833,11 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
+#if NEDDF_PROBE_NOY & 2      // timing probes (results invalid): NEDDF_PROBE_NOY bit 0 = no y' stores, bit 1 = no y' loads, bit 2 = every layer's y' in ONE slot (L2-resident)
+                        for (int c = 0; c < 2; ++c) yraw[mt][t][c] = (u32x4){ 0x3c003c00u + (unsigned)lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u };
+#else
                         for (int c = 0; c < 2; ++c) yraw[mt][t][c] = ((const u32x4 *)ysrc)[((mt * NT + t) * 2 + c) * 64];
+#endif
                 lds_barrier();              // every wave finished reading g_l (the y' just requested stays in flight)
                 STAMP();                    //                +2 barrier passed
 #pragma unroll

@@ -381,6 +381,9 @@ __device__ __forceinline__ void acc_init_pre(f32x16 (&acc)[MT][NT], const LayerP
 #ifndef NEDDF_PROBE_NOB
 #define NEDDF_PROBE_NOB 0
 #endif
+#ifndef NEDDF_PROBE_NOY
+#define NEDDF_PROBE_NOY 0          // the reverse-mode kernel's y' round trip (field_kernels.hip: bit 0 stores, bit 1 loads, bit 2 one slot for all layers)
+#endif
 #ifndef NEDDF_PROBE_NOA
 #define NEDDF_PROBE_NOA 0
 #endif
