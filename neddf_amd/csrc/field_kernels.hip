@@ -41,6 +41,27 @@ __device__ __forceinline__ void encode_pos(typename Ops::act_t *act, int col0, c
                                            const float *var, int64_t p0, int64_t N, int P, int tid, bool use_var = true, int stride = 3)
 {
     const int K3 = 3 * enc.E, KH = enc.KH;
+    if (!ROWS4 && (P & 63) == 0 && THREADS % P == 0) {
+        // value-row tiles of 64 / 128 points: thread -> point p = tid mod P for ALL its items, item -> pair q = tid / P, + THREADS / P, ...
+        // A wave's 64 lanes are 64 consecutive points of ONE (frequency, axis) pair: q, e, d, 2^e and the low-pass factor are scalars,
+        // the two runtime divisions per item (by 3 E and by 3: half of the loop's instructions) are gone, and the point's six inputs
+        // are loaded once per tile instead of once per item.  The same pe_pair per (point, pair): bit-identical values.
+        const int p = tid % P;
+        const int64_t gp = p0 + p < N ? p0 + p : N - 1;
+        float x[3], v[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { x[d] = pos[gp * stride + d]; v[d] = use_var ? var[gp * stride + d] : 0.0f; }
+        typename Ops::act_t *row = act + p * Ops::kLd + col0;
+        for (int q = __builtin_amdgcn_readfirstlane(tid / P); q < K3; q += THREADS / P) {
+            const int e = q / 3, d = q - 3 * e;
+            const float xd = d == 0 ? x[0] : d == 1 ? x[1] : x[2], vd = d == 0 ? v[0] : d == 1 ? v[1] : v[2];
+            float vs, vc, js, jc;
+            pe_pair<GRADSCALE, Ops::kFast>(e, xd, vd, lp[e], vs, vc, js, jc);
+            Ops::put(row + q, vs);
+            Ops::put(row + q + KH, vc);
+        }
+        return;
+    }
     for (int item = tid; item < P * K3; item += THREADS) {
         int p = item / K3, q = item - p * K3;
         int e = q / 3, d = q - 3 * e;
@@ -68,6 +89,24 @@ __device__ __forceinline__ void encode_dir(typename Ops::act_t *act, int col0, c
                                            int64_t N, int P, int tid, int stride = 3)
 {
     const int K3 = 3 * enc.Ed, KD = enc.KD;
+    if (!ROWS4 && (P & 63) == 0 && THREADS % P == 0) {         // (as in encode_pos: one point per thread, one (frequency, axis) pair per wave and step)
+        const int p = tid % P;
+        const int64_t gp = p0 + p < N ? p0 + p : N - 1;
+        float x[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) x[d] = dir[gp * stride + d];
+        typename Ops::act_t *row = act + p * Ops::kLd + col0;
+        for (int q = __builtin_amdgcn_readfirstlane(tid / P); q < K3; q += THREADS / P) {
+            const int e = q / 3, d = q - 3 * e;
+            const float xd = d == 0 ? x[0] : d == 1 ? x[1] : x[2];
+            float sn, cs;
+            if (Ops::kFast) fast_sincos((float)(1 << e) * xd, sn, cs);
+            else sincos_cw((float)(1 << e) * xd, sn, cs);
+            Ops::put(row + q, sn);
+            Ops::put(row + q + KD, cs);
+        }
+        return;
+    }
     for (int item = tid; item < P * K3; item += THREADS) {
         int p = item / K3, q = item - p * K3;
         int e = q / 3, d = q - 3 * e;
@@ -1008,6 +1047,10 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
 #pragma unroll
         for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
     }
+    // the colour head's weights [WID][3], LDS-resident behind the small scratch (col_lds_bytes): as global loads they were twelve vector loads per
+    // sixteen features, requested and awaited inside the head's loop -- 9.5 % of the eight-wave bf16 tile (profiles/r06_stamp_col_bf16_before.txt)
+    float *wo = lp + 16;
+    for (int i = tid; i < WID * 3; i += THREADS) wo[i] = a.w_out[i];
     const int ka = Ops::kStep * a.ksteps_a;
     const int c_dir = 2 * a.enc.KH, c_n = c_dir + 2 * a.enc.KD;
     const int64_t ntiles = (a.n_points + P - 1) / P;
@@ -1059,6 +1102,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
         // (global -> VGPR) and land in LDS after the small-input dense; the other variants lack the registers
         constexpr int CE = 16 / sizeof(act_t), CPP = WID / CE, CPR = Ops::kPlanes * CPP;     // 16-byte chunks per feature row
         constexpr int NF = ROWS * CPR / THREADS;
+        static_assert(NF * THREADS == ROWS * CPR, "a tile's feature chunks divide evenly over the threads");
         auto lds_chunk = [&](int idx) {     // chunk idx of the tile -> its place in LDS (planes are kPlane elements apart)
             const int r = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
             return (f32x4v *)(act + r * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP));
@@ -1074,9 +1118,23 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
             int64_t src = ROWS4 ? grow : grow * a.feat_rows;      // value row of [n][feat_rows][256]
             return (const f32x4v *)((const act_t *)a.features + (size_t)src * (Ops::kPlanes * WID) + CE * c4);
         };
+        // A full tile's chunks are affine in the chunk index: chunk tid + i * THREADS is row r0 + i * RSTEP at the thread's own column, so one
+        // pointer per thread and a uniform stride replace a clamped 64-bit address per chunk (the general form stays for the launch's last tile).
+        constexpr bool AFF = THREADS % CPR == 0;        // a thread keeps its column over the tile's chunks (every shape but the 384-wide ones)
+        constexpr int RSTEP = AFF ? THREADS / CPR : 1;
+        const bool full_tile = AFF && (p0 + P) <= a.n_points;
+        const int fr0 = tid / CPR, fc4 = tid % CPR;
+        const char *fsrc = (const char *)a.features + ((size_t)(p0 * RPP + fr0) * (ROWS4 ? 1 : a.feat_rows) * (Ops::kPlanes * WID) + CE * fc4) * sizeof(act_t);
+        const size_t fstep = (size_t)RSTEP * (ROWS4 ? 1 : a.feat_rows) * (Ops::kPlanes * WID) * sizeof(act_t);
+        act_t *fdst = act + fr0 * LD + (fc4 / CPP) * Ops::kPlane + CE * (fc4 % CPP);
         if constexpr (FPRE) {
+            if (full_tile) {
 #pragma unroll
-            for (int i = 0; i < NF; ++i) fpre[i] = *feature_src(tid + i * THREADS);
+                for (int i = 0; i < NF; ++i) fpre[i] = *(const f32x4v *)(fsrc + i * fstep);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NF; ++i) fpre[i] = *feature_src(tid + i * THREADS);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         acc_init<MT, NT, ROWS4>(acc, a.layer[0].bias, wave, lane, Ops::kWScale);
@@ -1089,12 +1147,29 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
         if constexpr (FPRE) {
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
-                int idx = tid + i * THREADS;
-                *lds_chunk(idx) = fpre[i];
+                if constexpr (AFF) *(f32x4v *)(fdst + i * RSTEP * LD) = fpre[i];
+                else *lds_chunk(tid + i * THREADS) = fpre[i];
             }
         } else {
-            for (int idx = tid; idx < ROWS * CPR; idx += THREADS)
-                *lds_chunk(idx) = *feature_src(idx);
+            // in batches of four chunks per thread (as a rolled loop hipcc waits for every chunk before it requests the next: eight round trips
+            // in a row per tile of the eight-wave bf16 shape)
+            constexpr int FB = NF % 4 == 0 ? 4 : 1;
+#pragma unroll
+            for (int b = 0; b < NF; b += FB) {
+                f32x4v f[FB];
+                if (full_tile) {
+#pragma unroll
+                    for (int i = 0; i < FB; ++i) f[i] = *(const f32x4v *)(fsrc + (b + i) * fstep);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < FB; ++i) f[i] = *feature_src(tid + (b + i) * THREADS);
+                }
+#pragma unroll
+                for (int i = 0; i < FB; ++i) {
+                    if constexpr (AFF) *(f32x4v *)(fdst + (b + i) * RSTEP * LD) = f[i];
+                    else *lds_chunk(tid + (b + i) * THREADS) = f[i];
+                }
+            }
         }
         STAMP();                                    // 6: features in LDS
         __syncthreads();
@@ -1114,15 +1189,16 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
             STAMP();                                //          11 + 4l barrier passed
         }
         // layer_col_out 256 -> 3 (neddf.py:257), no output activation.  Every thread works: NPART = THREADS / ROWS threads share a
-        // row, each over WID / NPART consecutive features.  With 64-row tiles the part index is the wave index, so the weights are
+        // row, each over WID / NPART consecutive features.  With 64- and 128-row tiles a wave's lanes share the part index, so the weights are
         // wave-uniform (scalar loads, SGPR operands) instead of one vector load per multiply-add; the 128 idle threads and those
-        // loads made this head 2.8 % of the kernel (profiles/r03_col_ablation.txt)
+        // loads made this head 2.8 % of the kernel (profiles/r03_col_ablation.txt; the eight-wave bf16 shape still had them until
+        // round 6: 9.5 % of its tile)
         constexpr int NPART = THREADS / ROWS, KPART = WID / NPART;
         static_assert(NPART >= 1 && NPART * ROWS == THREADS && KPART % 4 == 0, "the colour head splits a row over THREADS / ROWS threads");
         {
-            const int part = ROWS == 64 ? __builtin_amdgcn_readfirstlane(wave) : tid / ROWS, row = tid - (tid / ROWS) * ROWS;
+            const int part = ROWS % 64 == 0 ? __builtin_amdgcn_readfirstlane(tid / ROWS) : tid / ROWS, row = tid - (tid / ROWS) * ROWS;
             const act_t *ar = act + row * LD + part * KPART;
-            const float *w = a.w_out + part * KPART * 3;
+            const float *w = wo + part * KPART * 3;
             float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll 4
             for (int k = 0; k < KPART / 4; ++k) {
@@ -1460,11 +1536,12 @@ static void launch_ddf_g(const DdfArgs &a, int grid, hipStream_t s)
 template <int MT, int WPS, int NW, class Ops>
 static void launch_col_g(const ColArgs &a, int grid, bool rows4, hipStream_t s)
 {
-    static bool once = (set_lds((const void *)col_trunk_kernel<false, MT, WPS, Ops, NW>, lds_bytes<Ops>(MT)),
-                        set_lds((const void *)col_trunk_kernel<true, MT, WPS, Ops, NW>, lds_bytes<Ops>(MT)), true);
+    const size_t lds = lds_bytes<Ops>(MT) + (size_t)Ops::kWid * 3 * sizeof(float);      // + the colour head's weights (col_trunk_kernel: wo)
+    static bool once = (set_lds((const void *)col_trunk_kernel<false, MT, WPS, Ops, NW>, lds),
+                        set_lds((const void *)col_trunk_kernel<true, MT, WPS, Ops, NW>, lds), true);
     (void)once;
-    if (rows4) hipLaunchKernelGGL((col_trunk_kernel<true, MT, WPS, Ops, NW>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a);
-    else hipLaunchKernelGGL((col_trunk_kernel<false, MT, WPS, Ops, NW>), dim3(grid), dim3(64 * NW), lds_bytes<Ops>(MT), s, a);
+    if (rows4) hipLaunchKernelGGL((col_trunk_kernel<true, MT, WPS, Ops, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
+    else hipLaunchKernelGGL((col_trunk_kernel<false, MT, WPS, Ops, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
 }
 
 // the three operand policies over one engine width; MT etc. follow geo() / geo_col() above

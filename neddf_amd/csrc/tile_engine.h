@@ -674,6 +674,19 @@ __device__ __forceinline__ void epilogue_rt(const f32x16 (&acc)[MT][NT], typenam
 template <class Ops = OpsF32, int THREADS = kThreads>
 __device__ __forceinline__ void zero_cols(typename Ops::act_t *act, int rows, int ncols, int tid)
 {
+    typedef typename Ops::act_t act_t;
+    constexpr int E = 16 / (int)sizeof(act_t);          // elements per 16-byte store
+    if (ncols % E == 0 && (Ops::kLd * (int)sizeof(act_t)) % 16 == 0 && (Ops::kPlane * (int)sizeof(act_t)) % 16 == 0) {
+        // every caller's ncols is a whole number of MFMA k-steps: 16 bytes per store instead of one element (and one runtime division
+        // per ELEMENT: 28 of each per thread of the eight-wave bf16 colour tile, 9.6 % of its span)
+        const int cpr = ncols / E;
+        for (int i = tid; i < rows * cpr; i += THREADS) {
+            const int r = i / cpr, c = i - r * cpr;
+#pragma unroll
+            for (int pl = 0; pl < Ops::kPlanes; ++pl) *(f32x4v *)(act + r * Ops::kLd + pl * Ops::kPlane + c * E) = (f32x4v){ 0.f, 0.f, 0.f, 0.f };
+        }
+        return;
+    }
     for (int i = tid; i < rows * ncols; i += THREADS) {
         int r = i / ncols, c = i - r * ncols;
         Ops::zero(act + r * Ops::kLd + c);
