@@ -325,10 +325,12 @@ __device__ __forceinline__ float exp_acc(float x)
 template <bool CONE>
 __device__ __forceinline__ void sample_moments(const float *d, int j, int S, float r2, float &t_mu, float &t_var, float &r_var)
 {
-    const float dn = d[j];
+    // (all three distances requested unconditionally: with the far edge as a branch around its own loads, the field kernels' per-tile staging was
+    // a chain of dependent memory round trips.  At the last sample d[S - 1] is d[j] and d[S - 2] is d[j - 1]: the same arithmetic, the same bits.)
+    const float dn = d[j], dnx = d[j + 1 < S ? j + 1 : j], dpv = d[j > 0 ? j - 1 : 0];
     t_mu = dn; t_var = 0.f; r_var = 0.f;
     if (CONE) {
-        float df = (j + 1 < S) ? d[j + 1] : (2 * d[S - 1] - d[S - 2]);
+        float df = (j + 1 < S) ? dnx : (2 * dn - dpv);
         float mu = 0.5f * (dn + df);
         float sg = 0.5f * (df - dn);
         float mu2 = mu * mu, s2 = sg * sg, s4 = s2 * s2;

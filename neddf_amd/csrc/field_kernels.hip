@@ -774,6 +774,24 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
         {
             constexpr int CE = 16 / sizeof(act_t), CPP = WID / CE, CPR = Ops::kPlanes * CPP;
             act_t *features = (act_t *)a.features;
+            constexpr bool AFF = Ops::kTransposed && THREADS % CPR == 0 && (P * CPR) % (4 * THREADS) == 0;      // (fp32: measured 0.6 % slower with it)
+            if (AFF && features && p0 + P <= a.n_points) {
+                // a full tile: the thread keeps its column, chunk i is row r0 + i * RSTEP.  Four chunks in four register sets per batch: written
+                // as one loop, every store waits for the previous one's acknowledgement before its data registers are loaded again
+                // (s_waitcnt vmcnt(0) per chunk: eight L2 round trips in a row in the bf16 tile, sixteen in the fp32 one)
+                constexpr int RSTEP = AFF ? THREADS / CPR : 1, NCH = P * CPR / THREADS;
+                const int r0 = tid / CPR, c4 = tid % CPR;
+                const act_t *src = act + r0 * LD + (c4 / CPP) * Ops::kPlane + CE * (c4 % CPP);
+                act_t *dst = features + (size_t)(p0 + r0) * (Ops::kPlanes * WID) + CE * c4;
+#pragma unroll
+                for (int b = 0; b < NCH; b += 4) {
+                    f32x4v v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = *(const f32x4v *)(src + (b + i) * RSTEP * LD);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *(f32x4v *)(dst + (size_t)(b + i) * RSTEP * (Ops::kPlanes * WID)) = v[i];
+                }
+            } else
             for (int idx = tid; features && idx < P * CPR; idx += THREADS) {
                 const int p = (unsigned)idx / CPR, c4 = (unsigned)idx % CPR;
                 if (p0 + p < a.n_points) {
