@@ -566,6 +566,10 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
     // ... and behind them the factors of the encoding's Jacobian [ROWS][kPjLd] (written by the encoding loop, read by the tail: they made
     // a round trip through the global scratch -- four scattered 4-byte stores per item and an exposed L2 round trip in the tail)
     float *pjl = vecs + (a.n_layers + 1) * WID;
+    // ... and last the tile's sample points as the rays gave them [9][ROWS] (direction, position, variance): computed once at the tile's start for
+    // the encoding, they are also what the tail writes into the colour kernel's per-point record -- recomputed there, they were a 64-bit division
+    // and three dependent memory round trips on one wave while the other three waited at the tile's last barrier
+    float *rsv = Ops::kTransposed ? pjl + ROWS * kPjLd : vecs;
     if constexpr (Ops::kTransposed) {
         for (int i = tid; i < (a.n_layers + 1) * WID; i += THREADS) {
             const int l = i / WID, c = i - l * WID;
@@ -631,7 +635,10 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
                 float ps[3], vr[3], dr[3];
                 ray_point(a.rays, a.rays.base + gp, ps, vr, dr);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { stg[tid * 3 + k] = ps[k]; stg[3 * ROWS + tid * 3 + k] = a.neus ? 0.0f : vr[k]; }
+                for (int k = 0; k < 3; ++k) {
+                    stg[tid * 3 + k] = ps[k]; stg[3 * ROWS + tid * 3 + k] = a.neus ? 0.0f : vr[k];
+                    rsv[k * ROWS + tid] = dr[k]; rsv[(3 + k) * ROWS + tid] = ps[k]; rsv[(6 + k) * ROWS + tid] = vr[k];
+                }
             }
         } else
         for (int idx = tid; idx < 6 * ROWS; idx += THREADS) {
@@ -1020,8 +1027,9 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
                 f32x4v v2 = { dg0, dg1, dg2, 0.f };
                 f32x4v v3 = { 0.f, 0.f, dgn, dDdt };
                 if (a.rays.rd) {    // the colour kernel's inputs ride in the slots it does not read in eval-minimal mode (PA_R_*)
-                    float ps[3], vr[3], dr[3];
-                    ray_point(a.rays, a.rays.base + gp, ps, vr, dr);
+                    float ps[3], vr[3], dr[3];        // (this thread's own values from the tile's start: rsv)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { dr[k] = rsv[k * ROWS + tid]; ps[k] = rsv[(3 + k) * ROWS + tid]; vr[k] = rsv[(6 + k) * ROWS + tid]; }
                     v0[0] = dr[0]; v0[1] = dr[1]; v0[2] = dr[2];
                     v2[0] = ps[0]; v2[1] = ps[1]; v2[2] = ps[2]; v2[3] = vr[0];
                     v3[0] = vr[1]; v3[1] = vr[2];
@@ -1586,7 +1594,8 @@ static size_t rev_lds_bytes(int mt, int n_layers)
 {
     return lds_bytes<Ops>(mt) + (Ops::kEncInLds ? (size_t)mt * 32 * kEncLd * sizeof(typename Ops::act_t) : 0) +
            // the LDS-resident bias / head vectors and the encoding's Jacobian factors (ddf_rev_kernel: vecs, pjl)
-           (Ops::kTransposed ? ((size_t)(n_layers + 1) * Ops::kWid + (size_t)mt * 32 * kPjLd) * sizeof(float) : 0);
+           (Ops::kTransposed ? ((size_t)(n_layers + 1) * Ops::kWid + (size_t)mt * 32 * kPjLd) * sizeof(float) : 0) +
+           (size_t)mt * 32 * 9 * sizeof(float);         // rsv: the tile's sample points
 }
 
 template <int MT, class Ops>
