@@ -665,11 +665,8 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
         int next_tile = 0;
         if (tid == 0) next_tile = sched_next(a.sched, a.sched_flags, tile);
         // scaled integrated encoding (neddf.py:193-204), value rows; the factors of its Jacobian go to the scratch (or stay in LDS)
-        for (int item = tid; item < P * K3; item += THREADS) {
-            // item / K3 for item < 4096, K3 <= 30: (item * magic) >> 20 is exact; q / 3 for q < 30: (q * 11) >> 5
-            const int p = (int)(((unsigned)item * k3magic) >> 20), q = item - p * K3;
-            const int e = (q * 11) >> 5, d = q - 3 * e;
-            const float px = stg[p * 3 + d], vx = stg[3 * ROWS + p * 3 + d];
+        // one (point, pair) item = the pair's sine / cosine value into the tile (and the encoding's own tile), its Jacobian factors into pjl / pj
+        auto encode_item = [&](int p, int q, int e, float px, float vx) {
             float vs, vc, js, jc;
             if (a.neus) pe_pair<false, Ops::kFast>(e, px, 0.0f, lp[e], vs, vc, js, jc);      // plain PE (neus.py:118)
             else pe_pair<true, Ops::kFast>(e, px, vx, lp[e], vs, vc, js, jc);
@@ -689,6 +686,26 @@ __global__ __launch_bounds__(kThreads, 2) void ddf_rev_kernel(const DdfArgs a)
                 pj[p * 64 + q] = js;
                 pj[p * 64 + 32 + q] = jc;
             }
+        };
+        if constexpr (P % 64 == 0 && THREADS % P == 0 && Ops::kTransposed && Ops::kEncInLds) {
+            // a thread keeps ITS point (p = tid mod P) and walks the pairs q = tid / P, + THREADS / P, ...: q, the frequency, the axis and the
+            // low-pass factor are wave-uniform scalars, the point's six inputs are read from the staging area once.  Only where every output of
+            // an item stays in LDS: with the Jacobian factors / the encoding in the global scratch (fp32, split fp16) consecutive lanes on
+            // consecutive POINTS make their stores uncoalesced (fp32 distance kernel +0.7 %)
+            const int p = tid % P;
+            float x3[3], v3[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { x3[d] = stg[p * 3 + d]; v3[d] = stg[3 * ROWS + p * 3 + d]; }
+            for (int q = __builtin_amdgcn_readfirstlane(tid / P); q < K3; q += THREADS / P) {
+                const int e = q / 3, d = q - 3 * e;
+                encode_item(p, q, e, d == 0 ? x3[0] : d == 1 ? x3[1] : x3[2], d == 0 ? v3[0] : d == 1 ? v3[1] : v3[2]);
+            }
+        } else
+        for (int item = tid; item < P * K3; item += THREADS) {
+            // item / K3 for item < 4096, K3 <= 30: (item * magic) >> 20 is exact; q / 3 for q < 30: (q * 11) >> 5
+            const int p = (int)(((unsigned)item * k3magic) >> 20), q = item - p * K3;
+            const int e = (q * 11) >> 5, d = q - 3 * e;
+            encode_item(p, q, e, stg[p * 3 + d], stg[3 * ROWS + p * 3 + d]);
         }
         STAMP();                                    // 1: encoding done
         __syncthreads();
