@@ -74,7 +74,8 @@ end = torch.rand(4)                                # generator position after th
 np.savez(out_path + ".%d.npz" % rank, end=end.numpy(), rccl=np.int32(rccl), **{k: v.cpu().numpy() for k, v in img.items()})
 dist.barrier()
 dist.destroy_process_group()
-print("rank", rank, "ok", "rccl" if rccl else "gloo-shared-gpu")
+print("rank", rank, "ok", "rccl" if rccl else "gloo-shared-gpu", flush=True)
+os._exit(0)         # (as in tests/test_host.py: nothing is left to check, and a finished worker must not die in a backend thread's teardown)
 '''
 
 
