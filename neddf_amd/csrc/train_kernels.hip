@@ -368,11 +368,25 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
     const int c4n = a.kload0 >> 2, kpack0 = Ops::kStep * a.ksteps0;
     auto frags = [&](const float *wp, int ksteps) { return (const frag *)wp + (size_t)wave * NT * ksteps * 64 + lane; };
     auto stage = [&](const float *X, int ld, int c4cols, int kpack, int64_t r0) {       // X[r0 .. r0+64, 0:4*c4cols) -> LDS, zero padded to kpack
-        for (int idx = tid; idx < ROWS * c4cols; idx += kThreads) {
-            const int r = idx / c4cols, c = idx - r * c4cols;
-            f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-            if (r0 + r < a.R) v = *(const f32x4v *)(X + (r0 + r) * ld + 4 * c);
-            Ops::put4(act + r * LD + 4 * c, v);
+        // four chunks per thread and batch, requested together (row clamped, zero selected afterwards): as one load per iteration hipcc waits for
+        // every chunk before it requests the next -- a tile started with up to sixteen memory round trips in a row
+        const int total = ROWS * c4cols;
+        for (int base = 0; base < total; base += 4 * kThreads) {
+            f32x4v v[4];
+            int rr[4], cc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = base + tid + i * kThreads, ok = idx < total ? idx : total - 1;
+                rr[i] = ok / c4cols; cc[i] = ok - rr[i] * c4cols;
+                const int64_t row = r0 + rr[i] < a.R ? r0 + rr[i] : a.R - 1;
+                v[i] = *(const f32x4v *)(X + row * ld + 4 * cc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (base + tid + i * kThreads >= total) continue;
+                if (r0 + rr[i] >= a.R) v[i] = (f32x4v){ 0.f, 0.f, 0.f, 0.f };
+                Ops::put4(act + rr[i] * LD + 4 * cc[i], v[i]);
+            }
         }
         const int w = kpack - 4 * c4cols;
         for (int i = tid; i < ROWS * w; i += kThreads) {
@@ -381,12 +395,25 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward_kernel(const MlpForwa
         }
     };
     auto stage_pm = [&](const float *X, int64_t r0) {        // the tile's rows of a point-major [R, W] matrix -> the row-major LDS tile
-        for (int idx = tid; idx < (ROWS / 4) * W; idx += kThreads) {
-            const int p = idx / W, c = idx - p * W;
-            f32x4v v = { 0.f, 0.f, 0.f, 0.f };
-            if (r0 + 4 * p < a.R) v = *(const f32x4v *)(X + ((r0 >> 2) + p) * (4 * W) + 4 * c);
+        constexpr int NV = (ROWS / 4) * W / kThreads;         // chunks per thread (W = 256: 16, one point per chunk)
+        static_assert(NV % 4 == 0 && (ROWS / 4) * W == NV * kThreads, "point-major staging in batches of four chunks");
+        const int64_t last = (a.R >> 2) - 1;                  // R is a multiple of 4 (a point's rows are all inside or all outside)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Ops::put(act + (4 * p + q) * LD + c, v[q]);
+        for (int b = 0; b < NV; b += 4) {                     // (batches of four, as in stage)
+            f32x4v v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + (b + i) * kThreads, p = idx / W, c = idx - p * W;
+                const int64_t pt = (r0 >> 2) + p;
+                v[i] = *(const f32x4v *)(X + (pt < last ? pt : last) * (4 * W) + 4 * c);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + (b + i) * kThreads, p = idx / W, c = idx - p * W;
+                if (r0 + 4 * p >= a.R) v[i] = (f32x4v){ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Ops::put(act + (4 * p + q) * LD + c, v[i][q]);
+            }
         }
     };
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
