@@ -1386,7 +1386,9 @@ size_t field_lds_bytes(int mt) { return lds_bytes<OpsF32>(mt); }
 //     fp32        (2, 2, 4): 64-row tiles, two workgroups per CU (one workgroup's VALU epilogue beside the other's MFMA stream:
 //                 134 TF against 118 TF for one 128-row workgroup per CU, 124 / 119 TF for 32-row tiles at three / four)
 //     bf16        (4, 2, 4): 128-row tiles (half the LDS bytes of fp32): each fetched weight fragment feeds four M-tiles;
-//                 its colour trunk (4, 2, 8): the value-row-only epilogue is light enough for eight waves to pay
+//                 its colour trunk (2, 3, 4): 64-row tiles, THREE workgroups per CU (43 KB of LDS and 168 registers each).  Rounds 4-5 ran it
+//                 on (4, 2, 8); once round 6 had taken the waits out of the phases around the layers, three independent four-wave
+//                 workgroups beat two eight-wave ones in lockstep: 55.2 -> 50.4 ms per C2 step ((4, 2, 4): 52.5; (2, 2, 4): 56.6)
 //     split fp16  (2, 2, 4): two fp16 planes = the LDS bytes of fp32, same shape as fp32
 //   reverse-mode distance kernel: 64-point tiles, four waves, two workgroups per CU under every policy (ddf_rev_kernel)
 // Engine widths other than 256 (hidden width padded to 128 / 384 / 512; the reference's constructors take any width,
@@ -1398,7 +1400,7 @@ struct Geo {
 };
 static Geo geo_w(int width) { return width == 128 ? Geo{ 2, 2, 4 } : Geo{ 1, 2, 4 }; }
 static Geo geo(int operands, int width) { return width != 256 ? geo_w(width) : (operands == 1 ? Geo{ 4, 2, 4 } : Geo{ 2, 2, 4 }); }
-static Geo geo_col(int operands, int width) { return width != 256 ? geo_w(width) : (operands == 1 ? Geo{ 4, 2, 8 } : Geo{ 2, 2, 4 }); }
+static Geo geo_col(int operands, int width) { return width != 256 ? geo_w(width) : (operands == 1 ? Geo{ 2, 3, 4 } : Geo{ 2, 2, 4 }); }
 static Geo geo_nerf(int width) { return width == 256 ? Geo{ 2, 2, 4 } : geo_w(width); }
 int field_wgs_per_cu(int operands, int width) { return geo(operands, width).wps; }
 int col_wgs_per_cu(int operands, int width) { return geo_col(operands, width).wps; }
@@ -1496,7 +1498,7 @@ static void launch_col_w(const ColArgs &a, int grid, bool rows4, hipStream_t s)
     constexpr int MT = WID <= 256 ? 2 : 1;
     if (a.operands == 2) launch_col_g<MT, 2, 4, OpsF16SplitT<WID>>(a, grid, rows4, s);
     else if (a.operands == 1) {
-        if constexpr (WID == 256) launch_col_g<4, 2, 8, OpsBF16>(a, grid, rows4, s);
+        if constexpr (WID == 256) launch_col_g<2, 3, 4, OpsBF16>(a, grid, rows4, s);
         else launch_col_g<MT, 2, 4, OpsBF16T<WID>>(a, grid, rows4, s);
     } else launch_col_g<MT, 2, 4, OpsF32T<WID>>(a, grid, rows4, s);
 }
