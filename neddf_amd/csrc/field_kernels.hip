@@ -35,10 +35,9 @@ namespace neddf {
 // ----------------------------------------------------------------------------
 // NeDDF distance trunk
 // Geometry (MT, WPS, NW): MT*32 rows per tile, WPS workgroups per CU, NW waves per workgroup.  NW = 4: one wave per SIMD,
-// each owning 64 output columns (NT = 2 column tiles).  NW = 8 (16-bit operand policies): two waves per SIMD, each owning 32
-// columns (NT = 1) for ALL rows of a 128-row tile -- every weight fragment a wave fetches feeds four M-tiles, which halves the
-// L2 -> VGPR weight stream per row again; that stream through the per-CU vector cache (64 B/clk) is what paces the 16-bit
-// dense phase (42 B/clk/CU at 64-row tiles).  The packed weights are tile-major (tile = wave * NT + t), so both shapes read
+// each owning 64 output columns (NT = 2 column tiles) -- every shipped shape.  The kernels also compile with NW = 8 (two waves per
+// SIMD, each owning 32 columns for ALL rows of a 128-row tile: the bf16 colour trunk ran on it in rounds 4-5, until round 6 made
+// three four-wave workgroups per CU the faster shape); the packed weights are tile-major (tile = wave * NT + t), so either reads
 // the same blob.
 template <int MT, int WPS, class Ops, int NW = kWaves>
 __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void ddf_trunk_kernel(const DdfArgs a)
@@ -937,7 +936,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
         for (int e = 0; e < 10; ++e) lp[e] = a.enc.lowpass[e];
     }
     // the colour head's weights [WID][3], LDS-resident behind the small scratch (col_lds_bytes): as global loads they were twelve vector loads per
-    // sixteen features, requested and awaited inside the head's loop -- 9.5 % of the eight-wave bf16 tile (profiles/r06_stamp_col_bf16_before.txt)
+    // sixteen features, requested and awaited inside the head's loop -- 9.5 % of the bf16 tile of rounds 4-5 (eight waves, 128 points; profiles/r06_stamp_col_bf16_before.txt)
     float *wo = lp + 16;
     for (int i = tid; i < WID * 3; i += THREADS) wo[i] = a.w_out[i];
     const int ka = Ops::kStep * a.ksteps_a;
@@ -1041,7 +1040,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
             }
         } else {
             // in batches of four chunks per thread (as a rolled loop hipcc waits for every chunk before it requests the next: eight round trips
-            // in a row per tile of the eight-wave bf16 shape)
+            // in a row per tile of the shapes without FPRE)
             constexpr int FB = NF % 4 == 0 ? 4 : 1;
 #pragma unroll
             for (int b = 0; b < NF; b += FB) {
@@ -1080,7 +1079,7 @@ __global__ __launch_bounds__(64 * NW, WPS * NW / 4) void col_trunk_kernel(const 
         // layer_col_out 256 -> 3 (neddf.py:257), no output activation.  Every thread works: NPART = THREADS / ROWS threads share a
         // row, each over WID / NPART consecutive features.  With 64- and 128-row tiles a wave's lanes share the part index, so the weights are
         // wave-uniform (scalar loads, SGPR operands) instead of one vector load per multiply-add; the 128 idle threads and those
-        // loads made this head 2.8 % of the kernel (profiles/r03_col_ablation.txt; the eight-wave bf16 shape still had them until
+        // loads made this head 2.8 % of the kernel (profiles/r03_col_ablation.txt; the bf16 shape of rounds 4-5 (eight waves) still had them until
         // round 6: 9.5 % of its tile)
         constexpr int NPART = THREADS / ROWS, KPART = WID / NPART;
         static_assert(NPART >= 1 && NPART * ROWS == THREADS && KPART % 4 == 0, "the colour head splits a row over THREADS / ROWS threads");

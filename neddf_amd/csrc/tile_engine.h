@@ -678,7 +678,7 @@ __device__ __forceinline__ void zero_cols(typename Ops::act_t *act, int rows, in
     constexpr int E = 16 / (int)sizeof(act_t);          // elements per 16-byte store
     if (ncols % E == 0 && (Ops::kLd * (int)sizeof(act_t)) % 16 == 0 && (Ops::kPlane * (int)sizeof(act_t)) % 16 == 0) {
         // every caller's ncols is a whole number of MFMA k-steps: 16 bytes per store instead of one element (and one runtime division
-        // per ELEMENT: 28 of each per thread of the eight-wave bf16 colour tile, 9.6 % of its span)
+        // per ELEMENT: 28 of each per thread of the bf16 colour tile of rounds 4-5, 9.6 % of its span)
         const int cpr = ncols / E;
         for (int i = tid; i < rows * cpr; i += THREADS) {
             const int r = i / cpr, c = i - r * cpr;
