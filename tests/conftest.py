@@ -21,7 +21,7 @@ def pytest_configure(config):
 # runs, launchers -- so that a harness problem in a workflow test can never hide a kernel's parity result from the record.
 _HEAD = [
     "test_raygen", "test_sample_coarse_bitexact", "test_sampling_bitexact_vs_oracle", "test_composite", "test_composite_edges",
-    "test_resample_bitexact", "test_resample_edges", "test_layer_ops", "test_neddf_bunny_field", "test_render_rays_end_to_end",
+    "test_resample_bitexact", "test_resample_edges", "test_resample_sort_sizes", "test_layer_ops", "test_neddf_bunny_field", "test_render_rays_end_to_end",
     "test_render_image_small", "test_c1_bunny_400x400_vs_oracle", "test_c2_single_pass_vs_oracle", "test_full_size_properties",
     "test_c3_full_frame_hierarchical_properties", "test_rays_on_random_cameras", "test_stages_on_random_inputs_vs_the_reference",
     "test_neddf_synth", "test_nerf_synth", "test_neddf_negative_bias_regime", "test_neddf_negative_bias_render_rays",

@@ -194,6 +194,32 @@ def test_resample_edges(ctx, dev, orc):
     assert np.array_equal(N(ids), oi) and np.array_equal(N(out), oo)
 
 
+def test_resample_sort_sizes(ctx, dev, orc):
+    """The merged samples are sorted in registers, 1 / 2 / 4 / 8 values per lane (64 ... 512 padded values), in LDS above that: every
+    width, full and ragged, with ties (repeated uniforms, zero weights => repeated samples, repeated knots) -- bit-identical samples
+    and searchsorted indices against the oracle (base_neural_render.py:70-100)."""
+    rng = np.random.default_rng(77)
+    for n, nf, cat in ((5, 7, True), (9, 64, False), (2, 62, True), (33, 60, True), (64, 64, True), (65, 129, True), (65, 129, False),
+                       (100, 156, True), (129, 257, True), (256, 256, True), (129, 513, False), (300, 400, True)):
+        B = 37
+        d = np.sort(rng.uniform(0.5, 6, (B, n)).astype(np.float32), axis=1)
+        d[3, n // 2:] = d[3, n // 2]                                  # repeated knots
+        w = (rng.uniform(0, 1, (B, n - 1)) ** 8).astype(np.float32)
+        w[5] = 0.0                                                     # uniform pdf after the + 1e-2
+        w[7, : (n - 1) // 2] = 0.0
+        u = rng.uniform(0, 1, (B, nf)).astype(np.float32)
+        u[9] = u[9, 0]                                                 # one uniform for the whole ray: nf equal samples
+        u[11, ::2] = u[11, 0]
+        u[13] = np.sort(u[13])[::-1]                                   # descending: the worst case of the network's first stages
+        wt = T(w.copy(), dev)
+        out, ids = ctx.importance_resample(T(d, dev), wt, T(u, dev), cat, want_ids=True)
+        oo, oi, fb = orc.sample_pdf(d, w.copy(), u, cat)
+        assert not fb
+        assert np.array_equal(N(ids), oi), (n, nf, cat)
+        assert np.array_equal(N(out), oo), (n, nf, cat)
+        assert np.all(np.diff(N(out), axis=1) >= 0), (n, nf, cat)
+
+
 def test_rays_on_random_cameras(ctx, dev, orc):
     """Round 4: ray generation and cone / point sampling for twelve random pinhole cameras, poses, pixel dtypes and distance sets with
     random cone radii: bit-identical to the oracle, and within the fixed-shape tests' gates of the REFERENCE's `create_rays` /
