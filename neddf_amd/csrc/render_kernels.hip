@@ -327,7 +327,28 @@ __global__ __launch_bounds__(64) void resample_kernel(const float *dists, float 
     // in sample_coarse)
     for (int j = lane; j < nw; j += 64) srt[j] = w[j] / l1;
     __syncthreads();
-    if (lane == 0) {
+    // ... unless the order cannot matter: with at most 64 quotients whose exponents lie within 10 of the first one's, every partial sum is
+    // a multiple of 2^(emin - 23) below 2^(emax + 7) -- at most 51 bits -- so every double addition is EXACT in any order, and a wave-level
+    // prefix sum (six steps) gives the bits of the sequential chain (64 x five dependent instructions on one lane: a fifth of the kernel's
+    // instructions).  The sample weights of a render (w + 1e-2 with w in [0, 1]) always qualify; anything else takes the chain.
+    bool exact_scan = false;
+    if (nw <= 64) {
+        const float q = lane < nw ? srt[lane] : 0.0f;
+        const int e = (int)((__float_as_uint(q) >> 23) & 0xffu), e0 = __builtin_amdgcn_readfirstlane(e);
+        const bool ok = lane >= nw || q == 0.0f || (e != 255 && e - e0 <= 10 && e0 - e <= 10);
+        exact_scan = __all(ok);
+        if (exact_scan) {
+            double acc = (double)q;
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const double t = __shfl_up(acc, dlt, 64);
+                if (lane >= dlt) acc += t;
+            }
+            if (lane < nw) cdf[lane + 1] = (float)acc;
+            if (lane == 0) cdf[0] = 0.0f;
+        }
+    }
+    if (!exact_scan && lane == 0) {
         double acc = 0.0;
         cdf[0] = 0.0f;
         for (int k = 0; k < nw; ++k) {
@@ -337,12 +358,18 @@ __global__ __launch_bounds__(64) void resample_kernel(const float *dists, float 
     }
     __syncthreads();
     bool bad = false;
+    int nsteps = 0;
+    while ((1 << nsteps) < n + 1) ++nsteps;
     for (int s = lane; s < nf; s += 64) {
         float u = U[b * nf + s];
         int lo = 0, hi = n;                 // searchsorted(right=True): first index with cdf > u
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (cdf[mid] > u) hi = mid; else lo = mid + 1;
+        // the probes of `while (lo < hi)`, as a loop of the wave-uniform depth ceil(log2(n + 1)) without a divergent exit: a lane that
+        // is done keeps lo == hi (its read of cdf[lo], at most one past the end and inside this workgroup's LDS, is not used)
+        for (int it = 0; it < nsteps; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const bool go = lo < hi, right = cdf[mid] > u;
+            hi = go && right ? mid : hi;
+            lo = go && !right ? mid + 1 : lo;
         }
         int id = lo;
         int below = id - 1 > 0 ? id - 1 : 0;
@@ -385,17 +412,20 @@ __global__ __launch_bounds__(64) void resample_kernel(const float *dists, float 
 }
 
 // NaN fallback (:105-114): linspace(dists[0,0], dists[0,-1], no) for every ray of a group (= of a sample_pdf call of the
-// reference) in which any sample came out NaN; row 0 is the group's first ray
-__global__ void resample_fallback_kernel(const float *dists, int n, int64_t total, int no, float *out, const int *flag, int64_t group,
-                                         int64_t offset)
+// reference) in which any sample came out NaN; row 0 is the group's first ray.  One wavefront per ray: it reads its group's flag and
+// leaves (the regular case: one load per ray -- one thread per OUTPUT with a 64-bit division in front of the flag took 0.15 ms per
+// 640 k rays, a ninth of the resampling); a flagged ray's lanes write its row.
+__global__ __launch_bounds__(256) void resample_fallback_kernel(const float *dists, int n, int64_t n_rays, int no, float *out, const int *flag,
+                                                                int64_t group, int64_t offset)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int64_t g = (i / no + offset) / group;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_rays) return;
+    const int64_t g = (b + offset) / group;
     if (!flag[g]) return;
     const int64_t r0 = g * group - offset;          // a leading partial group (offset > 0) starts before this batch
     const float *first = dists + (r0 > 0 ? r0 : 0) * n;
-    out[i] = linspace_at(first[0], first[n - 1], no, (int)(i % no));
+    const float lo = first[0], hi = first[n - 1];
+    for (int j = threadIdx.x & 63; j < no; j += 64) out[b * no + j] = linspace_at(lo, hi, no, j);
 }
 
 void launch_resample(const float *dists, float *weights, const float *U, int64_t n_rays, int n, int nf, int cat,
@@ -412,8 +442,7 @@ void launch_resample(const float *dists, float *weights, const float *U, int64_t
     auto kernel = npow2 == 64 ? resample_kernel<1> : npow2 == 128 ? resample_kernel<2> : npow2 == 256 ? resample_kernel<4> :
                   npow2 == 512 ? resample_kernel<8> : resample_kernel<0>;
     hipLaunchKernelGGL(kernel, dim3((unsigned)n_rays), dim3(64), lds, s, dists, weights, U, n, nf, cat, npow2, out, ids, flag, group, offset);
-    int64_t total = n_rays * no;
-    hipLaunchKernelGGL(resample_fallback_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dists, n, total, no, out, flag, group, offset);
+    hipLaunchKernelGGL(resample_fallback_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, s, dists, n, n_rays, no, out, flag, group, offset);
 }
 
 }  // namespace neddf

@@ -207,6 +207,10 @@ def test_resample_sort_sizes(ctx, dev, orc):
         w = (rng.uniform(0, 1, (B, n - 1)) ** 8).astype(np.float32)
         w[5] = 0.0                                                     # uniform pdf after the + 1e-2
         w[7, : (n - 1) // 2] = 0.0
+        w[15] = (10.0 ** rng.uniform(-30, 30, n - 1)).astype(np.float32)     # sixty decades: the cdf's additions round, their order is the result
+        w[17] = (2.0 ** rng.uniform(-12, 12, n - 1)).astype(np.float32)      # around the limit of the order-free (exact) prefix sum
+        if cat:                                                               # (smoothed -- not merged -- this row is inf / inf: the NaN fallback)
+            w[19, 0] = 3e38; w[19, 1:] = 1e38                                 # the L1 norm overflows: quotients 0
         u = rng.uniform(0, 1, (B, nf)).astype(np.float32)
         u[9] = u[9, 0]                                                 # one uniform for the whole ray: nf equal samples
         u[11, ::2] = u[11, 0]
